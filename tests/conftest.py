@@ -1,0 +1,73 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_scenarios(name):
+    """tests/golden/<name>.npz -> {scenario: {field: array}} (schema: tests/golden/make_golden.py)."""
+    z = np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+    out = {}
+    for key in z.files:
+        s, f = key.split("/", 1)
+        out.setdefault(s, {})[f] = z[key]
+    for sc in out.values():
+        sc["params"] = json.loads(str(sc["params"]))
+    return out
+
+
+ALL_SCENARIO_FILES = ["g1_plumbing.npz", "g2_near_exact.npz", "g3_multi_person.npz", "g4_edge_cases.npz"]
+
+
+def all_scenarios():
+    items = []
+    for fn in ALL_SCENARIO_FILES:
+        for s, sc in load_scenarios(fn).items():
+            items.append(pytest.param(sc, id=f"{fn[:2]}-{s}"))
+    return items
+
+
+def assert_scores_close(got, want, rtol=1e-9, what="score", dist_err=5e-14, nterms=1):
+    """Scores are ~1/dist: compare relatively; inf/NaN patterns must match; scores above 1e11
+    (dist < ~1e-13 m, pure rounding noise in the reference itself) only need to be huge or inf."""
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    noise = np.abs(want) > 1e11
+    assert np.all((np.abs(got[noise]) > 1e10) | np.isnan(got[noise])), what
+    g, w = got[~noise], want[~noise]
+    assert np.array_equal(np.isnan(g), np.isnan(w)), what + ": NaN pattern"
+    fin = ~np.isnan(w)
+    g, w = g[fin], w[fin]
+    # score = c / (1000 * dist) with c ~ O(1..10): a rounding-level error of ddist (metres, on ~5 m
+    # operands) moves the score by 1000 * s^2 * ddist / c.  Budget ddist = 5e-14 m, c >= 1.
+    # A mean over J such scores is bounded through mean(s^2) <= J * mean(s)^2: pass nterms=J.
+    tol = rtol * np.abs(w) + dist_err * 1000.0 * nterms * w * w
+    bad = ~(np.abs(g - w) <= tol)
+    assert not bad.any(), f"{what}: {bad.sum()} mismatches, worst |d|/tol = {np.max(np.abs(g - w)[bad] / tol[bad]):.3g}"
+
+
+def assert_xyz_close(got, want, atol, score_ref=None, what="xyz"):
+    """3D joints in metres.  Where the reference itself is NaN (inf/inf in the fusion) ours must be
+    NaN or come from a rounding-noise score (see assert_scores_close)."""
+    got = np.asarray(got, dtype=np.float64)
+    want = np.asarray(want, dtype=np.float64)
+    assert got.shape == want.shape, (what, got.shape, want.shape)
+    fin = np.isfinite(want)
+    if score_ref is not None:
+        fin &= (np.abs(np.asarray(score_ref)) < 1e11)[..., None] & np.isfinite(np.asarray(score_ref))[..., None]
+    assert np.all(np.isfinite(got[fin])), what + ": non-finite where the reference is finite"
+    err = np.max(np.abs(got[fin] - want[fin])) if fin.any() else 0.0
+    assert err <= atol, f"{what}: max |err| = {err:.3e} m > {atol:.1e}"
+    return err
