@@ -1,0 +1,153 @@
+/*
+ * snowtri.h -- C ABI of the MI355X-native multi-view triangulation core (libsnowtri.so).
+ *
+ * Drop-in boundary for ONE path of liaochikon/SnowMocap: 2D keypoints from C calibrated cameras
+ * -> pairwise two-ray triangulation + scoring -> cross-view association / fusion ("condense").
+ * The reference has no FFI of its own (it is pure Python); each entry point below names the
+ * reference interface it replaces (file:line relative to the reference tree).  A maintainer binds
+ * them with ctypes -- see INTEGRATION.md; snowmocap_amd/_lib.py is that binding.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; caller allocates every input and output buffer;
+ *   - the library owns only the opaque context (rig constants + device scratch);
+ *   - every function returns a snowtri_status; nothing throws across the ABI;
+ *   - `memspace` says whether the data pointers are host (SNOWTRI_HOST: staged through the
+ *     context's device scratch, synchronous) or device (SNOWTRI_DEVICE: used in place,
+ *     asynchronous on `stream`, a hipStream_t passed as void*; NULL = the null stream);
+ *   - all arithmetic is IEEE fp64 on the GPU (the reference is NumPy float64); only the I/O
+ *     element type is selectable (snowtri_dtype);
+ *   - a context is not thread-safe; distinct contexts may be used concurrently.
+ *
+ * Layouts (row-major, innermost last)
+ *   kpts       [F][C][Pmax][J][3]   (u, v, score) per detected keypoint; persons p >= n_persons[f][c] ignored
+ *   n_persons  [F][C] int32         detections per camera in add_human_2D_points call order; NULL = Pmax everywhere
+ *   candidates slot k = pair(mc<sc) * Pmax*Pmax + pm * Pmax + ps, pairs in the reference's loop order
+ *              (triangulation.py:56-65), so increasing k over valid slots IS the reference's list order
+ *   out_xyzs   [F][Pout_max][keypoint_num][4]  (x, y, z, keypoint score)
+ */
+#ifndef SNOWTRI_H
+#define SNOWTRI_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SNOWTRI_VERSION 100 /* 0.1.0 */
+
+typedef struct snowtri_ctx snowtri_ctx;
+
+/* Thresholds of Human_Triangulation (triangulation.py:50) and Human_Triangulation_Condense
+ * (triangulation.py:95-100); JSON keys of configs/snowmocap_default_config.json:10-17. */
+typedef struct snowtri_params {
+    double keypoint_score_threshold;
+    double average_score_threshold;
+    double distance_threshold;
+    double condense_distance_tol;
+    double condense_person_num_tol;
+    double condense_score_tol;
+    int32_t center_point_index;
+    int32_t keypoint_num;
+} snowtri_params;
+
+typedef enum snowtri_status {
+    SNOWTRI_OK = 0,
+    SNOWTRI_ERR_BAD_ARG = 1,    /* null pointer, non-positive size, unsupported dtype/method        */
+    SNOWTRI_ERR_BAD_INDEX = 2,  /* center_point_index / keypoint_num outside [0, J]  (IndexError)   */
+    SNOWTRI_ERR_HIP = 3,        /* a HIP call failed: see snowtri_last_error()                      */
+    SNOWTRI_ERR_SINGULAR = 4,   /* an exactly singular ray pair was met (np.linalg.LinAlgError)     */
+    SNOWTRI_ERR_OVERFLOW = 5,   /* more output persons than Pout_max in some frame (count is true)  */
+    SNOWTRI_ERR_NO_DEVICE = 6   /* no HIP device visible                                            */
+} snowtri_status;
+
+typedef enum snowtri_dtype { SNOWTRI_F32 = 0, SNOWTRI_F64 = 1 } snowtri_dtype;
+typedef enum snowtri_memspace { SNOWTRI_HOST = 0, SNOWTRI_DEVICE = 1 } snowtri_memspace;
+typedef enum snowtri_method {
+    SNOWTRI_PAIRWISE = 0, /* the reference's algorithm: pairwise skew-ray midpoints, score-weighted */
+    SNOWTRI_DLT = 1       /* N-view DLT (A^T A smallest eigenvector), association still pairwise     */
+} snowtri_method;
+
+/* per-frame flag bits written to out_flags */
+#define SNOWTRI_FLAG_SINGULAR 1u /* exactly singular pair in this frame                  */
+#define SNOWTRI_FLAG_OVERFLOW 2u /* more than Pout_max persons; extra persons not written */
+#define SNOWTRI_FLAG_FASTPATH 4u /* frame was resolved by the single-cluster fast path    */
+
+int snowtri_version(void);
+const char *snowtri_status_string(int status);
+/* Message of the last failing HIP call on this thread ("" if none). */
+const char *snowtri_last_error(void);
+/* Number of visible HIP devices (0 on a CPU-only box; never fails). */
+int snowtri_device_count(void);
+
+/* Rig constants.  Replaces Camera.__init__/CameraGroup.__init__ state used by the path
+ * (camera.py:17-44,142-157): K[C][9], R[C][9] (camera->world), t[C][3] (camera centre), fp64.
+ * C == 0 gives a scratch-only context (enough for snowtri_condense / snowtri_skew_ray_batch). */
+int snowtri_ctx_create(int32_t C, const double *K, const double *R, const double *t, int device,
+                       snowtri_ctx **out);
+int snowtri_ctx_destroy(snowtri_ctx *ctx);
+int snowtri_ctx_num_cameras(const snowtri_ctx *ctx);
+/* Host copy of the per-camera ray matrices M_c = R_c * inv(K_c), [C][9] fp64. */
+int snowtri_ctx_ray_matrices(const snowtri_ctx *ctx, double *M_out);
+/* Block until everything queued by this context has finished. */
+int snowtri_ctx_synchronize(snowtri_ctx *ctx);
+
+/* A1  CameraGroup.add_human_2D_points (camera.py:234-253): uv[n][2] pixels of camera `cam`
+ * -> rays[n][3] = R . inv(K) . [u, v, 1] (un-normalised, world frame).  Host pointers, fp64. */
+int snowtri_rays_from_pixels(snowtri_ctx *ctx, int32_t cam, int64_t n, const double *uv, double *rays);
+
+/* A2  Skew_Ray_Solver (triangulation.py:24-31), batched: hm, hs, tm, ts [n][3] -> dist[n], W[n][3].
+ * Host pointers, fp64.  *n_singular (optional) counts exactly singular pairs (reference raises). */
+int snowtri_skew_ray_batch(snowtri_ctx *ctx, int64_t n, const double *hm, const double *hs,
+                           const double *tm, const double *ts, double *dist, double *W,
+                           int64_t *n_singular);
+
+/* A1+A3  Human_Triangulation (triangulation.py:50-93), candidates materialised.
+ * Outputs are indexed by candidate SLOT (see Layouts), fp64:
+ *   cand_xyz[F][Kc][J][3], cand_kscore[F][Kc][J], cand_pscore[F][Kc] (np.mean of kscore),
+ *   cand_keep[F][Kc] uint8 = slot is a real pair AND NOT (pscore < average_score_threshold).
+ * Kc = snowtri_num_candidate_slots(C, Pmax).  Returns SNOWTRI_ERR_SINGULAR (outputs still
+ * written) if any valid pair was exactly singular. */
+int snowtri_triangulate(snowtri_ctx *ctx, int64_t F, int32_t Pmax, int32_t J, const void *kpts,
+                        int in_dtype, const int32_t *n_persons, const snowtri_params *params,
+                        double *cand_xyz, double *cand_kscore, double *cand_pscore, uint8_t *cand_keep,
+                        int memspace, void *stream);
+int64_t snowtri_num_candidate_slots(int32_t C, int32_t Pmax);
+
+/* A4  Human_Triangulation_Condense (triangulation.py:95-162) on materialised candidates.
+ * cand_xyz[F][N][J][3], cand_kscore[F][N][J] fp64; cand_keep[F][N] (NULL = every slot is a
+ * candidate) selects, in slot order, the candidate list the reference would hold.
+ * Outputs fp64: out_xyz[F][Pout_max][kn][3], out_kscore[F][Pout_max][kn], out_pscore[F][Pout_max],
+ * out_count[F] (true number of persons), out_flags[F] (optional). */
+int snowtri_condense(snowtri_ctx *ctx, int64_t F, int32_t N, int32_t J, const double *cand_xyz,
+                     const double *cand_kscore, const uint8_t *cand_keep, const snowtri_params *params,
+                     int32_t Pout_max, double *out_xyz, double *out_kscore, double *out_pscore,
+                     int32_t *out_count, uint32_t *out_flags, int memspace, void *stream);
+
+/* A1..A4 fused over a batch of frames -- the hot path.  Replaces the per-frame sequence
+ * add_human_2D_points x (C*P) -> Human_Triangulation -> Human_Triangulation_Condense of
+ * main.py:50-71,106.  No candidate list ever reaches HBM on the fast path.
+ *   kpts [F][C][Pmax][J][3] of in_dtype;  out_xyzs [F][Pout_max][kn][4] of out_dtype
+ *   out_pscore [F][Pout_max] of out_dtype (may be NULL), out_count[F] int32, out_flags[F] (may be NULL)
+ * Entries of persons >= out_count[f] are zero-filled.  Returns OK / ERR_SINGULAR / ERR_OVERFLOW only
+ * for SNOWTRI_HOST calls (device calls are asynchronous: inspect out_flags). */
+int snowtri_triangulate_condense(snowtri_ctx *ctx, int64_t F, int32_t Pmax, int32_t J,
+                                 const void *kpts, int in_dtype, const int32_t *n_persons,
+                                 const snowtri_params *params, int method, int32_t Pout_max,
+                                 void *out_xyzs, void *out_pscore, int out_dtype, int32_t *out_count,
+                                 uint32_t *out_flags, int memspace, void *stream);
+
+/* Measurement aid: HIP-event time (ms) of the kernels launched by the LAST
+ * snowtri_triangulate_condense call on this context, measured on the stream they ran on
+ * (blocks until they finish).  kernel_ms[0] = dominant fused kernel, [1] = everything else. */
+int snowtri_last_kernel_ms(snowtri_ctx *ctx, float kernel_ms[2]);
+/* Toggle per-call event timing (off by default: it adds two event records per launch). */
+int snowtri_set_timing(snowtri_ctx *ctx, int enabled);
+/* Number of frames the last fused call had to route through the general (multi-cluster) kernels. */
+int64_t snowtri_last_slow_frames(snowtri_ctx *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SNOWTRI_H */

@@ -1,0 +1,191 @@
+"""ctypes binding of libsnowtri.so (the C ABI declared in include/snowtri.h).
+
+This is the binding a SnowMocap maintainer would add: no torch types, plain
+pointers and sizes.  There is NO CPU fallback: if the shared library is missing or no MI355X is
+visible, calls raise -- the product path never routes through oracle/ or NumPy.
+"""
+from __future__ import annotations
+
+import ctypes as ct
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libsnowtri.so")
+
+OK, ERR_BAD_ARG, ERR_BAD_INDEX, ERR_HIP, ERR_SINGULAR, ERR_OVERFLOW, ERR_NO_DEVICE = range(7)
+F32, F64 = 0, 1
+HOST, DEVICE = 0, 1
+PAIRWISE, DLT = 0, 1
+FLAG_SINGULAR, FLAG_OVERFLOW, FLAG_FASTPATH = 1, 2, 4
+
+
+class SnowtriError(RuntimeError):
+    def __init__(self, status, where):
+        self.status = status
+        msg = _lib.snowtri_status_string(status).decode() if _lib is not None else str(status)
+        detail = _lib.snowtri_last_error().decode() if (_lib is not None and status == ERR_HIP) else ""
+        super().__init__(f"{where}: {msg}" + (f" [{detail}]" if detail else ""))
+
+
+class Params(ct.Structure):
+    """snowtri_params: thresholds of Human_Triangulation / _Condense (triangulation.py:50,95-100)."""
+    _fields_ = [("keypoint_score_threshold", ct.c_double),
+                ("average_score_threshold", ct.c_double),
+                ("distance_threshold", ct.c_double),
+                ("condense_distance_tol", ct.c_double),
+                ("condense_person_num_tol", ct.c_double),
+                ("condense_score_tol", ct.c_double),
+                ("center_point_index", ct.c_int32),
+                ("keypoint_num", ct.c_int32)]
+
+
+def make_params(keypoint_score_threshold=0.5, average_score_threshold=0.0, distance_threshold=0.05,
+                condense_distance_tol=0.1, condense_person_num_tol=0, condense_score_tol=0.0,
+                center_point_index=18, keypoint_num=30, **_ignored):
+    """Defaults are the reference's function-signature defaults (triangulation.py:50,95-100)."""
+    return Params(float(keypoint_score_threshold), float(average_score_threshold),
+                  float(distance_threshold), float(condense_distance_tol),
+                  float(condense_person_num_tol), float(condense_score_tol),
+                  int(center_point_index), int(keypoint_num))
+
+
+_c_p = ct.c_void_p
+_SIGNATURES = {
+    # name: (restype, argtypes)  -- one entry per symbol declared in include/snowtri.h
+    "snowtri_version": (ct.c_int, []),
+    "snowtri_status_string": (ct.c_char_p, [ct.c_int]),
+    "snowtri_last_error": (ct.c_char_p, []),
+    "snowtri_device_count": (ct.c_int, []),
+    "snowtri_ctx_create": (ct.c_int, [ct.c_int32, _c_p, _c_p, _c_p, ct.c_int, ct.POINTER(_c_p)]),
+    "snowtri_ctx_destroy": (ct.c_int, [_c_p]),
+    "snowtri_ctx_num_cameras": (ct.c_int, [_c_p]),
+    "snowtri_ctx_ray_matrices": (ct.c_int, [_c_p, _c_p]),
+    "snowtri_ctx_synchronize": (ct.c_int, [_c_p]),
+    "snowtri_rays_from_pixels": (ct.c_int, [_c_p, ct.c_int32, ct.c_int64, _c_p, _c_p]),
+    "snowtri_skew_ray_batch": (ct.c_int, [_c_p, ct.c_int64, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,
+                                          ct.POINTER(ct.c_int64)]),
+    "snowtri_triangulate": (ct.c_int, [_c_p, ct.c_int64, ct.c_int32, ct.c_int32, _c_p, ct.c_int, _c_p,
+                                       ct.POINTER(Params), _c_p, _c_p, _c_p, _c_p, ct.c_int, _c_p]),
+    "snowtri_num_candidate_slots": (ct.c_int64, [ct.c_int32, ct.c_int32]),
+    "snowtri_condense": (ct.c_int, [_c_p, ct.c_int64, ct.c_int32, ct.c_int32, _c_p, _c_p, _c_p,
+                                    ct.POINTER(Params), ct.c_int32, _c_p, _c_p, _c_p, _c_p, _c_p,
+                                    ct.c_int, _c_p]),
+    "snowtri_triangulate_condense": (ct.c_int, [_c_p, ct.c_int64, ct.c_int32, ct.c_int32, _c_p, ct.c_int,
+                                                _c_p, ct.POINTER(Params), ct.c_int, ct.c_int32, _c_p,
+                                                _c_p, ct.c_int, _c_p, _c_p, ct.c_int, _c_p]),
+    "snowtri_last_kernel_ms": (ct.c_int, [_c_p, ct.POINTER(ct.c_float * 2)]),
+    "snowtri_set_timing": (ct.c_int, [_c_p, ct.c_int]),
+    "snowtri_last_slow_frames": (ct.c_int64, [_c_p]),
+}
+
+_lib = None
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def lib():
+    """Load libsnowtri.so (built by __graft_entry__.build() / `make -C snowmocap_amd/csrc`)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  snowmocap_amd has no CPU fallback.")
+        handle = ct.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(handle, name)      # AttributeError if the ABI lost a symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(status, where):
+    if status != OK:
+        raise SnowtriError(status, where)
+
+
+def ptr(a):
+    """void* of a NumPy array (or None)."""
+    if a is None:
+        return None
+    return ct.c_void_p(a.ctypes.data)
+
+
+def dtype_code(dt):
+    dt = np.dtype(dt)
+    if dt == np.float32:
+        return F32
+    if dt == np.float64:
+        return F64
+    raise TypeError(f"snowtri supports float32/float64 I/O, not {dt}")
+
+
+class Context:
+    """Owner of a snowtri_ctx (rig constants + device scratch).  Not thread-safe."""
+
+    def __init__(self, K=None, R=None, t=None, device=0):
+        L = lib()
+        if L.snowtri_device_count() <= 0:
+            raise SnowtriError(ERR_NO_DEVICE, "snowtri_ctx_create")
+        if K is None:
+            C = 0
+            Kc = Rc = tc = None
+        else:
+            Kc = np.ascontiguousarray(K, dtype=np.float64).reshape(-1, 9)
+            C = Kc.shape[0]
+            Rc = np.ascontiguousarray(R, dtype=np.float64).reshape(C, 9)
+            tc = np.ascontiguousarray(t, dtype=np.float64).reshape(C, 3)
+        h = ct.c_void_p()
+        rc = L.snowtri_ctx_create(C, ptr(Kc), ptr(Rc), ptr(tc), int(device), ct.byref(h))
+        if rc == ERR_SINGULAR:
+            raise np.linalg.LinAlgError("Singular matrix")     # np.linalg.inv(K), camera.py:242
+        check(rc, "snowtri_ctx_create")
+        self.handle = h
+        self.C = C
+        self.device = int(device)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().snowtri_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        check(lib().snowtri_ctx_synchronize(self.handle), "snowtri_ctx_synchronize")
+
+    def ray_matrices(self):
+        M = np.empty((self.C, 9))
+        check(lib().snowtri_ctx_ray_matrices(self.handle, ptr(M)), "snowtri_ctx_ray_matrices")
+        return M.reshape(self.C, 3, 3)
+
+    def set_timing(self, enabled=True):
+        check(lib().snowtri_set_timing(self.handle, int(bool(enabled))), "snowtri_set_timing")
+
+    def last_kernel_ms(self):
+        arr = (ct.c_float * 2)()
+        check(lib().snowtri_last_kernel_ms(self.handle, ct.byref(arr)), "snowtri_last_kernel_ms")
+        return float(arr[0]), float(arr[1])
+
+    def last_slow_frames(self):
+        return int(lib().snowtri_last_slow_frames(self.handle))
+
+
+_scratch_ctx = None
+
+
+def scratch_context():
+    """Rig-less context for entry points that need only device scratch (condense, skew rays)."""
+    global _scratch_ctx
+    if _scratch_ctx is None:
+        _scratch_ctx = Context()
+    return _scratch_ctx

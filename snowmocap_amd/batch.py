@@ -1,0 +1,84 @@
+"""Additive batched API over the fused hot-path entry (snowtri_triangulate_condense).
+
+`BatchTriangulator.run_host`  : NumPy in / NumPy out (staged through the context, synchronous).
+`BatchTriangulator.run_torch` : CUDA(=HIP) tensors in / out, asynchronous on torch's current stream.
+PyTorch is plumbing here (device memory + streams), never arithmetic.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _lib
+
+
+class BatchTriangulator:
+    def __init__(self, K, R, t, params, pout_max=1, out_dtype=np.float32, device=0, method=_lib.PAIRWISE):
+        self.ctx = _lib.Context(K, R, t, device=device)
+        self.C = self.ctx.C
+        self.params = params if isinstance(params, _lib.Params) else _lib.make_params(**params)
+        self.pout_max = int(pout_max)
+        self.out_dtype = np.dtype(out_dtype)
+        self.method = method
+        self.device = device
+
+    # -- host buffers ---------------------------------------------------------------------------
+    def run_host(self, kpts, n_persons=None):
+        kpts = np.ascontiguousarray(kpts)
+        F, C, Pmax, J, three = kpts.shape
+        assert C == self.C and three == 3
+        kn = self.params.keypoint_num
+        if n_persons is not None:
+            n_persons = np.ascontiguousarray(n_persons, dtype=np.int32).reshape(F, C)
+        xyzs = np.empty((F, self.pout_max, max(kn, 0), 4), dtype=self.out_dtype)
+        pscore = np.empty((F, self.pout_max), dtype=self.out_dtype)
+        count = np.zeros(F, dtype=np.int32)
+        flags = np.zeros(F, dtype=np.uint32)
+        rc = _lib.lib().snowtri_triangulate_condense(
+            self.ctx.handle, F, Pmax, J, _lib.ptr(kpts), _lib.dtype_code(kpts.dtype), _lib.ptr(n_persons),
+            self.params, self.method, self.pout_max, _lib.ptr(xyzs), _lib.ptr(pscore),
+            _lib.dtype_code(self.out_dtype), _lib.ptr(count), _lib.ptr(flags), _lib.HOST, None)
+        if rc not in (_lib.OK, _lib.ERR_SINGULAR, _lib.ERR_OVERFLOW):
+            if rc == _lib.ERR_BAD_INDEX:
+                raise IndexError("center_point_index / keypoint_num out of range")
+            _lib.check(rc, "snowtri_triangulate_condense")
+        return dict(xyzs=xyzs, pscore=pscore, count=count, flags=flags, status=rc)
+
+    # -- device buffers (torch tensors) ------------------------------------------------------------
+    def alloc_outputs(self, F, torch_device=None):
+        import torch
+        dev = torch_device or torch.device("cuda", self.device)
+        tdt = torch.float32 if self.out_dtype == np.float32 else torch.float64
+        kn = self.params.keypoint_num
+        return dict(xyzs=torch.empty((F, self.pout_max, kn, 4), dtype=tdt, device=dev),
+                    pscore=torch.empty((F, self.pout_max), dtype=tdt, device=dev),
+                    count=torch.empty((F,), dtype=torch.int32, device=dev),
+                    flags=torch.empty((F,), dtype=torch.int32, device=dev))
+
+    def run_torch(self, kpts, n_persons=None, out=None, stream=None):
+        """kpts: CUDA tensor [F,C,Pmax,J,3] float32/float64 (contiguous).  Launches on `stream`
+        (default: torch's current stream) and returns immediately; results are CUDA tensors."""
+        import torch
+        assert kpts.is_cuda and kpts.is_contiguous()
+        F, C, Pmax, J, three = kpts.shape
+        assert C == self.C and three == 3
+        in_code = _lib.F32 if kpts.dtype == torch.float32 else _lib.F64
+        if out is None:
+            out = self.alloc_outputs(F, kpts.device)
+        if n_persons is not None:
+            assert n_persons.is_cuda and n_persons.dtype == torch.int32 and n_persons.is_contiguous()
+        if stream is None:
+            stream = torch.cuda.current_stream(kpts.device).cuda_stream
+        import ctypes as ct
+        rc = _lib.lib().snowtri_triangulate_condense(
+            self.ctx.handle, F, Pmax, J, ct.c_void_p(kpts.data_ptr()), in_code,
+            ct.c_void_p(n_persons.data_ptr()) if n_persons is not None else None, self.params, self.method,
+            self.pout_max, ct.c_void_p(out["xyzs"].data_ptr()), ct.c_void_p(out["pscore"].data_ptr()),
+            _lib.dtype_code(self.out_dtype), ct.c_void_p(out["count"].data_ptr()),
+            ct.c_void_p(out["flags"].data_ptr()), _lib.DEVICE, ct.c_void_p(stream))
+        if rc == _lib.ERR_BAD_INDEX:
+            raise IndexError("center_point_index / keypoint_num out of range")
+        _lib.check(rc, "snowtri_triangulate_condense")
+        return out
+
+    def close(self):
+        self.ctx.close()

@@ -1,0 +1,681 @@
+// snowtri.hip -- C ABI of libsnowtri.so (declared in include/snowtri.h) over the HIP kernels.
+//
+// Built for gfx950 only:  hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC snowtri.hip
+// No torch types, no exceptions across the boundary; every entry point returns a snowtri_status.
+#include "../../include/snowtri.h"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "snowtri_fused.hpp"
+#include "snowtri_kernels.hpp"
+
+using namespace snowtri;
+
+namespace {
+
+thread_local std::string g_last_error;
+
+#define HIP_TRY(expr)                                                                            \
+    do {                                                                                         \
+        hipError_t _e = (expr);                                                                  \
+        if (_e != hipSuccess) {                                                                  \
+            char _buf[512];                                                                      \
+            snprintf(_buf, sizeof(_buf), "%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e),  \
+                     __FILE__, __LINE__);                                                        \
+            g_last_error = _buf;                                                                 \
+            return SNOWTRI_ERR_HIP;                                                              \
+        }                                                                                        \
+    } while (0)
+
+struct Scratch {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return SNOWTRI_OK;
+        if (p) {
+            HIP_TRY(hipFree(p));
+            p = nullptr;
+            cap = 0;
+        }
+        size_t want = std::max(bytes, (size_t)1 << 20);
+        HIP_TRY(hipMalloc(&p, want));
+        cap = want;
+        return SNOWTRI_OK;
+    }
+    void release() {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+int inv3(const double *m, double *o) {
+    const double c00 = m[4] * m[8] - m[5] * m[7];
+    const double c01 = m[5] * m[6] - m[3] * m[8];
+    const double c02 = m[3] * m[7] - m[4] * m[6];
+    const double det = m[0] * c00 + m[1] * c01 + m[2] * c02;
+    if (det == 0.0 || !std::isfinite(det)) return 1;
+    const double id = 1.0 / det;
+    o[0] = c00 * id;
+    o[1] = (m[2] * m[7] - m[1] * m[8]) * id;
+    o[2] = (m[1] * m[5] - m[2] * m[4]) * id;
+    o[3] = c01 * id;
+    o[4] = (m[0] * m[8] - m[2] * m[6]) * id;
+    o[5] = (m[2] * m[3] - m[0] * m[5]) * id;
+    o[6] = c02 * id;
+    o[7] = (m[1] * m[6] - m[0] * m[7]) * id;
+    o[8] = (m[0] * m[4] - m[1] * m[3]) * id;
+    return 0;
+}
+
+int grid_for(int64_t work_items, int per_block, int cap_blocks) {
+    int64_t b = (work_items + per_block - 1) / per_block;
+    return (int)std::max<int64_t>(1, std::min<int64_t>(b, cap_blocks));
+}
+
+}  // namespace
+
+struct snowtri_ctx {
+    int device = 0;
+    int32_t C = 0, npairs = 0;
+    int num_cus = 256;
+    std::vector<double> hM, ht;
+    std::vector<int32_t> hpairs;
+    double *dM = nullptr, *dt = nullptr;
+    int32_t *dpairs = nullptr;
+    unsigned long long *d_counters = nullptr;  // [0] singular pairs, [1] slow frames, [2..] spare
+    Scratch in, out, work, misc;
+    // measurement
+    bool timing = false;
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+    bool ev_valid = false;
+    hipStream_t ev_stream = nullptr;
+    int64_t last_slow_frames = 0;
+    Rig rig() const { return Rig{dM, dt, dpairs, C, npairs}; }
+};
+
+extern "C" {
+
+int snowtri_version(void) { return SNOWTRI_VERSION; }
+
+const char *snowtri_status_string(int s) {
+    switch (s) {
+        case SNOWTRI_OK: return "ok";
+        case SNOWTRI_ERR_BAD_ARG: return "bad argument";
+        case SNOWTRI_ERR_BAD_INDEX: return "center_point_index / keypoint_num out of range";
+        case SNOWTRI_ERR_HIP: return "HIP runtime error";
+        case SNOWTRI_ERR_SINGULAR: return "singular ray pair (parallel rays)";
+        case SNOWTRI_ERR_OVERFLOW: return "more output persons than Pout_max";
+        case SNOWTRI_ERR_NO_DEVICE: return "no HIP device";
+        default: return "unknown status";
+    }
+}
+
+const char *snowtri_last_error(void) { return g_last_error.c_str(); }
+
+int snowtri_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int snowtri_ctx_create(int32_t C, const double *K, const double *R, const double *t, int device,
+                       snowtri_ctx **out) {
+    if (!out || C < 0 || (C > 0 && (!K || !R || !t))) return SNOWTRI_ERR_BAD_ARG;
+    *out = nullptr;
+    if (snowtri_device_count() <= 0) return SNOWTRI_ERR_NO_DEVICE;
+    snowtri_ctx *ctx = new (std::nothrow) snowtri_ctx();
+    if (!ctx) return SNOWTRI_ERR_BAD_ARG;
+    ctx->device = device;
+    ctx->C = C;
+    ctx->hM.resize((size_t)C * 9);
+    ctx->ht.assign(t, t + (size_t)C * 3);
+    for (int c = 0; c < C; c++) {
+        double Ki[9];
+        if (inv3(K + 9 * c, Ki)) {  // np.linalg.inv(K) raises on a singular K (camera.py:242)
+            delete ctx;
+            return SNOWTRI_ERR_SINGULAR;
+        }
+        const double *Rc = R + 9 * c;
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++)
+                ctx->hM[9 * c + 3 * i + j] = Rc[3 * i] * Ki[j] + Rc[3 * i + 1] * Ki[3 + j] + Rc[3 * i + 2] * Ki[6 + j];
+    }
+    for (int mc = 0; mc < C - 1; mc++)  // triangulation.py:56-58 loop order
+        for (int sc = mc + 1; sc < C; sc++) {
+            ctx->hpairs.push_back(mc);
+            ctx->hpairs.push_back(sc);
+        }
+    ctx->npairs = (int32_t)(ctx->hpairs.size() / 2);
+    auto fail = [&](int rc) {
+        snowtri_ctx_destroy(ctx);
+        return rc;
+    };
+#define CTX_TRY(expr)                                         \
+    do {                                                      \
+        if ((expr) != hipSuccess) {                           \
+            g_last_error = std::string(#expr) + " failed";    \
+            return fail(SNOWTRI_ERR_HIP);                     \
+        }                                                     \
+    } while (0)
+    CTX_TRY(hipSetDevice(device));
+    hipDeviceProp_t prop;
+    CTX_TRY(hipGetDeviceProperties(&prop, device));
+    ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    CTX_TRY(hipMalloc(&ctx->dM, sizeof(double) * std::max<size_t>(9, ctx->hM.size())));
+    CTX_TRY(hipMalloc(&ctx->dt, sizeof(double) * std::max<size_t>(3, ctx->ht.size())));
+    CTX_TRY(hipMalloc(&ctx->dpairs, sizeof(int32_t) * std::max<size_t>(2, ctx->hpairs.size())));
+    CTX_TRY(hipMalloc(&ctx->d_counters, sizeof(unsigned long long) * 8));
+    if (C > 0) {
+        CTX_TRY(hipMemcpy(ctx->dM, ctx->hM.data(), sizeof(double) * ctx->hM.size(), hipMemcpyHostToDevice));
+        CTX_TRY(hipMemcpy(ctx->dt, ctx->ht.data(), sizeof(double) * ctx->ht.size(), hipMemcpyHostToDevice));
+    }
+    if (ctx->npairs > 0)
+        CTX_TRY(hipMemcpy(ctx->dpairs, ctx->hpairs.data(), sizeof(int32_t) * ctx->hpairs.size(), hipMemcpyHostToDevice));
+    CTX_TRY(hipMemset(ctx->d_counters, 0, sizeof(unsigned long long) * 8));
+    for (auto &e : ctx->ev) CTX_TRY(hipEventCreate(&e));
+#undef CTX_TRY
+    *out = ctx;
+    return SNOWTRI_OK;
+}
+
+int snowtri_ctx_destroy(snowtri_ctx *ctx) {
+    if (!ctx) return SNOWTRI_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipDeviceSynchronize();
+    if (ctx->dM) (void)hipFree(ctx->dM);
+    if (ctx->dt) (void)hipFree(ctx->dt);
+    if (ctx->dpairs) (void)hipFree(ctx->dpairs);
+    if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+    ctx->in.release();
+    ctx->out.release();
+    ctx->work.release();
+    ctx->misc.release();
+    for (auto &e : ctx->ev)
+        if (e) (void)hipEventDestroy(e);
+    delete ctx;
+    return SNOWTRI_OK;
+}
+
+int snowtri_ctx_num_cameras(const snowtri_ctx *ctx) { return ctx ? ctx->C : -1; }
+
+int snowtri_ctx_ray_matrices(const snowtri_ctx *ctx, double *M_out) {
+    if (!ctx || !M_out) return SNOWTRI_ERR_BAD_ARG;
+    std::memcpy(M_out, ctx->hM.data(), sizeof(double) * ctx->hM.size());
+    return SNOWTRI_OK;
+}
+
+int snowtri_ctx_synchronize(snowtri_ctx *ctx) {
+    if (!ctx) return SNOWTRI_ERR_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    HIP_TRY(hipDeviceSynchronize());
+    return SNOWTRI_OK;
+}
+
+int snowtri_set_timing(snowtri_ctx *ctx, int enabled) {
+    if (!ctx) return SNOWTRI_ERR_BAD_ARG;
+    ctx->timing = enabled != 0;
+    ctx->ev_valid = false;
+    return SNOWTRI_OK;
+}
+
+int snowtri_last_kernel_ms(snowtri_ctx *ctx, float kernel_ms[2]) {
+    if (!ctx || !kernel_ms) return SNOWTRI_ERR_BAD_ARG;
+    kernel_ms[0] = kernel_ms[1] = 0.f;
+    if (!ctx->ev_valid) return SNOWTRI_ERR_BAD_ARG;
+    HIP_TRY(hipEventSynchronize(ctx->ev[3]));
+    float a = 0.f, b = 0.f;
+    HIP_TRY(hipEventElapsedTime(&a, ctx->ev[0], ctx->ev[1]));
+    HIP_TRY(hipEventElapsedTime(&b, ctx->ev[2], ctx->ev[3]));
+    kernel_ms[0] = a;
+    kernel_ms[1] = b;
+    return SNOWTRI_OK;
+}
+
+int64_t snowtri_last_slow_frames(snowtri_ctx *ctx) { return ctx ? ctx->last_slow_frames : -1; }
+
+int64_t snowtri_num_candidate_slots(int32_t C, int32_t Pmax) {
+    if (C < 0 || Pmax < 0) return -1;
+    return (int64_t)C * (C - 1) / 2 * Pmax * Pmax;
+}
+
+// ------------------------------------------------------------------------------------------ A1
+int snowtri_rays_from_pixels(snowtri_ctx *ctx, int32_t cam, int64_t n, const double *uv, double *rays) {
+    if (!ctx || cam < 0 || cam >= ctx->C || n < 0 || (n > 0 && (!uv || !rays))) return SNOWTRI_ERR_BAD_ARG;
+    if (n == 0) return SNOWTRI_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    int rc = ctx->in.ensure(sizeof(double) * 2 * n);
+    if (rc) return rc;
+    rc = ctx->out.ensure(sizeof(double) * 3 * n);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(ctx->in.p, uv, sizeof(double) * 2 * n, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_rays, dim3(grid_for(n, kBlock, ctx->num_cus * 8)), dim3(kBlock), 0, 0, n,
+                       ctx->dM + 9 * cam, (const double *)ctx->in.p, (double *)ctx->out.p);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(rays, ctx->out.p, sizeof(double) * 3 * n, hipMemcpyDeviceToHost));
+    return SNOWTRI_OK;
+}
+
+// ------------------------------------------------------------------------------------------ A2
+int snowtri_skew_ray_batch(snowtri_ctx *ctx, int64_t n, const double *hm, const double *hs,
+                           const double *tm, const double *ts, double *dist, double *W,
+                           int64_t *n_singular) {
+    if (!ctx || n < 0 || (n > 0 && (!hm || !hs || !tm || !ts || !dist || !W))) return SNOWTRI_ERR_BAD_ARG;
+    if (n_singular) *n_singular = 0;
+    if (n == 0) return SNOWTRI_OK;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t v = sizeof(double) * 3 * n;
+    int rc = ctx->in.ensure(4 * v);
+    if (rc) return rc;
+    rc = ctx->out.ensure(v + sizeof(double) * n);
+    if (rc) return rc;
+    char *din = (char *)ctx->in.p;
+    HIP_TRY(hipMemcpy(din, hm, v, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(din + v, hs, v, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(din + 2 * v, tm, v, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(din + 3 * v, ts, v, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(ctx->d_counters, 0, sizeof(unsigned long long)));
+    double *dW = (double *)ctx->out.p, *ddist = dW + 3 * n;
+    hipLaunchKernelGGL(k_skew, dim3(grid_for(n, kBlock, ctx->num_cus * 8)), dim3(kBlock), 0, 0, n,
+                       (const double *)din, (const double *)(din + v), (const double *)(din + 2 * v),
+                       (const double *)(din + 3 * v), ddist, dW, ctx->d_counters);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(W, dW, v, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(dist, ddist, sizeof(double) * n, hipMemcpyDeviceToHost));
+    unsigned long long ns = 0;
+    HIP_TRY(hipMemcpy(&ns, ctx->d_counters, sizeof(ns), hipMemcpyDeviceToHost));
+    if (n_singular) *n_singular = (int64_t)ns;
+    return ns ? SNOWTRI_ERR_SINGULAR : SNOWTRI_OK;
+}
+
+}  // extern "C"
+
+// ---------------------------------------------------------------------------------- helpers
+namespace {
+
+int validate_params(const snowtri_params *p, int J, Params *out, bool need_condense) {
+    if (!p) return SNOWTRI_ERR_BAD_ARG;
+    Params q;
+    q.kthr = p->keypoint_score_threshold;
+    q.avg_thr = p->average_score_threshold;
+    q.dthr = p->distance_threshold;
+    q.ctol = p->condense_distance_tol;
+    q.num_tol = p->condense_person_num_tol;
+    q.score_tol = p->condense_score_tol;
+    q.center = p->center_point_index;
+    q.kn = p->keypoint_num;
+    if (need_condense) {
+        if (q.center < 0) q.center += J;  // Python negative indexing (triangulation.py:112)
+        if (q.center < 0 || q.center >= J || q.kn < 0 || q.kn > J) return SNOWTRI_ERR_BAD_INDEX;
+        if (q.kn > kCondenseMaxJointsPerThread * kBlock) return SNOWTRI_ERR_BAD_ARG;
+    }
+    *out = q;
+    return SNOWTRI_OK;
+}
+
+size_t dtype_size(int dt) { return dt == SNOWTRI_F32 ? 4 : 8; }
+
+template <typename TIn>
+void launch_triangulate(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax, int J, int Kc,
+                        const void *kpts, const int32_t *n_persons, const Params &prm, double *cxyz,
+                        double *cks, double *cps, uint8_t *ckeep) {
+    const int64_t total = F * (int64_t)Kc * J;
+    hipLaunchKernelGGL((k_triangulate<TIn>), dim3(grid_for(total, kBlock, ctx->num_cus * 16)), dim3(kBlock), 0,
+                       st, F, Pmax, J, Kc, ctx->rig(), (const TIn *)kpts, n_persons, prm, cxyz, cks,
+                       ctx->d_counters);
+    hipLaunchKernelGGL(k_cand_mean, dim3(grid_for(F * (int64_t)Kc, kBlock / 64, ctx->num_cus * 16)),
+                       dim3(kBlock), 0, st, F, Pmax, J, Kc, ctx->rig(), n_persons, prm, (const double *)cks,
+                       cps, ckeep);
+}
+
+constexpr int kCondenseMaxN = 9000;  // condense_lds_bytes(N) <= 160 KiB
+
+template <typename Writer>
+int launch_condense(snowtri_ctx *ctx, hipStream_t st, int64_t nframes, int N, int J, const double *cxyz,
+                    const double *cks, const uint8_t *ckeep, const Params &prm, int Pout, Writer wr,
+                    int32_t *out_count, uint32_t *out_flags) {
+    if (N > kCondenseMaxN) return SNOWTRI_ERR_BAD_ARG;
+    const size_t lds = condense_lds_bytes(N);
+    auto kern = k_condense<Writer>;
+    if (lds > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid_for(nframes, 1, ctx->num_cus * 8)), dim3(kBlock), lds, st, nframes, N, J,
+                       cxyz, cks, ckeep, prm, Pout, wr, out_count, out_flags);
+    HIP_TRY(hipGetLastError());
+    return SNOWTRI_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+// --------------------------------------------------------------------------------------- A1+A3
+int snowtri_triangulate(snowtri_ctx *ctx, int64_t F, int32_t Pmax, int32_t J, const void *kpts,
+                        int in_dtype, const int32_t *n_persons, const snowtri_params *params,
+                        double *cand_xyz, double *cand_kscore, double *cand_pscore, uint8_t *cand_keep,
+                        int memspace, void *stream) {
+    if (!ctx || ctx->C < 1 || F < 0 || Pmax < 1 || J < 1 || !params) return SNOWTRI_ERR_BAD_ARG;
+    if (in_dtype != SNOWTRI_F32 && in_dtype != SNOWTRI_F64) return SNOWTRI_ERR_BAD_ARG;
+    if (memspace != SNOWTRI_HOST && memspace != SNOWTRI_DEVICE) return SNOWTRI_ERR_BAD_ARG;
+    const int64_t Kc = snowtri_num_candidate_slots(ctx->C, Pmax);
+    if (F == 0 || Kc == 0) return SNOWTRI_OK;
+    if (!kpts || !cand_xyz || !cand_kscore || !cand_pscore || !cand_keep) return SNOWTRI_ERR_BAD_ARG;
+    Params prm;
+    int rc = validate_params(params, J, &prm, false);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t in_bytes = (size_t)F * ctx->C * Pmax * J * 3 * dtype_size(in_dtype);
+    const size_t np_bytes = n_persons ? sizeof(int32_t) * F * ctx->C : 0;
+    const size_t nx = (size_t)F * Kc * J;
+    const void *d_kpts = kpts;
+    const int32_t *d_np = n_persons;
+    double *d_xyz = cand_xyz, *d_ks = cand_kscore, *d_ps = cand_pscore;
+    uint8_t *d_keep = cand_keep;
+    HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long), st));
+    if (memspace == SNOWTRI_HOST) {
+        rc = ctx->in.ensure(in_bytes + np_bytes + 16);
+        if (rc) return rc;
+        const size_t out_bytes = sizeof(double) * (nx * 4 + (size_t)F * Kc) + (size_t)F * Kc;
+        rc = ctx->out.ensure(out_bytes + 64);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(ctx->in.p, kpts, in_bytes, hipMemcpyHostToDevice, st));
+        d_kpts = ctx->in.p;
+        if (n_persons) {
+            int32_t *p = (int32_t *)((char *)ctx->in.p + ((in_bytes + 15) & ~(size_t)15));
+            HIP_TRY(hipMemcpyAsync(p, n_persons, np_bytes, hipMemcpyHostToDevice, st));
+            d_np = p;
+        }
+        d_xyz = (double *)ctx->out.p;
+        d_ks = d_xyz + nx * 3;
+        d_ps = d_ks + nx;
+        d_keep = (uint8_t *)(d_ps + (size_t)F * Kc);
+        HIP_TRY(hipMemsetAsync(d_xyz, 0, out_bytes, st));  // invalid slots read back as zeros
+    }
+    if (in_dtype == SNOWTRI_F32)
+        launch_triangulate<float>(ctx, st, F, Pmax, J, (int)Kc, d_kpts, d_np, prm, d_xyz, d_ks, d_ps, d_keep);
+    else
+        launch_triangulate<double>(ctx, st, F, Pmax, J, (int)Kc, d_kpts, d_np, prm, d_xyz, d_ks, d_ps, d_keep);
+    HIP_TRY(hipGetLastError());
+    if (memspace == SNOWTRI_HOST) {
+        HIP_TRY(hipMemcpyAsync(cand_xyz, d_xyz, sizeof(double) * nx * 3, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(cand_kscore, d_ks, sizeof(double) * nx, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(cand_pscore, d_ps, sizeof(double) * F * Kc, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(cand_keep, d_keep, (size_t)F * Kc, hipMemcpyDeviceToHost, st));
+        unsigned long long ns = 0;
+        HIP_TRY(hipMemcpyAsync(&ns, ctx->d_counters, sizeof(ns), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (ns) return SNOWTRI_ERR_SINGULAR;
+    }
+    return SNOWTRI_OK;
+}
+
+// ------------------------------------------------------------------------------------------ A4
+int snowtri_condense(snowtri_ctx *ctx, int64_t F, int32_t N, int32_t J, const double *cand_xyz,
+                     const double *cand_kscore, const uint8_t *cand_keep, const snowtri_params *params,
+                     int32_t Pout_max, double *out_xyz, double *out_kscore, double *out_pscore,
+                     int32_t *out_count, uint32_t *out_flags, int memspace, void *stream) {
+    if (!ctx || F < 0 || N < 0 || J < 1 || Pout_max < 1 || !params) return SNOWTRI_ERR_BAD_ARG;
+    if (memspace != SNOWTRI_HOST && memspace != SNOWTRI_DEVICE) return SNOWTRI_ERR_BAD_ARG;
+    if (F == 0) return SNOWTRI_OK;
+    if (!out_xyz || !out_kscore || !out_pscore || !out_count) return SNOWTRI_ERR_BAD_ARG;
+    if (N > 0 && (!cand_xyz || !cand_kscore)) return SNOWTRI_ERR_BAD_ARG;
+    Params prm;
+    int rc = validate_params(params, J, &prm, true);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int kn = prm.kn;
+    const size_t nx = (size_t)F * N * J;
+    const size_t no = (size_t)F * Pout_max * kn;
+    const double *d_xyz = cand_xyz, *d_ks = cand_kscore;
+    const uint8_t *d_keep = cand_keep;
+    double *o_xyz = out_xyz, *o_ks = out_kscore, *o_ps = out_pscore;
+    int32_t *o_cnt = out_count;
+    uint32_t *o_fl = out_flags;
+    if (memspace == SNOWTRI_HOST) {
+        rc = ctx->in.ensure(sizeof(double) * nx * 4 + (size_t)F * N + 64);
+        if (rc) return rc;
+        rc = ctx->out.ensure(sizeof(double) * (no * 4 + (size_t)F * Pout_max) + 8 * (size_t)F + 64);
+        if (rc) return rc;
+        double *p = (double *)ctx->in.p;
+        if (nx) {
+            HIP_TRY(hipMemcpyAsync(p, cand_xyz, sizeof(double) * nx * 3, hipMemcpyHostToDevice, st));
+            HIP_TRY(hipMemcpyAsync(p + nx * 3, cand_kscore, sizeof(double) * nx, hipMemcpyHostToDevice, st));
+        }
+        d_xyz = p;
+        d_ks = p + nx * 3;
+        if (cand_keep && N) {
+            uint8_t *k = (uint8_t *)(p + nx * 4);
+            HIP_TRY(hipMemcpyAsync(k, cand_keep, (size_t)F * N, hipMemcpyHostToDevice, st));
+            d_keep = k;
+        }
+        o_xyz = (double *)ctx->out.p;
+        o_ks = o_xyz + no * 3;
+        o_ps = o_ks + no;
+        o_cnt = (int32_t *)(o_ps + (size_t)F * Pout_max);
+        o_fl = (uint32_t *)(o_cnt + F);
+    }
+    if (o_fl) HIP_TRY(hipMemsetAsync(o_fl, 0, sizeof(uint32_t) * F, st));
+    rc = launch_condense(ctx, st, F, N, J, d_xyz, d_ks, d_keep, prm, Pout_max, SplitWriter{o_xyz, o_ks, o_ps},
+                         o_cnt, o_fl);
+    if (rc) return rc;
+    if (memspace == SNOWTRI_HOST) {
+        if (no) {
+            HIP_TRY(hipMemcpyAsync(out_xyz, o_xyz, sizeof(double) * no * 3, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(out_kscore, o_ks, sizeof(double) * no, hipMemcpyDeviceToHost, st));
+        }
+        HIP_TRY(hipMemcpyAsync(out_pscore, o_ps, sizeof(double) * F * Pout_max, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(out_count, o_cnt, sizeof(int32_t) * F, hipMemcpyDeviceToHost, st));
+        if (out_flags) HIP_TRY(hipMemcpyAsync(out_flags, o_fl, sizeof(uint32_t) * F, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        for (int64_t f = 0; f < F; f++)
+            if (out_count[f] > Pout_max) return SNOWTRI_ERR_OVERFLOW;
+    }
+    return SNOWTRI_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------- fused A1..A4
+namespace {
+
+constexpr size_t kMaxScratchBytes = (size_t)8 << 30;
+
+// Frames per tile for the fast kernel: maximise (lane utilisation of the item loop) x (balance of
+// tiles over the resident workgroups), under the LDS budget.
+int choose_tile_frames(int64_t F, int J, int kn, int NP, int resident_blocks) {
+    int best = 1;
+    double best_score = -1.0;
+    for (int T = 1; T <= 64; T++) {
+        if (fused_single_lds_bytes(T, kn, NP) > 40 * 1024) break;
+        const int64_t items = (int64_t)T * J;
+        const double eff_pass = (double)items / (double)(((items + kBlock - 1) / kBlock) * kBlock);
+        const int64_t ntiles = (F + T - 1) / T;
+        const int64_t rounds = (ntiles + resident_blocks - 1) / resident_blocks;
+        const double eff_bal = (double)ntiles / (double)(rounds * resident_blocks);
+        const double score = eff_pass * eff_bal;
+        if (score > best_score + 1e-9) {
+            best_score = score;
+            best = T;
+        }
+    }
+    return best;
+}
+
+template <int C, typename TIn, typename TOut>
+int launch_fused_single(snowtri_ctx *ctx, hipStream_t st, int64_t F, int J, const TIn *d_kpts,
+                        const int32_t *d_np, const Params &prm, int Pout, TOut *d_xyzs, TOut *d_ps,
+                        int32_t *d_cnt, uint32_t *d_fl) {
+    constexpr int NP = C * (C - 1) / 2;
+    const int resident = ctx->num_cus * 4;
+    const int T = choose_tile_frames(F, J, prm.kn, NP, resident);
+    const int64_t ntiles = (F + T - 1) / T;
+    const int grid = (int)std::min<int64_t>(ntiles, resident);
+    const size_t per_block = general_scratch_bytes(NP, J);
+    int rc = ctx->work.ensure(per_block * (size_t)grid);
+    if (rc) return rc;
+    const size_t lds = fused_single_lds_bytes(T, prm.kn, NP);
+    auto kern = k_fused_single<C, TIn, TOut>;
+    if (lds > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, st, F, J, T, ctx->rig(), d_kpts, d_np, prm, Pout,
+                       d_xyzs, d_ps, d_cnt, d_fl, ctx->d_counters, (char *)ctx->work.p, per_block);
+    HIP_TRY(hipGetLastError());
+    return SNOWTRI_OK;
+}
+
+template <typename TIn, typename TOut>
+int launch_frame_general(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax, int J, const TIn *d_kpts,
+                         const int32_t *d_np, const Params &prm, int Pout, TOut *d_xyzs, TOut *d_ps,
+                         int32_t *d_cnt, uint32_t *d_fl) {
+    const int64_t Kc = snowtri_num_candidate_slots(ctx->C, Pmax);
+    if (Kc > kCondenseMaxN) return SNOWTRI_ERR_BAD_ARG;
+    const size_t per_block = general_scratch_bytes(Kc, J);
+    int64_t grid = std::min<int64_t>(F, (int64_t)ctx->num_cus * 2);
+    grid = std::max<int64_t>(1, std::min<int64_t>(grid, (int64_t)(kMaxScratchBytes / per_block)));
+    int rc = ctx->work.ensure(per_block * (size_t)grid);
+    if (rc) return rc;
+    const size_t lds = condense_lds_bytes((int)Kc);
+    auto kern = k_frame_general<TIn, TOut>;
+    if (lds > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((int)grid), dim3(kBlock), lds, st, F, Pmax, J, (int)Kc, ctx->rig(), d_kpts, d_np,
+                       prm, Pout, d_xyzs, d_ps, d_cnt, d_fl, (char *)ctx->work.p, per_block);
+    HIP_TRY(hipGetLastError());
+    return SNOWTRI_OK;
+}
+
+template <typename TIn, typename TOut>
+int fused_dispatch(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax, int J, const void *kpts,
+                   const int32_t *d_np, const Params &prm, int Pout, void *xyzs, void *ps, int32_t *d_cnt,
+                   uint32_t *d_fl) {
+    const TIn *d_kpts = (const TIn *)kpts;
+    TOut *d_xyzs = (TOut *)xyzs, *d_ps = (TOut *)ps;
+    const int C = ctx->C;
+    const bool fast = Pmax == 1 && C >= 3 && C <= 8 && prm.kn >= 1 && prm.avg_thr <= 0.0 &&
+                      !((double)ctx->npairs < prm.num_tol);
+    if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[0], st));
+    int rc;
+    if (fast) {
+        switch (C) {
+#define SNOWTRI_CASE(CC)                                                                                   \
+    case CC:                                                                                               \
+        rc = launch_fused_single<CC, TIn, TOut>(ctx, st, F, J, d_kpts, d_np, prm, Pout, d_xyzs, d_ps, d_cnt, d_fl); \
+        break;
+            SNOWTRI_CASE(3)
+            SNOWTRI_CASE(4)
+            SNOWTRI_CASE(5)
+            SNOWTRI_CASE(6)
+            SNOWTRI_CASE(7)
+            SNOWTRI_CASE(8)
+#undef SNOWTRI_CASE
+            default: rc = SNOWTRI_ERR_BAD_ARG;
+        }
+    } else {
+        rc = launch_frame_general<TIn, TOut>(ctx, st, F, Pmax, J, d_kpts, d_np, prm, Pout, d_xyzs, d_ps, d_cnt, d_fl);
+    }
+    if (rc) return rc;
+    if (ctx->timing) {
+        HIP_TRY(hipEventRecord(ctx->ev[1], st));
+        HIP_TRY(hipEventRecord(ctx->ev[2], st));
+        HIP_TRY(hipEventRecord(ctx->ev[3], st));
+        ctx->ev_valid = true;
+        ctx->ev_stream = st;
+    }
+    return SNOWTRI_OK;
+}
+
+}  // namespace
+
+extern "C" int snowtri_triangulate_condense(snowtri_ctx *ctx, int64_t F, int32_t Pmax, int32_t J,
+                                            const void *kpts, int in_dtype, const int32_t *n_persons,
+                                            const snowtri_params *params, int method, int32_t Pout_max,
+                                            void *out_xyzs, void *out_pscore, int out_dtype,
+                                            int32_t *out_count, uint32_t *out_flags, int memspace,
+                                            void *stream) {
+    if (!ctx || ctx->C < 1 || F < 0 || Pmax < 1 || J < 1 || Pout_max < 1 || !params) return SNOWTRI_ERR_BAD_ARG;
+    if ((in_dtype != SNOWTRI_F32 && in_dtype != SNOWTRI_F64) || (out_dtype != SNOWTRI_F32 && out_dtype != SNOWTRI_F64))
+        return SNOWTRI_ERR_BAD_ARG;
+    if (memspace != SNOWTRI_HOST && memspace != SNOWTRI_DEVICE) return SNOWTRI_ERR_BAD_ARG;
+    if (method != SNOWTRI_PAIRWISE) return SNOWTRI_ERR_BAD_ARG;  // SNOWTRI_DLT: not built yet
+    if (F == 0) return SNOWTRI_OK;
+    if (!kpts || !out_xyzs || !out_count) return SNOWTRI_ERR_BAD_ARG;
+    Params prm;
+    int rc = validate_params(params, J, &prm, true);
+    if (rc) return rc;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int kn = prm.kn;
+    const size_t isz = dtype_size(in_dtype), osz = dtype_size(out_dtype);
+    const size_t in_bytes = (size_t)F * ctx->C * Pmax * J * 3 * isz;
+    const size_t np_bytes = n_persons ? sizeof(int32_t) * F * ctx->C : 0;
+    const size_t o4 = (size_t)F * Pout_max * kn * 4 * osz, ops = (size_t)F * Pout_max * osz;
+    const void *d_kpts = kpts;
+    const int32_t *d_np = n_persons;
+    void *d_xyzs = out_xyzs, *d_ps = out_pscore;
+    int32_t *d_cnt = out_count;
+    uint32_t *d_fl = out_flags;
+    if (memspace == SNOWTRI_HOST) {
+        rc = ctx->in.ensure(in_bytes + np_bytes + 64);
+        if (rc) return rc;
+        rc = ctx->out.ensure(o4 + ops + 8 * (size_t)F + 256);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(ctx->in.p, kpts, in_bytes, hipMemcpyHostToDevice, st));
+        d_kpts = ctx->in.p;
+        if (n_persons) {
+            int32_t *p = (int32_t *)((char *)ctx->in.p + ((in_bytes + 15) & ~(size_t)15));
+            HIP_TRY(hipMemcpyAsync(p, n_persons, np_bytes, hipMemcpyHostToDevice, st));
+            d_np = p;
+        }
+        char *o = (char *)ctx->out.p;
+        d_xyzs = o;
+        d_ps = o + ((o4 + 15) & ~(size_t)15);
+        d_cnt = (int32_t *)((char *)d_ps + ((ops + 15) & ~(size_t)15));
+        d_fl = (uint32_t *)(d_cnt + F);
+    } else if (!d_fl) {
+        rc = ctx->misc.ensure(sizeof(uint32_t) * F);
+        if (rc) return rc;
+        d_fl = (uint32_t *)ctx->misc.p;
+    }
+    HIP_TRY(hipMemsetAsync(d_fl, 0, sizeof(uint32_t) * F, st));
+    HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * 2, st));
+    if (in_dtype == SNOWTRI_F32 && out_dtype == SNOWTRI_F32)
+        rc = fused_dispatch<float, float>(ctx, st, F, Pmax, J, d_kpts, d_np, prm, Pout_max, d_xyzs, d_ps, d_cnt, d_fl);
+    else if (in_dtype == SNOWTRI_F32)
+        rc = fused_dispatch<float, double>(ctx, st, F, Pmax, J, d_kpts, d_np, prm, Pout_max, d_xyzs, d_ps, d_cnt, d_fl);
+    else if (out_dtype == SNOWTRI_F32)
+        rc = fused_dispatch<double, float>(ctx, st, F, Pmax, J, d_kpts, d_np, prm, Pout_max, d_xyzs, d_ps, d_cnt, d_fl);
+    else
+        rc = fused_dispatch<double, double>(ctx, st, F, Pmax, J, d_kpts, d_np, prm, Pout_max, d_xyzs, d_ps, d_cnt, d_fl);
+    if (rc) return rc;
+    if (memspace == SNOWTRI_HOST) {
+        HIP_TRY(hipMemcpyAsync(out_xyzs, d_xyzs, o4, hipMemcpyDeviceToHost, st));
+        if (out_pscore) HIP_TRY(hipMemcpyAsync(out_pscore, d_ps, ops, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(out_count, d_cnt, sizeof(int32_t) * F, hipMemcpyDeviceToHost, st));
+        std::vector<uint32_t> fl_host;
+        uint32_t *fl = out_flags;
+        if (!fl) {
+            fl_host.resize(F);
+            fl = fl_host.data();
+        }
+        HIP_TRY(hipMemcpyAsync(fl, d_fl, sizeof(uint32_t) * F, hipMemcpyDeviceToHost, st));
+        unsigned long long ctr[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(ctr, ctx->d_counters, sizeof(ctr), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        ctx->last_slow_frames = (int64_t)ctr[1];
+        uint32_t any = 0;
+        for (int64_t f = 0; f < F; f++) any |= fl[f];
+        if (any & SNOWTRI_FLAG_SINGULAR) return SNOWTRI_ERR_SINGULAR;
+        if (any & SNOWTRI_FLAG_OVERFLOW) return SNOWTRI_ERR_OVERFLOW;
+    }
+    return SNOWTRI_OK;
+}

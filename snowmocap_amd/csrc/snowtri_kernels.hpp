@@ -1,0 +1,317 @@
+// snowtri_kernels.hpp -- materialised-candidate kernels (API-faithful path and general fallback).
+//
+//   k_rays          A1  camera.py:234-253
+//   k_skew          A2  triangulation.py:24-31
+//   k_triangulate   A1+A3 per (frame, candidate slot, joint)   triangulation.py:50-78
+//   k_cand_mean     A3  np.mean(p_score) + average_score_threshold filter   triangulation.py:79-81
+//   k_condense      A4  greedy clustering + score-weighted fusion   triangulation.py:95-162
+//
+// The fused single-cluster fast path lives in snowtri_fused.hpp.
+#pragma once
+#include "snowtri_math.hpp"
+
+namespace snowtri {
+
+constexpr int kBlock = 256;
+
+__global__ __launch_bounds__(kBlock) void k_rays(int64_t n, const double *__restrict__ M,
+                                                 const double *__restrict__ uv, double *__restrict__ rays) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        Vec3 h = ray_from_pixel(M, uv[2 * i], uv[2 * i + 1]);
+        rays[3 * i] = h.x;
+        rays[3 * i + 1] = h.y;
+        rays[3 * i + 2] = h.z;
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_skew(int64_t n, const double *__restrict__ hm,
+                                                 const double *__restrict__ hs, const double *__restrict__ tm,
+                                                 const double *__restrict__ ts, double *__restrict__ dist,
+                                                 double *__restrict__ W, unsigned long long *n_singular) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        Vec3 a = {hm[3 * i], hm[3 * i + 1], hm[3 * i + 2]}, b = {hs[3 * i], hs[3 * i + 1], hs[3 * i + 2]};
+        Vec3 c = {tm[3 * i], tm[3 * i + 1], tm[3 * i + 2]}, d = {ts[3 * i], ts[3 * i + 1], ts[3 * i + 2]};
+        SkewOut o = skew_ray_solve(a, b, c, d);
+        dist[i] = o.dist;
+        W[3 * i] = o.W.x;
+        W[3 * i + 1] = o.W.y;
+        W[3 * i + 2] = o.W.z;
+        if (o.singular) atomicAdd(n_singular, 1ull);
+    }
+}
+
+// Rig constants resident in HBM (<= 1.5 KB, L2/scalar-cache resident): M[C][9], t[C][3],
+// pair table [npairs][2] in the reference's loop order mc < sc (triangulation.py:56-58).
+struct Rig {
+    const double *M;
+    const double *t;
+    const int32_t *pairs;
+    int32_t C, npairs;
+};
+
+template <typename TIn>
+__global__ __launch_bounds__(kBlock) void k_triangulate(int64_t F, int Pmax, int J, int Kc, Rig rig,
+                                                        const TIn *__restrict__ kpts,
+                                                        const int32_t *__restrict__ n_persons, Params prm,
+                                                        double *__restrict__ cand_xyz,
+                                                        double *__restrict__ cand_kscore,
+                                                        unsigned long long *n_singular) {
+    const int64_t total = F * (int64_t)Kc * J;
+    const int pp = Pmax * Pmax;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int j = (int)(i % J);
+        const int64_t fk = i / J;
+        const int k = (int)(fk % Kc);
+        const int64_t f = fk / Kc;
+        const int q = k / pp, r = k - q * pp, pm = r / Pmax, ps = r - pm * Pmax;
+        const int mc = rig.pairs[2 * q], sc = rig.pairs[2 * q + 1];
+        const int nm = n_persons ? n_persons[f * rig.C + mc] : Pmax;
+        const int ns = n_persons ? n_persons[f * rig.C + sc] : Pmax;
+        if (pm >= nm || ps >= ns) continue;  // not a real pair: slot stays untouched, keep = 0
+        const TIn *km = kpts + ((((f * rig.C + mc) * Pmax + pm) * (int64_t)J) + j) * 3;
+        const TIn *ks = kpts + ((((f * rig.C + sc) * Pmax + ps) * (int64_t)J) + j) * 3;
+        const TIn um = km[0], vm = km[1], sm = km[2];
+        const TIn us = ks[0], vs = ks[1], ss = ks[2];
+        const Vec3 hm = ray_from_pixel(rig.M + 9 * mc, (double)um, (double)vm);
+        const Vec3 hs = ray_from_pixel(rig.M + 9 * sc, (double)us, (double)vs);
+        const Vec3 tm = {rig.t[3 * mc], rig.t[3 * mc + 1], rig.t[3 * mc + 2]};
+        const Vec3 ts = {rig.t[3 * sc], rig.t[3 * sc + 1], rig.t[3 * sc + 2]};
+        const SkewOut o = skew_ray_solve(hm, hs, tm, ts);
+        if (o.singular) atomicAdd(n_singular, 1ull);
+        const double s = pair_score(sm, ss, o.dist, prm);
+        cand_xyz[3 * i] = o.W.x;
+        cand_xyz[3 * i + 1] = o.W.y;
+        cand_xyz[3 * i + 2] = o.W.z;
+        cand_kscore[i] = s;
+    }
+}
+
+// One wave per (frame, slot): mean of the J joint scores and the keep decision.
+__global__ __launch_bounds__(kBlock) void k_cand_mean(int64_t F, int Pmax, int J, int Kc, Rig rig,
+                                                      const int32_t *__restrict__ n_persons, Params prm,
+                                                      const double *__restrict__ cand_kscore,
+                                                      double *__restrict__ cand_pscore,
+                                                      uint8_t *__restrict__ cand_keep) {
+    const int lane = threadIdx.x & 63;
+    const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
+    const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
+    const int pp = Pmax * Pmax;
+    for (int64_t fk = wave; fk < F * (int64_t)Kc; fk += nwaves) {
+        const int k = (int)(fk % Kc);
+        const int64_t f = fk / Kc;
+        const int q = k / pp, r = k - q * pp, pm = r / Pmax, ps = r - pm * Pmax;
+        const int mc = rig.pairs[2 * q], sc = rig.pairs[2 * q + 1];
+        const int nm = n_persons ? n_persons[f * rig.C + mc] : Pmax;
+        const int ns = n_persons ? n_persons[f * rig.C + sc] : Pmax;
+        const bool valid = pm < nm && ps < ns;
+        double s = 0.0;
+        if (valid)
+            for (int j = lane; j < J; j += 64) s += cand_kscore[fk * J + j];
+        s = wave_sum(s);
+        const double mean = s / (double)J;  // triangulation.py:79
+        if (lane == 0) {
+            cand_pscore[fk] = valid ? mean : 0.0;
+            cand_keep[fk] = (valid && !(mean < prm.avg_thr)) ? 1 : 0;  // :80-81 (NaN mean is kept)
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Output writers for k_condense: the API-faithful split fp64 arrays, or the packed
+// (x, y, z, score) layout of the batched hot path.
+struct SplitWriter {
+    double *xyz, *kscore, *pscore;
+    __device__ __forceinline__ void joint(int64_t f, int Pout, int kn, int slot, int b, double x, double y,
+                                          double z, double s) const {
+        const int64_t o = ((f * Pout + slot) * (int64_t)kn + b);
+        xyz[3 * o] = x;
+        xyz[3 * o + 1] = y;
+        xyz[3 * o + 2] = z;
+        kscore[o] = s;
+    }
+    __device__ __forceinline__ void person(int64_t f, int Pout, int slot, double s) const {
+        pscore[f * Pout + slot] = s;
+    }
+};
+
+template <typename TOut>
+struct PackedWriter {
+    TOut *xyzs, *pscore;
+    __device__ __forceinline__ void joint(int64_t f, int Pout, int kn, int slot, int b, double x, double y,
+                                          double z, double s) const {
+        TOut *o = xyzs + ((f * Pout + slot) * (int64_t)kn + b) * 4;
+        o[0] = (TOut)x;
+        o[1] = (TOut)y;
+        o[2] = (TOut)z;
+        o[3] = (TOut)s;
+    }
+    __device__ __forceinline__ void person(int64_t f, int Pout, int slot, double s) const {
+        if (pscore) pscore[f * Pout + slot] = (TOut)s;
+    }
+};
+
+__device__ __forceinline__ double block_sum(double v, double *red /*[kBlock/64]*/) {
+    v = wave_sum(v);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double t = 0.0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; w++) t += red[w];
+    return t;
+}
+
+constexpr int kCondenseMaxJointsPerThread = 4;  // keypoint_num <= 4 * kBlock
+
+// LDS footprint of condense_frame for N candidate slots.
+__host__ __device__ constexpr size_t condense_lds_bytes(int N) { return (size_t)16 * N + 64; }
+
+// A4 for ONE frame by one 256-thread workgroup.
+//   cx[N][J][3], cs[N][J]   candidate slots of this frame (global memory)
+//   keep                    global uint8[N] keep flags, or nullptr:
+//                             keep_in_lds == false -> every slot is a candidate
+//                             keep_in_lds == true  -> flags were left in the LDS `cluster_of` array
+//   f                       absolute frame index used for the outputs
+// Ends with a __syncthreads(), so the LDS can be reused right after it returns.
+template <typename Writer>
+__device__ __forceinline__ void condense_frame(int64_t f, int N, int J, const double *__restrict__ cx,
+                                               const double *__restrict__ cs,
+                                               const uint8_t *__restrict__ keep, bool keep_in_lds,
+                                               const Params &prm, int Pout, const Writer &wr,
+                                               int32_t *__restrict__ out_count,
+                                               uint32_t *__restrict__ out_flags, char *lds) {
+    int32_t *idx = reinterpret_cast<int32_t *>(lds);  // kept slots, reference list order
+    int32_t *cluster_of = idx + N;                    // cluster id per kept candidate, -1 = free
+    int32_t *csize = cluster_of + N;                  // members per cluster
+    int32_t *cseed = csize + N;                       // seed (kept index) per cluster
+    double *red = reinterpret_cast<double *>(cseed + N);
+    int32_t *misc = reinterpret_cast<int32_t *>(red + kBlock / 64);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int ci = prm.center, kn = prm.kn;
+
+    if (tid < 64) {
+        // ordered compaction of the kept slots (= the reference's candidate list)
+        int n = 0;
+        for (int base = 0; base < N; base += 64) {
+            const int k = base + lane;
+            bool kp = k < N;
+            if (kp && keep) kp = keep[k] != 0;
+            if (kp && !keep && keep_in_lds) kp = cluster_of[k] != 0;
+            const unsigned long long m = __ballot(kp);
+            if (kp) idx[n + __popcll(m & ((1ull << lane) - 1ull))] = k;
+            n += __popcll(m);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        for (int i = lane; i < n; i += 64) cluster_of[i] = -1;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        // greedy clustering, triangulation.py:107-130: seeds in list order, the last candidate
+        // never seeds, distance to the SEED's centre joint, `dist > tol` skips (NaN absorbs).
+        int ncl = 0;
+        for (int mc = 0; mc < n - 1; mc++) {
+            if (cluster_of[mc] != -1) continue;
+            const double *pm = cx + ((int64_t)idx[mc] * J + ci) * 3;
+            const double mx = pm[0], my = pm[1], mz = pm[2];
+            int cnt = 0;
+            for (int base = mc + 1; base < n; base += 64) {
+                const int sc = base + lane;
+                bool ab = false;
+                if (sc < n && cluster_of[sc] == -1) {
+                    const double *ps = cx + ((int64_t)idx[sc] * J + ci) * 3;
+                    const double dx = mx - ps[0], dy = my - ps[1], dz = mz - ps[2];
+                    const double dist = sqrt(fma(dz, dz, fma(dy, dy, dx * dx)));
+                    if (!(dist > prm.ctol)) {
+                        cluster_of[sc] = ncl;
+                        ab = true;
+                    }
+                }
+                cnt += __popcll(__ballot(ab));
+            }
+            if (lane == 0) {
+                cluster_of[mc] = ncl;
+                csize[ncl] = cnt + 1;
+                cseed[ncl] = mc;
+            }
+            ncl++;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        }
+        if (lane == 0) {
+            misc[0] = n;
+            misc[1] = ncl;
+        }
+    }
+    __syncthreads();
+    const int n = misc[0], ncl = misc[1];
+    int nout = 0;
+    for (int cid = 0; cid < ncl; cid++) {
+        const int size = csize[cid];
+        if ((double)size < prm.num_tol) continue;  // :132-134 (members stay absorbed)
+        const int seed = cseed[cid];
+        double jx[kCondenseMaxJointsPerThread], jy[kCondenseMaxJointsPerThread],
+            jz[kCondenseMaxJointsPerThread], js[kCondenseMaxJointsPerThread];
+        double part = 0.0;
+#pragma unroll
+        for (int r = 0; r < kCondenseMaxJointsPerThread; r++) {
+            const int b = tid + r * kBlock;
+            jx[r] = jy[r] = jz[r] = js[r] = 0.0;
+            if (b < kn) {
+                double sum = 0.0;  // :141
+                for (int i = seed; i < n; i++)
+                    if (cluster_of[i] == cid) sum += cs[(int64_t)idx[i] * J + b];
+                if (!(sum == 0.0)) {  // :142-143
+                    double x = 0.0, y = 0.0, z = 0.0;
+                    for (int i = seed; i < n; i++)
+                        if (cluster_of[i] == cid) {
+                            const int64_t o = (int64_t)idx[i] * J + b;
+                            const double w = cs[o] / sum;  // :144
+                            x = fma(cx[3 * o], w, x);      // :145-147
+                            y = fma(cx[3 * o + 1], w, y);
+                            z = fma(cx[3 * o + 2], w, z);
+                        }
+                    jx[r] = x;
+                    jy[r] = y;
+                    jz[r] = z;
+                    js[r] = sum / (double)size;  // :148
+                }
+                part += js[r];
+            }
+        }
+        const double avg = block_sum(part, red) / (double)kn;  // :150
+        if (avg < prm.score_tol) continue;                     // :151-152
+        if (nout < Pout) {
+#pragma unroll
+            for (int r = 0; r < kCondenseMaxJointsPerThread; r++) {
+                const int b = tid + r * kBlock;
+                if (b < kn) wr.joint(f, Pout, kn, nout, b, jx[r], jy[r], jz[r], js[r]);
+            }
+            if (tid == 0) wr.person(f, Pout, nout, avg);
+        }
+        nout++;
+    }
+    for (int slot = nout; slot < Pout; slot++) {  // deterministic padding
+        for (int b = tid; b < kn; b += kBlock) wr.joint(f, Pout, kn, slot, b, 0.0, 0.0, 0.0, 0.0);
+        if (tid == 0) wr.person(f, Pout, slot, 0.0);
+    }
+    if (tid == 0) {
+        out_count[f] = nout;
+        if (out_flags && nout > Pout) atomicOr(&out_flags[f], 2u /*SNOWTRI_FLAG_OVERFLOW*/);
+    }
+    __syncthreads();
+}
+
+// A4 over materialised candidates: one workgroup per frame (grid-stride).
+// Dynamic LDS: condense_lds_bytes(N).
+template <typename Writer>
+__global__ __launch_bounds__(kBlock) void k_condense(int64_t F, int N, int J,
+                                                     const double *__restrict__ cand_xyz,
+                                                     const double *__restrict__ cand_kscore,
+                                                     const uint8_t *__restrict__ cand_keep, Params prm,
+                                                     int Pout, Writer wr, int32_t *__restrict__ out_count,
+                                                     uint32_t *__restrict__ out_flags) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    for (int64_t f = blockIdx.x; f < F; f += gridDim.x)
+        condense_frame(f, N, J, cand_xyz + f * (int64_t)N * J * 3, cand_kscore + f * (int64_t)N * J,
+                       cand_keep ? cand_keep + f * (int64_t)N : nullptr, false, prm, Pout, wr, out_count,
+                       out_flags, smem);
+}
+
+}  // namespace snowtri

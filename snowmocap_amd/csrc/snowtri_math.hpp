@@ -1,0 +1,86 @@
+// snowtri_math.hpp -- device-side small linear algebra shared by every kernel.
+//
+// All arithmetic is fp64 (the reference is NumPy float64; an fp32 restatement misses the
+// 1e-4 m budget and gives meaningless scores -- SURVEY.md F5).  hipcc contracts a*b+c into
+// v_fma_f64, which only tightens rounding relative to the reference.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace snowtri {
+
+// Device copy of snowtri_params (include/snowtri.h), already validated on the host:
+// center is wrapped into [0, J), 0 <= kn <= J.
+struct Params {
+    double kthr, avg_thr, dthr;       // Human_Triangulation        (triangulation.py:50)
+    double ctol, num_tol, score_tol;  // Human_Triangulation_Condense (triangulation.py:95-100)
+    int32_t center, kn;
+};
+
+struct Vec3 {
+    double x, y, z;
+};
+
+__device__ __forceinline__ double dot3(const Vec3 &a, const Vec3 &b) {
+    return fma(a.z, b.z, fma(a.y, b.y, a.x * b.x));
+}
+
+// A1, camera.py:241-243: f = R . (inv(K) . [u, v, 1]) with M = R . inv(K) folded on the host.
+__device__ __forceinline__ Vec3 ray_from_pixel(const double *__restrict__ M, double u, double v) {
+    Vec3 h;
+    h.x = fma(M[0], u, fma(M[1], v, M[2]));
+    h.y = fma(M[3], u, fma(M[4], v, M[5]));
+    h.z = fma(M[6], u, fma(M[7], v, M[8]));
+    return h;
+}
+
+// (sm + ss) / 2 of triangulation.py:72.  When the caller handed float32 confidence arrays the
+// reference evaluates this in float32 (NumPy scalar arithmetic) -- reproduced by the overload.
+__device__ __forceinline__ double half_score(float sm, float ss) { return (double)((sm + ss) * 0.5f); }
+__device__ __forceinline__ double half_score(double sm, double ss) { return (sm + ss) * 0.5; }
+
+struct SkewOut {
+    Vec3 W;       // midpoint (Wm + Ws) / 2
+    double dist;  // ||Wm - Ws||
+    bool singular;
+};
+
+// A2, Skew_Ray_Solver (triangulation.py:24-31) in closed form:
+//   a = hm.hm, b = hm.hs, c = hs.hs, d = ts - tm, e = hm.d, f = hs.d, det = a c - b^2
+//   S0 = (c e - b f) / det,  S1 = (a f - b e) / det
+//   Wm = tm + hm S0,  Ws = ts - hs S1
+__device__ __forceinline__ SkewOut skew_ray_solve(const Vec3 &hm, const Vec3 &hs, const Vec3 &tm,
+                                                  const Vec3 &ts) {
+    const double a = dot3(hm, hm), b = dot3(hm, hs), c = dot3(hs, hs);
+    const double det = fma(a, c, -(b * b));
+    const Vec3 d = {ts.x - tm.x, ts.y - tm.y, ts.z - tm.z};
+    const double e = dot3(hm, d), f = dot3(hs, d);
+    const double inv = 1.0 / det;
+    const double S0 = fma(c, e, -(b * f)) * inv;
+    const double S1 = fma(a, f, -(b * e)) * inv;
+    const Vec3 Wm = {fma(hm.x, S0, tm.x), fma(hm.y, S0, tm.y), fma(hm.z, S0, tm.z)};
+    const Vec3 Ws = {fma(-hs.x, S1, ts.x), fma(-hs.y, S1, ts.y), fma(-hs.z, S1, ts.z)};
+    const Vec3 df = {Wm.x - Ws.x, Wm.y - Ws.y, Wm.z - Ws.z};
+    SkewOut o;
+    o.dist = sqrt(dot3(df, df));
+    o.W = {0.5 * (Wm.x + Ws.x), 0.5 * (Wm.y + Ws.y), 0.5 * (Wm.z + Ws.z)};
+    o.singular = (det == 0.0);
+    return o;
+}
+
+// triangulation.py:72-74: score = half / (dist * 1000), zeroed by the three gates (strict < and >,
+// so NaN operands leave the score untouched, exactly like the NumPy comparisons).
+template <typename TS>
+__device__ __forceinline__ double pair_score(TS sm, TS ss, double dist, const Params &p) {
+    double s = half_score(sm, ss) / (dist * 1000.0);
+    if ((double)sm < p.kthr || (double)ss < p.kthr || dist > p.dthr) s = 0.0;
+    return s;
+}
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+}  // namespace snowtri

@@ -1,0 +1,158 @@
+"""The reference's triangulation API (snowvision/triangulation.py) on the MI355X kernels.
+
+Same names, positional/keyword signatures, return schema and error behaviour as the reference:
+
+  Skew_Ray_Solver(hm, hs, tm, ts)                      triangulation.py:24-31   -> snowtri_skew_ray_batch
+  Human_Triangulation(camera_group, ...)               triangulation.py:50-93   -> snowtri_triangulate
+  Human_Triangulation_Condense(result, ...)            triangulation.py:95-162  -> snowtri_condense
+  Human_Triangulation_Smooth / SecondOrderDynamic      triangulation.py:4-22,164-186 (host shim, row N1)
+
+Every ★ function runs on the GPU through the C ABI; there is no NumPy fallback.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from . import _lib
+
+_KEYS = ("hrnet_triangulate_points", "hrnet_triangulate_keypoint_scores", "hrnet_triangulate_person_scores")
+
+
+def Skew_Ray_Solver(hm, hs, tm, ts):
+    """Closest approach of rays tm + a*hm and ts + b*hs -> (skew distance, midpoint[3])."""
+    L = _lib.lib()
+    ctx = _lib.scratch_context()
+    arrs = [np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(1, 3)) for x in (hm, hs, tm, ts)]
+    dist = np.empty(1)
+    W = np.empty((1, 3))
+    rc = L.snowtri_skew_ray_batch(ctx.handle, 1, *[_lib.ptr(a) for a in arrs], _lib.ptr(dist), _lib.ptr(W), None)
+    if rc == _lib.ERR_SINGULAR:
+        raise np.linalg.LinAlgError("Singular matrix")
+    _lib.check(rc, "snowtri_skew_ray_batch")
+    return np.float64(dist[0]), W[0].copy()
+
+
+def skew_ray_solver_batch(hm, hs, tm, ts):
+    """Additive batched form of Skew_Ray_Solver: [n,3] x4 -> dist[n], W[n,3], n_singular."""
+    L = _lib.lib()
+    ctx = _lib.scratch_context()
+    arrs = [np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1, 3)) for x in (hm, hs, tm, ts)]
+    n = arrs[0].shape[0]
+    dist = np.empty(n)
+    W = np.empty((n, 3))
+    import ctypes as ct
+    ns = ct.c_int64(0)
+    rc = L.snowtri_skew_ray_batch(ctx.handle, n, *[_lib.ptr(a) for a in arrs], _lib.ptr(dist), _lib.ptr(W),
+                                  ct.byref(ns))
+    if rc not in (_lib.OK, _lib.ERR_SINGULAR):
+        _lib.check(rc, "snowtri_skew_ray_batch")
+    return dist, W, int(ns.value)
+
+
+def Human_Triangulation(camera_group, keypoint_score_threshold=0.5, average_score_threshold=0.0,
+                        distance_threshold=0.05):
+    """All camera-pair x person-pair candidate skeletons of the current frame, scored and filtered
+    by their mean score; list order = the reference's loop order (triangulation.py:56-65)."""
+    L = _lib.lib()
+    ctx = camera_group.native_context()
+    kpts, n_persons = camera_group.pack_frame()
+    C, Pmax, J, _ = kpts.shape
+    Kc = int(L.snowtri_num_candidate_slots(C, Pmax))
+    result = {k: [] for k in _KEYS}
+    if Kc == 0 or not n_persons.any():
+        return result
+    prm = _lib.make_params(keypoint_score_threshold=keypoint_score_threshold,
+                           average_score_threshold=average_score_threshold,
+                           distance_threshold=distance_threshold)
+    xyz = np.empty((Kc, J, 3))
+    ks = np.empty((Kc, J))
+    ps = np.empty(Kc)
+    keep = np.empty(Kc, dtype=np.uint8)
+    rc = L.snowtri_triangulate(ctx.handle, 1, Pmax, J, _lib.ptr(kpts), _lib.dtype_code(kpts.dtype),
+                               _lib.ptr(n_persons), prm, _lib.ptr(xyz), _lib.ptr(ks), _lib.ptr(ps),
+                               _lib.ptr(keep), _lib.HOST, None)
+    if rc == _lib.ERR_SINGULAR:
+        raise np.linalg.LinAlgError("Singular matrix")      # np.linalg.inv at triangulation.py:26
+    _lib.check(rc, "snowtri_triangulate")
+    for k in np.nonzero(keep)[0]:
+        result[_KEYS[0]].append(xyz[k].copy())
+        result[_KEYS[1]].append(ks[k].copy())
+        result[_KEYS[2]].append(np.float64(ps[k]))
+    return result
+
+
+def Human_Triangulation_Condense(result, condense_distance_tol=0.1, condense_person_num_tol=0,
+                                 condense_score_tol=0.0, center_point_index=18, keypoint_num=30):
+    """Greedy centre-joint clustering of the candidates + score-weighted fusion per joint."""
+    points = result[_KEYS[0]]
+    scores = result[_KEYS[1]]
+    out = {k: [] for k in _KEYS}
+    n = len(points)
+    if n - 1 <= 0:                 # range(person_num - 1) is empty: nothing is ever emitted
+        return out
+    L = _lib.lib()
+    ctx = _lib.scratch_context()
+    cxyz = np.ascontiguousarray(np.stack([np.asarray(p, dtype=np.float64) for p in points]))
+    cks = np.ascontiguousarray(np.stack([np.asarray(s, dtype=np.float64) for s in scores]))
+    J = cxyz.shape[1]
+    prm = _lib.make_params(condense_distance_tol=condense_distance_tol,
+                           condense_person_num_tol=condense_person_num_tol,
+                           condense_score_tol=condense_score_tol,
+                           center_point_index=center_point_index, keypoint_num=keypoint_num)
+    kn = int(keypoint_num)
+    pout = n                        # at most n - 1 clusters
+    oxyz = np.empty((pout, max(kn, 0), 3))
+    oks = np.empty((pout, max(kn, 0)))
+    ops = np.empty(pout)
+    cnt = np.zeros(1, dtype=np.int32)
+    rc = L.snowtri_condense(ctx.handle, 1, n, J, _lib.ptr(cxyz), _lib.ptr(cks), None, prm, pout,
+                            _lib.ptr(oxyz), _lib.ptr(oks), _lib.ptr(ops), _lib.ptr(cnt), None, _lib.HOST, None)
+    if rc == _lib.ERR_BAD_INDEX:
+        raise IndexError("index out of bounds (center_point_index / keypoint_num vs. joints per candidate)")
+    _lib.check(rc, "snowtri_condense")
+    for i in range(int(cnt[0])):
+        out[_KEYS[0]].append(oxyz[i].copy())
+        out[_KEYS[1]].append(oks[i].copy())
+        out[_KEYS[2]].append(np.float64(ops[i]))
+    return out
+
+
+class SecondOrderDynamic:
+    """Second-order low-pass (semi-implicit Euler), triangulation.py:4-22: state (xp, y, yd),
+    gains k1 = z/(pi f), k2 = 1/(2 pi f)^2, k3 = r z/(2 pi f)."""
+
+    def __init__(self, f, z, r, x0):
+        w = 2.0 * math.pi * f
+        self.k1 = z / (math.pi * f)
+        self.k2 = 1.0 / (w * w)
+        self.k3 = r * z / w
+        self.xp = x0
+        self.y = x0
+        self.yd = 0
+
+    def update(self, T, x, xd=None):
+        if xd is None:
+            xd = (x - self.xp) / T
+            self.xp = x
+        self.y = self.y + T * self.yd
+        self.yd = self.yd + T * (x + self.k3 * xd - self.y - self.k1 * self.yd) / self.k2
+        return self.y
+
+
+def Human_Triangulation_Smooth(result, previous_result=None, f=2, z=0.75, r=0, delta_time=1 / 30):
+    """Per-joint temporal filter carried from frame to frame inside the result dict
+    (triangulation.py:164-186).  Persons are matched by list index; the first frame passes through
+    and seeds one SecondOrderDynamic per joint."""
+    out = {_KEYS[1]: result[_KEYS[1]], _KEYS[2]: result[_KEYS[2]]}
+    if isinstance(previous_result, dict):
+        filters = previous_result["second_order_dynamics"]
+        out[_KEYS[0]] = [[flt.update(delta_time, joint) for joint, flt in zip(person, bank)]
+                         for person, bank in zip(result[_KEYS[0]], filters)]
+        out["second_order_dynamics"] = filters
+    else:
+        out[_KEYS[0]] = result[_KEYS[0]]
+        out["second_order_dynamics"] = [[SecondOrderDynamic(f, z, r, joint) for joint in person]
+                                        for person in result[_KEYS[0]]]
+    return out

@@ -1,0 +1,117 @@
+"""CPU-side checks (no GPU): the C-ABI library loads and exports every symbol the header declares,
+the host-side mirror behaves like the reference where no kernel is involved, and the product
+package never reaches into oracle/."""
+import ctypes as ct
+import os
+import re
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, GOLDEN
+from snowmocap_amd import _lib, synth
+from snowmocap_amd.camera import CameraGroup
+from snowmocap_amd.triangulation import SecondOrderDynamic, Human_Triangulation_Smooth, Human_Triangulation_Condense
+from snowmocap_amd.util import Check_If_File_Exist, Load_Config_Json
+
+
+def _header_functions():
+    src = open(os.path.join(ROOT, "include", "snowtri.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(snowtri_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol():
+    names = _header_functions()
+    assert len(names) >= 15
+    assert names == _lib.exported_symbols()          # binding and header agree
+    handle = ct.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(handle, n), f"libsnowtri.so does not export {n}"
+    assert _lib.lib().snowtri_version() == 100
+    assert _lib.lib().snowtri_status_string(_lib.ERR_SINGULAR).decode().startswith("singular")
+    assert _lib.lib().snowtri_num_candidate_slots(4, 1) == 6
+    assert _lib.lib().snowtri_num_candidate_slots(16, 8) == 7680
+
+
+def test_params_struct_layout_matches_header():
+    assert ct.sizeof(_lib.Params) == 6 * 8 + 2 * 4
+    p = _lib.make_params()
+    assert (p.keypoint_score_threshold, p.distance_threshold, p.center_point_index, p.keypoint_num) == (0.5, 0.05, 18, 30)
+    assert p.condense_distance_tol == 0.1     # reference signature defaults, triangulation.py:95-100
+
+
+@pytest.mark.skipif(_lib.lib().snowtri_device_count() > 0, reason="GPU present")
+def test_no_device_is_reported_not_faked():
+    K, R, t = synth.load_rig_json()
+    with pytest.raises(_lib.SnowtriError) as ei:
+        _lib.Context(K, R, t)
+    assert ei.value.status == _lib.ERR_NO_DEVICE
+
+
+def test_product_package_never_imports_the_oracle():
+    pkg = os.path.join(ROOT, "snowmocap_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for fn in files:
+            if fn.endswith((".py", ".hip", ".hpp", ".h", ".cpp")):
+                text = open(os.path.join(dirpath, fn)).read()
+                assert "import oracle" not in text and "from oracle" not in text, fn
+
+
+def test_pack_frame_layout_and_dtype():
+    cg = CameraGroup(camera_group_info_path=synth.FLOOR_RIG_PATH)
+    assert cg.camera_num == 4 and cg.cameras[0].t.shape == (3, 1)
+    rng = np.random.default_rng(0)
+    a = rng.uniform(0, 1000, (133, 2)).astype(np.float32)
+    s = rng.uniform(0, 8, 133).astype(np.float32)
+    cg.add_human_2D_points(a, s, 0)
+    cg.add_human_2D_points(a + 1, s, 2)
+    cg.add_human_2D_points(a + 2, s, 2)
+    kpts, n = cg.pack_frame()
+    assert kpts.dtype == np.float32 and kpts.shape == (4, 2, 133, 3)
+    assert n.tolist() == [1, 0, 2, 0]
+    assert np.array_equal(kpts[2, 1, :, :2], a + 2) and np.array_equal(kpts[0, 0, :, 2], s)
+    cg.add_human_2D_points(a.astype(np.float64), s, 1)      # one float64 array promotes the frame
+    assert cg.pack_frame()[0].dtype == np.float64
+    cg.clear_2D_points()
+    assert cg.pack_frame()[1].tolist() == [0, 0, 0, 0]
+    K, R, t = cg.rig_arrays()
+    K0, R0, t0 = synth.load_rig_json()
+    assert np.array_equal(K, K0) and np.array_equal(R, R0) and np.array_equal(t, t0)
+
+
+def test_condense_with_fewer_than_two_candidates_is_empty_without_gpu():
+    # triangulation.py:107: range(person_num - 1) is empty -> no kernel is needed, nothing emitted
+    res = {"hrnet_triangulate_points": [np.zeros((5, 3))], "hrnet_triangulate_keypoint_scores": [np.ones(5)],
+           "hrnet_triangulate_person_scores": [1.0]}
+    out = Human_Triangulation_Condense(res, center_point_index=99)
+    assert out["hrnet_triangulate_points"] == []
+
+
+def test_second_order_dynamic_matches_reference_track():
+    """N1 host shim against the reference's own smoothed trajectory (fixture G6)."""
+    z = np.load(os.path.join(GOLDEN, "g6_smooth_blender.npz"))
+    track, want = z["track"], z["smoothed"]
+    prev = None
+    for k in range(track.shape[0]):
+        res = {"hrnet_triangulate_points": [track[k, p] for p in range(track.shape[1])],
+               "hrnet_triangulate_keypoint_scores": [None] * track.shape[1],
+               "hrnet_triangulate_person_scores": [None] * track.shape[1]}
+        res = Human_Triangulation_Smooth(res, prev, f=float(z["f"]), z=float(z["z"]), r=float(z["r"]),
+                                         delta_time=float(z["dt"]))
+        prev = res
+        got = np.array([np.array(p) for p in res["hrnet_triangulate_points"]])
+        np.testing.assert_allclose(got, want[k], rtol=0, atol=1e-13)
+    sod = SecondOrderDynamic(2.0, 0.75, 0.0, np.zeros(3))
+    assert sod.k2 == pytest.approx(1.0 / (4 * np.pi * 2.0) ** 2 * 4)   # 1/(2 pi f)^2
+
+
+def test_util_helpers(tmp_path):
+    p = tmp_path / "out.json"
+    assert Check_If_File_Exist(str(p)) == (False, str(p))
+    p.write_text("{\"a\": 1}")
+    assert Load_Config_Json(str(p)) == {"a": 1}
+    exists, alt = Check_If_File_Exist(str(p))
+    assert alt.endswith("out_0.json") and exists is False
+    (tmp_path / "out_0.json").write_text("{}")
+    assert Check_If_File_Exist(str(p))[1].endswith("out_1.json")
