@@ -144,7 +144,9 @@ int snowtri_triangulate_condense(snowtri_ctx *ctx, int64_t F, int32_t Pmax, int3
 int snowtri_last_kernel_ms(snowtri_ctx *ctx, float kernel_ms[2]);
 /* Toggle per-call event timing (off by default: it adds two event records per launch). */
 int snowtri_set_timing(snowtri_ctx *ctx, int enabled);
-/* Number of frames the last fused call had to route through the general (multi-cluster) kernels. */
+/* Frames of the last SNOWTRI_HOST fused call that were resolved by the general routine instead of
+ * the single-cluster fast path (-1 after a SNOWTRI_DEVICE call: count the frames whose out_flags
+ * lack SNOWTRI_FLAG_FASTPATH instead). */
 int64_t snowtri_last_slow_frames(snowtri_ctx *ctx);
 
 #ifdef __cplusplus

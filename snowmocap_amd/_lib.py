@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libsnowtri.so")
+LIB_PATH = os.environ.get("SNOWTRI_LIB") or os.path.join(_HERE, "libsnowtri.so")   # override: A/B builds
 
 OK, ERR_BAD_ARG, ERR_BAD_INDEX, ERR_HIP, ERR_SINGULAR, ERR_OVERFLOW, ERR_NO_DEVICE = range(7)
 F32, F64 = 0, 1
@@ -95,6 +95,15 @@ def lib():
             raise ImportError(
                 f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  snowmocap_amd has no CPU fallback.")
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (same SONAME as
+        # /opt/rocm's).  Loading it FIRST makes the dynamic linker bind libsnowtri.so to that copy,
+        # so torch streams / device pointers and our kernels share one runtime.  Loading ours first
+        # would leave torch with a second runtime that sees no GPU.
+        if os.environ.get("SNOWTRI_NO_TORCH", "0") != "1":
+            try:
+                import torch  # noqa: F401
+            except Exception:
+                pass
         handle = ct.CDLL(LIB_PATH)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(handle, name)      # AttributeError if the ABI lost a symbol

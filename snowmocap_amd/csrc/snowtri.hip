@@ -89,7 +89,7 @@ struct snowtri_ctx {
     int num_cus = 256;
     std::vector<double> hM, ht;
     std::vector<int32_t> hpairs;
-    double *dM = nullptr, *dt = nullptr;
+    double *dM = nullptr, *dt = nullptr, *dpairc = nullptr;
     int32_t *dpairs = nullptr;
     unsigned long long *d_counters = nullptr;  // [0] singular pairs, [1] slow frames, [2..] spare
     Scratch in, out, work, misc;
@@ -99,7 +99,7 @@ struct snowtri_ctx {
     bool ev_valid = false;
     hipStream_t ev_stream = nullptr;
     int64_t last_slow_frames = 0;
-    Rig rig() const { return Rig{dM, dt, dpairs, C, npairs}; }
+    Rig rig() const { return Rig{dM, dt, dpairs, dpairc, C, npairs}; }
 };
 
 extern "C" {
@@ -155,6 +155,14 @@ int snowtri_ctx_create(int32_t C, const double *K, const double *R, const double
             ctx->hpairs.push_back(sc);
         }
     ctx->npairs = (int32_t)(ctx->hpairs.size() / 2);
+    std::vector<double> hpairc((size_t)ctx->npairs * 6);
+    for (int q = 0; q < ctx->npairs; q++) {
+        const double *tm = &ctx->ht[3 * ctx->hpairs[2 * q]], *ts = &ctx->ht[3 * ctx->hpairs[2 * q + 1]];
+        for (int i = 0; i < 3; i++) {
+            hpairc[6 * q + i] = ts[i] - tm[i];
+            hpairc[6 * q + 3 + i] = tm[i] + ts[i];
+        }
+    }
     auto fail = [&](int rc) {
         snowtri_ctx_destroy(ctx);
         return rc;
@@ -174,6 +182,9 @@ int snowtri_ctx_create(int32_t C, const double *K, const double *R, const double
     CTX_TRY(hipMalloc(&ctx->dt, sizeof(double) * std::max<size_t>(3, ctx->ht.size())));
     CTX_TRY(hipMalloc(&ctx->dpairs, sizeof(int32_t) * std::max<size_t>(2, ctx->hpairs.size())));
     CTX_TRY(hipMalloc(&ctx->d_counters, sizeof(unsigned long long) * 8));
+    CTX_TRY(hipMalloc(&ctx->dpairc, sizeof(double) * std::max<size_t>(6, hpairc.size())));
+    if (ctx->npairs > 0)
+        CTX_TRY(hipMemcpy(ctx->dpairc, hpairc.data(), sizeof(double) * hpairc.size(), hipMemcpyHostToDevice));
     if (C > 0) {
         CTX_TRY(hipMemcpy(ctx->dM, ctx->hM.data(), sizeof(double) * ctx->hM.size(), hipMemcpyHostToDevice));
         CTX_TRY(hipMemcpy(ctx->dt, ctx->ht.data(), sizeof(double) * ctx->ht.size(), hipMemcpyHostToDevice));
@@ -194,6 +205,7 @@ int snowtri_ctx_destroy(snowtri_ctx *ctx) {
     if (ctx->dM) (void)hipFree(ctx->dM);
     if (ctx->dt) (void)hipFree(ctx->dt);
     if (ctx->dpairs) (void)hipFree(ctx->dpairs);
+    if (ctx->dpairc) (void)hipFree(ctx->dpairc);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     ctx->in.release();
     ctx->out.release();
@@ -528,7 +540,7 @@ int launch_fused_single(snowtri_ctx *ctx, hipStream_t st, int64_t F, int J, cons
     if (lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, st, F, J, T, ctx->rig(), d_kpts, d_np, prm, Pout,
-                       d_xyzs, d_ps, d_cnt, d_fl, ctx->d_counters, (char *)ctx->work.p, per_block);
+                       d_xyzs, d_ps, d_cnt, d_fl, (char *)ctx->work.p, per_block);
     HIP_TRY(hipGetLastError());
     return SNOWTRI_OK;
 }
@@ -646,8 +658,8 @@ extern "C" int snowtri_triangulate_condense(snowtri_ctx *ctx, int64_t F, int32_t
         if (rc) return rc;
         d_fl = (uint32_t *)ctx->misc.p;
     }
-    HIP_TRY(hipMemsetAsync(d_fl, 0, sizeof(uint32_t) * F, st));
-    HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long) * 2, st));
+    // no memsets: the kernels own every output word, including the per-frame flags
+    ctx->last_slow_frames = -1;
     if (in_dtype == SNOWTRI_F32 && out_dtype == SNOWTRI_F32)
         rc = fused_dispatch<float, float>(ctx, st, F, Pmax, J, d_kpts, d_np, prm, Pout_max, d_xyzs, d_ps, d_cnt, d_fl);
     else if (in_dtype == SNOWTRI_F32)
@@ -668,12 +680,14 @@ extern "C" int snowtri_triangulate_condense(snowtri_ctx *ctx, int64_t F, int32_t
             fl = fl_host.data();
         }
         HIP_TRY(hipMemcpyAsync(fl, d_fl, sizeof(uint32_t) * F, hipMemcpyDeviceToHost, st));
-        unsigned long long ctr[2] = {0, 0};
-        HIP_TRY(hipMemcpyAsync(ctr, ctx->d_counters, sizeof(ctr), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
-        ctx->last_slow_frames = (int64_t)ctr[1];
         uint32_t any = 0;
-        for (int64_t f = 0; f < F; f++) any |= fl[f];
+        int64_t slow = 0;
+        for (int64_t f = 0; f < F; f++) {
+            any |= fl[f];
+            slow += (fl[f] & SNOWTRI_FLAG_FASTPATH) ? 0 : 1;
+        }
+        ctx->last_slow_frames = slow;
         if (any & SNOWTRI_FLAG_SINGULAR) return SNOWTRI_ERR_SINGULAR;
         if (any & SNOWTRI_FLAG_OVERFLOW) return SNOWTRI_ERR_OVERFLOW;
     }

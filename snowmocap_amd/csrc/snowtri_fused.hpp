@@ -35,6 +35,7 @@ __device__ __forceinline__ void general_frame(int64_t f, int Pmax, int J, int Kc
     int32_t *keep_lds = reinterpret_cast<int32_t *>(lds) + Kc;  // = condense_frame's cluster_of
     const int pp = Pmax * Pmax;
     const int32_t *np_f = n_persons ? n_persons + f * rig.C : nullptr;
+    if (tid == 0 && out_flags) out_flags[f] = 0u;  // this routine owns the frame's flag word
     // A1 + A3 per (slot, joint): triangulation.py:56-78
     bool sing = false;
     for (int i = tid; i < Kc * J; i += kBlock) {
@@ -58,8 +59,8 @@ __device__ __forceinline__ void general_frame(int64_t f, int Pmax, int J, int Kc
         cxyz[3 * i + 2] = o.W.z;
         cks[i] = pair_score(sm, ss, o.dist, prm);
     }
-    if (sing && out_flags) atomicOr(&out_flags[f], kFlagSingular);
     __syncthreads();
+    if (sing && out_flags) atomicOr(&out_flags[f], kFlagSingular);
     // A3 candidate means (triangulation.py:79-81): one wave per slot, flags parked in LDS
     for (int k = wave; k < Kc; k += kBlock / 64) {
         const int q = k / pp, r = k - q * pp, pm = r / Pmax, ps = r - pm * Pmax;
@@ -104,32 +105,38 @@ __global__ __launch_bounds__(kBlock) void k_frame_general(int64_t F, int Pmax, i
 //   and every candidate is kept; NaN means are kept by the reference as well);
 //   every candidate's centre joint lies within condense_distance_tol of candidate 0's
 //   (seed 0 then absorbs all: one cluster);  the fused mean score is not below condense_score_tol.
+// Minimum waves per SIMD the fast kernel is compiled for (caps its VGPR allocation: 4 -> 128).
+#ifndef SNOWTRI_FAST_WAVES
+#define SNOWTRI_FAST_WAVES 4
+#endif
+
 template <typename T>
 struct Vec4T {
     T x, y, z, w;
 };
 
+template <typename T>
+struct Kp3 {  // one detected keypoint as stored in kpts: (u, v, score)
+    T u, v, s;
+};
+
 template <int C, typename TIn, typename TOut>
-__global__ __launch_bounds__(kBlock) void k_fused_single(int64_t F, int J, int T, Rig rig,
+__global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_single(int64_t F, int J, int T, Rig rig,
                                                          const TIn *__restrict__ kpts,
                                                          const int32_t *__restrict__ n_persons, Params prm,
                                                          int Pout, TOut *__restrict__ out4,
                                                          TOut *__restrict__ out_ps,
                                                          int32_t *__restrict__ out_count,
-                                                         uint32_t *__restrict__ out_flags,
-                                                         unsigned long long *counters, char *scratch,
+                                                         uint32_t *__restrict__ out_flags, char *scratch,
                                                          size_t scratch_per_block) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NP = C * (C - 1) / 2;
     const int kn = prm.kn, ci = prm.center;
-    double *stash = reinterpret_cast<double *>(smem);           // [T][kn] fused joint scores
+    double *stash = reinterpret_cast<double *>(smem);                        // [T][kn] fused joint scores
     uint32_t *fflag = reinterpret_cast<uint32_t *>(stash + (size_t)T * kn);  // [T]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const PackedWriter<TOut> wr{out4, out_ps};
-
-    // Rig constants (M[C][9], t[C][3]) are wave-uniform: they are fetched with scalar loads INSIDE
-    // the item loop (pointer laundered so the loads cannot be hoisted) -- hoisting them keeps
-    // 48 doubles live across the whole loop and costs ~100 VGPRs.
+    const Kp3<TIn> *kp3 = reinterpret_cast<const Kp3<TIn> *>(kpts);
     const double inv_np = 1.0 / (double)NP;
     const int dfl = kBlock / J, dj = kBlock - dfl * J;
     const int64_t ntiles = (F + T - 1) / T;
@@ -140,73 +147,93 @@ __global__ __launch_bounds__(kBlock) void k_fused_single(int64_t F, int J, int T
         const int nitems = nf * J;
         for (int i = tid; i < nf; i += kBlock) fflag[i] = 0;
         __syncthreads();
+
+        // ---- main loop: one lane per (frame, joint); the next item's keypoints are in flight
+        //      while the current one is solved.
         int fl = tid / J, j = tid - fl * J;
-        for (int it = tid; it < nitems; it += kBlock) {
-            const int64_t f = f0 + fl;
-            const TIn *kp = kpts + ((f * C) * (int64_t)J + j) * 3;
-            const double *Mp = rig.M, *tp = rig.t;
-            asm volatile("" : "+s"(Mp), "+s"(tp));
-            Vec3 tc[C];
+        Kp3<TIn> cur[C], nxt[C];
+        if (tid < nitems) {
+            const Kp3<TIn> *p = kp3 + ((f0 + fl) * C) * (int64_t)J + j;
 #pragma unroll
-            for (int c = 0; c < C; c++) tc[c] = {tp[3 * c], tp[3 * c + 1], tp[3 * c + 2]};
+            for (int c = 0; c < C; c++) cur[c] = p[(size_t)c * J];
+        }
+        for (int it = tid; it < nitems; it += kBlock) {
+            int fl2 = fl + dfl, j2 = j + dj;
+            if (j2 >= J) {
+                j2 -= J;
+                fl2++;
+            }
+            if (it + kBlock < nitems) {
+                const Kp3<TIn> *p = kp3 + ((f0 + fl2) * C) * (int64_t)J + j2;
+#pragma unroll
+                for (int c = 0; c < C; c++) nxt[c] = p[(size_t)c * J];
+            }
+            // Rig constants are wave-uniform: scalar loads issued INSIDE the loop (pointers laundered
+            // so they are not hoisted: 66 live doubles would cost ~130 registers).
+            typedef const __attribute__((address_space(4))) double *cptr;  // AMDGPU constant space
+            cptr Mp = (cptr)(uintptr_t)rig.M, pc = (cptr)(uintptr_t)rig.pairc;
+            asm volatile("" : "+s"(Mp), "+s"(pc));
             Vec3 h[C];
             double a[C];
-            TIn s[C];
+            bool pass[C];
 #pragma unroll
             for (int c = 0; c < C; c++) {
-                const TIn u = kp[(size_t)c * J * 3], v = kp[(size_t)c * J * 3 + 1];
-                s[c] = kp[(size_t)c * J * 3 + 2];
-                h[c] = ray_from_pixel(Mp + 9 * c, (double)u, (double)v);
+                {  // A1, camera.py:241-243 with M = R inv(K)
+                    const double u = (double)cur[c].u, v = (double)cur[c].v;
+                    h[c].x = fma(Mp[9 * c + 0], u, fma(Mp[9 * c + 1], v, Mp[9 * c + 2]));
+                    h[c].y = fma(Mp[9 * c + 3], u, fma(Mp[9 * c + 4], v, Mp[9 * c + 5]));
+                    h[c].z = fma(Mp[9 * c + 6], u, fma(Mp[9 * c + 7], v, Mp[9 * c + 8]));
+                }
                 a[c] = dot3(h[c], h[c]);
+                pass[c] = !((double)cur[c].s < prm.kthr);  // :73
             }
-            const bool want_centre = __ballot(j == ci) != 0ull;  // wave-uniform
             double accS = 0.0, accX = 0.0, accY = 0.0, accZ = 0.0;
-            Vec3 W0 = {0.0, 0.0, 0.0};
             bool bad = false, sing = false;
             int q = 0;
 #pragma unroll
             for (int mc = 0; mc < C - 1; mc++) {
 #pragma unroll
                 for (int sc = mc + 1; sc < C; sc++, q++) {
-                    // A2 with the per-ray norms hoisted (triangulation.py:24-31)
+                    // A2 (triangulation.py:24-31), per-ray norms hoisted, d = ts - tm and tm + ts constant
                     const Vec3 &hm = h[mc], &hs = h[sc];
+                    const Vec3 d = {pc[6 * q], pc[6 * q + 1], pc[6 * q + 2]};
+                    const Vec3 tsum = {pc[6 * q + 3], pc[6 * q + 4], pc[6 * q + 5]};
                     const double b = dot3(hm, hs);
                     const double det = fma(a[mc], a[sc], -(b * b));
-                    const Vec3 d = {tc[sc].x - tc[mc].x, tc[sc].y - tc[mc].y, tc[sc].z - tc[mc].z};
                     const double e = dot3(hm, d), g = dot3(hs, d);
-                    const double inv = 1.0 / det;
+                    const double inv = rcp_nr2(det);
                     const double S0 = fma(a[sc], e, -(b * g)) * inv;
                     const double S1 = fma(a[mc], g, -(b * e)) * inv;
-                    const Vec3 Wm = {fma(hm.x, S0, tc[mc].x), fma(hm.y, S0, tc[mc].y), fma(hm.z, S0, tc[mc].z)};
-                    const Vec3 Ws = {fma(-hs.x, S1, tc[sc].x), fma(-hs.y, S1, tc[sc].y), fma(-hs.z, S1, tc[sc].z)};
-                    const Vec3 df = {Wm.x - Ws.x, Wm.y - Ws.y, Wm.z - Ws.z};
-                    const double dist = sqrt(dot3(df, df));
-                    const Vec3 W = {0.5 * (Wm.x + Ws.x), 0.5 * (Wm.y + Ws.y), 0.5 * (Wm.z + Ws.z)};
-                    const double sq = pair_score(s[mc], s[sc], dist, prm);  // :72-74
+                    // Wm - Ws = hm S0 + hs S1 - d ;  Wm + Ws = (tm + ts) + hm S0 - hs S1
+                    const Vec3 df = {fma(hs.x, S1, fma(hm.x, S0, -d.x)), fma(hs.y, S1, fma(hm.y, S0, -d.y)),
+                                     fma(hs.z, S1, fma(hm.z, S0, -d.z))};
+                    const Vec3 sw = {fma(-hs.x, S1, fma(hm.x, S0, tsum.x)), fma(-hs.y, S1, fma(hm.y, S0, tsum.y)),
+                                     fma(-hs.z, S1, fma(hm.z, S0, tsum.z))};
+                    const double d2 = dot3(df, df);
+                    double idist = rsq_nr1(d2);
+                    idist = (d2 == 0.0) ? __builtin_inf() : idist;  // exact intersection: score = half / 0
+                    const double dist = d2 * idist;
+                    double sq = half_score(cur[mc].s, cur[sc].s) * (idist * 0.001);  // :72
+                    const bool keep = pass[mc] & pass[sc] & !(dist > prm.dthr);      // :73-74
+                    sq = keep ? sq : 0.0;
                     sing |= (det == 0.0);
                     bad |= (sq < 0.0);
-                    accS += sq;  // fusion, :141-147, as (sum s W) / (sum s)
-                    accX = fma(sq, W.x, accX);
-                    accY = fma(sq, W.y, accY);
-                    accZ = fma(sq, W.z, accZ);
-                    if (q == 0) {
-                        W0 = W;
-                    } else if (want_centre) {
-                        const double dx = W0.x - W.x, dy = W0.y - W.y, dz = W0.z - W.z;
-                        const double cd = sqrt(fma(dz, dz, fma(dy, dy, dx * dx)));  // :124
-                        bad |= (j == ci) && (cd > prm.ctol);                          // :125
-                    }
+                    accS += sq;  // fusion :141-147 as (sum s (Wm+Ws)) / (2 sum s)
+                    accX = fma(sq, sw.x, accX);
+                    accY = fma(sq, sw.y, accY);
+                    accZ = fma(sq, sw.z, accZ);
                 }
             }
             double ox = 0.0, oy = 0.0, oz = 0.0, os = 0.0;
             if (!(accS == 0.0)) {  // :142-143
-                const double r = 1.0 / accS;
+                const double r = 0.5 * rcp_nr1(accS);
                 ox = accX * r;
                 oy = accY * r;
                 oz = accZ * r;
                 os = accS * inv_np;  // :148
             }
             if (j < kn) {
+                const int64_t f = f0 + fl;
                 Vec4T<TOut> o4 = {(TOut)ox, (TOut)oy, (TOut)oz, (TOut)os};
                 *reinterpret_cast<Vec4T<TOut> *>(out4 + ((f * Pout) * (int64_t)kn + j) * 4) = o4;
                 for (int slot = 1; slot < Pout; slot++) {
@@ -215,16 +242,38 @@ __global__ __launch_bounds__(kBlock) void k_fused_single(int64_t F, int J, int T
                 }
                 stash[fl * kn + j] = os;
             }
-            if (bad | sing) atomicOr(&fflag[fl], kSlow | (sing ? kFlagSingular : 0u));
-            fl += dfl;
-            j += dj;
-            if (j >= J) {
-                j -= J;
-                fl++;
+            if (bad | sing) atomicOr(&fflag[fl], kSlow);
+#pragma unroll
+            for (int c = 0; c < C; c++) cur[c] = nxt[c];
+            fl = fl2;
+            j = j2;
+        }
+
+        // ---- single-cluster check (:116-130): candidate q >= 1 must have its centre joint within
+        //      condense_distance_tol of candidate 0's.  One lane per (frame, q); ~1 % of the work.
+        for (int i = tid; i < nf * (NP - 1); i += kBlock) {
+            const int w = i / (NP - 1), qq = 1 + (i - w * (NP - 1));
+            const int64_t f = f0 + w;
+            const Kp3<TIn> *p = kp3 + (f * C) * (int64_t)J + ci;
+            Vec3 Wc[2];
+#pragma unroll 1
+            for (int k = 0; k < 2; k++) {
+                const int qk = k == 0 ? 0 : qq;
+                const int mc = rig.pairs[2 * qk], sc = rig.pairs[2 * qk + 1];
+                const Kp3<TIn> km = p[(size_t)mc * J], ks = p[(size_t)sc * J];
+                const Vec3 hm = ray_from_pixel(rig.M + 9 * mc, (double)km.u, (double)km.v);
+                const Vec3 hs = ray_from_pixel(rig.M + 9 * sc, (double)ks.u, (double)ks.v);
+                const Vec3 tm = {rig.t[3 * mc], rig.t[3 * mc + 1], rig.t[3 * mc + 2]};
+                const Vec3 ts = {rig.t[3 * sc], rig.t[3 * sc + 1], rig.t[3 * sc + 2]};
+                Wc[k] = skew_ray_solve(hm, hs, tm, ts).W;
             }
+            const double dx = Wc[0].x - Wc[1].x, dy = Wc[0].y - Wc[1].y, dz = Wc[0].z - Wc[1].z;
+            const double cd = sqrt(fma(dz, dz, fma(dy, dy, dx * dx)));  // :124
+            if (cd > prm.ctol) atomicOr(&fflag[w], kSlow);                // :125
         }
         __syncthreads();
-        // per-frame epilogue: mean fused score (:150), filters, count; one wave per frame
+
+        // ---- per-frame epilogue: mean fused score (:150), filters, count; one wave per frame
         for (int w = wave; w < nf; w += kBlock / 64) {
             const int64_t f = f0 + w;
             double sum = 0.0;
@@ -250,14 +299,13 @@ __global__ __launch_bounds__(kBlock) void k_fused_single(int64_t F, int J, int T
             }
         }
         __syncthreads();
-        // rare: frames the speculation could not resolve -> the reference's full algorithm
+        // ---- rare: frames the speculation could not resolve -> the reference's full algorithm
         unsigned long long slow_mask = 0ull;
         for (int w = 0; w < nf; w++)
             if (fflag[w] & kSlow) slow_mask |= 1ull << w;
         __syncthreads();
         if (slow_mask) {
             double *slab = reinterpret_cast<double *>(scratch + (size_t)blockIdx.x * scratch_per_block);
-            if (tid == 0) atomicAdd(&counters[1], (unsigned long long)__popcll(slow_mask));
             while (slow_mask) {
                 const int w = __ffsll((long long)slow_mask) - 1;
                 slow_mask &= slow_mask - 1ull;

@@ -46,6 +46,7 @@ struct Rig {
     const double *M;
     const double *t;
     const int32_t *pairs;
+    const double *pairc;  // [npairs][6]: d = t_sc - t_mc, tsum = t_mc + t_sc (host-precomputed)
     int32_t C, npairs;
 };
 

@@ -77,6 +77,27 @@ __device__ __forceinline__ double pair_score(TS sm, TS ss, double dist, const Pa
     return s;
 }
 
+// ---- fast reciprocal / reciprocal square root for the fused fast path ------------------------
+// v_rcp_f64 / v_rsq_f64 deliver ~2^-23 relative accuracy; each Newton step squares the error.
+//   rcp_nr2 : two steps  -> ~1 ulp            (used for 1/det: feeds the 3D point)
+//   rcp_nr1 : one step   -> ~2^-46 (1.4e-14)  (used for 1/sum(score): 1e-13 m on a 5 m coordinate)
+//   rsq_nr1 : one step   -> ~2e-14            (used for 1/dist: only scales the score)
+__device__ __forceinline__ double rcp_nr2(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+__device__ __forceinline__ double rcp_nr1(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    return fma(fma(-x, r, 1.0), r, r);
+}
+__device__ __forceinline__ double rsq_nr1(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    const double e = fma(-(x * y), y, 1.0);  // 1 - x y^2
+    return fma(y * 0.5, e, y);               // y (1 + e/2)
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);

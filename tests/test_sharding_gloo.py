@@ -1,0 +1,61 @@
+"""N > 1 path on CPU: world_size-2 gloo.  Each rank resolves its contiguous frame block (with the
+oracle standing in for the GPU kernel -- this test is about the sharding arithmetic and the single
+all-gather), the gathered track must equal the unsharded result bit for bit."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+from snowmocap_amd.sharded import shard_bounds, gather_track
+
+
+def test_shard_bounds_cover_and_are_contiguous():
+    for F in (0, 1, 7, 10, 10000, 1000003):
+        for world in (1, 2, 3, 8):
+            spans = [shard_bounds(F, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == F
+            for (lo, hi, per), (lo2, _, _) in zip(spans[:-1], spans[1:]):
+                assert hi == lo2 and hi - lo <= per
+            assert sum(hi - lo for lo, hi, _ in spans) == F
+
+
+def _worker(rank, world, port, F, tmp):
+    sys.path.insert(0, ROOT)
+    from snowmocap_amd import synth
+    from oracle import oracle as orc
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    wl = synth.config_workload(2, F, seed=11)
+    K, R, t = wl["rig"]
+    prm = orc.make_params(**wl["params"])
+    lo, hi, per = shard_bounds(F, world, rank)
+    loc = orc.triangulate_condense_batch(K, R, t, wl["kpts"][lo:hi], wl["n_persons"][lo:hi], prm, 1, nthreads=1)
+    packed = np.concatenate([loc["xyz"], loc["kscore"][..., None]], axis=-1).astype(np.float32)
+    full = gather_track(torch.from_numpy(packed), F)
+    cnt = gather_track(torch.from_numpy(loc["count"]), F)
+    if rank == 0:
+        np.save(os.path.join(tmp, "full.npy"), full.numpy())
+        np.save(os.path.join(tmp, "cnt.npy"), cnt.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("F", [37, 64])
+def test_two_rank_gather_equals_unsharded(tmp_path, F):
+    from snowmocap_amd import synth
+    from oracle import oracle as orc
+    port = 29500 + (os.getpid() % 500) + F
+    mp.spawn(_worker, args=(2, port, F, str(tmp_path)), nprocs=2, join=True)
+    wl = synth.config_workload(2, F, seed=11)
+    K, R, t = wl["rig"]
+    ref = orc.triangulate_condense_batch(K, R, t, wl["kpts"], wl["n_persons"], orc.make_params(**wl["params"]), 1, nthreads=1)
+    want = np.concatenate([ref["xyz"], ref["kscore"][..., None]], axis=-1).astype(np.float32)
+    got = np.load(tmp_path / "full.npy")
+    assert got.shape == want.shape and np.array_equal(got, want)
+    assert np.array_equal(np.load(tmp_path / "cnt.npy"), ref["count"])
