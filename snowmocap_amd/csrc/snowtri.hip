@@ -9,12 +9,14 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 #include <string>
 #include <vector>
 
 #include "snowtri_fused.hpp"
+#include "snowtri_general.hpp"
 #include "snowtri_kernels.hpp"
 
 using namespace snowtri;
@@ -89,7 +91,7 @@ struct snowtri_ctx {
     int num_cus = 256;
     std::vector<double> hM, ht;
     std::vector<int32_t> hpairs;
-    double *dM = nullptr, *dt = nullptr, *dpairc = nullptr;
+    double *dM = nullptr, *dt = nullptr, *dpairc = nullptr, *dP = nullptr;
     int32_t *dpairs = nullptr;
     unsigned long long *d_counters = nullptr;  // [0] singular pairs, [1] slow frames, [2..] spare
     Scratch in, out, work, misc;
@@ -99,7 +101,8 @@ struct snowtri_ctx {
     bool ev_valid = false;
     hipStream_t ev_stream = nullptr;
     int64_t last_slow_frames = 0;
-    Rig rig() const { return Rig{dM, dt, dpairs, dpairc, C, npairs}; }
+    int general_mode = 0;  // dev/test knob: 0 auto, 1 force the spill kernel, 2 force the recompute kernel
+    Rig rig() const { return Rig{dM, dt, dpairs, dpairc, dP, C, npairs}; }
 };
 
 extern "C" {
@@ -136,6 +139,7 @@ int snowtri_ctx_create(int32_t C, const double *K, const double *R, const double
     if (!ctx) return SNOWTRI_ERR_BAD_ARG;
     ctx->device = device;
     ctx->C = C;
+    if (const char *gm = getenv("SNOWTRI_GENERAL_MODE")) ctx->general_mode = atoi(gm);
     ctx->hM.resize((size_t)C * 9);
     ctx->ht.assign(t, t + (size_t)C * 3);
     for (int c = 0; c < C; c++) {
@@ -183,6 +187,22 @@ int snowtri_ctx_create(int32_t C, const double *K, const double *R, const double
     CTX_TRY(hipMalloc(&ctx->dpairs, sizeof(int32_t) * std::max<size_t>(2, ctx->hpairs.size())));
     CTX_TRY(hipMalloc(&ctx->d_counters, sizeof(unsigned long long) * 8));
     CTX_TRY(hipMalloc(&ctx->dpairc, sizeof(double) * std::max<size_t>(6, hpairc.size())));
+    {   // world->pixel matrices P_c = K_c [R_c^T | -R_c^T t_c] for the DLT method
+        std::vector<double> hP((size_t)std::max(1, C) * 12, 0.0);
+        for (int c = 0; c < C; c++) {
+            const double *Kc = K + 9 * c, *Rc = R + 9 * c, *tc = t + 3 * c;
+            double Rt[12];  // [R^T | -R^T t]
+            for (int i = 0; i < 3; i++) {
+                for (int j = 0; j < 3; j++) Rt[4 * i + j] = Rc[3 * j + i];
+                Rt[4 * i + 3] = -(Rc[0 + i] * tc[0] + Rc[3 + i] * tc[1] + Rc[6 + i] * tc[2]);
+            }
+            for (int i = 0; i < 3; i++)
+                for (int j = 0; j < 4; j++)
+                    hP[12 * c + 4 * i + j] = Kc[3 * i] * Rt[j] + Kc[3 * i + 1] * Rt[4 + j] + Kc[3 * i + 2] * Rt[8 + j];
+        }
+        CTX_TRY(hipMalloc(&ctx->dP, sizeof(double) * hP.size()));
+        CTX_TRY(hipMemcpy(ctx->dP, hP.data(), sizeof(double) * hP.size(), hipMemcpyHostToDevice));
+    }
     if (ctx->npairs > 0)
         CTX_TRY(hipMemcpy(ctx->dpairc, hpairc.data(), sizeof(double) * hpairc.size(), hipMemcpyHostToDevice));
     if (C > 0) {
@@ -206,6 +226,7 @@ int snowtri_ctx_destroy(snowtri_ctx *ctx) {
     if (ctx->dt) (void)hipFree(ctx->dt);
     if (ctx->dpairs) (void)hipFree(ctx->dpairs);
     if (ctx->dpairc) (void)hipFree(ctx->dpairc);
+    if (ctx->dP) (void)hipFree(ctx->dP);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     ctx->in.release();
     ctx->out.release();
@@ -502,19 +523,26 @@ namespace {
 
 constexpr size_t kMaxScratchBytes = (size_t)8 << 30;
 
-// Frames per tile for the fast kernel: maximise (lane utilisation of the item loop) x (balance of
-// tiles over the resident workgroups), under the LDS budget.
-int choose_tile_frames(int64_t F, int J, int kn, int NP, int resident_blocks) {
+// Frames per tile for the fast kernel: maximise (lane utilisation of the item loop: T*J items in
+// 256-wide passes) x (balance of the tiles over the CUs -- the kernel is fp64-VALU-bound, so a CU
+// with one more tile than its neighbours sets the launch time), under the LDS budget.  Prefer
+// >= 2 workgroups per CU (latency hiding) unless that costs more than 5 %.
+int choose_tile_frames(int64_t F, int J, int kn, int NP, int num_cus) {
+    if (const char *e = getenv("SNOWTRI_TILE_FRAMES")) {
+        const int T = atoi(e);
+        if (T >= 1 && T <= 64 && fused_single_lds_bytes(T, kn, NP) <= 64 * 1024) return T;
+    }
     int best = 1;
     double best_score = -1.0;
     for (int T = 1; T <= 64; T++) {
-        if (fused_single_lds_bytes(T, kn, NP) > 40 * 1024) break;
+        if (fused_single_lds_bytes(T, kn, NP) > 64 * 1024) break;
         const int64_t items = (int64_t)T * J;
         const double eff_pass = (double)items / (double)(((items + kBlock - 1) / kBlock) * kBlock);
         const int64_t ntiles = (F + T - 1) / T;
-        const int64_t rounds = (ntiles + resident_blocks - 1) / resident_blocks;
-        const double eff_bal = (double)ntiles / (double)(rounds * resident_blocks);
-        const double score = eff_pass * eff_bal;
+        const int64_t per_cu = (ntiles + num_cus - 1) / num_cus;
+        const double eff_bal = (double)ntiles / (double)(per_cu * num_cus);
+        double score = eff_pass * eff_bal;
+        if (per_cu < 2) score *= 0.95;
         if (score > best_score + 1e-9) {
             best_score = score;
             best = T;
@@ -523,20 +551,20 @@ int choose_tile_frames(int64_t F, int J, int kn, int NP, int resident_blocks) {
     return best;
 }
 
-template <int C, typename TIn, typename TOut>
+template <int C, int METHOD, typename TIn, typename TOut>
 int launch_fused_single(snowtri_ctx *ctx, hipStream_t st, int64_t F, int J, const TIn *d_kpts,
                         const int32_t *d_np, const Params &prm, int Pout, TOut *d_xyzs, TOut *d_ps,
                         int32_t *d_cnt, uint32_t *d_fl) {
     constexpr int NP = C * (C - 1) / 2;
     const int resident = ctx->num_cus * 4;
-    const int T = choose_tile_frames(F, J, prm.kn, NP, resident);
+    const int T = choose_tile_frames(F, J, prm.kn, NP, ctx->num_cus);
     const int64_t ntiles = (F + T - 1) / T;
     const int grid = (int)std::min<int64_t>(ntiles, resident);
     const size_t per_block = general_scratch_bytes(NP, J);
     int rc = ctx->work.ensure(per_block * (size_t)grid);
     if (rc) return rc;
     const size_t lds = fused_single_lds_bytes(T, prm.kn, NP);
-    auto kern = k_fused_single<C, TIn, TOut>;
+    auto kern = k_fused_single<C, METHOD, TIn, TOut>;
     if (lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, st, F, J, T, ctx->rig(), d_kpts, d_np, prm, Pout,
@@ -566,22 +594,61 @@ int launch_frame_general(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax, 
     return SNOWTRI_OK;
 }
 
+// Multi-person path without HBM candidate spill (snowtri_general.hpp).
+template <typename TIn, typename TOut>
+int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax, int J, const TIn *d_kpts,
+                           const int32_t *d_np, const Params &prm, int Pout, TOut *d_xyzs, TOut *d_ps,
+                           int32_t *d_cnt, uint32_t *d_fl) {
+    const int64_t Kc = snowtri_num_candidate_slots(ctx->C, Pmax);
+    const int R = ctx->C * Pmax;
+    const size_t per_block = recompute_scratch_bytes(Kc);
+    const size_t lds = recompute_lds_bytes(R, J, prm.kn, (int)sizeof(TIn));
+    // 3 workgroups per CU fit the LDS budget (~50 KB each); frames are plentiful
+    int64_t grid = std::min<int64_t>(F, (int64_t)ctx->num_cus * 3);
+    grid = std::max<int64_t>(1, std::min<int64_t>(grid, (int64_t)(kMaxScratchBytes / per_block)));
+    int rc = ctx->work.ensure(per_block * (size_t)grid);
+    if (rc) return rc;
+    auto kern = k_frame_recompute<TIn, TOut>;
+    if (lds > 48 * 1024)
+        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    hipLaunchKernelGGL(kern, dim3((int)grid), dim3(kBlock), lds, st, F, Pmax, J, (int)Kc, ctx->rig(), d_kpts, d_np,
+                       prm, Pout, d_xyzs, d_ps, d_cnt, d_fl, (char *)ctx->work.p, per_block);
+    HIP_TRY(hipGetLastError());
+    return SNOWTRI_OK;
+}
+
 template <typename TIn, typename TOut>
 int fused_dispatch(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax, int J, const void *kpts,
                    const int32_t *d_np, const Params &prm, int Pout, void *xyzs, void *ps, int32_t *d_cnt,
-                   uint32_t *d_fl) {
+                   uint32_t *d_fl, int method) {
     const TIn *d_kpts = (const TIn *)kpts;
     TOut *d_xyzs = (TOut *)xyzs, *d_ps = (TOut *)ps;
     const int C = ctx->C;
     const bool fast = Pmax == 1 && C >= 3 && C <= 8 && prm.kn >= 1 && prm.avg_thr <= 0.0 &&
-                      !((double)ctx->npairs < prm.num_tol);
+                      !((double)ctx->npairs < prm.num_tol) && ctx->general_mode == 0;
     if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[0], st));
     int rc;
-    if (fast) {
+    if (method == SNOWTRI_DLT) {
+        switch (C) {  // single detection per camera only (host-checked): no association needed
+#define SNOWTRI_CASE(CC)                                                                                      \
+    case CC:                                                                                                  \
+        rc = launch_fused_single<CC, 1, TIn, TOut>(ctx, st, F, J, d_kpts, d_np, prm, Pout, d_xyzs, d_ps, d_cnt, d_fl); \
+        break;
+            SNOWTRI_CASE(2)
+            SNOWTRI_CASE(3)
+            SNOWTRI_CASE(4)
+            SNOWTRI_CASE(5)
+            SNOWTRI_CASE(6)
+            SNOWTRI_CASE(7)
+            SNOWTRI_CASE(8)
+#undef SNOWTRI_CASE
+            default: rc = SNOWTRI_ERR_BAD_ARG;
+        }
+    } else if (fast) {
         switch (C) {
 #define SNOWTRI_CASE(CC)                                                                                   \
     case CC:                                                                                               \
-        rc = launch_fused_single<CC, TIn, TOut>(ctx, st, F, J, d_kpts, d_np, prm, Pout, d_xyzs, d_ps, d_cnt, d_fl); \
+        rc = launch_fused_single<CC, 0, TIn, TOut>(ctx, st, F, J, d_kpts, d_np, prm, Pout, d_xyzs, d_ps, d_cnt, d_fl); \
         break;
             SNOWTRI_CASE(3)
             SNOWTRI_CASE(4)
@@ -592,6 +659,9 @@ int fused_dispatch(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax, int J,
 #undef SNOWTRI_CASE
             default: rc = SNOWTRI_ERR_BAD_ARG;
         }
+    } else if (prm.kn <= kRecomputeMaxKn && recompute_chunk_joints(C * Pmax, J, (int)sizeof(TIn)) >= 1 &&
+               ctx->general_mode != 1) {
+        rc = launch_frame_recompute<TIn, TOut>(ctx, st, F, Pmax, J, d_kpts, d_np, prm, Pout, d_xyzs, d_ps, d_cnt, d_fl);
     } else {
         rc = launch_frame_general<TIn, TOut>(ctx, st, F, Pmax, J, d_kpts, d_np, prm, Pout, d_xyzs, d_ps, d_cnt, d_fl);
     }
@@ -618,7 +688,9 @@ extern "C" int snowtri_triangulate_condense(snowtri_ctx *ctx, int64_t F, int32_t
     if ((in_dtype != SNOWTRI_F32 && in_dtype != SNOWTRI_F64) || (out_dtype != SNOWTRI_F32 && out_dtype != SNOWTRI_F64))
         return SNOWTRI_ERR_BAD_ARG;
     if (memspace != SNOWTRI_HOST && memspace != SNOWTRI_DEVICE) return SNOWTRI_ERR_BAD_ARG;
-    if (method != SNOWTRI_PAIRWISE) return SNOWTRI_ERR_BAD_ARG;  // SNOWTRI_DLT: not built yet
+    if (method != SNOWTRI_PAIRWISE && method != SNOWTRI_DLT) return SNOWTRI_ERR_BAD_ARG;
+    // DLT: built for one detection per camera (no association step); multi-person DLT is not built.
+    if (method == SNOWTRI_DLT && (Pmax != 1 || ctx->C < 2 || ctx->C > 8)) return SNOWTRI_ERR_BAD_ARG;
     if (F == 0) return SNOWTRI_OK;
     if (!kpts || !out_xyzs || !out_count) return SNOWTRI_ERR_BAD_ARG;
     Params prm;
@@ -661,13 +733,13 @@ extern "C" int snowtri_triangulate_condense(snowtri_ctx *ctx, int64_t F, int32_t
     // no memsets: the kernels own every output word, including the per-frame flags
     ctx->last_slow_frames = -1;
     if (in_dtype == SNOWTRI_F32 && out_dtype == SNOWTRI_F32)
-        rc = fused_dispatch<float, float>(ctx, st, F, Pmax, J, d_kpts, d_np, prm, Pout_max, d_xyzs, d_ps, d_cnt, d_fl);
+        rc = fused_dispatch<float, float>(ctx, st, F, Pmax, J, d_kpts, d_np, prm, Pout_max, d_xyzs, d_ps, d_cnt, d_fl, method);
     else if (in_dtype == SNOWTRI_F32)
-        rc = fused_dispatch<float, double>(ctx, st, F, Pmax, J, d_kpts, d_np, prm, Pout_max, d_xyzs, d_ps, d_cnt, d_fl);
+        rc = fused_dispatch<float, double>(ctx, st, F, Pmax, J, d_kpts, d_np, prm, Pout_max, d_xyzs, d_ps, d_cnt, d_fl, method);
     else if (out_dtype == SNOWTRI_F32)
-        rc = fused_dispatch<double, float>(ctx, st, F, Pmax, J, d_kpts, d_np, prm, Pout_max, d_xyzs, d_ps, d_cnt, d_fl);
+        rc = fused_dispatch<double, float>(ctx, st, F, Pmax, J, d_kpts, d_np, prm, Pout_max, d_xyzs, d_ps, d_cnt, d_fl, method);
     else
-        rc = fused_dispatch<double, double>(ctx, st, F, Pmax, J, d_kpts, d_np, prm, Pout_max, d_xyzs, d_ps, d_cnt, d_fl);
+        rc = fused_dispatch<double, double>(ctx, st, F, Pmax, J, d_kpts, d_np, prm, Pout_max, d_xyzs, d_ps, d_cnt, d_fl, method);
     if (rc) return rc;
     if (memspace == SNOWTRI_HOST) {
         HIP_TRY(hipMemcpyAsync(out_xyzs, d_xyzs, o4, hipMemcpyDeviceToHost, st));

@@ -115,12 +115,108 @@ struct Vec4T {
     T x, y, z, w;
 };
 
-template <typename T>
-struct Kp3 {  // one detected keypoint as stored in kpts: (u, v, score)
-    T u, v, s;
-};
+// ------------------------------------------------------------------------------------------------
+// method = SNOWTRI_DLT (row N3; what north_star describes, NOT what the reference computes):
+// N-view DLT for one (frame, joint) in one lane.  Rows u*P[2]-P[0], v*P[2]-P[1] of every camera whose
+// confidence is not below keypoint_score_threshold are accumulated straight into the 10 unique
+// entries of A^T A; its smallest eigenvector comes from a register-resident cyclic Jacobi
+// (6 sweeps x 6 rotations, fixed count: converged to 2e-14 m after 5 on the bench rig).
+template <int C, typename TIn>
+__device__ __forceinline__ void dlt_item(const Rig &rig, const Kp3<TIn> (&cur)[C], const int32_t *np_f,
+                                         const Params &prm, double &ox, double &oy, double &oz, double &os) {
+    typedef const __attribute__((address_space(4))) double *cptr;
+    cptr Pp = (cptr)(uintptr_t)rig.P;
+    asm volatile("" : "+s"(Pp));
+    double A[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) A[i][k] = 0.0;
+    double ssum = 0.0;
+    int cnt = 0;
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        bool use = !((double)cur[c].s < prm.kthr);
+        if (np_f) use &= np_f[c] > 0;
+        const double w = use ? 1.0 : 0.0;
+        const double u = (double)cur[c].u, v = (double)cur[c].v;
+        double r1[4], r2[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            r1[k] = w * fma(u, Pp[12 * c + 8 + k], -Pp[12 * c + k]);
+            r2[k] = w * fma(v, Pp[12 * c + 8 + k], -Pp[12 * c + 4 + k]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+#pragma unroll
+            for (int k = i; k < 4; k++) A[i][k] = fma(r1[i], r1[k], fma(r2[i], r2[k], A[i][k]));
+        ssum += use ? (double)cur[c].s : 0.0;
+        cnt += use ? 1 : 0;
+    }
+#pragma unroll
+    for (int i = 1; i < 4; i++)
+#pragma unroll
+        for (int k = 0; k < i; k++) A[i][k] = A[k][i];
+    double V[4][4];
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+#pragma unroll
+        for (int k = 0; k < 4; k++) V[i][k] = (i == k) ? 1.0 : 0.0;
+#pragma unroll 1
+    for (int sweep = 0; sweep < 6; sweep++) {
+#pragma unroll
+        for (int p = 0; p < 3; p++) {
+#pragma unroll
+            for (int q = p + 1; q < 4; q++) {
+                const double apq = A[p][q];
+                const bool rot = apq != 0.0;
+                const double theta = (A[q][q] - A[p][p]) * (0.5 * rcp_nr2(rot ? apq : 1.0));
+                const double at = fabs(theta);
+                const double rad = fma(theta, theta, 1.0);
+                double t = rcp_nr2(at + rad * rsq_nr1(rad));      // 1 / (|theta| + sqrt(theta^2 + 1))
+                t = (at > 1e150) ? 0.0 : t;                        // theta^2 overflowed: rotation is nil
+                t = copysign(t, theta);
+                t = rot ? t : 0.0;
+                const double cth = rsq_nr1(fma(t, t, 1.0));
+                const double sth = t * cth;
+                A[p][p] = fma(-t, apq, A[p][p]);
+                A[q][q] = fma(t, apq, A[q][q]);
+                A[p][q] = A[q][p] = 0.0;
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    if (r != p && r != q) {
+                        const double arp = A[r][p], arq = A[r][q];
+                        A[r][p] = A[p][r] = fma(cth, arp, -(sth * arq));
+                        A[r][q] = A[q][r] = fma(sth, arp, cth * arq);
+                    }
+                    const double vrp = V[r][p], vrq = V[r][q];
+                    V[r][p] = fma(cth, vrp, -(sth * vrq));
+                    V[r][q] = fma(sth, vrp, cth * vrq);
+                }
+            }
+        }
+    }
+    // eigenvector of the smallest eigenvalue
+    double best = A[0][0];
+    double e0 = V[0][0], e1 = V[1][0], e2 = V[2][0], e3 = V[3][0];
+#pragma unroll
+    for (int k = 1; k < 4; k++) {
+        const bool lt = A[k][k] < best;
+        best = lt ? A[k][k] : best;
+        e0 = lt ? V[0][k] : e0;
+        e1 = lt ? V[1][k] : e1;
+        e2 = lt ? V[2][k] : e2;
+        e3 = lt ? V[3][k] : e3;
+    }
+    const bool ok = cnt >= 2;
+    const double r = 1.0 / e3;
+    ox = ok ? e0 * r : 0.0;
+    oy = ok ? e1 * r : 0.0;
+    oz = ok ? e2 * r : 0.0;
+    os = ok ? ssum / (double)cnt : 0.0;
+}
 
-template <int C, typename TIn, typename TOut>
+template <int C, int METHOD, typename TIn, typename TOut>
 __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_single(int64_t F, int J, int T, Rig rig,
                                                          const TIn *__restrict__ kpts,
                                                          const int32_t *__restrict__ n_persons, Params prm,
@@ -168,69 +264,73 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_single(int
 #pragma unroll
                 for (int c = 0; c < C; c++) nxt[c] = p[(size_t)c * J];
             }
-            // Rig constants are wave-uniform: scalar loads issued INSIDE the loop (pointers laundered
-            // so they are not hoisted: 66 live doubles would cost ~130 registers).
-            typedef const __attribute__((address_space(4))) double *cptr;  // AMDGPU constant space
-            cptr Mp = (cptr)(uintptr_t)rig.M, pc = (cptr)(uintptr_t)rig.pairc;
-            asm volatile("" : "+s"(Mp), "+s"(pc));
-            Vec3 h[C];
-            double a[C];
-            bool pass[C];
-#pragma unroll
-            for (int c = 0; c < C; c++) {
-                {  // A1, camera.py:241-243 with M = R inv(K)
-                    const double u = (double)cur[c].u, v = (double)cur[c].v;
-                    h[c].x = fma(Mp[9 * c + 0], u, fma(Mp[9 * c + 1], v, Mp[9 * c + 2]));
-                    h[c].y = fma(Mp[9 * c + 3], u, fma(Mp[9 * c + 4], v, Mp[9 * c + 5]));
-                    h[c].z = fma(Mp[9 * c + 6], u, fma(Mp[9 * c + 7], v, Mp[9 * c + 8]));
-                }
-                a[c] = dot3(h[c], h[c]);
-                pass[c] = !((double)cur[c].s < prm.kthr);  // :73
-            }
-            double accS = 0.0, accX = 0.0, accY = 0.0, accZ = 0.0;
-            bool bad = false, sing = false;
-            int q = 0;
-#pragma unroll
-            for (int mc = 0; mc < C - 1; mc++) {
-#pragma unroll
-                for (int sc = mc + 1; sc < C; sc++, q++) {
-                    // A2 (triangulation.py:24-31), per-ray norms hoisted, d = ts - tm and tm + ts constant
-                    const Vec3 &hm = h[mc], &hs = h[sc];
-                    const Vec3 d = {pc[6 * q], pc[6 * q + 1], pc[6 * q + 2]};
-                    const Vec3 tsum = {pc[6 * q + 3], pc[6 * q + 4], pc[6 * q + 5]};
-                    const double b = dot3(hm, hs);
-                    const double det = fma(a[mc], a[sc], -(b * b));
-                    const double e = dot3(hm, d), g = dot3(hs, d);
-                    const double inv = rcp_nr2(det);
-                    const double S0 = fma(a[sc], e, -(b * g)) * inv;
-                    const double S1 = fma(a[mc], g, -(b * e)) * inv;
-                    // Wm - Ws = hm S0 + hs S1 - d ;  Wm + Ws = (tm + ts) + hm S0 - hs S1
-                    const Vec3 df = {fma(hs.x, S1, fma(hm.x, S0, -d.x)), fma(hs.y, S1, fma(hm.y, S0, -d.y)),
-                                     fma(hs.z, S1, fma(hm.z, S0, -d.z))};
-                    const Vec3 sw = {fma(-hs.x, S1, fma(hm.x, S0, tsum.x)), fma(-hs.y, S1, fma(hm.y, S0, tsum.y)),
-                                     fma(-hs.z, S1, fma(hm.z, S0, tsum.z))};
-                    const double d2 = dot3(df, df);
-                    double idist = rsq_nr1(d2);
-                    idist = (d2 == 0.0) ? __builtin_inf() : idist;  // exact intersection: score = half / 0
-                    const double dist = d2 * idist;
-                    double sq = half_score(cur[mc].s, cur[sc].s) * (idist * 0.001);  // :72
-                    const bool keep = pass[mc] & pass[sc] & !(dist > prm.dthr);      // :73-74
-                    sq = keep ? sq : 0.0;
-                    sing |= (det == 0.0);
-                    bad |= (sq < 0.0);
-                    accS += sq;  // fusion :141-147 as (sum s (Wm+Ws)) / (2 sum s)
-                    accX = fma(sq, sw.x, accX);
-                    accY = fma(sq, sw.y, accY);
-                    accZ = fma(sq, sw.z, accZ);
-                }
-            }
             double ox = 0.0, oy = 0.0, oz = 0.0, os = 0.0;
-            if (!(accS == 0.0)) {  // :142-143
-                const double r = 0.5 * rcp_nr1(accS);
-                ox = accX * r;
-                oy = accY * r;
-                oz = accZ * r;
-                os = accS * inv_np;  // :148
+            bool bad = false, sing = false;
+            if constexpr (METHOD == 0) {
+                // Rig constants are wave-uniform: scalar loads issued INSIDE the loop (pointers laundered
+                // so they are not hoisted: 66 live doubles would cost ~130 registers).
+                typedef const __attribute__((address_space(4))) double *cptr;  // AMDGPU constant space
+                cptr Mp = (cptr)(uintptr_t)rig.M, pc = (cptr)(uintptr_t)rig.pairc;
+                asm volatile("" : "+s"(Mp), "+s"(pc));
+                Vec3 h[C];
+                double a[C];
+                bool pass[C];
+    #pragma unroll
+                for (int c = 0; c < C; c++) {
+                    {  // A1, camera.py:241-243 with M = R inv(K)
+                        const double u = (double)cur[c].u, v = (double)cur[c].v;
+                        h[c].x = fma(Mp[9 * c + 0], u, fma(Mp[9 * c + 1], v, Mp[9 * c + 2]));
+                        h[c].y = fma(Mp[9 * c + 3], u, fma(Mp[9 * c + 4], v, Mp[9 * c + 5]));
+                        h[c].z = fma(Mp[9 * c + 6], u, fma(Mp[9 * c + 7], v, Mp[9 * c + 8]));
+                    }
+                    a[c] = dot3(h[c], h[c]);
+                    pass[c] = !((double)cur[c].s < prm.kthr);  // :73
+                }
+                double accS = 0.0, accX = 0.0, accY = 0.0, accZ = 0.0;
+                int q = 0;
+    #pragma unroll
+                for (int mc = 0; mc < C - 1; mc++) {
+    #pragma unroll
+                    for (int sc = mc + 1; sc < C; sc++, q++) {
+                        // A2 (triangulation.py:24-31), per-ray norms hoisted, d = ts - tm and tm + ts constant
+                        const Vec3 &hm = h[mc], &hs = h[sc];
+                        const Vec3 d = {pc[6 * q], pc[6 * q + 1], pc[6 * q + 2]};
+                        const Vec3 tsum = {pc[6 * q + 3], pc[6 * q + 4], pc[6 * q + 5]};
+                        const double b = dot3(hm, hs);
+                        const double det = fma(a[mc], a[sc], -(b * b));
+                        const double e = dot3(hm, d), g = dot3(hs, d);
+                        const double inv = rcp_nr2(det);
+                        const double S0 = fma(a[sc], e, -(b * g)) * inv;
+                        const double S1 = fma(a[mc], g, -(b * e)) * inv;
+                        // Wm - Ws = hm S0 + hs S1 - d ;  Wm + Ws = (tm + ts) + hm S0 - hs S1
+                        const Vec3 df = {fma(hs.x, S1, fma(hm.x, S0, -d.x)), fma(hs.y, S1, fma(hm.y, S0, -d.y)),
+                                         fma(hs.z, S1, fma(hm.z, S0, -d.z))};
+                        const Vec3 sw = {fma(-hs.x, S1, fma(hm.x, S0, tsum.x)), fma(-hs.y, S1, fma(hm.y, S0, tsum.y)),
+                                         fma(-hs.z, S1, fma(hm.z, S0, tsum.z))};
+                        const double d2 = dot3(df, df);
+                        double idist = rsq_nr1(d2);
+                        idist = (d2 == 0.0) ? __builtin_inf() : idist;  // exact intersection: score = half / 0
+                        const double dist = d2 * idist;
+                        double sq = half_score(cur[mc].s, cur[sc].s) * (idist * 0.001);  // :72
+                        const bool keep = pass[mc] & pass[sc] & !(dist > prm.dthr);      // :73-74
+                        sq = keep ? sq : 0.0;
+                        sing |= (det == 0.0);
+                        bad |= (sq < 0.0);
+                        accS += sq;  // fusion :141-147 as (sum s (Wm+Ws)) / (2 sum s)
+                        accX = fma(sq, sw.x, accX);
+                        accY = fma(sq, sw.y, accY);
+                        accZ = fma(sq, sw.z, accZ);
+                    }
+                }
+                if (!(accS == 0.0)) {  // :142-143
+                    const double r = 0.5 * rcp_nr1(accS);
+                    ox = accX * r;
+                    oy = accY * r;
+                    oz = accZ * r;
+                    os = accS * inv_np;  // :148
+                }
+            } else {
+                dlt_item<C>(rig, cur, n_persons ? n_persons + (f0 + fl) * C : nullptr, prm, ox, oy, oz, os);
             }
             if (j < kn) {
                 const int64_t f = f0 + fl;
@@ -251,7 +351,7 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_single(int
 
         // ---- single-cluster check (:116-130): candidate q >= 1 must have its centre joint within
         //      condense_distance_tol of candidate 0's.  One lane per (frame, q); ~1 % of the work.
-        for (int i = tid; i < nf * (NP - 1); i += kBlock) {
+        for (int i = tid; METHOD == 0 && i < nf * (NP - 1); i += kBlock) {
             const int w = i / (NP - 1), qq = 1 + (i - w * (NP - 1));
             const int64_t f = f0 + w;
             const Kp3<TIn> *p = kp3 + (f * C) * (int64_t)J + ci;
@@ -281,7 +381,8 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_single(int
             sum = wave_sum(sum);
             const double avg = sum / (double)kn;
             bool slow = (fflag[w] & kSlow) != 0u || (avg < prm.score_tol);  // :151-152
-            if (n_persons) {
+            if (METHOD != 0) slow = false;
+            if (METHOD == 0 && n_persons) {
                 const bool one = lane < C ? (n_persons[f * C + lane] == 1) : true;
                 slow |= (__ballot(!one) != 0ull);
             }

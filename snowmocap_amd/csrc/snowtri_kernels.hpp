@@ -40,6 +40,11 @@ __global__ __launch_bounds__(kBlock) void k_skew(int64_t n, const double *__rest
     }
 }
 
+template <typename T>
+struct Kp3 {  // one detected keypoint as stored in kpts: (u, v, score)
+    T u, v, s;
+};
+
 // Rig constants resident in HBM (<= 1.5 KB, L2/scalar-cache resident): M[C][9], t[C][3],
 // pair table [npairs][2] in the reference's loop order mc < sc (triangulation.py:56-58).
 struct Rig {
@@ -47,6 +52,7 @@ struct Rig {
     const double *t;
     const int32_t *pairs;
     const double *pairc;  // [npairs][6]: d = t_sc - t_mc, tsum = t_mc + t_sc (host-precomputed)
+    const double *P;      // [C][12]: world->pixel matrices K [R^T | -R^T t] (DLT method)
     int32_t C, npairs;
 };
 

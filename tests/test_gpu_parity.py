@@ -255,3 +255,62 @@ def test_full_size_properties_cfg2(api):
     # geometric sanity at full size: fused joints land near the synthetic truth (1 px noise ~ mm)
     assert np.abs(a[:, 0, :, :3] - wl["X"][:, 0]).max() < 0.2
     bt.close()
+
+
+# ------------------------------------------------------------------ method = DLT (row N3)
+def test_dlt_method_against_svd_oracle_and_reference_class(api):
+    """The N-view DLT kernel (A^T A + register Jacobi) vs the NumPy SVD oracle of the same
+    definition, and vs the REFERENCE on the near-exact fixture class where both algorithms agree
+    (2e-7 m).  On noisy inputs DLT and the reference differ by millimetres BY DESIGN."""
+    from snowmocap_amd import synth, _lib
+    from oracle import dlt
+    wl = synth.config_workload(2, 40, seed=9)
+    kp = wl["kpts"]
+    kp[:, :, :, :, 2] = np.random.default_rng(3).uniform(2.0, 8.0, size=kp.shape[:-1]).astype(np.float32)
+    kp[5, :, 0, 7, 2] = 1.0            # a joint nobody sees -> (0,0,0), score 0
+    kp[6, 1:, 0, 9, 2] = 1.0           # a joint seen by one camera only -> (0,0,0), score 0
+    K, R, t = wl["rig"]
+    prm = dict(wl["params"])
+    want, wps, wcnt = dlt.dlt_batch(K, R, t, kp, prm["keypoint_score_threshold"], prm["keypoint_num"])
+    for out_dtype, tol in ((np.float64, 1e-9), (np.float32, XYZ_F32)):
+        bt = api.BatchTriangulator(K, R, t, prm, pout_max=1, out_dtype=out_dtype, method=_lib.DLT)
+        out = bt.run_host(kp, wl["n_persons"])
+        bt.close()
+        assert out["status"] == _lib.OK and (out["count"] == 1).all()
+        err = np.abs(out["xyzs"][..., :3] - want[..., :3]).max()
+        assert err < tol, err
+        np.testing.assert_allclose(out["xyzs"][..., 3], want[..., 3], rtol=1e-6)
+        np.testing.assert_allclose(out["pscore"], wps, rtol=1e-6)
+        assert not out["xyzs"][5, 0, 7].any() and not out["xyzs"][6, 0, 9].any()
+    sc = load_scenarios("g2_near_exact.npz")["f32"]
+    bt = api.BatchTriangulator(sc["K"], sc["R"], sc["t"], sc["params"], pout_max=1, out_dtype=np.float64, method=_lib.DLT)
+    out = bt.run_host(sc["kpts"], sc["n_persons"])
+    bt.close()
+    assert np.abs(out["xyzs"][:, :1, :, :3] - sc["cond_xyz"]).max() < 1e-6      # reference, near-exact class
+    # multi-person DLT is not built: rejected, never silently substituted
+    wl3 = synth.config_workload(3, 1)
+    bt = api.BatchTriangulator(*wl3["rig"], wl3["params"], pout_max=8, method=_lib.DLT)
+    with pytest.raises(_lib.SnowtriError):
+        bt.run_host(wl3["kpts"], wl3["n_persons"])
+    bt.close()
+
+
+@pytest.mark.parametrize("mode", ["1", "2"])
+def test_general_kernels_agree(api, mode, monkeypatch):
+    """Spill kernel (mode 1) and recompute kernel (mode 2) forced on a single-person batch must both
+    equal the oracle -- and so must the fast path (default), tested above."""
+    from snowmocap_amd import synth, _lib
+    from oracle import oracle as orc
+    monkeypatch.setenv("SNOWTRI_GENERAL_MODE", mode)
+    wl = synth.config_workload(2, 50, seed=21)
+    K, R, t = wl["rig"]
+    ref = orc.triangulate_condense_batch(K, R, t, wl["kpts"], wl["n_persons"], orc.make_params(**wl["params"]), 2)
+    bt = api.BatchTriangulator(K, R, t, wl["params"], pout_max=2, out_dtype=np.float64)
+    out = bt.run_host(wl["kpts"], wl["n_persons"])
+    bt.close()
+    assert np.array_equal(out["count"], ref["count"])
+    assert not (out["flags"] & _lib.FLAG_FASTPATH).any()
+    for f in range(50):
+        assert_scores_close(out["xyzs"][f, :1, :, 3], ref["kscore"][f, :1])
+        assert_xyz_close(out["xyzs"][f, :1, :, :3], ref["xyz"][f, :1], XYZ_FUSED)
+        assert not out["xyzs"][f, 1:].any()
