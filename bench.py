@@ -198,17 +198,25 @@ def main():
         ncores = usable_cores()
         sample = wl["kpts"][: min(F, 10000)]
         nps = wl["n_persons"][: sample.shape[0]]
-        orc.triangulate_condense_batch(Kc, Rc, tc, sample[:256], nps[:256], prm, Pout, nthreads=ncores)   # warm
-        reps, t_cpu, used = 0, 0.0, 1
-        c0 = time.perf_counter()
-        while t_cpu < args.cpu_seconds:
-            r = orc.triangulate_condense_batch(Kc, Rc, tc, sample, nps, prm, Pout, nthreads=ncores)
-            used = r["threads"]
-            reps += 1
-            t_cpu = time.perf_counter() - c0
-        cpu = {"value": sample.shape[0] * reps * J / t_cpu, "unit": "joints/s", "cores": int(used), "kind": "port",
-               "sample": f"cfg2 batch of {sample.shape[0]} frames x {reps} repeats ({t_cpu:.1f} s), "
-                         f"oracle/snowtri_oracle.c fp64, OpenMP over frames"}
+        orc.triangulate_condense_batch(Kc, Rc, tc, sample[:256], nps[:256], prm, Pout, nthreads=1)   # warm
+        # Containers often expose more logical CPUs than they may use: try a few team sizes on the
+        # bounded sample and report the best one together with the thread count that achieved it.
+        trials = sorted({1, min(8, ncores), min(32, ncores), ncores})
+        budget = args.cpu_seconds / len(trials)
+        best = None
+        for nt in trials:
+            reps, t_cpu = 0, 0.0
+            c0 = time.perf_counter()
+            while t_cpu < budget:
+                r = orc.triangulate_condense_batch(Kc, Rc, tc, sample, nps, prm, Pout, nthreads=nt)
+                reps += 1
+                t_cpu = time.perf_counter() - c0
+            rate = sample.shape[0] * reps * J / t_cpu
+            if best is None or rate > best[0]:
+                best = (rate, int(r["threads"]), reps, t_cpu)
+        cpu = {"value": best[0], "unit": "joints/s", "cores": best[1], "kind": "port",
+               "sample": f"cfg2 batch of {sample.shape[0]} frames x {best[2]} repeats ({best[3]:.1f} s) at the best of "
+                         f"{trials} OpenMP threads ({ncores} logical CPUs visible); oracle/snowtri_oracle.c fp64"}
 
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
