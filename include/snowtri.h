@@ -93,6 +93,11 @@ int snowtri_ctx_ray_matrices(const snowtri_ctx *ctx, double *M_out);
 /* Block until everything queued by this context has finished. */
 int snowtri_ctx_synchronize(snowtri_ctx *ctx);
 
+/* Test hook (no reference counterpart): evaluates the fast reciprocal / reciprocal-square-root helpers
+ * the throughput kernels use (v_rcp_f64 / v_rsq_f64 + Newton steps) on x[n]; host pointers. */
+int snowtri_fastmath_probe(snowtri_ctx *ctx, int64_t n, const double *x, double *rcp_nr2_out,
+                           double *rcp_nr1_out, double *rsq_nr1_out);
+
 /* A1  CameraGroup.add_human_2D_points (camera.py:234-253): uv[n][2] pixels of camera `cam`
  * -> rays[n][3] = R . inv(K) . [u, v, 1] (un-normalised, world frame).  Host pointers, fp64. */
 int snowtri_rays_from_pixels(snowtri_ctx *ctx, int32_t cam, int64_t n, const double *uv, double *rays);

@@ -9,11 +9,11 @@ export TMPDIR=/tmp
 BENCH="python $ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline"
 cd /tmp
 # 1. per-kernel time (no counters)
-rocprofv3 --kernel-trace --stats -d $OUT/stats -o stats -- $BENCH > $OUT/stats_bench.log 2>&1
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats -o stats -- $BENCH > $OUT/stats_bench.log 2>&1
 # 2. HBM traffic: separate passes (TCC slots: FETCH_SIZE 3, WRITE_SIZE 2)
-rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o fetch -- $BENCH --large-frames 0 > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o write -- $BENCH --large-frames 0 > $OUT/pmc_write.log 2>&1
-rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $OUT/pmc_sq -o sq -- $BENCH --large-frames 0 > $OUT/pmc_sq.log 2>&1
+rocprofv3 --output-format csv --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o fetch -- $BENCH --large-frames 0 > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --output-format csv --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o write -- $BENCH --large-frames 0 > $OUT/pmc_write.log 2>&1
+rocprofv3 --output-format csv --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $OUT/pmc_sq -o sq -- $BENCH --large-frames 0 > $OUT/pmc_sq.log 2>&1
 cd $ROOT
 python scripts/summarize_profile.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt

@@ -63,6 +63,7 @@ _SIGNATURES = {
     "snowtri_ctx_num_cameras": (ct.c_int, [_c_p]),
     "snowtri_ctx_ray_matrices": (ct.c_int, [_c_p, _c_p]),
     "snowtri_ctx_synchronize": (ct.c_int, [_c_p]),
+    "snowtri_fastmath_probe": (ct.c_int, [_c_p, ct.c_int64, _c_p, _c_p, _c_p, _c_p]),
     "snowtri_rays_from_pixels": (ct.c_int, [_c_p, ct.c_int32, ct.c_int64, _c_p, _c_p]),
     "snowtri_skew_ray_batch": (ct.c_int, [_c_p, ct.c_int64, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,
                                           ct.POINTER(ct.c_int64)]),

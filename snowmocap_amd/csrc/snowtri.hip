@@ -11,6 +11,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <limits>
 #include <new>
 #include <string>
 #include <vector>
@@ -280,6 +281,27 @@ int64_t snowtri_num_candidate_slots(int32_t C, int32_t Pmax) {
     return (int64_t)C * (C - 1) / 2 * Pmax * Pmax;
 }
 
+// Test hook: the fast-math helpers of the throughput kernels on caller-supplied values.
+int snowtri_fastmath_probe(snowtri_ctx *ctx, int64_t n, const double *x, double *rcp_nr2_out,
+                           double *rcp_nr1_out, double *rsq_nr1_out) {
+    if (!ctx || n < 1 || !x || !rcp_nr2_out || !rcp_nr1_out || !rsq_nr1_out) return SNOWTRI_ERR_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    const size_t b = sizeof(double) * n;
+    int rc = ctx->in.ensure(b);
+    if (rc) return rc;
+    rc = ctx->out.ensure(3 * b);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(ctx->in.p, x, b, hipMemcpyHostToDevice));
+    double *o = (double *)ctx->out.p;
+    hipLaunchKernelGGL(k_fastmath_probe, dim3(grid_for(n, kBlock, ctx->num_cus * 8)), dim3(kBlock), 0, 0, n,
+                       (const double *)ctx->in.p, o, o + n, o + 2 * n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(rcp_nr2_out, o, b, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(rcp_nr1_out, o + n, b, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(rsq_nr1_out, o + 2 * n, b, hipMemcpyDeviceToHost));
+    return SNOWTRI_OK;
+}
+
 // ------------------------------------------------------------------------------------------ A1
 int snowtri_rays_from_pixels(snowtri_ctx *ctx, int32_t cam, int64_t n, const double *uv, double *rays) {
     if (!ctx || cam < 0 || cam >= ctx->C || n < 0 || (n > 0 && (!uv || !rays))) return SNOWTRI_ERR_BAD_ARG;
@@ -349,6 +371,12 @@ int validate_params(const snowtri_params *p, int J, Params *out, bool need_conde
         if (q.center < 0) q.center += J;  // Python negative indexing (triangulation.py:112)
         if (q.center < 0 || q.center >= J || q.kn < 0 || q.kn > J) return SNOWTRI_ERR_BAD_INDEX;
         if (q.kn > kCondenseMaxJointsPerThread * kBlock) return SNOWTRI_ERR_BAD_ARG;
+    }
+    q.dthr2 = (q.dthr < 0.0) ? -1.0 : q.dthr * q.dthr;
+    {
+        float kf = (float)q.kthr;  // round to nearest, then step up if that landed below kthr
+        if ((double)kf < q.kthr) kf = std::nextafter(kf, std::numeric_limits<float>::infinity());
+        q.kthr_f32 = kf;            // NaN stays NaN: every comparison false, as in NumPy
     }
     *out = q;
     return SNOWTRI_OK;
@@ -624,7 +652,9 @@ int fused_dispatch(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax, int J,
     const TIn *d_kpts = (const TIn *)kpts;
     TOut *d_xyzs = (TOut *)xyzs, *d_ps = (TOut *)ps;
     const int C = ctx->C;
-    const bool fast = Pmax == 1 && C >= 3 && C <= 8 && prm.kn >= 1 && prm.avg_thr <= 0.0 &&
+    // kthr >= 0: scores that pass the keypoint gate are non-negative, so no candidate mean can fall
+    // below avg_thr <= 0 and the fast kernel needs no negative-score check
+    const bool fast = Pmax == 1 && C >= 3 && C <= 8 && prm.kn >= 1 && prm.avg_thr <= 0.0 && prm.kthr >= 0.0 &&
                       !((double)ctx->npairs < prm.num_tol) && ctx->general_mode == 0;
     if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[0], st));
     int rc;

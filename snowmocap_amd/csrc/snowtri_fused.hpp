@@ -107,7 +107,7 @@ __global__ __launch_bounds__(kBlock) void k_frame_general(int64_t F, int Pmax, i
 //   (seed 0 then absorbs all: one cluster);  the fused mean score is not below condense_score_tol.
 // Minimum waves per SIMD the fast kernel is compiled for (caps its VGPR allocation: 4 -> 128).
 #ifndef SNOWTRI_FAST_WAVES
-#define SNOWTRI_FAST_WAVES 4
+#define SNOWTRI_FAST_WAVES 2
 #endif
 
 template <typename T>
@@ -116,11 +116,96 @@ struct Vec4T {
 };
 
 // ------------------------------------------------------------------------------------------------
+// One (frame, joint) of the single-detection fast path: C rays, all C(C,2) pair solves, fusion.
+// Returns true if the item needs the IEEE-exact general routine (a pair whose dist^2 is not a
+// comfortably normal positive number: exact intersection, singular pair, or NaN).
+//
+// Fusion is regrouped per RAY instead of per pair: with Wm + Ws = (t_m + t_s) + hm S0 - hs S1,
+//   sum_q s_q (Wm+Ws)_q = sum_c ( alpha_c h_c + beta_c t_c ),
+//   alpha_c = sum_{q: c=m} s_q S0_q - sum_{q: c=s} s_q S1_q,   beta_c = sum_{q contains c} s_q,
+// so a pair costs 2 FMA + 2 adds here instead of 9 FMA, and sum_q s_q = (sum_c beta_c) / 2.
+template <int C, typename TIn>
+__device__ __forceinline__ bool pairwise_item(const Rig &rig, const Kp3<TIn> (&cur)[C], const Params &prm,
+                                              double &ox, double &oy, double &oz, double &os) {
+    // Rig constants are wave-uniform: scalar loads issued per item (pointers laundered so the loads
+    // are not hoisted out of the item loop: ~70 live doubles would cost ~140 registers).
+    typedef const __attribute__((address_space(4))) double *cptr;  // AMDGPU constant address space
+    cptr Mp = (cptr)(uintptr_t)rig.M, pc = (cptr)(uintptr_t)rig.pairc, tp = (cptr)(uintptr_t)rig.t;
+    asm volatile("" : "+s"(Mp), "+s"(pc), "+s"(tp));
+    Vec3 h[C];
+    double a[C], alpha[C], beta[C];
+    bool pass[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        // A1, camera.py:241-243 with M = R inv(K); (mul, fma, add) keeps the constant column a scalar operand
+        const double u = (double)cur[c].u, v = (double)cur[c].v;
+        h[c].x = fma(Mp[9 * c + 1], v, Mp[9 * c + 0] * u) + Mp[9 * c + 2];
+        h[c].y = fma(Mp[9 * c + 4], v, Mp[9 * c + 3] * u) + Mp[9 * c + 5];
+        h[c].z = fma(Mp[9 * c + 7], v, Mp[9 * c + 6] * u) + Mp[9 * c + 8];
+        a[c] = dot3(h[c], h[c]);
+        pass[c] = !below_kthr(cur[c].s, prm);  // :73
+        alpha[c] = 0.0;
+        beta[c] = 0.0;
+    }
+    bool bad = false;
+    int q = 0;
+#pragma unroll
+    for (int mc = 0; mc < C - 1; mc++) {
+#pragma unroll
+        for (int sc = mc + 1; sc < C; sc++, q++) {
+            // A2 (triangulation.py:24-31): per-ray norms hoisted, d = ts - tm precomputed
+            const Vec3 &hm = h[mc], &hs = h[sc];
+            const Vec3 d = {pc[6 * q], pc[6 * q + 1], pc[6 * q + 2]};
+            const double b = dot3(hm, hs);
+            const double det = fma(a[mc], a[sc], -(b * b));
+            const double e = dot3(hm, d), g = dot3(hs, d);
+            const double inv = rcp_nr2(det);
+            const double S0 = fma(a[sc], e, -(b * g)) * inv;
+            const double S1 = fma(a[mc], g, -(b * e)) * inv;
+            // Wm - Ws = hm S0 + hs S1 - d
+            const Vec3 df = {fma(hs.x, S1, fma(hm.x, S0, -d.x)), fma(hs.y, S1, fma(hm.y, S0, -d.y)),
+                             fma(hs.z, S1, fma(hm.z, S0, -d.z))};
+            const double d2 = dot3(df, df);
+            const double idist = rsq_nr1(d2);
+            // :72  ((sm+ss)/2) / (dist*1000); the halving is exact, so it is folded into the constant
+            double sq = sum_score(cur[mc].s, cur[sc].s) * (idist * 0.0005);
+            const bool keep = pass[mc] & pass[sc] & !(d2 > prm.dthr2);  // :73-74
+            sq = keep ? sq : 0.0;
+            bad |= !(d2 > 1e-280);  // exact intersection / singular / NaN / rsq out of range -> exact path
+            alpha[mc] = fma(sq, S0, alpha[mc]);
+            alpha[sc] = fma(-sq, S1, alpha[sc]);
+            beta[mc] += sq;
+            beta[sc] += sq;
+        }
+    }
+    double sx = 0.0, sy = 0.0, sz = 0.0, sb = 0.0;
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        sx = fma(alpha[c], h[c].x, fma(beta[c], tp[3 * c + 0], sx));
+        sy = fma(alpha[c], h[c].y, fma(beta[c], tp[3 * c + 1], sy));
+        sz = fma(alpha[c], h[c].z, fma(beta[c], tp[3 * c + 2], sz));
+        sb += beta[c];
+    }
+    const double accS = 0.5 * sb;  // = sum_q s_q  (:141)
+    ox = oy = oz = os = 0.0;
+    if (!(accS == 0.0)) {  // :142-143
+        const double r = rcp_nr1(sb);  // 1 / (2 sum s): the 1/2 of the midpoint folded in
+        ox = sx * r;                   // :144-147 as (sum s (Wm+Ws)) / (2 sum s)
+        oy = sy * r;
+        oz = sz * r;
+        os = accS * (1.0 / (double)(C * (C - 1) / 2));  // :148
+    }
+    return bad;
+}
+
+// ------------------------------------------------------------------------------------------------
 // method = SNOWTRI_DLT (row N3; what north_star describes, NOT what the reference computes):
 // N-view DLT for one (frame, joint) in one lane.  Rows u*P[2]-P[0], v*P[2]-P[1] of every camera whose
 // confidence is not below keypoint_score_threshold are accumulated straight into the 10 unique
 // entries of A^T A; its smallest eigenvector comes from a register-resident cyclic Jacobi
 // (6 sweeps x 6 rotations, fixed count: converged to 2e-14 m after 5 on the bench rig).
+// IEEE divide / sqrt on purpose: off-diagonal entries decay through the denormal range on their way
+// to zero, where the v_rcp_f64-based helpers return NaN.
 template <int C, typename TIn>
 __device__ __forceinline__ void dlt_item(const Rig &rig, const Kp3<TIn> (&cur)[C], const int32_t *np_f,
                                          const Params &prm, double &ox, double &oy, double &oz, double &os) {
@@ -170,14 +255,12 @@ __device__ __forceinline__ void dlt_item(const Rig &rig, const Kp3<TIn> (&cur)[C
             for (int q = p + 1; q < 4; q++) {
                 const double apq = A[p][q];
                 const bool rot = apq != 0.0;
-                const double theta = (A[q][q] - A[p][p]) * (0.5 * rcp_nr2(rot ? apq : 1.0));
+                const double theta = (A[q][q] - A[p][p]) / (2.0 * (rot ? apq : 1.0));
                 const double at = fabs(theta);
-                const double rad = fma(theta, theta, 1.0);
-                double t = rcp_nr2(at + rad * rsq_nr1(rad));      // 1 / (|theta| + sqrt(theta^2 + 1))
-                t = (at > 1e150) ? 0.0 : t;                        // theta^2 overflowed: rotation is nil
+                double t = 1.0 / (at + sqrt(fma(theta, theta, 1.0)));  // overflowing theta^2 -> t = 0
                 t = copysign(t, theta);
                 t = rot ? t : 0.0;
-                const double cth = rsq_nr1(fma(t, t, 1.0));
+                const double cth = 1.0 / sqrt(fma(t, t, 1.0));
                 const double sth = t * cth;
                 A[p][p] = fma(-t, apq, A[p][p]);
                 A[q][q] = fma(t, apq, A[q][q]);
@@ -244,130 +327,78 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_single(int
         for (int i = tid; i < nf; i += kBlock) fflag[i] = 0;
         __syncthreads();
 
-        // ---- main loop: one lane per (frame, joint); the next item's keypoints are in flight
-        //      while the current one is solved.
-        int fl = tid / J, j = tid - fl * J;
-        Kp3<TIn> cur[C], nxt[C];
-        if (tid < nitems) {
-            const Kp3<TIn> *p = kp3 + ((f0 + fl) * C) * (int64_t)J + j;
+        // ---- main loop: one lane per (frame, joint).  Two register buffers alternate so the next
+        //      item's keypoints are in flight while the current one is solved (no copies).
+        {
+            int fl = tid / J, j = tid - fl * J;
+            Kp3<TIn> bufA[C], bufB[C];
+            auto fetch = [&](Kp3<TIn>(&dst)[C], int fl_, int j_) {
+                const Kp3<TIn> *p = kp3 + ((f0 + fl_) * C) * (int64_t)J + j_;
 #pragma unroll
-            for (int c = 0; c < C; c++) cur[c] = p[(size_t)c * J];
-        }
-        for (int it = tid; it < nitems; it += kBlock) {
-            int fl2 = fl + dfl, j2 = j + dj;
-            if (j2 >= J) {
-                j2 -= J;
-                fl2++;
-            }
-            if (it + kBlock < nitems) {
-                const Kp3<TIn> *p = kp3 + ((f0 + fl2) * C) * (int64_t)J + j2;
-#pragma unroll
-                for (int c = 0; c < C; c++) nxt[c] = p[(size_t)c * J];
-            }
-            double ox = 0.0, oy = 0.0, oz = 0.0, os = 0.0;
-            bool bad = false, sing = false;
-            if constexpr (METHOD == 0) {
-                // Rig constants are wave-uniform: scalar loads issued INSIDE the loop (pointers laundered
-                // so they are not hoisted: 66 live doubles would cost ~130 registers).
-                typedef const __attribute__((address_space(4))) double *cptr;  // AMDGPU constant space
-                cptr Mp = (cptr)(uintptr_t)rig.M, pc = (cptr)(uintptr_t)rig.pairc;
-                asm volatile("" : "+s"(Mp), "+s"(pc));
-                Vec3 h[C];
-                double a[C];
-                bool pass[C];
-    #pragma unroll
-                for (int c = 0; c < C; c++) {
-                    {  // A1, camera.py:241-243 with M = R inv(K)
-                        const double u = (double)cur[c].u, v = (double)cur[c].v;
-                        h[c].x = fma(Mp[9 * c + 0], u, fma(Mp[9 * c + 1], v, Mp[9 * c + 2]));
-                        h[c].y = fma(Mp[9 * c + 3], u, fma(Mp[9 * c + 4], v, Mp[9 * c + 5]));
-                        h[c].z = fma(Mp[9 * c + 6], u, fma(Mp[9 * c + 7], v, Mp[9 * c + 8]));
+                for (int c = 0; c < C; c++) dst[c] = p[(size_t)c * J];
+            };
+            auto advance = [&](int &fl_, int &j_) {
+                fl_ += dfl;
+                j_ += dj;
+                if (j_ >= J) {
+                    j_ -= J;
+                    fl_++;
+                }
+            };
+            auto solve_store = [&](const Kp3<TIn>(&buf)[C], int fl_, int j_) {
+                double ox, oy, oz, os;
+                bool bad;
+                if constexpr (METHOD == 0) {
+                    bad = pairwise_item<C>(rig, buf, prm, ox, oy, oz, os);
+                } else {
+                    bad = false;
+                    dlt_item<C>(rig, buf, n_persons ? n_persons + (f0 + fl_) * C : nullptr, prm, ox, oy, oz, os);
+                }
+                if (j_ < kn) {
+                    const int64_t f = f0 + fl_;
+                    Vec4T<TOut> o4 = {(TOut)ox, (TOut)oy, (TOut)oz, (TOut)os};
+                    *reinterpret_cast<Vec4T<TOut> *>(out4 + ((f * Pout) * (int64_t)kn + j_) * 4) = o4;
+                    for (int slot = 1; slot < Pout; slot++) {
+                        Vec4T<TOut> z4 = {(TOut)0, (TOut)0, (TOut)0, (TOut)0};
+                        *reinterpret_cast<Vec4T<TOut> *>(out4 + ((f * Pout + slot) * (int64_t)kn + j_) * 4) = z4;
                     }
-                    a[c] = dot3(h[c], h[c]);
-                    pass[c] = !((double)cur[c].s < prm.kthr);  // :73
+                    stash[fl_ * kn + j_] = os;
                 }
-                double accS = 0.0, accX = 0.0, accY = 0.0, accZ = 0.0;
-                int q = 0;
-    #pragma unroll
-                for (int mc = 0; mc < C - 1; mc++) {
-    #pragma unroll
-                    for (int sc = mc + 1; sc < C; sc++, q++) {
-                        // A2 (triangulation.py:24-31), per-ray norms hoisted, d = ts - tm and tm + ts constant
-                        const Vec3 &hm = h[mc], &hs = h[sc];
-                        const Vec3 d = {pc[6 * q], pc[6 * q + 1], pc[6 * q + 2]};
-                        const Vec3 tsum = {pc[6 * q + 3], pc[6 * q + 4], pc[6 * q + 5]};
-                        const double b = dot3(hm, hs);
-                        const double det = fma(a[mc], a[sc], -(b * b));
-                        const double e = dot3(hm, d), g = dot3(hs, d);
-                        const double inv = rcp_nr2(det);
-                        const double S0 = fma(a[sc], e, -(b * g)) * inv;
-                        const double S1 = fma(a[mc], g, -(b * e)) * inv;
-                        // Wm - Ws = hm S0 + hs S1 - d ;  Wm + Ws = (tm + ts) + hm S0 - hs S1
-                        const Vec3 df = {fma(hs.x, S1, fma(hm.x, S0, -d.x)), fma(hs.y, S1, fma(hm.y, S0, -d.y)),
-                                         fma(hs.z, S1, fma(hm.z, S0, -d.z))};
-                        const Vec3 sw = {fma(-hs.x, S1, fma(hm.x, S0, tsum.x)), fma(-hs.y, S1, fma(hm.y, S0, tsum.y)),
-                                         fma(-hs.z, S1, fma(hm.z, S0, tsum.z))};
-                        const double d2 = dot3(df, df);
-                        double idist = rsq_nr1(d2);
-                        idist = (d2 == 0.0) ? __builtin_inf() : idist;  // exact intersection: score = half / 0
-                        const double dist = d2 * idist;
-                        double sq = half_score(cur[mc].s, cur[sc].s) * (idist * 0.001);  // :72
-                        const bool keep = pass[mc] & pass[sc] & !(dist > prm.dthr);      // :73-74
-                        sq = keep ? sq : 0.0;
-                        sing |= (det == 0.0);
-                        bad |= (sq < 0.0);
-                        accS += sq;  // fusion :141-147 as (sum s (Wm+Ws)) / (2 sum s)
-                        accX = fma(sq, sw.x, accX);
-                        accY = fma(sq, sw.y, accY);
-                        accZ = fma(sq, sw.z, accZ);
-                    }
-                }
-                if (!(accS == 0.0)) {  // :142-143
-                    const double r = 0.5 * rcp_nr1(accS);
-                    ox = accX * r;
-                    oy = accY * r;
-                    oz = accZ * r;
-                    os = accS * inv_np;  // :148
-                }
-            } else {
-                dlt_item<C>(rig, cur, n_persons ? n_persons + (f0 + fl) * C : nullptr, prm, ox, oy, oz, os);
+                if (bad) atomicOr(&fflag[fl_], kSlow);
+            };
+            if (tid < nitems) fetch(bufA, fl, j);
+            for (int it = tid; it < nitems; it += 2 * kBlock) {
+                int fl2 = fl, j2 = j;
+                advance(fl2, j2);
+                const bool hasB = it + kBlock < nitems;
+                if (hasB) fetch(bufB, fl2, j2);
+                solve_store(bufA, fl, j);
+                if (!hasB) break;
+                fl = fl2;
+                j = j2;
+                advance(fl, j);
+                if (it + 2 * kBlock < nitems) fetch(bufA, fl, j);
+                solve_store(bufB, fl2, j2);
             }
-            if (j < kn) {
-                const int64_t f = f0 + fl;
-                Vec4T<TOut> o4 = {(TOut)ox, (TOut)oy, (TOut)oz, (TOut)os};
-                *reinterpret_cast<Vec4T<TOut> *>(out4 + ((f * Pout) * (int64_t)kn + j) * 4) = o4;
-                for (int slot = 1; slot < Pout; slot++) {
-                    Vec4T<TOut> z4 = {(TOut)0, (TOut)0, (TOut)0, (TOut)0};
-                    *reinterpret_cast<Vec4T<TOut> *>(out4 + ((f * Pout + slot) * (int64_t)kn + j) * 4) = z4;
-                }
-                stash[fl * kn + j] = os;
-            }
-            if (bad | sing) atomicOr(&fflag[fl], kSlow);
-#pragma unroll
-            for (int c = 0; c < C; c++) cur[c] = nxt[c];
-            fl = fl2;
-            j = j2;
         }
 
         // ---- single-cluster check (:116-130): candidate q >= 1 must have its centre joint within
         //      condense_distance_tol of candidate 0's.  One lane per (frame, q); ~1 % of the work.
         for (int i = tid; METHOD == 0 && i < nf * (NP - 1); i += kBlock) {
             const int w = i / (NP - 1), qq = 1 + (i - w * (NP - 1));
-            const int64_t f = f0 + w;
-            const Kp3<TIn> *p = kp3 + (f * C) * (int64_t)J + ci;
-            Vec3 Wc[2];
-#pragma unroll 1
-            for (int k = 0; k < 2; k++) {
-                const int qk = k == 0 ? 0 : qq;
+            const Kp3<TIn> *p = kp3 + ((f0 + w) * C) * (int64_t)J + ci;
+            auto centre_of = [&](int qk) {
                 const int mc = rig.pairs[2 * qk], sc = rig.pairs[2 * qk + 1];
                 const Kp3<TIn> km = p[(size_t)mc * J], ks = p[(size_t)sc * J];
-                const Vec3 hm = ray_from_pixel(rig.M + 9 * mc, (double)km.u, (double)km.v);
-                const Vec3 hs = ray_from_pixel(rig.M + 9 * sc, (double)ks.u, (double)ks.v);
-                const Vec3 tm = {rig.t[3 * mc], rig.t[3 * mc + 1], rig.t[3 * mc + 2]};
-                const Vec3 ts = {rig.t[3 * sc], rig.t[3 * sc + 1], rig.t[3 * sc + 2]};
-                Wc[k] = skew_ray_solve(hm, hs, tm, ts).W;
-            }
-            const double dx = Wc[0].x - Wc[1].x, dy = Wc[0].y - Wc[1].y, dz = Wc[0].z - Wc[1].z;
+                const double *pcq = rig.pairc + 6 * qk;
+                const PairSolve o = pair_solve_fast<true>(make_ray(rig.M + 9 * mc, km.u, km.v),
+                                                          make_ray(rig.M + 9 * sc, ks.u, ks.v),
+                                                          Vec3{pcq[0], pcq[1], pcq[2]}, Vec3{pcq[3], pcq[4], pcq[5]});
+                return o.sw;  // = 2 W
+            };
+            const Vec3 w0 = centre_of(0);
+            const Vec3 wq = centre_of(qq);
+            const double dx = 0.5 * (w0.x - wq.x), dy = 0.5 * (w0.y - wq.y), dz = 0.5 * (w0.z - wq.z);
             const double cd = sqrt(fma(dz, dz, fma(dy, dy, dx * dx)));  // :124
             if (cd > prm.ctol) atomicOr(&fflag[w], kSlow);                // :125
         }
@@ -401,9 +432,7 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_single(int
         }
         __syncthreads();
         // ---- rare: frames the speculation could not resolve -> the reference's full algorithm
-        unsigned long long slow_mask = 0ull;
-        for (int w = 0; w < nf; w++)
-            if (fflag[w] & kSlow) slow_mask |= 1ull << w;
+        unsigned long long slow_mask = __ballot(lane < nf && (fflag[lane] & kSlow) != 0u);  // T <= 64
         __syncthreads();
         if (slow_mask) {
             double *slab = reinterpret_cast<double *>(scratch + (size_t)blockIdx.x * scratch_per_block);

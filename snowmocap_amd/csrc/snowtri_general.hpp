@@ -20,10 +20,6 @@ namespace snowtri {
 constexpr int kRecomputeMaxKn = 256;          // joints handled per lane in phase 3: lane + 64 p, p < 4
 constexpr int kRayChunkBytes = 32 * 1024;     // LDS budget for one chunk of rays
 
-struct RayRec {  // one world ray in LDS: direction (un-normalised) and its squared norm
-    double x, y, z, a;
-};
-
 __host__ __device__ constexpr size_t recompute_scratch_bytes(int64_t Kc) {
     return (((size_t)Kc * 64) + 1024 + 255) & ~(size_t)255;
 }
@@ -36,45 +32,6 @@ __host__ __device__ inline int recompute_chunk_joints(int R, int J, int score_by
 __host__ __device__ inline size_t recompute_lds_bytes(int R, int J, int kn, int score_bytes) {
     const int jc = recompute_chunk_joints(R, J, score_bytes);
     return (size_t)jc * R * (32 + score_bytes) + (size_t)(kBlock / 64) * kn * 32 + 256;
-}
-
-// fast-math pair solve shared by phases 1 and 3 (same formulas as k_fused_single)
-struct PairSolve {
-    double score_base;  // idist * 0.001 (multiply by (sm+ss)/2)
-    double dist;
-    Vec3 sw;            // Wm + Ws
-    bool singular;
-};
-
-template <bool kNeedW>
-__device__ __forceinline__ PairSolve pair_solve_fast(const RayRec &rm, const RayRec &rs, const Vec3 &d,
-                                                     const Vec3 &tsum) {
-    const double b = fma(rm.z, rs.z, fma(rm.y, rs.y, rm.x * rs.x));
-    const double det = fma(rm.a, rs.a, -(b * b));
-    const double e = fma(rm.z, d.z, fma(rm.y, d.y, rm.x * d.x));
-    const double g = fma(rs.z, d.z, fma(rs.y, d.y, rs.x * d.x));
-    const double inv = rcp_nr2(det);
-    const double S0 = fma(rs.a, e, -(b * g)) * inv;
-    const double S1 = fma(rm.a, g, -(b * e)) * inv;
-    const Vec3 df = {fma(rs.x, S1, fma(rm.x, S0, -d.x)), fma(rs.y, S1, fma(rm.y, S0, -d.y)),
-                     fma(rs.z, S1, fma(rm.z, S0, -d.z))};
-    const double d2 = dot3(df, df);
-    double idist = rsq_nr1(d2);
-    idist = (d2 == 0.0) ? __builtin_inf() : idist;
-    PairSolve o;
-    o.dist = d2 * idist;
-    o.score_base = idist * 0.001;
-    o.singular = (det == 0.0);
-    if (kNeedW)
-        o.sw = {fma(-rs.x, S1, fma(rm.x, S0, tsum.x)), fma(-rs.y, S1, fma(rm.y, S0, tsum.y)),
-                fma(-rs.z, S1, fma(rm.z, S0, tsum.z))};
-    return o;
-}
-
-template <typename TIn>
-__device__ __forceinline__ RayRec make_ray(const double *__restrict__ M, TIn u, TIn v) {
-    const Vec3 h = ray_from_pixel(M, (double)u, (double)v);
-    return RayRec{h.x, h.y, h.z, dot3(h, h)};
 }
 
 // Dynamic LDS = recompute_lds_bytes(R, J, kn, sizeof(TIn)); scratch = gridDim.x slabs of

@@ -45,6 +45,17 @@ struct Kp3 {  // one detected keypoint as stored in kpts: (u, v, score)
     T u, v, s;
 };
 
+// Accuracy probe of the fast reciprocal / rsqrt helpers (tests/test_gpu_parity.py).
+__global__ __launch_bounds__(kBlock) void k_fastmath_probe(int64_t n, const double *__restrict__ x,
+                                                           double *__restrict__ r2, double *__restrict__ r1,
+                                                           double *__restrict__ q1) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        r2[i] = rcp_nr2(x[i]);
+        r1[i] = rcp_nr1(x[i]);
+        q1[i] = rsq_nr1(x[i]);
+    }
+}
+
 // Rig constants resident in HBM (<= 1.5 KB, L2/scalar-cache resident): M[C][9], t[C][3],
 // pair table [npairs][2] in the reference's loop order mc < sc (triangulation.py:56-58).
 struct Rig {

@@ -15,7 +15,14 @@ struct Params {
     double kthr, avg_thr, dthr;       // Human_Triangulation        (triangulation.py:50)
     double ctol, num_tol, score_tol;  // Human_Triangulation_Condense (triangulation.py:95-100)
     int32_t center, kn;
+    // derived on the host for the throughput kernels
+    double dthr2;    // dist > dthr  <=>  dist^2 > dthr2   (dthr < 0: -1, so every finite dist^2 exceeds it)
+    float kthr_f32;  // smallest float >= kthr: for a float s,  s < kthr  <=>  s < kthr_f32  (exactly)
 };
+
+// `s < kthr` of triangulation.py:73 on the stored element type, without widening float scores.
+__device__ __forceinline__ bool below_kthr(float s, const Params &p) { return s < p.kthr_f32; }
+__device__ __forceinline__ bool below_kthr(double s, const Params &p) { return s < p.kthr; }
 
 struct Vec3 {
     double x, y, z;
@@ -38,6 +45,10 @@ __device__ __forceinline__ Vec3 ray_from_pixel(const double *__restrict__ M, dou
 // reference evaluates this in float32 (NumPy scalar arithmetic) -- reproduced by the overload.
 __device__ __forceinline__ double half_score(float sm, float ss) { return (double)((sm + ss) * 0.5f); }
 __device__ __forceinline__ double half_score(double sm, double ss) { return (sm + ss) * 0.5; }
+
+// sm + ss with the reference's evaluation type (float32 scalars add in float32), widened to double
+__device__ __forceinline__ double sum_score(float sm, float ss) { return (double)(sm + ss); }
+__device__ __forceinline__ double sum_score(double sm, double ss) { return sm + ss; }
 
 struct SkewOut {
     Vec3 W;       // midpoint (Wm + Ws) / 2
@@ -96,6 +107,49 @@ __device__ __forceinline__ double rsq_nr1(double x) {
     double y = __builtin_amdgcn_rsq(x);
     const double e = fma(-(x * y), y, 1.0);  // 1 - x y^2
     return fma(y * 0.5, e, y);               // y (1 + e/2)
+}
+
+struct RayRec {  // one world ray in LDS: direction (un-normalised) and its squared norm
+    double x, y, z, a;
+};
+
+// fast-math pair solve (k_frame_recompute phases 1/3, centre check of k_fused_single)
+struct PairSolve {
+    double score_base;  // idist * 0.001 (multiply by (sm+ss)/2)
+    double dist;
+    Vec3 sw;            // Wm + Ws
+    bool singular;
+};
+
+template <bool kNeedW>
+__device__ __forceinline__ PairSolve pair_solve_fast(const RayRec &rm, const RayRec &rs, const Vec3 &d,
+                                                     const Vec3 &tsum) {
+    const double b = fma(rm.z, rs.z, fma(rm.y, rs.y, rm.x * rs.x));
+    const double det = fma(rm.a, rs.a, -(b * b));
+    const double e = fma(rm.z, d.z, fma(rm.y, d.y, rm.x * d.x));
+    const double g = fma(rs.z, d.z, fma(rs.y, d.y, rs.x * d.x));
+    const double inv = rcp_nr2(det);
+    const double S0 = fma(rs.a, e, -(b * g)) * inv;
+    const double S1 = fma(rm.a, g, -(b * e)) * inv;
+    const Vec3 df = {fma(rs.x, S1, fma(rm.x, S0, -d.x)), fma(rs.y, S1, fma(rm.y, S0, -d.y)),
+                     fma(rs.z, S1, fma(rm.z, S0, -d.z))};
+    const double d2 = dot3(df, df);
+    double idist = rsq_nr1(d2);
+    idist = (d2 == 0.0) ? __builtin_inf() : idist;
+    PairSolve o;
+    o.dist = d2 * idist;
+    o.score_base = idist * 0.001;
+    o.singular = (det == 0.0);
+    if (kNeedW)
+        o.sw = {fma(-rs.x, S1, fma(rm.x, S0, tsum.x)), fma(-rs.y, S1, fma(rm.y, S0, tsum.y)),
+                fma(-rs.z, S1, fma(rm.z, S0, tsum.z))};
+    return o;
+}
+
+template <typename TIn>
+__device__ __forceinline__ RayRec make_ray(const double *__restrict__ M, TIn u, TIn v) {
+    const Vec3 h = ray_from_pixel(M, (double)u, (double)v);
+    return RayRec{h.x, h.y, h.z, dot3(h, h)};
 }
 
 __device__ __forceinline__ double wave_sum(double v) {

@@ -196,12 +196,13 @@ def test_fast_path_falls_back_per_frame(api):
     from oracle import oracle as orc
     wl = synth.config_workload(2, 200, seed=5)
     kp = wl["kpts"]
-    kp[3, 1, 0, :, 2] = -4.0            # negative confidences -> candidate means < 0 -> dropped
     kp[77, 2, 0, :, :2] += 400.0        # one camera far off -> centre joints > tol apart
     kp[150, :, 0, 10, 2] = 1.0          # plain gating only: stays on the fast path
+    kp[3, 1, 0, :, 2] = -4.0            # negative confidences are gated to 0 (kthr >= 0): fast path
     npers = wl["n_persons"].copy()
     npers[120, 3] = 0                    # a camera without detection
-    prm = dict(wl["params"], condense_distance_tol=0.5, keypoint_score_threshold=-10.0)
+    prm = dict(wl["params"], condense_distance_tol=0.5, condense_score_tol=0.2)
+    kp[33, :, 0, :, 2] = 0.0            # everything gated -> fused mean 0 < score_tol -> person dropped
     K, R, t = wl["rig"]
     ref = orc.triangulate_condense_batch(K, R, t, kp, npers, orc.make_params(**prm), 4)
     bt = api.BatchTriangulator(K, R, t, prm, pout_max=4, out_dtype=np.float64)
@@ -209,8 +210,9 @@ def test_fast_path_falls_back_per_frame(api):
     slow = bt.ctx.last_slow_frames()
     bt.close()
     assert np.array_equal(out["count"], ref["count"])
+    assert ref["count"][33] == 0 and ref["count"][77] >= 1
     fast = (out["flags"] & _lib.FLAG_FASTPATH) != 0
-    assert not fast[3] and not fast[77] and not fast[120] and fast[150]
+    assert not fast[77] and not fast[120] and not fast[33] and fast[150] and fast[3]
     assert slow == int((~fast).sum()) and 3 <= slow <= 20
     for f in range(200):
         m = int(ref["count"][f])
@@ -218,6 +220,19 @@ def test_fast_path_falls_back_per_frame(api):
         if m:
             assert_scores_close(out["xyzs"][f, :m, :, 3], ref["kscore"][f, :m])
             assert_xyz_close(out["xyzs"][f, :m, :, :3], ref["xyz"][f, :m], XYZ_FUSED, score_ref=ref["kscore"][f, :m])
+    # a negative keypoint threshold disables the fast path altogether (negative scores could then
+    # pull a candidate mean below average_score_threshold): general kernel, same answers
+    prm2 = dict(prm, keypoint_score_threshold=-10.0)
+    ref2 = orc.triangulate_condense_batch(K, R, t, kp, npers, orc.make_params(**prm2), 4)
+    bt = api.BatchTriangulator(K, R, t, prm2, pout_max=4, out_dtype=np.float64)
+    out2 = bt.run_host(kp, npers)
+    bt.close()
+    assert np.array_equal(out2["count"], ref2["count"]) and not (out2["flags"] & _lib.FLAG_FASTPATH).any()
+    for f in (3, 33, 77, 150):
+        m = int(ref2["count"][f])
+        if m:
+            assert_scores_close(out2["xyzs"][f, :m, :, 3], ref2["kscore"][f, :m])
+            assert_xyz_close(out2["xyzs"][f, :m, :, :3], ref2["xyz"][f, :m], XYZ_FUSED, score_ref=ref2["kscore"][f, :m])
 
 
 # ------------------------------------------------------------- full BASELINE sizes: properties
@@ -314,3 +329,19 @@ def test_general_kernels_agree(api, mode, monkeypatch):
         assert_scores_close(out["xyzs"][f, :1, :, 3], ref["kscore"][f, :1])
         assert_xyz_close(out["xyzs"][f, :1, :, :3], ref["xyz"][f, :1], XYZ_FUSED)
         assert not out["xyzs"][f, 1:].any()
+
+
+def test_fastmath_helpers_accuracy_contract(api):
+    """rcp_nr2 ~ 1 ulp, rcp_nr1 / rsq_nr1 <= 1e-14 relative over +-300 decades (normal range): the
+    bounds DESIGN.md §2 relies on for the throughput kernels."""
+    from snowmocap_amd import _lib
+    ctx = _lib.scratch_context()
+    rng = np.random.default_rng(0)
+    n = 100000
+    x = rng.uniform(1, 10, n) * 10.0 ** rng.integers(-300, 301, n)
+    xs = x * rng.choice([-1.0, 1.0], n)
+    r2, r1, q1 = np.empty(n), np.empty(n), np.empty(n)
+    _lib.check(_lib.lib().snowtri_fastmath_probe(ctx.handle, n, _lib.ptr(xs), _lib.ptr(r2), _lib.ptr(r1), _lib.ptr(q1)), "probe")
+    assert np.abs(r2 * xs - 1).max() < 4e-16 and np.abs(r1 * xs - 1).max() < 1e-14
+    _lib.check(_lib.lib().snowtri_fastmath_probe(ctx.handle, n, _lib.ptr(x), _lib.ptr(r2), _lib.ptr(r1), _lib.ptr(q1)), "probe")
+    assert (np.abs(q1 * q1 * x - 1) / 2).max() < 1e-14
