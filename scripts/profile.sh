@@ -6,18 +6,23 @@ ROOT=$PWD
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
-BENCH="python $ROOT/bench.py --steps 50 --warmup 5 --no-cpu-baseline"
+# the bench command whose JSON line the numbers below belong to (configs[1]: 10 000 frames per launch)
+BENCH="python $ROOT/bench.py --steps 200 --warmup 20 --no-cpu-baseline --large-frames 0"
+LARGE="python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --large-frames 2000000"
 cd /tmp
 # 1. per-kernel time (no counters)
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats -o stats -- $BENCH > $OUT/stats_bench.log 2>&1
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats_large -o stats -- $LARGE > $OUT/stats_large_bench.log 2>&1
 # 2. HBM traffic: separate passes (TCC slots: FETCH_SIZE 3, WRITE_SIZE 2)
-rocprofv3 --output-format csv --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o fetch -- $BENCH --large-frames 0 > $OUT/pmc_fetch.log 2>&1
-rocprofv3 --output-format csv --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o write -- $BENCH --large-frames 0 > $OUT/pmc_write.log 2>&1
-rocprofv3 --output-format csv --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $OUT/pmc_sq -o sq -- $BENCH --large-frames 0 > $OUT/pmc_sq.log 2>&1
+rocprofv3 --output-format csv --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o fetch -- $BENCH > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --output-format csv --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o write -- $BENCH > $OUT/pmc_write.log 2>&1
+rocprofv3 --output-format csv --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $OUT/pmc_sq -o sq -- $LARGE > $OUT/pmc_sq.log 2>&1
 cd $ROOT
 python scripts/summarize_profile.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
+grep -h '"metric"' $OUT/stats_bench.log $OUT/stats_large_bench.log > $OUT/bench_lines.jsonl
 # keep the merge small: drop raw traces, keep CSV summaries
 find $OUT -name "*.db" -delete 2>/dev/null
-find $OUT -name "*kernel_trace.csv" -size +2M -delete 2>/dev/null
+find $OUT -name "*kernel_trace.csv" -delete 2>/dev/null
+find $OUT -name "*counter_collection.csv" -size +1M -delete 2>/dev/null
 du -sh $OUT

@@ -26,7 +26,8 @@ for tag in ("pmc_fetch", "pmc_write", "pmc_sq"):
     for path in files:
         acc = defaultdict(lambda: defaultdict(list))
         for r in csv.DictReader(open(path)):
-            acc[r.get("Kernel_Name", "")[:80]][r.get("Counter_Name")].append(float(r.get("Counter_Value", 0)))
+            key = r.get("Kernel_Name", "")[:80] + " grid=" + str(r.get("Grid_Size") or r.get("Grid_Size_X") or "?")
+            acc[key][r.get("Counter_Name")].append(float(r.get("Counter_Value", 0)))
         print(f"== {os.path.relpath(path, out)}")
         for kname, ctrs in acc.items():
             if "snowtri" not in kname:

@@ -115,6 +115,13 @@ struct Vec4T {
     T x, y, z, w;
 };
 
+// LDS bytes the fast kernel needs for T frames per tile.
+__host__ __device__ constexpr size_t fused_single_lds_bytes(int T, int kn, int NP) {
+    const size_t a = (((size_t)T * kn * 8 + (size_t)T * 4 + 16) + 15) & ~(size_t)15;
+    const size_t b = (condense_lds_bytes(NP) + 15) & ~(size_t)15;
+    return (a > b ? a : b) + 8 * 9 * 8;  // + ray matrices of up to 8 cameras
+}
+
 // ------------------------------------------------------------------------------------------------
 // One (frame, joint) of the single-detection fast path: C rays, all C(C,2) pair solves, fusion.
 // Returns true if the item needs the IEEE-exact general routine (a pair whose dist^2 is not a
@@ -125,13 +132,17 @@ struct Vec4T {
 //   alpha_c = sum_{q: c=m} s_q S0_q - sum_{q: c=s} s_q S1_q,   beta_c = sum_{q contains c} s_q,
 // so a pair costs 2 FMA + 2 adds here instead of 9 FMA, and sum_q s_q = (sum_c beta_c) / 2.
 template <int C, typename TIn>
-__device__ __forceinline__ bool pairwise_item(const Rig &rig, const Kp3<TIn> (&cur)[C], const Params &prm,
-                                              double &ox, double &oy, double &oz, double &os) {
-    // Rig constants are wave-uniform: scalar loads issued per item (pointers laundered so the loads
-    // are not hoisted out of the item loop: ~70 live doubles would cost ~140 registers).
+__device__ __forceinline__ bool pairwise_item(const Rig &rig, const double *__restrict__ Mlds,
+                                              const Kp3<TIn> (&cur)[C], const Params &prm, double &ox,
+                                              double &oy, double &oz, double &os) {
+    // Rig constants are wave-uniform.  The 36 ray-matrix entries come from LDS (broadcast reads: no
+    // SGPRs, transient VGPRs); the per-pair d vectors and camera centres are scalar loads issued per
+    // item (pointers laundered so the loads are not hoisted: hoisting all ~70 doubles costs ~140
+    // registers and pushes every loop-invariant scalar into VGPR-lane spills).
     typedef const __attribute__((address_space(4))) double *cptr;  // AMDGPU constant address space
-    cptr Mp = (cptr)(uintptr_t)rig.M, pc = (cptr)(uintptr_t)rig.pairc, tp = (cptr)(uintptr_t)rig.t;
-    asm volatile("" : "+s"(Mp), "+s"(pc), "+s"(tp));
+    cptr pc = (cptr)(uintptr_t)rig.pairc, tp = (cptr)(uintptr_t)rig.t;
+    asm volatile("" : "+s"(pc), "+s"(tp));
+    const double *Mp = Mlds;
     Vec3 h[C];
     double a[C], alpha[C], beta[C];
     bool pass[C];
@@ -313,9 +324,12 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_single(int
     const int kn = prm.kn, ci = prm.center;
     double *stash = reinterpret_cast<double *>(smem);                        // [T][kn] fused joint scores
     uint32_t *fflag = reinterpret_cast<uint32_t *>(stash + (size_t)T * kn);  // [T]
+    // ray matrices M[C][9] live at the very end of the allocation (general_frame reuses the front)
+    double *Mlds = reinterpret_cast<double *>(smem + fused_single_lds_bytes(T, kn, NP) - sizeof(double) * 9 * C);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const PackedWriter<TOut> wr{out4, out_ps};
     const Kp3<TIn> *kp3 = reinterpret_cast<const Kp3<TIn> *>(kpts);
+    if (tid < 9 * C) Mlds[tid] = rig.M[tid];  // visible after the first __syncthreads() below
     const double inv_np = 1.0 / (double)NP;
     const int dfl = kBlock / J, dj = kBlock - dfl * J;
     const int64_t ntiles = (F + T - 1) / T;
@@ -332,10 +346,11 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_single(int
         {
             int fl = tid / J, j = tid - fl * J;
             Kp3<TIn> bufA[C], bufB[C];
+            const Kp3<TIn> *tile_in = kp3 + f0 * C * (int64_t)J;  // wave-uniform base, 32-bit lane offsets
             auto fetch = [&](Kp3<TIn>(&dst)[C], int fl_, int j_) {
-                const Kp3<TIn> *p = kp3 + ((f0 + fl_) * C) * (int64_t)J + j_;
+                const unsigned off = (unsigned)(fl_ * C * J + j_);
 #pragma unroll
-                for (int c = 0; c < C; c++) dst[c] = p[(size_t)c * J];
+                for (int c = 0; c < C; c++) dst[c] = tile_in[off + (unsigned)(c * J)];
             };
             auto advance = [&](int &fl_, int &j_) {
                 fl_ += dfl;
@@ -349,19 +364,17 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_single(int
                 double ox, oy, oz, os;
                 bool bad;
                 if constexpr (METHOD == 0) {
-                    bad = pairwise_item<C>(rig, buf, prm, ox, oy, oz, os);
+                    bad = pairwise_item<C>(rig, Mlds, buf, prm, ox, oy, oz, os);
                 } else {
                     bad = false;
                     dlt_item<C>(rig, buf, n_persons ? n_persons + (f0 + fl_) * C : nullptr, prm, ox, oy, oz, os);
                 }
                 if (j_ < kn) {
-                    const int64_t f = f0 + fl_;
-                    Vec4T<TOut> o4 = {(TOut)ox, (TOut)oy, (TOut)oz, (TOut)os};
-                    *reinterpret_cast<Vec4T<TOut> *>(out4 + ((f * Pout) * (int64_t)kn + j_) * 4) = o4;
-                    for (int slot = 1; slot < Pout; slot++) {
-                        Vec4T<TOut> z4 = {(TOut)0, (TOut)0, (TOut)0, (TOut)0};
-                        *reinterpret_cast<Vec4T<TOut> *>(out4 + ((f * Pout + slot) * (int64_t)kn + j_) * 4) = z4;
-                    }
+                    Vec4T<TOut> *tile_out = reinterpret_cast<Vec4T<TOut> *>(out4) + f0 * Pout * (int64_t)kn;
+                    const unsigned o = (unsigned)(fl_ * Pout * kn + j_);
+                    tile_out[o] = Vec4T<TOut>{(TOut)ox, (TOut)oy, (TOut)oz, (TOut)os};
+                    for (int slot = 1; slot < Pout; slot++)
+                        tile_out[o + (unsigned)(slot * kn)] = Vec4T<TOut>{(TOut)0, (TOut)0, (TOut)0, (TOut)0};
                     stash[fl_ * kn + j_] = os;
                 }
                 if (bad) atomicOr(&fflag[fl_], kSlow);
@@ -444,13 +457,6 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_single(int
             }
         }
     }
-}
-
-// LDS bytes the fast kernel needs for T frames per tile.
-__host__ __device__ constexpr size_t fused_single_lds_bytes(int T, int kn, int NP) {
-    const size_t a = (size_t)T * kn * 8 + (size_t)T * 4 + 16;
-    const size_t b = condense_lds_bytes(NP);
-    return a > b ? a : b;
 }
 
 }  // namespace snowtri
