@@ -106,6 +106,10 @@ __global__ __launch_bounds__(kBlock) void k_frame_general(int64_t F, int Pmax, i
 //   every candidate's centre joint lies within condense_distance_tol of candidate 0's
 //   (seed 0 then absorbs all: one cluster);  the fused mean score is not below condense_score_tol.
 // Minimum waves per SIMD the fast kernel is compiled for (caps its VGPR allocation: 4 -> 128).
+// Depth of the register prefetch ring of k_fused_single (2 or 3 keypoint buffers per lane).
+#ifndef SNOWTRI_RING
+#define SNOWTRI_RING 2
+#endif
 #ifndef SNOWTRI_FAST_WAVES
 #define SNOWTRI_FAST_WAVES 2
 #endif
@@ -116,10 +120,49 @@ struct Vec4T {
 };
 
 // LDS bytes the fast kernel needs for T frames per tile.
+constexpr size_t kFusedConstBytes = 8 * (12 * 8 + 3 * 28);  // M, t of <= 8 cameras + d of <= 28 pairs
+
 __host__ __device__ constexpr size_t fused_single_lds_bytes(int T, int kn, int NP) {
     const size_t a = (((size_t)T * kn * 8 + (size_t)T * 4 + 16) + 15) & ~(size_t)15;
     const size_t b = (condense_lds_bytes(NP) + 15) & ~(size_t)15;
-    return (a > b ? a : b) + 8 * 9 * 8;  // + ray matrices of up to 8 cameras
+    return (a > b ? a : b) + kFusedConstBytes;
+}
+
+// ---- item cursor / fetch helpers of k_fused_single ------------------------------------------------
+__device__ __forceinline__ void advance_item(int &fl, int &j, int dfl, int dj, int J) {
+    fl += dfl;  // next item of this lane is kBlock items further: (fl, j) += (kBlock / J, kBlock % J)
+    j += dj;
+    if (j >= J) {
+        j -= J;
+        fl++;
+    }
+}
+
+// Loads are issued UNCONDITIONALLY (item index clamped into the tile): the compiler can then count
+// exactly how many vector-memory operations are younger than the buffer it is about to read and emits
+// s_waitcnt vmcnt(N>0); with conditional fetches it falls back to vmcnt(0) and the ring is useless.
+template <int C, typename TIn>
+__device__ __forceinline__ void fetch_item(Kp3<TIn> (&dst)[C], const Kp3<TIn> *__restrict__ tile_in, int fl,
+                                           int j, int J, unsigned last_off) {
+    unsigned off = (unsigned)(fl * C * J + j);
+    off = off < last_off ? off : last_off;
+#pragma unroll
+    for (int c = 0; c < C; c++) dst[c] = tile_in[off + (unsigned)(c * J)];
+}
+
+// first two items of this lane in tile `tile` -> bufA, bufB
+template <int C, typename TIn>
+__device__ __forceinline__ void prefetch_tile_head(Kp3<TIn> (&bufA)[C], Kp3<TIn> (&bufB)[C],
+                                                   const Kp3<TIn> *__restrict__ kp3, int64_t tile, int T,
+                                                   int64_t F, int J, int tid, int dfl, int dj) {
+    const int64_t f0 = tile * T;
+    const int nf = (int)((F - f0) < T ? (F - f0) : T);
+    const unsigned last_off = (unsigned)((nf - 1) * C * J + J - 1);
+    const Kp3<TIn> *tile_in = kp3 + f0 * C * (int64_t)J;
+    int fl = tid / J, j = tid - fl * J;
+    fetch_item<C>(bufA, tile_in, fl, j, J, last_off);
+    advance_item(fl, j, dfl, dj, J);
+    fetch_item<C>(bufB, tile_in, fl, j, J, last_off);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -135,17 +178,41 @@ template <int C, typename TIn>
 __device__ __forceinline__ bool pairwise_item(const Rig &rig, const double *__restrict__ Mlds,
                                               const Kp3<TIn> (&cur)[C], const Params &prm, double &ox,
                                               double &oy, double &oz, double &os) {
-    // Rig constants are wave-uniform.  The 36 ray-matrix entries come from LDS (broadcast reads: no
-    // SGPRs, transient VGPRs); the per-pair d vectors and camera centres are scalar loads issued per
-    // item (pointers laundered so the loads are not hoisted: hoisting all ~70 doubles costs ~140
-    // registers and pushes every loop-invariant scalar into VGPR-lane spills).
-    typedef const __attribute__((address_space(4))) double *cptr;  // AMDGPU constant address space
-    cptr pc = (cptr)(uintptr_t)rig.pairc, tp = (cptr)(uintptr_t)rig.t;
-    asm volatile("" : "+s"(pc), "+s"(tp));
-    const double *Mp = Mlds;
+    // Rig constants are wave-uniform and all come from LDS (broadcast reads into transient VGPRs):
+    // ray matrices M[C][9], camera centres t[C][3], per-pair d = t_s - t_m.  Holding the ~70 doubles
+    // in scalar registers instead overflows the SGPR file: loop-invariant scalars then live in
+    // VGPR-lane spills and the remainder is re-fetched with serialised scalar loads every item.
+#if defined(SNOWTRI_CONST_IN_VGPR) || !defined(SNOWTRI_BULK_CONST)
+    const double *Mp = Mlds, *tp = Mlds + 9 * C, *pc = Mlds + 12 * C;
+#else
+    // issue every LDS read of M and d up front (one wait instead of ~25 scattered ones)
+    constexpr int NPc = C * (C - 1) / 2;
+    double Mp[9 * C], pc[3 * NPc];
+#pragma unroll
+    for (int i = 0; i < 9 * C; i++) Mp[i] = Mlds[i];
+#pragma unroll
+    for (int i = 0; i < 3 * NPc; i++) pc[i] = Mlds[12 * C + i];
+    __builtin_amdgcn_sched_barrier(0);
+    const double *tp = Mlds + 9 * C;
+#endif
+#ifdef SNOWTRI_MEMTEST  // dev experiment: memory path only, no solves
+    {
+        double su = 0, sv = 0, ss = 0;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            su += (double)cur[c].u;
+            sv += (double)cur[c].v;
+            ss += (double)cur[c].s;
+        }
+        ox = su;
+        oy = sv;
+        oz = ss;
+        os = su + sv;
+        return false;
+    }
+#endif
     Vec3 h[C];
     double a[C], alpha[C], beta[C];
-    bool pass[C];
 #pragma unroll
     for (int c = 0; c < C; c++) {
         // A1, camera.py:241-243 with M = R inv(K); (mul, fma, add) keeps the constant column a scalar operand
@@ -154,9 +221,6 @@ __device__ __forceinline__ bool pairwise_item(const Rig &rig, const double *__re
         h[c].y = fma(Mp[9 * c + 4], v, Mp[9 * c + 3] * u) + Mp[9 * c + 5];
         h[c].z = fma(Mp[9 * c + 7], v, Mp[9 * c + 6] * u) + Mp[9 * c + 8];
         a[c] = dot3(h[c], h[c]);
-        pass[c] = !below_kthr(cur[c].s, prm);  // :73
-        alpha[c] = 0.0;
-        beta[c] = 0.0;
     }
     bool bad = false;
     int q = 0;
@@ -166,7 +230,7 @@ __device__ __forceinline__ bool pairwise_item(const Rig &rig, const double *__re
         for (int sc = mc + 1; sc < C; sc++, q++) {
             // A2 (triangulation.py:24-31): per-ray norms hoisted, d = ts - tm precomputed
             const Vec3 &hm = h[mc], &hs = h[sc];
-            const Vec3 d = {pc[6 * q], pc[6 * q + 1], pc[6 * q + 2]};
+            const Vec3 d = {pc[3 * q], pc[3 * q + 1], pc[3 * q + 2]};
             const double b = dot3(hm, hs);
             const double det = fma(a[mc], a[sc], -(b * b));
             const double e = dot3(hm, d), g = dot3(hs, d);
@@ -178,34 +242,54 @@ __device__ __forceinline__ bool pairwise_item(const Rig &rig, const double *__re
                              fma(hs.z, S1, fma(hm.z, S0, -d.z))};
             const double d2 = dot3(df, df);
             const double idist = rsq_nr1(d2);
-            // :72  ((sm+ss)/2) / (dist*1000); the halving is exact, so it is folded into the constant
-            double sq = sum_score(cur[mc].s, cur[sc].s) * (idist * 0.0005);
-            const bool keep = pass[mc] & pass[sc] & !(d2 > prm.dthr2);  // :73-74
-            sq = keep ? sq : 0.0;
+            // :72-74  score = ((sm+ss)/2) / (dist*1000), zeroed by the three gates.  The gate is applied to
+            // the (element-typed) score sum: items whose 1/dist is not finite take the exact path anyway.
+            const bool keep = !below_kthr(cur[mc].s, prm) && !below_kthr(cur[sc].s, prm) && !(d2 > prm.dthr2);
+            const double sq = gated_sum(cur[mc].s, cur[sc].s, keep) * (idist * 0.0005);  // halving folded in
             bad |= !(d2 > 1e-280);  // exact intersection / singular / NaN / rsq out of range -> exact path
-            alpha[mc] = fma(sq, S0, alpha[mc]);
-            alpha[sc] = fma(-sq, S1, alpha[sc]);
-            beta[mc] += sq;
-            beta[sc] += sq;
+            // first touch of every accumulator happens in the pairs with mc == 0 (compile-time known):
+            // no zero-initialisation, no wasted FMA
+            if (mc == 0) {
+                alpha[sc] = -sq * S1;
+                beta[sc] = sq;
+                if (sc == 1) {
+                    alpha[0] = sq * S0;
+                    beta[0] = sq;
+                } else {
+                    alpha[0] = fma(sq, S0, alpha[0]);
+                    beta[0] += sq;
+                }
+            } else {
+                alpha[mc] = fma(sq, S0, alpha[mc]);
+                alpha[sc] = fma(-sq, S1, alpha[sc]);
+                beta[mc] += sq;
+                beta[sc] += sq;
+            }
+#ifdef SNOWTRI_PAIR_BARRIER
+            if ((q % SNOWTRI_PAIR_BARRIER) == SNOWTRI_PAIR_BARRIER - 1)
+                __builtin_amdgcn_sched_barrier(0);  // experiment: solve the pairs in groups (fewer live registers)
+#endif
         }
     }
-    double sx = 0.0, sy = 0.0, sz = 0.0, sb = 0.0;
+    double sx = alpha[0] * h[0].x, sy = alpha[0] * h[0].y, sz = alpha[0] * h[0].z, sb = beta[0];
+    sx = fma(beta[0], tp[0], sx);
+    sy = fma(beta[0], tp[1], sy);
+    sz = fma(beta[0], tp[2], sz);
 #pragma unroll
-    for (int c = 0; c < C; c++) {
+    for (int c = 1; c < C; c++) {
         sx = fma(alpha[c], h[c].x, fma(beta[c], tp[3 * c + 0], sx));
         sy = fma(alpha[c], h[c].y, fma(beta[c], tp[3 * c + 1], sy));
         sz = fma(alpha[c], h[c].z, fma(beta[c], tp[3 * c + 2], sz));
         sb += beta[c];
     }
-    const double accS = 0.5 * sb;  // = sum_q s_q  (:141)
-    ox = oy = oz = os = 0.0;
-    if (!(accS == 0.0)) {  // :142-143
-        const double r = rcp_nr1(sb);  // 1 / (2 sum s): the 1/2 of the midpoint folded in
-        ox = sx * r;                   // :144-147 as (sum s (Wm+Ws)) / (2 sum s)
-        oy = sy * r;
-        oz = sz * r;
-        os = accS * (1.0 / (double)(C * (C - 1) / 2));  // :148
-    }
+    // sb = 2 sum_q s_q (:141).  sum == 0 -> the joint stays (0,0,0)/0 (:142-143): then sx = sy = sz = 0 too,
+    // so zeroing the reciprocal is enough.
+    double r = rcp_nr1(sb);  // 1 / (2 sum s): the 1/2 of the midpoint folded in
+    r = (sb == 0.0) ? 0.0 : r;
+    ox = sx * r;  // :144-147 as (sum s (Wm+Ws)) / (2 sum s)
+    oy = sy * r;
+    oz = sz * r;
+    os = sb * (0.5 / (double)(C * (C - 1) / 2));  // :148
     return bad;
 }
 
@@ -324,16 +408,34 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_single(int
     const int kn = prm.kn, ci = prm.center;
     double *stash = reinterpret_cast<double *>(smem);                        // [T][kn] fused joint scores
     uint32_t *fflag = reinterpret_cast<uint32_t *>(stash + (size_t)T * kn);  // [T]
-    // ray matrices M[C][9] live at the very end of the allocation (general_frame reuses the front)
-    double *Mlds = reinterpret_cast<double *>(smem + fused_single_lds_bytes(T, kn, NP) - sizeof(double) * 9 * C);
+    // rig constants M[C][9], t[C][3], d[NP][3] live at the very end of the allocation
+    // (general_frame reuses the front)
+    double *Mlds = reinterpret_cast<double *>(smem + fused_single_lds_bytes(T, kn, NP) - kFusedConstBytes);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const PackedWriter<TOut> wr{out4, out_ps};
     const Kp3<TIn> *kp3 = reinterpret_cast<const Kp3<TIn> *>(kpts);
     if (tid < 9 * C) Mlds[tid] = rig.M[tid];  // visible after the first __syncthreads() below
+    if (tid < 3 * C) Mlds[9 * C + tid] = rig.t[tid];
+    if (tid < 3 * NP) Mlds[12 * C + tid] = rig.pairc[6 * (tid / 3) + tid % 3];
     const double inv_np = 1.0 / (double)NP;
     const int dfl = kBlock / J, dj = kBlock - dfl * J;
     const int64_t ntiles = (F + T - 1) / T;
 
+#ifdef SNOWTRI_CONST_IN_VGPR
+    __syncthreads();
+    double Mreg[12 * C + 3 * NP];  // experiment: all rig constants resident in VGPRs (1 wave / SIMD)
+#pragma unroll
+    for (int i = 0; i < 12 * C + 3 * NP; i++) Mreg[i] = Mlds[i];
+    const double *Mlds_k = Mlds;
+    (void)Mlds_k;
+#define Mlds Mreg
+#endif
+#if SNOWTRI_RING == 3
+    Kp3<TIn> bufA[C], bufB[C], bufC[C];
+#else
+    Kp3<TIn> bufA[C], bufB[C];
+#endif
+    if (blockIdx.x < ntiles) prefetch_tile_head<C>(bufA, bufB, kp3, (int64_t)blockIdx.x, T, F, J, tid, dfl, dj);
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t f0 = tile * T;
         const int nf = (int)((F - f0) < T ? (F - f0) : T);
@@ -341,25 +443,11 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_single(int
         for (int i = tid; i < nf; i += kBlock) fflag[i] = 0;
         __syncthreads();
 
-        // ---- main loop: one lane per (frame, joint).  Two register buffers alternate so the next
-        //      item's keypoints are in flight while the current one is solved (no copies).
+        // ---- main loop: one lane per (frame, joint).  A ring of three register buffers keeps the
+        //      keypoints of the next TWO items in flight while the current one is solved: with only
+        //      two waves per SIMD the kernel is otherwise bound by bytes-in-flight / HBM latency.
+        //      The first two items of a tile were fetched before the previous tile's epilogue.
         {
-            int fl = tid / J, j = tid - fl * J;
-            Kp3<TIn> bufA[C], bufB[C];
-            const Kp3<TIn> *tile_in = kp3 + f0 * C * (int64_t)J;  // wave-uniform base, 32-bit lane offsets
-            auto fetch = [&](Kp3<TIn>(&dst)[C], int fl_, int j_) {
-                const unsigned off = (unsigned)(fl_ * C * J + j_);
-#pragma unroll
-                for (int c = 0; c < C; c++) dst[c] = tile_in[off + (unsigned)(c * J)];
-            };
-            auto advance = [&](int &fl_, int &j_) {
-                fl_ += dfl;
-                j_ += dj;
-                if (j_ >= J) {
-                    j_ -= J;
-                    fl_++;
-                }
-            };
             auto solve_store = [&](const Kp3<TIn>(&buf)[C], int fl_, int j_) {
                 double ox, oy, oz, os;
                 bool bad;
@@ -373,26 +461,59 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_single(int
                     Vec4T<TOut> *tile_out = reinterpret_cast<Vec4T<TOut> *>(out4) + f0 * Pout * (int64_t)kn;
                     const unsigned o = (unsigned)(fl_ * Pout * kn + j_);
                     tile_out[o] = Vec4T<TOut>{(TOut)ox, (TOut)oy, (TOut)oz, (TOut)os};
-                    for (int slot = 1; slot < Pout; slot++)
-                        tile_out[o + (unsigned)(slot * kn)] = Vec4T<TOut>{(TOut)0, (TOut)0, (TOut)0, (TOut)0};
                     stash[fl_ * kn + j_] = os;
                 }
                 if (bad) atomicOr(&fflag[fl_], kSlow);
             };
-            if (tid < nitems) fetch(bufA, fl, j);
-            for (int it = tid; it < nitems; it += 2 * kBlock) {
-                int fl2 = fl, j2 = j;
-                advance(fl2, j2);
-                const bool hasB = it + kBlock < nitems;
-                if (hasB) fetch(bufB, fl2, j2);
-                solve_store(bufA, fl, j);
-                if (!hasB) break;
-                fl = fl2;
-                j = j2;
-                advance(fl, j);
-                if (it + 2 * kBlock < nitems) fetch(bufA, fl, j);
-                solve_store(bufB, fl2, j2);
+            const Kp3<TIn> *tile_in = kp3 + f0 * C * (int64_t)J;  // wave-uniform base, 32-bit lane offsets
+            const unsigned last_off = (unsigned)((nf - 1) * C * J + J - 1);
+            // item k of this lane is tid + k*kBlock -> (fl, j); two cursors walk the ring
+            const int n_my = tid < nitems ? (nitems - tid + kBlock - 1) / kBlock : 0;
+            int fs = tid / J, js = tid - fs * J;  // item being solved
+            int ff = fs, jf = js;                 // item being fetched: two ahead
+            advance_item(ff, jf, dfl, dj, J);
+            advance_item(ff, jf, dfl, dj, J);
+#if SNOWTRI_RING == 3
+            for (int k = 0; k < n_my; k += 3) {
+                fetch_item<C>(bufC, tile_in, ff, jf, J, last_off);
+                solve_store(bufA, fs, js);
+                advance_item(fs, js, dfl, dj, J);
+                advance_item(ff, jf, dfl, dj, J);
+                fetch_item<C>(bufA, tile_in, ff, jf, J, last_off);
+                if (k + 1 < n_my) solve_store(bufB, fs, js);
+                advance_item(fs, js, dfl, dj, J);
+                advance_item(ff, jf, dfl, dj, J);
+                fetch_item<C>(bufB, tile_in, ff, jf, J, last_off);
+                if (k + 2 < n_my) solve_store(bufC, fs, js);
+                advance_item(fs, js, dfl, dj, J);
+                advance_item(ff, jf, dfl, dj, J);
             }
+#else  // ring of two: bufA / bufB alternate, fetch distance 2 items (the solved buffer is refilled at once)
+            for (int k = 0; k < n_my; k += 2) {
+                solve_store(bufA, fs, js);
+                fetch_item<C>(bufA, tile_in, ff, jf, J, last_off);
+                advance_item(fs, js, dfl, dj, J);
+                advance_item(ff, jf, dfl, dj, J);
+                if (k + 1 < n_my) solve_store(bufB, fs, js);
+                fetch_item<C>(bufB, tile_in, ff, jf, J, last_off);
+                advance_item(fs, js, dfl, dj, J);
+                advance_item(ff, jf, dfl, dj, J);
+            }
+#endif
+            // unused person slots are zero-filled here, NOT inside the item loop: a store loop with a
+            // run-time trip count there makes the compiler's vmcnt bookkeeping give up and wait for
+            // every outstanding load (vmcnt(0)) at each item, which defeats the prefetch ring
+            if (Pout > 1) {
+                Vec4T<TOut> *tile_out = reinterpret_cast<Vec4T<TOut> *>(out4) + f0 * Pout * (int64_t)kn;
+                const int per = (Pout - 1) * kn;
+                for (int i = tid; i < nf * per; i += kBlock) {
+                    const int w = i / per, r = i - w * per;
+                    tile_out[(unsigned)(w * Pout * kn + kn + r)] = Vec4T<TOut>{(TOut)0, (TOut)0, (TOut)0, (TOut)0};
+                }
+            }
+            // next tile of this workgroup: start its first two fetches now, they fly during the epilogue
+            const int64_t nt = tile + gridDim.x;
+            if (nt < ntiles) prefetch_tile_head<C>(bufA, bufB, kp3, nt, T, F, J, tid, dfl, dj);  // wave-uniform
         }
 
         // ---- single-cluster check (:116-130): candidate q >= 1 must have its centre joint within
@@ -458,5 +579,8 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_single(int
         }
     }
 }
+#ifdef SNOWTRI_CONST_IN_VGPR
+#undef Mlds
+#endif
 
 }  // namespace snowtri

@@ -50,6 +50,10 @@ __device__ __forceinline__ double half_score(double sm, double ss) { return (sm 
 __device__ __forceinline__ double sum_score(float sm, float ss) { return (double)(sm + ss); }
 __device__ __forceinline__ double sum_score(double sm, double ss) { return sm + ss; }
 
+// sm + ss (reference evaluation type) if the pair passes its gates, else 0 -- selected before widening
+__device__ __forceinline__ double gated_sum(float sm, float ss, bool keep) { return (double)(keep ? sm + ss : 0.0f); }
+__device__ __forceinline__ double gated_sum(double sm, double ss, bool keep) { return keep ? sm + ss : 0.0; }
+
 struct SkewOut {
     Vec3 W;       // midpoint (Wm + Ws) / 2
     double dist;  // ||Wm - Ws||
