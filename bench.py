@@ -69,6 +69,9 @@ def main():
     ap.add_argument("--pool", type=int, default=32, help="distinct HBM-resident input batches cycled through")
     ap.add_argument("--large-frames", type=int, default=2000000,
                     help="extra single-launch roofline run (0 = skip); SURVEY §8d asks for >= 2e6 frames")
+    ap.add_argument("--streams", type=int, default=2,
+                    help="HIP streams the steps are issued on round-robin (one context each); 2 lets the ramp-up / "
+                         "tail of consecutive 10 000-frame launches overlap")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the RCCL all-gather of the track")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -99,6 +102,10 @@ def main():
     C, P, Pout = Kc.shape[0], 1, 1
     params = wl["params"]
     bt = BatchTriangulator(Kc, Rc, tc, params, pout_max=Pout, out_dtype=np.float32, device=local_rank)
+    nstreams = max(1, args.streams)
+    bts = [bt] + [BatchTriangulator(Kc, Rc, tc, params, pout_max=Pout, out_dtype=np.float32, device=local_rank)
+                  for _ in range(nstreams - 1)]
+    streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
 
     # pool of distinct resident batches: exact projections + N(0, 1 px) noise, scores U(3.5, 8)
     base = torch.from_numpy(wl["kpts"]).to(dev)
@@ -122,20 +129,19 @@ def main():
 
     def step(i):
         b = i % len(pool)
-        bt.run_torch(pool[b], None, out=outs[b])
+        k = i % nstreams
+        bts[k].run_torch(pool[b], None, out=outs[b], stream=streams[k].cuda_stream)
         if gather_on:
             slot = i & 1
             ready = torch.cuda.Event()
-            ready.record(main_stream)
+            ready.record(streams[k])
             side.wait_event(ready)
             with torch.cuda.stream(side):
                 dist.all_gather_into_tensor(gbuf[slot], outs[b]["xyzs"])
                 g_done[slot].record(side)
 
     def fence():
-        if gather_on:
-            main_stream.wait_stream(side)
-        torch.cuda.synchronize(dev)
+        torch.cuda.synchronize(dev)        # every stream of this device, side stream included
         if dist is not None:
             dist.barrier()
 
@@ -236,6 +242,7 @@ def main():
                                    f"steps cycle a pool of {len(pool)} distinct HBM-resident batches",
                        "frames_per_step_per_gpu": F, "cameras": C, "persons": P, "joints": J,
                        "method": "pairwise (reference-exact)", "io": "fp32 in / fp32 out, fp64 math",
+                       "streams": nstreams,
                        "parallelism": f"frames sharded x{world}" + (", all-gather of the track overlapped" if gather_on else "")},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_fused_single<4,float,float>",
@@ -246,7 +253,8 @@ def main():
             "ray_pair_solves_per_s": value * (C * (C - 1) // 2),
         }
         print(json.dumps(line))
-    bt.close()
+    for b_ in bts:
+        b_.close()
     if dist is not None:
         dist.destroy_process_group()
 

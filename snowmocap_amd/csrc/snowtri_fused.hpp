@@ -182,19 +182,7 @@ __device__ __forceinline__ bool pairwise_item(const Rig &rig, const double *__re
     // ray matrices M[C][9], camera centres t[C][3], per-pair d = t_s - t_m.  Holding the ~70 doubles
     // in scalar registers instead overflows the SGPR file: loop-invariant scalars then live in
     // VGPR-lane spills and the remainder is re-fetched with serialised scalar loads every item.
-#if defined(SNOWTRI_CONST_IN_VGPR) || !defined(SNOWTRI_BULK_CONST)
     const double *Mp = Mlds, *tp = Mlds + 9 * C, *pc = Mlds + 12 * C;
-#else
-    // issue every LDS read of M and d up front (one wait instead of ~25 scattered ones)
-    constexpr int NPc = C * (C - 1) / 2;
-    double Mp[9 * C], pc[3 * NPc];
-#pragma unroll
-    for (int i = 0; i < 9 * C; i++) Mp[i] = Mlds[i];
-#pragma unroll
-    for (int i = 0; i < 3 * NPc; i++) pc[i] = Mlds[12 * C + i];
-    __builtin_amdgcn_sched_barrier(0);
-    const double *tp = Mlds + 9 * C;
-#endif
 #ifdef SNOWTRI_MEMTEST  // dev experiment: memory path only, no solves
     {
         double su = 0, sv = 0, ss = 0;
@@ -265,10 +253,6 @@ __device__ __forceinline__ bool pairwise_item(const Rig &rig, const double *__re
                 beta[mc] += sq;
                 beta[sc] += sq;
             }
-#ifdef SNOWTRI_PAIR_BARRIER
-            if ((q % SNOWTRI_PAIR_BARRIER) == SNOWTRI_PAIR_BARRIER - 1)
-                __builtin_amdgcn_sched_barrier(0);  // experiment: solve the pairs in groups (fewer live registers)
-#endif
         }
     }
     double sx = alpha[0] * h[0].x, sy = alpha[0] * h[0].y, sz = alpha[0] * h[0].z, sb = beta[0];
@@ -417,19 +401,9 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_single(int
     if (tid < 9 * C) Mlds[tid] = rig.M[tid];  // visible after the first __syncthreads() below
     if (tid < 3 * C) Mlds[9 * C + tid] = rig.t[tid];
     if (tid < 3 * NP) Mlds[12 * C + tid] = rig.pairc[6 * (tid / 3) + tid % 3];
-    const double inv_np = 1.0 / (double)NP;
     const int dfl = kBlock / J, dj = kBlock - dfl * J;
     const int64_t ntiles = (F + T - 1) / T;
 
-#ifdef SNOWTRI_CONST_IN_VGPR
-    __syncthreads();
-    double Mreg[12 * C + 3 * NP];  // experiment: all rig constants resident in VGPRs (1 wave / SIMD)
-#pragma unroll
-    for (int i = 0; i < 12 * C + 3 * NP; i++) Mreg[i] = Mlds[i];
-    const double *Mlds_k = Mlds;
-    (void)Mlds_k;
-#define Mlds Mreg
-#endif
 #if SNOWTRI_RING == 3
     Kp3<TIn> bufA[C], bufB[C], bufC[C];
 #else
@@ -579,8 +553,5 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_single(int
         }
     }
 }
-#ifdef SNOWTRI_CONST_IN_VGPR
-#undef Mlds
-#endif
 
 }  // namespace snowtri
