@@ -143,6 +143,14 @@ int snowtri_triangulate_condense(snowtri_ctx *ctx, int64_t F, int32_t Pmax, int3
                                  void *out_xyzs, void *out_pscore, int out_dtype, int32_t *out_count,
                                  uint32_t *out_flags, int memspace, void *stream);
 
+/* N1  Human_Triangulation_Smooth / SecondOrderDynamic (triangulation.py:4-22,164-186) over a whole track.
+ * x[T][n] fp64, frame-major, n = persons * joints * 3 lanes (persons matched by index, as the reference does)
+ * -> y[T][n].  Frame 0 passes through and seeds xp = y = x0, yd = 0; f, z, r, dt as in the reference
+ * (main.py:72-77).  Evaluated as a chunked linear scan over frames (results equal the sequential recurrence
+ * to rounding: ~1e-13 m).  T <= 1 + 256 * 65535 frames. */
+int snowtri_smooth_track(snowtri_ctx *ctx, int64_t T, int64_t n, const double *x, double f, double z, double r,
+                         double dt, double *y, int memspace, void *stream);
+
 /* Measurement aid: HIP-event time (ms) of the kernels launched by the LAST
  * snowtri_triangulate_condense call on this context, measured on the stream they ran on
  * (blocks until they finish).  kernel_ms[0] = dominant fused kernel, [1] = everything else. */

@@ -76,6 +76,8 @@ _SIGNATURES = {
     "snowtri_triangulate_condense": (ct.c_int, [_c_p, ct.c_int64, ct.c_int32, ct.c_int32, _c_p, ct.c_int,
                                                 _c_p, ct.POINTER(Params), ct.c_int, ct.c_int32, _c_p,
                                                 _c_p, ct.c_int, _c_p, _c_p, ct.c_int, _c_p]),
+    "snowtri_smooth_track": (ct.c_int, [_c_p, ct.c_int64, ct.c_int64, _c_p, ct.c_double, ct.c_double, ct.c_double,
+                                        ct.c_double, _c_p, ct.c_int, _c_p]),
     "snowtri_last_kernel_ms": (ct.c_int, [_c_p, ct.POINTER(ct.c_float * 2)]),
     "snowtri_set_timing": (ct.c_int, [_c_p, ct.c_int]),
     "snowtri_last_slow_frames": (ct.c_int64, [_c_p]),

@@ -18,6 +18,7 @@
 
 #include "snowtri_fused.hpp"
 #include "snowtri_general.hpp"
+#include "snowtri_smooth.hpp"
 #include "snowtri_kernels.hpp"
 
 using namespace snowtri;
@@ -545,6 +546,68 @@ int snowtri_condense(snowtri_ctx *ctx, int64_t F, int32_t N, int32_t J, const do
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------- N1
+extern "C" int snowtri_smooth_track(snowtri_ctx *ctx, int64_t T, int64_t n, const double *x, double f, double z,
+                                    double r, double dt, double *y, int memspace, void *stream) {
+    if (!ctx || T < 0 || n < 0 || !(f > 0.0) || !(dt > 0.0)) return SNOWTRI_ERR_BAD_ARG;
+    if (memspace != SNOWTRI_HOST && memspace != SNOWTRI_DEVICE) return SNOWTRI_ERR_BAD_ARG;
+    if (T == 0 || n == 0) return SNOWTRI_OK;
+    if (!x || !y) return SNOWTRI_ERR_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const double pi = 3.141592653589793;
+    const double k1 = z / (pi * f), k2 = 1.0 / ((2 * pi * f) * (2 * pi * f)), k3 = r * z / (2 * pi * f);
+    const int L = 256;
+    const int64_t nchunks = T > 1 ? (T - 1 + L - 1) / L : 0;
+    SmoothCoef k;
+    k.a00 = 1.0;
+    k.a01 = dt;
+    k.a10 = -dt / k2;
+    k.a11 = 1.0 - dt * dt / k2 - dt * k1 / k2;
+    k.cx = dt / k2;
+    k.cxd = k3 / k2;  // (T/k2) * k3 * (x - xp)/T
+    {                 // A^L by repeated multiplication on the host (fp64)
+        double p[4] = {1, 0, 0, 1};
+        for (int i = 0; i < L; i++) {
+            const double q0 = k.a00 * p[0] + k.a01 * p[2], q1 = k.a00 * p[1] + k.a01 * p[3];
+            const double q2 = k.a10 * p[0] + k.a11 * p[2], q3 = k.a10 * p[1] + k.a11 * p[3];
+            p[0] = q0; p[1] = q1; p[2] = q2; p[3] = q3;
+        }
+        k.p00 = p[0]; k.p01 = p[1]; k.p10 = p[2]; k.p11 = p[3];
+    }
+    const size_t bytes = sizeof(double) * (size_t)T * n;
+    const double *dx = x;
+    double *dy = y;
+    if (memspace == SNOWTRI_HOST) {
+        int rc = ctx->in.ensure(bytes);
+        if (rc) return rc;
+        rc = ctx->out.ensure(bytes);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(ctx->in.p, x, bytes, hipMemcpyHostToDevice, st));
+        dx = (const double *)ctx->in.p;
+        dy = (double *)ctx->out.p;
+    }
+    if (T == 1) {
+        HIP_TRY(hipMemcpyAsync(dy, dx, bytes, hipMemcpyDeviceToDevice, st));
+    } else {
+        int rc = ctx->work.ensure(sizeof(double) * 4 * (size_t)nchunks * n + 64);
+        if (rc) return rc;
+        double *E = (double *)ctx->work.p, *S = E + 2 * (size_t)nchunks * n;
+        const dim3 grid2((unsigned)((n + kSmoothBlock - 1) / kSmoothBlock), (unsigned)nchunks);
+        const dim3 grid1((unsigned)((n + kSmoothBlock - 1) / kSmoothBlock));
+        if (nchunks > 65535) return SNOWTRI_ERR_BAD_ARG;
+        hipLaunchKernelGGL(k_smooth_local, grid2, dim3(kSmoothBlock), 0, st, T, n, L, nchunks, k, dx, dy, E);
+        hipLaunchKernelGGL(k_smooth_carry, grid1, dim3(kSmoothBlock), 0, st, n, nchunks, k, dx, (const double *)E, S);
+        hipLaunchKernelGGL(k_smooth_fix, grid2, dim3(kSmoothBlock), 0, st, T, n, L, k, (const double *)S, dy);
+        HIP_TRY(hipGetLastError());
+    }
+    if (memspace == SNOWTRI_HOST) {
+        HIP_TRY(hipMemcpyAsync(y, dy, bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return SNOWTRI_OK;
+}
 
 // ------------------------------------------------------------------------------- fused A1..A4
 namespace {

@@ -1,0 +1,90 @@
+// snowtri_smooth.hpp -- row N1: Human_Triangulation_Smooth / SecondOrderDynamic over a whole track.
+//
+// Reference (triangulation.py:4-22,164-186): per (person, joint, axis) lane, frame 0 passes through and seeds
+// xp = y = x0, yd = 0; every later frame
+//     xd = (x - xp)/T;  xp = x;  y += T*yd;  yd += T*(x + k3*xd - y - k1*yd)/k2
+// with k1 = z/(pi f), k2 = 1/(2 pi f)^2, k3 = r z/(2 pi f).
+//
+// The recurrence couples frames, so it cannot ride the frame sharding of the triangulation path; but it is
+// LINEAR in the state s = (y, yd):  s_t = A s_{t-1} + (0, c_t),  c_t = (T/k2)(x_t + k3 xd_t),
+//     A = [[1, T], [-T/k2, 1 - T^2/k2 - T k1/k2]].
+// It is therefore evaluated as a chunked scan over frames (chunk length L):
+//   k_smooth_local   lane x chunk: zero-state response z_t of the chunk, written to y; chunk-end state E[c]
+//   k_smooth_carry   lane: S_{c+1} = A^L S_c + E[c]  (S_0 = (x0, 0));  A^L precomputed on the host
+//   k_smooth_fix     lane x chunk: y_t += (A^{t-t0+1} S_c).y
+// Lanes are the fast axis of x[T][n] / y[T][n]: every load and store is coalesced.
+#pragma once
+#include "snowtri_math.hpp"
+
+namespace snowtri {
+
+struct SmoothCoef {
+    double a00, a01, a10, a11;  // A
+    double cx, cxd;             // c_t = cx * x_t + cxd * (x_t - x_{t-1})      (cxd = (T/k2) k3 / T)
+    double p00, p01, p10, p11;  // A^L
+};
+
+constexpr int kSmoothBlock = 256;
+
+// frames 1..T-1 are the filtered ones; chunk c covers frames [1 + c L, min(T, 1 + (c+1) L))
+__global__ __launch_bounds__(kSmoothBlock) void k_smooth_local(int64_t T, int64_t n, int L, int64_t nchunks,
+                                                               SmoothCoef k, const double *__restrict__ x,
+                                                               double *__restrict__ y, double *__restrict__ E) {
+    const int64_t lane = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t c = blockIdx.y;
+    if (lane >= n) return;
+    const int64_t t0 = 1 + c * L, t1 = (t0 + L < T) ? t0 + L : T;
+    if (c == 0) y[lane] = x[lane];  // frame 0 passes through (:180-181)
+    double sy = 0.0, syd = 0.0;
+    double xp = x[(t0 - 1) * n + lane];
+    for (int64_t t = t0; t < t1; t++) {
+        const double xt = x[t * n + lane];
+        const double ct = fma(k.cxd, xt - xp, k.cx * xt);
+        xp = xt;
+        const double ny = fma(k.a01, syd, k.a00 * sy);
+        const double nyd = fma(k.a11, syd, fma(k.a10, sy, ct));
+        sy = ny;
+        syd = nyd;
+        y[t * n + lane] = sy;
+    }
+    // a short last chunk still needs its end state advanced as if full? No: the carry only feeds LATER chunks.
+    E[(c * n + lane) * 2] = sy;
+    E[(c * n + lane) * 2 + 1] = syd;
+}
+
+__global__ __launch_bounds__(kSmoothBlock) void k_smooth_carry(int64_t n, int64_t nchunks, SmoothCoef k,
+                                                               const double *__restrict__ x,
+                                                               const double *__restrict__ E,
+                                                               double *__restrict__ S) {
+    const int64_t lane = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (lane >= n) return;
+    double sy = x[lane], syd = 0.0;  // state after frame 0: y = x0, yd = 0 (:11-13)
+    for (int64_t c = 0; c < nchunks; c++) {
+        S[(c * n + lane) * 2] = sy;
+        S[(c * n + lane) * 2 + 1] = syd;
+        const double ey = E[(c * n + lane) * 2], eyd = E[(c * n + lane) * 2 + 1];
+        const double ny = fma(k.p01, syd, fma(k.p00, sy, ey));
+        const double nyd = fma(k.p11, syd, fma(k.p10, sy, eyd));
+        sy = ny;
+        syd = nyd;
+    }
+}
+
+__global__ __launch_bounds__(kSmoothBlock) void k_smooth_fix(int64_t T, int64_t n, int L, SmoothCoef k,
+                                                             const double *__restrict__ S,
+                                                             double *__restrict__ y) {
+    const int64_t lane = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t c = blockIdx.y;
+    if (lane >= n) return;
+    const int64_t t0 = 1 + c * L, t1 = (t0 + L < T) ? t0 + L : T;
+    double vy = S[(c * n + lane) * 2], vyd = S[(c * n + lane) * 2 + 1];
+    for (int64_t t = t0; t < t1; t++) {
+        const double ny = fma(k.a01, vyd, k.a00 * vy);
+        const double nyd = fma(k.a11, vyd, k.a10 * vy);
+        vy = ny;
+        vyd = nyd;
+        y[t * n + lane] += vy;
+    }
+}
+
+}  // namespace snowtri

@@ -156,3 +156,18 @@ def Human_Triangulation_Smooth(result, previous_result=None, f=2, z=0.75, r=0, d
         out["second_order_dynamics"] = [[SecondOrderDynamic(f, z, r, joint) for joint in person]
                                         for person in result[_KEYS[0]]]
     return out
+
+
+def smooth_track(track, f=2, z=0.75, r=0, delta_time=1 / 30):
+    """Additive batched form of Human_Triangulation_Smooth (row N1): track[T, ...] (e.g. [T, P, J, 3]) ->
+    filtered track of the same shape, every trailing element an independent SecondOrderDynamic lane,
+    frame 0 passing through.  Runs on the GPU as a chunked linear scan (snowtri_smooth_track)."""
+    x = np.ascontiguousarray(track, dtype=np.float64)
+    T = x.shape[0]
+    n = int(np.prod(x.shape[1:])) if x.ndim > 1 else 1
+    y = np.empty_like(x)
+    ctx = _lib.scratch_context()
+    _lib.check(_lib.lib().snowtri_smooth_track(ctx.handle, T, n, _lib.ptr(x), float(f), float(z), float(r),
+                                               float(delta_time), _lib.ptr(y), _lib.HOST, None),
+               "snowtri_smooth_track")
+    return y

@@ -345,3 +345,23 @@ def test_fastmath_helpers_accuracy_contract(api):
     assert np.abs(r2 * xs - 1).max() < 4e-16 and np.abs(r1 * xs - 1).max() < 1e-14
     _lib.check(_lib.lib().snowtri_fastmath_probe(ctx.handle, n, _lib.ptr(x), _lib.ptr(r2), _lib.ptr(r1), _lib.ptr(q1)), "probe")
     assert (np.abs(q1 * q1 * x - 1) / 2).max() < 1e-14
+
+
+# ------------------------------------------------------------------ row N1: temporal smoothing
+def test_smooth_track_against_reference_and_oracle(api):
+    """snowtri_smooth_track (chunked linear scan) vs the reference's own smoothed trajectory (G6) and,
+    on a long track spanning many chunks, vs the sequential oracle."""
+    from oracle import oracle as orc
+    z = np.load(f"{GOLDEN}/g6_smooth_blender.npz")
+    f, zz, r, dt = float(z["f"]), float(z["z"]), float(z["r"]), float(z["dt"])
+    got = api.smooth_track(z["track"], f=f, z=zz, r=r, delta_time=dt)
+    np.testing.assert_allclose(got, z["smoothed"], rtol=0, atol=1e-11)
+    rng = np.random.default_rng(1)
+    T = 3000                                             # 12 chunks of 256 frames
+    x = np.cumsum(rng.normal(0, 0.01, size=(T, 2, 133, 3)), axis=0) + rng.uniform(-2, 2, size=(1, 2, 133, 3))
+    for (ff, zf, rf) in ((2.5, 0.75, 0.0), (4.0, 0.5, 2.0), (1.0, 1.5, -0.5)):
+        want = orc.second_order_track(x, ff, zf, rf, 1 / 30)
+        got = api.smooth_track(x, f=ff, z=zf, r=rf, delta_time=1 / 30)
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-9)
+    one = api.smooth_track(x[:1], f=2.5, z=0.75, r=0.0, delta_time=1 / 30)
+    assert np.array_equal(one, x[:1])
