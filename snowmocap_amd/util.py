@@ -28,3 +28,25 @@ def Load_Config_Json(config_path):
     """util.py:21-24: flat JSON dict, no validation, no defaults."""
     with open(config_path, "r") as fh:
         return json.load(fh)
+
+
+def Load_Video(video_name):
+    """util.py:34-41 (video I/O, outside the triangulation path): OpenCV capture + length + image size.
+    OpenCV is imported lazily: the triangulation core itself never needs it."""
+    import cv2
+    cap = cv2.VideoCapture(video_name)
+    return {"cap": cap,
+            "length": int(cap.get(cv2.CAP_PROP_FRAME_COUNT)),
+            "image_size": (int(cap.get(cv2.CAP_PROP_FRAME_WIDTH)), int(cap.get(cv2.CAP_PROP_FRAME_HEIGHT)))}
+
+
+def _display_only(name):
+    def stub(*_a, **_k):
+        raise NotImplementedError(f"{name} is matplotlib display code outside the triangulation path; "
+                                  "import it from the original snowvision.util")
+    stub.__name__ = name
+    return stub
+
+
+Draw_Camera_Group = _display_only("Draw_Camera_Group")
+Draw_Skeleton = _display_only("Draw_Skeleton")

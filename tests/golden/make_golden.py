@@ -329,9 +329,53 @@ def g6_smooth_blender():
     print("g6_smooth_blender.npz", os.path.getsize(path) / 1e6, "MB")
 
 
+def g7_pipeline():
+    """The whole per-frame sequence of main.py:47-106 (minus video / pose / display) on synthetic detections:
+    add points -> triangulate -> condense -> smooth -> Blender points -> Blender smooth -> result list."""
+    rng = np.random.default_rng(7)
+    K, R, t = synth.load_rig_json()
+    th = synth.default_thresholds()
+    with open(os.path.join(REF, "configs/blender_armature_profile.json")) as fh:
+        arm = json.load(fh)
+    with open(os.path.join(REF, "configs/blender_smooth_profile.json")) as fh:
+        smo = json.load(fh)
+    F = 6
+    base = synth.make_people(rng, 1, 1)[0]
+    X = base[None] + np.cumsum(rng.normal(0, 0.004, size=(F, 1, 133, 3)), axis=0)
+    kpts, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=0.5, score_range=(2.5, 8.0))
+    cg = ref_camera_group(K, R, t)
+    prev_tri = prev_bl = None
+    frames = []
+    for f in range(F):
+        for c in range(4):
+            cg.add_human_2D_points(kpts[f, c, 0, :, :2], kpts[f, c, 0, :, 2], c)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            tri = sv.Human_Triangulation(cg, keypoint_score_threshold=th["keypoint_score_threshold"],
+                                         average_score_threshold=th["average_score_threshold"],
+                                         distance_threshold=th["distance_threshold"])
+            tri = sv.Human_Triangulation_Condense(tri, condense_distance_tol=th["condense_distance_tol"],
+                                                  condense_person_num_tol=th["condense_person_num_tol"],
+                                                  condense_score_tol=th["condense_score_tol"],
+                                                  center_point_index=th["center_point_index"],
+                                                  keypoint_num=th["keypoint_num"])
+            tri = sv.Human_Triangulation_Smooth(tri, prev_tri, f=th["smooth_f"], z=th["smooth_z"], r=th["smooth_r"],
+                                                delta_time=th["smooth_delta_time"])
+            prev_tri = tri
+            bl = sv.Human_Triangulation_Blender(tri, arm)
+            bl = sv.Human_Triangulation_Blender_Smooth(bl, arm, smo, prev_bl, delta_time=th["smooth_delta_time"])
+            prev_bl = bl
+        frames.append(sv.Human_Triangulation_To_Blender_Result(bl))
+        cg.clear_2D_points()
+    path = os.path.join(HERE, "g7_pipeline.npz")
+    np.savez_compressed(path, K=K, R=R, t=t, kpts=kpts, thresholds=json.dumps(th), armature=json.dumps(arm),
+                        smooth=json.dumps(smo), result=json.dumps(frames))
+    print("g7_pipeline.npz", os.path.getsize(path) / 1e6, "MB")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
     fns = dict(g1=g1_plumbing, g2=g2_near_exact, g3=g3_multi_person, g4=g4_edge_cases,
-               g5=g5_skew_ray, g6=g6_smooth_blender)
+               g5=g5_skew_ray, g6=g6_smooth_blender, g7=g7_pipeline)
     for w in which:
         fns[w]()

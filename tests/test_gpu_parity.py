@@ -365,3 +365,50 @@ def test_smooth_track_against_reference_and_oracle(api):
         np.testing.assert_allclose(got, want, rtol=0, atol=1e-9)
     one = api.smooth_track(x[:1], f=2.5, z=0.75, r=0.0, delta_time=1 / 30)
     assert np.array_equal(one, x[:1])
+
+
+def test_main_loop_sequence_as_snowvision(api, tmp_path, monkeypatch):
+    """main.py:47-106 minus video / pose / display, with this package standing in for `snowvision`
+    (INTEGRATION.md 1): the JSON track it writes equals the reference's (fixture G7)."""
+    import importlib, json, sys
+    monkeypatch.setitem(sys.modules, "snowvision", api)
+    sv = importlib.import_module("snowvision")
+    z = np.load(f"{GOLDEN}/g7_pipeline.npz")
+    th, arm, smo = json.loads(str(z["thresholds"])), json.loads(str(z["armature"])), json.loads(str(z["smooth"]))
+    want = json.loads(str(z["result"]))
+    rig = tmp_path / "rig.json"
+    rig.write_text(json.dumps({"camera_num": 4, "camera_group_info": [
+        {"cap_id": i, "frame_width": 1280, "frame_height": 720, "K": z["K"][i].tolist(), "R": z["R"][i].tolist(),
+         "t": z["t"][i].reshape(3, 1).tolist(), "D": [[0.0] * 5]} for i in range(4)]}))
+    cameragroup = sv.CameraGroup(camera_group_info_path=str(rig))
+    _, out_path = sv.Check_If_File_Exist(str(tmp_path / "blender_mocap_data.json"))
+    previous_triangulation_result = previous_blender_result = None
+    blender_result_list = []
+    kpts = z["kpts"]
+    for i in range(kpts.shape[0]):
+        for camera_index in range(cameragroup.camera_num):
+            keypoints, scores = kpts[i, camera_index, :, :, :2], kpts[i, camera_index, :, :, 2]
+            for person, score in zip(keypoints, scores):
+                cameragroup.add_human_2D_points(person, score, camera_index)
+        tri = sv.Human_Triangulation(cameragroup, keypoint_score_threshold=th["keypoint_score_threshold"],
+                                     average_score_threshold=th["average_score_threshold"],
+                                     distance_threshold=th["distance_threshold"])
+        tri = sv.Human_Triangulation_Condense(tri, condense_distance_tol=th["condense_distance_tol"],
+                                              condense_person_num_tol=th["condense_person_num_tol"],
+                                              condense_score_tol=th["condense_score_tol"],
+                                              center_point_index=th["center_point_index"], keypoint_num=th["keypoint_num"])
+        tri = sv.Human_Triangulation_Smooth(tri, previous_triangulation_result, f=th["smooth_f"], z=th["smooth_z"],
+                                            r=th["smooth_r"], delta_time=th["smooth_delta_time"])
+        previous_triangulation_result = tri
+        bl = sv.Human_Triangulation_Blender(tri, arm)
+        bl = sv.Human_Triangulation_Blender_Smooth(bl, arm, smo, previous_blender_result, delta_time=th["smooth_delta_time"])
+        previous_blender_result = bl
+        blender_result_list.append(sv.Human_Triangulation_To_Blender_Result(bl))
+        sv.save_blender_result(blender_result_list, out_path)
+        cameragroup.clear_2D_points()
+    got = json.load(open(out_path))
+    assert len(got) == len(want)
+    for g, w in zip(got, want):
+        assert g["score"] == w["score"] and len(g["armature"]) == len(w["armature"]) == 1
+        for name, vec in w["armature"][0].items():
+            np.testing.assert_allclose(g["armature"][0][name], vec, rtol=0, atol=1e-8, err_msg=name)
