@@ -647,7 +647,7 @@ int launch_fused_single(snowtri_ctx *ctx, hipStream_t st, int64_t F, int J, cons
                         const int32_t *d_np, const Params &prm, int Pout, TOut *d_xyzs, TOut *d_ps,
                         int32_t *d_cnt, uint32_t *d_fl) {
     constexpr int NP = C * (C - 1) / 2;
-    const int resident = ctx->num_cus * 4;
+    const int resident = ctx->num_cus * 4;  // 2 workgroups per CU are resident; 2 more queued ones even out the tail (measured)
     const int T = choose_tile_frames(F, J, prm.kn, NP, ctx->num_cus);
     const int64_t ntiles = (F + T - 1) / T;
     const int grid = (int)std::min<int64_t>(ntiles, resident);

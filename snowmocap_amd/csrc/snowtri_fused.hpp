@@ -146,8 +146,13 @@ __device__ __forceinline__ void fetch_item(Kp3<TIn> (&dst)[C], const Kp3<TIn> *_
                                            int j, int J, unsigned last_off) {
     unsigned off = (unsigned)(fl * C * J + j);
     off = off < last_off ? off : last_off;
+#ifdef SNOWTRI_COMPUTETEST  // dev experiment: arithmetic only, keypoints synthesised from the lane offset
+#pragma unroll
+    for (int c = 0; c < C; c++) dst[c] = Kp3<TIn>{(TIn)(600 + (off & 255) + 40 * c), (TIn)(300 + (off & 127) - 30 * c), (TIn)5};
+#else
 #pragma unroll
     for (int c = 0; c < C; c++) dst[c] = tile_in[off + (unsigned)(c * J)];
+#endif
 }
 
 // first two items of this lane in tile `tile` -> bufA, bufB

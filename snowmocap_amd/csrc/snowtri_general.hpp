@@ -103,15 +103,14 @@ __global__ __launch_bounds__(kBlock) void k_frame_recompute(int64_t F, int Pmax,
                 const double *pc = rig.pairc + 6 * q;
                 const Vec3 d = {pc[0], pc[1], pc[2]}, tsum = {0.0, 0.0, 0.0};
                 double acc = 0.0;
+#pragma unroll 2
                 for (int jj = 0; jj < nj; jj++) {
                     const RayRec a = rays[jj * R + rm], b = rays[jj * R + rs];
                     const TIn sm = rsc[jj * R + rm], ss = rsc[jj * R + rs];
                     const PairSolve o = pair_solve_fast<false>(a, b, d, tsum);
-                    double s = half_score(sm, ss) * o.score_base;                                // :72
-                    const bool kp_ = !((double)sm < prm.kthr) & !((double)ss < prm.kthr) & !(o.dist > prm.dthr);
-                    s = kp_ ? s : 0.0;                                                            // :73-74
+                    const bool kp_ = !below_kthr(sm, prm) && !below_kthr(ss, prm) && !(o.d2 > prm.dthr2);  // :73-74
+                    acc += gated_sum(sm, ss, kp_) * (0.5 * o.score_base);                              // :72
                     sing |= o.singular;
-                    acc += s;
                 }
                 sum[k] += acc;
             }
@@ -226,9 +225,8 @@ __global__ __launch_bounds__(kBlock) void k_frame_recompute(int64_t F, int Pmax,
                     if (b < kn) {
                         const Kp3<TIn> km = rowm[b], ks = rows[b];
                         const PairSolve o = pair_solve_fast<true>(make_ray(Mm, km.u, km.v), make_ray(Ms, ks.u, ks.v), d, tsum);
-                        double s = half_score(km.s, ks.s) * o.score_base;
-                        const bool kp_ = !((double)km.s < prm.kthr) & !((double)ks.s < prm.kthr) & !(o.dist > prm.dthr);
-                        s = kp_ ? s : 0.0;
+                        const bool kp_ = !below_kthr(km.s, prm) && !below_kthr(ks.s, prm) && !(o.d2 > prm.dthr2);
+                        const double s = gated_sum(km.s, ks.s, kp_) * (0.5 * o.score_base);
                         aS[p] += s;                                                                // :141
                         aX[p] = fma(s, o.sw.x, aX[p]);                                             // :144-147
                         aY[p] = fma(s, o.sw.y, aY[p]);

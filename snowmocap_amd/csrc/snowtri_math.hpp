@@ -120,7 +120,7 @@ struct RayRec {  // one world ray in LDS: direction (un-normalised) and its squa
 // fast-math pair solve (k_frame_recompute phases 1/3, centre check of k_fused_single)
 struct PairSolve {
     double score_base;  // idist * 0.001 (multiply by (sm+ss)/2)
-    double dist;
+    double d2;          // dist^2 (gate: dist > dthr  <=>  d2 > dthr2)
     Vec3 sw;            // Wm + Ws
     bool singular;
 };
@@ -141,7 +141,7 @@ __device__ __forceinline__ PairSolve pair_solve_fast(const RayRec &rm, const Ray
     double idist = rsq_nr1(d2);
     idist = (d2 == 0.0) ? __builtin_inf() : idist;
     PairSolve o;
-    o.dist = d2 * idist;
+    o.d2 = d2;
     o.score_base = idist * 0.001;
     o.singular = (det == 0.0);
     if (kNeedW)
