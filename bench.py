@@ -124,12 +124,15 @@ def main():
     if gather_on:
         gbuf = [torch.empty((world * F, Pout, J, 4), dtype=torch.float32, device=dev) for _ in range(2)]
         side = torch.cuda.Stream(device=dev)
-        g_done = [torch.cuda.Event() for _ in range(2)]
     main_stream = torch.cuda.current_stream(dev)
+
+    gathered = [None] * len(pool)      # event: the all-gather that last read outs[b] has finished
 
     def step(i):
         b = i % len(pool)
         k = i % nstreams
+        if gather_on and gathered[b] is not None:
+            streams[k].wait_event(gathered[b])          # do not overwrite a shard that is still being gathered
         bts[k].run_torch(pool[b], None, out=outs[b], stream=streams[k].cuda_stream)
         if gather_on:
             slot = i & 1
@@ -138,7 +141,9 @@ def main():
             side.wait_event(ready)
             with torch.cuda.stream(side):
                 dist.all_gather_into_tensor(gbuf[slot], outs[b]["xyzs"])
-                g_done[slot].record(side)
+                done = torch.cuda.Event()
+                done.record(side)
+            gathered[b] = done
 
     def fence():
         torch.cuda.synchronize(dev)        # every stream of this device, side stream included

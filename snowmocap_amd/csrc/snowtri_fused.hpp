@@ -217,6 +217,29 @@ __device__ __forceinline__ bool pairwise_item(const Rig &rig, const double *__re
     }
     bool bad = false;
     int q = 0;
+    // one reciprocal for all C(C,2) determinants (Montgomery's trick): 1/det_q from 1/prod(det) and prefix
+    // products -- 3 multiplies per pair instead of a v_rcp_f64 (16 cycles) + two Newton steps.  A singular
+    // pair poisons the product; every pair then reports dist^2 = NaN and the item takes the exact path.
+    constexpr int NPc = C * (C - 1) / 2;
+    double bq[NPc], detq[NPc], pre[NPc], invq[NPc];
+#pragma unroll
+    for (int mc = 0; mc < C - 1; mc++)
+#pragma unroll
+        for (int sc = mc + 1; sc < C; sc++, q++) {
+            bq[q] = dot3(h[mc], h[sc]);
+            detq[q] = fma(a[mc], a[sc], -(bq[q] * bq[q]));
+            pre[q] = q == 0 ? detq[0] : pre[q - 1] * detq[q];
+        }
+    {
+        double run = rcp_nr2(pre[NPc - 1]);
+#pragma unroll
+        for (int k = NPc - 1; k > 0; k--) {
+            invq[k] = run * pre[k - 1];
+            run *= detq[k];
+        }
+        invq[0] = run;
+    }
+    q = 0;
 #pragma unroll
     for (int mc = 0; mc < C - 1; mc++) {
 #pragma unroll
@@ -224,10 +247,8 @@ __device__ __forceinline__ bool pairwise_item(const Rig &rig, const double *__re
             // A2 (triangulation.py:24-31): per-ray norms hoisted, d = ts - tm precomputed
             const Vec3 &hm = h[mc], &hs = h[sc];
             const Vec3 d = {pc[3 * q], pc[3 * q + 1], pc[3 * q + 2]};
-            const double b = dot3(hm, hs);
-            const double det = fma(a[mc], a[sc], -(b * b));
+            const double b = bq[q], inv = invq[q];
             const double e = dot3(hm, d), g = dot3(hs, d);
-            const double inv = rcp_nr2(det);
             const double S0 = fma(a[sc], e, -(b * g)) * inv;
             const double S1 = fma(a[mc], g, -(b * e)) * inv;
             // Wm - Ws = hm S0 + hs S1 - d
@@ -517,29 +538,39 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_single(int
         }
         __syncthreads();
 
-        // ---- per-frame epilogue: mean fused score (:150), filters, count; one wave per frame
-        for (int w = wave; w < nf; w += kBlock / 64) {
-            const int64_t f = f0 + w;
-            double sum = 0.0;
-            for (int b = lane; b < kn; b += 64) sum += stash[w * kn + b];
-            sum = wave_sum(sum);
-            const double avg = sum / (double)kn;
-            bool slow = (fflag[w] & kSlow) != 0u || (avg < prm.score_tol);  // :151-152
-            if (METHOD != 0) slow = false;
-            if (METHOD == 0 && n_persons) {
-                const bool one = lane < C ? (n_persons[f * C + lane] == 1) : true;
-                slow |= (__ballot(!one) != 0ull);
-            }
-            if (lane == 0) {
-                if (slow) {
-                    fflag[w] |= kSlow;
-                } else {
-                    out_count[f] = 1;
-                    if (out_ps) {
-                        out_ps[f * Pout] = (TOut)avg;
-                        for (int slot = 1; slot < Pout; slot++) out_ps[f * Pout + slot] = (TOut)0;
+        // ---- per-frame epilogue: mean fused score (:150), filters, count.  Eight lanes per frame
+        //      (32 frames per pass of the workgroup) sum the stash and combine with three shuffles.
+        {
+            constexpr int G = 8;
+            const int sub = tid & (G - 1);
+            for (int base = 0; base < nf; base += kBlock / G) {
+                const int w = base + tid / G;
+                const bool live = w < nf;
+                const int64_t f = f0 + (live ? w : 0);
+                double sum = 0.0;
+                if (live)
+                    for (int b = sub; b < kn; b += G) sum += stash[w * kn + b];
+                int not_one = 0;
+                if (METHOD == 0 && n_persons && live && sub < C) not_one = n_persons[f * C + sub] != 1;
+#pragma unroll
+                for (int off = G / 2; off > 0; off >>= 1) {
+                    sum += __shfl_xor(sum, off, 64);
+                    not_one |= __shfl_xor(not_one, off, 64);
+                }
+                if (live && sub == 0) {
+                    const double avg = sum / (double)kn;
+                    bool slow = (fflag[w] & kSlow) != 0u || (avg < prm.score_tol) || not_one != 0;  // :151-152
+                    if (METHOD != 0) slow = false;
+                    if (slow) {
+                        fflag[w] |= kSlow;
+                    } else {
+                        out_count[f] = 1;
+                        if (out_ps) {
+                            out_ps[f * Pout] = (TOut)avg;
+                            for (int slot = 1; slot < Pout; slot++) out_ps[f * Pout + slot] = (TOut)0;
+                        }
+                        if (out_flags) out_flags[f] = kFlagFast;
                     }
-                    if (out_flags) out_flags[f] = kFlagFast;
                 }
             }
         }
