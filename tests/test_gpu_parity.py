@@ -412,3 +412,27 @@ def test_main_loop_sequence_as_snowvision(api, tmp_path, monkeypatch):
         assert g["score"] == w["score"] and len(g["armature"]) == len(w["armature"]) == 1
         for name, vec in w["armature"][0].items():
             np.testing.assert_allclose(g["armature"][0][name], vec, rtol=0, atol=1e-8, err_msg=name)
+
+
+@pytest.mark.parametrize("C", [3, 5, 6, 8])
+def test_fast_path_other_camera_counts(api, C):
+    """k_fused_single is instantiated for 3..8 cameras: ring rigs with one person vs the oracle."""
+    from snowmocap_amd import synth, _lib
+    from oracle import oracle as orc
+    rng = np.random.default_rng(40 + C)
+    K, R, t = synth.ring_rig(C)
+    X = synth.make_people(rng, 70, 1)
+    kpts, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=1.0, score_range=(2.0, 8.0))
+    prm = dict(synth.default_thresholds(), condense_distance_tol=0.5)
+    ref = orc.triangulate_condense_batch(K, R, t, kpts, npers, orc.make_params(**prm), 2)
+    bt = api.BatchTriangulator(K, R, t, prm, pout_max=2, out_dtype=np.float64)
+    out = bt.run_host(kpts, npers)
+    bt.close()
+    assert np.array_equal(out["count"], ref["count"])
+    assert ((out["flags"] & _lib.FLAG_FASTPATH) != 0).mean() > 0.9      # opposite cameras may flag a few frames
+    for f in range(70):
+        m = int(ref["count"][f])
+        assert not out["xyzs"][f, m:].any()
+        if m:
+            assert_scores_close(out["xyzs"][f, :m, :, 3], ref["kscore"][f, :m])
+            assert_xyz_close(out["xyzs"][f, :m, :, :3], ref["xyz"][f, :m], XYZ_FUSED, score_ref=ref["kscore"][f, :m])
