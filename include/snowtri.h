@@ -151,6 +151,23 @@ int snowtri_triangulate_condense(snowtri_ctx *ctx, int64_t F, int32_t Pmax, int3
 int snowtri_smooth_track(snowtri_ctx *ctx, int64_t T, int64_t n, const double *x, double f, double z, double r,
                          double dt, double *y, int memspace, void *stream);
 
+/* N1 on a FRAME-SHARDED track (one contiguous frame block per rank).  The filter is linear in its state, so a
+ * shard is processed in two calls around ONE small exchange of carries (3n doubles per rank):
+ *   snowtri_smooth_shard_local  y = response of the shard from a ZERO entering state (first != 0: this shard
+ *                               starts the track, its frame 0 passes through; otherwise every frame is
+ *                               filtered and the first one takes xd = 0), end_state[2n] = that response's
+ *                               final (y, yd) per lane;
+ *   snowtri_smooth_shard_fix    y += response of the true entering state start_state[2n].
+ * snowmocap_amd/sharded.py::combine_carries turns the gathered (end_state, first/last input row, length) of the
+ * preceding shards into start_state.  snowtri_smooth_coeffs returns {a00,a01,a10,a11,cx,cxd} of the update
+ * s_t = A s_{t-1} + (0, cx x_t + cxd (x_t - x_{t-1})) it needs. */
+int snowtri_smooth_coeffs(double f, double z, double r, double dt, double out[6]);
+int snowtri_smooth_shard_local(snowtri_ctx *ctx, int64_t T, int64_t n, const double *x, int first, double f,
+                               double z, double r, double dt, double *y, double *end_state, int memspace,
+                               void *stream);
+int snowtri_smooth_shard_fix(snowtri_ctx *ctx, int64_t T, int64_t n, int first, const double *start_state, double f,
+                             double z, double r, double dt, double *y, int memspace, void *stream);
+
 /* Measurement aid: HIP-event time (ms) of the kernels launched by the LAST
  * snowtri_triangulate_condense call on this context, measured on the stream they ran on
  * (blocks until they finish).  kernel_ms[0] = dominant fused kernel, [1] = everything else. */

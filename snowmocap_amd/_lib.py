@@ -78,6 +78,11 @@ _SIGNATURES = {
                                                 _c_p, ct.c_int, _c_p, _c_p, ct.c_int, _c_p]),
     "snowtri_smooth_track": (ct.c_int, [_c_p, ct.c_int64, ct.c_int64, _c_p, ct.c_double, ct.c_double, ct.c_double,
                                         ct.c_double, _c_p, ct.c_int, _c_p]),
+    "snowtri_smooth_coeffs": (ct.c_int, [ct.c_double, ct.c_double, ct.c_double, ct.c_double, _c_p]),
+    "snowtri_smooth_shard_local": (ct.c_int, [_c_p, ct.c_int64, ct.c_int64, _c_p, ct.c_int, ct.c_double, ct.c_double,
+                                              ct.c_double, ct.c_double, _c_p, _c_p, ct.c_int, _c_p]),
+    "snowtri_smooth_shard_fix": (ct.c_int, [_c_p, ct.c_int64, ct.c_int64, ct.c_int, _c_p, ct.c_double, ct.c_double,
+                                            ct.c_double, ct.c_double, _c_p, ct.c_int, _c_p]),
     "snowtri_last_kernel_ms": (ct.c_int, [_c_p, ct.POINTER(ct.c_float * 2)]),
     "snowtri_set_timing": (ct.c_int, [_c_p, ct.c_int]),
     "snowtri_last_slow_frames": (ct.c_int64, [_c_p]),

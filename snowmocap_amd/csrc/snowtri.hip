@@ -548,18 +548,13 @@ int snowtri_condense(snowtri_ctx *ctx, int64_t F, int32_t N, int32_t J, const do
 }  // extern "C"
 
 // ---------------------------------------------------------------------------------------- N1
-extern "C" int snowtri_smooth_track(snowtri_ctx *ctx, int64_t T, int64_t n, const double *x, double f, double z,
-                                    double r, double dt, double *y, int memspace, void *stream) {
-    if (!ctx || T < 0 || n < 0 || !(f > 0.0) || !(dt > 0.0)) return SNOWTRI_ERR_BAD_ARG;
-    if (memspace != SNOWTRI_HOST && memspace != SNOWTRI_DEVICE) return SNOWTRI_ERR_BAD_ARG;
-    if (T == 0 || n == 0) return SNOWTRI_OK;
-    if (!x || !y) return SNOWTRI_ERR_BAD_ARG;
-    HIP_TRY(hipSetDevice(ctx->device));
-    hipStream_t st = (hipStream_t)stream;
+namespace {
+
+constexpr int kSmoothChunk = 256;
+
+SmoothCoef smooth_coef(double f, double z, double r, double dt) {
     const double pi = 3.141592653589793;
     const double k1 = z / (pi * f), k2 = 1.0 / ((2 * pi * f) * (2 * pi * f)), k3 = r * z / (2 * pi * f);
-    const int L = 256;
-    const int64_t nchunks = T > 1 ? (T - 1 + L - 1) / L : 0;
     SmoothCoef k;
     k.a00 = 1.0;
     k.a01 = dt;
@@ -567,15 +562,150 @@ extern "C" int snowtri_smooth_track(snowtri_ctx *ctx, int64_t T, int64_t n, cons
     k.a11 = 1.0 - dt * dt / k2 - dt * k1 / k2;
     k.cx = dt / k2;
     k.cxd = k3 / k2;  // (T/k2) * k3 * (x - xp)/T
-    {                 // A^L by repeated multiplication on the host (fp64)
-        double p[4] = {1, 0, 0, 1};
-        for (int i = 0; i < L; i++) {
-            const double q0 = k.a00 * p[0] + k.a01 * p[2], q1 = k.a00 * p[1] + k.a01 * p[3];
-            const double q2 = k.a10 * p[0] + k.a11 * p[2], q3 = k.a10 * p[1] + k.a11 * p[3];
-            p[0] = q0; p[1] = q1; p[2] = q2; p[3] = q3;
-        }
-        k.p00 = p[0]; k.p01 = p[1]; k.p10 = p[2]; k.p11 = p[3];
+    double p[4] = {1, 0, 0, 1};  // A^L by repeated multiplication (fp64)
+    for (int i = 0; i < kSmoothChunk; i++) {
+        const double q0 = k.a00 * p[0] + k.a01 * p[2], q1 = k.a00 * p[1] + k.a01 * p[3];
+        const double q2 = k.a10 * p[0] + k.a11 * p[2], q3 = k.a10 * p[1] + k.a11 * p[3];
+        p[0] = q0; p[1] = q1; p[2] = q2; p[3] = q3;
     }
+    k.p00 = p[0]; k.p01 = p[1]; k.p10 = p[2]; k.p11 = p[3];
+    return k;
+}
+
+dim3 smooth_grid(int64_t n, int64_t nchunks) {
+    return dim3((unsigned)((n + kSmoothBlock - 1) / kSmoothBlock), (unsigned)std::max<int64_t>(1, nchunks));
+}
+
+// Zero-state response of frames [tb, T) into dy (frame 0 passes through when first); optional end state.
+int smooth_local_dev(snowtri_ctx *ctx, hipStream_t st, int64_t T, int64_t n, const double *dx, double *dy,
+                     bool first, const SmoothCoef &k, double *d_end) {
+    const int tb = first ? 1 : 0;
+    const int64_t m = T - tb, nchunks = (m + kSmoothChunk - 1) / kSmoothChunk;
+    if (nchunks > 65535) return SNOWTRI_ERR_BAD_ARG;
+    if (m <= 0) {  // a one-frame first shard: nothing is filtered
+        HIP_TRY(hipMemcpyAsync(dy, dx, sizeof(double) * (size_t)T * n, hipMemcpyDeviceToDevice, st));
+        if (d_end) HIP_TRY(hipMemsetAsync(d_end, 0, sizeof(double) * 2 * n, st));
+        return SNOWTRI_OK;
+    }
+    int rc = ctx->work.ensure(sizeof(double) * 4 * (size_t)nchunks * n + 64);
+    if (rc) return rc;
+    double *E = (double *)ctx->work.p, *S = E + 2 * (size_t)nchunks * n;
+    const dim3 g2 = smooth_grid(n, nchunks), g1 = smooth_grid(n, 1);
+    hipLaunchKernelGGL(k_smooth_local, g2, dim3(kSmoothBlock), 0, st, T, n, kSmoothChunk, tb, k, dx, dy, E);
+    hipLaunchKernelGGL(k_smooth_carry, g1, dim3(kSmoothBlock), 0, st, n, nchunks, k, (const double *)nullptr,
+                       (const double *)E, S);
+    hipLaunchKernelGGL(k_smooth_fix, g2, dim3(kSmoothBlock), 0, st, T, n, kSmoothChunk, tb, k, (const double *)S, dy,
+                       (double *)nullptr);
+    if (d_end)
+        hipLaunchKernelGGL(k_smooth_shard_end, g1, dim3(kSmoothBlock), 0, st, T, n, kSmoothChunk, tb, nchunks, k,
+                           (const double *)S, (const double *)E, d_end);
+    HIP_TRY(hipGetLastError());
+    return SNOWTRI_OK;
+}
+
+// dy += homogeneous response of the state `d_start` entering frame tb.
+int smooth_fix_dev(snowtri_ctx *ctx, hipStream_t st, int64_t T, int64_t n, double *dy, bool first,
+                   const double *d_start, const SmoothCoef &k) {
+    const int tb = first ? 1 : 0;
+    const int64_t m = T - tb, nchunks = (m + kSmoothChunk - 1) / kSmoothChunk;
+    if (m <= 0) return SNOWTRI_OK;
+    if (nchunks > 65535) return SNOWTRI_ERR_BAD_ARG;
+    int rc = ctx->work.ensure(sizeof(double) * 2 * (size_t)nchunks * n + 64);
+    if (rc) return rc;
+    double *S = (double *)ctx->work.p;
+    hipLaunchKernelGGL(k_smooth_carry, smooth_grid(n, 1), dim3(kSmoothBlock), 0, st, n, nchunks, k, d_start,
+                       (const double *)nullptr, S);
+    hipLaunchKernelGGL(k_smooth_fix, smooth_grid(n, nchunks), dim3(kSmoothBlock), 0, st, T, n, kSmoothChunk, tb, k,
+                       (const double *)S, dy, (double *)nullptr);
+    HIP_TRY(hipGetLastError());
+    return SNOWTRI_OK;
+}
+
+bool smooth_args_ok(snowtri_ctx *ctx, int64_t T, int64_t n, double f, double dt, int memspace) {
+    return ctx && T >= 0 && n >= 0 && f > 0.0 && dt > 0.0 && (memspace == SNOWTRI_HOST || memspace == SNOWTRI_DEVICE);
+}
+
+}  // namespace
+
+extern "C" {
+
+int snowtri_smooth_coeffs(double f, double z, double r, double dt, double out[6]) {
+    if (!out || !(f > 0.0) || !(dt > 0.0)) return SNOWTRI_ERR_BAD_ARG;
+    const SmoothCoef k = smooth_coef(f, z, r, dt);
+    out[0] = k.a00; out[1] = k.a01; out[2] = k.a10; out[3] = k.a11; out[4] = k.cx; out[5] = k.cxd;
+    return SNOWTRI_OK;
+}
+
+int snowtri_smooth_shard_local(snowtri_ctx *ctx, int64_t T, int64_t n, const double *x, int first, double f,
+                               double z, double r, double dt, double *y, double *end_state, int memspace,
+                               void *stream) {
+    if (!smooth_args_ok(ctx, T, n, f, dt, memspace)) return SNOWTRI_ERR_BAD_ARG;
+    if (T == 0 || n == 0) return SNOWTRI_OK;
+    if (!x || !y) return SNOWTRI_ERR_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const SmoothCoef k = smooth_coef(f, z, r, dt);
+    const size_t bytes = sizeof(double) * (size_t)T * n;
+    const double *dx = x;
+    double *dy = y, *dend = end_state;
+    if (memspace == SNOWTRI_HOST) {
+        int rc = ctx->in.ensure(bytes);
+        if (rc) return rc;
+        rc = ctx->out.ensure(bytes + sizeof(double) * 2 * n);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(ctx->in.p, x, bytes, hipMemcpyHostToDevice, st));
+        dx = (const double *)ctx->in.p;
+        dy = (double *)ctx->out.p;
+        dend = end_state ? dy + (size_t)T * n : nullptr;
+    }
+    int rc = smooth_local_dev(ctx, st, T, n, dx, dy, first != 0, k, dend);
+    if (rc) return rc;
+    if (memspace == SNOWTRI_HOST) {
+        HIP_TRY(hipMemcpyAsync(y, dy, bytes, hipMemcpyDeviceToHost, st));
+        if (end_state) HIP_TRY(hipMemcpyAsync(end_state, dend, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return SNOWTRI_OK;
+}
+
+int snowtri_smooth_shard_fix(snowtri_ctx *ctx, int64_t T, int64_t n, int first, const double *start_state, double f,
+                             double z, double r, double dt, double *y, int memspace, void *stream) {
+    if (!smooth_args_ok(ctx, T, n, f, dt, memspace)) return SNOWTRI_ERR_BAD_ARG;
+    if (T == 0 || n == 0) return SNOWTRI_OK;
+    if (!start_state || !y) return SNOWTRI_ERR_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const SmoothCoef k = smooth_coef(f, z, r, dt);
+    const size_t bytes = sizeof(double) * (size_t)T * n;
+    double *dy = y;
+    const double *dstart = start_state;
+    if (memspace == SNOWTRI_HOST) {
+        int rc = ctx->out.ensure(bytes);
+        if (rc) return rc;
+        rc = ctx->misc.ensure(sizeof(double) * 2 * n);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(ctx->out.p, y, bytes, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(ctx->misc.p, start_state, sizeof(double) * 2 * n, hipMemcpyHostToDevice, st));
+        dy = (double *)ctx->out.p;
+        dstart = (const double *)ctx->misc.p;
+    }
+    int rc = smooth_fix_dev(ctx, st, T, n, dy, first != 0, dstart, k);
+    if (rc) return rc;
+    if (memspace == SNOWTRI_HOST) {
+        HIP_TRY(hipMemcpyAsync(y, dy, bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return SNOWTRI_OK;
+}
+
+int snowtri_smooth_track(snowtri_ctx *ctx, int64_t T, int64_t n, const double *x, double f, double z, double r,
+                         double dt, double *y, int memspace, void *stream) {
+    if (!smooth_args_ok(ctx, T, n, f, dt, memspace)) return SNOWTRI_ERR_BAD_ARG;
+    if (T == 0 || n == 0) return SNOWTRI_OK;
+    if (!x || !y) return SNOWTRI_ERR_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const SmoothCoef k = smooth_coef(f, z, r, dt);
     const size_t bytes = sizeof(double) * (size_t)T * n;
     const double *dx = x;
     double *dy = y;
@@ -588,26 +718,21 @@ extern "C" int snowtri_smooth_track(snowtri_ctx *ctx, int64_t T, int64_t n, cons
         dx = (const double *)ctx->in.p;
         dy = (double *)ctx->out.p;
     }
-    if (T == 1) {
-        HIP_TRY(hipMemcpyAsync(dy, dx, bytes, hipMemcpyDeviceToDevice, st));
-    } else {
-        int rc = ctx->work.ensure(sizeof(double) * 4 * (size_t)nchunks * n + 64);
-        if (rc) return rc;
-        double *E = (double *)ctx->work.p, *S = E + 2 * (size_t)nchunks * n;
-        const dim3 grid2((unsigned)((n + kSmoothBlock - 1) / kSmoothBlock), (unsigned)nchunks);
-        const dim3 grid1((unsigned)((n + kSmoothBlock - 1) / kSmoothBlock));
-        if (nchunks > 65535) return SNOWTRI_ERR_BAD_ARG;
-        hipLaunchKernelGGL(k_smooth_local, grid2, dim3(kSmoothBlock), 0, st, T, n, L, nchunks, k, dx, dy, E);
-        hipLaunchKernelGGL(k_smooth_carry, grid1, dim3(kSmoothBlock), 0, st, n, nchunks, k, dx, (const double *)E, S);
-        hipLaunchKernelGGL(k_smooth_fix, grid2, dim3(kSmoothBlock), 0, st, T, n, L, k, (const double *)S, dy);
-        HIP_TRY(hipGetLastError());
-    }
+    int rc = smooth_local_dev(ctx, st, T, n, dx, dy, true, k, nullptr);
+    if (rc) return rc;
+    rc = ctx->misc.ensure(sizeof(double) * 2 * n);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_smooth_seed, smooth_grid(n, 1), dim3(kSmoothBlock), 0, st, n, dx, (double *)ctx->misc.p);
+    rc = smooth_fix_dev(ctx, st, T, n, dy, true, (const double *)ctx->misc.p, k);
+    if (rc) return rc;
     if (memspace == SNOWTRI_HOST) {
         HIP_TRY(hipMemcpyAsync(y, dy, bytes, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
     }
     return SNOWTRI_OK;
 }
+
+}  // extern "C"
 
 // ------------------------------------------------------------------------------- fused A1..A4
 namespace {

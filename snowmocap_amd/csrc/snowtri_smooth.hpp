@@ -26,17 +26,19 @@ struct SmoothCoef {
 
 constexpr int kSmoothBlock = 256;
 
-// frames 1..T-1 are the filtered ones; chunk c covers frames [1 + c L, min(T, 1 + (c+1) L))
-__global__ __launch_bounds__(kSmoothBlock) void k_smooth_local(int64_t T, int64_t n, int L, int64_t nchunks,
+// frames tb..T-1 are the filtered ones (tb = 1: frame 0 is the seed and passes through; tb = 0: a later
+// shard of a frame-sharded track, whose first frame is filtered with xd = 0 -- the caller corrects for the
+// true previous input afterwards); chunk c covers frames [tb + c L, min(T, tb + (c+1) L))
+__global__ __launch_bounds__(kSmoothBlock) void k_smooth_local(int64_t T, int64_t n, int L, int tb,
                                                                SmoothCoef k, const double *__restrict__ x,
                                                                double *__restrict__ y, double *__restrict__ E) {
     const int64_t lane = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t c = blockIdx.y;
     if (lane >= n) return;
-    const int64_t t0 = 1 + c * L, t1 = (t0 + L < T) ? t0 + L : T;
-    if (c == 0) y[lane] = x[lane];  // frame 0 passes through (:180-181)
+    const int64_t t0 = tb + c * L, t1 = (t0 + L < T) ? t0 + L : T;
+    if (c == 0 && tb == 1) y[lane] = x[lane];  // frame 0 passes through (:180-181)
     double sy = 0.0, syd = 0.0;
-    double xp = x[(t0 - 1) * n + lane];
+    double xp = x[(t0 > 0 ? t0 - 1 : 0) * n + lane];
     for (int64_t t = t0; t < t1; t++) {
         const double xt = x[t * n + lane];
         const double ct = fma(k.cxd, xt - xp, k.cx * xt);
@@ -52,17 +54,21 @@ __global__ __launch_bounds__(kSmoothBlock) void k_smooth_local(int64_t T, int64_
     E[(c * n + lane) * 2 + 1] = syd;
 }
 
+// start: state entering the first chunk -- [2n] array, or nullptr = zero.  E: chunk zero-state end states,
+// or nullptr = none (pure homogeneous propagation).  end_out (optional, [2n]): state after the last FULL-LENGTH
+// step count, i.e. exact only when every chunk is full; callers that need the shard's end state use the
+// per-lane sequential tail below instead.
 __global__ __launch_bounds__(kSmoothBlock) void k_smooth_carry(int64_t n, int64_t nchunks, SmoothCoef k,
-                                                               const double *__restrict__ x,
+                                                               const double *__restrict__ start,
                                                                const double *__restrict__ E,
                                                                double *__restrict__ S) {
     const int64_t lane = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (lane >= n) return;
-    double sy = x[lane], syd = 0.0;  // state after frame 0: y = x0, yd = 0 (:11-13)
+    double sy = start ? start[2 * lane] : 0.0, syd = start ? start[2 * lane + 1] : 0.0;
     for (int64_t c = 0; c < nchunks; c++) {
         S[(c * n + lane) * 2] = sy;
         S[(c * n + lane) * 2 + 1] = syd;
-        const double ey = E[(c * n + lane) * 2], eyd = E[(c * n + lane) * 2 + 1];
+        const double ey = E ? E[(c * n + lane) * 2] : 0.0, eyd = E ? E[(c * n + lane) * 2 + 1] : 0.0;
         const double ny = fma(k.p01, syd, fma(k.p00, sy, ey));
         const double nyd = fma(k.p11, syd, fma(k.p10, sy, eyd));
         sy = ny;
@@ -70,13 +76,23 @@ __global__ __launch_bounds__(kSmoothBlock) void k_smooth_carry(int64_t n, int64_
     }
 }
 
-__global__ __launch_bounds__(kSmoothBlock) void k_smooth_fix(int64_t T, int64_t n, int L, SmoothCoef k,
-                                                             const double *__restrict__ S,
-                                                             double *__restrict__ y) {
+// seed state of a track: (x0, 0) per lane (:11-13)
+__global__ __launch_bounds__(kSmoothBlock) void k_smooth_seed(int64_t n, const double *__restrict__ x0,
+                                                              double *__restrict__ st) {
+    const int64_t lane = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (lane >= n) return;
+    st[2 * lane] = x0[lane];
+    st[2 * lane + 1] = 0.0;
+}
+
+// y_t += (A^{t-t0+1} S_c).y ; the last chunk (optionally) also reports the propagated state (end_out, [2n])
+__global__ __launch_bounds__(kSmoothBlock) void k_smooth_fix(int64_t T, int64_t n, int L, int tb, SmoothCoef k,
+                                                             const double *__restrict__ S, double *__restrict__ y,
+                                                             double *__restrict__ end_out) {
     const int64_t lane = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t c = blockIdx.y;
     if (lane >= n) return;
-    const int64_t t0 = 1 + c * L, t1 = (t0 + L < T) ? t0 + L : T;
+    const int64_t t0 = tb + c * L, t1 = (t0 + L < T) ? t0 + L : T;
     double vy = S[(c * n + lane) * 2], vyd = S[(c * n + lane) * 2 + 1];
     for (int64_t t = t0; t < t1; t++) {
         const double ny = fma(k.a01, vyd, k.a00 * vy);
@@ -85,6 +101,32 @@ __global__ __launch_bounds__(kSmoothBlock) void k_smooth_fix(int64_t T, int64_t 
         vyd = nyd;
         y[t * n + lane] += vy;
     }
+    if (end_out && t1 == T) {
+        end_out[2 * lane] = vy;
+        end_out[2 * lane + 1] = vyd;
+    }
+}
+
+// zero-state end state of the whole shard = zero-start carry over the chunks, advanced through the last chunk:
+// the last chunk's own zero-state end E[last] plus the homogeneous propagation of its start state.
+__global__ __launch_bounds__(kSmoothBlock) void k_smooth_shard_end(int64_t T, int64_t n, int L, int tb,
+                                                                   int64_t nchunks, SmoothCoef k,
+                                                                   const double *__restrict__ S,
+                                                                   const double *__restrict__ E,
+                                                                   double *__restrict__ end_out) {
+    const int64_t lane = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (lane >= n) return;
+    const int64_t c = nchunks - 1;
+    const int64_t t0 = tb + c * L;
+    double vy = S[(c * n + lane) * 2], vyd = S[(c * n + lane) * 2 + 1];
+    for (int64_t t = t0; t < T; t++) {
+        const double ny = fma(k.a01, vyd, k.a00 * vy);
+        const double nyd = fma(k.a11, vyd, k.a10 * vy);
+        vy = ny;
+        vyd = nyd;
+    }
+    end_out[2 * lane] = vy + E[(c * n + lane) * 2];
+    end_out[2 * lane + 1] = vyd + E[(c * n + lane) * 2 + 1];
 }
 
 }  // namespace snowtri

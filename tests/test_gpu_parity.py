@@ -436,3 +436,34 @@ def test_fast_path_other_camera_counts(api, C):
         if m:
             assert_scores_close(out["xyzs"][f, :m, :, 3], ref["kscore"][f, :m])
             assert_xyz_close(out["xyzs"][f, :m, :, :3], ref["xyz"][f, :m], XYZ_FUSED, score_ref=ref["kscore"][f, :m])
+
+
+def test_sharded_smoothing_kernels_with_carry_exchange(api):
+    """snowtri_smooth_shard_local / _fix on three uneven frame blocks + combine_carries (what
+    smooth_track_sharded does around its one all-gather) == the sequential oracle on the whole track."""
+    import ctypes as ct
+    from snowmocap_amd import _lib
+    from snowmocap_amd.sharded import combine_carries, smooth_coeffs
+    from oracle import oracle as orc
+    rng = np.random.default_rng(11)
+    f, z, r, dt = 2.5, 0.75, 0.4, 1 / 30
+    x = np.cumsum(rng.normal(0, 0.01, size=(1500, 399)), axis=0) + rng.uniform(-2, 2, size=(1, 399))
+    want = orc.second_order_track(x, f, z, r, dt)
+    A, cx, cxd = smooth_coeffs(f, z, r, dt)
+    ctx = _lib.scratch_context()
+    L = _lib.lib()
+    cuts = [0, 700, 701, 1500]           # spans chunk boundaries (256), includes a one-frame block
+    shards = [np.ascontiguousarray(x[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+    ys, payloads = [], []
+    for q, sh in enumerate(shards):
+        y = np.empty_like(sh)
+        E = np.empty((399, 2))
+        _lib.check(L.snowtri_smooth_shard_local(ctx.handle, sh.shape[0], 399, _lib.ptr(sh), 1 if q == 0 else 0, f, z, r, dt,
+                                                _lib.ptr(y), _lib.ptr(E), _lib.HOST, None), "local")
+        ys.append(y)
+        payloads.append((E, sh[0], sh[-1], sh.shape[0]))
+    for q, sh in enumerate(shards):
+        start = combine_carries(payloads, q, A, cxd)
+        _lib.check(L.snowtri_smooth_shard_fix(ctx.handle, sh.shape[0], 399, 1 if q == 0 else 0, _lib.ptr(start), f, z, r, dt,
+                                              _lib.ptr(ys[q]), _lib.HOST, None), "fix")
+    np.testing.assert_allclose(np.concatenate(ys), want, rtol=0, atol=1e-9)

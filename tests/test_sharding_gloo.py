@@ -59,3 +59,60 @@ def test_two_rank_gather_equals_unsharded(tmp_path, F):
     got = np.load(tmp_path / "full.npy")
     assert got.shape == want.shape and np.array_equal(got, want)
     assert np.array_equal(np.load(tmp_path / "cnt.npy"), ref["count"])
+
+
+# ------------------------------------------------------------------ N1 on a sharded track: carry exchange
+def _seq_filter(x, f, z, r, dt):
+    from oracle import oracle as orc
+    return orc.second_order_track(x, f, z, r, dt)
+
+
+def _local_and_fix_numpy(x, first, A, cx, cxd):
+    """NumPy stand-in for snowtri_smooth_shard_local: zero-state response + end state (same convention)."""
+    T, n = x.shape
+    y = np.zeros_like(x)
+    s = np.zeros((n, 2))
+    tb = 1 if first else 0
+    if first:
+        y[0] = x[0]
+    xp = x[0].copy()
+    for t in range(tb, T):
+        c = cx * x[t] + cxd * (x[t] - xp)
+        xp = x[t]
+        s = s @ A.T + np.stack([np.zeros(n), c], axis=1)
+        y[t] = s[:, 0]
+    return y, s
+
+
+def _homogeneous(T, first, start, A):
+    tb = 1 if first else 0
+    out = np.zeros((T, start.shape[0]))
+    v = start.copy()
+    for t in range(tb, T):
+        v = v @ A.T
+        out[t] = v[:, 0]
+    return out
+
+
+@pytest.mark.parametrize("cuts", [[0, 40, 97, 150], [0, 1, 2, 150], [0, 150, 150, 150]])
+def test_carry_combination_reproduces_sequential_filter(cuts):
+    """combine_carries (the host math between the two shard calls) on 3 shards == the unsharded recurrence."""
+    from snowmocap_amd.sharded import combine_carries
+    rng = np.random.default_rng(3)
+    f, z, r, dt = 2.5, 0.75, 0.6, 1 / 30
+    pi = np.pi
+    k1, k2, k3 = z / (pi * f), 1 / (2 * pi * f) ** 2, r * z / (2 * pi * f)
+    A = np.array([[1.0, dt], [-dt / k2, 1 - dt * dt / k2 - dt * k1 / k2]])
+    cx, cxd = dt / k2, k3 / k2
+    x = np.cumsum(rng.normal(0, 0.01, size=(150, 7)), axis=0) + 1.0
+    want = _seq_filter(x, f, z, r, dt)
+    shards = [x[a:b] for a, b in zip(cuts[:-1], cuts[1:])]
+    locs = [(_local_and_fix_numpy(sh, q == 0, A, cx, cxd) if len(sh) else (sh, np.zeros((7, 2)))) for q, sh in enumerate(shards)]
+    payloads = [(E, sh[0] if len(sh) else np.zeros(7), sh[-1] if len(sh) else np.zeros(7), len(sh)) for (y, E), sh in zip(locs, shards)]
+    got = []
+    for q, sh in enumerate(shards):
+        if not len(sh):
+            continue
+        start = combine_carries(payloads, q, A, cxd)
+        got.append(locs[q][0] + _homogeneous(len(sh), q == 0, start, A))
+    np.testing.assert_allclose(np.concatenate(got), want, rtol=0, atol=1e-11)
