@@ -74,6 +74,8 @@ def main():
                     help="HIP streams the steps are issued on round-robin (one context each); 2 lets the ramp-up / "
                          "tail of consecutive 10 000-frame launches overlap")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the RCCL all-gather of the track")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="testing aid: run the torch.distributed / all-gather code path even with --gpus 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     args = ap.parse_args()
@@ -86,9 +88,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("NCCL_DEBUG", "NONE")      # no RCCL version banner on stdout
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
         dist.init_process_group("nccl", rank=rank, world_size=int(os.environ.get("WORLD_SIZE", world)),
@@ -121,7 +125,7 @@ def main():
             jitter[..., :2] = torch.randn(base.shape[:-1] + (2,), generator=gen, device=dev) * 0.25
             pool.append((base + jitter).contiguous())
     outs = [bt.alloc_outputs(F, dev) for _ in range(len(pool))]
-    can_gather = world > 1 and not args.no_gather
+    can_gather = dist is not None and not args.no_gather
     if can_gather:
         gbuf = [torch.empty((world * F, Pout, J, 4), dtype=torch.float32, device=dev) for _ in range(2)]
         side = torch.cuda.Stream(device=dev)
@@ -251,6 +255,7 @@ def main():
         except Exception:
             traffic = None
 
+    line = None
     if rank == 0:
         line = {
             "metric": "joint-triangulations/sec", "value": value, "unit": "joints/s", "n_gpus": world,
@@ -272,11 +277,22 @@ def main():
             "large_batch": large,
             "ray_pair_solves_per_s": value * (C * (C - 1) // 2),
         }
-        print(json.dumps(line))
     for b_ in bts:
         b_.close()
     if dist is not None:
         dist.destroy_process_group()
+    if line is not None:
+        # the JSON line must be the LAST thing on stdout: RCCL prints a version banner through C stdio,
+        # which would otherwise be flushed after Python's output at exit
+        import ctypes
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        sys.stdout.flush()
+        if world > 1:
+            time.sleep(1.0)                                # let the other ranks' exit-time output drain first
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == "__main__":

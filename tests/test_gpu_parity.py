@@ -467,3 +467,27 @@ def test_sharded_smoothing_kernels_with_carry_exchange(api):
         _lib.check(L.snowtri_smooth_shard_fix(ctx.handle, sh.shape[0], 399, 1 if q == 0 else 0, _lib.ptr(start), f, z, r, dt,
                                               _lib.ptr(ys[q]), _lib.HOST, None), "fix")
     np.testing.assert_allclose(np.concatenate(ys), want, rtol=0, atol=1e-9)
+
+
+def test_smooth_track_sharded_single_rank_group(api):
+    """The torch.distributed plumbing of smooth_track_sharded (RCCL all-gather of the carries) in a 1-rank group."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from snowmocap_amd.sharded import smooth_track_sharded
+    from oracle import oracle as orc
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29650 + os.getpid() % 200))
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        rng = np.random.default_rng(5)
+        x = np.cumsum(rng.normal(0, 0.01, size=(900, 2, 133, 3)), axis=0)
+        y = smooth_track_sharded(torch.from_numpy(x).cuda(), f=2.5, z=0.75, r=0.0, delta_time=1 / 30)
+        torch.cuda.synchronize()
+        np.testing.assert_allclose(y.cpu().numpy(), orc.second_order_track(x, 2.5, 0.75, 0.0, 1 / 30), rtol=0, atol=1e-9)
+    finally:
+        if created:
+            dist.destroy_process_group()
