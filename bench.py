@@ -74,6 +74,8 @@ def main():
                     help="HIP streams the steps are issued on round-robin (one context each); 2 lets the ramp-up / "
                          "tail of consecutive 10 000-frame launches overlap")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the RCCL all-gather of the track")
+    ap.add_argument("--method", choices=["pairwise", "dlt"], default="pairwise",
+                    help="pairwise = the reference's algorithm (the metric); dlt = N-view DLT (row N3), for comparison only")
     ap.add_argument("--force-dist", action="store_true",
                     help="testing aid: run the torch.distributed / all-gather code path even with --gpus 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -106,10 +108,11 @@ def main():
     Kc, Rc, tc = wl["rig"]
     C, P, Pout = Kc.shape[0], 1, 1
     params = wl["params"]
-    bt = BatchTriangulator(Kc, Rc, tc, params, pout_max=Pout, out_dtype=np.float32, device=local_rank)
+    method = _lib.DLT if args.method == "dlt" else _lib.PAIRWISE
+    bt = BatchTriangulator(Kc, Rc, tc, params, pout_max=Pout, out_dtype=np.float32, device=local_rank, method=method)
     nstreams = max(1, args.streams)
-    bts = [bt] + [BatchTriangulator(Kc, Rc, tc, params, pout_max=Pout, out_dtype=np.float32, device=local_rank)
-                  for _ in range(nstreams - 1)]
+    bts = [bt] + [BatchTriangulator(Kc, Rc, tc, params, pout_max=Pout, out_dtype=np.float32, device=local_rank,
+                                    method=method) for _ in range(nstreams - 1)]
     streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
 
     # pool of distinct resident batches: exact projections + N(0, 1 px) noise, scores U(3.5, 8)
@@ -265,11 +268,12 @@ def main():
                                    f"{F} frames per step per GPU, floor rig, default thresholds; "
                                    f"steps cycle a pool of {len(pool)} distinct HBM-resident batches",
                        "frames_per_step_per_gpu": F, "cameras": C, "persons": P, "joints": J,
-                       "method": "pairwise (reference-exact)", "io": "fp32 in / fp32 out, fp64 math",
+                       "method": "pairwise (reference-exact)" if args.method == "pairwise" else "dlt (N-view, NOT the reference's algorithm)",
+                       "io": "fp32 in / fp32 out, fp64 math",
                        "streams": nstreams,
                        "parallelism": f"frames sharded x{world}, no data-path collective"},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_fused_single<4,float,float>",
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_fused_single<4,%d,float,float>" % (1 if args.method == "dlt" else 0),
                          "kernel_ms_mean": kernel_ms, "kernel_ms_min": kernel_ms_min,
                          "algorithmic_bytes_per_launch": bpf * F, "bytes_per_joint": bpf / (Pout * J)},
             "cpu_baseline": cpu,

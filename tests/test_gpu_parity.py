@@ -491,3 +491,27 @@ def test_smooth_track_sharded_single_rank_group(api):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("kn,ci", [(50, 100), (1, 0), (133, 132), (64, 63)])
+def test_fast_path_keypoint_subset_and_centre_index(api, kn, ci):
+    """keypoint_num < J and a centre joint outside the emitted range, on the single-detection fast path."""
+    from snowmocap_amd import synth, _lib
+    from oracle import oracle as orc
+    wl = synth.config_workload(2, 90, seed=77)
+    wl["kpts"][..., 2] = np.random.default_rng(8).uniform(2.0, 8.0, size=wl["kpts"].shape[:-1]).astype(np.float32)
+    prm = dict(wl["params"], keypoint_num=kn, center_point_index=ci, condense_distance_tol=0.4)
+    K, R, t = wl["rig"]
+    ref = orc.triangulate_condense_batch(K, R, t, wl["kpts"], wl["n_persons"], orc.make_params(**prm), 1)
+    for out_dtype, tol in ((np.float64, XYZ_FUSED), (np.float32, XYZ_F32)):
+        bt = api.BatchTriangulator(K, R, t, prm, pout_max=1, out_dtype=out_dtype)
+        out = bt.run_host(wl["kpts"], wl["n_persons"])
+        bt.close()
+        assert out["xyzs"].shape == (90, 1, kn, 4)
+        assert np.array_equal(out["count"], ref["count"])
+        assert ((out["flags"] & _lib.FLAG_FASTPATH) != 0).mean() > 0.8
+        for f in range(90):
+            if ref["count"][f]:
+                assert_scores_close(out["xyzs"][f, :1, :, 3], ref["kscore"][f, :1], rtol=3e-7 if out_dtype == np.float32 else 1e-9)
+                assert_xyz_close(out["xyzs"][f, :1, :, :3], ref["xyz"][f, :1], tol, score_ref=ref["kscore"][f, :1])
+                assert_scores_close(out["pscore"][f, :1], ref["pscore"][f, :1], rtol=3e-7 if out_dtype == np.float32 else 1e-9, nterms=kn)
