@@ -187,7 +187,15 @@ __device__ __forceinline__ bool pairwise_item(const Rig &rig, const double *__re
     // ray matrices M[C][9], camera centres t[C][3], per-pair d = t_s - t_m.  Holding the ~70 doubles
     // in scalar registers instead overflows the SGPR file: loop-invariant scalars then live in
     // VGPR-lane spills and the remainder is re-fetched with serialised scalar loads every item.
-    const double *Mp = Mlds, *tp = Mlds + 9 * C, *pc = Mlds + 12 * C;
+    // Issue every LDS read of M and d up front into registers (sched_barrier keeps them there): one wait
+    // per item instead of ~25 scattered ones (+2.5 % measured); t is read where it is used, at the end.
+    double Mp[9 * C], pc[3 * (C * (C - 1) / 2)];
+#pragma unroll
+    for (int i = 0; i < 9 * C; i++) Mp[i] = Mlds[i];
+#pragma unroll
+    for (int i = 0; i < 3 * (C * (C - 1) / 2); i++) pc[i] = Mlds[12 * C + i];
+    __builtin_amdgcn_sched_barrier(0);
+    const double *tp = Mlds + 9 * C;
 #ifdef SNOWTRI_MEMTEST  // dev experiment: memory path only, no solves
     {
         double su = 0, sv = 0, ss = 0;
