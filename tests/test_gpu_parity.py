@@ -515,3 +515,58 @@ def test_fast_path_keypoint_subset_and_centre_index(api, kn, ci):
                 assert_scores_close(out["xyzs"][f, :1, :, 3], ref["kscore"][f, :1], rtol=3e-7 if out_dtype == np.float32 else 1e-9)
                 assert_xyz_close(out["xyzs"][f, :1, :, :3], ref["xyz"][f, :1], tol, score_ref=ref["kscore"][f, :1])
                 assert_scores_close(out["pscore"][f, :1], ref["pscore"][f, :1], rtol=3e-7 if out_dtype == np.float32 else 1e-9, nterms=kn)
+
+
+def test_materialised_entries_with_device_pointers(api):
+    """snowtri_triangulate / snowtri_condense with SNOWTRI_DEVICE pointers (torch tensors) on a stream:
+    same answers as the host-pointer calls."""
+    import ctypes as ct
+    import torch
+    from snowmocap_amd import synth, _lib
+    wl = synth.config_workload(3, 3, seed=31)
+    K, R, t = wl["rig"]
+    ctx = _lib.Context(K, R, t)
+    L = _lib.lib()
+    kp, npers = wl["kpts"], wl["n_persons"]
+    F, C, Pmax, J, _ = kp.shape
+    Kc = int(L.snowtri_num_candidate_slots(C, Pmax))
+    prm = _lib.make_params(**wl["params"])
+    # host reference
+    hx, hk, hp, hkeep = np.zeros((F, Kc, J, 3)), np.zeros((F, Kc, J)), np.zeros((F, Kc)), np.zeros((F, Kc), np.uint8)
+    _lib.check(L.snowtri_triangulate(ctx.handle, F, Pmax, J, _lib.ptr(kp), _lib.F32, _lib.ptr(npers), prm, _lib.ptr(hx),
+                                     _lib.ptr(hk), _lib.ptr(hp), _lib.ptr(hkeep), _lib.HOST, None), "tri host")
+    dev = torch.device("cuda", 0)
+    st = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(st):
+        dkp, dnp = torch.from_numpy(kp).to(dev), torch.from_numpy(npers).to(dev)
+        dx = torch.zeros((F, Kc, J, 3), dtype=torch.float64, device=dev)
+        dk = torch.zeros((F, Kc, J), dtype=torch.float64, device=dev)
+        dp = torch.zeros((F, Kc), dtype=torch.float64, device=dev)
+        dkeep = torch.zeros((F, Kc), dtype=torch.uint8, device=dev)
+        p = lambda tns: ct.c_void_p(tns.data_ptr())
+        _lib.check(L.snowtri_triangulate(ctx.handle, F, Pmax, J, p(dkp), _lib.F32, p(dnp), prm, p(dx), p(dk), p(dp), p(dkeep),
+                                         _lib.DEVICE, ct.c_void_p(st.cuda_stream)), "tri dev")
+        pout = 16
+        ox = torch.empty((F, pout, 133, 3), dtype=torch.float64, device=dev)
+        ok = torch.empty((F, pout, 133), dtype=torch.float64, device=dev)
+        op = torch.empty((F, pout), dtype=torch.float64, device=dev)
+        oc = torch.empty((F,), dtype=torch.int32, device=dev)
+        ofl = torch.empty((F,), dtype=torch.int32, device=dev)
+        _lib.check(L.snowtri_condense(ctx.handle, F, Kc, J, p(dx), p(dk), p(dkeep), prm, pout, p(ox), p(ok), p(op), p(oc), p(ofl),
+                                      _lib.DEVICE, ct.c_void_p(st.cuda_stream)), "condense dev")
+    st.synchronize()
+    assert np.array_equal(dkeep.cpu().numpy(), hkeep)
+    keep = hkeep.astype(bool)
+    np.testing.assert_array_equal(dx.cpu().numpy()[keep], hx[keep])
+    np.testing.assert_array_equal(dk.cpu().numpy()[keep], hk[keep])
+    # condensed persons from the device path == fused batch entry on the same frames
+    bt = api.BatchTriangulator(K, R, t, wl["params"], pout_max=pout, out_dtype=np.float64)
+    fused = bt.run_host(kp, npers)
+    bt.close()
+    cnt = oc.cpu().numpy()
+    assert np.array_equal(cnt, fused["count"])
+    for f in range(F):
+        m = int(cnt[f])
+        assert_xyz_close(ox.cpu().numpy()[f, :m], fused["xyzs"][f, :m, :, :3], 1e-9)
+        assert_scores_close(ok.cpu().numpy()[f, :m], fused["xyzs"][f, :m, :, 3])
+    ctx.close()
