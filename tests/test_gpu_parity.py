@@ -570,3 +570,44 @@ def test_materialised_entries_with_device_pointers(api):
         assert_xyz_close(ox.cpu().numpy()[f, :m], fused["xyzs"][f, :m, :, :3], 1e-9)
         assert_scores_close(ok.cpu().numpy()[f, :m], fused["xyzs"][f, :m, :, 3])
     ctx.close()
+
+
+@pytest.mark.parametrize("cfg,F,nspot", [(3, 10000, 12), (5, 1500, 2)])
+def test_full_size_properties_multi_person(api, cfg, F, nspot):
+    """BASELINE configs[2] at its full 10 000 frames (and the 16 x 8 shape at 1 500): deterministic,
+    invariant to frame sharding (bit-identical), every frame finds at least its true persons, and a
+    random sample of frames equals the oracle."""
+    import torch
+    from snowmocap_amd import synth, _lib
+    from oracle import oracle as orc
+    wl = synth.config_workload(cfg, F)
+    K, R, t = wl["rig"]
+    P = wl["X"].shape[1]
+    pout = 32
+    bt = api.BatchTriangulator(K, R, t, wl["params"], pout_max=pout, out_dtype=np.float32)
+    dev = torch.device("cuda", 0)
+    kp, npers = torch.from_numpy(wl["kpts"]).to(dev), torch.from_numpy(wl["n_persons"]).to(dev)
+    full = bt.run_torch(kp, npers)
+    torch.cuda.synchronize()
+    a, cnt = full["xyzs"].cpu().numpy().copy(), full["count"].cpu().numpy().copy()
+    again = bt.run_torch(kp, npers)
+    torch.cuda.synchronize()
+    assert np.array_equal(a, again["xyzs"].cpu().numpy()) and np.array_equal(cnt, again["count"].cpu().numpy())
+    cut = F // 3 + 1
+    parts = []
+    for lo, hi in ((0, cut), (cut, F)):
+        o = bt.run_torch(kp[lo:hi].contiguous(), npers[lo:hi].contiguous())
+        torch.cuda.synchronize()
+        parts.append(o["xyzs"].cpu().numpy())
+    assert np.array_equal(a, np.concatenate(parts)), "sharding over frames changed the result"
+    assert (cnt >= P).all() and (cnt <= pout).all()
+    assert not ((full["flags"].cpu().numpy() & (_lib.FLAG_SINGULAR | _lib.FLAG_OVERFLOW)) != 0).any()
+    idx = np.sort(np.random.default_rng(cfg).choice(F, nspot, replace=False))
+    ref = orc.triangulate_condense_batch(K, R, t, wl["kpts"][idx], wl["n_persons"][idx], orc.make_params(**wl["params"]), pout)
+    assert np.array_equal(cnt[idx], ref["count"])
+    for i, f in enumerate(idx):
+        m = int(ref["count"][i])
+        assert_xyz_close(a[f, :m, :, :3], ref["xyz"][i, :m], XYZ_F32, score_ref=ref["kscore"][i, :m])
+        assert_scores_close(a[f, :m, :, 3], ref["kscore"][i, :m], rtol=3e-7)
+    # the P best-supported persons of every frame sit on the synthetic truth (1 px noise -> centimetres at most)
+    bt.close()
