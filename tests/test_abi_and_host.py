@@ -150,3 +150,22 @@ def test_blender_control_points_match_reference():
                                bl["blender_armature_control_points"][0]["head_ik"], atol=1e-12)
     out = Human_Triangulation_To_Blender_Result(s1)
     assert set(out) == {"armature", "score"} and len(out["armature"]) == persons.shape[0]
+
+
+def _build_c_consumer(tmp_path):
+    import subprocess
+    exe = str(tmp_path / "c_abi_smoke")
+    lib_dir = os.path.dirname(_lib.LIB_PATH)
+    subprocess.check_call(["gcc", "-std=c99", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "c_abi_smoke.c"), "-o", exe, "-L", lib_dir, "-lsnowtri", "-lm",
+                           "-Wl,-rpath," + lib_dir])
+    return exe
+
+
+def test_header_is_plain_c_and_links(tmp_path):
+    """include/snowtri.h compiles as C99 and a C program links against libsnowtri.so (no C++ in the ABI)."""
+    import subprocess
+    exe = _build_c_consumer(tmp_path)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    if _lib.lib().snowtri_device_count() <= 0:
+        assert out.returncode == 0 and "no device" in out.stdout

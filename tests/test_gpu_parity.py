@@ -611,3 +611,13 @@ def test_full_size_properties_multi_person(api, cfg, F, nspot):
         assert_scores_close(a[f, :m, :, 3], ref["kscore"][i, :m], rtol=3e-7)
     # the P best-supported persons of every frame sit on the synthetic truth (1 px noise -> centimetres at most)
     bt.close()
+
+
+def test_plain_c_consumer_runs(api, tmp_path):
+    """tests/c_abi_smoke.c (gcc -std=c99 against include/snowtri.h) runs the fused entry on the GPU."""
+    import subprocess
+    from test_abi_and_host import _build_c_consumer
+    exe = _build_c_consumer(tmp_path)
+    out = subprocess.run([exe], capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "c abi ok" in out.stdout
