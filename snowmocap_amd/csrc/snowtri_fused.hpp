@@ -108,7 +108,7 @@ __global__ __launch_bounds__(kBlock) void k_frame_general(int64_t F, int Pmax, i
 // Minimum waves per SIMD the fast kernel is compiled for (caps its VGPR allocation: 4 -> 128).
 // Depth of the register prefetch ring of k_fused_single (2 or 3 keypoint buffers per lane).
 #ifndef SNOWTRI_RING
-#define SNOWTRI_RING 2
+#define SNOWTRI_RING 3
 #endif
 #ifndef SNOWTRI_FAST_WAVES
 #define SNOWTRI_FAST_WAVES 2
