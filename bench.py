@@ -189,11 +189,12 @@ def main():
 
     # dominant-kernel duration: HIP events bracketing each launch on the launch stream
     # (snowtri_set_timing records them inside the C ABI around k_fused_single only).
+    # (launches are queued back to back on ONE stream and their event pairs read afterwards: a synchronize
+    # between launches would let the GPU idle and clock down, and stretch every launch by ~10 %)
     bt.ctx.set_timing(True)
-    kms = []
-    for i in range(min(K_steps, 200)):
+    for i in range(min(K_steps, 1000)):
         bt.run_torch(pool[i % len(pool)], None, out=outs[i % len(pool)])
-        kms.append(bt.ctx.last_kernel_ms()[0])
+    kms = bt.ctx.timing_collect()
     bt.ctx.set_timing(False)
     torch.cuda.synchronize(dev)
     kernel_ms = float(np.mean(kms))

@@ -172,6 +172,11 @@ int snowtri_smooth_shard_fix(snowtri_ctx *ctx, int64_t T, int64_t n, int first, 
  * snowtri_triangulate_condense call on this context, measured on the stream they ran on
  * (blocks until they finish).  kernel_ms[0] = dominant fused kernel, [1] = everything else. */
 int snowtri_last_kernel_ms(snowtri_ctx *ctx, float kernel_ms[2]);
+/* With timing enabled every fused call also records a (begin, end) HIP-event pair in a ring (1024 deep), so a
+ * caller can queue many launches back to back on one stream and read their individual durations afterwards:
+ * writes up to `cap` durations (ms, oldest first) of the calls recorded since the last collect, returns how
+ * many (blocks until they have finished; -1 on error). */
+int snowtri_timing_collect(snowtri_ctx *ctx, float *kernel_ms, int32_t cap);
 /* Toggle per-call event timing (off by default: it adds two event records per launch). */
 int snowtri_set_timing(snowtri_ctx *ctx, int enabled);
 /* Frames of the last SNOWTRI_HOST fused call that were resolved by the general routine instead of

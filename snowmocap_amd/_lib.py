@@ -85,6 +85,7 @@ _SIGNATURES = {
                                             ct.c_double, ct.c_double, _c_p, ct.c_int, _c_p]),
     "snowtri_last_kernel_ms": (ct.c_int, [_c_p, ct.POINTER(ct.c_float * 2)]),
     "snowtri_set_timing": (ct.c_int, [_c_p, ct.c_int]),
+    "snowtri_timing_collect": (ct.c_int, [_c_p, _c_p, ct.c_int32]),
     "snowtri_last_slow_frames": (ct.c_int64, [_c_p]),
 }
 
@@ -192,6 +193,14 @@ class Context:
         arr = (ct.c_float * 2)()
         check(lib().snowtri_last_kernel_ms(self.handle, ct.byref(arr)), "snowtri_last_kernel_ms")
         return float(arr[0]), float(arr[1])
+
+    def timing_collect(self, cap=1024):
+        """Durations (ms) of the fused calls recorded since the last collect (timing must be enabled)."""
+        arr = (ct.c_float * cap)()
+        n = lib().snowtri_timing_collect(self.handle, arr, cap)
+        if n < 0:
+            raise SnowtriError(ERR_HIP, "snowtri_timing_collect")
+        return [float(arr[i]) for i in range(n)]
 
     def last_slow_frames(self):
         return int(lib().snowtri_last_slow_frames(self.handle))

@@ -80,6 +80,8 @@ int inv3(const double *m, double *o) {
     return 0;
 }
 
+constexpr int kTimingRing = 1024;
+
 int grid_for(int64_t work_items, int per_block, int cap_blocks) {
     int64_t b = (work_items + per_block - 1) / per_block;
     return (int)std::max<int64_t>(1, std::min<int64_t>(b, cap_blocks));
@@ -102,6 +104,8 @@ struct snowtri_ctx {
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false;
     hipStream_t ev_stream = nullptr;
+    std::vector<hipEvent_t> ev_ring;  // 2 events per recorded fused call (begin, end), kTimingRing calls deep
+    int64_t ev_count = 0;             // fused calls recorded since the last snowtri_timing_collect
     int64_t last_slow_frames = 0;
     int general_mode = 0;  // dev/test knob: 0 auto, 1 force the spill kernel, 2 force the recompute kernel
     Rig rig() const { return Rig{dM, dt, dpairs, dpairc, dP, C, npairs}; }
@@ -236,6 +240,8 @@ int snowtri_ctx_destroy(snowtri_ctx *ctx) {
     ctx->misc.release();
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
+    for (auto &e : ctx->ev_ring)
+        if (e) (void)hipEventDestroy(e);
     delete ctx;
     return SNOWTRI_OK;
 }
@@ -259,7 +265,26 @@ int snowtri_set_timing(snowtri_ctx *ctx, int enabled) {
     if (!ctx) return SNOWTRI_ERR_BAD_ARG;
     ctx->timing = enabled != 0;
     ctx->ev_valid = false;
+    ctx->ev_count = 0;
+    if (ctx->timing && ctx->ev_ring.empty()) {
+        HIP_TRY(hipSetDevice(ctx->device));
+        ctx->ev_ring.resize(2 * kTimingRing, nullptr);
+        for (auto &e : ctx->ev_ring) HIP_TRY(hipEventCreate(&e));
+    }
     return SNOWTRI_OK;
+}
+
+int snowtri_timing_collect(snowtri_ctx *ctx, float *kernel_ms, int32_t cap) {
+    if (!ctx || !kernel_ms || cap < 0) return -1;
+    const int64_t n = std::min<int64_t>(std::min<int64_t>(ctx->ev_count, kTimingRing), cap);
+    const int64_t first = ctx->ev_count - n;
+    for (int64_t i = 0; i < n; i++) {
+        const int64_t slot = (first + i) % kTimingRing;
+        if (hipEventSynchronize(ctx->ev_ring[2 * slot + 1]) != hipSuccess) return -1;
+        if (hipEventElapsedTime(&kernel_ms[i], ctx->ev_ring[2 * slot], ctx->ev_ring[2 * slot + 1]) != hipSuccess) return -1;
+    }
+    ctx->ev_count = 0;
+    return (int)n;
 }
 
 int snowtri_last_kernel_ms(snowtri_ctx *ctx, float kernel_ms[2]) {
@@ -845,7 +870,11 @@ int fused_dispatch(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax, int J,
     // below avg_thr <= 0 and the fast kernel needs no negative-score check
     const bool fast = Pmax == 1 && C >= 3 && C <= 8 && prm.kn >= 1 && prm.avg_thr <= 0.0 && prm.kthr >= 0.0 &&
                       !((double)ctx->npairs < prm.num_tol) && ctx->general_mode == 0;
-    if (ctx->timing) HIP_TRY(hipEventRecord(ctx->ev[0], st));
+    const int64_t ring_slot = ctx->ev_count % kTimingRing;
+    if (ctx->timing) {
+        HIP_TRY(hipEventRecord(ctx->ev[0], st));
+        HIP_TRY(hipEventRecord(ctx->ev_ring[2 * ring_slot], st));
+    }
     int rc;
     if (method == SNOWTRI_DLT) {
         switch (C) {  // single detection per camera only (host-checked): no association needed
@@ -886,6 +915,8 @@ int fused_dispatch(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax, int J,
     }
     if (rc) return rc;
     if (ctx->timing) {
+        HIP_TRY(hipEventRecord(ctx->ev_ring[2 * ring_slot + 1], st));
+        ctx->ev_count++;
         HIP_TRY(hipEventRecord(ctx->ev[1], st));
         HIP_TRY(hipEventRecord(ctx->ev[2], st));
         HIP_TRY(hipEventRecord(ctx->ev[3], st));
