@@ -168,6 +168,30 @@ int snowtri_smooth_shard_local(snowtri_ctx *ctx, int64_t T, int64_t n, const dou
 int snowtri_smooth_shard_fix(snowtri_ctx *ctx, int64_t T, int64_t n, int first, const double *start_state, double f,
                              double z, double r, double dt, double *y, int memspace, void *stream);
 
+/* N2  Blender IK control points (blender.py:98-143; names and order of configs/blender_armature_profile.json:
+ * root_position, root_rotation, clavicle_r_ik, clavicle_l_ik, arm_r_ik, arm_r_pole, arm_l_ik, arm_l_pole,
+ * leg_r_ik, leg_r_pole, leg_l_ik, leg_l_pole, hand_r_ik, hand_r_pole, hand_l_ik, hand_l_pole, foot_r_ik,
+ * foot_r_pole, foot_l_ik, foot_l_pole, chest_ik, chest_pole, head_ik, head_pole).
+ *   xyzs [n][keypoint_num][4] of xyz_dtype -- n skeletons as written by snowtri_triangulate_condense
+ *        (x, y, z, score; the score is not read); keypoint_num >= 130 (COCO-WholeBody joints up to 129 are used),
+ *        otherwise SNOWTRI_ERR_BAD_INDEX (the reference raises IndexError);
+ *   out_points [n][24][4] fp64: 3-vectors padded with 0, root_rotation as the quaternion (w, x, y, z)
+ *        (blender.py:28-29);  out_valid [n][24]: 0 where the point has a NaN component (blender.py:135-139).
+ * A NaN root_rotation (coincident hips, or spine parallel to the pelvis axis) makes the reference raise inside
+ * SciPy's SVD; here it is reported as out_valid = 0 and the Python mirror raises. */
+#define SNOWTRI_BLENDER_POINTS 24
+int snowtri_blender_points(snowtri_ctx *ctx, int64_t n, int32_t keypoint_num, const void *xyzs, int xyz_dtype,
+                           double *out_points, uint8_t *out_valid, int memspace, void *stream);
+
+/* N2  Human_Triangulation_Blender_Smooth (blender.py:145-178) over a whole track of control points:
+ *   points [T][n_persons][24][4] fp64, valid [T][n_persons][24], fzr [24][3] = per-point (f, z, r) of
+ *   configs/blender_smooth_profile.json, dt = delta_time  ->  out [T][n_persons][24][4].
+ * Frame 0 is returned as given (NaNs included) and seeds every filter with the point, or with zeros when it is
+ * invalid; a later invalid point feeds the filter its previous input.  Evaluated as chunked scans over frames. */
+int snowtri_blender_smooth(snowtri_ctx *ctx, int64_t T, int64_t n_persons, const double *points,
+                           const uint8_t *valid, const double *fzr, double dt, double *out, int memspace,
+                           void *stream);
+
 /* Measurement aid: HIP-event time (ms) of the kernels launched by the LAST
  * snowtri_triangulate_condense call on this context, measured on the stream they ran on
  * (blocks until they finish).  kernel_ms[0] = dominant fused kernel, [1] = everything else. */

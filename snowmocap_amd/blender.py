@@ -1,10 +1,13 @@
 """Row N2 (after the hot path): 133 whole-body joints -> the 24 Blender IK control points of
 snowvision/blender.py, per-control-point temporal filtering, and the on-disk JSON track.
 
-Host-side shim so the reference's caller sequence (main.py:80-87,104) runs on this package; same names,
-signatures and dict schemas as the reference.  The geometry is written as one declarative table
-(CONTROL_POINTS) instead of the reference's per-name helper calls + `eval` (blender.py:98-143); results are
-pinned to the reference by tests/golden/g6_smooth_blender.npz.
+Same names, signatures and dict schemas as the reference, so its caller sequence (main.py:80-87,104) runs on
+this package.  The geometry runs on the GPU (snowtri_blender_points: one lane per skeleton); the per-frame
+`Human_Triangulation_Blender` is a one-skeleton-batch call of it, `blender_points_track` / `blender_smooth_track`
+are the additive whole-track forms (snowtri_blender_smooth: hold + per-bone filters as chunked scans).
+`Human_Triangulation_Blender_Smooth` keeps the reference's stateful per-frame protocol (filter objects travel
+inside the result dict, blender.py:152-178) and is host bookkeeping around those objects.
+Pinned to the reference by tests/golden/g6_smooth_blender.npz, g7_pipeline.npz, g8_blender_track.npz.
 """
 from __future__ import annotations
 
@@ -12,72 +15,55 @@ import copy
 import json
 
 import numpy as np
-from scipy.spatial.transform import Rotation
 
+from . import _lib
 from .triangulation import SecondOrderDynamic
 
-
-def _unit(v):
-    return v / np.linalg.norm(v)
-
-
-def _mid(a, b):
-    return (a + b) / 2
-
-
-def _cross_pole(base, first, second):
-    """base + unit(first x second)"""
-    return base + _unit(np.cross(first, second))
+# order of configs/blender_armature_profile.json = slot order of snowtri_blender_points (include/snowtri.h)
+CONTROL_POINT_NAMES = ("root_position", "root_rotation", "clavicle_r_ik", "clavicle_l_ik", "arm_r_ik", "arm_r_pole",
+                       "arm_l_ik", "arm_l_pole", "leg_r_ik", "leg_r_pole", "leg_l_ik", "leg_l_pole", "hand_r_ik",
+                       "hand_r_pole", "hand_l_ik", "hand_l_pole", "foot_r_ik", "foot_r_pole", "foot_l_ik",
+                       "foot_l_pole", "chest_ik", "chest_pole", "head_ik", "head_pole")
+_SLOT = {n: i for i, n in enumerate(CONTROL_POINT_NAMES)}
+_WIDTH = {n: (4 if n == "root_rotation" else 3) for n in CONTROL_POINT_NAMES}
 
 
-def _joint_pole(joint, upper, lower):
-    """Elbow / knee pole (blender.py:87-95): joint + unit((b x a) x c), a = upper-joint, b = lower-joint, c = upper-lower."""
-    a, b, c = upper - joint, lower - joint, upper - lower
-    return joint + _unit(np.cross(np.cross(b, a), c))
+def blender_points_track(xyzs):
+    """xyzs[..., kn, 4] (x, y, z, score; float32 or float64, as the fused triangulation writes them) or
+    xyzs[..., kn, 3]  ->  points[..., 24, 4] fp64 (3-vectors padded with 0; root_rotation = (w, x, y, z)),
+    valid[..., 24] uint8.  GPU, one lane per skeleton."""
+    a = np.asarray(xyzs)
+    if a.shape[-1] == 3:
+        a = np.concatenate([a, np.zeros(a.shape[:-1] + (1,), a.dtype)], axis=-1)
+    if a.dtype != np.float32:
+        a = a.astype(np.float64, copy=False)
+    a = np.ascontiguousarray(a)
+    lead, kn = a.shape[:-2], a.shape[-2]
+    n = int(np.prod(lead)) if lead else 1
+    pts = np.empty((n, 24, 4), np.float64)
+    val = np.empty((n, 24), np.uint8)
+    ctx = _lib.scratch_context()
+    st = _lib.lib().snowtri_blender_points(ctx.handle, n, kn, _lib.ptr(a), _lib.dtype_code(a.dtype), _lib.ptr(pts),
+                                           _lib.ptr(val), _lib.HOST, None)
+    if st == _lib.ERR_BAD_INDEX:
+        raise IndexError(f"index 129 is out of bounds for axis 0 with size {kn}")      # blender.py:117
+    _lib.check(st, "snowtri_blender_points")
+    return pts.reshape(lead + (24, 4)), val.reshape(lead + (24,))
 
 
-def _root_rotation(p5, p6, p11, p12):
-    """Pelvis frame (blender.py:15-35): x = pelvis axis, y = spine, z = x x y (each normalised, NOT mutually
-    orthogonal), turned into a quaternion by SciPy (which orthogonalises first) and reordered to (w, x, y, z)."""
-    x = _unit(p11 - p12)
-    y = _unit(_mid(p5, p6) - _mid(p11, p12))
-    z = _unit(np.cross(x, y))
-    q = Rotation.from_matrix(np.array([x, y, z]).T).as_quat()
-    return np.array([q[3], q[0], q[1], q[2]])
-
-
-def _head_ik(p3, p4, p5, p6):
-    sh = _mid(p5, p6)
-    return sh + _unit(_mid(p3, p4) - sh)
-
-
-# name -> function of the person array P[J,3]; joint numbers are COCO-WholeBody indices (blender.py:105-130)
-CONTROL_POINTS = {
-    "root_position": lambda P: _mid(P[11], P[12]),
-    "root_rotation": lambda P: _root_rotation(P[5], P[6], P[11], P[12]),
-    "clavicle_r_ik": lambda P: P[6],
-    "clavicle_l_ik": lambda P: P[5],
-    "arm_r_ik": lambda P: P[10],
-    "arm_r_pole": lambda P: _joint_pole(P[8], P[6], P[10]),
-    "arm_l_ik": lambda P: P[9],
-    "arm_l_pole": lambda P: _joint_pole(P[7], P[5], P[9]),
-    "leg_r_ik": lambda P: P[16],
-    "leg_r_pole": lambda P: _joint_pole(P[14], P[12], P[16]),
-    "leg_l_ik": lambda P: P[15],
-    "leg_l_pole": lambda P: _joint_pole(P[13], P[11], P[15]),
-    "hand_r_ik": lambda P: P[121],
-    "hand_r_pole": lambda P: _cross_pole(P[112], P[117] - P[112], P[129] - P[112]),
-    "hand_l_ik": lambda P: P[100],
-    "hand_l_pole": lambda P: _cross_pole(P[91], P[108] - P[91], P[96] - P[91]),
-    "foot_r_ik": lambda P: _mid(P[20], P[21]),
-    "foot_r_pole": lambda P: _cross_pole(P[22], P[20] - P[22], P[21] - P[22]),
-    "foot_l_ik": lambda P: _mid(P[17], P[18]),
-    "foot_l_pole": lambda P: _cross_pole(P[19], P[18] - P[19], P[17] - P[19]),
-    "chest_ik": lambda P: _mid(P[5], P[6]),
-    "chest_pole": lambda P: _cross_pole(_mid(P[5], P[6]), P[5] - P[6], _mid(P[5], P[6]) - _mid(P[11], P[12])),
-    "head_ik": lambda P: _head_ik(P[3], P[4], P[5], P[6]),
-    "head_pole": lambda P: _cross_pole(_mid(P[3], P[4]), P[3] - P[4], _mid(P[3], P[4]) - _mid(P[5], P[6])),
-}
+def blender_smooth_track(points, valid, blender_smooth_profile, delta_time=1 / 30):
+    """Whole-track form of Human_Triangulation_Blender_Smooth: points[T, P, 24, 4], valid[T, P, 24], per-bone
+    (f, z, r) from the smooth profile dict  ->  smoothed[T, P, 24, 4] (frame 0 as given)."""
+    x = np.ascontiguousarray(points, dtype=np.float64)
+    v = np.ascontiguousarray(valid, dtype=np.uint8)
+    T, P = x.shape[0], x.shape[1]
+    fzr = np.ascontiguousarray([blender_smooth_profile[n] for n in CONTROL_POINT_NAMES], dtype=np.float64)
+    y = np.empty_like(x)
+    ctx = _lib.scratch_context()
+    _lib.check(_lib.lib().snowtri_blender_smooth(ctx.handle, T, P, _lib.ptr(x), _lib.ptr(v), _lib.ptr(fzr),
+                                                 float(delta_time), _lib.ptr(y), _lib.HOST, None),
+               "snowtri_blender_smooth")
+    return y
 
 
 def save_blender_result(blender_result, file_path):
@@ -89,14 +75,18 @@ def Human_Triangulation_Blender(result, blender_armature_profile):
     """Per person: {control point name: list} for every name in the armature profile, plus a 0/1 score
     (0 when the point is NaN, e.g. built from a zero-score joint at the origin) -- blender.py:98-143."""
     out = {"blender_armature_control_points": [], "blender_armature_control_points_scores": []}
-    for person in result["hrnet_triangulate_points"]:
-        P = np.asarray(person)
+    persons = result["hrnet_triangulate_points"]
+    if len(persons) == 0:
+        return out
+    pts, val = blender_points_track(np.stack([np.asarray(p, dtype=np.float64) for p in persons]))
+    if not val[:, _SLOT["root_rotation"]].all():
+        raise np.linalg.LinAlgError("SVD did not converge")            # what SciPy raises on the NaN pelvis matrix
+    for p in range(len(persons)):
         points, scores = copy.deepcopy(blender_armature_profile), copy.deepcopy(blender_armature_profile)
-        with np.errstate(all="ignore"):
-            for name in blender_armature_profile.keys():
-                value = CONTROL_POINTS[name](P)
-                points[name] = value.tolist()
-                scores[name] = 0 if np.isnan(value).any() else 1
+        for name in blender_armature_profile.keys():
+            i = _SLOT[name]
+            points[name] = pts[p, i, :_WIDTH[name]].tolist()
+            scores[name] = int(val[p, i])
         out["blender_armature_control_points"].append(points)
         out["blender_armature_control_points_scores"].append(scores)
     return out

@@ -19,6 +19,7 @@
 #include "snowtri_fused.hpp"
 #include "snowtri_general.hpp"
 #include "snowtri_smooth.hpp"
+#include "snowtri_blender.hpp"
 #include "snowtri_kernels.hpp"
 
 using namespace snowtri;
@@ -98,7 +99,7 @@ struct snowtri_ctx {
     double *dM = nullptr, *dt = nullptr, *dpairc = nullptr, *dP = nullptr;
     int32_t *dpairs = nullptr;
     unsigned long long *d_counters = nullptr;  // [0] singular pairs, [1] slow frames, [2..] spare
-    Scratch in, out, work, misc;
+    Scratch in, out, work, misc, aux;
     // measurement
     bool timing = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -238,6 +239,7 @@ int snowtri_ctx_destroy(snowtri_ctx *ctx) {
     ctx->out.release();
     ctx->work.release();
     ctx->misc.release();
+    ctx->aux.release();
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
     for (auto &e : ctx->ev_ring)
@@ -602,8 +604,10 @@ dim3 smooth_grid(int64_t n, int64_t nchunks) {
 }
 
 // Zero-state response of frames [tb, T) into dy (frame 0 passes through when first); optional end state.
+// This is the first half of the two-call protocol of a frame-sharded track.
+template <typename KS>
 int smooth_local_dev(snowtri_ctx *ctx, hipStream_t st, int64_t T, int64_t n, const double *dx, double *dy,
-                     bool first, const SmoothCoef &k, double *d_end) {
+                     bool first, const KS &k, double *d_end) {
     const int tb = first ? 1 : 0;
     const int64_t m = T - tb, nchunks = (m + kSmoothChunk - 1) / kSmoothChunk;
     if (nchunks > 65535) return SNOWTRI_ERR_BAD_ARG;
@@ -616,21 +620,23 @@ int smooth_local_dev(snowtri_ctx *ctx, hipStream_t st, int64_t T, int64_t n, con
     if (rc) return rc;
     double *E = (double *)ctx->work.p, *S = E + 2 * (size_t)nchunks * n;
     const dim3 g2 = smooth_grid(n, nchunks), g1 = smooth_grid(n, 1);
-    hipLaunchKernelGGL(k_smooth_local, g2, dim3(kSmoothBlock), 0, st, T, n, kSmoothChunk, tb, k, dx, dy, E);
-    hipLaunchKernelGGL(k_smooth_carry, g1, dim3(kSmoothBlock), 0, st, n, nchunks, k, (const double *)nullptr,
+    hipLaunchKernelGGL((k_smooth_local<KS, NoHold>), g2, dim3(kSmoothBlock), 0, st, T, n, kSmoothChunk, tb, k, NoHold{}, dx,
+                       (const double *)nullptr, dy, E);
+    hipLaunchKernelGGL(k_smooth_carry<KS>, g1, dim3(kSmoothBlock), 0, st, n, nchunks, k, (const double *)nullptr,
                        (const double *)E, S);
-    hipLaunchKernelGGL(k_smooth_fix, g2, dim3(kSmoothBlock), 0, st, T, n, kSmoothChunk, tb, k, (const double *)S, dy,
+    hipLaunchKernelGGL(k_smooth_fix<KS>, g2, dim3(kSmoothBlock), 0, st, T, n, kSmoothChunk, tb, k, (const double *)S, dy,
                        (double *)nullptr);
     if (d_end)
-        hipLaunchKernelGGL(k_smooth_shard_end, g1, dim3(kSmoothBlock), 0, st, T, n, kSmoothChunk, tb, nchunks, k,
+        hipLaunchKernelGGL(k_smooth_shard_end<KS>, g1, dim3(kSmoothBlock), 0, st, T, n, kSmoothChunk, tb, nchunks, k,
                            (const double *)S, (const double *)E, d_end);
     HIP_TRY(hipGetLastError());
     return SNOWTRI_OK;
 }
 
-// dy += homogeneous response of the state `d_start` entering frame tb.
+// dy += homogeneous response of the state `d_start` entering frame tb (second half of the sharded protocol).
+template <typename KS>
 int smooth_fix_dev(snowtri_ctx *ctx, hipStream_t st, int64_t T, int64_t n, double *dy, bool first,
-                   const double *d_start, const SmoothCoef &k) {
+                   const double *d_start, const KS &k) {
     const int tb = first ? 1 : 0;
     const int64_t m = T - tb, nchunks = (m + kSmoothChunk - 1) / kSmoothChunk;
     if (m <= 0) return SNOWTRI_OK;
@@ -638,9 +644,39 @@ int smooth_fix_dev(snowtri_ctx *ctx, hipStream_t st, int64_t T, int64_t n, doubl
     int rc = ctx->work.ensure(sizeof(double) * 2 * (size_t)nchunks * n + 64);
     if (rc) return rc;
     double *S = (double *)ctx->work.p;
-    hipLaunchKernelGGL(k_smooth_carry, smooth_grid(n, 1), dim3(kSmoothBlock), 0, st, n, nchunks, k, d_start,
+    hipLaunchKernelGGL(k_smooth_carry<KS>, smooth_grid(n, 1), dim3(kSmoothBlock), 0, st, n, nchunks, k, d_start,
                        (const double *)nullptr, S);
-    hipLaunchKernelGGL(k_smooth_fix, smooth_grid(n, nchunks), dim3(kSmoothBlock), 0, st, T, n, kSmoothChunk, tb, k,
+    hipLaunchKernelGGL(k_smooth_fix<KS>, smooth_grid(n, nchunks), dim3(kSmoothBlock), 0, st, T, n, kSmoothChunk, tb, k,
+                       (const double *)S, dy, (double *)nullptr);
+    HIP_TRY(hipGetLastError());
+    return SNOWTRI_OK;
+}
+
+// A whole (unsharded) track in three passes: chunk-end states of the zero-state response (reads x, writes
+// nothing per frame), the sequential carry over chunks from the seed (x_0, 0), then the exact recurrence of
+// every chunk from its true entering state (reads x, writes y).  d_seed_row: [n] inputs of frame 0 as the
+// filters see them (x[0] itself for N1; the held x_eff[0] for N2).
+template <typename KS, typename HS>
+int smooth_whole_dev(snowtri_ctx *ctx, hipStream_t st, int64_t T, int64_t n, const double *dx, double *dy,
+                     const double *d_seed_row, const KS &k, const HS &hs) {
+    const int64_t m = T - 1, nchunks = (m + kSmoothChunk - 1) / kSmoothChunk;
+    if (nchunks > 65535) return SNOWTRI_ERR_BAD_ARG;
+    if (m <= 0) {
+        HIP_TRY(hipMemcpyAsync(dy, dx, sizeof(double) * (size_t)T * n, hipMemcpyDeviceToDevice, st));
+        return SNOWTRI_OK;
+    }
+    int rc = ctx->work.ensure(sizeof(double) * 4 * (size_t)nchunks * n + 64);
+    if (rc) return rc;
+    rc = ctx->misc.ensure(sizeof(double) * 2 * n);
+    if (rc) return rc;
+    double *E = (double *)ctx->work.p, *S = E + 2 * (size_t)nchunks * n, *seed = (double *)ctx->misc.p;
+    const dim3 g2 = smooth_grid(n, nchunks), g1 = smooth_grid(n, 1);
+    hipLaunchKernelGGL((k_smooth_local<KS, HS>), g2, dim3(kSmoothBlock), 0, st, T, n, kSmoothChunk, 1, k, hs, dx,
+                       (const double *)nullptr, (double *)nullptr, E);
+    hipLaunchKernelGGL(k_smooth_seed, g1, dim3(kSmoothBlock), 0, st, n, d_seed_row, seed);
+    hipLaunchKernelGGL(k_smooth_carry<KS>, g1, dim3(kSmoothBlock), 0, st, n, nchunks, k, (const double *)seed,
+                       (const double *)E, S);
+    hipLaunchKernelGGL((k_smooth_local<KS, HS>), g2, dim3(kSmoothBlock), 0, st, T, n, kSmoothChunk, 1, k, hs, dx,
                        (const double *)S, dy, (double *)nullptr);
     HIP_TRY(hipGetLastError());
     return SNOWTRI_OK;
@@ -669,7 +705,7 @@ int snowtri_smooth_shard_local(snowtri_ctx *ctx, int64_t T, int64_t n, const dou
     if (!x || !y) return SNOWTRI_ERR_BAD_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
-    const SmoothCoef k = smooth_coef(f, z, r, dt);
+    const UniformCoef k{smooth_coef(f, z, r, dt)};
     const size_t bytes = sizeof(double) * (size_t)T * n;
     const double *dx = x;
     double *dy = y, *dend = end_state;
@@ -700,7 +736,7 @@ int snowtri_smooth_shard_fix(snowtri_ctx *ctx, int64_t T, int64_t n, int first, 
     if (!start_state || !y) return SNOWTRI_ERR_BAD_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
-    const SmoothCoef k = smooth_coef(f, z, r, dt);
+    const UniformCoef k{smooth_coef(f, z, r, dt)};
     const size_t bytes = sizeof(double) * (size_t)T * n;
     double *dy = y;
     const double *dstart = start_state;
@@ -730,7 +766,7 @@ int snowtri_smooth_track(snowtri_ctx *ctx, int64_t T, int64_t n, const double *x
     if (!x || !y) return SNOWTRI_ERR_BAD_ARG;
     HIP_TRY(hipSetDevice(ctx->device));
     hipStream_t st = (hipStream_t)stream;
-    const SmoothCoef k = smooth_coef(f, z, r, dt);
+    const UniformCoef k{smooth_coef(f, z, r, dt)};
     const size_t bytes = sizeof(double) * (size_t)T * n;
     const double *dx = x;
     double *dy = y;
@@ -743,15 +779,112 @@ int snowtri_smooth_track(snowtri_ctx *ctx, int64_t T, int64_t n, const double *x
         dx = (const double *)ctx->in.p;
         dy = (double *)ctx->out.p;
     }
-    int rc = smooth_local_dev(ctx, st, T, n, dx, dy, true, k, nullptr);
-    if (rc) return rc;
-    rc = ctx->misc.ensure(sizeof(double) * 2 * n);
-    if (rc) return rc;
-    hipLaunchKernelGGL(k_smooth_seed, smooth_grid(n, 1), dim3(kSmoothBlock), 0, st, n, dx, (double *)ctx->misc.p);
-    rc = smooth_fix_dev(ctx, st, T, n, dy, true, (const double *)ctx->misc.p, k);
+    int rc = smooth_whole_dev(ctx, st, T, n, dx, dy, dx, k, NoHold{});
     if (rc) return rc;
     if (memspace == SNOWTRI_HOST) {
         HIP_TRY(hipMemcpyAsync(y, dy, bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return SNOWTRI_OK;
+}
+
+// ---------------------------------------------------------------------------------------- N2
+int snowtri_blender_points(snowtri_ctx *ctx, int64_t n, int32_t keypoint_num, const void *xyzs, int xyz_dtype,
+                           double *out_points, uint8_t *out_valid, int memspace, void *stream) {
+    if (!ctx || n < 0 || (xyz_dtype != SNOWTRI_F32 && xyz_dtype != SNOWTRI_F64) ||
+        (memspace != SNOWTRI_HOST && memspace != SNOWTRI_DEVICE))
+        return SNOWTRI_ERR_BAD_ARG;
+    if (keypoint_num < kBlenderMinJoints) return SNOWTRI_ERR_BAD_INDEX;  // person[129] would raise IndexError
+    if (n == 0) return SNOWTRI_OK;
+    if (!xyzs || !out_points || !out_valid) return SNOWTRI_ERR_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const size_t esz = xyz_dtype == SNOWTRI_F32 ? 4 : 8;
+    const size_t in_bytes = esz * 4 * (size_t)keypoint_num * n, pt_bytes = sizeof(double) * 4 * kBlenderPoints * n;
+    const void *dx = xyzs;
+    double *dp = out_points;
+    uint8_t *dv = out_valid;
+    if (memspace == SNOWTRI_HOST) {
+        int rc = ctx->in.ensure(in_bytes);
+        if (rc) return rc;
+        rc = ctx->out.ensure(pt_bytes + (size_t)kBlenderPoints * n);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(ctx->in.p, xyzs, in_bytes, hipMemcpyHostToDevice, st));
+        dx = ctx->in.p;
+        dp = (double *)ctx->out.p;
+        dv = (uint8_t *)ctx->out.p + pt_bytes;
+    }
+    const dim3 grid((unsigned)((n + 255) / 256));
+    if (xyz_dtype == SNOWTRI_F32)
+        hipLaunchKernelGGL(k_blender_points<float>, grid, dim3(256), 0, st, n, (int)keypoint_num, (const float *)dx, dp, dv);
+    else
+        hipLaunchKernelGGL(k_blender_points<double>, grid, dim3(256), 0, st, n, (int)keypoint_num, (const double *)dx, dp, dv);
+    HIP_TRY(hipGetLastError());
+    if (memspace == SNOWTRI_HOST) {
+        HIP_TRY(hipMemcpyAsync(out_points, dp, pt_bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipMemcpyAsync(out_valid, dv, (size_t)kBlenderPoints * n, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return SNOWTRI_OK;
+}
+
+int snowtri_blender_smooth(snowtri_ctx *ctx, int64_t T, int64_t n_persons, const double *points,
+                           const uint8_t *valid, const double *fzr, double dt, double *out, int memspace,
+                           void *stream) {
+    if (!ctx || T < 0 || n_persons < 0 || !fzr || !(dt > 0.0) ||
+        (memspace != SNOWTRI_HOST && memspace != SNOWTRI_DEVICE))
+        return SNOWTRI_ERR_BAD_ARG;
+    for (int i = 0; i < kBlenderPoints; i++)
+        if (!(fzr[3 * i] > 0.0)) return SNOWTRI_ERR_BAD_ARG;
+    if (T == 0 || n_persons == 0) return SNOWTRI_OK;
+    if (!points || !valid || !out) return SNOWTRI_ERR_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t n = n_persons * kBlenderPoints * 4, nv = n_persons * kBlenderPoints;
+    const int64_t nchunks = (T - 1 + kSmoothChunk - 1) / kSmoothChunk;  // the filter's chunks: frames 1..T-1
+    if (nchunks > 65535) return SNOWTRI_ERR_BAD_ARG;
+    const size_t bytes = sizeof(double) * (size_t)T * n, vbytes = (size_t)T * nv;
+    // aux: [coef table | hold scratch (H, start, Hf)] (+ staged valid for host calls)
+    const size_t cn = (size_t)std::max<int64_t>(1, nchunks) * n;
+    const size_t off_H = 4096, off_start = off_H + sizeof(double) * cn, off_Hf = off_start + sizeof(double) * cn,
+                 off_valid = (off_Hf + cn + 255) & ~(size_t)255;
+    int rc = ctx->aux.ensure(off_valid + vbytes);
+    if (rc) return rc;
+    char *aux = (char *)ctx->aux.p;
+    SmoothCoef tab[kBlenderPoints];
+    for (int i = 0; i < kBlenderPoints; i++) tab[i] = smooth_coef(fzr[3 * i], fzr[3 * i + 1], fzr[3 * i + 2], dt);
+    static_assert(sizeof(tab) <= 4096, "coefficient table does not fit its slot");
+    HIP_TRY(hipMemcpyAsync(aux, tab, sizeof(tab), hipMemcpyHostToDevice, st));
+    HIP_TRY(hipStreamSynchronize(st));  // tab is a stack array
+    const double *dx = points;
+    const uint8_t *dv = valid;
+    double *dy = out;
+    if (memspace == SNOWTRI_HOST) {
+        rc = ctx->in.ensure(bytes);
+        if (rc) return rc;
+        rc = ctx->out.ensure(bytes);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(ctx->in.p, points, bytes, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(aux + off_valid, valid, vbytes, hipMemcpyHostToDevice, st));
+        dx = (const double *)ctx->in.p;
+        dv = (const uint8_t *)(aux + off_valid);
+        dy = (double *)ctx->out.p;
+    }
+    double *H = (double *)(aux + off_H), *start = (double *)(aux + off_start);
+    uint8_t *Hf = (uint8_t *)(aux + off_Hf);
+    const dim3 g1 = smooth_grid(n, 1);
+    if (nchunks > 0)
+        hipLaunchKernelGGL(k_hold_last, smooth_grid(n, nchunks), dim3(256), 0, st, T, n, kSmoothChunk, 4, dx, dv, H, Hf);
+    hipLaunchKernelGGL(k_hold_carry, g1, dim3(256), 0, st, n, nchunks, 4, dx, dv, (const double *)H, (const uint8_t *)Hf,
+                       start);
+    HIP_TRY(hipGetLastError());
+    const TableCoef k{(const SmoothCoef *)aux, 4, kBlenderPoints};
+    const HoldInput hs{dv, (const double *)start, 4};
+    // frame 0 is returned as given, NaNs included (blender.py:176); the filters are seeded with the held row
+    rc = smooth_whole_dev(ctx, st, T, n, dx, dy, (const double *)start, k, hs);
+    if (rc) return rc;
+    if (memspace == SNOWTRI_HOST) {
+        HIP_TRY(hipMemcpyAsync(out, dy, bytes, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
     }
     return SNOWTRI_OK;

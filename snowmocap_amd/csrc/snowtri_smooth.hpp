@@ -26,44 +26,87 @@ struct SmoothCoef {
 
 constexpr int kSmoothBlock = 256;
 
+// Where a lane's coefficients come from: one set for the whole track (N1), or a table indexed by the lane's
+// control point (N2: per-bone f, z, r -- blender.py:171; lanes = [person][ncoef points][comps]).
+struct UniformCoef {
+    SmoothCoef k;
+    __device__ __forceinline__ const SmoothCoef &at(int64_t) const { return k; }
+};
+struct TableCoef {
+    const SmoothCoef *tab;
+    int comps, ncoef;
+    __device__ __forceinline__ SmoothCoef at(int64_t lane) const { return tab[(lane / comps) % ncoef]; }
+};
+
+// What a lane's input is: the track itself (N1), or the track with invalid points replaced by the lane's
+// previous input (N2, blender.py:157-160: `flt.update(dt, x if score else flt.xp)`).
+struct NoHold {
+    __device__ __forceinline__ double entering(const double *x, int64_t t0, int64_t, int64_t n, int64_t lane) const {
+        return x[(t0 > 0 ? t0 - 1 : 0) * n + lane];
+    }
+    __device__ __forceinline__ int64_t groups(int64_t) const { return 0; }
+    __device__ __forceinline__ int64_t group(int64_t) const { return 0; }
+    __device__ __forceinline__ double input(double xt, double, int64_t) const { return xt; }
+};
+struct HoldInput {
+    const uint8_t *valid;  // [T][n / comps]
+    const double *start;   // [nchunks][n]: the held input entering each chunk (k_hold_carry)
+    int comps;
+    __device__ __forceinline__ double entering(const double *, int64_t, int64_t c, int64_t n, int64_t lane) const {
+        return start[c * n + lane];
+    }
+    __device__ __forceinline__ int64_t groups(int64_t n) const { return n / comps; }
+    __device__ __forceinline__ int64_t group(int64_t lane) const { return lane / comps; }
+    __device__ __forceinline__ double input(double xt, double xp, int64_t vidx) const { return valid[vidx] ? xt : xp; }
+};
+
 // frames tb..T-1 are the filtered ones (tb = 1: frame 0 is the seed and passes through; tb = 0: a later
 // shard of a frame-sharded track, whose first frame is filtered with xd = 0 -- the caller corrects for the
-// true previous input afterwards); chunk c covers frames [tb + c L, min(T, tb + (c+1) L))
-__global__ __launch_bounds__(kSmoothBlock) void k_smooth_local(int64_t T, int64_t n, int L, int tb,
-                                                               SmoothCoef k, const double *__restrict__ x,
+// true previous input afterwards); chunk c covers frames [tb + c L, min(T, tb + (c+1) L)).
+// S (optional): state entering each chunk, [nchunks][n][2]; absent = zero state.
+// y (optional): the response is written; E (optional): the chunk-end state is written.
+template <typename KS, typename HS>
+__global__ __launch_bounds__(kSmoothBlock) void k_smooth_local(int64_t T, int64_t n, int L, int tb, KS ks, HS hs,
+                                                               const double *__restrict__ x,
+                                                               const double *__restrict__ S,
                                                                double *__restrict__ y, double *__restrict__ E) {
     const int64_t lane = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t c = blockIdx.y;
     if (lane >= n) return;
+    const SmoothCoef k = ks.at(lane);
     const int64_t t0 = tb + c * L, t1 = (t0 + L < T) ? t0 + L : T;
-    if (c == 0 && tb == 1) y[lane] = x[lane];  // frame 0 passes through (:180-181)
-    double sy = 0.0, syd = 0.0;
-    double xp = x[(t0 > 0 ? t0 - 1 : 0) * n + lane];
+    if (y && c == 0 && tb == 1) y[lane] = x[lane];  // frame 0 passes through (:180-181)
+    double sy = S ? S[(c * n + lane) * 2] : 0.0, syd = S ? S[(c * n + lane) * 2 + 1] : 0.0;
+    double xp = hs.entering(x, t0, c, n, lane);
+    const int64_t nv = hs.groups(n), g = hs.group(lane);
     for (int64_t t = t0; t < t1; t++) {
-        const double xt = x[t * n + lane];
+        const double xt = hs.input(x[t * n + lane], xp, t * nv + g);
         const double ct = fma(k.cxd, xt - xp, k.cx * xt);
         xp = xt;
         const double ny = fma(k.a01, syd, k.a00 * sy);
         const double nyd = fma(k.a11, syd, fma(k.a10, sy, ct));
         sy = ny;
         syd = nyd;
-        y[t * n + lane] = sy;
+        if (y) y[t * n + lane] = sy;
     }
-    // a short last chunk still needs its end state advanced as if full? No: the carry only feeds LATER chunks.
-    E[(c * n + lane) * 2] = sy;
-    E[(c * n + lane) * 2 + 1] = syd;
+    if (E) {
+        E[(c * n + lane) * 2] = sy;
+        E[(c * n + lane) * 2 + 1] = syd;
+    }
 }
 
 // start: state entering the first chunk -- [2n] array, or nullptr = zero.  E: chunk zero-state end states,
 // or nullptr = none (pure homogeneous propagation).  end_out (optional, [2n]): state after the last FULL-LENGTH
 // step count, i.e. exact only when every chunk is full; callers that need the shard's end state use the
 // per-lane sequential tail below instead.
-__global__ __launch_bounds__(kSmoothBlock) void k_smooth_carry(int64_t n, int64_t nchunks, SmoothCoef k,
+template <typename KS>
+__global__ __launch_bounds__(kSmoothBlock) void k_smooth_carry(int64_t n, int64_t nchunks, KS ks,
                                                                const double *__restrict__ start,
                                                                const double *__restrict__ E,
                                                                double *__restrict__ S) {
     const int64_t lane = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (lane >= n) return;
+    const SmoothCoef k = ks.at(lane);
     double sy = start ? start[2 * lane] : 0.0, syd = start ? start[2 * lane + 1] : 0.0;
     for (int64_t c = 0; c < nchunks; c++) {
         S[(c * n + lane) * 2] = sy;
@@ -86,12 +129,14 @@ __global__ __launch_bounds__(kSmoothBlock) void k_smooth_seed(int64_t n, const d
 }
 
 // y_t += (A^{t-t0+1} S_c).y ; the last chunk (optionally) also reports the propagated state (end_out, [2n])
-__global__ __launch_bounds__(kSmoothBlock) void k_smooth_fix(int64_t T, int64_t n, int L, int tb, SmoothCoef k,
+template <typename KS>
+__global__ __launch_bounds__(kSmoothBlock) void k_smooth_fix(int64_t T, int64_t n, int L, int tb, KS ks,
                                                              const double *__restrict__ S, double *__restrict__ y,
                                                              double *__restrict__ end_out) {
     const int64_t lane = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     const int64_t c = blockIdx.y;
     if (lane >= n) return;
+    const SmoothCoef k = ks.at(lane);
     const int64_t t0 = tb + c * L, t1 = (t0 + L < T) ? t0 + L : T;
     double vy = S[(c * n + lane) * 2], vyd = S[(c * n + lane) * 2 + 1];
     for (int64_t t = t0; t < t1; t++) {
@@ -109,13 +154,15 @@ __global__ __launch_bounds__(kSmoothBlock) void k_smooth_fix(int64_t T, int64_t 
 
 // zero-state end state of the whole shard = zero-start carry over the chunks, advanced through the last chunk:
 // the last chunk's own zero-state end E[last] plus the homogeneous propagation of its start state.
+template <typename KS>
 __global__ __launch_bounds__(kSmoothBlock) void k_smooth_shard_end(int64_t T, int64_t n, int L, int tb,
-                                                                   int64_t nchunks, SmoothCoef k,
+                                                                   int64_t nchunks, KS ks,
                                                                    const double *__restrict__ S,
                                                                    const double *__restrict__ E,
                                                                    double *__restrict__ end_out) {
     const int64_t lane = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (lane >= n) return;
+    const SmoothCoef k = ks.at(lane);
     const int64_t c = nchunks - 1;
     const int64_t t0 = tb + c * L;
     double vy = S[(c * n + lane) * 2], vyd = S[(c * n + lane) * 2 + 1];

@@ -9,7 +9,8 @@ it -- SURVEY.md §8c); nothing of the reference's source is copied.
     python tests/golden/make_golden.py            # regenerates every fixture (~2 min)
 
 Fixture classes: G1 cfg-1 plumbing, G2 near-exact, G3 multi-person,
-G4 edge cases, G5 Skew_Ray_Solver unit vectors, G6 smoothing + Blender control points.
+G4 edge cases, G5 Skew_Ray_Solver unit vectors, G6 smoothing + Blender control points, G7 the main.py
+sequence, G8 a Blender control-point track with invalid (NaN) points through the per-bone filters.
 
 Scenario schema (one prefix per scenario inside an .npz):
   K[C,3,3] R[C,3,3] t[C,3]      rig (R = camera->world, t = camera centre)
@@ -373,9 +374,61 @@ def g7_pipeline():
     print("g7_pipeline.npz", os.path.getsize(path) / 1e6, "MB")
 
 
+def g8_blender_track():
+    """Row N2 over a track: Human_Triangulation_Blender + Human_Triangulation_Blender_Smooth (blender.py:98-178)
+    frame after frame, with joints knocked out to (0,0,0) (what Condense emits for a zero-score joint) so some
+    control points turn NaN -> score 0 -> the filter holds its previous input; includes an invalid FIRST frame."""
+    rng = np.random.default_rng(8)
+    T, P, J = 80, 2, 133
+    with open(os.path.join(REF, "configs/blender_armature_profile.json")) as fh:
+        arm = json.load(fh)
+    with open(os.path.join(REF, "configs/blender_smooth_profile.json")) as fh:
+        smo = json.load(fh)
+    names = list(arm.keys())
+    base = synth.make_people(rng, 1, P)[0]
+    track = base[None] + np.cumsum(rng.normal(0, 0.01, size=(T, P, J, 3)), axis=0)
+    # knock-outs: (frames, person, joints)
+    for frames, p, joints in ((range(0, 3), 1, (112, 117, 129)),       # right hand, person 1, from frame 0
+                              (range(10, 11), 0, (91, 96, 108)),         # single frame
+                              (range(20, 29), 0, (19, 17, 18)),          # left foot, a run of 9
+                              (range(40, 44), 1, (3, 4)),                # ears: head_ik / head_pole go (hips or shoulders at 0
+                              # make the pelvis matrix NaN and the reference raises in SciPy's SVD)
+                              (range(60, 62), 0, (7,)), (range(70, 80), 1, (14,))):  # elbow / knee to the end
+        for f in frames:
+            for j in joints:
+                track[f, p, j] = 0.0
+    dt = 1 / 30
+    raw = np.zeros((T, P, len(names), 4))
+    valid = np.zeros((T, P, len(names)), np.uint8)
+    smoothed = np.zeros((T, P, len(names), 4))
+    prev = None
+    for f in range(T):
+        res = {"hrnet_triangulate_points": [track[f, p].copy() for p in range(P)],
+               "hrnet_triangulate_keypoint_scores": [np.ones(J) for _ in range(P)]}
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            bl = sv.Human_Triangulation_Blender(res, arm)
+            for p in range(P):
+                for i, nm in enumerate(names):
+                    v = bl["blender_armature_control_points"][p][nm]
+                    raw[f, p, i, :len(v)] = v
+                    valid[f, p, i] = bl["blender_armature_control_points_scores"][p][nm]
+            sm = sv.Human_Triangulation_Blender_Smooth(bl, arm, smo, prev, delta_time=dt)
+        prev = sm
+        for p in range(P):
+            for i, nm in enumerate(names):
+                v = sm["blender_armature_control_points"][p][nm]
+                smoothed[f, p, i, :len(v)] = v
+    assert valid.min() == 0 and valid[0].min() == 0
+    path = os.path.join(HERE, "g8_blender_track.npz")
+    np.savez_compressed(path, track=track, raw=raw, valid=valid, smoothed=smoothed, dt=dt,
+                        names=np.array(names), fzr=np.array([smo[n] for n in names], dtype=np.float64))
+    print("g8_blender_track.npz", os.path.getsize(path) / 1e6, "MB")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
     fns = dict(g1=g1_plumbing, g2=g2_near_exact, g3=g3_multi_person, g4=g4_edge_cases,
-               g5=g5_skew_ray, g6=g6_smooth_blender, g7=g7_pipeline)
+               g5=g5_skew_ray, g6=g6_smooth_blender, g7=g7_pipeline, g8=g8_blender_track)
     for w in which:
         fns[w]()

@@ -117,39 +117,37 @@ def test_util_helpers(tmp_path):
     assert Check_If_File_Exist(str(p))[1].endswith("out_1.json")
 
 
-def test_blender_control_points_match_reference():
-    """Row N2 host shim vs the reference's Human_Triangulation_Blender outputs (fixture G6)."""
-    from snowmocap_amd.blender import (Human_Triangulation_Blender, Human_Triangulation_Blender_Smooth,
-                                       Human_Triangulation_To_Blender_Result, CONTROL_POINTS)
-    z = np.load(os.path.join(GOLDEN, "g6_smooth_blender.npz"))
-    names = [str(n) for n in z["blender_names"]]
-    assert names == list(CONTROL_POINTS.keys())
-    profile = {n: [] for n in names}
-    persons = z["blender_persons"]
-    res = {"hrnet_triangulate_points": [persons[p] for p in range(persons.shape[0])],
-           "hrnet_triangulate_keypoint_scores": [np.ones(133)] * persons.shape[0]}
-    bl = Human_Triangulation_Blender(res, profile)
-    for p in range(persons.shape[0]):
-        for i, n in enumerate(names):
-            got = np.array(bl["blender_armature_control_points"][p][n])
-            want = z["blender_ctrl"][p, i, :len(got)]
-            np.testing.assert_allclose(got, want, rtol=0, atol=1e-12, err_msg=n)
-            assert len(got) == (4 if n == "root_rotation" else 3)
-            assert bl["blender_armature_control_points_scores"][p][n] == 1
-    # a zero-score joint sits at the origin -> degenerate cross products -> NaN -> score 0
-    broken = persons[0].copy()
-    broken[112] = broken[117] = broken[129] = 0.0
-    bl2 = Human_Triangulation_Blender({"hrnet_triangulate_points": [broken]}, profile)
-    assert bl2["blender_armature_control_points_scores"][0]["hand_r_pole"] == 0
-    # smoothing: first frame passes through and seeds the filters, second frame moves towards the input
-    smooth_profile = {n: [2.5, 0.75, 0] for n in names}
-    s0 = Human_Triangulation_Blender_Smooth(bl, profile, smooth_profile, None, delta_time=1 / 30)
-    assert s0["blender_armature_control_points"] is bl["blender_armature_control_points"]
-    s1 = Human_Triangulation_Blender_Smooth(bl, profile, smooth_profile, s0, delta_time=1 / 30)
-    np.testing.assert_allclose(s1["blender_armature_control_points"][0]["head_ik"],
-                               bl["blender_armature_control_points"][0]["head_ik"], atol=1e-12)
-    out = Human_Triangulation_To_Blender_Result(s1)
-    assert set(out) == {"armature", "score"} and len(out["armature"]) == persons.shape[0]
+def test_blender_smooth_host_protocol():
+    """Human_Triangulation_Blender_Smooth keeps the reference's stateful per-frame protocol (blender.py:145-178):
+    replay fixture G8's raw control points frame by frame (no GPU involved) and compare with the reference."""
+    from snowmocap_amd.blender import (Human_Triangulation_Blender_Smooth, Human_Triangulation_To_Blender_Result,
+                                       CONTROL_POINT_NAMES)
+    z = np.load(os.path.join(GOLDEN, "g8_blender_track.npz"))
+    names = [str(n) for n in z["names"]]
+    assert names == list(CONTROL_POINT_NAMES)
+    arm = {n: [] for n in names}
+    smo = {n: z["fzr"][i].tolist() for i, n in enumerate(names)}
+    raw = z["raw"].copy()
+    raw[z["valid"] == 0] = np.nan          # the fixture stores padded zeros; invalid points are NaN in the reference
+    T, P = raw.shape[:2]
+    prev = None
+    for f in range(T):
+        bl = {"blender_armature_control_points":
+              [{n: raw[f, p, i, :4 if n == "root_rotation" else 3].tolist() for i, n in enumerate(names)} for p in range(P)],
+              "blender_armature_control_points_scores":
+              [{n: int(z["valid"][f, p, i]) for i, n in enumerate(names)} for p in range(P)]}
+        sm = Human_Triangulation_Blender_Smooth(bl, arm, smo, prev, delta_time=float(z["dt"]))
+        prev = sm
+        for p in range(P):
+            for i, n in enumerate(names):
+                got = np.array(sm["blender_armature_control_points"][p][n])
+                want = z["smoothed"][f, p, i, :len(got)]
+                if f == 0 and not z["valid"][f, p, i]:
+                    assert np.isnan(got).any()
+                else:
+                    np.testing.assert_allclose(got, want, rtol=0, atol=1e-13, err_msg=f"{f} {n}")
+    out = Human_Triangulation_To_Blender_Result(sm)
+    assert set(out) == {"armature", "score"} and len(out["armature"]) == P
 
 
 def _build_c_consumer(tmp_path):

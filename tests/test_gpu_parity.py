@@ -367,6 +367,116 @@ def test_smooth_track_against_reference_and_oracle(api):
     assert np.array_equal(one, x[:1])
 
 
+# ------------------------------------------------------------------ row N2: Blender control points
+def test_blender_points_against_reference(api):
+    """snowtri_blender_points vs the reference's Human_Triangulation_Blender (fixtures G6 and G8): values to
+    1e-12, validity flags identical, NaN exactly where the reference has NaN; the per-frame mirror too."""
+    from snowmocap_amd import blender as bl
+    z6 = np.load(f"{GOLDEN}/g6_smooth_blender.npz")
+    names = [str(n) for n in z6["blender_names"]]
+    assert names == list(bl.CONTROL_POINT_NAMES)
+    persons = z6["blender_persons"]
+    res = {"hrnet_triangulate_points": [persons[p] for p in range(persons.shape[0])],
+           "hrnet_triangulate_keypoint_scores": [np.ones(133)] * persons.shape[0]}
+    profile = {n: [] for n in names}
+    out = api.Human_Triangulation_Blender(res, profile)
+    for p in range(persons.shape[0]):
+        for i, n in enumerate(names):
+            got = np.array(out["blender_armature_control_points"][p][n])
+            assert len(got) == (4 if n == "root_rotation" else 3)
+            np.testing.assert_allclose(got, z6["blender_ctrl"][p, i, :len(got)], rtol=0, atol=1e-12, err_msg=n)
+            assert out["blender_armature_control_points_scores"][p][n] == 1
+    assert api.Human_Triangulation_Blender({"hrnet_triangulate_points": []}, profile) == \
+        {"blender_armature_control_points": [], "blender_armature_control_points_scores": []}
+    sub = {n: [] for n in names[:5]}                       # a profile may name a subset
+    assert list(api.Human_Triangulation_Blender(res, sub)["blender_armature_control_points"][0]) == names[:5]
+
+    z8 = np.load(f"{GOLDEN}/g8_blender_track.npz")
+    pts, val = bl.blender_points_track(z8["track"])        # [T,P,133,3] fp64
+    np.testing.assert_array_equal(val, z8["valid"])
+    ok = z8["valid"].astype(bool)
+    np.testing.assert_allclose(pts[ok], z8["raw"][ok], rtol=0, atol=1e-12)
+    assert np.isnan(pts[~ok][:, :3]).any(axis=1).all()
+    # errors the reference raises
+    with pytest.raises(IndexError):
+        bl.blender_points_track(z8["track"][0, :, :100])
+    bad = z8["track"][5, 0].copy()
+    bad[11] = bad[12] = 0.0
+    with pytest.raises(np.linalg.LinAlgError):
+        api.Human_Triangulation_Blender({"hrnet_triangulate_points": [bad]}, profile)
+
+
+def test_blender_points_float32_records_and_device_pointers(api):
+    """The [kn][4] float32 records the fused kernel writes feed snowtri_blender_points directly (device
+    pointers, no host round trip); compared with the oracle on the same float32 values."""
+    import torch
+    from oracle import blender as ob
+    from snowmocap_amd import _lib, synth
+    rng = np.random.default_rng(21)
+    n = 3000
+    xyz = synth.make_people(rng, 1, n)[0].astype(np.float32)                       # [n,133,3]
+    rec = np.concatenate([xyz, rng.uniform(0, 9, (n, 133, 1)).astype(np.float32)], axis=-1)
+    rec[7, 112] = rec[7, 117] = 0.0                                                # one broken hand
+    want, wval = ob.control_points_track(rec[..., :3].astype(np.float64))
+    dev = torch.device("cuda", 0)
+    d_rec = torch.from_numpy(rec).to(dev)
+    d_pts = torch.empty((n, 24, 4), dtype=torch.float64, device=dev)
+    d_val = torch.empty((n, 24), dtype=torch.uint8, device=dev)
+    ctx = _lib.scratch_context()
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(_lib.lib().snowtri_blender_points(ctx.handle, n, 133, d_rec.data_ptr(), _lib.F32, d_pts.data_ptr(),
+                                                 d_val.data_ptr(), _lib.DEVICE, st), "blender_points")
+    torch.cuda.synchronize()
+    got, gval = d_pts.cpu().numpy(), d_val.cpu().numpy()
+    np.testing.assert_array_equal(gval, wval)
+    assert gval[7, 13] == 0 and gval.sum() == gval.size - 1
+    ok = wval.astype(bool)
+    # the quaternion's sign convention and every point agree to rounding (SVD vs closed-form projection: 1e-14)
+    np.testing.assert_allclose(got[ok], want[ok], rtol=0, atol=1e-11)
+    # and through the host-pointer entry with the 4-wide records
+    pts2, val2 = __import__("snowmocap_amd.blender", fromlist=["x"]).blender_points_track(rec)
+    np.testing.assert_array_equal(pts2[ok], got[ok])
+    np.testing.assert_array_equal(val2, gval)
+
+
+def test_blender_smooth_track_against_reference_and_oracle(api):
+    """snowtri_blender_smooth (hold + per-bone filters as chunked scans) vs the reference's frame-by-frame
+    Human_Triangulation_Blender_Smooth (G8, invalid first frame included) and, over many chunks with invalid
+    runs that cross chunk boundaries, vs the sequential oracle."""
+    from oracle import blender as ob
+    from snowmocap_amd import blender as bl
+    z = np.load(f"{GOLDEN}/g8_blender_track.npz")
+    names = [str(n) for n in z["names"]]
+    smo = {n: z["fzr"][i].tolist() for i, n in enumerate(names)}
+    ok = z["valid"].astype(bool)
+    raw = z["raw"].copy()
+    raw[~ok] = np.nan
+    got = bl.blender_smooth_track(raw, z["valid"], smo, float(z["dt"]))
+    keep = np.ones(ok.shape, bool)
+    keep[0] = ok[0]
+    np.testing.assert_allclose(got[keep], z["smoothed"][keep], rtol=0, atol=1e-11)
+    assert np.isnan(got[0][~ok[0]]).all()
+    # long track: 5 chunks of 256 frames, 3 persons, invalid runs across chunk edges and a whole invalid chunk
+    rng = np.random.default_rng(22)
+    T, P = 1200, 3
+    pts = np.cumsum(rng.normal(0, 0.01, (T, P, 24, 4)), axis=0) + rng.uniform(-2, 2, (1, P, 24, 4))
+    val = (rng.uniform(size=(T, P, 24)) > 0.03).astype(np.uint8)
+    val[250:262, 0, 5] = 0
+    val[256:600, 1, 13] = 0
+    val[0:300, 2, 7] = 0
+    val[:, 2, 9] = 0
+    pts[val == 0] = np.nan
+    fzr = np.stack([rng.uniform(1.0, 4.0, 24), rng.uniform(0.4, 1.2, 24), rng.uniform(-1, 2, 24)], axis=1)
+    prof = {n: fzr[i].tolist() for i, n in enumerate(bl.CONTROL_POINT_NAMES)}
+    want = ob.smooth_track(pts, val, fzr, 1 / 30)
+    got = bl.blender_smooth_track(pts, val, prof, 1 / 30)
+    np.testing.assert_allclose(got[1:], want[1:], rtol=0, atol=1e-9)
+    np.testing.assert_array_equal(np.isnan(got[0]), np.isnan(want[0]))
+    assert np.array_equal(got[0][val[0] == 1], pts[0][val[0] == 1])
+    one = bl.blender_smooth_track(pts[:1], val[:1], prof, 1 / 30)
+    np.testing.assert_array_equal(np.isnan(one), np.isnan(pts[:1]))
+
+
 def test_main_loop_sequence_as_snowvision(api, tmp_path, monkeypatch):
     """main.py:47-106 minus video / pose / display, with this package standing in for `snowvision`
     (INTEGRATION.md 1): the JSON track it writes equals the reference's (fixture G7)."""

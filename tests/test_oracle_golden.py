@@ -106,3 +106,32 @@ def test_second_order_track():
     z = np.load(f"{GOLDEN}/g6_smooth_blender.npz")
     y = orc.second_order_track(z["track"], float(z["f"]), float(z["z"]), float(z["r"]), float(z["dt"]))
     np.testing.assert_allclose(y, z["smoothed"], rtol=0, atol=1e-12)
+
+
+def test_blender_restatement_against_reference():
+    """N2: oracle/blender.py vs the reference's Human_Triangulation_Blender (fixtures G6, G8) and
+    Human_Triangulation_Blender_Smooth over an 80-frame track with invalid points (G8)."""
+    from oracle import blender as ob
+    z6 = np.load(f"{GOLDEN}/g6_smooth_blender.npz")
+    assert [str(n) for n in z6["blender_names"]] == ob.NAMES
+    pts, val = ob.control_points_track(z6["blender_persons"])
+    assert val.all()
+    np.testing.assert_allclose(pts, np.nan_to_num(z6["blender_ctrl"]), rtol=0, atol=1e-15)
+    z8 = np.load(f"{GOLDEN}/g8_blender_track.npz")
+    pts, val = ob.control_points_track(z8["track"])
+    np.testing.assert_array_equal(val, z8["valid"])
+    ok = z8["valid"].astype(bool)
+    np.testing.assert_allclose(pts[ok], z8["raw"][ok], rtol=0, atol=1e-15)
+    assert np.isnan(pts[~ok][:, :3]).any(axis=1).all()
+    raw = z8["raw"].copy()
+    raw[~ok] = np.nan
+    sm = ob.smooth_track(raw, z8["valid"], z8["fzr"], float(z8["dt"]))
+    keep = np.ones(sm.shape[:3], bool)
+    keep[0] = ok[0]                                   # frame 0 passes through: NaN where invalid
+    np.testing.assert_allclose(sm[keep], z8["smoothed"][keep], rtol=0, atol=1e-13)
+    assert np.isnan(sm[0][~ok[0]][:, :3]).all()
+    # a NaN pelvis matrix: the reference raises inside SciPy's SVD
+    bad = z8["track"][5, 0].copy()
+    bad[11] = bad[12] = 0.0
+    with pytest.raises(np.linalg.LinAlgError):
+        ob.control_points(bad)
