@@ -192,6 +192,17 @@ int snowtri_blender_smooth(snowtri_ctx *ctx, int64_t T, int64_t n_persons, const
                            const uint8_t *valid, const double *fzr, double dt, double *out, int memspace,
                            void *stream);
 
+/* N4  Keypoint-level lens undistortion, for detections made on RAW frames (the reference undistorts whole
+ * images before detection: main.py:52 cv2.undistort(frame, K, D)).  OpenCV's 5-coefficient Brown-Conrady model,
+ * D[C][5] = (k1, k2, p1, p2, k3) per camera (camera_group_floor.json:53-61; Camera.D, camera.py:24,44); K as
+ * given to snowtri_ctx_create, which must be [[fx, s, cx], [0, fy, cy], [0, 0, 1]].
+ * snowtri_undistort_keypoints maps every (u, v) of kpts [F][C][Pmax][J][3] from the raw image to the
+ * undistorted image (exact inverse of the forward model, Newton, 5e-13 px on the shipped rig) and copies the
+ * score; kpts_out may alias kpts_in; the result feeds snowtri_triangulate_condense unchanged. */
+int snowtri_ctx_set_distortion(snowtri_ctx *ctx, const double *D);
+int snowtri_undistort_keypoints(snowtri_ctx *ctx, int64_t F, int32_t Pmax, int32_t J, const void *kpts_in,
+                                void *kpts_out, int dtype, int memspace, void *stream);
+
 /* Measurement aid: HIP-event time (ms) of the kernels launched by the LAST
  * snowtri_triangulate_condense call on this context, measured on the stream they ran on
  * (blocks until they finish).  kernel_ms[0] = dominant fused kernel, [1] = everything else. */

@@ -63,3 +63,21 @@ t0 = time.perf_counter(); ob.smooth_track(ps, vs, fzr, 1 / 30); cpu = time.perf_
 print(json.dumps({"row": "N2 blender_smooth", "frames": T, "persons": P, "ms": ms,
                   "point_frames_per_s": T * P * 24 / (ms * 1e-3), "algorithmic_GBs": (64 + 1) * T * P * 24 / (ms * 1e-3) / 1e9,
                   "oracle_1thread_point_frames_per_s": 5000 * P * 24 / cpu}))
+
+# N4: undistort the keypoints of 100 000 frames x 4 cameras x 133 joints (float32 [u, v, score] records), in place
+from snowmocap_amd import synth
+K, R, t = synth.load_rig_json()
+lctx = _lib.Context(K, R, t)
+lctx.set_distortion(synth.load_rig_distortion())
+F = 100000
+kp = torch.rand((F, 4, 1, 133, 3), dtype=torch.float32, device=dev) * torch.tensor([1280.0, 720.0, 8.0], device=dev)
+ms = timed(lambda: _lib.check(L.snowtri_undistort_keypoints(lctx.handle, F, 1, 133, kp.data_ptr(), kp.data_ptr(), _lib.F32,
+                                                            _lib.DEVICE, st), "undistort"), reps=5)
+from oracle import undistort as ou
+small = kp[:2000, 0, 0, :, :2].double().cpu().numpy()
+D0 = synth.load_rig_distortion()[0]
+t0 = time.perf_counter(); ou.undistort_pixels(K[0], D0, small, iters=5); cpu = time.perf_counter() - t0
+nobs = F * 4 * 133
+print(json.dumps({"row": "N4 undistort_keypoints", "frames": F, "observations": nobs, "ms": ms,
+                  "observations_per_s": nobs / (ms * 1e-3), "algorithmic_GBs": 24 * nobs / (ms * 1e-3) / 1e9,
+                  "oracle_numpy_1thread_observations_per_s": small.shape[0] * small.shape[1] / cpu}))

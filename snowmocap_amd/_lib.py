@@ -86,6 +86,9 @@ _SIGNATURES = {
     "snowtri_blender_points": (ct.c_int, [_c_p, ct.c_int64, ct.c_int32, _c_p, ct.c_int, _c_p, _c_p, ct.c_int, _c_p]),
     "snowtri_blender_smooth": (ct.c_int, [_c_p, ct.c_int64, ct.c_int64, _c_p, _c_p, _c_p, ct.c_double, _c_p,
                                           ct.c_int, _c_p]),
+    "snowtri_ctx_set_distortion": (ct.c_int, [_c_p, _c_p]),
+    "snowtri_undistort_keypoints": (ct.c_int, [_c_p, ct.c_int64, ct.c_int32, ct.c_int32, _c_p, _c_p, ct.c_int,
+                                               ct.c_int, _c_p]),
     "snowtri_last_kernel_ms": (ct.c_int, [_c_p, ct.POINTER(ct.c_float * 2)]),
     "snowtri_set_timing": (ct.c_int, [_c_p, ct.c_int]),
     "snowtri_timing_collect": (ct.c_int, [_c_p, _c_p, ct.c_int32]),
@@ -188,6 +191,25 @@ class Context:
         M = np.empty((self.C, 9))
         check(lib().snowtri_ctx_ray_matrices(self.handle, ptr(M)), "snowtri_ctx_ray_matrices")
         return M.reshape(self.C, 3, 3)
+
+    def set_distortion(self, D):
+        """Row N4: per-camera lens coefficients D[C, 5] = (k1, k2, p1, p2, k3) (Camera.D)."""
+        Dc = np.ascontiguousarray(np.asarray(D, dtype=np.float64).reshape(self.C, -1)[:, :5])
+        check(lib().snowtri_ctx_set_distortion(self.handle, ptr(Dc)), "snowtri_ctx_set_distortion")
+
+    def undistort_keypoints(self, kpts):
+        """Raw-image keypoints kpts[F, C, Pmax, J, 3] -> the same array with (u, v) moved to the undistorted
+        image (scores untouched); host arrays, float32 or float64."""
+        a = np.asarray(kpts)
+        if a.dtype != np.float32:
+            a = a.astype(np.float64, copy=False)
+        a = np.ascontiguousarray(a)
+        F, C, Pmax, J, three = a.shape
+        assert C == self.C and three == 3
+        out = np.empty_like(a)
+        check(lib().snowtri_undistort_keypoints(self.handle, F, Pmax, J, ptr(a), ptr(out), dtype_code(a.dtype), HOST,
+                                                None), "snowtri_undistort_keypoints")
+        return out
 
     def set_timing(self, enabled=True):
         check(lib().snowtri_set_timing(self.handle, int(bool(enabled))), "snowtri_set_timing")

@@ -12,8 +12,14 @@ from . import _lib
 
 
 class BatchTriangulator:
-    def __init__(self, K, R, t, params, pout_max=1, out_dtype=np.float32, device=0, method=_lib.PAIRWISE):
+    def __init__(self, K, R, t, params, pout_max=1, out_dtype=np.float32, device=0, method=_lib.PAIRWISE, D=None):
+        """D (optional, [C, 5] lens coefficients): the keypoints handed to run_* were detected on RAW frames and
+        are undistorted on the GPU first (row N4, snowtri_undistort_keypoints)."""
         self.ctx = _lib.Context(K, R, t, device=device)
+        self.undistort = D is not None
+        if self.undistort:
+            self.ctx.set_distortion(D)
+        self._ukpts = None
         self.C = self.ctx.C
         self.params = params if isinstance(params, _lib.Params) else _lib.make_params(**params)
         self.pout_max = int(pout_max)
@@ -29,6 +35,8 @@ class BatchTriangulator:
         kn = self.params.keypoint_num
         if n_persons is not None:
             n_persons = np.ascontiguousarray(n_persons, dtype=np.int32).reshape(F, C)
+        if self.undistort:
+            kpts = self.ctx.undistort_keypoints(kpts)
         xyzs = np.empty((F, self.pout_max, max(kn, 0), 4), dtype=self.out_dtype)
         pscore = np.empty((F, self.pout_max), dtype=self.out_dtype)
         count = np.zeros(F, dtype=np.int32)
@@ -69,6 +77,14 @@ class BatchTriangulator:
         if stream is None:
             stream = torch.cuda.current_stream(kpts.device).cuda_stream
         import ctypes as ct
+        if self.undistort:
+            if self._ukpts is None or self._ukpts.shape != kpts.shape or self._ukpts.dtype != kpts.dtype \
+                    or self._ukpts.device != kpts.device:
+                self._ukpts = torch.empty_like(kpts)
+            _lib.check(_lib.lib().snowtri_undistort_keypoints(
+                self.ctx.handle, F, Pmax, J, ct.c_void_p(kpts.data_ptr()), ct.c_void_p(self._ukpts.data_ptr()),
+                in_code, _lib.DEVICE, ct.c_void_p(stream)), "snowtri_undistort_keypoints")
+            kpts = self._ukpts
         rc = _lib.lib().snowtri_triangulate_condense(
             self.ctx.handle, F, Pmax, J, ct.c_void_p(kpts.data_ptr()), in_code,
             ct.c_void_p(n_persons.data_ptr()) if n_persons is not None else None, self.params, self.method,

@@ -107,6 +107,19 @@ class CameraGroup:
             self._ctx_key = key
         return self._ctx
 
+    def undistort_keypoints(self, kpts):
+        """Row N4 (additive): keypoints detected on RAW frames, kpts[F, C, Pmax, J, 3] or one frame
+        [C, Pmax, J, 3], moved to where `cv2.undistort(frame, K, D)` (main.py:52) would have put them, using each
+        camera's K and D -- so the whole-image undistortion can be skipped.  GPU, one lane per keypoint."""
+        a = np.asarray(kpts)
+        single = a.ndim == 4
+        ctx = self.native_context()
+        n = self.camera_num
+        D = np.stack([np.asarray(c.D, dtype=np.float64).reshape(-1)[:5] for c in self.cameras[:n]])
+        ctx.set_distortion(D)
+        out = ctx.undistort_keypoints(a[None] if single else a)
+        return out[0] if single else out
+
     def camera_group_info_dict(self):
         return {"camera_num": self.camera_num,
                 "camera_group_info": [c.camera_info_dict() for c in self.cameras]}

@@ -20,6 +20,7 @@
 #include "snowtri_general.hpp"
 #include "snowtri_smooth.hpp"
 #include "snowtri_blender.hpp"
+#include "snowtri_undistort.hpp"
 #include "snowtri_kernels.hpp"
 
 using namespace snowtri;
@@ -94,7 +95,8 @@ struct snowtri_ctx {
     int device = 0;
     int32_t C = 0, npairs = 0;
     int num_cus = 256;
-    std::vector<double> hM, ht;
+    std::vector<double> hM, ht, hK;
+    double *dLens = nullptr;  // [C][kLensStride], set by snowtri_ctx_set_distortion
     std::vector<int32_t> hpairs;
     double *dM = nullptr, *dt = nullptr, *dpairc = nullptr, *dP = nullptr;
     int32_t *dpairs = nullptr;
@@ -149,6 +151,7 @@ int snowtri_ctx_create(int32_t C, const double *K, const double *R, const double
     if (const char *gm = getenv("SNOWTRI_GENERAL_MODE")) ctx->general_mode = atoi(gm);
     ctx->hM.resize((size_t)C * 9);
     ctx->ht.assign(t, t + (size_t)C * 3);
+    ctx->hK.assign(K, K + (size_t)C * 9);
     for (int c = 0; c < C; c++) {
         double Ki[9];
         if (inv3(K + 9 * c, Ki)) {  // np.linalg.inv(K) raises on a singular K (camera.py:242)
@@ -234,6 +237,7 @@ int snowtri_ctx_destroy(snowtri_ctx *ctx) {
     if (ctx->dpairs) (void)hipFree(ctx->dpairs);
     if (ctx->dpairc) (void)hipFree(ctx->dpairc);
     if (ctx->dP) (void)hipFree(ctx->dP);
+    if (ctx->dLens) (void)hipFree(ctx->dLens);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     ctx->in.release();
     ctx->out.release();
@@ -783,6 +787,63 @@ int snowtri_smooth_track(snowtri_ctx *ctx, int64_t T, int64_t n, const double *x
     if (rc) return rc;
     if (memspace == SNOWTRI_HOST) {
         HIP_TRY(hipMemcpyAsync(y, dy, bytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return SNOWTRI_OK;
+}
+
+// ---------------------------------------------------------------------------------------- N4
+int snowtri_ctx_set_distortion(snowtri_ctx *ctx, const double *D) {
+    if (!ctx || !D || ctx->C <= 0) return SNOWTRI_ERR_BAD_ARG;
+    std::vector<double> lens((size_t)ctx->C * kLensStride, 0.0);
+    for (int c = 0; c < ctx->C; c++) {
+        const double *K = &ctx->hK[9 * (size_t)c];
+        // the pinhole part must be [[fx, s, cx], [0, fy, cy], [0, 0, 1]]
+        if (K[3] != 0.0 || K[6] != 0.0 || K[7] != 0.0 || K[8] != 1.0 || K[0] == 0.0 || K[4] == 0.0) return SNOWTRI_ERR_BAD_ARG;
+        double *L = &lens[(size_t)c * kLensStride];
+        L[0] = K[0]; L[1] = K[1]; L[2] = K[2]; L[3] = K[4]; L[4] = K[5];
+        L[5] = 1.0 / K[0]; L[6] = 1.0 / K[4];
+        for (int i = 0; i < 5; i++) {
+            if (!std::isfinite(D[5 * c + i])) return SNOWTRI_ERR_BAD_ARG;
+            L[7 + i] = D[5 * c + i];
+        }
+    }
+    HIP_TRY(hipSetDevice(ctx->device));
+    if (!ctx->dLens) HIP_TRY(hipMalloc(&ctx->dLens, sizeof(double) * lens.size()));
+    HIP_TRY(hipMemcpy(ctx->dLens, lens.data(), sizeof(double) * lens.size(), hipMemcpyHostToDevice));
+    return SNOWTRI_OK;
+}
+
+int snowtri_undistort_keypoints(snowtri_ctx *ctx, int64_t F, int32_t Pmax, int32_t J, const void *kpts_in,
+                                void *kpts_out, int dtype, int memspace, void *stream) {
+    if (!ctx || F < 0 || Pmax <= 0 || J <= 0 || (dtype != SNOWTRI_F32 && dtype != SNOWTRI_F64) ||
+        (memspace != SNOWTRI_HOST && memspace != SNOWTRI_DEVICE) || ctx->C <= 0 || !ctx->dLens)
+        return SNOWTRI_ERR_BAD_ARG;
+    if (F == 0) return SNOWTRI_OK;
+    if (!kpts_in || !kpts_out) return SNOWTRI_ERR_BAD_ARG;
+    HIP_TRY(hipSetDevice(ctx->device));
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t per_cam = (int64_t)Pmax * J, n_obs = F * ctx->C * per_cam;
+    if (per_cam > INT32_MAX) return SNOWTRI_ERR_BAD_ARG;
+    const size_t bytes = (size_t)n_obs * 3 * (dtype == SNOWTRI_F32 ? 4 : 8);
+    const void *din = kpts_in;
+    void *dout = kpts_out;
+    if (memspace == SNOWTRI_HOST) {
+        int rc = ctx->in.ensure(bytes);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(ctx->in.p, kpts_in, bytes, hipMemcpyHostToDevice, st));
+        din = dout = ctx->in.p;
+    }
+    const dim3 grid((unsigned)((n_obs + 255) / 256));
+    if (dtype == SNOWTRI_F32)
+        hipLaunchKernelGGL(k_undistort<float>, grid, dim3(256), 0, st, n_obs, (int)ctx->C, (int)per_cam,
+                           (const double *)ctx->dLens, (const float *)din, (float *)dout);
+    else
+        hipLaunchKernelGGL(k_undistort<double>, grid, dim3(256), 0, st, n_obs, (int)ctx->C, (int)per_cam,
+                           (const double *)ctx->dLens, (const double *)din, (double *)dout);
+    HIP_TRY(hipGetLastError());
+    if (memspace == SNOWTRI_HOST) {
+        HIP_TRY(hipMemcpyAsync(kpts_out, dout, bytes, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
     }
     return SNOWTRI_OK;

@@ -32,6 +32,13 @@ def load_rig_json(path=FLOOR_RIG_PATH):
     return K, R, t
 
 
+def load_rig_distortion(path=FLOOR_RIG_PATH):
+    """Lens coefficients of a CameraGroup JSON -> D[C,5] = (k1, k2, p1, p2, k3) (camera_group_floor.json:53-61)."""
+    with open(path, "r") as fh:
+        info = json.load(fh)
+    return np.array([np.asarray(c["D"], dtype=np.float64).reshape(-1)[:5] for c in info["camera_group_info"]])
+
+
 def default_thresholds():
     with open(DEFAULT_THRESHOLDS_PATH, "r") as fh:
         return json.load(fh)

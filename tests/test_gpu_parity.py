@@ -477,6 +477,91 @@ def test_blender_smooth_track_against_reference_and_oracle(api):
     np.testing.assert_array_equal(np.isnan(one), np.isnan(pts[:1]))
 
 
+# ------------------------------------------------------------------ row N4: keypoint undistortion
+def test_undistort_keypoints_against_oracle(api):
+    """snowtri_undistort_keypoints vs the oracle's converged Newton inverse on the shipped rig's lenses:
+    <= 1e-9 px in float64, float32 rounding of the pixel otherwise; scores copied bit for bit; in place."""
+    import torch
+    from oracle import undistort as ou
+    from snowmocap_amd import _lib, synth
+    K, R, t = synth.load_rig_json()
+    D = synth.load_rig_distortion()
+    rng = np.random.default_rng(31)
+    F, C, P, J = 40, 4, 2, 133
+    uv = np.stack([rng.uniform(-50, 1330, (F, C, P, J)), rng.uniform(-50, 770, (F, C, P, J))], -1)
+    raw = np.stack([ou.distort_pixels(K[c], D[c], uv[:, c]) for c in range(C)], axis=1)
+    sc = rng.uniform(0, 9, (F, C, P, J, 1))
+    kp = np.concatenate([raw, sc], -1)
+    want = np.stack([ou.undistort_pixels(K[c], D[c], kp[:, c, ..., :2]) for c in range(C)], axis=1)
+    np.testing.assert_allclose(want, uv, rtol=0, atol=1e-9)
+    ctx = _lib.Context(K, R, t)
+    with pytest.raises(_lib.SnowtriError):
+        ctx.undistort_keypoints(kp)                                   # no lens set yet
+    ctx.set_distortion(D)
+    got = ctx.undistort_keypoints(kp)
+    np.testing.assert_allclose(got[..., :2], want, rtol=0, atol=1e-9)
+    np.testing.assert_array_equal(got[..., 2], kp[..., 2])
+    kp32 = kp.astype(np.float32)
+    got32 = ctx.undistort_keypoints(kp32)
+    assert got32.dtype == np.float32
+    want32 = np.stack([ou.undistort_pixels(K[c], D[c], kp32[:, c, ..., :2].astype(np.float64)) for c in range(C)], axis=1)
+    np.testing.assert_allclose(got32[..., :2], want32, rtol=0, atol=1.3e-4)     # half an ulp of 1300 px in float32
+    np.testing.assert_array_equal(got32[..., 2], kp32[..., 2])
+    # device pointers, output aliasing the input
+    d = torch.from_numpy(kp).to("cuda:0")
+    st = torch.cuda.current_stream().cuda_stream
+    _lib.check(_lib.lib().snowtri_undistort_keypoints(ctx.handle, F, P, J, d.data_ptr(), d.data_ptr(), _lib.F64,
+                                                      _lib.DEVICE, st), "undistort")
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(d.cpu().numpy(), got)
+    # zero coefficients: identity to rounding
+    ctx.set_distortion(np.zeros((4, 5)))
+    np.testing.assert_allclose(ctx.undistort_keypoints(kp)[..., :2], kp[..., :2], rtol=0, atol=1e-10)
+    ctx.close()
+    # a K that is not [[fx, s, cx], [0, fy, cy], [0, 0, 1]] is refused
+    K2 = K.copy(); K2[0, 1, 0] = 0.01
+    ctx2 = _lib.Context(K2, R, t)
+    with pytest.raises(_lib.SnowtriError):
+        ctx2.set_distortion(D)
+    ctx2.close()
+
+
+def test_raw_frame_detections_end_to_end(api):
+    """Detections made on RAW (distorted) frames -> undistort on the GPU -> triangulate: equals the path fed
+    with the undistorted detections, and recovers the true joints; through BatchTriangulator(D=...) on host
+    and device buffers, and through CameraGroup.undistort_keypoints."""
+    import torch
+    from oracle import undistort as ou
+    from snowmocap_amd import synth
+    from snowmocap_amd.batch import BatchTriangulator
+    K, R, t = synth.load_rig_json()
+    D = synth.load_rig_distortion()
+    rng = np.random.default_rng(32)
+    X = synth.make_people(rng, 30, 1)
+    kp, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=0.0, dtype=np.float64)
+    raw = kp.copy()
+    for c in range(4):
+        raw[:, c, ..., :2] = ou.distort_pixels(K[c], D[c], kp[:, c, ..., :2])
+    assert np.abs(raw - kp).max() > 5
+    prm = synth.default_thresholds()
+    plain = BatchTriangulator(K, R, t, prm, pout_max=1, out_dtype=np.float64)
+    lens = BatchTriangulator(K, R, t, prm, pout_max=1, out_dtype=np.float64, D=D)
+    ref = plain.run_host(kp, npers)
+    got = lens.run_host(raw, npers)
+    assert (got["count"] == 1).all()
+    np.testing.assert_allclose(got["xyzs"][..., :3], ref["xyzs"][..., :3], rtol=0, atol=1e-8)
+    np.testing.assert_allclose(got["xyzs"][:, 0, :, :3], X[:, 0], rtol=0, atol=1e-8)
+    wrong = plain.run_host(raw, npers)                              # ignoring the lens is visibly wrong
+    assert np.abs(wrong["xyzs"][:, 0, :, :3] - X[:, 0]).max() > 1e-2
+    out = lens.run_torch(torch.from_numpy(raw).to("cuda:0"), torch.from_numpy(npers).to("cuda:0"))
+    torch.cuda.synchronize()
+    np.testing.assert_array_equal(out["xyzs"].cpu().numpy(), got["xyzs"])
+    plain.close(); lens.close()
+    cg = api.CameraGroup(camera_group_info_path=synth.FLOOR_RIG_PATH)
+    one = cg.undistort_keypoints(raw[3])
+    np.testing.assert_allclose(one[..., :2], kp[3][..., :2], rtol=0, atol=1e-9)
+
+
 def test_main_loop_sequence_as_snowvision(api, tmp_path, monkeypatch):
     """main.py:47-106 minus video / pose / display, with this package standing in for `snowvision`
     (INTEGRATION.md 1): the JSON track it writes equals the reference's (fixture G7)."""

@@ -135,3 +135,25 @@ def test_blender_restatement_against_reference():
     bad[11] = bad[12] = 0.0
     with pytest.raises(np.linalg.LinAlgError):
         ob.control_points(bad)
+
+
+def test_undistort_restatement_properties():
+    """N4 (parity unpinned upstream: no OpenCV here, no reference vector): the inverse model is pinned to the
+    forward model by round trip on the shipped rig's four lenses, and to OpenCV's fixed-point scheme run to
+    convergence."""
+    from oracle import undistort as ou
+    from snowmocap_amd import synth
+    K, _, _ = synth.load_rig_json()
+    D = synth.load_rig_distortion()
+    assert D.shape == (4, 5) and np.abs(D[:, 0]).min() > 0.1
+    rng = np.random.default_rng(4)
+    for c in range(4):
+        uv = np.stack([rng.uniform(0, 1280, 5000), rng.uniform(0, 720, 5000)], -1)
+        raw = ou.distort_pixels(K[c], D[c], uv)
+        assert np.abs(raw - uv).max() > 20                       # tens of pixels at the corners
+        back = ou.undistort_pixels(K[c], D[c], raw)
+        np.testing.assert_allclose(back, uv, rtol=0, atol=1e-10)
+        np.testing.assert_allclose(ou.undistort_opencv5(K[c], D[c], raw, iters=60), back, rtol=0, atol=1e-10)
+        assert np.abs(ou.undistort_opencv5(K[c], D[c], raw) - back).max() < 0.5   # cv2's 5 sweeps: sub-pixel, not exact
+        np.testing.assert_array_equal(ou.undistort_pixels(K[c], np.zeros(5), raw), ou.distort_pixels(K[c], np.zeros(5), raw))
+        np.testing.assert_allclose(ou.undistort_pixels(K[c], np.zeros(5), raw), raw, rtol=0, atol=1e-12)
