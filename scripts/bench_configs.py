@@ -10,14 +10,16 @@ from snowmocap_amd.batch import BatchTriangulator
 from oracle import oracle as orc
 
 J = 133
-for cfg, F, pout in ((3, 2000, 16), (5, 256, 32)):
+SIZES = ((3, 2000, 16), (5, 256, 32)) if "--small" in sys.argv else ((3, 10000, 16), (5, 2000, 32))
+MODES = ("2", "1") if "--spill" in sys.argv else ("2",)
+for cfg, F, pout in SIZES:
     wl = synth.config_workload(cfg, F)
     K, R, t = wl["rig"]
     C, P = K.shape[0], wl["kpts"].shape[2]
     dev = torch.device("cuda", 0)
     kp = torch.from_numpy(wl["kpts"]).to(dev)
     npers = torch.from_numpy(wl["n_persons"]).to(dev)
-    for mode in ("2", "1"):
+    for mode in MODES:
         os.environ["SNOWTRI_GENERAL_MODE"] = mode
         bt = BatchTriangulator(K, R, t, wl["params"], pout_max=pout, out_dtype=np.float32)
         out = bt.run_torch(kp, npers)

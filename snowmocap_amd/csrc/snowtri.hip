@@ -1039,16 +1039,22 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax
     const int R = ctx->C * Pmax;
     const size_t per_block = recompute_scratch_bytes(Kc);
     const size_t lds = recompute_lds_bytes(R, J, prm.kn, (int)sizeof(TIn));
-    // 3 workgroups per CU fit the LDS budget (~50 KB each); frames are plentiful
-    int64_t grid = std::min<int64_t>(F, (int64_t)ctx->num_cus * 3);
-    grid = std::max<int64_t>(1, std::min<int64_t>(grid, (int64_t)(kMaxScratchBytes / per_block)));
-    int rc = ctx->work.ensure(per_block * (size_t)grid);
-    if (rc) return rc;
     auto kern = k_frame_recompute<TIn, TOut>;
     if (lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    // exactly the workgroups that are resident at once (registers and the ~50 KB of LDS decide: 3 per CU);
+    // they pull frames from an atomic counter until none are left
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, lds));
+    if (const char *e = getenv("SNOWTRI_RECOMPUTE_WG_PER_CU")) per_cu = atoi(e);
+    int64_t grid = std::min<int64_t>(F, (int64_t)ctx->num_cus * std::max(1, per_cu));
+    grid = std::max<int64_t>(1, std::min<int64_t>(grid, (int64_t)(kMaxScratchBytes / per_block)));
+    int rc = ctx->work.ensure(per_block * (size_t)grid);
+    if (rc) return rc;
+    unsigned long long *next_frame = ctx->d_counters + 2;
+    HIP_TRY(hipMemsetAsync(next_frame, 0, sizeof(unsigned long long), st));
     hipLaunchKernelGGL(kern, dim3((int)grid), dim3(kBlock), lds, st, F, Pmax, J, (int)Kc, ctx->rig(), d_kpts, d_np,
-                       prm, Pout, d_xyzs, d_ps, d_cnt, d_fl, (char *)ctx->work.p, per_block);
+                       prm, Pout, d_xyzs, d_ps, d_cnt, d_fl, (char *)ctx->work.p, per_block, next_frame);
     HIP_TRY(hipGetLastError());
     return SNOWTRI_OK;
 }

@@ -36,15 +36,24 @@ __host__ __device__ inline size_t recompute_lds_bytes(int R, int J, int kn, int 
 
 // Dynamic LDS = recompute_lds_bytes(R, J, kn, sizeof(TIn)); scratch = gridDim.x slabs of
 // recompute_scratch_bytes(Kc).  R = C * Pmax ray rows.  Requires keypoint_num <= kRecomputeMaxKn.
+#ifndef SNOWTRI_RECOMPUTE_WAVES
+#define SNOWTRI_RECOMPUTE_WAVES 3
+#endif
+#ifndef SNOWTRI_RECOMPUTE_UNROLL
+#define SNOWTRI_RECOMPUTE_UNROLL 4
+#endif
+// Frames are handed out through an atomic counter (next_frame, zeroed by the host before the launch): the
+// time of a frame depends on how many candidates survive, so a static frame->workgroup map leaves CUs idle.
 template <typename TIn, typename TOut>
-__global__ __launch_bounds__(kBlock) void k_frame_recompute(int64_t F, int Pmax, int J, int Kc, Rig rig,
+__global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recompute(int64_t F, int Pmax, int J, int Kc, Rig rig,
                                                             const TIn *__restrict__ kpts,
                                                             const int32_t *__restrict__ n_persons, Params prm,
                                                             int Pout, TOut *__restrict__ out4,
                                                             TOut *__restrict__ out_ps,
                                                             int32_t *__restrict__ out_count,
                                                             uint32_t *__restrict__ out_flags, char *scratch,
-                                                            size_t scratch_per_block) {
+                                                            size_t scratch_per_block,
+                                                            unsigned long long *next_frame) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int C = rig.C, R = C * Pmax, pp = Pmax * Pmax;
@@ -72,7 +81,15 @@ __global__ __launch_bounds__(kBlock) void k_frame_recompute(int64_t F, int Pmax,
     const PackedWriter<TOut> wr{out4, out_ps};
     const Kp3<TIn> *kp3 = reinterpret_cast<const Kp3<TIn> *>(kpts);
 
-    for (int64_t f = blockIdx.x; f < F; f += gridDim.x) {
+    for (;;) {
+        if (tid == 0) {
+            const unsigned long long nf = atomicAdd(next_frame, 1ull);
+            misc[2] = (int32_t)(nf & 0xffffffffu);
+            misc[3] = (int32_t)(nf >> 32);
+        }
+        __syncthreads();
+        const int64_t f = (int64_t)(((unsigned long long)(uint32_t)misc[3] << 32) | (uint32_t)misc[2]);
+        if (f >= F) break;
         const int32_t *np_f = n_persons ? n_persons + f * C : nullptr;
         const Kp3<TIn> *kpf = kp3 + f * (int64_t)R * J;
         for (int k = tid; k < Kc; k += kBlock) sum[k] = 0.0;
@@ -103,7 +120,7 @@ __global__ __launch_bounds__(kBlock) void k_frame_recompute(int64_t F, int Pmax,
                 const double *pc = rig.pairc + 6 * q;
                 const Vec3 d = {pc[0], pc[1], pc[2]}, tsum = {0.0, 0.0, 0.0};
                 double acc = 0.0;
-#pragma unroll 2
+#pragma unroll SNOWTRI_RECOMPUTE_UNROLL
                 for (int jj = 0; jj < nj; jj++) {
                     const RayRec a = rays[jj * R + rm], b = rays[jj * R + rs];
                     const TIn sm = rsc[jj * R + rm], ss = rsc[jj * R + rs];
