@@ -253,7 +253,7 @@ def main():
 
     traffic = None
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc_path):
+    if os.path.exists(pmc_path) and args.method != "dlt":     # the PMC pass was made on the pairwise kernel
         try:
             traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
         except Exception:

@@ -66,7 +66,9 @@ typedef enum snowtri_dtype { SNOWTRI_F32 = 0, SNOWTRI_F64 = 1 } snowtri_dtype;
 typedef enum snowtri_memspace { SNOWTRI_HOST = 0, SNOWTRI_DEVICE = 1 } snowtri_memspace;
 typedef enum snowtri_method {
     SNOWTRI_PAIRWISE = 0, /* the reference's algorithm: pairwise skew-ray midpoints, score-weighted */
-    SNOWTRI_DLT = 1       /* N-view DLT (A^T A smallest eigenvector), association still pairwise     */
+    SNOWTRI_DLT = 1       /* N-view DLT (A^T A smallest eigenvector; NOT reference behaviour).  One detection
+                           * per camera: no association.  Several: the reference's association (candidates +
+                           * greedy clustering), then one DLT per cluster over its distinct observations. */
 } snowtri_method;
 
 /* per-frame flag bits written to out_flags */

@@ -1031,15 +1031,15 @@ int launch_frame_general(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax, 
 }
 
 // Multi-person path without HBM candidate spill (snowtri_general.hpp).
-template <typename TIn, typename TOut>
+template <int METHOD, typename TIn, typename TOut>
 int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax, int J, const TIn *d_kpts,
                            const int32_t *d_np, const Params &prm, int Pout, TOut *d_xyzs, TOut *d_ps,
                            int32_t *d_cnt, uint32_t *d_fl) {
     const int64_t Kc = snowtri_num_candidate_slots(ctx->C, Pmax);
     const int R = ctx->C * Pmax;
-    const size_t per_block = recompute_scratch_bytes(Kc);
+    const size_t per_block = recompute_scratch_bytes(Kc, R);
     const size_t lds = recompute_lds_bytes(R, J, prm.kn, (int)sizeof(TIn));
-    auto kern = k_frame_recompute<TIn, TOut>;
+    auto kern = k_frame_recompute<METHOD, TIn, TOut>;
     if (lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     // exactly the workgroups that are resident at once (registers and the ~50 KB of LDS decide: 3 per CU);
@@ -1076,8 +1076,12 @@ int fused_dispatch(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax, int J,
         HIP_TRY(hipEventRecord(ctx->ev_ring[2 * ring_slot], st));
     }
     int rc;
-    if (method == SNOWTRI_DLT) {
-        switch (C) {  // single detection per camera only (host-checked): no association needed
+    if (method == SNOWTRI_DLT && (Pmax > 1 || C > 8)) {
+        // several detections per camera: the reference's association (phases 1-2), then DLT per cluster
+        if (prm.kn > kRecomputeMaxKn || recompute_chunk_joints(C * Pmax, J, (int)sizeof(TIn)) < 1) return SNOWTRI_ERR_BAD_ARG;
+        rc = launch_frame_recompute<1, TIn, TOut>(ctx, st, F, Pmax, J, d_kpts, d_np, prm, Pout, d_xyzs, d_ps, d_cnt, d_fl);
+    } else if (method == SNOWTRI_DLT) {
+        switch (C) {  // one detection per camera: no association needed
 #define SNOWTRI_CASE(CC)                                                                                      \
     case CC:                                                                                                  \
         rc = launch_fused_single<CC, 1, TIn, TOut>(ctx, st, F, J, d_kpts, d_np, prm, Pout, d_xyzs, d_ps, d_cnt, d_fl); \
@@ -1109,7 +1113,7 @@ int fused_dispatch(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax, int J,
         }
     } else if (prm.kn <= kRecomputeMaxKn && recompute_chunk_joints(C * Pmax, J, (int)sizeof(TIn)) >= 1 &&
                ctx->general_mode != 1) {
-        rc = launch_frame_recompute<TIn, TOut>(ctx, st, F, Pmax, J, d_kpts, d_np, prm, Pout, d_xyzs, d_ps, d_cnt, d_fl);
+        rc = launch_frame_recompute<0, TIn, TOut>(ctx, st, F, Pmax, J, d_kpts, d_np, prm, Pout, d_xyzs, d_ps, d_cnt, d_fl);
     } else {
         rc = launch_frame_general<TIn, TOut>(ctx, st, F, Pmax, J, d_kpts, d_np, prm, Pout, d_xyzs, d_ps, d_cnt, d_fl);
     }
@@ -1139,8 +1143,7 @@ extern "C" int snowtri_triangulate_condense(snowtri_ctx *ctx, int64_t F, int32_t
         return SNOWTRI_ERR_BAD_ARG;
     if (memspace != SNOWTRI_HOST && memspace != SNOWTRI_DEVICE) return SNOWTRI_ERR_BAD_ARG;
     if (method != SNOWTRI_PAIRWISE && method != SNOWTRI_DLT) return SNOWTRI_ERR_BAD_ARG;
-    // DLT: built for one detection per camera (no association step); multi-person DLT is not built.
-    if (method == SNOWTRI_DLT && (Pmax != 1 || ctx->C < 2 || ctx->C > 8)) return SNOWTRI_ERR_BAD_ARG;
+    if (method == SNOWTRI_DLT && ctx->C < 2) return SNOWTRI_ERR_BAD_ARG;
     if (F == 0) return SNOWTRI_OK;
     if (!kpts || !out_xyzs || !out_count) return SNOWTRI_ERR_BAD_ARG;
     Params prm;

@@ -13,15 +13,15 @@
 //                                                                          (triangulation.py:136-152)
 // Only O(Kc) bookkeeping (57 B per candidate slot) lives in a per-workgroup scratch slab.
 #pragma once
-#include "snowtri_kernels.hpp"
+#include "snowtri_fused.hpp"
 
 namespace snowtri {
 
 constexpr int kRecomputeMaxKn = 256;          // joints handled per lane in phase 3: lane + 64 p, p < 4
 constexpr int kRayChunkBytes = 32 * 1024;     // LDS budget for one chunk of rays
 
-__host__ __device__ constexpr size_t recompute_scratch_bytes(int64_t Kc) {
-    return (((size_t)Kc * 64) + 1024 + 255) & ~(size_t)255;
+__host__ __device__ constexpr size_t recompute_scratch_bytes(int64_t Kc, int R) {
+    return (((size_t)Kc * 64) + (size_t)R * 8 + 1024 + 255) & ~(size_t)255;
 }
 
 __host__ __device__ inline int recompute_chunk_joints(int R, int J, int score_bytes) {
@@ -44,7 +44,13 @@ __host__ __device__ inline size_t recompute_lds_bytes(int R, int J, int kn, int 
 #endif
 // Frames are handed out through an atomic counter (next_frame, zeroed by the host before the launch): the
 // time of a frame depends on how many candidates survive, so a static frame->workgroup map leaves CUs idle.
-template <typename TIn, typename TOut>
+//
+// METHOD = 1 (SNOWTRI_DLT with several detections per camera -- row N3; not reference behaviour): phases 1-2
+// are the reference's association unchanged; phase 3 instead solves, per surviving cluster and joint, the
+// N-view DLT over the DISTINCT (camera, person) observations its member candidates are made of, keeping those
+// whose confidence is not below keypoint_score_threshold (>= 2 needed, else the joint stays (0,0,0)/0);
+// joint score = their mean confidence.  One lane per (cluster, joint); no cross-lane reduction.
+template <int METHOD, typename TIn, typename TOut>
 __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recompute(int64_t F, int Pmax, int J, int Kc, Rig rig,
                                                             const TIn *__restrict__ kpts,
                                                             const int32_t *__restrict__ n_persons, Params prm,
@@ -77,6 +83,8 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
     int32_t *members = cseed + Kc;                                  // [Kc] kept indices grouped by cluster
     int32_t *cstart = members + Kc;                                 // [Kc + 1]
     uint8_t *keep = reinterpret_cast<uint8_t *>(cstart + Kc + 1);   // [Kc]
+    int32_t *rowlist = reinterpret_cast<int32_t *>(slab + (((size_t)Kc * 64 + 1024) & ~(size_t)7));  // [R] (DLT)
+    int32_t *rowflag = rowlist + R;                                                                   // [R] (DLT)
 
     const PackedWriter<TOut> wr{out4, out_ps};
     const Kp3<TIn> *kp3 = reinterpret_cast<const Kp3<TIn> *>(kpts);
@@ -227,59 +235,111 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
             const int size = csize[cid];
             if ((double)size < prm.num_tol) continue;                                             // :132-134
             const int m0 = cstart[cid];
-            double aS[4] = {0, 0, 0, 0}, aX[4] = {0, 0, 0, 0}, aY[4] = {0, 0, 0, 0}, aZ[4] = {0, 0, 0, 0};
-            for (int mi = wave; mi < size; mi += kBlock / 64) {
-                const int k = kidx[members[m0 + mi]];
-                const int q = k / pp, rr = k - q * pp, pm = rr / Pmax, ps = rr - pm * Pmax;
-                const int mc = rig.pairs[2 * q], sc = rig.pairs[2 * q + 1];
-                const Kp3<TIn> *rowm = kpf + (size_t)(mc * Pmax + pm) * J, *rows = kpf + (size_t)(sc * Pmax + ps) * J;
-                const double *pc = rig.pairc + 6 * q;
-                const Vec3 d = {pc[0], pc[1], pc[2]}, tsum = {pc[3], pc[4], pc[5]};
-                const double *Mm = rig.M + 9 * mc, *Ms = rig.M + 9 * sc;
+            double ox = 0.0, oy = 0.0, oz = 0.0, os = 0.0;
+            if constexpr (METHOD == 1) {
+                // distinct observation rows of this cluster, in row order
+                for (int r = tid; r < R; r += kBlock) rowflag[r] = 0;
+                __syncthreads();
+                for (int mi = tid; mi < size; mi += kBlock) {
+                    const int k = kidx[members[m0 + mi]];
+                    const int q = k / pp, rr = k - q * pp, pm = rr / Pmax, ps = rr - pm * Pmax;
+                    rowflag[rig.pairs[2 * q] * Pmax + pm] = 1;
+                    rowflag[rig.pairs[2 * q + 1] * Pmax + ps] = 1;
+                }
+                __syncthreads();
+                if (tid < 64) {
+                    int nr = 0;
+                    for (int base = 0; base < R; base += 64) {
+                        const int r = base + lane;
+                        const bool in = r < R && rowflag[r] != 0;
+                        const unsigned long long m = __ballot(in);
+                        if (in) rowlist[nr + __popcll(m & ((1ull << lane) - 1ull))] = r;
+                        nr += __popcll(m);
+                    }
+                    if (lane == 0) misc[4] = nr;
+                }
+                __syncthreads();
+                const int nrows = misc[4];
+                if (tid < kn) {
+                    double A[4][4];
+#pragma unroll
+                    for (int i = 0; i < 4; i++)
+#pragma unroll
+                        for (int k2 = 0; k2 < 4; k2++) A[i][k2] = 0.0;
+                    double ssum = 0.0;
+                    int cnt = 0;
+                    for (int i = 0; i < nrows; i++) {
+                        const int r = rowlist[i];
+                        const Kp3<TIn> kp = kpf[(size_t)r * J + tid];
+                        const bool use = !below_kthr(kp.s, prm);
+                        dlt_add_observation(A, rig.P + 12 * (r / Pmax), (double)kp.u, (double)kp.v, use ? 1.0 : 0.0);
+                        ssum += use ? (double)kp.s : 0.0;
+                        cnt += use ? 1 : 0;
+                    }
+                    double e[4];
+                    dlt_solve(A, cnt >= 2, e);
+                    if (cnt >= 2) {
+                        const double r = 1.0 / e[3];
+                        ox = e[0] * r;
+                        oy = e[1] * r;
+                        oz = e[2] * r;
+                        os = ssum / (double)cnt;
+                    }
+                }
+            } else {
+                double aS[4] = {0, 0, 0, 0}, aX[4] = {0, 0, 0, 0}, aY[4] = {0, 0, 0, 0}, aZ[4] = {0, 0, 0, 0};
+                for (int mi = wave; mi < size; mi += kBlock / 64) {
+                    const int k = kidx[members[m0 + mi]];
+                    const int q = k / pp, rr = k - q * pp, pm = rr / Pmax, ps = rr - pm * Pmax;
+                    const int mc = rig.pairs[2 * q], sc = rig.pairs[2 * q + 1];
+                    const Kp3<TIn> *rowm = kpf + (size_t)(mc * Pmax + pm) * J, *rows = kpf + (size_t)(sc * Pmax + ps) * J;
+                    const double *pc = rig.pairc + 6 * q;
+                    const Vec3 d = {pc[0], pc[1], pc[2]}, tsum = {pc[3], pc[4], pc[5]};
+                    const double *Mm = rig.M + 9 * mc, *Ms = rig.M + 9 * sc;
+#pragma unroll
+                    for (int p = 0; p < 4; p++) {
+                        const int b = lane + 64 * p;
+                        if (b < kn) {
+                            const Kp3<TIn> km = rowm[b], ks = rows[b];
+                            const PairSolve o = pair_solve_fast<true>(make_ray(Mm, km.u, km.v), make_ray(Ms, ks.u, ks.v), d, tsum);
+                            const bool kp_ = !below_kthr(km.s, prm) && !below_kthr(ks.s, prm) && !(o.d2 > prm.dthr2);
+                            const double s = gated_sum(km.s, ks.s, kp_) * (0.5 * o.score_base);
+                            aS[p] += s;                                                                // :141
+                            aX[p] = fma(s, o.sw.x, aX[p]);                                             // :144-147
+                            aY[p] = fma(s, o.sw.y, aY[p]);
+                            aZ[p] = fma(s, o.sw.z, aZ[p]);
+                        }
+                    }
+                }
 #pragma unroll
                 for (int p = 0; p < 4; p++) {
                     const int b = lane + 64 * p;
                     if (b < kn) {
-                        const Kp3<TIn> km = rowm[b], ks = rows[b];
-                        const PairSolve o = pair_solve_fast<true>(make_ray(Mm, km.u, km.v), make_ray(Ms, ks.u, ks.v), d, tsum);
-                        const bool kp_ = !below_kthr(km.s, prm) && !below_kthr(ks.s, prm) && !(o.d2 > prm.dthr2);
-                        const double s = gated_sum(km.s, ks.s, kp_) * (0.5 * o.score_base);
-                        aS[p] += s;                                                                // :141
-                        aX[p] = fma(s, o.sw.x, aX[p]);                                             // :144-147
-                        aY[p] = fma(s, o.sw.y, aY[p]);
-                        aZ[p] = fma(s, o.sw.z, aZ[p]);
+                        double *dst = partial + ((size_t)wave * kn + b) * 4;
+                        dst[0] = aS[p];
+                        dst[1] = aX[p];
+                        dst[2] = aY[p];
+                        dst[3] = aZ[p];
                     }
                 }
-            }
+                __syncthreads();
+                if (tid < kn) {
+                    double S = 0.0, X = 0.0, Y = 0.0, Z = 0.0;
 #pragma unroll
-            for (int p = 0; p < 4; p++) {
-                const int b = lane + 64 * p;
-                if (b < kn) {
-                    double *dst = partial + ((size_t)wave * kn + b) * 4;
-                    dst[0] = aS[p];
-                    dst[1] = aX[p];
-                    dst[2] = aY[p];
-                    dst[3] = aZ[p];
-                }
-            }
-            __syncthreads();
-            double ox = 0.0, oy = 0.0, oz = 0.0, os = 0.0;
-            if (tid < kn) {
-                double S = 0.0, X = 0.0, Y = 0.0, Z = 0.0;
-#pragma unroll
-                for (int w = 0; w < kBlock / 64; w++) {
-                    const double *src = partial + ((size_t)w * kn + tid) * 4;
-                    S += src[0];
-                    X += src[1];
-                    Y += src[2];
-                    Z += src[3];
-                }
-                if (!(S == 0.0)) {                                                                 // :142-143
-                    const double r = 0.5 / S;
-                    ox = X * r;
-                    oy = Y * r;
-                    oz = Z * r;
-                    os = S / (double)size;                                                         // :148
+                    for (int w = 0; w < kBlock / 64; w++) {
+                        const double *src = partial + ((size_t)w * kn + tid) * 4;
+                        S += src[0];
+                        X += src[1];
+                        Y += src[2];
+                        Z += src[3];
+                    }
+                    if (!(S == 0.0)) {                                                                 // :142-143
+                        const double r = 0.5 / S;
+                        ox = X * r;
+                        oy = Y * r;
+                        oz = Z * r;
+                        os = S / (double)size;                                                         // :148
+                    }
                 }
             }
             const double avg = block_sum(tid < kn ? os : 0.0, red) / (double)kn;                   // :150

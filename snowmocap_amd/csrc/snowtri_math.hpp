@@ -107,6 +107,18 @@ __device__ __forceinline__ double rcp_nr1(double x) {
     double r = __builtin_amdgcn_rcp(x);
     return fma(fma(-x, r, 1.0), r, r);
 }
+// two steps -> ~1 ulp; sqrt(x) = x * rsq(x) with one more correction (x > 0, normal range)
+__device__ __forceinline__ double rsq_nr2(double x) {
+    double y = __builtin_amdgcn_rsq(x);
+    y = fma(y * 0.5, fma(-(x * y), y, 1.0), y);
+    y = fma(y * 0.5, fma(-(x * y), y, 1.0), y);
+    return y;
+}
+__device__ __forceinline__ double sqrt_nr(double x) {
+    const double y = rsq_nr2(x);
+    const double g = x * y;                      // ~sqrt(x)
+    return fma(fma(-g, g, x), y * 0.5, g);       // g + (x - g^2) / (2 sqrt(x))
+}
 __device__ __forceinline__ double rsq_nr1(double x) {
     double y = __builtin_amdgcn_rsq(x);
     const double e = fma(-(x * y), y, 1.0);  // 1 - x y^2

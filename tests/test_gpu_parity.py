@@ -284,6 +284,8 @@ def test_dlt_method_against_svd_oracle_and_reference_class(api):
     kp[:, :, :, :, 2] = np.random.default_rng(3).uniform(2.0, 8.0, size=kp.shape[:-1]).astype(np.float32)
     kp[5, :, 0, 7, 2] = 1.0            # a joint nobody sees -> (0,0,0), score 0
     kp[6, 1:, 0, 9, 2] = 1.0           # a joint seen by one camera only -> (0,0,0), score 0
+    kp[7, 2, 0, 20:30, 0] += 150.0     # gross outliers: inverse iteration does not settle -> Jacobi fallback
+    kp[8, :, 0, 40:44, :2] += np.random.default_rng(4).normal(0, 25, size=(4, 4, 2)).astype(np.float32)
     K, R, t = wl["rig"]
     prm = dict(wl["params"])
     want, wps, wcnt = dlt.dlt_batch(K, R, t, kp, prm["keypoint_score_threshold"], prm["keypoint_num"])
@@ -302,12 +304,53 @@ def test_dlt_method_against_svd_oracle_and_reference_class(api):
     out = bt.run_host(sc["kpts"], sc["n_persons"])
     bt.close()
     assert np.abs(out["xyzs"][:, :1, :, :3] - sc["cond_xyz"]).max() < 1e-6      # reference, near-exact class
-    # multi-person DLT is not built: rejected, never silently substituted
-    wl3 = synth.config_workload(3, 1)
-    bt = api.BatchTriangulator(*wl3["rig"], wl3["params"], pout_max=8, method=_lib.DLT)
-    with pytest.raises(_lib.SnowtriError):
-        bt.run_host(wl3["kpts"], wl3["n_persons"])
+
+
+def test_dlt_multi_person_against_oracle(api):
+    """method = DLT with several detections per camera: the reference's association (candidates + greedy
+    clustering), then an N-view DLT per cluster over its distinct observations -- vs oracle/dlt.py, on the
+    8-camera x 4-person ring (permuted person order, ragged person counts, low-confidence joints) and on a
+    16-camera single-person rig (more cameras than the single-detection kernel is built for)."""
+    from snowmocap_amd import synth, _lib
+    from oracle import dlt, oracle as orc
+    wl = synth.config_workload(3, 6, seed=41, dtype=np.float64)
+    kp, npers = wl["kpts"], wl["n_persons"].copy()
+    rng = np.random.default_rng(5)
+    kp[..., 2] = rng.uniform(2.5, 8.0, size=kp.shape[:-1])
+    kp[2, :, :, 11, 2] = 1.0                # a joint nobody sees
+    npers[3, 0] = 2                         # ragged: camera 0 lists only two persons in frame 3
+    npers[4, 5] = 0                         # camera 5 sees nobody in frame 4
+    K, R, t = wl["rig"]
+    prm = dict(wl["params"])
+    want, wps, wcnt = dlt.dlt_multi_batch(K, R, t, kp, npers, orc.make_params(**prm), 12)
+    assert (wcnt >= 4).all() and wcnt.max() <= 12
+    bt = api.BatchTriangulator(K, R, t, prm, pout_max=12, out_dtype=np.float64, method=_lib.DLT)
+    out = bt.run_host(kp, npers)
     bt.close()
+    np.testing.assert_array_equal(out["count"], wcnt)
+    assert np.abs(out["xyzs"][..., :3] - want[..., :3]).max() < 1e-9
+    np.testing.assert_allclose(out["xyzs"][..., 3], want[..., 3], rtol=1e-12)
+    np.testing.assert_allclose(out["pscore"], wps, rtol=1e-12)
+    # persons are where the truth is (noise 1 px -> millimetres), for the four real clusters
+    X = wl["X"]
+    for f in range(kp.shape[0]):
+        for p in range(4):
+            d = np.linalg.norm(out["xyzs"][f, :wcnt[f], :, :3] - X[f, p][None], axis=-1)
+            vis = out["xyzs"][f, :wcnt[f], :, 3] > 0
+            assert np.where(vis, d, 0).max(axis=1).min() < 0.05
+    # 16 cameras x 1 person goes through the same kernel
+    K16, R16, t16 = synth.ring_rig(16)
+    X1 = synth.make_people(rng, 5, 1)
+    kp1, np1 = synth.make_keypoints(rng, K16, R16, t16, X1, pixel_sigma=0.5, dtype=np.float64)
+    prm1 = dict(synth.default_thresholds())
+    prm1.update(condense_distance_tol=0.3)
+    want1, _, wc1 = dlt.dlt_multi_batch(K16, R16, t16, kp1, np1, orc.make_params(**prm1), 4)
+    bt = api.BatchTriangulator(K16, R16, t16, prm1, pout_max=4, out_dtype=np.float64, method=_lib.DLT)
+    out1 = bt.run_host(kp1, np1)
+    bt.close()
+    np.testing.assert_array_equal(out1["count"], wc1)
+    assert np.abs(out1["xyzs"][..., :3] - want1[..., :3]).max() < 1e-9
+    assert np.abs(out1["xyzs"][:, 0, :, :3] - X1[:, 0]).max() < 0.01
 
 
 @pytest.mark.parametrize("mode", ["1", "2"])
