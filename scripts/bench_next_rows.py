@@ -81,3 +81,16 @@ nobs = F * 4 * 133
 print(json.dumps({"row": "N4 undistort_keypoints", "frames": F, "observations": nobs, "ms": ms,
                   "observations_per_s": nobs / (ms * 1e-3), "algorithmic_GBs": 24 * nobs / (ms * 1e-3) / 1e9,
                   "oracle_numpy_1thread_observations_per_s": small.shape[0] * small.shape[1] / cpu}))
+
+# the whole-recording pipeline: 100 000 frames, 4 cameras, 1 person, float32 detections resident in HBM
+from snowmocap_amd import TrackPipeline
+th = synth.default_thresholds()
+smo = {n: [2.5, 0.75, 0.0] for n in __import__("snowmocap_amd.blender", fromlist=["x"]).CONTROL_POINT_NAMES}
+wl = synth.config_workload(2, 10000)
+kp = torch.from_numpy(wl["kpts"]).to(dev).repeat(10, 1, 1, 1, 1).contiguous()
+for D, tag in ((None, "undistorted detections"), (synth.load_rig_distortion() * 0.0 + synth.load_rig_distortion(), "raw-frame detections + lens")):
+    pipe = TrackPipeline(K, R, t, th, smo, n_persons_out=1, D=D)
+    ms = timed(lambda: pipe.run(kp, check=False), reps=5)
+    print(json.dumps({"row": "pipeline A1-A4 + N1 + N2" + (" + N4" if D is not None else ""), "input": tag, "frames": kp.shape[0],
+                      "ms": ms, "frames_per_s": kp.shape[0] / (ms * 1e-3), "joints_per_s": kp.shape[0] * 133 / (ms * 1e-3)}))
+    pipe.close()

@@ -652,6 +652,47 @@ def test_main_loop_sequence_as_snowvision(api, tmp_path, monkeypatch):
             np.testing.assert_allclose(g["armature"][0][name], vec, rtol=0, atol=1e-8, err_msg=name)
 
 
+def test_track_pipeline_reproduces_reference_json(api):
+    """The whole-recording pipeline (triangulate -> smooth -> Blender points -> Blender smooth, one GPU call per
+    stage for ALL frames) writes the same track as the reference's frame-by-frame loop (fixture G7); and fed with
+    raw-frame (distorted) detections plus the lens coefficients it still does."""
+    import json
+    from oracle import undistort as ou
+    from snowmocap_amd import synth
+    z = np.load(f"{GOLDEN}/g7_pipeline.npz")
+    th, arm, smo = json.loads(str(z["thresholds"])), json.loads(str(z["armature"])), json.loads(str(z["smooth"]))
+    want = json.loads(str(z["result"]))
+    K, R, t, kpts = z["K"], z["R"], z["t"], z["kpts"]
+
+    def compare(got, tol):
+        assert len(got) == len(want)
+        for g, w in zip(got, want):
+            assert g["score"] == w["score"] and list(g["armature"][0]) == list(w["armature"][0])
+            for name, vec in w["armature"][0].items():
+                np.testing.assert_allclose(g["armature"][0][name], vec, rtol=0, atol=tol, err_msg=name)
+
+    pipe = api.TrackPipeline(K, R, t, th, smo, n_persons_out=1)
+    out = pipe.run(kpts)
+    compare(pipe.to_blender_result(out["points_smoothed"], out["valid"], arm), 1e-8)
+    assert out["smoothed"].shape == (kpts.shape[0], 1, 133, 4)
+    assert bool((out["smoothed"][..., 3] == out["xyzs"][..., 3]).all())       # scores are not filtered
+    pipe.close()
+    # raw-frame detections: distort the fixture's pixels with the shipped lenses, hand the lenses to the pipeline
+    D = synth.load_rig_distortion()
+    raw = kpts.astype(np.float64)
+    for c in range(4):
+        raw[:, c, ..., :2] = ou.distort_pixels(K[c], D[c], kpts[:, c, ..., :2].astype(np.float64))
+    pipe = api.TrackPipeline(K, R, t, th, smo, n_persons_out=1, D=D)
+    out = pipe.run(raw)
+    compare(pipe.to_blender_result(out["points_smoothed"], out["valid"], arm), 2e-6)   # kpts were float32 in G7
+    pipe.close()
+    # a frame that resolves to a different person count is refused, not silently padded
+    pipe = api.TrackPipeline(K, R, t, th, smo, n_persons_out=2)
+    with pytest.raises(ValueError):
+        pipe.run(kpts)
+    pipe.close()
+
+
 @pytest.mark.parametrize("C", [3, 5, 6, 8])
 def test_fast_path_other_camera_counts(api, C):
     """k_fused_single is instantiated for 3..8 cameras: ring rigs with one person vs the oracle."""
