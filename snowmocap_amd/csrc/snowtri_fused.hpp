@@ -216,11 +216,11 @@ __device__ __forceinline__ bool pairwise_item(const Rig &rig, const double *__re
     double a[C], alpha[C], beta[C];
 #pragma unroll
     for (int c = 0; c < C; c++) {
-        // A1, camera.py:241-243 with M = R inv(K); (mul, fma, add) keeps the constant column a scalar operand
+        // A1, camera.py:241-243 with M = R inv(K)
         const double u = (double)cur[c].u, v = (double)cur[c].v;
-        h[c].x = fma(Mp[9 * c + 1], v, Mp[9 * c + 0] * u) + Mp[9 * c + 2];
-        h[c].y = fma(Mp[9 * c + 4], v, Mp[9 * c + 3] * u) + Mp[9 * c + 5];
-        h[c].z = fma(Mp[9 * c + 7], v, Mp[9 * c + 6] * u) + Mp[9 * c + 8];
+        h[c].x = fma(Mp[9 * c + 0], u, fma(Mp[9 * c + 1], v, Mp[9 * c + 2]));
+        h[c].y = fma(Mp[9 * c + 3], u, fma(Mp[9 * c + 4], v, Mp[9 * c + 5]));
+        h[c].z = fma(Mp[9 * c + 6], u, fma(Mp[9 * c + 7], v, Mp[9 * c + 8]));
         a[c] = dot3(h[c], h[c]);
     }
     bool bad = false;

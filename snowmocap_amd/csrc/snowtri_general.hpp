@@ -42,6 +42,7 @@ __host__ __device__ inline size_t recompute_lds_bytes(int R, int J, int kn, int 
 #ifndef SNOWTRI_RECOMPUTE_UNROLL
 #define SNOWTRI_RECOMPUTE_UNROLL 4
 #endif
+constexpr int kRecomputeUnroll = SNOWTRI_RECOMPUTE_UNROLL;
 // Frames are handed out through an atomic counter (next_frame, zeroed by the host before the launch): the
 // time of a frame depends on how many candidates survive, so a static frame->workgroup map leaves CUs idle.
 //
@@ -128,7 +129,7 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
                 const double *pc = rig.pairc + 6 * q;
                 const Vec3 d = {pc[0], pc[1], pc[2]}, tsum = {0.0, 0.0, 0.0};
                 double acc = 0.0;
-#pragma unroll SNOWTRI_RECOMPUTE_UNROLL
+#pragma unroll(kRecomputeUnroll)
                 for (int jj = 0; jj < nj; jj++) {
                     const RayRec a = rays[jj * R + rm], b = rays[jj * R + rs];
                     const TIn sm = rsc[jj * R + rm], ss = rsc[jj * R + rs];
