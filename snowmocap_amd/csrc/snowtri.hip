@@ -1037,7 +1037,7 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax
                            int32_t *d_cnt, uint32_t *d_fl) {
     const int64_t Kc = snowtri_num_candidate_slots(ctx->C, Pmax);
     const int R = ctx->C * Pmax;
-    const size_t per_block = recompute_scratch_bytes(Kc, R);
+    const size_t per_block = recompute_scratch_bytes(Kc, R, prm.kn);
     const size_t lds = recompute_lds_bytes(R, J, prm.kn, (int)sizeof(TIn));
     auto kern = k_frame_recompute<METHOD, TIn, TOut>;
     if (lds > 48 * 1024)

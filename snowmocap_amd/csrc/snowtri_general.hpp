@@ -9,8 +9,8 @@
 //            rays of a joint chunk are built once into LDS; one lane per candidate walks the chunk
 //   phase 2  kept list (ordered), centre joints, greedy clustering (one wave) (triangulation.py:107-130)
 //   phase 3  per surviving cluster and joint: sum s, sum s*(Wm+Ws) over the members, recomputing
-//            their solves; lanes = joints (coalesced pixel reads), members split over the 4 waves
-//                                                                          (triangulation.py:136-152)
+//            their solves in a second sweep over the joint chunks (rays back in LDS); thread = (member
+//            group, joint of the chunk), group partials added through LDS               (triangulation.py:136-152)
 // Only O(Kc) bookkeeping (57 B per candidate slot) lives in a per-workgroup scratch slab.
 #pragma once
 #include "snowtri_fused.hpp"
@@ -20,22 +20,32 @@ namespace snowtri {
 constexpr int kRecomputeMaxKn = 256;          // joints handled per lane in phase 3: lane + 64 p, p < 4
 constexpr int kRayChunkBytes = 32 * 1024;     // LDS budget for one chunk of rays
 
-__host__ __device__ constexpr size_t recompute_scratch_bytes(int64_t Kc, int R) {
-    return (((size_t)Kc * 64) + (size_t)R * 8 + 1024 + 255) & ~(size_t)255;
+constexpr int kRecomputeSlotTile = 64;        // fused persons whose joint scores are parked per sweep (phase 3)
+
+__host__ __device__ constexpr size_t recompute_scratch_bytes(int64_t Kc, int R, int kn) {
+    return (((size_t)Kc * 64) + (size_t)R * 8 + 1024 + (size_t)kRecomputeSlotTile * kn * 8 + 255) & ~(size_t)255;
 }
 
+// LDS layout of one joint chunk (Jc joints): rays[R][Jc] with a row stride of 32 Jc + 16 bytes and scores[R][Jc | 1]:
+// a lane walks the joints of ITS candidate's two rows with compile-time offsets (no address arithmetic in the
+// solve loop), and the odd strides (in 16-byte / 4-byte units) spread the rows of neighbouring lanes over the banks.
 __host__ __device__ inline int recompute_chunk_joints(int R, int J, int score_bytes) {
-    int jc = kRayChunkBytes / (R * (32 + score_bytes));
+    const int per_row = kRayChunkBytes / R - 16 - score_bytes;
+    int jc = per_row / (32 + score_bytes);
     return jc < 1 ? 0 : (jc > J ? J : jc);
 }
+__host__ __device__ inline size_t recompute_ray_stride(int Jc) { return (size_t)32 * Jc + 16; }
+__host__ __device__ inline int recompute_score_stride(int Jc) { return Jc | 1; }
 
 __host__ __device__ inline size_t recompute_lds_bytes(int R, int J, int kn, int score_bytes) {
     const int jc = recompute_chunk_joints(R, J, score_bytes);
-    return (size_t)jc * R * (32 + score_bytes) + (size_t)(kBlock / 64) * kn * 32 + 256;
+    const size_t chunk = (size_t)R * (recompute_ray_stride(jc) + (size_t)recompute_score_stride(jc) * score_bytes);
+    (void)kn;
+    return ((chunk + 15) & ~(size_t)15) + (size_t)kBlock * 32 + 256;   // + one (S, X, Y, Z) partial per thread
 }
 
 // Dynamic LDS = recompute_lds_bytes(R, J, kn, sizeof(TIn)); scratch = gridDim.x slabs of
-// recompute_scratch_bytes(Kc).  R = C * Pmax ray rows.  Requires keypoint_num <= kRecomputeMaxKn.
+// recompute_scratch_bytes(Kc, R).  R = C * Pmax ray rows.  Requires keypoint_num <= kRecomputeMaxKn.
 #ifndef SNOWTRI_RECOMPUTE_WAVES
 #define SNOWTRI_RECOMPUTE_WAVES 3
 #endif
@@ -62,15 +72,17 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
                                                             size_t scratch_per_block,
                                                             unsigned long long *next_frame) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int C = rig.C, R = C * Pmax, pp = Pmax * Pmax;
     const int kn = prm.kn, ci = prm.center;
     const int Jc = recompute_chunk_joints(R, J, (int)sizeof(TIn));
-    RayRec *rays = reinterpret_cast<RayRec *>(smem);                                   // [Jc][R]
-    TIn *rsc = reinterpret_cast<TIn *>(rays + (size_t)Jc * R);                          // [Jc][R]
-    double *partial = reinterpret_cast<double *>(smem + (size_t)Jc * R * (32 + sizeof(TIn)));  // [4][kn][4]
-    partial = reinterpret_cast<double *>((reinterpret_cast<uintptr_t>(partial) + 15) & ~(uintptr_t)15);
-    double *red = partial + (size_t)(kBlock / 64) * kn * 4;                              // [4] + misc
+    const size_t rstride = recompute_ray_stride(Jc);            // bytes between the ray rows
+    const int sstride = recompute_score_stride(Jc);             // elements between the score rows
+    char *rays = smem;                                          // [R] rows of Jc RayRec (+16 B pad)
+    TIn *rsc = reinterpret_cast<TIn *>(smem + (size_t)R * rstride);                      // [R][sstride]
+    double *partial = reinterpret_cast<double *>(
+        smem + ((((size_t)R * (rstride + (size_t)sstride * sizeof(TIn))) + 15) & ~(size_t)15));  // [kBlock][4]
+    double *red = partial + (size_t)kBlock * 4;                              // [4] + misc
     int32_t *misc = reinterpret_cast<int32_t *>(red + kBlock / 64);
 
     // per-workgroup bookkeeping slab (global, reused frame after frame)
@@ -86,6 +98,7 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
     uint8_t *keep = reinterpret_cast<uint8_t *>(cstart + Kc + 1);   // [Kc]
     int32_t *rowlist = reinterpret_cast<int32_t *>(slab + (((size_t)Kc * 64 + 1024) & ~(size_t)7));  // [R] (DLT)
     int32_t *rowflag = rowlist + R;                                                                   // [R] (DLT)
+    double *osbuf = reinterpret_cast<double *>(rowflag + R);   // [kRecomputeSlotTile][kn] fused joint scores
 
     const PackedWriter<TOut> wr{out4, out_ps};
     const Kp3<TIn> *kp3 = reinterpret_cast<const Kp3<TIn> *>(kpts);
@@ -115,8 +128,8 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
                 const int nc = np_f ? np_f[c] : Pmax;
                 if (p < nc) {
                     const Kp3<TIn> kp = kpf[(size_t)r * J + j0 + jj];
-                    rays[jj * R + r] = make_ray(rig.M + 9 * c, kp.u, kp.v);
-                    rsc[jj * R + r] = kp.s;
+                    *reinterpret_cast<RayRec *>(rays + r * rstride + 32 * jj) = make_ray(rig.M + 9 * c, kp.u, kp.v);
+                    rsc[r * sstride + jj] = kp.s;
                 }
             }
             __syncthreads();
@@ -127,16 +140,71 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
                 if (pm >= nm || ps >= ns) continue;
                 const int rm = mc * Pmax + pm, rs = sc * Pmax + ps;
                 const double *pc = rig.pairc + 6 * q;
-                const Vec3 d = {pc[0], pc[1], pc[2]}, tsum = {0.0, 0.0, 0.0};
+                const Vec3 d = {pc[0], pc[1], pc[2]};
+                const RayRec *ra = reinterpret_cast<const RayRec *>(rays + rm * rstride);
+                const RayRec *rb = reinterpret_cast<const RayRec *>(rays + rs * rstride);
+                const TIn *sa = rsc + rm * sstride, *sb = rsc + rs * sstride;
                 double acc = 0.0;
-#pragma unroll(kRecomputeUnroll)
-                for (int jj = 0; jj < nj; jj++) {
-                    const RayRec a = rays[jj * R + rm], b = rays[jj * R + rs];
-                    const TIn sm = rsc[jj * R + rm], ss = rsc[jj * R + rs];
-                    const PairSolve o = pair_solve_fast<false>(a, b, d, tsum);
-                    const bool kp_ = !below_kthr(sm, prm) && !below_kthr(ss, prm) && !(o.d2 > prm.dthr2);  // :73-74
-                    acc += gated_sum(sm, ss, kp_) * (0.5 * o.score_base);                              // :72
-                    sing |= o.singular;
+                // one solve, reciprocal of the determinant supplied (A2 + the score of :72-74)
+                auto finish = [&](const RayRec &a, const RayRec &b, double bq, double e, double g, double inv, TIn sm,
+                                  TIn ss) {
+                    const double S0 = fma(b.a, e, -(bq * g)) * inv;
+                    const double S1 = fma(a.a, g, -(bq * e)) * inv;
+                    const Vec3 df = {fma(b.x, S1, fma(a.x, S0, -d.x)), fma(b.y, S1, fma(a.y, S0, -d.y)),
+                                     fma(b.z, S1, fma(a.z, S0, -d.z))};
+                    const double d2 = dot3(df, df);
+                    double idist = rsq_nr1(d2);
+                    idist = (d2 == 0.0) ? __builtin_inf() : idist;
+                    const bool kp_ = !below_kthr(sm, prm) && !below_kthr(ss, prm) && !(d2 > prm.dthr2);  // :73-74
+                    acc += gated_sum(sm, ss, kp_) * (idist * 0.0005);                                // :72
+                };
+                int jj = 0;
+                // four joints at a time share ONE reciprocal (Montgomery): v_rcp_f64 issues at quarter rate.
+                // A product outside the normal range (a singular or wildly conditioned pair in the group)
+                // falls back to four separate reciprocals.
+                for (; jj + 4 <= nj; jj += 4) {
+                    RayRec a[4], b[4];
+                    TIn sm[4], ss[4];
+                    double bq[4], e[4], g[4], det[4], inv[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        a[u] = ra[jj + u];
+                        b[u] = rb[jj + u];
+                        sm[u] = sa[jj + u];
+                        ss[u] = sb[jj + u];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        bq[u] = fma(a[u].z, b[u].z, fma(a[u].y, b[u].y, a[u].x * b[u].x));
+                        e[u] = fma(a[u].z, d.z, fma(a[u].y, d.y, a[u].x * d.x));
+                        g[u] = fma(b[u].z, d.z, fma(b[u].y, d.y, b[u].x * d.x));
+                        det[u] = fma(a[u].a, b[u].a, -(bq[u] * bq[u]));
+                        sing |= det[u] == 0.0;
+                    }
+                    const double p01 = det[0] * det[1], p012 = p01 * det[2], p0123 = p012 * det[3];
+                    if (fabs(p0123) > 1e-250 && fabs(p0123) < 1e250) {
+                        double run = rcp_nr2(p0123);
+                        inv[3] = run * p012;
+                        run *= det[3];
+                        inv[2] = run * p01;
+                        run *= det[2];
+                        inv[1] = run * det[0];
+                        inv[0] = run * det[1];
+                    } else {
+#pragma unroll
+                        for (int u = 0; u < 4; u++) inv[u] = rcp_nr2(det[u]);
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++) finish(a[u], b[u], bq[u], e[u], g[u], inv[u], sm[u], ss[u]);
+                }
+                for (; jj < nj; jj++) {
+                    const RayRec a = ra[jj], b = rb[jj];
+                    const double bq = fma(a.z, b.z, fma(a.y, b.y, a.x * b.x));
+                    const double e = fma(a.z, d.z, fma(a.y, d.y, a.x * d.x));
+                    const double g = fma(b.z, d.z, fma(b.y, d.y, b.x * d.x));
+                    const double det = fma(a.a, b.a, -(bq * bq));
+                    sing |= det == 0.0;
+                    finish(a, b, bq, e, g, rcp_nr2(det), sa[jj], sb[jj]);
                 }
                 sum[k] += acc;
             }
@@ -232,12 +300,12 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
 
         // ---------------- phase 3: fusion per surviving cluster ------------------------------
         int nout = 0;
-        for (int cid = 0; cid < ncl; cid++) {
-            const int size = csize[cid];
-            if ((double)size < prm.num_tol) continue;                                             // :132-134
-            const int m0 = cstart[cid];
-            double ox = 0.0, oy = 0.0, oz = 0.0, os = 0.0;
-            if constexpr (METHOD == 1) {
+        if constexpr (METHOD == 1) {
+            for (int cid = 0; cid < ncl; cid++) {
+                const int size = csize[cid];
+                if ((double)size < prm.num_tol) continue;                                         // :132-134
+                const int m0 = cstart[cid];
+                double ox = 0.0, oy = 0.0, oz = 0.0, os = 0.0;
                 // distinct observation rows of this cluster, in row order
                 for (int r = tid; r < R; r += kBlock) rowflag[r] = 0;
                 __syncthreads();
@@ -263,9 +331,9 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
                 const int nrows = misc[4];
                 if (tid < kn) {
                     double A[4][4];
-#pragma unroll
+    #pragma unroll
                     for (int i = 0; i < 4; i++)
-#pragma unroll
+    #pragma unroll
                         for (int k2 = 0; k2 < 4; k2++) A[i][k2] = 0.0;
                     double ssum = 0.0;
                     int cnt = 0;
@@ -287,71 +355,151 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
                         os = ssum / (double)cnt;
                     }
                 }
-            } else {
-                double aS[4] = {0, 0, 0, 0}, aX[4] = {0, 0, 0, 0}, aY[4] = {0, 0, 0, 0}, aZ[4] = {0, 0, 0, 0};
-                for (int mi = wave; mi < size; mi += kBlock / 64) {
-                    const int k = kidx[members[m0 + mi]];
-                    const int q = k / pp, rr = k - q * pp, pm = rr / Pmax, ps = rr - pm * Pmax;
-                    const int mc = rig.pairs[2 * q], sc = rig.pairs[2 * q + 1];
-                    const Kp3<TIn> *rowm = kpf + (size_t)(mc * Pmax + pm) * J, *rows = kpf + (size_t)(sc * Pmax + ps) * J;
-                    const double *pc = rig.pairc + 6 * q;
-                    const Vec3 d = {pc[0], pc[1], pc[2]}, tsum = {pc[3], pc[4], pc[5]};
-                    const double *Mm = rig.M + 9 * mc, *Ms = rig.M + 9 * sc;
-#pragma unroll
-                    for (int p = 0; p < 4; p++) {
-                        const int b = lane + 64 * p;
-                        if (b < kn) {
-                            const Kp3<TIn> km = rowm[b], ks = rows[b];
-                            const PairSolve o = pair_solve_fast<true>(make_ray(Mm, km.u, km.v), make_ray(Ms, ks.u, ks.v), d, tsum);
-                            const bool kp_ = !below_kthr(km.s, prm) && !below_kthr(ks.s, prm) && !(o.d2 > prm.dthr2);
-                            const double s = gated_sum(km.s, ks.s, kp_) * (0.5 * o.score_base);
-                            aS[p] += s;                                                                // :141
-                            aX[p] = fma(s, o.sw.x, aX[p]);                                             // :144-147
-                            aY[p] = fma(s, o.sw.y, aY[p]);
-                            aZ[p] = fma(s, o.sw.z, aZ[p]);
-                        }
+
+                const double avg = block_sum(tid < kn ? os : 0.0, red) / (double)kn;               // :150
+                if (!(avg < prm.score_tol)) {                                                      // :151-152
+                    if (nout < Pout) {
+                        if (tid < kn) wr.joint(f, Pout, kn, nout, tid, ox, oy, oz, os);
+                        if (tid == 0) wr.person(f, Pout, nout, avg);
                     }
-                }
-#pragma unroll
-                for (int p = 0; p < 4; p++) {
-                    const int b = lane + 64 * p;
-                    if (b < kn) {
-                        double *dst = partial + ((size_t)wave * kn + b) * 4;
-                        dst[0] = aS[p];
-                        dst[1] = aX[p];
-                        dst[2] = aY[p];
-                        dst[3] = aZ[p];
-                    }
+                    nout++;
                 }
                 __syncthreads();
-                if (tid < kn) {
-                    double S = 0.0, X = 0.0, Y = 0.0, Z = 0.0;
-#pragma unroll
-                    for (int w = 0; w < kBlock / 64; w++) {
-                        const double *src = partial + ((size_t)w * kn + tid) * 4;
-                        S += src[0];
-                        X += src[1];
-                        Y += src[2];
-                        Z += src[3];
-                    }
-                    if (!(S == 0.0)) {                                                                 // :142-143
-                        const double r = 0.5 / S;
-                        ox = X * r;
-                        oy = Y * r;
-                        oz = Z * r;
-                        os = S / (double)size;                                                         // :148
-                    }
-                }
             }
-            const double avg = block_sum(tid < kn ? os : 0.0, red) / (double)kn;                   // :150
-            if (!(avg < prm.score_tol)) {                                                          // :151-152
-                if (nout < Pout) {
-                    if (tid < kn) wr.joint(f, Pout, kn, nout, tid, ox, oy, oz, os);
-                    if (tid == 0) wr.person(f, Pout, nout, avg);
+        } else {
+            // Pairwise fusion (:136-152), second sweep over the joint chunks with the rays back in LDS:
+            // thread (jj, g) walks members g, g + G, ... of a cluster for joint jj of the chunk; G is a power of
+            // two, so the G partial sums of a joint sit in adjacent lanes and are added with shuffles -- no LDS
+            // traffic and NO barrier per cluster.  Joints go straight to their output slot, assigned in cluster
+            // order to the clusters that pass the size filter; their scores are parked in `osbuf` (up to
+            // kRecomputeSlotTile persons per sweep) for the mean-score filter, applied at the end by compacting.
+            int32_t *crows = reinterpret_cast<int32_t *>(centre);   // [n]  rm | rs << 16, cluster-member order
+            int32_t *cq = crows + Kc;                               // [n]  camera pair
+            int32_t *cslot = cq + Kc;                               // [ncl] preliminary output slot or -1
+            for (int pos = tid; pos < n; pos += kBlock) {
+                const int k = kidx[members[pos]];
+                const int q = k / pp, rr = k - q * pp, pm = rr / Pmax, ps = rr - pm * Pmax;
+                crows[pos] = (rig.pairs[2 * q] * Pmax + pm) | ((rig.pairs[2 * q + 1] * Pmax + ps) << 16);
+                cq[pos] = q;
+            }
+            if (tid < 64) {
+                int ns = 0;
+                for (int base = 0; base < ncl; base += 64) {
+                    const int c = base + lane;
+                    const bool in = c < ncl && !((double)csize[c] < prm.num_tol);                  // :132-134
+                    const unsigned long long m = __ballot(in);
+                    if (c < ncl) cslot[c] = in ? ns + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+                    ns += __popcll(m);
                 }
-                nout++;
+                if (lane == 0) misc[5] = ns;
             }
             __syncthreads();
+            const int nsurv = misc[5];
+            for (int sbase = 0; sbase < nsurv; sbase += kRecomputeSlotTile) {
+                for (int j0 = 0; j0 < kn; j0 += Jc) {
+                    const int nj = (kn - j0) < Jc ? (kn - j0) : Jc;
+                    for (int i = tid; i < R * nj; i += kBlock) {
+                        const int r = i / nj, jj = i - r * nj;
+                        const int c = r / Pmax, p = r - c * Pmax;
+                        const int nc = np_f ? np_f[c] : Pmax;
+                        if (p < nc) {
+                            const Kp3<TIn> kp = kpf[(size_t)r * J + j0 + jj];
+                            *reinterpret_cast<RayRec *>(rays + r * rstride + 32 * jj) = make_ray(rig.M + 9 * c, kp.u, kp.v);
+                            rsc[r * sstride + jj] = kp.s;
+                        }
+                    }
+                    __syncthreads();
+                    int G = 64;                                   // largest power of two with nj * G <= 256
+                    while (G > 1 && nj * G > kBlock) G >>= 1;
+                    const int jj = tid / G, g = tid & (G - 1);
+                    const bool active = jj < nj;
+                    const int jc = active ? jj : 0;
+                    for (int cid = 0; cid < ncl; cid++) {
+                        const int slot = cslot[cid];
+                        if (slot < sbase || slot >= sbase + kRecomputeSlotTile) continue;
+                        const int size = csize[cid], m0 = cstart[cid];
+                        double aS = 0.0, aX = 0.0, aY = 0.0, aZ = 0.0;
+                        for (int mi = g; mi < size && active; mi += G) {
+                            const int rw = crows[m0 + mi], q = cq[m0 + mi];
+                            const int rm = rw & 0xffff, rs = rw >> 16;
+                            const double *pc = rig.pairc + 6 * q;
+                            const Vec3 d = {pc[0], pc[1], pc[2]}, tsum = {pc[3], pc[4], pc[5]};
+                            const RayRec a = *reinterpret_cast<const RayRec *>(rays + rm * rstride + 32 * jc);
+                            const RayRec b = *reinterpret_cast<const RayRec *>(rays + rs * rstride + 32 * jc);
+                            const TIn sm = rsc[rm * sstride + jc], ss = rsc[rs * sstride + jc];
+                            const PairSolve o = pair_solve_fast<true>(a, b, d, tsum);
+                            const bool kp_ = !below_kthr(sm, prm) && !below_kthr(ss, prm) && !(o.d2 > prm.dthr2);
+                            const double sq = gated_sum(sm, ss, kp_) * (0.5 * o.score_base);
+                            aS += sq;                                                              // :141
+                            aX = fma(sq, o.sw.x, aX);                                              // :144-147
+                            aY = fma(sq, o.sw.y, aY);
+                            aZ = fma(sq, o.sw.z, aZ);
+                        }
+                        for (int off = G >> 1; off > 0; off >>= 1) {   // the G lanes of a joint are adjacent
+                            aS += __shfl_xor(aS, off, 64);
+                            aX += __shfl_xor(aX, off, 64);
+                            aY += __shfl_xor(aY, off, 64);
+                            aZ += __shfl_xor(aZ, off, 64);
+                        }
+                        if (active && g == 0) {
+                            double ox = 0.0, oy = 0.0, oz = 0.0, os = 0.0;
+                            if (!(aS == 0.0)) {                                                    // :142-143
+                                const double r = 0.5 / aS;
+                                ox = aX * r;
+                                oy = aY * r;
+                                oz = aZ * r;
+                                os = aS / (double)size;                                            // :148
+                            }
+                            if (slot < Pout) wr.joint(f, Pout, kn, slot, j0 + jj, ox, oy, oz, os);
+                            osbuf[(size_t)(slot - sbase) * kn + j0 + jj] = os;
+                        }
+                    }
+                    __syncthreads();
+                }
+                // mean fused score of every person of this sweep (:150): one wave per person, fixed order
+                for (int cid = 0; cid < ncl; cid++) {
+                    const int slot = cslot[cid];
+                    if (slot < sbase || slot >= sbase + kRecomputeSlotTile || ((slot - sbase) & (kBlock / 64 - 1)) != (tid >> 6))
+                        continue;
+                    double v = 0.0;
+                    for (int b = lane; b < kn; b += 64) v += osbuf[(size_t)(slot - sbase) * kn + b];
+                    v = wave_sum(v);
+                    if (lane == 0) sum[cid] = v;
+                }
+                __syncthreads();
+            }
+            // mean-score filter (:150-152) and final slots
+            if (tid < 64) {
+                int nf_ = 0, moved = 0;
+                for (int base = 0; base < ncl; base += 64) {
+                    const int c = base + lane;
+                    const int slot = c < ncl ? cslot[c] : -1;
+                    const double avg = slot >= 0 ? sum[c] / (double)kn : 0.0;
+                    const bool in = slot >= 0 && !(avg < prm.score_tol);
+                    const unsigned long long m = __ballot(in);
+                    const int fin = nf_ + __popcll(m & ((1ull << lane) - 1ull));
+                    if (c < ncl) cluster_of[c] = in ? fin : -1;      // final slot (cluster_of is free by now)
+                    if (in && fin < Pout) wr.person(f, Pout, fin, avg);
+                    moved |= __ballot(in && fin != slot) != 0ull;
+                    moved |= __ballot(slot >= 0 && !in) != 0ull;
+                    nf_ += __popcll(m);
+                }
+                if (lane == 0) {
+                    misc[5] = nf_;
+                    misc[6] = moved;
+                }
+            }
+            __syncthreads();
+            nout = misc[5];
+            if (misc[6]) {   // a cluster was dropped by the score filter: close the gap, in slot order
+                for (int cid = 0; cid < ncl; cid++) {
+                    const int from = cslot[cid], to = cluster_of[cid];
+                    if (from < 0 || to < 0 || from == to || from >= Pout) continue;
+                    TOut *base = out4 + (f * Pout) * (int64_t)kn * 4;
+                    for (int i = tid; i < kn * 4; i += kBlock) base[(size_t)to * kn * 4 + i] = base[(size_t)from * kn * 4 + i];
+                    __syncthreads();
+                }
+            }
         }
         for (int slot = nout; slot < Pout; slot++) {
             for (int b = tid; b < kn; b += kBlock) wr.joint(f, Pout, kn, slot, b, 0.0, 0.0, 0.0, 0.0);

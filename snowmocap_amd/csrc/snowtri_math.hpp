@@ -125,7 +125,7 @@ __device__ __forceinline__ double rsq_nr1(double x) {
     return fma(y * 0.5, e, y);               // y (1 + e/2)
 }
 
-struct RayRec {  // one world ray in LDS: direction (un-normalised) and its squared norm
+struct alignas(16) RayRec {  // one world ray in LDS: direction (un-normalised) and its squared norm
     double x, y, z, a;
 };
 
