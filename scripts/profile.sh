@@ -17,6 +17,9 @@ rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats_large -o stat
 rocprofv3 --output-format csv --pmc FETCH_SIZE --kernel-trace -d $OUT/pmc_fetch -o fetch -- $BENCH > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --output-format csv --pmc WRITE_SIZE --kernel-trace -d $OUT/pmc_write -o write -- $BENCH > $OUT/pmc_write.log 2>&1
 rocprofv3 --output-format csv --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_WAVE_CYCLES GRBM_GUI_ACTIVE --kernel-trace -d $OUT/pmc_sq -o sq -- $LARGE > $OUT/pmc_sq.log 2>&1
+# 3. the other kernels: multi-person configs and the rows after the hot path (kernel stats only)
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats_multi -o stats -- python $ROOT/scripts/bench_configs.py > $OUT/stats_multi.log 2>&1
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats_next -o stats -- python $ROOT/scripts/bench_next_rows.py > $OUT/stats_next.log 2>&1
 cd $ROOT
 python scripts/summarize_profile.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
