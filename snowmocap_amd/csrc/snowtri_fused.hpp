@@ -403,10 +403,11 @@ __device__ __forceinline__ void dlt_min_eigenvector(double (&A)[4][4], double (&
 // The same eigenvector by shifted inverse iteration: G = A^T A + mu I = L L^T (Cholesky, mu = 64 eps trace keeps
 // every pivot positive when the data are exact and A^T A is singular), x <- normalise(G^-1 x) from e_4.
 // The wanted eigenvalue is the squared reprojection residual (tiny), the next one is ~1e4..1e5 times larger at
-// one pixel of noise, so four steps reach 2e-14 m (same as the SVD oracle) and a fifth confirms it -- ~15x
-// fewer instructions than the Jacobi sweeps.  The loop leaves when every lane of the wave moved less than
-// 1e-13; lanes that have not by SNOWTRI_DLT_INVIT steps (gross outliers: eigenvalue ratio above ~0.02) report
-// false and the caller re-solves them with Jacobi.  `live` = false lanes (fewer than two cameras) never block.
+// one pixel of noise, so four steps reach 2e-14 m (same as the SVD oracle) -- ~15x fewer instructions than the
+// Jacobi sweeps.  Convergence is linear, so a lane is done when (step length)^2 / (previous step length), the
+// estimate of the error left, drops below 1e-14; the loop leaves when every lane of the wave is done; lanes that
+// are not by SNOWTRI_DLT_INVIT steps (gross outliers: eigenvalue ratio above ~0.02) report false and the caller
+// re-solves them with Jacobi.  `live` = false lanes (fewer than two cameras) never block.
 __device__ __forceinline__ bool dlt_inverse_iteration(const double (&A)[4][4], bool live, double (&e)[4]) {
     const double mu = (A[0][0] + A[1][1] + A[2][2] + A[3][3]) * (64.0 * 2.220446049250313e-16);
     double L[4][4], inv[4];  // L strictly-lower entries, inv[i] = 1 / L[i][i]
@@ -425,6 +426,7 @@ __device__ __forceinline__ bool dlt_inverse_iteration(const double (&A)[4][4], b
         }
     }
     double x[4] = {0.0, 0.0, 0.0, 1.0};
+    double prev = 1.0;  // previous step length
     bool conv = !live;
 #pragma unroll 1
     for (int it = 0; it < SNOWTRI_DLT_INVIT; it++) {
@@ -451,7 +453,9 @@ __device__ __forceinline__ bool dlt_inverse_iteration(const double (&A)[4][4], b
             diff = fmax(diff, fabs(xn - x[i]));
             x[i] = xn;
         }
-        conv = conv || (diff < 1e-13);
+        // linear convergence with ratio r = diff / prev: the error left after this step is ~ diff * r
+        conv = conv || (diff * diff < 1e-14 * prev);
+        prev = diff;
         if (__all(conv)) break;
     }
 #pragma unroll
@@ -471,11 +475,13 @@ __device__ __forceinline__ void dlt_solve(double (&A)[4][4], bool live, double (
 }
 
 template <int C, typename TIn>
-__device__ __forceinline__ void dlt_item(const Rig &rig, const Kp3<TIn> (&cur)[C], const int32_t *np_f,
+__device__ __forceinline__ void dlt_item(const double *__restrict__ Plds, const Kp3<TIn> (&cur)[C], const int32_t *np_f,
                                          const Params &prm, double &ox, double &oy, double &oz, double &os) {
-    typedef const __attribute__((address_space(4))) double *cptr;
-    cptr Pp = (cptr)(uintptr_t)rig.P;
-    asm volatile("" : "+s"(Pp));
+    // world->pixel matrices P[C][12] come from LDS (broadcast reads), like the ray matrices of the pairwise
+    // item: 96 doubles in scalar registers overflow the SGPR file and come back as v_readlane traffic
+    double Pp[12 * C];
+#pragma unroll
+    for (int i = 0; i < 12 * C; i++) Pp[i] = Plds[i];
     double A[4][4];
 #pragma unroll
     for (int i = 0; i < 4; i++)
@@ -521,9 +527,13 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_single(int
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const PackedWriter<TOut> wr{out4, out_ps};
     const Kp3<TIn> *kp3 = reinterpret_cast<const Kp3<TIn> *>(kpts);
-    if (tid < 9 * C) Mlds[tid] = rig.M[tid];  // visible after the first __syncthreads() below
-    if (tid < 3 * C) Mlds[9 * C + tid] = rig.t[tid];
-    if (tid < 3 * NP) Mlds[12 * C + tid] = rig.pairc[6 * (tid / 3) + tid % 3];
+    if constexpr (METHOD == 1) {
+        if (tid < 12 * C) Mlds[tid] = rig.P[tid];  // DLT: the 12 C doubles of M and t hold P instead
+    } else {
+        if (tid < 9 * C) Mlds[tid] = rig.M[tid];  // visible after the first __syncthreads() below
+        if (tid < 3 * C) Mlds[9 * C + tid] = rig.t[tid];
+        if (tid < 3 * NP) Mlds[12 * C + tid] = rig.pairc[6 * (tid / 3) + tid % 3];
+    }
     const int dfl = kBlock / J, dj = kBlock - dfl * J;
     const int64_t ntiles = (F + T - 1) / T;
 
@@ -552,7 +562,7 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_single(int
                     bad = pairwise_item<C>(rig, Mlds, buf, prm, ox, oy, oz, os);
                 } else {
                     bad = false;
-                    dlt_item<C>(rig, buf, n_persons ? n_persons + (f0 + fl_) * C : nullptr, prm, ox, oy, oz, os);
+                    dlt_item<C>(Mlds, buf, n_persons ? n_persons + (f0 + fl_) * C : nullptr, prm, ox, oy, oz, os);
                 }
                 if (j_ < kn) {
                     Vec4T<TOut> *tile_out = reinterpret_cast<Vec4T<TOut> *>(out4) + f0 * Pout * (int64_t)kn;

@@ -47,6 +47,22 @@ int main(void) {
                 fabs(out[f][0][j][2] - X[j][2]) > 2e-2 || count[f] != 1)
                 return 13;
         }
+    /* rows after the hot path through the same ABI: lens undistortion with zero coefficients is the identity,
+     * a one-lane track passes its first frame through the temporal filter and then moves towards the input */
+    const double D[15] = {0};
+    rc = snowtri_ctx_set_distortion(ctx, D);
+    if (rc) { printf("set_distortion: %s\n", snowtri_status_string(rc)); return 14; }
+    float und[2][3][1][2][3];
+    rc = snowtri_undistort_keypoints(ctx, 2, 1, 2, kpts, und, SNOWTRI_F32, SNOWTRI_HOST, NULL);
+    if (rc) { printf("undistort: %s\n", snowtri_status_string(rc)); return 15; }
+    for (int i = 0; i < 2 * 3 * 2 * 3; i++)
+        if (fabs(((float *)und)[i] - ((float *)kpts)[i]) > 1e-6) return 16;
+    const double track[4] = {0.0, 1.0, 1.0, 1.0};
+    double smooth[4];
+    rc = snowtri_smooth_track(ctx, 4, 1, track, 2.5, 0.75, 0.0, 1.0 / 30, smooth, SNOWTRI_HOST, NULL);
+    if (rc) { printf("smooth_track: %s\n", snowtri_status_string(rc)); return 17; }
+    if (smooth[0] != 0.0 || !(smooth[3] > smooth[2] && smooth[2] > smooth[1] && smooth[3] < 1.0)) return 18;
+    printf("smooth: %.4f %.4f %.4f %.4f\n", smooth[0], smooth[1], smooth[2], smooth[3]);
     snowtri_ctx_destroy(ctx);
     printf("c abi ok\n");
     return 0;
