@@ -376,7 +376,8 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
             int32_t *crows = reinterpret_cast<int32_t *>(centre);   // [n]  rm | rs << 16, cluster-member order
             int32_t *cq = crows + Kc;                               // [n]  camera pair
             int32_t *cslot = cq + Kc;                               // [ncl] preliminary output slot or -1
-            for (int pos = tid; pos < n; pos += kBlock) {
+            const int nmem = cstart[ncl];   // members of all clusters (<= n: the last candidate never seeds, :107)
+            for (int pos = tid; pos < nmem; pos += kBlock) {
                 const int k = kidx[members[pos]];
                 const int q = k / pp, rr = k - q * pp, pm = rr / Pmax, ps = rr - pm * Pmax;
                 crows[pos] = (rig.pairs[2 * q] * Pmax + pm) | ((rig.pairs[2 * q + 1] * Pmax + ps) << 16);
