@@ -395,6 +395,10 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
                 if (lane == 0) misc[5] = ns;
             }
             __syncthreads();
+            // pass 0 writes to the preliminary slots; if the mean-score filter then drops a cluster, the later
+            // ones belong further down (and one that did not fit Pout_max may now fit): pass 1 repeats the
+            // sweep with the final slots.  The filter never fires with the shipped thresholds.
+            for (int pass = 0; pass < 2; pass++) {
             const int nsurv = misc[5];
             for (int sbase = 0; sbase < nsurv; sbase += kRecomputeSlotTile) {
                 for (int j0 = 0; j0 < kn; j0 += Jc) {
@@ -479,10 +483,10 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
                     const bool in = slot >= 0 && !(avg < prm.score_tol);
                     const unsigned long long m = __ballot(in);
                     const int fin = nf_ + __popcll(m & ((1ull << lane) - 1ull));
-                    if (c < ncl) cluster_of[c] = in ? fin : -1;      // final slot (cluster_of is free by now)
                     if (in && fin < Pout) wr.person(f, Pout, fin, avg);
                     moved |= __ballot(in && fin != slot) != 0ull;
                     moved |= __ballot(slot >= 0 && !in) != 0ull;
+                    if (c < ncl) cslot[c] = in ? fin : -1;           // the slots of pass 1, if there is one
                     nf_ += __popcll(m);
                 }
                 if (lane == 0) {
@@ -492,14 +496,8 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
             }
             __syncthreads();
             nout = misc[5];
-            if (misc[6]) {   // a cluster was dropped by the score filter: close the gap, in slot order
-                for (int cid = 0; cid < ncl; cid++) {
-                    const int from = cslot[cid], to = cluster_of[cid];
-                    if (from < 0 || to < 0 || from == to || from >= Pout) continue;
-                    TOut *base = out4 + (f * Pout) * (int64_t)kn * 4;
-                    for (int i = tid; i < kn * 4; i += kBlock) base[(size_t)to * kn * 4 + i] = base[(size_t)from * kn * 4 + i];
-                    __syncthreads();
-                }
+            if (!misc[6]) break;
+            __syncthreads();   // misc[5] (= survivors of pass 1) is read at the top of the loop
             }
         }
         for (int slot = nout; slot < Pout; slot++) {

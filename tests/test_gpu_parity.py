@@ -374,6 +374,54 @@ def test_general_kernels_agree(api, mode, monkeypatch):
         assert not out["xyzs"][f, 1:].any()
 
 
+def test_random_small_rigs_against_oracle(api):
+    """Randomised sweep of the shapes the fused entry can meet -- 2..6 cameras, 1..3 detections per camera with
+    ragged (also empty) person lists, 3..40 joints, keypoint_num <= J, any centre joint, thresholds that switch
+    every filter on and off -- against the oracle: identical person counts, joints within 1e-8 m."""
+    from snowmocap_amd import synth, _lib
+    from oracle import oracle as orc
+    rng = np.random.default_rng(2024)
+    checked = 0
+    for trial in range(60):
+        C = int(rng.integers(2, 7))
+        P = int(rng.integers(1, 4))
+        J = int(rng.choice([3, 5, 20, 33, 40]))
+        F = int(rng.integers(1, 6))
+        K, R, t = synth.ring_rig(C, radius=float(rng.uniform(3, 6)))
+        X = synth.make_people(rng, F, P, J=J)
+        kp, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=float(rng.choice([0.3, 1.0, 3.0])),
+                                         score_range=(2.0, 8.0), permute_persons=True,
+                                         dtype=np.float64 if trial % 2 else np.float32)
+        npers = npers.copy()
+        for _ in range(int(rng.integers(0, 4))):                          # ragged / empty person lists
+            npers[rng.integers(0, F), rng.integers(0, C)] = rng.integers(0, P + 1)
+        kn = int(rng.integers(1, J + 1))
+        prm = dict(keypoint_score_threshold=float(rng.choice([0.0, 3.0, 3.0, 5.0])),
+                   average_score_threshold=float(rng.choice([0.0, 0.0, 0.3, 1.5])),
+                   distance_threshold=float(rng.choice([0.02, 0.05, 1.0])),
+                   condense_distance_tol=float(rng.choice([0.05, 0.3, 10.0])),
+                   condense_person_num_tol=int(rng.choice([0, 0, 1, 2])),
+                   condense_score_tol=float(rng.choice([0.0, 0.0, 0.3, 2.0])),
+                   center_point_index=int(rng.integers(0, J)), keypoint_num=kn)
+        pout = int(rng.choice([1, 4, 16]))
+        ref = orc.triangulate_condense_batch(K, R, t, kp, npers, orc.make_params(**prm), 64)
+        bt = api.BatchTriangulator(K, R, t, prm, pout_max=pout, out_dtype=np.float64)
+        out = bt.run_host(kp, npers)
+        bt.close()
+        msg = f"trial {trial}: C={C} P={P} J={J} kn={kn} F={F} {prm} pout={pout} n={npers.tolist()}"
+        np.testing.assert_array_equal(out["count"], ref["count"], err_msg=msg)
+        for f in range(F):
+            m = min(int(ref["count"][f]), pout)
+            assert not out["xyzs"][f, m:].any(), msg
+            if m:
+                assert_scores_close(out["xyzs"][f, :m, :, 3], ref["kscore"][f, :m])
+                assert_xyz_close(out["xyzs"][f, :m, :, :3], ref["xyz"][f, :m], XYZ_FUSED, score_ref=ref["kscore"][f, :m],
+                                 what=msg)
+                assert_scores_close(out["pscore"][f, :m], ref["pscore"][f, :m], nterms=kn, what=msg)   # a mean of kn scores
+                checked += m
+    assert checked > 150
+
+
 def test_fastmath_helpers_accuracy_contract(api):
     """rcp_nr2 ~ 1 ulp, rcp_nr1 / rsq_nr1 <= 1e-14 relative over +-300 decades (normal range): the
     bounds DESIGN.md §2 relies on for the throughput kernels."""
