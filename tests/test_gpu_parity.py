@@ -374,13 +374,17 @@ def test_general_kernels_agree(api, mode, monkeypatch):
         assert not out["xyzs"][f, 1:].any()
 
 
-def test_random_small_rigs_against_oracle(api):
+@pytest.mark.parametrize("mode", ["auto", "spill"])
+def test_random_small_rigs_against_oracle(api, mode, monkeypatch):
     """Randomised sweep of the shapes the fused entry can meet -- 2..6 cameras, 1..3 detections per camera with
     ragged (also empty) person lists, 3..40 joints, keypoint_num <= J, any centre joint, thresholds that switch
-    every filter on and off -- against the oracle: identical person counts, joints within 1e-8 m."""
+    every filter on and off -- against the oracle: identical person counts, joints within 1e-8 m.
+    mode "auto" = the dispatch a user gets (fast kernel / recompute kernel), "spill" = the HBM-spill kernel."""
     from snowmocap_amd import synth, _lib
     from oracle import oracle as orc
-    rng = np.random.default_rng(2024)
+    if mode == "spill":
+        monkeypatch.setenv("SNOWTRI_GENERAL_MODE", "1")
+    rng = np.random.default_rng(2024 if mode == "auto" else 7)
     checked = 0
     for trial in range(60):
         C = int(rng.integers(2, 7))
@@ -420,6 +424,43 @@ def test_random_small_rigs_against_oracle(api):
                 assert_scores_close(out["pscore"][f, :m], ref["pscore"][f, :m], nterms=kn, what=msg)   # a mean of kn scores
                 checked += m
     assert checked > 150
+
+
+def test_random_small_rigs_dlt_against_oracle(api):
+    """The same kind of sweep for method = DLT with several detections per camera (association + per-cluster
+    DLT) against oracle/dlt.py: identical counts, joints within 1e-8 m."""
+    from snowmocap_amd import synth, _lib
+    from oracle import dlt, oracle as orc
+    rng = np.random.default_rng(77)
+    checked = 0
+    for trial in range(16):
+        C = int(rng.integers(3, 7))
+        P = int(rng.integers(2, 4))
+        J = int(rng.choice([5, 12, 20]))
+        F = int(rng.integers(1, 4))
+        K, R, t = synth.ring_rig(C, radius=float(rng.uniform(3, 6)))
+        X = synth.make_people(rng, F, P, J=J)
+        kp, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=float(rng.choice([0.3, 1.0])), score_range=(2.0, 8.0),
+                                         permute_persons=True, dtype=np.float64)
+        npers = npers.copy()
+        for _ in range(int(rng.integers(0, 3))):
+            npers[rng.integers(0, F), rng.integers(0, C)] = rng.integers(0, P + 1)
+        prm = dict(keypoint_score_threshold=float(rng.choice([0.0, 3.0, 4.0])), average_score_threshold=float(rng.choice([0.0, 0.3])),
+                   distance_threshold=0.05, condense_distance_tol=float(rng.choice([0.3, 10.0])),
+                   condense_person_num_tol=int(rng.choice([0, 2])), condense_score_tol=float(rng.choice([0.0, 4.5])),
+                   center_point_index=int(rng.integers(0, J)), keypoint_num=int(rng.integers(1, J + 1)))
+        pout = int(rng.choice([2, 8]))
+        want, wps, wcnt = dlt.dlt_multi_batch(K, R, t, kp, npers, orc.make_params(**prm), pout)
+        bt = api.BatchTriangulator(K, R, t, prm, pout_max=pout, out_dtype=np.float64, method=_lib.DLT)
+        out = bt.run_host(kp, npers)
+        bt.close()
+        msg = f"trial {trial}: C={C} P={P} J={J} F={F} {prm} pout={pout} n={npers.tolist()}"
+        np.testing.assert_array_equal(out["count"], wcnt, err_msg=msg)
+        assert np.abs(out["xyzs"][..., :3] - want[..., :3]).max() < 1e-8, msg
+        np.testing.assert_allclose(out["xyzs"][..., 3], want[..., 3], rtol=1e-12, err_msg=msg)
+        np.testing.assert_allclose(out["pscore"], wps, rtol=1e-12, err_msg=msg)
+        checked += int(np.minimum(wcnt, pout).sum())
+    assert checked > 20
 
 
 def test_fastmath_helpers_accuracy_contract(api):
