@@ -173,9 +173,25 @@ __global__ __launch_bounds__(256) void k_hold_carry(int64_t n, int64_t nchunks, 
     const int64_t lane = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (lane >= n) return;
     double v = valid[lane / comps] ? x[lane] : 0.0;
-    for (int64_t c = 0; c < nchunks; c++) {
+    constexpr int U = 8;   // chunk summaries in flight ahead of the carried value
+    int64_t c = 0;
+    for (; c + U <= nchunks; c += U) {
+        double h[U];
+        uint8_t hf[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            h[u] = H[(c + u) * n + lane];
+            hf[u] = Hf[(c + u) * n + lane];
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            start[(c + u) * n + lane] = v;
+            v = hf[u] ? h[u] : v;
+        }
+    }
+    for (; c < nchunks; c++) {
         start[c * n + lane] = v;
-        const double h = H[c * n + lane];  // unconditional: keeps the loads independent of the carried value
+        const double h = H[c * n + lane];
         v = Hf[c * n + lane] ? h : v;
     }
 }

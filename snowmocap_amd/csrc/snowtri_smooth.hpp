@@ -25,6 +25,7 @@ struct SmoothCoef {
 };
 
 constexpr int kSmoothBlock = 256;
+constexpr int kSmoothUnroll = 8;   // frames whose loads are in flight per lane
 
 // Where a lane's coefficients come from: one set for the whole track (N1), or a table indexed by the lane's
 // control point (N2: per-bone f, z, r -- blender.py:171; lanes = [person][ncoef points][comps]).
@@ -46,7 +47,7 @@ struct NoHold {
     }
     __device__ __forceinline__ int64_t groups(int64_t) const { return 0; }
     __device__ __forceinline__ int64_t group(int64_t) const { return 0; }
-    __device__ __forceinline__ double input(double xt, double, int64_t) const { return xt; }
+    __device__ __forceinline__ bool ok(int64_t) const { return true; }
 };
 struct HoldInput {
     const uint8_t *valid;  // [T][n / comps]
@@ -57,7 +58,7 @@ struct HoldInput {
     }
     __device__ __forceinline__ int64_t groups(int64_t n) const { return n / comps; }
     __device__ __forceinline__ int64_t group(int64_t lane) const { return lane / comps; }
-    __device__ __forceinline__ double input(double xt, double xp, int64_t vidx) const { return valid[vidx] ? xt : xp; }
+    __device__ __forceinline__ bool ok(int64_t vidx) const { return valid[vidx] != 0; }
 };
 
 // frames tb..T-1 are the filtered ones (tb = 1: frame 0 is the seed and passes through; tb = 0: a later
@@ -79,8 +80,8 @@ __global__ __launch_bounds__(kSmoothBlock) void k_smooth_local(int64_t T, int64_
     double sy = S ? S[(c * n + lane) * 2] : 0.0, syd = S ? S[(c * n + lane) * 2 + 1] : 0.0;
     double xp = hs.entering(x, t0, c, n, lane);
     const int64_t nv = hs.groups(n), g = hs.group(lane);
-    for (int64_t t = t0; t < t1; t++) {
-        const double xt = hs.input(x[t * n + lane], xp, t * nv + g);
+    auto step = [&](int64_t t, double xraw, bool okt) {
+        const double xt = okt ? xraw : xp;   // an invalid point repeats the previous input (N2 hold)
         const double ct = fma(k.cxd, xt - xp, k.cx * xt);
         xp = xt;
         const double ny = fma(k.a01, syd, k.a00 * sy);
@@ -88,7 +89,22 @@ __global__ __launch_bounds__(kSmoothBlock) void k_smooth_local(int64_t T, int64_
         sy = ny;
         syd = nyd;
         if (y) y[t * n + lane] = sy;
+    };
+    // the loads do not depend on the recurrence: issue kSmoothUnroll frames of them ahead of the dependent
+    // FMA chain, otherwise every frame pays a full memory latency (the loop is not unrolled by itself)
+    int64_t t = t0;
+    for (; t + kSmoothUnroll <= t1; t += kSmoothUnroll) {
+        double xv[kSmoothUnroll];
+        bool ov[kSmoothUnroll];
+#pragma unroll
+        for (int u = 0; u < kSmoothUnroll; u++) {
+            xv[u] = x[(t + u) * n + lane];
+            ov[u] = hs.ok((t + u) * nv + g);
+        }
+#pragma unroll
+        for (int u = 0; u < kSmoothUnroll; u++) step(t + u, xv[u], ov[u]);
     }
+    for (; t < t1; t++) step(t, x[t * n + lane], hs.ok(t * nv + g));
     if (E) {
         E[(c * n + lane) * 2] = sy;
         E[(c * n + lane) * 2 + 1] = syd;
@@ -108,15 +124,27 @@ __global__ __launch_bounds__(kSmoothBlock) void k_smooth_carry(int64_t n, int64_
     if (lane >= n) return;
     const SmoothCoef k = ks.at(lane);
     double sy = start ? start[2 * lane] : 0.0, syd = start ? start[2 * lane + 1] : 0.0;
-    for (int64_t c = 0; c < nchunks; c++) {
+    auto step = [&](int64_t c, double ey, double eyd) {
         S[(c * n + lane) * 2] = sy;
         S[(c * n + lane) * 2 + 1] = syd;
-        const double ey = E ? E[(c * n + lane) * 2] : 0.0, eyd = E ? E[(c * n + lane) * 2 + 1] : 0.0;
         const double ny = fma(k.p01, syd, fma(k.p00, sy, ey));
         const double nyd = fma(k.p11, syd, fma(k.p10, sy, eyd));
         sy = ny;
         syd = nyd;
+    };
+    // few lanes, many chunks: keep kSmoothUnroll chunk-end states in flight ahead of the dependent chain
+    int64_t c = 0;
+    for (; c + kSmoothUnroll <= nchunks; c += kSmoothUnroll) {
+        double ey[kSmoothUnroll], eyd[kSmoothUnroll];
+#pragma unroll
+        for (int u = 0; u < kSmoothUnroll; u++) {
+            ey[u] = E ? E[((c + u) * n + lane) * 2] : 0.0;
+            eyd[u] = E ? E[((c + u) * n + lane) * 2 + 1] : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < kSmoothUnroll; u++) step(c + u, ey[u], eyd[u]);
     }
+    for (; c < nchunks; c++) step(c, E ? E[(c * n + lane) * 2] : 0.0, E ? E[(c * n + lane) * 2 + 1] : 0.0);
 }
 
 // seed state of a track: (x0, 0) per lane (:11-13)
@@ -139,7 +167,21 @@ __global__ __launch_bounds__(kSmoothBlock) void k_smooth_fix(int64_t T, int64_t 
     const SmoothCoef k = ks.at(lane);
     const int64_t t0 = tb + c * L, t1 = (t0 + L < T) ? t0 + L : T;
     double vy = S[(c * n + lane) * 2], vyd = S[(c * n + lane) * 2 + 1];
-    for (int64_t t = t0; t < t1; t++) {
+    int64_t t = t0;
+    for (; t + kSmoothUnroll <= t1; t += kSmoothUnroll) {
+        double yv[kSmoothUnroll];
+#pragma unroll
+        for (int u = 0; u < kSmoothUnroll; u++) yv[u] = y[(t + u) * n + lane];
+#pragma unroll
+        for (int u = 0; u < kSmoothUnroll; u++) {
+            const double ny = fma(k.a01, vyd, k.a00 * vy);
+            const double nyd = fma(k.a11, vyd, k.a10 * vy);
+            vy = ny;
+            vyd = nyd;
+            y[(t + u) * n + lane] = yv[u] + vy;
+        }
+    }
+    for (; t < t1; t++) {
         const double ny = fma(k.a01, vyd, k.a00 * vy);
         const double nyd = fma(k.a11, vyd, k.a10 * vy);
         vy = ny;
