@@ -235,66 +235,85 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
         }
         __syncthreads();
         const int n = misc[0];
-        for (int i = tid; i < n; i += kBlock) {
-            const int k = kidx[i];
-            const int q = k / pp, rr = k - q * pp, pm = rr / Pmax, ps = rr - pm * Pmax;
-            const int mc = rig.pairs[2 * q], sc = rig.pairs[2 * q + 1];
-            const Kp3<TIn> km = kpf[(size_t)(mc * Pmax + pm) * J + ci], ks = kpf[(size_t)(sc * Pmax + ps) * J + ci];
-            const RayRec a = make_ray(rig.M + 9 * mc, km.u, km.v), b = make_ray(rig.M + 9 * sc, ks.u, ks.v);
-            const double *pc = rig.pairc + 6 * q;
-            const PairSolve o = pair_solve_fast<true>(a, b, Vec3{pc[0], pc[1], pc[2]}, Vec3{pc[3], pc[4], pc[5]});
-            centre[3 * i] = 0.5 * o.sw.x;
-            centre[3 * i + 1] = 0.5 * o.sw.y;
-            centre[3 * i + 2] = 0.5 * o.sw.z;
-            cluster_of[i] = -1;
-        }
-        __syncthreads();
-        if (tid < 64) {
-            // triangulation.py:107-130 -- seeds in list order, the last candidate never seeds,
-            // distance to the SEED's centre, `dist > tol` skips (NaN absorbs)
-            int ncl = 0;
-            for (int mc = 0; mc < n - 1; mc++) {
-                if (cluster_of[mc] != -1) continue;
-                const double mx = centre[3 * mc], my = centre[3 * mc + 1], mz = centre[3 * mc + 2];
-                int cnt = 0;
-                for (int base = mc + 1; base < n; base += 64) {
-                    const int sc = base + lane;
-                    bool ab = false;
-                    if (sc < n && cluster_of[sc] == -1) {
-                        const double dx = mx - centre[3 * sc], dy = my - centre[3 * sc + 1], dz = mz - centre[3 * sc + 2];
-                        const double dist = sqrt(fma(dz, dz, fma(dy, dy, dx * dx)));
-                        if (!(dist > prm.ctol)) {
-                            cluster_of[sc] = ncl;
-                            ab = true;
-                        }
+        // The clustering below is one wave walking the kept list: every step is a dependent load, so it runs
+        // at memory LATENCY.  While it runs the ray chunk is idle: if the centres (24 B) and cluster ids (4 B) of
+        // the n kept candidates fit there they live in LDS (~8x lower latency than the L2-resident slab).
+        const size_t chunk_bytes = (size_t)R * (rstride + (size_t)sstride * sizeof(TIn));
+        const bool in_lds = (size_t)n * 28 + 16 <= chunk_bytes;
+        auto phase2 = [&](int32_t *cof, double *cen) {
+            for (int i = tid; i < n; i += kBlock) {
+                const int k = kidx[i];
+                const int q = k / pp, rr = k - q * pp, pm = rr / Pmax, ps = rr - pm * Pmax;
+                const int mc = rig.pairs[2 * q], sc = rig.pairs[2 * q + 1];
+                const Kp3<TIn> km = kpf[(size_t)(mc * Pmax + pm) * J + ci], ks = kpf[(size_t)(sc * Pmax + ps) * J + ci];
+                const RayRec a = make_ray(rig.M + 9 * mc, km.u, km.v), b = make_ray(rig.M + 9 * sc, ks.u, ks.v);
+                const double *pc = rig.pairc + 6 * q;
+                const PairSolve o = pair_solve_fast<true>(a, b, Vec3{pc[0], pc[1], pc[2]}, Vec3{pc[3], pc[4], pc[5]});
+                cen[3 * i] = 0.5 * o.sw.x;
+                cen[3 * i + 1] = 0.5 * o.sw.y;
+                cen[3 * i + 2] = 0.5 * o.sw.z;
+                cof[i] = -1;
+            }
+            __syncthreads();
+            if (tid < 64) {
+                // triangulation.py:107-130 -- seeds in list order, the last candidate never seeds,
+                // distance to the SEED's centre, `dist > tol` skips (NaN absorbs)
+                int ncl = 0;
+                for (int next = 0;;) {
+                    // first candidate >= next that is not absorbed yet (64 at a time)
+                    int mc = -1;
+                    for (int base = next & ~63; base < n - 1 && mc < 0; base += 64) {
+                        const int i = base + lane;
+                        const unsigned long long m = __ballot(i >= next && i < n - 1 && cof[i] == -1);
+                        if (m) mc = base + __ffsll((long long)m) - 1;
                     }
-                    cnt += __popcll(__ballot(ab));
+                    if (mc < 0) break;
+                    const double mx = cen[3 * mc], my = cen[3 * mc + 1], mz = cen[3 * mc + 2];
+                    int cnt = 0;
+                    for (int base = mc + 1; base < n; base += 64) {
+                        const int sc = base + lane;
+                        bool ab = false;
+                        if (sc < n && cof[sc] == -1) {
+                            const double dx = mx - cen[3 * sc], dy = my - cen[3 * sc + 1], dz = mz - cen[3 * sc + 2];
+                            const double dist = sqrt(fma(dz, dz, fma(dy, dy, dx * dx)));
+                            if (!(dist > prm.ctol)) {
+                                cof[sc] = ncl;
+                                ab = true;
+                            }
+                        }
+                        cnt += __popcll(__ballot(ab));
+                    }
+                    if (lane == 0) {
+                        cof[mc] = ncl;
+                        csize[ncl] = cnt + 1;
+                        cseed[ncl] = mc;
+                    }
+                    ncl++;
+                    next = mc + 1;
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                }
+                // members grouped by cluster, list order inside each cluster
+                int off = 0;
+                for (int c = 0; c < ncl; c++) {
+                    if (lane == 0) cstart[c] = off;
+                    for (int base = cseed[c]; base < n; base += 64) {
+                        const int i = base + lane;
+                        const bool in = i < n && cof[i] == c;
+                        const unsigned long long m = __ballot(in);
+                        if (in) members[off + __popcll(m & ((1ull << lane) - 1ull))] = i;
+                        off += __popcll(m);
+                    }
                 }
                 if (lane == 0) {
-                    cluster_of[mc] = ncl;
-                    csize[ncl] = cnt + 1;
-                    cseed[ncl] = mc;
-                }
-                ncl++;
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-            }
-            // members grouped by cluster, list order inside each cluster
-            int off = 0;
-            for (int c = 0; c < ncl; c++) {
-                if (lane == 0) cstart[c] = off;
-                for (int base = cseed[c]; base < n; base += 64) {
-                    const int i = base + lane;
-                    const bool in = i < n && cluster_of[i] == c;
-                    const unsigned long long m = __ballot(in);
-                    if (in) members[off + __popcll(m & ((1ull << lane) - 1ull))] = i;
-                    off += __popcll(m);
+                    cstart[ncl] = off;
+                    misc[1] = ncl;
                 }
             }
-            if (lane == 0) {
-                cstart[ncl] = off;
-                misc[1] = ncl;
-            }
-        }
+        };
+        if (in_lds)
+            phase2(reinterpret_cast<int32_t *>(smem + (((size_t)n * 24 + 15) & ~(size_t)15)), reinterpret_cast<double *>(smem));
+        else
+            phase2(cluster_of, centre);
         __syncthreads();
         const int ncl = misc[1];
 
