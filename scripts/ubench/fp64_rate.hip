@@ -19,6 +19,8 @@ __global__ __launch_bounds__(256) void k(double *out, int iters, double a, doubl
                 if (MODE == 2) x[i] = x[i] + b;                          // v_add_f64
                 if (MODE == 3) x[i] = __builtin_amdgcn_rcp(x[i]);        // v_rcp_f64
                 if (MODE == 4) { float f = (float)x[i]; x[i] = (double)(f + 1.0f); }  // cvt + f32 add + cvt
+                if (MODE == 5) x[i] = __builtin_amdgcn_rsq(x[i]);        // v_rsq_f64
+                if (MODE == 6) x[i] = fma(x[i], x[(i + 1) % ILP], x[(i + 2) % ILP]);  // three VGPR-pair operands
             }
         }
     }
@@ -64,5 +66,14 @@ int main() {
     run<8, 3>("rcp (trans)", 2, 1);
     run<8, 3>("rcp (trans)", 8, 1);
     run<8, 4>("cvt+addf32+cvt (3 instr)", 2, 3);
+    run<8, 5>("rsq (trans)", 2, 1);
+    run<8, 6>("fma 3 vgpr operands", 2, 1);
+    run<2, 0>("fma ILP2", 1, 1);
+    run<2, 0>("fma ILP2", 2, 1);
+    run<1, 0>("fma dep-chain", 3, 1);
+    run<2, 0>("fma ILP2", 3, 1);
+    run<3, 0>("fma ILP3", 1, 1);
+    run<1, 1>("mul dep-chain", 1, 1);
+    run<1, 2>("add dep-chain", 1, 1);
     return 0;
 }

@@ -1,2 +1,3 @@
 #!/bin/bash
-cd scripts/ubench && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o /tmp/fp64_rate fp64_rate.hip && /tmp/fp64_rate
+# GPU box: build and run the issue-rate microbenchmark.
+/opt/rocm/bin/hipcc -O3 --offload-arch=gfx950 -w -o /tmp/fp64_rate scripts/ubench/fp64_rate.hip && /tmp/fp64_rate
