@@ -21,6 +21,14 @@ __global__ __launch_bounds__(256) void k(double *out, int iters, double a, doubl
                 if (MODE == 4) { float f = (float)x[i]; x[i] = (double)(f + 1.0f); }  // cvt + f32 add + cvt
                 if (MODE == 5) x[i] = __builtin_amdgcn_rsq(x[i]);        // v_rsq_f64
                 if (MODE == 6) x[i] = fma(x[i], x[(i + 1) % ILP], x[(i + 2) % ILP]);  // three VGPR-pair operands
+                if (MODE == 7) {  // the solve's mix: 40 fma/mul/add per 2 transcendental ops (counted as 42 instructions)
+#pragma unroll
+                    for (int q = 0; q < 20; q++) x[i] = fma(x[i], b, a);
+                    x[i] = __builtin_amdgcn_rsq(x[i]);
+#pragma unroll
+                    for (int q = 0; q < 20; q++) x[i] = fma(x[i], b, a);
+                    x[i] = __builtin_amdgcn_rcp(x[i]);
+                }
             }
         }
     }
@@ -73,6 +81,9 @@ int main() {
     run<1, 0>("fma dep-chain", 3, 1);
     run<2, 0>("fma ILP2", 3, 1);
     run<3, 0>("fma ILP3", 1, 1);
+    run<6, 7>("mix 40 fma + rsq + rcp", 1, 42);
+    run<6, 7>("mix 40 fma + rsq + rcp", 2, 42);
+    run<6, 7>("mix 40 fma + rsq + rcp", 3, 42);
     run<1, 1>("mul dep-chain", 1, 1);
     run<1, 2>("add dep-chain", 1, 1);
     return 0;

@@ -189,6 +189,10 @@ __device__ __forceinline__ bool pairwise_item(const Rig &rig, const double *__re
     // VGPR-lane spills and the remainder is re-fetched with serialised scalar loads every item.
     // Issue every LDS read of M and d up front into registers (sched_barrier keeps them there): one wait
     // per item instead of ~25 scattered ones (+2.5 % measured); t is read where it is used, at the end.
+#ifdef SNOWTRI_ITEM_TIMERS
+    unsigned long long ts0 = __builtin_amdgcn_s_memtime();
+    asm volatile("" : "+s"(ts0), "+v"(Mlds) :: "memory");   // the constant reads are issued after this stamp
+#endif
     double Mp[9 * C], pc[3 * (C * (C - 1) / 2)];
 #pragma unroll
     for (int i = 0; i < 9 * C; i++) Mp[i] = Mlds[i];
@@ -212,6 +216,11 @@ __device__ __forceinline__ bool pairwise_item(const Rig &rig, const double *__re
         return false;
     }
 #endif
+#ifdef SNOWTRI_ITEM_TIMERS  // dev experiment: cycle stamps of the item's stages replace its outputs
+    asm volatile("" :: "v"(Mp[0]), "v"(Mp[9 * C - 1]), "v"(pc[0]), "v"(pc[3 * (C * (C - 1) / 2) - 1]) : "memory");  // constants arrived
+    unsigned long long tm0 = __builtin_amdgcn_s_memtime();
+    asm volatile("" : "+s"(tm0), "+v"(Mp[0]), "+v"(Mp[9]), "+v"(Mp[18]), "+v"(Mp[27]) :: "memory");  // rays start after it
+#endif
     Vec3 h[C];
     double a[C], alpha[C], beta[C];
 #pragma unroll
@@ -223,6 +232,11 @@ __device__ __forceinline__ bool pairwise_item(const Rig &rig, const double *__re
         h[c].z = fma(Mp[9 * c + 6], u, fma(Mp[9 * c + 7], v, Mp[9 * c + 8]));
         a[c] = dot3(h[c], h[c]);
     }
+#ifdef SNOWTRI_ITEM_TIMERS
+    asm volatile("" :: "v"(a[0]), "v"(a[C - 1]), "v"(h[C - 1].z) : "memory");   // the rays are done here
+    unsigned long long tm1 = __builtin_amdgcn_s_memtime();
+    asm volatile("" : "+s"(tm1), "+v"(h[0].x) :: "memory");                       // nothing below starts earlier
+#endif
     bool bad = false;
     int q = 0;
     // one reciprocal for all C(C,2) determinants (Montgomery's trick): 1/det_q from 1/prod(det) and prefix
@@ -289,6 +303,11 @@ __device__ __forceinline__ bool pairwise_item(const Rig &rig, const double *__re
             }
         }
     }
+#ifdef SNOWTRI_ITEM_TIMERS
+    asm volatile("" :: "v"(alpha[0]), "v"(alpha[C - 1]), "v"(beta[C - 1]), "v"(beta[0]) : "memory");
+    unsigned long long tm2 = __builtin_amdgcn_s_memtime();
+    asm volatile("" : "+s"(tm2), "+v"(alpha[0]) :: "memory");
+#endif
     double sx = alpha[0] * h[0].x, sy = alpha[0] * h[0].y, sz = alpha[0] * h[0].z, sb = beta[0];
     sx = fma(beta[0], tp[0], sx);
     sy = fma(beta[0], tp[1], sy);
@@ -308,6 +327,15 @@ __device__ __forceinline__ bool pairwise_item(const Rig &rig, const double *__re
     oy = sy * r;
     oz = sz * r;
     os = sb * (0.5 / (double)(C * (C - 1) / 2));  // :148
+#ifdef SNOWTRI_ITEM_TIMERS
+    asm volatile("" :: "v"(ox), "v"(oy), "v"(oz), "v"(os) : "memory");
+    const unsigned long long tm3 = __builtin_amdgcn_s_memtime();
+    ox = (double)(tm0 - ts0) + 1e-9 * ox;   // wait for the LDS constants
+    oy = (double)(tm1 - tm0) + 1e-9 * oy;   // rays, including the wait for the item's keypoints
+    oz = (double)(tm3 - tm1) + 1e-9 * oz;   // pair solves + fusion tail
+    os = (double)(ts0 & 0x7fffffffull);      // start stamp
+    bad = false;
+#endif
     return bad;
 }
 
@@ -517,6 +545,9 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_single(int
                                                          uint32_t *__restrict__ out_flags, char *scratch,
                                                          size_t scratch_per_block) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+#ifdef SNOWTRI_ITEM_TIMERS
+    const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
+#endif
     constexpr int NP = C * (C - 1) / 2;
     const int kn = prm.kn, ci = prm.center;
     double *stash = reinterpret_cast<double *>(smem);                        // [T][kn] fused joint scores
@@ -672,6 +703,11 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_single(int
                         fflag[w] |= kSlow;
                     } else {
                         out_count[f] = 1;
+#ifdef SNOWTRI_ITEM_TIMERS
+                        out_count[f] = (int32_t)(t_entry & 0x7fffffffull);
+                        if (out_ps) out_ps[f * Pout] = (TOut)(double)(__builtin_amdgcn_s_memtime() & 0x7fffffffull);
+                        if (false)
+#endif
                         if (out_ps) {
                             out_ps[f * Pout] = (TOut)avg;
                             for (int slot = 1; slot < Pout; slot++) out_ps[f * Pout + slot] = (TOut)0;
