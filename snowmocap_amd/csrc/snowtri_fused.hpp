@@ -686,8 +686,22 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_single(int
                 const bool live = w < nf;
                 const int64_t f = f0 + (live ? w : 0);
                 double sum = 0.0;
-                if (live)
-                    for (int b = sub; b < kn; b += G) sum += stash[w * kn + b];
+                if (live) {
+                    // four independent partial sums: the LDS reads of one round trip are issued together
+                    // (a single running sum pays the LDS latency once per element)
+                    const double *row = stash + w * kn;
+                    double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+                    int b = sub;
+                    for (; b + 3 * G < kn; b += 4 * G) {
+                        const double v0 = row[b], v1 = row[b + G], v2 = row[b + 2 * G], v3 = row[b + 3 * G];
+                        sum += v0;
+                        s1 += v1;
+                        s2 += v2;
+                        s3 += v3;
+                    }
+                    for (; b < kn; b += G) sum += row[b];
+                    sum = (sum + s1) + (s2 + s3);
+                }
                 int not_one = 0;
                 if (METHOD == 0 && n_persons && live && sub < C) not_one = n_persons[f * C + sub] != 1;
 #pragma unroll
