@@ -12,6 +12,7 @@ from oracle import oracle as orc
 J = 133
 SIZES = ((3, 2000, 16), (5, 256, 32)) if "--small" in sys.argv else ((3, 10000, 16), (5, 2000, 32))
 MODES = ("2", "1") if "--spill" in sys.argv else ("2",)
+METHOD = _lib.DLT if "--dlt" in sys.argv else _lib.PAIRWISE
 for cfg, F, pout in SIZES:
     wl = synth.config_workload(cfg, F)
     K, R, t = wl["rig"]
@@ -21,7 +22,7 @@ for cfg, F, pout in SIZES:
     npers = torch.from_numpy(wl["n_persons"]).to(dev)
     for mode in MODES:
         os.environ["SNOWTRI_GENERAL_MODE"] = mode
-        bt = BatchTriangulator(K, R, t, wl["params"], pout_max=pout, out_dtype=np.float32)
+        bt = BatchTriangulator(K, R, t, wl["params"], pout_max=pout, out_dtype=np.float32, method=METHOD)
         out = bt.run_torch(kp, npers)
         torch.cuda.synchronize()
         bt.ctx.set_timing(True)
@@ -33,7 +34,7 @@ for cfg, F, pout in SIZES:
         joints = int(cnt.clip(max=pout).sum()) * J
         kc = C * (C - 1) // 2 * P * P
         m = float(np.median(ms))
-        print(json.dumps({"cfg": cfg, "frames": F, "kernel": "recompute" if mode == "2" else "spill", "ms": m,
+        print(json.dumps({"cfg": cfg, "frames": F, "kernel": ("recompute" if mode == "2" else "spill") + (" dlt" if METHOD == _lib.DLT else ""), "ms": m,
                           "frames_per_s": F / (m * 1e-3), "output_joints_per_s": joints / (m * 1e-3),
                           "pair_solves_per_s": F * kc * J / (m * 1e-3), "mean_persons": float(cnt.mean())}))
         bt.close()
