@@ -7,17 +7,19 @@
 //
 //   phase 1  per candidate: mean of the J joint scores -> keep flag        (triangulation.py:70-81)
 //            rays of a joint chunk are built once into LDS; one lane per candidate walks the chunk
-//   phase 2  kept list (ordered), centre joints, greedy clustering (one wave) (triangulation.py:107-130)
+//   phase 2  kept list (ordered), centre joints, greedy clustering by one wave, its state in the idle
+//            LDS chunk when it fits (every step is a dependent load)            (triangulation.py:107-130)
 //   phase 3  per surviving cluster and joint: sum s, sum s*(Wm+Ws) over the members, recomputing
-//            their solves in a second sweep over the joint chunks (rays back in LDS); thread = (member
-//            group, joint of the chunk), group partials added through LDS               (triangulation.py:136-152)
-// Only O(Kc) bookkeeping (57 B per candidate slot) lives in a per-workgroup scratch slab.
+//            their solves in a second sweep over the joint chunks (rays back in LDS); thread = (joint of
+//            the chunk, member group), group partials added with shuffles        (triangulation.py:136-152)
+// Only O(Kc) bookkeeping (57 B per candidate slot) and the fused joint scores of up to 64 persons
+// live in a per-workgroup scratch slab.
 #pragma once
 #include "snowtri_fused.hpp"
 
 namespace snowtri {
 
-constexpr int kRecomputeMaxKn = 256;          // joints handled per lane in phase 3: lane + 64 p, p < 4
+constexpr int kRecomputeMaxKn = 256;          // keypoint_num bound: one thread per joint in the DLT phase, chunk joints x groups <= 256
 constexpr int kRayChunkBytes = 32 * 1024;     // LDS budget for one chunk of rays
 
 constexpr int kRecomputeSlotTile = 64;        // fused persons whose joint scores are parked per sweep (phase 3)
@@ -41,11 +43,11 @@ __host__ __device__ inline size_t recompute_lds_bytes(int R, int J, int kn, int 
     const int jc = recompute_chunk_joints(R, J, score_bytes);
     const size_t chunk = (size_t)R * (recompute_ray_stride(jc) + (size_t)recompute_score_stride(jc) * score_bytes);
     (void)kn;
-    return ((chunk + 15) & ~(size_t)15) + (size_t)kBlock * 32 + 256;   // + one (S, X, Y, Z) partial per thread
+    return ((chunk + 15) & ~(size_t)15) + (size_t)kBlock * 32 + 256;   // + 8 KB spare (block reductions, flags)
 }
 
 // Dynamic LDS = recompute_lds_bytes(R, J, kn, sizeof(TIn)); scratch = gridDim.x slabs of
-// recompute_scratch_bytes(Kc, R).  R = C * Pmax ray rows.  Requires keypoint_num <= kRecomputeMaxKn.
+// recompute_scratch_bytes(Kc, R, kn).  R = C * Pmax ray rows.  Requires keypoint_num <= kRecomputeMaxKn.
 #ifndef SNOWTRI_RECOMPUTE_WAVES
 #define SNOWTRI_RECOMPUTE_WAVES 3
 #endif
