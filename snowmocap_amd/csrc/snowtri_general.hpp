@@ -20,7 +20,7 @@
 namespace snowtri {
 
 constexpr int kRecomputeMaxKn = 256;          // keypoint_num bound: one thread per joint in the DLT phase, chunk joints x groups <= 256
-constexpr int kRayChunkBytes = 32 * 1024;     // LDS budget for one chunk of rays
+constexpr int kRayChunkBytes = 48 * 1024;     // LDS budget for one chunk of rays (3 workgroups per CU: 3 x 48.3 KB <= 160 KB)
 
 constexpr int kRecomputeSlotTile = 64;        // fused persons whose joint scores are parked per sweep (phase 3)
 
@@ -43,7 +43,7 @@ __host__ __device__ inline size_t recompute_lds_bytes(int R, int J, int kn, int 
     const int jc = recompute_chunk_joints(R, J, score_bytes);
     const size_t chunk = (size_t)R * (recompute_ray_stride(jc) + (size_t)recompute_score_stride(jc) * score_bytes);
     (void)kn;
-    return ((chunk + 15) & ~(size_t)15) + (size_t)kBlock * 32 + 256;   // + 8 KB spare (block reductions, flags)
+    return ((chunk + 15) & ~(size_t)15) + 256;   // + block-reduction slots and flags
 }
 
 // Dynamic LDS = recompute_lds_bytes(R, J, kn, sizeof(TIn)); scratch = gridDim.x slabs of
@@ -82,9 +82,8 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
     const int sstride = recompute_score_stride(Jc);             // elements between the score rows
     char *rays = smem;                                          // [R] rows of Jc RayRec (+16 B pad)
     TIn *rsc = reinterpret_cast<TIn *>(smem + (size_t)R * rstride);                      // [R][sstride]
-    double *partial = reinterpret_cast<double *>(
-        smem + ((((size_t)R * (rstride + (size_t)sstride * sizeof(TIn))) + 15) & ~(size_t)15));  // [kBlock][4]
-    double *red = partial + (size_t)kBlock * 4;                              // [4] + misc
+    double *red = reinterpret_cast<double *>(
+        smem + ((((size_t)R * (rstride + (size_t)sstride * sizeof(TIn))) + 15) & ~(size_t)15));  // [4] + misc
     int32_t *misc = reinterpret_cast<int32_t *>(red + kBlock / 64);
 
     // per-workgroup bookkeeping slab (global, reused frame after frame)
