@@ -11,6 +11,7 @@ from oracle import oracle as orc
 
 J = 133
 SIZES = ((3, 2000, 16), (5, 256, 32)) if "--small" in sys.argv else ((3, 10000, 16), (5, 2000, 32))
+REPEAT = {5: 6} if "--full" in sys.argv else {}   # cfg5: 2 000 generated frames tiled to 12 000 = its per-GPU share
 MODES = ("2", "1") if "--spill" in sys.argv else ("2",)
 METHOD = _lib.DLT if "--dlt" in sys.argv else _lib.PAIRWISE
 for cfg, F, pout in SIZES:
@@ -20,6 +21,10 @@ for cfg, F, pout in SIZES:
     dev = torch.device("cuda", 0)
     kp = torch.from_numpy(wl["kpts"]).to(dev)
     npers = torch.from_numpy(wl["n_persons"]).to(dev)
+    if cfg in REPEAT:
+        kp = kp.repeat(REPEAT[cfg], 1, 1, 1, 1).contiguous()
+        npers = npers.repeat(REPEAT[cfg], 1).contiguous()
+        F = F * REPEAT[cfg]
     for mode in MODES:
         os.environ["SNOWTRI_GENERAL_MODE"] = mode
         bt = BatchTriangulator(K, R, t, wl["params"], pout_max=pout, out_dtype=np.float32, method=METHOD)
