@@ -13,6 +13,12 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # a fresh checkout has no built artefacts (they are git-ignored): build them once, exactly as
+    # __graft_entry__.build() does (hipcc cross-compiles gfx950 without a GPU; ~1 min)
+    so = os.path.join(ROOT, "snowmocap_amd", "libsnowtri.so")
+    if not os.path.exists(so) and not os.environ.get("SNOWTRI_LIB"):
+        import subprocess
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "snowmocap_amd", "csrc"), "-s"])
 
 
 def load_scenarios(name):
