@@ -157,7 +157,8 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
                     double idist = rsq_nr1(d2);
                     idist = (d2 == 0.0) ? __builtin_inf() : idist;
                     const bool kp_ = !below_kthr(sm, prm) && !below_kthr(ss, prm) && !(d2 > prm.dthr2);  // :73-74
-                    acc += gated_sum(sm, ss, kp_) * (idist * 0.0005);                                // :72
+                    // the gate ASSIGNS 0 (:73-74): select after the product, 0 * inf (exact intersection) would be NaN
+                    acc += kp_ ? sum_score(sm, ss) * (idist * 0.0005) : 0.0;                         // :72
                 };
                 int jj = 0;
                 // four joints at a time share ONE reciprocal (Montgomery): v_rcp_f64 issues at quarter rate.
@@ -454,7 +455,7 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
                             const TIn sm = rsc[rm * sstride + jc], ss = rsc[rs * sstride + jc];
                             const PairSolve o = pair_solve_fast<true>(a, b, d, tsum);
                             const bool kp_ = !below_kthr(sm, prm) && !below_kthr(ss, prm) && !(o.d2 > prm.dthr2);
-                            const double sq = gated_sum(sm, ss, kp_) * (0.5 * o.score_base);
+                            const double sq = kp_ ? sum_score(sm, ss) * (0.5 * o.score_base) : 0.0;    // gate assigns 0
                             aS += sq;                                                              // :141
                             aX = fma(sq, o.sw.x, aX);                                              // :144-147
                             aY = fma(sq, o.sw.y, aY);

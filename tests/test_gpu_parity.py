@@ -5,6 +5,8 @@ CPU oracle.  Tolerances (north_star: 3D joints within 1e-4 m of the reference):
                 conditioning term of conftest.assert_scores_close), identical counts / gating;
   fp32 outputs  <= 2e-6 m (fp32 rounding of ~5 m coordinates), far inside the 1e-4 m budget.
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -461,6 +463,46 @@ def test_random_small_rigs_dlt_against_oracle(api):
         np.testing.assert_allclose(out["pscore"], wps, rtol=1e-12, err_msg=msg)
         checked += int(np.minimum(wcnt, pout).sum())
     assert checked > 20
+
+
+def test_exact_intersection_with_gated_confidence_multi_person(api):
+    """dist == 0 gives an inf score in the reference, and a confidence below the threshold ASSIGNS 0 to that pair
+    (triangulation.py:72-74) -- the other pairs' inf survives; a kernel that multiplies a zeroed confidence by inf
+    makes NaN instead.  Exactly representable geometry (K = R = I) so that rays really intersect."""
+    from oracle import oracle as orc
+    C, P, J = 3, 2, 4
+    K = np.tile(np.eye(3), (C, 1, 1)); R = np.tile(np.eye(3), (C, 1, 1))
+    t = np.array([[0.0, 0, 0], [2.0, 0, 0], [0, 2.0, 0]])
+    X = np.array([[[1.0, 0.0, 4.0], [0.5, 0.5, 2.0], [1.0, 1.0, 4.0], [0.0, 1.0, 2.0]],
+                  [[3.0, 2.0, 8.0], [2.5, 2.5, 4.0], [3.0, 3.0, 8.0], [2.0, 3.0, 4.0]]])
+    kp = np.zeros((1, C, P, J, 3))
+    for c in range(C):
+        for p in range(P):
+            kp[0, c, p, :, 0] = (X[p, :, 0] - t[c, 0]) / X[p, :, 2]
+            kp[0, c, p, :, 1] = (X[p, :, 1] - t[c, 1]) / X[p, :, 2]
+            kp[0, c, p, :, 2] = 5.0
+    kp[0, 0, 0, 1, 2] = 1.0
+    kp[0, 1, 1, 2, 2] = 1.0
+    npers = np.full((1, C), P, np.int32)
+    prm = dict(keypoint_score_threshold=3.0, average_score_threshold=0.0, distance_threshold=0.05,
+               condense_distance_tol=0.5, condense_person_num_tol=0, condense_score_tol=0.0, center_point_index=0,
+               keypoint_num=J)
+    ref = orc.triangulate_condense_batch(K, R, t, kp, npers, orc.make_params(**prm), 8)
+    assert np.isinf(ref["kscore"]).any()
+    for mode in ("2", "1"):
+        os.environ["SNOWTRI_GENERAL_MODE"] = mode
+        try:
+            bt = api.BatchTriangulator(K, R, t, prm, pout_max=8, out_dtype=np.float64)
+            out = bt.run_host(kp, npers)
+            bt.close()
+        finally:
+            os.environ.pop("SNOWTRI_GENERAL_MODE", None)
+        np.testing.assert_array_equal(out["count"], ref["count"])
+        m = int(ref["count"][0])
+        g, o = out["xyzs"][0, :m, :, 3], ref["kscore"][0, :m]
+        np.testing.assert_array_equal(np.isinf(g), np.isinf(o))
+        np.testing.assert_array_equal(np.isnan(g), np.isnan(o))
+        np.testing.assert_array_equal(np.isnan(out["xyzs"][0, :m, :, :3]), np.isnan(ref["xyz"][0, :m]))
 
 
 def test_fastmath_helpers_accuracy_contract(api):
