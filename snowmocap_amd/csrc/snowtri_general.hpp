@@ -181,7 +181,6 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
                         e[u] = fma(a[u].z, d.z, fma(a[u].y, d.y, a[u].x * d.x));
                         g[u] = fma(b[u].z, d.z, fma(b[u].y, d.y, b[u].x * d.x));
                         det[u] = fma(a[u].a, b[u].a, -(bq[u] * bq[u]));
-                        sing |= det[u] == 0.0;
                     }
                     const double p01 = det[0] * det[1], p012 = p01 * det[2], p0123 = p012 * det[3];
                     if (fabs(p0123) > 1e-250 && fabs(p0123) < 1e250) {
@@ -192,9 +191,12 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
                         run *= det[2];
                         inv[1] = run * det[0];
                         inv[0] = run * det[1];
-                    } else {
+                    } else {   // includes every exactly singular pair (product 0): flagged here, off the common path
 #pragma unroll
-                        for (int u = 0; u < 4; u++) inv[u] = rcp_nr2(det[u]);
+                        for (int u = 0; u < 4; u++) {
+                            inv[u] = rcp_nr2(det[u]);
+                            sing |= det[u] == 0.0;
+                        }
                     }
 #pragma unroll
                     for (int u = 0; u < 4; u++) finish(a[u], b[u], bq[u], e[u], g[u], inv[u], sm[u], ss[u]);
