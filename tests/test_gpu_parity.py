@@ -505,6 +505,73 @@ def test_exact_intersection_with_gated_confidence_multi_person(api):
         np.testing.assert_array_equal(np.isnan(out["xyzs"][0, :m, :, :3]), np.isnan(ref["xyz"][0, :m]))
 
 
+@pytest.mark.parametrize("mode", ["auto", "spill"])
+def test_random_special_values_against_oracle(api, mode, monkeypatch):
+    """Adversarial inputs through the fused entry: exactly intersecting rays (dist == 0 -> inf score -> NaN fused
+    joint), NaN pixels, NaN / negative / zero confidences, negative thresholds.  The NaN / inf / zero patterns and
+    the person counts must equal the oracle's; finite values must agree."""
+    from oracle import oracle as orc
+    if mode == "spill":
+        monkeypatch.setenv("SNOWTRI_GENERAL_MODE", "1")
+    rng = np.random.default_rng(99 if mode == "auto" else 98)
+    compared = 0
+    for trial in range(40):
+        C = int(rng.integers(2, 5))
+        P = int(rng.integers(1, 3))
+        J = int(rng.choice([3, 6, 10]))
+        F = int(rng.integers(1, 4))
+        K = np.tile(np.eye(3), (C, 1, 1)); R = np.tile(np.eye(3), (C, 1, 1))
+        t = np.zeros((C, 3))
+        t[:, 0] = 2.0 * np.arange(C)
+        t[1::2, 1] = 2.0
+        # joints on a dyadic grid in front of the cameras: pixels and rays are exactly representable
+        X = np.stack([rng.integers(-4, 5, (F, P, J)) / 2.0, rng.integers(-4, 5, (F, P, J)) / 2.0,
+                      rng.choice([2.0, 4.0, 8.0], (F, P, J))], axis=-1)
+        X[:, 1:] += np.array([0.0, 0.0, 0.0])
+        kp = np.zeros((F, C, P, J, 3))
+        for c in range(C):
+            kp[:, c, :, :, 0] = (X[..., 0] - t[c, 0]) / X[..., 2]
+            kp[:, c, :, :, 1] = (X[..., 1] - t[c, 1]) / X[..., 2]
+        kp[..., 2] = rng.choice([5.0, 5.0, 5.0, 1.0, 0.0, -2.0], size=kp.shape[:-1])
+        if trial % 3 == 0:
+            kp[..., :2] += rng.normal(0, 1e-3, size=kp[..., :2].shape)          # some trials: near-exact instead
+        for _ in range(int(rng.integers(0, 3))):
+            kp[rng.integers(0, F), rng.integers(0, C), rng.integers(0, P), rng.integers(0, J), rng.integers(0, 3)] = np.nan
+        npers = np.full((F, C), P, np.int32)
+        if rng.uniform() < 0.3:
+            npers[rng.integers(0, F), rng.integers(0, C)] = rng.integers(0, P + 1)
+        prm = dict(keypoint_score_threshold=float(rng.choice([3.0, 0.5, -1.0])), average_score_threshold=float(rng.choice([0.0, -5.0])),
+                   distance_threshold=float(rng.choice([0.05, 1.0])), condense_distance_tol=float(rng.choice([0.3, 10.0])),
+                   condense_person_num_tol=int(rng.choice([0, 2])), condense_score_tol=float(rng.choice([0.0, -1.0, 0.5])),
+                   center_point_index=int(rng.integers(0, J)), keypoint_num=int(rng.integers(1, J + 1)))
+        ref = orc.triangulate_condense_batch(K, R, t, kp, npers, orc.make_params(**prm), 32)
+        bt = api.BatchTriangulator(K, R, t, prm, pout_max=32, out_dtype=np.float64)
+        out = bt.run_host(kp, npers)
+        bt.close()
+        msg = f"trial {trial}: C={C} P={P} J={J} F={F} {prm} n={npers.tolist()}"
+        for f in range(F):
+            if ref["status"][f] != 0:                     # singular pair: the reference raises, outputs are unspecified
+                assert out["flags"][f] & 1, msg
+                continue
+            assert out["count"][f] == ref["count"][f], msg
+            m = int(ref["count"][f])
+            g, o = out["xyzs"][f, :m, :, 3], ref["kscore"][f, :m]
+            # classes: 0 (gated / unseen), moderate finite, and "blown up" = huge, inf or NaN.  Whether a distance
+            # is EXACTLY 0 (inf score) or 1e-17 (score 1e14) depends on the rounding of the solve's formulation,
+            # so inside the blown-up class the two sides need not agree (conftest.assert_scores_close, same rule).
+            def classes(s):
+                return np.where(~np.isfinite(s) | (np.abs(s) > 1e9), 2, np.where(s == 0.0, 0, 1))
+            np.testing.assert_array_equal(classes(g), classes(o), err_msg=msg)
+            fin = classes(o) == 1
+            np.testing.assert_allclose(g[fin], o[fin], rtol=1e-6, atol=1e-12, err_msg=msg)
+            gx, ox = out["xyzs"][f, :m, :, :3], ref["xyz"][f, :m]
+            zero = classes(o) == 0
+            assert not gx[zero].any() and not ox[zero].any(), msg
+            np.testing.assert_allclose(gx[fin], ox[fin], rtol=0, atol=1e-7, err_msg=msg)
+            compared += m
+    assert compared > 30
+
+
 def test_fastmath_helpers_accuracy_contract(api):
     """rcp_nr2 ~ 1 ulp, rcp_nr1 / rsq_nr1 <= 1e-14 relative over +-300 decades (normal range): the
     bounds DESIGN.md §2 relies on for the throughput kernels."""
