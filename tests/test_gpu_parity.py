@@ -428,6 +428,49 @@ def test_random_small_rigs_against_oracle(api, mode, monkeypatch):
     assert checked > 150
 
 
+def test_random_single_person_fast_path_and_fallback(api):
+    """One detection per camera, 3..8 cameras: the speculative fast kernel, with thresholds and person lists that
+    make some frames fail its checks (tight condense_distance_tol, a camera that sees nobody, mean-score filter)
+    so they are re-done by the in-launch fallback -- all against the oracle, several tiles per launch."""
+    from snowmocap_amd import synth, _lib
+    from oracle import oracle as orc
+    rng = np.random.default_rng(555)
+    fast_frames = slow_frames = 0
+    for trial in range(30):
+        C = int(rng.integers(3, 9))
+        J = int(rng.choice([5, 20, 133]))
+        F = int(rng.choice([3, 40, 150]))
+        K, R, t = synth.ring_rig(C, radius=float(rng.uniform(3, 6)))
+        X = synth.make_people(rng, F, 1, J=J)
+        kp, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=float(rng.choice([0.3, 1.0, 4.0])), score_range=(2.0, 8.0),
+                                         dtype=np.float64 if trial % 2 else np.float32)
+        npers = npers.copy()
+        for _ in range(int(rng.integers(0, 3))):
+            npers[rng.integers(0, F), rng.integers(0, C)] = 0
+        kn = int(rng.integers(1, J + 1))
+        prm = dict(keypoint_score_threshold=float(rng.choice([0.0, 3.0, 5.0])), average_score_threshold=0.0,
+                   distance_threshold=float(rng.choice([0.02, 0.05, 1.0])), condense_distance_tol=float(rng.choice([0.01, 0.05, 10.0])),
+                   condense_person_num_tol=int(rng.choice([0, 2, C * (C - 1) // 2])), condense_score_tol=float(rng.choice([0.0, 0.0, 0.8])),
+                   center_point_index=int(rng.integers(0, J)), keypoint_num=kn)
+        pout = int(rng.choice([1, 3]))
+        ref = orc.triangulate_condense_batch(K, R, t, kp, npers, orc.make_params(**prm), 32)
+        bt = api.BatchTriangulator(K, R, t, prm, pout_max=pout, out_dtype=np.float64)
+        out = bt.run_host(kp, npers)
+        bt.close()
+        msg = f"trial {trial}: C={C} J={J} kn={kn} F={F} {prm} pout={pout}"
+        np.testing.assert_array_equal(out["count"], ref["count"], err_msg=msg)
+        fastf = (out["flags"] & _lib.FLAG_FASTPATH) != 0
+        fast_frames += int(fastf.sum()); slow_frames += int((~fastf).sum())
+        for f in range(F):
+            m = min(int(ref["count"][f]), pout)
+            assert not out["xyzs"][f, m:].any(), msg
+            if m:
+                assert_scores_close(out["xyzs"][f, :m, :, 3], ref["kscore"][f, :m], what=msg)
+                assert_xyz_close(out["xyzs"][f, :m, :, :3], ref["xyz"][f, :m], XYZ_FUSED, score_ref=ref["kscore"][f, :m], what=msg)
+                assert_scores_close(out["pscore"][f, :m], ref["pscore"][f, :m], nterms=kn, what=msg)
+    assert fast_frames > 300 and slow_frames > 300, (fast_frames, slow_frames)
+
+
 def test_random_small_rigs_dlt_against_oracle(api):
     """The same kind of sweep for method = DLT with several detections per camera (association + per-cluster
     DLT) against oracle/dlt.py: identical counts, joints within 1e-8 m."""
