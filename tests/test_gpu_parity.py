@@ -651,6 +651,30 @@ def test_smooth_track_against_reference_and_oracle(api):
     assert np.array_equal(one, x[:1])
 
 
+@pytest.mark.parametrize("T", [2, 3, 9, 10, 17, 256, 257, 258, 265, 513, 777])
+def test_smoothing_lengths_around_chunk_and_unroll_boundaries(api, T):
+    """Track lengths that end inside / exactly at a 256-frame chunk and inside the 8-frame load batches, for the
+    plain filter (N1) and the per-bone filter with invalid points (N2), vs the sequential oracles."""
+    from oracle import oracle as orc, blender as ob
+    from snowmocap_amd import blender as bl
+    rng = np.random.default_rng(T)
+    x = np.cumsum(rng.normal(0, 0.01, size=(T, 1, 7, 3)), axis=0) + rng.uniform(-2, 2, size=(1, 1, 7, 3))
+    want = orc.second_order_track(x, 2.5, 0.75, 0.5, 1 / 30)
+    got = api.smooth_track(x, f=2.5, z=0.75, r=0.5, delta_time=1 / 30)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-10)
+    pts = np.cumsum(rng.normal(0, 0.01, (T, 2, 24, 4)), axis=0)
+    val = (rng.uniform(size=(T, 2, 24)) > 0.1).astype(np.uint8)
+    val[0, 0, 3] = 0
+    val[T // 2:, 1, 5] = 0                      # invalid to the end of the track
+    pts[val == 0] = np.nan
+    fzr = np.stack([rng.uniform(1.0, 4.0, 24), rng.uniform(0.4, 1.2, 24), rng.uniform(-1, 2, 24)], axis=1)
+    prof = {n: fzr[i].tolist() for i, n in enumerate(bl.CONTROL_POINT_NAMES)}
+    want = ob.smooth_track(pts, val, fzr, 1 / 30)
+    got = bl.blender_smooth_track(pts, val, prof, 1 / 30)
+    np.testing.assert_allclose(got[1:], want[1:], rtol=1e-9, atol=1e-10)     # some random (f, z, r) are unstable: relative
+    np.testing.assert_array_equal(np.isnan(got[0]), np.isnan(want[0]))
+
+
 # ------------------------------------------------------------------ row N2: Blender control points
 def test_blender_points_against_reference(api):
     """snowtri_blender_points vs the reference's Human_Triangulation_Blender (fixtures G6 and G8): values to
