@@ -1,0 +1,51 @@
+#!/usr/bin/env python3
+"""Dev aid (GPU box): soak run of the randomised parity sweeps of tests/test_gpu_parity.py with many seeds.
+usage: python scripts/soak_fuzz.py <rounds>   -- every round re-seeds each sweep; the first failures are printed."""
+import os, sys, time, traceback
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import snowmocap_amd as api
+import test_gpu_parity as T
+
+real_rng = np.random.default_rng
+
+
+class Env:                       # minimal stand-in for pytest's monkeypatch
+    def setenv(self, k, v): os.environ[k] = v
+    def undo(self): os.environ.pop("SNOWTRI_GENERAL_MODE", None)
+
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+sweeps = [("small_rigs auto", lambda e: T.test_random_small_rigs_against_oracle(api, "auto", e)),
+          ("small_rigs spill", lambda e: T.test_random_small_rigs_against_oracle(api, "spill", e)),
+          ("special auto", lambda e: T.test_random_special_values_against_oracle(api, "auto", e)),
+          ("special spill", lambda e: T.test_random_special_values_against_oracle(api, "spill", e)),
+          ("single person", lambda e: T.test_random_single_person_fast_path_and_fallback(api)),
+          ("dlt multi", lambda e: T.test_random_small_rigs_dlt_against_oracle(api))]
+fails = 0
+t0 = time.time()
+for r in range(rounds):
+    np.random.default_rng = lambda seed=None, r=r: real_rng(None if seed is None else int(seed) * 100003 + r + 1)
+    for name, fn in sweeps:
+        env = Env()
+        try:
+            fn(env)
+        except AssertionError as ex:
+            msg = str(ex)
+            if msg.strip() == "" or msg.strip().startswith("("):     # bare coverage asserts of the fixed-seed tests
+                pass                                    # coverage counters of the fixed-seed test, not a parity failure
+            else:
+                fails += 1
+                print(f"FAIL round {r} sweep {name}: {msg[:900]}")
+                if fails >= 12:
+                    print("stopping after 12 failures"); sys.exit(1)
+        except Exception:
+            fails += 1
+            print(f"ERROR round {r} sweep {name}:"); traceback.print_exc()
+            if fails >= 5: sys.exit(1)
+        finally:
+            env.undo()
+    if r % 5 == 4: print(f"round {r + 1}/{rounds} done, {fails} failures, {time.time() - t0:.0f} s", flush=True)
+np.random.default_rng = real_rng
+print("soak finished:", rounds, "rounds,", fails, "failures")
