@@ -579,6 +579,18 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_single(int
         const int nf = (int)((F - f0) < T ? (F - f0) : T);
         const int nitems = nf * J;
         for (int i = tid; i < nf; i += kBlock) fflag[i] = 0;
+        // centre joints for the single-cluster check of the epilogue: fetched now, used after the item loop
+        Kp3<TIn> ck[4];
+        bool have_centres = false;
+        if (METHOD == 0 && tid < nf * (NP - 1)) {
+            const int w = tid / (NP - 1), qq = 1 + (tid - w * (NP - 1));
+            const Kp3<TIn> *p = kp3 + ((f0 + w) * C) * (int64_t)J + ci;
+            ck[0] = p[(size_t)rig.pairs[0] * J];
+            ck[1] = p[(size_t)rig.pairs[1] * J];
+            ck[2] = p[(size_t)rig.pairs[2 * qq] * J];
+            ck[3] = p[(size_t)rig.pairs[2 * qq + 1] * J];
+            have_centres = true;
+        }
         __syncthreads();
 
         // ---- main loop: one lane per (frame, joint).  A ring of three register buffers keeps the
@@ -659,17 +671,18 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_single(int
         for (int i = tid; METHOD == 0 && i < nf * (NP - 1); i += kBlock) {
             const int w = i / (NP - 1), qq = 1 + (i - w * (NP - 1));
             const Kp3<TIn> *p = kp3 + ((f0 + w) * C) * (int64_t)J + ci;
-            auto centre_of = [&](int qk) {
+            const bool pre = i == tid && have_centres;   // first pass: keypoints fetched before the item loop
+            auto centre_of = [&](int qk, int slot) {
                 const int mc = rig.pairs[2 * qk], sc = rig.pairs[2 * qk + 1];
-                const Kp3<TIn> km = p[(size_t)mc * J], ks = p[(size_t)sc * J];
+                const Kp3<TIn> km = pre ? ck[2 * slot] : p[(size_t)mc * J], ks = pre ? ck[2 * slot + 1] : p[(size_t)sc * J];
                 const double *pcq = rig.pairc + 6 * qk;
                 const PairSolve o = pair_solve_fast<true>(make_ray(rig.M + 9 * mc, km.u, km.v),
                                                           make_ray(rig.M + 9 * sc, ks.u, ks.v),
                                                           Vec3{pcq[0], pcq[1], pcq[2]}, Vec3{pcq[3], pcq[4], pcq[5]});
                 return o.sw;  // = 2 W
             };
-            const Vec3 w0 = centre_of(0);
-            const Vec3 wq = centre_of(qq);
+            const Vec3 w0 = centre_of(0, 0);
+            const Vec3 wq = centre_of(qq, 1);
             const double dx = 0.5 * (w0.x - wq.x), dy = 0.5 * (w0.y - wq.y), dz = 0.5 * (w0.z - wq.z);
             const double cd = sqrt(fma(dz, dz, fma(dy, dy, dx * dx)));  // :124
             if (cd > prm.ctol) atomicOr(&fflag[w], kSlow);                // :125
