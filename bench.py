@@ -277,12 +277,12 @@ def main():
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_fused_single<4,%d,float,float>" % (1 if args.method == "dlt" else 0),
                          "kernel_ms_mean": kernel_ms, "kernel_ms_min": kernel_ms_min,
                          "algorithmic_bytes_per_launch": bpf * F, "bytes_per_joint": bpf / (Pout * J)},
-            # the roof that actually binds this kernel: fp64 VALU issue.  426 VALU wave-instructions
+            # the roof that actually binds this kernel: fp64 VALU issue.  422 VALU wave-instructions
             # per 64 joints (rocprofv3 SQ_INSTS_VALU, profiles/), 4 issue cycles each, 1024 SIMDs at the 2.4 GHz peak clock.
             "fp64_valu_issue": None if args.method != "pairwise" else {
-                "valu_insts_per_64_joints": 426, "simds": 1024, "peak_clock_GHz": 2.4,
-                "frac_this_launch": (F * Pout * J / 64.0 * 426 * 4) / (kernel_ms * 1e-3) / (1024 * 2.4e9),
-                "frac_large_batch": None if large is None else (large["joints_per_s"] / 64.0 * 426 * 4) / (1024 * 2.4e9)},
+                "valu_insts_per_64_joints": 422, "simds": 1024, "peak_clock_GHz": 2.4,
+                "frac_this_launch": (F * Pout * J / 64.0 * 422 * 4) / (kernel_ms * 1e-3) / (1024 * 2.4e9),
+                "frac_large_batch": None if large is None else (large["joints_per_s"] / 64.0 * 422 * 4) / (1024 * 2.4e9)},
             "cpu_baseline": cpu,
             "with_track_allgather": with_gather,
             "large_batch": large,
