@@ -1,3 +1,3 @@
 #!/bin/bash
 # usage: bash scripts/gpu_py.sh <script.py> [args]   (GPU box; output tail)
-timeout 900 python "$@" 2>&1 | tail -60
+timeout 1700 python "$@" 2>&1 | tail -60
