@@ -428,6 +428,56 @@ def test_random_small_rigs_against_oracle(api, mode, monkeypatch):
     assert checked > 150
 
 
+def test_random_small_rigs_per_frame_api(api):
+    """The frame-by-frame drop-in API (add_human_2D_points -> Human_Triangulation -> Human_Triangulation_Condense;
+    its own kernels: candidates are materialised) on randomised small rigs vs the oracle's per-frame functions."""
+    from snowmocap_amd import synth
+    from oracle import oracle as orc
+    rng = np.random.default_rng(31337)
+    ncand = nfused = 0
+    for trial in range(45):
+        C = int(rng.integers(2, 6))
+        P = int(rng.integers(1, 4))
+        J = int(rng.choice([3, 12, 33]))
+        K, R, t = synth.ring_rig(C, radius=float(rng.uniform(3, 6)))
+        X = synth.make_people(rng, 1, P, J=J)
+        kp, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=float(rng.choice([0.3, 1.0, 3.0])), score_range=(2.0, 8.0),
+                                         permute_persons=True, dtype=np.float64 if trial % 2 else np.float32)
+        npers = npers.copy()
+        if rng.uniform() < 0.4:
+            npers[0, rng.integers(0, C)] = rng.integers(0, P + 1)
+        prm = dict(keypoint_score_threshold=float(rng.choice([0.0, 3.0, 5.0])), average_score_threshold=float(rng.choice([0.0, 0.3, 1.5])),
+                   distance_threshold=float(rng.choice([0.02, 0.05, 1.0])), condense_distance_tol=float(rng.choice([0.05, 0.3, 10.0])),
+                   condense_person_num_tol=int(rng.choice([0, 1, 2])), condense_score_tol=float(rng.choice([0.0, 0.3, 2.0])),
+                   center_point_index=int(rng.integers(0, J)), keypoint_num=int(rng.integers(1, J + 1)))
+        sc = dict(K=K, R=R, t=t, kpts=kp, n_persons=npers)
+        cg = _group(api, sc)
+        _feed(cg, sc, 0)
+        tri = api.Human_Triangulation(cg, keypoint_score_threshold=prm["keypoint_score_threshold"],
+                                      average_score_threshold=prm["average_score_threshold"], distance_threshold=prm["distance_threshold"])
+        op = orc.make_params(**prm)
+        want = orc.human_triangulation_frame(K, R, t, kp[0], npers[0], op)
+        msg = f"trial {trial}: C={C} P={P} J={J} {prm} n={npers.tolist()}"
+        n = len(want["hrnet_triangulate_points"])
+        assert len(tri["hrnet_triangulate_points"]) == n, msg
+        if n:
+            assert_scores_close(np.stack(tri["hrnet_triangulate_keypoint_scores"]), np.stack(want["hrnet_triangulate_keypoint_scores"]), what=msg)
+            assert_xyz_close(np.stack(tri["hrnet_triangulate_points"]), np.stack(want["hrnet_triangulate_points"]), XYZ_CAND, what=msg)
+            assert_scores_close(tri["hrnet_triangulate_person_scores"], want["hrnet_triangulate_person_scores"], nterms=J, what=msg)
+        con_kw = {k: prm[k] for k in ("condense_distance_tol", "condense_person_num_tol", "condense_score_tol", "center_point_index", "keypoint_num")}
+        con = api.Human_Triangulation_Condense(tri, **con_kw)
+        wcon = orc.condense_frame(want, op)
+        m = len(wcon["hrnet_triangulate_points"])
+        assert len(con["hrnet_triangulate_points"]) == m, msg
+        if m:
+            ks = np.stack(wcon["hrnet_triangulate_keypoint_scores"])
+            assert_scores_close(np.stack(con["hrnet_triangulate_keypoint_scores"]), ks, what=msg)
+            assert_xyz_close(np.stack(con["hrnet_triangulate_points"]), np.stack(wcon["hrnet_triangulate_points"]), XYZ_FUSED, score_ref=ks, what=msg)
+        ncand += n; nfused += m
+        cg.clear_2D_points()
+    assert ncand > 100 and nfused > 15, (ncand, nfused)
+
+
 def test_random_single_person_fast_path_and_fallback(api):
     """One detection per camera, 3..8 cameras: the speculative fast kernel, with thresholds and person lists that
     make some frames fail its checks (tight condense_distance_tol, a camera that sees nobody, mean-score filter)
