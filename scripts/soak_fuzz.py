@@ -22,7 +22,8 @@ sweeps = [("small_rigs auto", lambda e: T.test_random_small_rigs_against_oracle(
           ("special auto", lambda e: T.test_random_special_values_against_oracle(api, "auto", e)),
           ("special spill", lambda e: T.test_random_special_values_against_oracle(api, "spill", e)),
           ("single person", lambda e: T.test_random_single_person_fast_path_and_fallback(api)),
-          ("dlt multi", lambda e: T.test_random_small_rigs_dlt_against_oracle(api))]
+          ("dlt multi", lambda e: T.test_random_small_rigs_dlt_against_oracle(api)),
+          ("per-frame api", lambda e: T.test_random_small_rigs_per_frame_api(api))]
 fails = 0
 t0 = time.time()
 for r in range(rounds):
