@@ -150,6 +150,28 @@ def test_blender_smooth_host_protocol():
     assert set(out) == {"armature", "score"} and len(out["armature"]) == P
 
 
+def test_track_pipeline_result_formatting_is_host_only():
+    """TrackPipeline.to_blender_result turns a control-point track into the list the reference dumps
+    (blender.py:180-187); pure host code, also fed NumPy arrays.  A NaN pelvis quaternion (valid = 0) is the
+    reference's SciPy failure and raises."""
+    from snowmocap_amd.pipeline import TrackPipeline
+    from snowmocap_amd.blender import CONTROL_POINT_NAMES
+    rng = np.random.default_rng(0)
+    pts = rng.normal(size=(3, 2, 24, 4))
+    val = np.ones((3, 2, 24), np.uint8)
+    val[1, 0, 13] = 0
+    out = TrackPipeline.to_blender_result(pts, val)
+    assert len(out) == 3 and len(out[0]["armature"]) == 2 and list(out[0]["armature"][0]) == list(CONTROL_POINT_NAMES)
+    assert len(out[0]["armature"][0]["root_rotation"]) == 4 and len(out[0]["armature"][0]["hand_r_pole"]) == 3
+    assert out[1]["score"][0]["hand_r_pole"] == 0 and out[1]["score"][1]["hand_r_pole"] == 1
+    np.testing.assert_array_equal(out[2]["armature"][1]["head_ik"], pts[2, 1, 22, :3])
+    sub = {"root_position": [], "head_ik": []}
+    assert list(TrackPipeline.to_blender_result(pts, val, sub)[0]["armature"][0]) == ["root_position", "head_ik"]
+    val[2, 1, 1] = 0
+    with pytest.raises(np.linalg.LinAlgError):
+        TrackPipeline.to_blender_result(pts, val)
+
+
 def _build_c_consumer(tmp_path):
     import subprocess
     exe = str(tmp_path / "c_abi_smoke")
