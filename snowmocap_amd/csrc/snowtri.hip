@@ -97,6 +97,8 @@ struct snowtri_ctx {
     int num_cus = 256;
     std::vector<double> hM, ht, hK;
     double *dLens = nullptr;  // [C][kLensStride], set by snowtri_ctx_set_distortion
+    void *dBlenderTab = nullptr;          // 24 SmoothCoef of the last (fzr, dt) given to snowtri_blender_smooth
+    std::vector<double> blender_key;      // that (fzr[72], dt)
     std::vector<int32_t> hpairs;
     double *dM = nullptr, *dt = nullptr, *dpairc = nullptr, *dP = nullptr;
     int32_t *dpairs = nullptr;
@@ -238,6 +240,7 @@ int snowtri_ctx_destroy(snowtri_ctx *ctx) {
     if (ctx->dpairc) (void)hipFree(ctx->dpairc);
     if (ctx->dP) (void)hipFree(ctx->dP);
     if (ctx->dLens) (void)hipFree(ctx->dLens);
+    if (ctx->dBlenderTab) (void)hipFree(ctx->dBlenderTab);
     if (ctx->d_counters) (void)hipFree(ctx->d_counters);
     ctx->in.release();
     ctx->out.release();
@@ -912,11 +915,18 @@ int snowtri_blender_smooth(snowtri_ctx *ctx, int64_t T, int64_t n_persons, const
     int rc = ctx->aux.ensure(off_valid + vbytes);
     if (rc) return rc;
     char *aux = (char *)ctx->aux.p;
-    SmoothCoef tab[kBlenderPoints];
-    for (int i = 0; i < kBlenderPoints; i++) tab[i] = smooth_coef(fzr[3 * i], fzr[3 * i + 1], fzr[3 * i + 2], dt);
-    static_assert(sizeof(tab) <= 4096, "coefficient table does not fit its slot");
-    HIP_TRY(hipMemcpyAsync(aux, tab, sizeof(tab), hipMemcpyHostToDevice, st));
-    HIP_TRY(hipStreamSynchronize(st));  // tab is a stack array
+    // per-bone coefficient table: rebuilt and uploaded only when (fzr, dt) change -- the common caller passes the
+    // same smooth profile every time, and an upload has to drain the stream first
+    std::vector<double> key(fzr, fzr + 3 * kBlenderPoints);
+    key.push_back(dt);
+    if (!ctx->dBlenderTab) HIP_TRY(hipMalloc(&ctx->dBlenderTab, sizeof(SmoothCoef) * kBlenderPoints));
+    if (key != ctx->blender_key) {
+        SmoothCoef tab[kBlenderPoints];
+        for (int i = 0; i < kBlenderPoints; i++) tab[i] = smooth_coef(fzr[3 * i], fzr[3 * i + 1], fzr[3 * i + 2], dt);
+        HIP_TRY(hipStreamSynchronize(st));   // kernels of an earlier call may still read the old table
+        HIP_TRY(hipMemcpy(ctx->dBlenderTab, tab, sizeof(tab), hipMemcpyHostToDevice));
+        ctx->blender_key = key;
+    }
     const double *dx = points;
     const uint8_t *dv = valid;
     double *dy = out;
@@ -939,7 +949,7 @@ int snowtri_blender_smooth(snowtri_ctx *ctx, int64_t T, int64_t n_persons, const
     hipLaunchKernelGGL(k_hold_carry, g1, dim3(256), 0, st, n, nchunks, 4, dx, dv, (const double *)H, (const uint8_t *)Hf,
                        start);
     HIP_TRY(hipGetLastError());
-    const TableCoef k{(const SmoothCoef *)aux, 4, kBlenderPoints};
+    const TableCoef k{(const SmoothCoef *)ctx->dBlenderTab, 4, kBlenderPoints};
     const HoldInput hs{dv, (const double *)start, 4};
     // frame 0 is returned as given, NaNs included (blender.py:176); the filters are seeded with the held row
     rc = smooth_whole_dev(ctx, st, T, n, dx, dy, (const double *)start, k, hs);
