@@ -17,7 +17,7 @@ for tag in "abc":
     for path in glob.glob("$OUT/%s/**/*counter_collection.csv" % tag, recursive=True):
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(path)):
-            if "fused_single" in r["Kernel_Name"]:
+            if "k_fused_" in r["Kernel_Name"]:
                 g = r.get("Grid_Size") or r.get("Grid_Size_X") or "?"
                 acc[g][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for g, c in acc.items():

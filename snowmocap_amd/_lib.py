@@ -194,7 +194,13 @@ class Context:
 
     def set_distortion(self, D):
         """Row N4: per-camera lens coefficients D[C, 5] = (k1, k2, p1, p2, k3) (Camera.D)."""
-        Dc = np.ascontiguousarray(np.asarray(D, dtype=np.float64).reshape(self.C, -1)[:, :5])
+        D2 = np.asarray(D, dtype=np.float64).reshape(self.C, -1)
+        if D2.shape[1] > 5:
+            if np.any(D2[:, 5:] != 0.0):
+                raise ValueError("only the 5-coefficient lens model (k1, k2, p1, p2, k3) is supported")
+            D2 = D2[:, :5]
+        Dc = np.zeros((self.C, 5), dtype=np.float64)          # OpenCV's shorter forms (4 coefficients) mean k3 = 0
+        Dc[:, :D2.shape[1]] = D2
         check(lib().snowtri_ctx_set_distortion(self.handle, ptr(Dc)), "snowtri_ctx_set_distortion")
 
     def undistort_keypoints(self, kpts):
@@ -231,12 +237,28 @@ class Context:
         return int(lib().snowtri_last_slow_frames(self.handle))
 
 
-_scratch_ctx = None
+_scratch_ctx = {}
 
 
-def scratch_context():
-    """Rig-less context for entry points that need only device scratch (condense, skew rays)."""
-    global _scratch_ctx
-    if _scratch_ctx is None:
-        _scratch_ctx = Context()
-    return _scratch_ctx
+def current_device():
+    """The HIP device index the calling thread's work should land on: torch's current device when torch is loaded
+    and sees a GPU (one process per GPU sets it with torch.cuda.set_device(local_rank)), else SNOWTRI_DEVICE or 0."""
+    import sys
+    t = sys.modules.get("torch")
+    if t is not None:
+        try:
+            if t.cuda.is_available():
+                return int(t.cuda.current_device())
+        except Exception:
+            pass
+    return int(os.environ.get("SNOWTRI_DEVICE", "0"))
+
+
+def scratch_context(device=None):
+    """Rig-less context for entry points that need only device scratch (condense, skew rays, smoothing).
+    One per device: a context's scratch and kernels live on the GPU it was created for."""
+    dev = current_device() if device is None else int(device)
+    ctx = _scratch_ctx.get(dev)
+    if ctx is None:
+        ctx = _scratch_ctx[dev] = Context(device=dev)
+    return ctx

@@ -69,7 +69,12 @@ class BatchTriangulator:
         assert kpts.is_cuda and kpts.is_contiguous()
         F, C, Pmax, J, three = kpts.shape
         assert C == self.C and three == 3
-        in_code = _lib.F32 if kpts.dtype == torch.float32 else _lib.F64
+        if kpts.dtype == torch.float32:
+            in_code = _lib.F32
+        elif kpts.dtype == torch.float64:
+            in_code = _lib.F64
+        else:
+            raise TypeError(f"snowtri supports float32/float64 keypoints, not {kpts.dtype}")
         if out is None:
             out = self.alloc_outputs(F, kpts.device)
         if n_persons is not None:

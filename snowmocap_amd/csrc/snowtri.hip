@@ -17,6 +17,7 @@
 #include <vector>
 
 #include "snowtri_fused.hpp"
+#include "snowtri_lean.hpp"
 #include "snowtri_general.hpp"
 #include "snowtri_smooth.hpp"
 #include "snowtri_blender.hpp"
@@ -40,6 +41,27 @@ thread_local std::string g_last_error;
             return SNOWTRI_ERR_HIP;                                                              \
         }                                                                                        \
     } while (0)
+
+// Every entry point runs on its context's device and leaves the caller's current device as it found it
+// (one process may drive several GPUs, or torch may have selected another device for the thread).
+struct DeviceGuard {
+    int prev = -1;
+    hipError_t err = hipSuccess;
+    explicit DeviceGuard(int device) {
+        err = hipGetDevice(&prev);
+        if (err == hipSuccess && prev != device) err = hipSetDevice(device);
+        else if (err != hipSuccess) prev = -1;
+    }
+    ~DeviceGuard() {
+        int cur = -1;
+        if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+    }
+    DeviceGuard(const DeviceGuard &) = delete;
+    DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+#define ENTER_DEVICE(device)              \
+    DeviceGuard _device_guard(device);    \
+    HIP_TRY(_device_guard.err)
 
 struct Scratch {
     void *p = nullptr;
@@ -113,6 +135,7 @@ struct snowtri_ctx {
     int64_t ev_count = 0;             // fused calls recorded since the last snowtri_timing_collect
     int64_t last_slow_frames = 0;
     int general_mode = 0;  // dev/test knob: 0 auto, 1 force the spill kernel, 2 force the recompute kernel
+    int lean_mode = 1;     // dev/test knob: 0 keeps float32-output batches on k_fused_single (A/B against k_fused_lean)
     Rig rig() const { return Rig{dM, dt, dpairs, dpairc, dP, C, npairs}; }
 };
 
@@ -151,6 +174,7 @@ int snowtri_ctx_create(int32_t C, const double *K, const double *R, const double
     ctx->device = device;
     ctx->C = C;
     if (const char *gm = getenv("SNOWTRI_GENERAL_MODE")) ctx->general_mode = atoi(gm);
+    if (const char *lm = getenv("SNOWTRI_LEAN_MODE")) ctx->lean_mode = atoi(lm);
     ctx->hM.resize((size_t)C * 9);
     ctx->ht.assign(t, t + (size_t)C * 3);
     ctx->hK.assign(K, K + (size_t)C * 9);
@@ -190,7 +214,8 @@ int snowtri_ctx_create(int32_t C, const double *K, const double *R, const double
             return fail(SNOWTRI_ERR_HIP);                     \
         }                                                     \
     } while (0)
-    CTX_TRY(hipSetDevice(device));
+    DeviceGuard _device_guard(device);
+    CTX_TRY(_device_guard.err);
     hipDeviceProp_t prop;
     CTX_TRY(hipGetDeviceProperties(&prop, device));
     ctx->num_cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
@@ -232,7 +257,7 @@ int snowtri_ctx_create(int32_t C, const double *K, const double *R, const double
 
 int snowtri_ctx_destroy(snowtri_ctx *ctx) {
     if (!ctx) return SNOWTRI_OK;
-    (void)hipSetDevice(ctx->device);
+    DeviceGuard _device_guard(ctx->device);
     (void)hipDeviceSynchronize();
     if (ctx->dM) (void)hipFree(ctx->dM);
     if (ctx->dt) (void)hipFree(ctx->dt);
@@ -265,7 +290,7 @@ int snowtri_ctx_ray_matrices(const snowtri_ctx *ctx, double *M_out) {
 
 int snowtri_ctx_synchronize(snowtri_ctx *ctx) {
     if (!ctx) return SNOWTRI_ERR_BAD_ARG;
-    HIP_TRY(hipSetDevice(ctx->device));
+    ENTER_DEVICE(ctx->device);
     HIP_TRY(hipDeviceSynchronize());
     return SNOWTRI_OK;
 }
@@ -276,7 +301,7 @@ int snowtri_set_timing(snowtri_ctx *ctx, int enabled) {
     ctx->ev_valid = false;
     ctx->ev_count = 0;
     if (ctx->timing && ctx->ev_ring.empty()) {
-        HIP_TRY(hipSetDevice(ctx->device));
+        ENTER_DEVICE(ctx->device);
         ctx->ev_ring.resize(2 * kTimingRing, nullptr);
         for (auto &e : ctx->ev_ring) HIP_TRY(hipEventCreate(&e));
     }
@@ -320,7 +345,7 @@ int64_t snowtri_num_candidate_slots(int32_t C, int32_t Pmax) {
 int snowtri_fastmath_probe(snowtri_ctx *ctx, int64_t n, const double *x, double *rcp_nr2_out,
                            double *rcp_nr1_out, double *rsq_nr1_out) {
     if (!ctx || n < 1 || !x || !rcp_nr2_out || !rcp_nr1_out || !rsq_nr1_out) return SNOWTRI_ERR_BAD_ARG;
-    HIP_TRY(hipSetDevice(ctx->device));
+    ENTER_DEVICE(ctx->device);
     const size_t b = sizeof(double) * n;
     int rc = ctx->in.ensure(b);
     if (rc) return rc;
@@ -341,7 +366,7 @@ int snowtri_fastmath_probe(snowtri_ctx *ctx, int64_t n, const double *x, double 
 int snowtri_rays_from_pixels(snowtri_ctx *ctx, int32_t cam, int64_t n, const double *uv, double *rays) {
     if (!ctx || cam < 0 || cam >= ctx->C || n < 0 || (n > 0 && (!uv || !rays))) return SNOWTRI_ERR_BAD_ARG;
     if (n == 0) return SNOWTRI_OK;
-    HIP_TRY(hipSetDevice(ctx->device));
+    ENTER_DEVICE(ctx->device);
     int rc = ctx->in.ensure(sizeof(double) * 2 * n);
     if (rc) return rc;
     rc = ctx->out.ensure(sizeof(double) * 3 * n);
@@ -361,7 +386,7 @@ int snowtri_skew_ray_batch(snowtri_ctx *ctx, int64_t n, const double *hm, const 
     if (!ctx || n < 0 || (n > 0 && (!hm || !hs || !tm || !ts || !dist || !W))) return SNOWTRI_ERR_BAD_ARG;
     if (n_singular) *n_singular = 0;
     if (n == 0) return SNOWTRI_OK;
-    HIP_TRY(hipSetDevice(ctx->device));
+    ENTER_DEVICE(ctx->device);
     const size_t v = sizeof(double) * 3 * n;
     int rc = ctx->in.ensure(4 * v);
     if (rc) return rc;
@@ -467,7 +492,7 @@ int snowtri_triangulate(snowtri_ctx *ctx, int64_t F, int32_t Pmax, int32_t J, co
     Params prm;
     int rc = validate_params(params, J, &prm, false);
     if (rc) return rc;
-    HIP_TRY(hipSetDevice(ctx->device));
+    ENTER_DEVICE(ctx->device);
     hipStream_t st = (hipStream_t)stream;
     const size_t in_bytes = (size_t)F * ctx->C * Pmax * J * 3 * dtype_size(in_dtype);
     const size_t np_bytes = n_persons ? sizeof(int32_t) * F * ctx->C : 0;
@@ -527,7 +552,7 @@ int snowtri_condense(snowtri_ctx *ctx, int64_t F, int32_t N, int32_t J, const do
     Params prm;
     int rc = validate_params(params, J, &prm, true);
     if (rc) return rc;
-    HIP_TRY(hipSetDevice(ctx->device));
+    ENTER_DEVICE(ctx->device);
     hipStream_t st = (hipStream_t)stream;
     const int kn = prm.kn;
     const size_t nx = (size_t)F * N * J;
@@ -710,7 +735,7 @@ int snowtri_smooth_shard_local(snowtri_ctx *ctx, int64_t T, int64_t n, const dou
     if (!smooth_args_ok(ctx, T, n, f, dt, memspace)) return SNOWTRI_ERR_BAD_ARG;
     if (T == 0 || n == 0) return SNOWTRI_OK;
     if (!x || !y) return SNOWTRI_ERR_BAD_ARG;
-    HIP_TRY(hipSetDevice(ctx->device));
+    ENTER_DEVICE(ctx->device);
     hipStream_t st = (hipStream_t)stream;
     const UniformCoef k{smooth_coef(f, z, r, dt)};
     const size_t bytes = sizeof(double) * (size_t)T * n;
@@ -741,7 +766,7 @@ int snowtri_smooth_shard_fix(snowtri_ctx *ctx, int64_t T, int64_t n, int first, 
     if (!smooth_args_ok(ctx, T, n, f, dt, memspace)) return SNOWTRI_ERR_BAD_ARG;
     if (T == 0 || n == 0) return SNOWTRI_OK;
     if (!start_state || !y) return SNOWTRI_ERR_BAD_ARG;
-    HIP_TRY(hipSetDevice(ctx->device));
+    ENTER_DEVICE(ctx->device);
     hipStream_t st = (hipStream_t)stream;
     const UniformCoef k{smooth_coef(f, z, r, dt)};
     const size_t bytes = sizeof(double) * (size_t)T * n;
@@ -771,7 +796,7 @@ int snowtri_smooth_track(snowtri_ctx *ctx, int64_t T, int64_t n, const double *x
     if (!smooth_args_ok(ctx, T, n, f, dt, memspace)) return SNOWTRI_ERR_BAD_ARG;
     if (T == 0 || n == 0) return SNOWTRI_OK;
     if (!x || !y) return SNOWTRI_ERR_BAD_ARG;
-    HIP_TRY(hipSetDevice(ctx->device));
+    ENTER_DEVICE(ctx->device);
     hipStream_t st = (hipStream_t)stream;
     const UniformCoef k{smooth_coef(f, z, r, dt)};
     const size_t bytes = sizeof(double) * (size_t)T * n;
@@ -811,7 +836,7 @@ int snowtri_ctx_set_distortion(snowtri_ctx *ctx, const double *D) {
             L[7 + i] = D[5 * c + i];
         }
     }
-    HIP_TRY(hipSetDevice(ctx->device));
+    ENTER_DEVICE(ctx->device);
     if (!ctx->dLens) HIP_TRY(hipMalloc(&ctx->dLens, sizeof(double) * lens.size()));
     HIP_TRY(hipMemcpy(ctx->dLens, lens.data(), sizeof(double) * lens.size(), hipMemcpyHostToDevice));
     return SNOWTRI_OK;
@@ -824,7 +849,7 @@ int snowtri_undistort_keypoints(snowtri_ctx *ctx, int64_t F, int32_t Pmax, int32
         return SNOWTRI_ERR_BAD_ARG;
     if (F == 0) return SNOWTRI_OK;
     if (!kpts_in || !kpts_out) return SNOWTRI_ERR_BAD_ARG;
-    HIP_TRY(hipSetDevice(ctx->device));
+    ENTER_DEVICE(ctx->device);
     hipStream_t st = (hipStream_t)stream;
     const int64_t per_cam = (int64_t)Pmax * J, n_obs = F * ctx->C * per_cam;
     if (per_cam > INT32_MAX) return SNOWTRI_ERR_BAD_ARG;
@@ -861,7 +886,7 @@ int snowtri_blender_points(snowtri_ctx *ctx, int64_t n, int32_t keypoint_num, co
     if (keypoint_num < kBlenderMinJoints) return SNOWTRI_ERR_BAD_INDEX;  // person[129] would raise IndexError
     if (n == 0) return SNOWTRI_OK;
     if (!xyzs || !out_points || !out_valid) return SNOWTRI_ERR_BAD_ARG;
-    HIP_TRY(hipSetDevice(ctx->device));
+    ENTER_DEVICE(ctx->device);
     hipStream_t st = (hipStream_t)stream;
     const size_t esz = xyz_dtype == SNOWTRI_F32 ? 4 : 8;
     const size_t in_bytes = esz * 4 * (size_t)keypoint_num * n, pt_bytes = sizeof(double) * 4 * kBlenderPoints * n;
@@ -902,7 +927,7 @@ int snowtri_blender_smooth(snowtri_ctx *ctx, int64_t T, int64_t n_persons, const
         if (!(fzr[3 * i] > 0.0)) return SNOWTRI_ERR_BAD_ARG;
     if (T == 0 || n_persons == 0) return SNOWTRI_OK;
     if (!points || !valid || !out) return SNOWTRI_ERR_BAD_ARG;
-    HIP_TRY(hipSetDevice(ctx->device));
+    ENTER_DEVICE(ctx->device);
     hipStream_t st = (hipStream_t)stream;
     const int64_t n = n_persons * kBlenderPoints * 4, nv = n_persons * kBlenderPoints;
     const int64_t nchunks = (T - 1 + kSmoothChunk - 1) / kSmoothChunk;  // the filter's chunks: frames 1..T-1
@@ -1019,13 +1044,56 @@ int launch_fused_single(snowtri_ctx *ctx, hipStream_t st, int64_t F, int J, cons
     return SNOWTRI_OK;
 }
 
+// Production shape of the fast path (snowtri_lean.hpp): float32 outputs, keypoint_num == J == 133, one slot.
+// Every wave of the launch gets the same number of frames (+-1) in tiles of <= kLeanTw frames; a launch covers at
+// most kLeanMaxTilesPerWave tiles per wave (the slow-frame bit words live in LDS), longer batches are cut into
+// several launches on the same stream.
+constexpr int kLeanJ = 133;
+constexpr int kLeanMaxTilesPerWave = 128;
+
+template <int C, typename TIn>
+int launch_fused_lean(snowtri_ctx *ctx, hipStream_t st, int64_t F, const TIn *d_kpts, const int32_t *d_np,
+                      const Params &prm, float *d_xyzs, float *d_ps, int32_t *d_cnt, uint32_t *d_fl) {
+    constexpr int NP = C * (C - 1) / 2;
+    int wg_per_cu = SNOWTRI_FAST_WAVES;  // resident workgroups per CU = waves per SIMD the kernel is compiled for
+    if (const char *e = getenv("SNOWTRI_LEAN_WG_PER_CU")) wg_per_cu = std::max(1, atoi(e));
+    const int64_t grid_full = (int64_t)ctx->num_cus * wg_per_cu;
+    const size_t per_block = general_scratch_bytes(NP, kLeanJ);
+    auto kern = k_fused_lean<C, TIn, kLeanJ>;
+    const int64_t seg_max = grid_full * kLeanWaves * (int64_t)kLeanTw * kLeanMaxTilesPerWave;
+    for (int64_t s0 = 0; s0 < F; s0 += seg_max) {
+        const int64_t Fs = std::min<int64_t>(seg_max, F - s0);
+        // small batches are spread over every resident wave (down to one frame per wave)
+        const int grid = (int)std::min<int64_t>(grid_full, (Fs + kLeanWaves - 1) / kLeanWaves);
+        const int64_t W = (int64_t)grid * kLeanWaves;
+        const int64_t tiles_per_wave = (Fs + W * kLeanTw - 1) / (W * kLeanTw);
+        const int64_t ntiles = std::min<int64_t>(Fs, W * tiles_per_wave);
+        const int base = (int)(Fs / ntiles);
+        const int64_t rem = Fs % ntiles;
+        const int slow_words = (int)((tiles_per_wave * kLeanWaves * (1 << kLeanSlowShift) + 31) / 32);
+        const size_t lds = lean_lds_bytes(C, kLeanJ, slow_words);
+        int rc = ctx->work.ensure(per_block * (size_t)grid);
+        if (rc) return rc;
+        if (lds > 48 * 1024)
+            HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, st, Fs, ntiles, base, rem, slow_words, ctx->rig(),
+                           d_kpts + s0 * (int64_t)(C * kLeanJ * 3), d_np ? d_np + s0 * C : nullptr, prm,
+                           d_xyzs + s0 * (int64_t)(kLeanJ * 4), d_ps ? d_ps + s0 : nullptr, d_cnt + s0,
+                           d_fl ? d_fl + s0 : nullptr, (char *)ctx->work.p, per_block);
+        HIP_TRY(hipGetLastError());
+    }
+    return SNOWTRI_OK;
+}
+
 template <typename TIn, typename TOut>
 int launch_frame_general(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax, int J, const TIn *d_kpts,
                          const int32_t *d_np, const Params &prm, int Pout, TOut *d_xyzs, TOut *d_ps,
                          int32_t *d_cnt, uint32_t *d_fl) {
     const int64_t Kc = snowtri_num_candidate_slots(ctx->C, Pmax);
     if (Kc > kCondenseMaxN) return SNOWTRI_ERR_BAD_ARG;
-    const size_t per_block = general_scratch_bytes(Kc, J);
+    // a single camera has no pair (Kc == 0): the kernel then writes count = 0 and zero-filled slots, like the
+    // reference's empty candidate list; keep the slab size non-zero for the division below
+    const size_t per_block = std::max<size_t>(256, general_scratch_bytes(Kc, J));
     int64_t grid = std::min<int64_t>(F, (int64_t)ctx->num_cus * 2);
     grid = std::max<int64_t>(1, std::min<int64_t>(grid, (int64_t)(kMaxScratchBytes / per_block)));
     int rc = ctx->work.ensure(per_block * (size_t)grid);
@@ -1096,13 +1164,33 @@ int fused_dispatch(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax, int J,
     case CC:                                                                                                  \
         rc = launch_fused_single<CC, 1, TIn, TOut>(ctx, st, F, J, d_kpts, d_np, prm, Pout, d_xyzs, d_ps, d_cnt, d_fl); \
         break;
+#ifndef SNOWTRI_DEV_MIN
             SNOWTRI_CASE(2)
             SNOWTRI_CASE(3)
-            SNOWTRI_CASE(4)
             SNOWTRI_CASE(5)
             SNOWTRI_CASE(6)
             SNOWTRI_CASE(7)
             SNOWTRI_CASE(8)
+#endif
+            SNOWTRI_CASE(4)
+#undef SNOWTRI_CASE
+            default: rc = SNOWTRI_ERR_BAD_ARG;
+        }
+    } else if (fast && std::is_same<TOut, float>::value && J == kLeanJ && prm.kn == kLeanJ && Pout == 1 &&
+               ctx->lean_mode != 0) {
+        switch (C) {
+#define SNOWTRI_CASE(CC)                                                                                          \
+    case CC:                                                                                                      \
+        rc = launch_fused_lean<CC, TIn>(ctx, st, F, d_kpts, d_np, prm, (float *)xyzs, (float *)ps, d_cnt, d_fl); \
+        break;
+#ifndef SNOWTRI_DEV_MIN
+            SNOWTRI_CASE(3)
+            SNOWTRI_CASE(5)
+            SNOWTRI_CASE(6)
+            SNOWTRI_CASE(7)
+            SNOWTRI_CASE(8)
+#endif
+            SNOWTRI_CASE(4)
 #undef SNOWTRI_CASE
             default: rc = SNOWTRI_ERR_BAD_ARG;
         }
@@ -1112,12 +1200,14 @@ int fused_dispatch(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax, int J,
     case CC:                                                                                               \
         rc = launch_fused_single<CC, 0, TIn, TOut>(ctx, st, F, J, d_kpts, d_np, prm, Pout, d_xyzs, d_ps, d_cnt, d_fl); \
         break;
+#ifndef SNOWTRI_DEV_MIN
             SNOWTRI_CASE(3)
-            SNOWTRI_CASE(4)
             SNOWTRI_CASE(5)
             SNOWTRI_CASE(6)
             SNOWTRI_CASE(7)
             SNOWTRI_CASE(8)
+#endif
+            SNOWTRI_CASE(4)
 #undef SNOWTRI_CASE
             default: rc = SNOWTRI_ERR_BAD_ARG;
         }
@@ -1159,7 +1249,7 @@ extern "C" int snowtri_triangulate_condense(snowtri_ctx *ctx, int64_t F, int32_t
     Params prm;
     int rc = validate_params(params, J, &prm, true);
     if (rc) return rc;
-    HIP_TRY(hipSetDevice(ctx->device));
+    ENTER_DEVICE(ctx->device);
     hipStream_t st = (hipStream_t)stream;
     const int kn = prm.kn;
     const size_t isz = dtype_size(in_dtype), osz = dtype_size(out_dtype);
@@ -1197,12 +1287,17 @@ extern "C" int snowtri_triangulate_condense(snowtri_ctx *ctx, int64_t F, int32_t
     ctx->last_slow_frames = -1;
     if (in_dtype == SNOWTRI_F32 && out_dtype == SNOWTRI_F32)
         rc = fused_dispatch<float, float>(ctx, st, F, Pmax, J, d_kpts, d_np, prm, Pout_max, d_xyzs, d_ps, d_cnt, d_fl, method);
+#ifdef SNOWTRI_DEV_MIN  // kernel-development builds (scripts/ab_build.sh): float32 I/O, 4 cameras only
+    else
+        rc = SNOWTRI_ERR_BAD_ARG;
+#else
     else if (in_dtype == SNOWTRI_F32)
         rc = fused_dispatch<float, double>(ctx, st, F, Pmax, J, d_kpts, d_np, prm, Pout_max, d_xyzs, d_ps, d_cnt, d_fl, method);
     else if (out_dtype == SNOWTRI_F32)
         rc = fused_dispatch<double, float>(ctx, st, F, Pmax, J, d_kpts, d_np, prm, Pout_max, d_xyzs, d_ps, d_cnt, d_fl, method);
     else
         rc = fused_dispatch<double, double>(ctx, st, F, Pmax, J, d_kpts, d_np, prm, Pout_max, d_xyzs, d_ps, d_cnt, d_fl, method);
+#endif
     if (rc) return rc;
     if (memspace == SNOWTRI_HOST) {
         HIP_TRY(hipMemcpyAsync(out_xyzs, d_xyzs, o4, hipMemcpyDeviceToHost, st));

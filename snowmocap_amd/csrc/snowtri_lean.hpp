@@ -1,0 +1,395 @@
+// snowtri_lean.hpp -- k_fused_lean: the production shape of the fast path (A1..A4 of SURVEY.md §8a in one launch).
+//
+// Same algorithm, speculation and fall-back as k_fused_single (snowtri_fused.hpp) for the case the bench and the
+// shipped configuration run: pairwise method, FLOAT32 outputs, one detection per camera, one output slot, and
+// keypoint_num == J known at compile time (JC = 133, the Wholebody skeleton of main.py).  float64 outputs and
+// every other shape stay on k_fused_single, bit for bit as before.
+//
+// What is different, and why (the kernel is bound by VALU issue):
+//   * WAVE-AUTONOMOUS tiles.  A wave owns whole frames (<= kLeanTw of them per tile): its item loop, the
+//     single-cluster check and the per-frame mean score never leave the wave, so there is no __syncthreads()
+//     per tile and the prologue / epilogue of one wave overlap the item loops of the others on the same SIMD.
+//     The only workgroup barrier is at the very end, before the (rare) frames the speculation could not
+//     resolve are re-done by general_frame.
+//   * Tiles are cut so that every wave of the launch gets the same number of frames +-1 (a 10 000-frame
+//     launch no longer leaves a fifth of the chip idle behind the 25-frame tiles of 400 workgroups).
+//   * A shorter item (lean_item): 1/dist is the raw v_rsq_f64 (2^-23 relative, below the float32 rounding
+//     of the stored score); the 1/2000 of triangulation.py:72 is applied once to the score sum; the keypoint
+//     gate (:73) is evaluated once per camera into a lane mask; exact intersection / singular pair / NaN are
+//     detected on the score sum; the per-pair offsets d = t_s - t_m live in scalar registers (one SGPR operand
+//     per v_fma_f64, no LDS read, no VGPR); item -> (frame, joint) uses the compile-time J; loads and stores
+//     take a scalar base + 32-bit lane offset; lanes past the end of a tile recompute its last item instead
+//     of branching around the stores.
+#pragma once
+#include "snowtri_fused.hpp"
+
+namespace snowtri {
+
+constexpr int kLeanTw = 12;              // frames per wave tile (12 x 133 = 24.94 passes of 64 lanes)
+constexpr int kLeanWaves = kBlock / 64;  // waves per workgroup
+constexpr int kLeanSlowShift = 4;        // slow-frame bit index = (tile ordinal of the workgroup << 4) | frame in tile
+
+__host__ __device__ constexpr size_t lean_lds_bytes(int C, int JC, int slow_words) {
+    const size_t stash = (size_t)kLeanWaves * kLeanTw * JC * 8;              // fused joint scores, per wave
+    const size_t consts = (size_t)8 * ((12 * C + 3 * (C * (C - 1) / 2) + 1) & ~1);  // M[C][9], t[C][3], d[NP][3]
+    return ((stash + consts + (size_t)4 * slow_words) + 15) & ~(size_t)15;
+}
+
+__device__ __forceinline__ double uniform_f64(double x) {  // wave-uniform value -> scalar registers
+    const int lo = __builtin_amdgcn_readfirstlane(__double2loint(x));
+    const int hi = __builtin_amdgcn_readfirstlane(__double2hiint(x));
+    return __hiloint2double(hi, lo);
+}
+
+// x if the lane's bit of `mask` is set, else 0: one v_cndmask_b32 on a scalar lane mask (the compiler turns
+// a bool that crosses basic blocks into a VGPR 0/1 and three more VALU instructions)
+__device__ __forceinline__ float select_by_mask(float x, unsigned long long mask) {
+    float r;
+    asm("v_cndmask_b32_e64 %0, 0, %1, %2" : "=v"(r) : "v"(x), "s"(mask));
+    return r;
+}
+
+// One (frame, joint): C rays, all C(C,2) pair solves, score-weighted fusion (see pairwise_item for the
+// algebra: fusion regrouped per ray, one reciprocal for all determinants).  Returns true if the item needs
+// the IEEE-exact routine.
+#ifndef SNOWTRI_LEAN_M_VGPR
+#define SNOWTRI_LEAN_M_VGPR 0
+#endif
+template <int C, typename TIn>
+__device__ __forceinline__ bool lean_item(const double *__restrict__ Mlds, const double (&Mres)[9 * C],
+                                          const double (&dS)[3 * (C * (C - 1) / 2)],
+                                          const Kp3<TIn> (&cur)[C], float kthr_f32, double kthr, double dthr2,
+                                          float &ox, float &oy, float &oz, double &os) {
+    constexpr int NPc = C * (C - 1) / 2;
+#if SNOWTRI_LEAN_M_VGPR  // dev experiment: ray matrices resident in VGPRs for the whole launch (passed in Mres)
+    const double (&Mp)[9 * C] = Mres;
+#else
+    double Mp[9 * C];
+#pragma unroll
+    for (int i = 0; i < 9 * C; i++) Mp[i] = Mlds[i];
+    __builtin_amdgcn_sched_barrier(0);  // one burst of LDS reads, one wait (+2.5 % measured in round 1)
+#endif
+    const double *tp = Mlds + 9 * C;
+    Vec3 h[C];
+    double a[C], alpha[C], beta[C];
+    unsigned long long okm[C];
+#pragma unroll
+    for (int c = 0; c < C; c++) {
+        // A1, camera.py:241-243 with M = R inv(K)
+        const double u = (double)cur[c].u, v = (double)cur[c].v;
+        h[c].x = fma(Mp[9 * c + 0], u, fma(Mp[9 * c + 1], v, Mp[9 * c + 2]));
+        h[c].y = fma(Mp[9 * c + 3], u, fma(Mp[9 * c + 4], v, Mp[9 * c + 5]));
+        h[c].z = fma(Mp[9 * c + 6], u, fma(Mp[9 * c + 7], v, Mp[9 * c + 8]));
+        a[c] = dot3(h[c], h[c]);
+        // triangulation.py:73, once per camera: lanes whose confidence is NOT below the threshold
+        if constexpr (sizeof(TIn) == 4)
+            okm[c] = __ballot(!((float)cur[c].s < kthr_f32));
+        else
+            okm[c] = __ballot(!((double)cur[c].s < kthr));
+    }
+    double bq[NPc], detq[NPc], pre[NPc], invq[NPc];
+    int q = 0;
+#pragma unroll
+    for (int mc = 0; mc < C - 1; mc++)
+#pragma unroll
+        for (int sc = mc + 1; sc < C; sc++, q++) {
+            bq[q] = dot3(h[mc], h[sc]);
+            detq[q] = fma(a[mc], a[sc], -(bq[q] * bq[q]));
+            pre[q] = q == 0 ? detq[0] : pre[q - 1] * detq[q];
+        }
+    {
+        double run = rcp_nr1(pre[NPc - 1]);  // 2^-46: 1e-13 m on the 3D point, far below its float32 rounding
+#pragma unroll
+        for (int k = NPc - 1; k > 0; k--) {
+            invq[k] = run * pre[k - 1];
+            run *= detq[k];
+        }
+        invq[0] = run;
+    }
+    q = 0;
+#pragma unroll
+    for (int mc = 0; mc < C - 1; mc++) {
+#pragma unroll
+        for (int sc = mc + 1; sc < C; sc++, q++) {
+            // A2 (triangulation.py:24-31): per-ray norms hoisted, d = ts - tm in scalar registers
+            const Vec3 &hm = h[mc], &hs = h[sc];
+            const double dx = dS[3 * q], dy = dS[3 * q + 1], dz = dS[3 * q + 2];
+            const double b = bq[q], inv = invq[q];
+            const double e = fma(hm.z, dz, fma(hm.y, dy, hm.x * dx));
+            const double g = fma(hs.z, dz, fma(hs.y, dy, hs.x * dx));
+            const double S0 = fma(a[sc], e, -(b * g)) * inv;
+            const double S1 = fma(a[mc], g, -(b * e)) * inv;
+            // Wm - Ws = hm S0 + hs S1 - d
+            const double fx = fma(hs.x, S1, fma(hm.x, S0, -dx));
+            const double fy = fma(hs.y, S1, fma(hm.y, S0, -dy));
+            const double fz = fma(hs.z, S1, fma(hm.z, S0, -dz));
+            const double d2 = fma(fz, fz, fma(fy, fy, fx * fx));
+            const double idist = __builtin_amdgcn_rsq(d2);
+            // :72-74  score = ((sm+ss)/2) / (dist*1000), zeroed by the three gates; sq = 2000 x that score
+            const unsigned long long keep = okm[mc] & okm[sc] & __ballot(!(d2 > dthr2));
+            double sq;
+            if constexpr (sizeof(TIn) == 4) {
+                sq = (double)select_by_mask((float)cur[mc].s + (float)cur[sc].s, keep) * idist;  // float32 sum as NumPy
+            } else {
+                const double ssum = (double)cur[mc].s + (double)cur[sc].s;
+                sq = __hiloint2double(__float_as_int(select_by_mask(__int_as_float(__double2hiint(ssum)), keep)),
+                                      __float_as_int(select_by_mask(__int_as_float(__double2loint(ssum)), keep))) * idist;
+            }
+            if (mc == 0) {
+                alpha[sc] = -sq * S1;
+                beta[sc] = sq;
+                if (sc == 1) {
+                    alpha[0] = sq * S0;
+                    beta[0] = sq;
+                } else {
+                    alpha[0] = fma(sq, S0, alpha[0]);
+                    beta[0] += sq;
+                }
+            } else {
+                alpha[mc] = fma(sq, S0, alpha[mc]);
+                alpha[sc] = fma(-sq, S1, alpha[sc]);
+                beta[mc] += sq;
+                beta[sc] += sq;
+            }
+        }
+    }
+    double sx = alpha[0] * h[0].x, sy = alpha[0] * h[0].y, sz = alpha[0] * h[0].z, sb = beta[0];
+    sx = fma(beta[0], tp[0], sx);
+    sy = fma(beta[0], tp[1], sy);
+    sz = fma(beta[0], tp[2], sz);
+#pragma unroll
+    for (int c = 1; c < C; c++) {
+        sx = fma(alpha[c], h[c].x, fma(beta[c], tp[3 * c + 0], sx));
+        sy = fma(alpha[c], h[c].y, fma(beta[c], tp[3 * c + 1], sy));
+        sz = fma(alpha[c], h[c].z, fma(beta[c], tp[3 * c + 2], sz));
+        sb += beta[c];
+    }
+    // sb = 2 x 2000 x sum_q s_q (:141).  sum == 0 -> the joint stays (0,0,0)/0 (:142-143): sx = sy = sz = 0 then,
+    // so any finite reciprocal will do: 1 / max(sb, 1e-300) saves the compare-and-select.
+    const double r = rcp_nr1(fmax(sb, 1e-300));
+    ox = (float)(sx * r);  // :144-147 as (sum s (Wm+Ws)) / (2 sum s)
+    oy = (float)(sy * r);
+    oz = (float)(sz * r);
+    os = sb * (0.00025 / (double)NPc);  // :148
+    // dist == 0 (1/dist = inf), a singular pair (1/prod(det) poisons every pair) or NaN input leave sum s
+    // inf or NaN: the IEEE-exact routine decides those frames
+    return !(sb < 1e300);
+}
+
+// frames [f0, f0 + nf) of tile `t` when F frames are cut into ntiles tiles of base or base + 1 frames
+__device__ __forceinline__ void lean_tile_range(int64_t t, int base, int64_t rem, int64_t &f0, int &nf) {
+    f0 = t * base + (t < rem ? t : rem);
+    nf = base + (t < rem ? 1 : 0);
+}
+
+// Grid: any number of workgroups; wave gw = 4 blockIdx.x + wave takes tiles gw, gw + 4 gridDim.x, ...
+// Dynamic LDS: lean_lds_bytes(C, JC, slow_words); slow_words >= ceil(tiles of one WORKGROUP * 16 / 32).
+template <int C, typename TIn, int JC>
+__global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean(
+    int64_t F, int64_t ntiles, int tile_base, int64_t tile_rem, int slow_words, Rig rig, const TIn *__restrict__ kpts,
+    const int32_t *__restrict__ n_persons, Params prm, float *__restrict__ out4, float *__restrict__ out_ps,
+    int32_t *__restrict__ out_count, uint32_t *__restrict__ out_flags, char *scratch, size_t scratch_per_block) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NP = C * (C - 1) / 2;
+    constexpr int kItemsMax = kLeanTw * JC;
+    constexpr int kConstDoubles = (12 * C + 3 * NP + 1) & ~1;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: tile bookkeeping and loop control stay on the SALU
+    // LDS: [rig constants | per-wave stash of fused joint scores | slow-frame bit words]; the constants sit at
+    // offset 0 so that every ds_read of them is base + immediate
+    double *Mlds = reinterpret_cast<double *>(smem);
+    double *stash = Mlds + kConstDoubles + wave * kItemsMax;
+    uint32_t *slowbits = reinterpret_cast<uint32_t *>(Mlds + kConstDoubles + kLeanWaves * kItemsMax);
+    const Kp3<TIn> *kp3 = reinterpret_cast<const Kp3<TIn> *>(kpts);
+    const int64_t wstride = (int64_t)gridDim.x * kLeanWaves;
+    Kp3<TIn> bufA[C], bufB[C], bufC[C];
+
+    // lane's k-th item of a tile: i = lane + 64 k, clamped to the tile's last item (lanes past the end redo it:
+    // same inputs, same outputs, same addresses -- no branch around the stores); input record of camera c is
+    // tile_in[(i + (i / JC) (C-1) JC) + c JC]
+    auto fetch = [&](Kp3<TIn>(&dst)[C], const Kp3<TIn> *tile_in, unsigned i, unsigned last) {
+        i = i < last ? i : last;
+        const unsigned off = i + (i / (unsigned)JC) * (unsigned)((C - 1) * JC);
+        const char *p = reinterpret_cast<const char *>(tile_in) + (size_t)(off * (unsigned)sizeof(Kp3<TIn>));
+#pragma unroll
+        for (int c = 0; c < C; c++) dst[c] = *reinterpret_cast<const Kp3<TIn> *>(p + (size_t)c * JC * sizeof(Kp3<TIn>));
+    };
+
+    int64_t tile = (int64_t)blockIdx.x * kLeanWaves + wave;
+    int64_t f0 = 0;
+    int nf = 0;
+    if (tile < ntiles) {
+        lean_tile_range(tile, tile_base, tile_rem, f0, nf);
+        const Kp3<TIn> *tile_in = kp3 + f0 * (int64_t)(C * JC);
+        const unsigned last = (unsigned)(nf * JC - 1);
+        fetch(bufA, tile_in, (unsigned)lane, last);
+        fetch(bufB, tile_in, (unsigned)lane + 64u, last);
+    }
+    // (the first keypoints are in flight while the constants are set up)
+    if (tid < 9 * C) Mlds[tid] = rig.M[tid];
+    if (tid < 3 * C) Mlds[9 * C + tid] = rig.t[tid];
+    if (tid < 3 * NP) Mlds[12 * C + tid] = rig.pairc[6 * (tid / 3) + tid % 3];
+    for (int i = tid; i < slow_words; i += kBlock) slowbits[i] = 0u;
+    double dS[3 * NP];  // per-pair d = t_s - t_m, wave-uniform -> scalar registers
+#pragma unroll
+    for (int i = 0; i < 3 * NP; i++) dS[i] = uniform_f64(rig.pairc[6 * (i / 3) + i % 3]);
+    const float kthr_f32 = prm.kthr_f32;
+    const double kthr = prm.kthr, dthr2 = prm.dthr2;
+    __syncthreads();  // constants and the cleared slow-frame bits are visible to every wave
+    double Mres[9 * C];
+#if SNOWTRI_LEAN_M_VGPR
+#pragma unroll
+    for (int i = 0; i < 9 * C; i++) Mres[i] = Mlds[i];
+#endif
+
+    for (int ord = 0; tile < ntiles; tile += wstride, ord++) {
+        const Kp3<TIn> *tile_in = kp3 + f0 * (int64_t)(C * JC);
+        float4 *tile_out = reinterpret_cast<float4 *>(out4) + f0 * (int64_t)JC;
+        const unsigned last = (unsigned)(nf * JC - 1);
+        const int npass = (nf * JC + 63) >> 6;
+        const unsigned slow_base = (unsigned)((ord * kLeanWaves + wave) << kLeanSlowShift);
+
+        auto solve_store = [&](const Kp3<TIn>(&buf)[C], unsigned i) {
+            i = i < last ? i : last;
+            float ox, oy, oz;
+            double os;
+            const bool bad = lean_item<C>(Mlds, Mres, dS, buf, kthr_f32, kthr, dthr2, ox, oy, oz, os);
+            *reinterpret_cast<float4 *>(reinterpret_cast<char *>(tile_out) + (size_t)(i * 16u)) =
+                make_float4(ox, oy, oz, (float)os);
+            stash[i] = os;
+            if (__ballot(bad)) {  // rare, wave-uniform branch
+                const unsigned bit = slow_base + i / (unsigned)JC;
+                if (bad) atomicOr(&slowbits[bit >> 5], 1u << (bit & 31u));
+            }
+        };
+        // ---- item loop: a ring of three register buffers keeps the keypoints of the next two items in flight
+        unsigned is = (unsigned)lane;  // item being solved; the one being fetched is two passes ahead
+        for (int k = 0; k < npass; k += 3) {
+            fetch(bufC, tile_in, is + 128u, last);
+            solve_store(bufA, is);
+            fetch(bufA, tile_in, is + 192u, last);
+            if (k + 1 < npass) solve_store(bufB, is + 64u);
+            fetch(bufB, tile_in, is + 256u, last);
+            if (k + 2 < npass) solve_store(bufC, is + 128u);
+            is += 192u;
+        }
+        // this wave's next tile: its first two fetches fly during the epilogue
+        const int64_t f0_cur = f0;
+        const int nf_cur = nf;
+        const int64_t nt = tile + wstride;
+        if (nt < ntiles) {
+            lean_tile_range(nt, tile_base, tile_rem, f0, nf);
+            const Kp3<TIn> *next_in = kp3 + f0 * (int64_t)(C * JC);
+            const unsigned nlast = (unsigned)(nf * JC - 1);
+            fetch(bufA, next_in, (unsigned)lane, nlast);
+            fetch(bufB, next_in, (unsigned)lane + 64u, nlast);
+        }
+
+        // ---- single-cluster check (:116-130): every candidate's centre joint within condense_distance_tol of
+        //      candidate 0's.  One lane per (frame, pair): its centre, then candidate 0's from the frame's first lane.
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        for (int base = 0; base < nf_cur * NP; base += 64) {
+            const int l = base + lane;
+            const bool live = l < nf_cur * NP;
+            const int w = live ? l / NP : 0, qq = live ? l - w * NP : 0;
+            const int mc = rig.pairs[2 * qq], sc = rig.pairs[2 * qq + 1];
+            const Kp3<TIn> *p = kp3 + (f0_cur + w) * (int64_t)(C * JC) + prm.center;
+            const Kp3<TIn> km = p[mc * JC], ks = p[sc * JC];
+            const double *pcq = rig.pairc + 6 * qq;
+            const PairSolve o = pair_solve_fast<true>(make_ray(rig.M + 9 * mc, km.u, km.v),
+                                                      make_ray(rig.M + 9 * sc, ks.u, ks.v),
+                                                      Vec3{pcq[0], pcq[1], pcq[2]}, Vec3{pcq[3], pcq[4], pcq[5]});
+            // candidate 0 of the same frame sits qq lanes below (never across a 64-lane pass when NP | 64 fails:
+            // take it from LDS-free shuffles only if it is in this pass, else recompute)
+            const int src = lane - qq;
+            Vec3 w0 = {__shfl(o.sw.x, src < 0 ? lane : src, 64), __shfl(o.sw.y, src < 0 ? lane : src, 64),
+                       __shfl(o.sw.z, src < 0 ? lane : src, 64)};
+            if (src < 0) {  // the frame's pair 0 was handled by the previous pass: solve it again here
+                const int m0 = rig.pairs[0], s0 = rig.pairs[1];
+                const Kp3<TIn> k0 = p[m0 * JC], k1 = p[s0 * JC];
+                const double *pc0 = rig.pairc;
+                w0 = pair_solve_fast<true>(make_ray(rig.M + 9 * m0, k0.u, k0.v), make_ray(rig.M + 9 * s0, k1.u, k1.v),
+                                           Vec3{pc0[0], pc0[1], pc0[2]}, Vec3{pc0[3], pc0[4], pc0[5]}).sw;
+            }
+            const double ex = 0.5 * (w0.x - o.sw.x), ey = 0.5 * (w0.y - o.sw.y), ez = 0.5 * (w0.z - o.sw.z);
+            const double cd = sqrt(fma(ez, ez, fma(ey, ey, ex * ex)));  // :124
+            if (live && qq > 0 && cd > prm.ctol) {                       // :125
+                const unsigned bit = slow_base + (unsigned)w;
+                atomicOr(&slowbits[bit >> 5], 1u << (bit & 31u));
+            }
+        }
+        // ---- per-frame mean fused score (:150), filters, count: four lanes per frame
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        {
+            constexpr int G = 4;
+            const int w = lane / G, sub = lane & (G - 1);
+            const bool live = w < nf_cur;
+            const int64_t f = f0_cur + (live ? w : 0);
+            double sum = 0.0;
+            if (live) {
+                const double *row = stash + w * JC;
+                double s1 = 0.0, s2 = 0.0, s3 = 0.0;
+                int b = sub;
+#pragma unroll 2
+                for (; b + 3 * G < JC; b += 4 * G) {
+                    const double v0 = row[b], v1 = row[b + G], v2 = row[b + 2 * G], v3 = row[b + 3 * G];
+                    sum += v0;
+                    s1 += v1;
+                    s2 += v2;
+                    s3 += v3;
+                }
+                for (; b < JC; b += G) sum += row[b];
+                sum = (sum + s1) + (s2 + s3);
+            }
+            int not_one = 0;
+            if (n_persons && live)
+                for (int c = sub; c < C; c += G) not_one |= n_persons[f * C + c] != 1;
+#pragma unroll
+            for (int off = G / 2; off > 0; off >>= 1) {
+                sum += __shfl_xor(sum, off, 64);
+                not_one |= __shfl_xor(not_one, off, 64);
+            }
+            if (live && sub == 0) {
+                const double avg = sum / (double)JC;
+                const unsigned bit = slow_base + (unsigned)w;
+                const bool slow = ((slowbits[bit >> 5] >> (bit & 31u)) & 1u) != 0u || (avg < prm.score_tol) || not_one != 0;  // :151-152
+                if (slow) {
+                    atomicOr(&slowbits[bit >> 5], 1u << (bit & 31u));
+                } else {
+                    out_count[f] = 1;
+                    if (out_ps) out_ps[f] = (float)avg;
+                    if (out_flags) out_flags[f] = kFlagFast;
+                }
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // the next tile's stash writes stay behind these reads
+    }
+
+    // ---- rare: frames the speculation could not resolve -> the reference's full algorithm, by the whole workgroup
+    __syncthreads();
+    unsigned any = 0u;
+    for (int i = lane; i < slow_words; i += 64) any |= slowbits[i];
+    if (__ballot(any != 0u) == 0ull) return;  // every wave reads the same words: uniform exit
+    {
+        const PackedWriter<float> wr{out4, out_ps};
+        double *slab = reinterpret_cast<double *>(scratch + (size_t)blockIdx.x * scratch_per_block);
+        for (int wd = 0; wd < slow_words; wd++) {
+            uint32_t m = slowbits[wd];
+            __syncthreads();  // general_frame reuses the front of the LDS, not the bit words, but keep passes apart
+            while (m) {
+                const int bpos = __ffs((int)m) - 1;
+                m &= m - 1u;
+                const unsigned bit = (unsigned)(wd * 32 + bpos);
+                const unsigned slot = bit >> kLeanSlowShift;              // = ord * kLeanWaves + wave
+                const int64_t t = (int64_t)blockIdx.x * kLeanWaves + (slot % kLeanWaves) + (int64_t)(slot / kLeanWaves) * wstride;
+                int64_t tf0;
+                int tnf;
+                lean_tile_range(t, tile_base, tile_rem, tf0, tnf);
+                general_frame<TIn>(tf0 + (bit & ((1u << kLeanSlowShift) - 1u)), 1, JC, NP, rig, kpts, n_persons, prm, 1, wr,
+                                   out_count, out_flags, slab, smem);
+            }
+        }
+    }
+}
+
+}  // namespace snowtri

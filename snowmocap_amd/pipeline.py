@@ -54,6 +54,9 @@ class TrackPipeline:
         tri = self.bt.run_torch(kpts, n_persons)
         if check:
             cnt = tri["count"].cpu().numpy()
+            flg = tri["flags"].cpu().numpy()
+            if (flg & _lib.FLAG_SINGULAR).any():    # the reference's np.linalg.inv raises (triangulation.py:26)
+                raise np.linalg.LinAlgError(f"Singular matrix (frame {int(np.argmax((flg & _lib.FLAG_SINGULAR) != 0))})")
             if not (cnt == self.P).all():
                 bad = int(np.argmax(cnt != self.P))
                 raise ValueError(f"frame {bad} resolved to {int(cnt[bad])} persons, the track is built for {self.P}")

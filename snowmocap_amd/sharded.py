@@ -114,7 +114,7 @@ def smooth_track_sharded(x_local, f=2, z=0.75, r=0, delta_time=1 / 30, group=Non
     T = int(x_local.shape[0])
     lanes = tuple(x_local.shape[1:])
     n = int(np.prod(lanes)) if lanes else 1
-    ctx = ctx or _lib.scratch_context()
+    ctx = ctx or _lib.scratch_context(x_local.device.index)     # scratch and kernels on the GPU that holds the shard
     stream = ct.c_void_p(torch.cuda.current_stream(x_local.device).cuda_stream)
     L = _lib.lib()
     y = torch.empty_like(x_local)
