@@ -25,13 +25,16 @@
 
 namespace snowtri {
 
-constexpr int kLeanTw = 12;              // frames per wave tile (12 x 133 = 24.94 passes of 64 lanes)
+#ifndef SNOWTRI_LEAN_TW
+#define SNOWTRI_LEAN_TW 12
+#endif
+constexpr int kLeanTw = SNOWTRI_LEAN_TW;  // frames per wave tile (12 x 133 = 24.94 passes of 64 lanes)
 constexpr int kLeanWaves = kBlock / 64;  // waves per workgroup
 constexpr int kLeanSlowShift = 4;        // slow-frame bit index = (tile ordinal of the workgroup << 4) | frame in tile
 
 __host__ __device__ constexpr size_t lean_lds_bytes(int C, int JC, int slow_words) {
     const size_t stash = (size_t)kLeanWaves * kLeanTw * JC * 8;              // fused joint scores, per wave
-    const size_t consts = (size_t)8 * ((12 * C + 3 * (C * (C - 1) / 2) + 1) & ~1);  // M[C][9], t[C][3], d[NP][3]
+    const size_t consts = (size_t)8 * ((12 * C + 4 * (C * (C - 1) / 2) + 1) & ~1);  // M[C][9], t[C][3], d[NP][3], pairs[NP][2] (int32)
     return ((stash + consts + (size_t)4 * slow_words) + 15) & ~(size_t)15;
 }
 
@@ -54,6 +57,9 @@ __device__ __forceinline__ float select_by_mask(float x, unsigned long long mask
 // the IEEE-exact routine.
 #ifndef SNOWTRI_LEAN_M_VGPR
 #define SNOWTRI_LEAN_M_VGPR 0
+#endif
+#ifndef SNOWTRI_LEAN_RING
+#define SNOWTRI_LEAN_RING 3
 #endif
 template <int C, typename TIn>
 __device__ __forceinline__ bool lean_item(const double *__restrict__ Mlds, const double (&Mres)[9 * C],
@@ -192,7 +198,7 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean(
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NP = C * (C - 1) / 2;
     constexpr int kItemsMax = kLeanTw * JC;
-    constexpr int kConstDoubles = (12 * C + 3 * NP + 1) & ~1;
+    constexpr int kConstDoubles = (12 * C + 4 * NP + 1) & ~1;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: tile bookkeeping and loop control stay on the SALU
     // LDS: [rig constants | per-wave stash of fused joint scores | slow-frame bit words]; the constants sit at
@@ -202,7 +208,11 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean(
     uint32_t *slowbits = reinterpret_cast<uint32_t *>(Mlds + kConstDoubles + kLeanWaves * kItemsMax);
     const Kp3<TIn> *kp3 = reinterpret_cast<const Kp3<TIn> *>(kpts);
     const int64_t wstride = (int64_t)gridDim.x * kLeanWaves;
+#if SNOWTRI_LEAN_RING == 3
     Kp3<TIn> bufA[C], bufB[C], bufC[C];
+#else
+    Kp3<TIn> bufA[C], bufB[C];
+#endif
 
     // lane's k-th item of a tile: i = lane + 64 k, clamped to the tile's last item (lanes past the end redo it:
     // same inputs, same outputs, same addresses -- no branch around the stores); input record of camera c is
@@ -229,6 +239,8 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean(
     if (tid < 9 * C) Mlds[tid] = rig.M[tid];
     if (tid < 3 * C) Mlds[9 * C + tid] = rig.t[tid];
     if (tid < 3 * NP) Mlds[12 * C + tid] = rig.pairc[6 * (tid / 3) + tid % 3];
+    int32_t *pairs_lds = reinterpret_cast<int32_t *>(Mlds + 12 * C + 3 * NP);
+    if (tid < 2 * NP) pairs_lds[tid] = rig.pairs[tid];
     for (int i = tid; i < slow_words; i += kBlock) slowbits[i] = 0u;
     double dS[3 * NP];  // per-pair d = t_s - t_m, wave-uniform -> scalar registers
 #pragma unroll
@@ -246,8 +258,23 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean(
         const Kp3<TIn> *tile_in = kp3 + f0 * (int64_t)(C * JC);
         float4 *tile_out = reinterpret_cast<float4 *>(out4) + f0 * (int64_t)JC;
         const unsigned last = (unsigned)(nf * JC - 1);
+#ifdef SNOWTRI_LEAN_NOLOOP  // dev experiment (timing only, outputs are wrong): fixed cost of a launch without its items
+        const int npass = 0;
+#else
         const int npass = (nf * JC + 63) >> 6;
+#endif
         const unsigned slow_base = (unsigned)((ord * kLeanWaves + wave) << kLeanSlowShift);
+        // centre-joint keypoints for the single-cluster check after the item loop (lane = frame x pair)
+        constexpr int kCheckFrames = 64 / NP;
+        Kp3<TIn> ckm[2], cks[2];
+#pragma unroll
+        for (int pass = 0; pass < 2; pass++) {
+            const int wl = lane / NP, qq = lane - wl * NP, w = pass * kCheckFrames + wl;
+            const bool live = wl < kCheckFrames && w < nf;
+            const Kp3<TIn> *p = kp3 + (f0 + (live ? w : 0)) * (int64_t)(C * JC) + prm.center;
+            ckm[pass] = p[pairs_lds[2 * qq] * JC];
+            cks[pass] = p[pairs_lds[2 * qq + 1] * JC];
+        }
 
         auto solve_store = [&](const Kp3<TIn>(&buf)[C], unsigned i) {
             i = i < last ? i : last;
@@ -264,6 +291,7 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean(
         };
         // ---- item loop: a ring of three register buffers keeps the keypoints of the next two items in flight
         unsigned is = (unsigned)lane;  // item being solved; the one being fetched is two passes ahead
+#if SNOWTRI_LEAN_RING == 3
         for (int k = 0; k < npass; k += 3) {
             fetch(bufC, tile_in, is + 128u, last);
             solve_store(bufA, is);
@@ -273,6 +301,15 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean(
             if (k + 2 < npass) solve_store(bufC, is + 128u);
             is += 192u;
         }
+#else  // two buffers: the solved one is refilled at once (fetch distance still two passes)
+        for (int k = 0; k < npass; k += 2) {
+            solve_store(bufA, is);
+            fetch(bufA, tile_in, is + 128u, last);
+            if (k + 1 < npass) solve_store(bufB, is + 64u);
+            fetch(bufB, tile_in, is + 192u, last);
+            is += 128u;
+        }
+#endif
         // this wave's next tile: its first two fetches fly during the epilogue
         const int64_t f0_cur = f0;
         const int nf_cur = nf;
@@ -286,32 +323,33 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean(
         }
 
         // ---- single-cluster check (:116-130): every candidate's centre joint within condense_distance_tol of
-        //      candidate 0's.  One lane per (frame, pair): its centre, then candidate 0's from the frame's first lane.
+        //      candidate 0's.  One lane per (frame, pair), whole frames per 64-lane pass: the lane solves its pair at
+        //      the centre joint and takes candidate 0's point from the frame's first lane.  The keypoints of the
+        //      first two passes were fetched before the item loop; rig constants come from LDS.
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        for (int base = 0; base < nf_cur * NP; base += 64) {
-            const int l = base + lane;
-            const bool live = l < nf_cur * NP;
-            const int w = live ? l / NP : 0, qq = live ? l - w * NP : 0;
-            const int mc = rig.pairs[2 * qq], sc = rig.pairs[2 * qq + 1];
-            const Kp3<TIn> *p = kp3 + (f0_cur + w) * (int64_t)(C * JC) + prm.center;
-            const Kp3<TIn> km = p[mc * JC], ks = p[sc * JC];
-            const double *pcq = rig.pairc + 6 * qq;
-            const PairSolve o = pair_solve_fast<true>(make_ray(rig.M + 9 * mc, km.u, km.v),
-                                                      make_ray(rig.M + 9 * sc, ks.u, ks.v),
-                                                      Vec3{pcq[0], pcq[1], pcq[2]}, Vec3{pcq[3], pcq[4], pcq[5]});
-            // candidate 0 of the same frame sits qq lanes below (never across a 64-lane pass when NP | 64 fails:
-            // take it from LDS-free shuffles only if it is in this pass, else recompute)
-            const int src = lane - qq;
-            Vec3 w0 = {__shfl(o.sw.x, src < 0 ? lane : src, 64), __shfl(o.sw.y, src < 0 ? lane : src, 64),
-                       __shfl(o.sw.z, src < 0 ? lane : src, 64)};
-            if (src < 0) {  // the frame's pair 0 was handled by the previous pass: solve it again here
-                const int m0 = rig.pairs[0], s0 = rig.pairs[1];
-                const Kp3<TIn> k0 = p[m0 * JC], k1 = p[s0 * JC];
-                const double *pc0 = rig.pairc;
-                w0 = pair_solve_fast<true>(make_ray(rig.M + 9 * m0, k0.u, k0.v), make_ray(rig.M + 9 * s0, k1.u, k1.v),
-                                           Vec3{pc0[0], pc0[1], pc0[2]}, Vec3{pc0[3], pc0[4], pc0[5]}).sw;
+#ifdef SNOWTRI_LEAN_NOEPI  // dev experiment (timing only, outputs are wrong): no per-tile epilogue
+        if (nf_cur >= 0) continue;
+#endif
+        for (int pass = 0; pass * kCheckFrames < nf_cur; pass++) {
+            const int wl = lane / NP, qq = lane - wl * NP, w = pass * kCheckFrames + wl;
+            const bool live = wl < kCheckFrames && w < nf_cur;
+            const int mc = pairs_lds[2 * qq], sc = pairs_lds[2 * qq + 1];
+            Kp3<TIn> km, ks;
+            if (pass < 2) {
+                km = ckm[pass];
+                ks = cks[pass];
+            } else {
+                const Kp3<TIn> *p = kp3 + (f0_cur + (live ? w : 0)) * (int64_t)(C * JC) + prm.center;
+                km = p[mc * JC];
+                ks = p[sc * JC];
             }
-            const double ex = 0.5 * (w0.x - o.sw.x), ey = 0.5 * (w0.y - o.sw.y), ez = 0.5 * (w0.z - o.sw.z);
+            const double *tm = Mlds + 9 * C + 3 * mc, *ts = Mlds + 9 * C + 3 * sc, *dq = Mlds + 12 * C + 3 * qq;
+            const PairSolve o = pair_solve_fast<true>(make_ray(Mlds + 9 * mc, km.u, km.v), make_ray(Mlds + 9 * sc, ks.u, ks.v),
+                                                      Vec3{dq[0], dq[1], dq[2]},
+                                                      Vec3{tm[0] + ts[0], tm[1] + ts[1], tm[2] + ts[2]});
+            const int src = lane - qq;  // the frame's pair 0, same pass
+            const double w0x = __shfl(o.sw.x, src, 64), w0y = __shfl(o.sw.y, src, 64), w0z = __shfl(o.sw.z, src, 64);
+            const double ex = 0.5 * (w0x - o.sw.x), ey = 0.5 * (w0y - o.sw.y), ez = 0.5 * (w0z - o.sw.z);
             const double cd = sqrt(fma(ez, ez, fma(ey, ey, ex * ex)));  // :124
             if (live && qq > 0 && cd > prm.ctol) {                       // :125
                 const unsigned bit = slow_base + (unsigned)w;
