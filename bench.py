@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- joint-triangulations/s + HBM roofline of the fused hot path on MI355X.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames 10000] [--pool 32]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--frames 10000] [--pool 32] [--repeats 7]
 
 A "step" is one pass of the hot path (snowtri_triangulate_condense: pixel->ray, pairwise
 triangulation + scoring, association/fusion) over one batch of synthetic input per GPU:
@@ -10,22 +10,37 @@ in HBM.  Successive steps walk a POOL of distinct resident batches (default 32 x
 far larger than the 256 MB Infinity Cache) so every launch streams its input from HBM instead
 of re-reading a cache-resident 85 MB working set (SURVEY.md §7 hard part 6).
 
-Timed region: barrier + synchronize, K steps, synchronize + barrier; MAX over ranks.
-N > 1: one rank per GPU (torch.distributed, backend nccl = RCCL); frames are sharded across ranks
-(weak scaling: every rank processes --frames per step) and the path itself needs NO collective (frames are
-independent), so `value` is measured without one.  north_star also names a RCCL all-gather that reassembles
-the 3D track on every GPU: the same K steps are then timed a second time with that all-gather per step
-(double-buffered on a side stream, overlapping the next kernels) and reported as `with_track_allgather`.
+Timed region: barrier + synchronize, K steps, synchronize + barrier; MAX over ranks.  The region is
+repeated --repeats times in one run (the chip's clock follows its power budget and a 20-step region
+lasts half a millisecond: single regions scatter by +-20 %); `value` / `ms_per_step` are the MEDIAN
+region, `repeats` lists min / max / all.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
-  roofline      dominant kernel (k_fused_single): algorithmic bytes per launch / mean launch duration
-                measured with HIP events on the launch stream; peak = 8 TB/s HBM3E
-  cpu_baseline  the oracle (oracle/snowtri_oracle.c, OpenMP over frames) on the host cores, on a
-                bounded sample of the same workload (rank 0, N = 1 only)
+N > 1: one rank per GPU (torch.distributed, backend nccl = RCCL).  Started WITHOUT a launcher
+(`python bench.py --gpus 8`) the script re-executes itself under `python -m torch.distributed.run`
+on 127.0.0.1; started by a launcher it reads RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the
+environment.  Frames are sharded across ranks (weak scaling: every rank processes --frames per step)
+and the path itself needs NO collective (frames are independent), so `value` is measured without one.
+north_star also names a RCCL all-gather that reassembles the 3D track on every GPU: the same K steps
+are then timed a second time with that all-gather per step (double-buffered on a side stream,
+overlapping the next kernels) and reported as `with_track_allgather`.
+`--dry-run` exercises the launch / rendezvous logic alone (gloo, no GPU work): used by the CPU tests.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with these extra objects:
+  roofline          dominant kernel: algorithmic bytes per launch / mean launch duration measured with HIP
+                    events on the launch stream (one stream, launches back to back); peak = 8 TB/s HBM3E
+  roofline_region   the same bytes / `ms_per_step` of the timed region (--streams streams, launches overlap)
+  large_batch       one 2 000 000-frame launch (SURVEY 8d's roofline run)
+  extra_workloads   BASELINE configs[2] (8 cameras x 4 persons, 10 000 frames) and the per-GPU share of
+                    configs[4] (16 x 8, 12 500 frames): multi-person kernel, fp64-VALU roofline each
+  cpu_baseline      the oracle (oracle/snowtri_oracle.c, OpenMP over frames) on the host cores, on a
+                    bounded sample of the same workload (rank 0, N = 1 only), and its distance to the GPU result
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -35,6 +50,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+FP64_VALU_PEAK_TFLOPS = 78.6   # MI355X vector fp64 (256 CUs x 4 SIMDs x 16 lanes x 2 flop x 2.4 GHz)
+FLOP_PER_SOLVE = 90.0          # one ray-pair solve + score + accumulate
 J = 133
 
 
@@ -61,6 +78,53 @@ def usable_cores():
     return max(1, n)
 
 
+def kernel_source_hash():
+    """sha256 over the HIP sources of libsnowtri.so: ties a PMC traffic measurement to the kernels it was made on."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "snowmocap_amd", "csrc")
+    for fn in sorted(os.listdir(d)):
+        if fn.endswith((".hpp", ".hip")):
+            h.update(fn.encode())
+            h.update(open(os.path.join(d, fn), "rb").read())
+    return h.hexdigest()
+
+
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def relaunch_under_torchrun(args):
+    """`python bench.py --gpus N` without a launcher: become N ranks on this node (rendezvous on 127.0.0.1)."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("NCCL_DEBUG", "NONE")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
+def dry_run(args):
+    """Launch / rendezvous logic only: gloo, no GPU.  Rank 0 prints the ranks it saw."""
+    import torch.distributed as dist
+    world = args.gpus
+    rank = int(os.environ.get("RANK", "0"))
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29533")
+    dist.init_process_group("gloo", rank=rank, world_size=int(os.environ.get("WORLD_SIZE", world)))
+    assert dist.get_world_size() == world, (dist.get_world_size(), world)
+    seen = [None] * world
+    dist.all_gather_object(seen, {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "pid": os.getpid()})
+    dist.barrier()
+    if rank == 0:
+        print(json.dumps({"dry_run": True, "n_gpus": world, "rccl_ranks": dist.get_world_size(), "backend": "gloo",
+                          "ranks": seen}), flush=True)
+    dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -68,6 +132,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--frames", type=int, default=10000, help="frames per step per GPU (configs[1] = 10000)")
     ap.add_argument("--pool", type=int, default=32, help="distinct HBM-resident input batches cycled through")
+    ap.add_argument("--repeats", type=int, default=7, help="how many times the K-step region is timed (median reported)")
     ap.add_argument("--large-frames", type=int, default=2000000,
                     help="extra single-launch roofline run (0 = skip); SURVEY §8d asks for >= 2e6 frames")
     ap.add_argument("--streams", type=int, default=2,
@@ -79,8 +144,17 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="testing aid: run the torch.distributed / all-gather code path even with --gpus 1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the multi-person extra workloads")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--dry-run", action="store_true", help="rendezvous only (gloo, no GPU): CPU test of the launcher")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(relaunch_under_torchrun(args))
+    if "WORLD_SIZE" in os.environ and int(os.environ["WORLD_SIZE"]) != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={os.environ['WORLD_SIZE']} ranks")
+    if args.dry_run:
+        return dry_run(args)
 
     import torch
     from snowmocap_amd import synth, _lib
@@ -102,6 +176,12 @@ def main():
         assert dist.get_world_size() == world
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
+    me = {"rank": rank, "local_rank": local_rank, "device": int(torch.cuda.current_device()),
+          "name": torch.cuda.get_device_name(dev)}
+    ranks_seen = [me]
+    if dist is not None:
+        ranks_seen = [None] * world
+        dist.all_gather_object(ranks_seen, me)
 
     F, K_steps, W_steps = args.frames, args.steps, args.warmup
     wl = synth.config_workload(2, F, seed=1000 + rank)           # cfg2 shape, per-rank shard
@@ -174,7 +254,8 @@ def main():
         return dt
 
     # `value`: frames sharded across ranks, no data-path collective (frames are independent: SURVEY 8e).
-    elapsed = timed_region(False)
+    regions = [timed_region(False) for _ in range(max(1, args.repeats))]
+    elapsed = float(np.median(regions))
     joints_per_step = F * Pout * J * world
     value = joints_per_step * K_steps / elapsed
     ms_per_step = elapsed / K_steps * 1e3
@@ -182,17 +263,17 @@ def main():
     # beside `value` (it is xGMI-bandwidth-bound: 16 B/joint over the links vs 64 B/joint over HBM).
     with_gather = None
     if can_gather:
-        e2 = timed_region(True)
+        e2 = float(np.median([timed_region(True) for _ in range(max(1, min(3, args.repeats)))]))
         with_gather = {"value": joints_per_step * K_steps / e2, "ms_per_step": e2 / K_steps * 1e3,
                        "what": "same steps + one RCCL all_gather_into_tensor of the step's track shard "
                                f"({F * Pout * J * 16 / 1e6:.1f} MB per rank) per step, overlapped on a side stream"}
 
     # dominant-kernel duration: HIP events bracketing each launch on the launch stream
-    # (snowtri_set_timing records them inside the C ABI around k_fused_single only).
+    # (snowtri_set_timing records them inside the C ABI around the fused kernel only).
     # (launches are queued back to back on ONE stream and their event pairs read afterwards: a synchronize
     # between launches would let the GPU idle and clock down, and stretch every launch by ~10 %)
     bt.ctx.set_timing(True)
-    for i in range(min(K_steps, 1000)):
+    for i in range(min(max(K_steps, 200), 1000)):
         bt.run_torch(pool[i % len(pool)], None, out=outs[i % len(pool)])
     kms = bt.ctx.timing_collect()
     bt.ctx.set_timing(False)
@@ -201,12 +282,18 @@ def main():
     kernel_ms_min = float(np.min(kms))
     bpf = algorithmic_bytes_per_frame(C, P, Pout)
     ach = bpf * F / (kernel_ms * 1e-3) / 1e9
+    ach_region = bpf * F / (ms_per_step * 1e-3) / 1e9          # per GPU: every rank streams its own shard
 
-    # correctness guard inside the bench: every frame resolved (count == 1) on the fast path
-    cnt = outs[0]["count"].cpu().numpy()
-    flg = outs[0]["flags"].cpu().numpy()
+    # correctness guard inside the bench: every frame of every pool batch resolved (count == 1) on the fast path
     if os.environ.get("SNOWTRI_BENCH_NOCHECK") != "1":       # (timing-only development builds write wrong outputs)
-        assert (cnt == 1).all() and ((flg & _lib.FLAG_FASTPATH) != 0).all(), "bench output is not the expected fast path"
+        for o in outs:
+            cnt = o["count"].cpu().numpy()
+            flg = o["flags"].cpu().numpy()
+            assert (cnt == 1).all() and ((flg & _lib.FLAG_FASTPATH) != 0).all(), "bench output is not the expected fast path"
+
+    lean = method == _lib.PAIRWISE and os.environ.get("SNOWTRI_LEAN_MODE", "1") != "0" and F > 0
+    kernel_name = ("k_fused_lean<4,float,133>" if lean else "k_fused_single<4,%d,float,float>" % (1 if args.method == "dlt" else 0))
+    valu_per_64 = 355 if lean else 422      # rocprofv3 SQ_INSTS_VALU per 64 joints (profiles/)
 
     large = None
     if args.large_frames and rank == 0 and world == 1:
@@ -216,14 +303,18 @@ def main():
         bout = bt.alloc_outputs(FL, dev)
         bt.ctx.set_timing(True)
         lms = []
-        for _ in range(5):
+        for _ in range(6):
             bt.run_torch(big, None, out=bout)
             lms.append(bt.ctx.last_kernel_ms()[0])
         bt.ctx.set_timing(False)
         lm = float(np.median(lms[1:]))
-        large = {"frames": FL, "kernel_ms": lm, "joints_per_s": FL * J / (lm * 1e-3),
+        large = {"frames": FL, "kernel_ms": lm, "kernel_ms_all": lms[1:], "joints_per_s": FL * J / (lm * 1e-3),
                  "achieved_GBs": bpf * FL / (lm * 1e-3) / 1e9, "frac": bpf * FL / (lm * 1e-3) / 1e9 / HBM_PEAK_GBS}
         del big, bout
+
+    extra = None
+    if rank == 0 and world == 1 and not args.no_extra and args.method == "pairwise":
+        extra = extra_workloads(torch, dev, local_rank)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -248,17 +339,32 @@ def main():
             rate = sample.shape[0] * reps * J / t_cpu
             if best is None or rate > best[0]:
                 best = (rate, int(r["threads"]), reps, t_cpu)
+        # the oracle as the checker of this run's GPU output: pool batch 0 is the sample's own batch
+        bt.run_torch(pool[0], None, out=outs[0])
+        torch.cuda.synchronize(dev)
+        got = outs[0]["xyzs"][: sample.shape[0]].cpu().numpy().astype(np.float64)
+        err_m = float(np.abs(got[..., :3] - r["xyz"]).max())
+        err_s = float((np.abs(got[..., 3] - r["kscore"]) / np.maximum(np.abs(r["kscore"]), 1e-30)).max())
+        assert err_m < 1e-4, f"GPU joints differ from the oracle by {err_m} m"
         cpu = {"value": best[0], "unit": "joints/s", "cores": best[1], "kind": "port",
                "sample": f"cfg2 batch of {sample.shape[0]} frames x {best[2]} repeats ({best[3]:.1f} s) at the best of "
-                         f"{trials} OpenMP threads ({ncores} logical CPUs visible); oracle/snowtri_oracle.c fp64"}
+                         f"{trials} OpenMP threads ({ncores} logical CPUs visible); oracle/snowtri_oracle.c fp64",
+               "gpu_vs_oracle_max_abs_m": err_m, "gpu_vs_oracle_max_rel_score": err_s}
 
-    traffic = None
+    # HBM bytes per launch from the PMC counters (rocprofv3 FETCH_SIZE / WRITE_SIZE passes, scripts/profile.sh):
+    # only quoted while the kernels are the ones it was measured on.
+    traffic, traffic_note = None, "no PMC measurement on file"
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(pmc_path) and args.method != "dlt":     # the PMC pass was made on the pairwise kernel
+    if os.path.exists(pmc_path) and args.method != "dlt":
         try:
-            traffic = json.load(open(pmc_path)).get("hbm_bytes_per_launch")
+            pj = json.load(open(pmc_path))
+            if pj.get("source_sha256") == kernel_source_hash() and pj.get("frames_per_launch") == F:
+                traffic = pj.get("hbm_bytes_per_launch")
+                traffic_note = "rocprofv3 PMC passes of this kernel source (profiles/pmc_traffic.json: source_sha256 matches)"
+            else:
+                traffic_note = "profiles/pmc_traffic.json was measured on other kernel sources or another launch size: not quoted"
         except Exception:
-            traffic = None
+            pass
 
     line = None
     if rank == 0:
@@ -266,6 +372,11 @@ def main():
             "metric": "joint-triangulations/sec", "value": value, "unit": "joints/s", "n_gpus": world,
             "steps": K_steps, "warmup": W_steps, "ms_per_step": ms_per_step, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "rccl_ranks": dist.get_world_size() if dist is not None else 1,
+            "ranks": ranks_seen,
+            "repeats": {"n": len(regions), "statistic": "median", "ms_per_step_min": min(regions) / K_steps * 1e3,
+                        "ms_per_step_max": max(regions) / K_steps * 1e3,
+                        "ms_per_step_all": [r / K_steps * 1e3 for r in regions]},
             "config": {"workload": "BASELINE configs[1]: 4 cameras x 1 person x 133 joints x "
                                    f"{F} frames per step per GPU, floor rig, default thresholds; "
                                    f"steps cycle a pool of {len(pool)} distinct HBM-resident batches",
@@ -273,20 +384,28 @@ def main():
                        "method": "pairwise (reference-exact)" if args.method == "pairwise" else "dlt (N-view, NOT the reference's algorithm)",
                        "io": "fp32 in / fp32 out, fp64 math",
                        "streams": nstreams,
-                       "parallelism": f"frames sharded x{world}, no data-path collective"},
+                       "parallelism": f"frames sharded x{world}, no data-path collective",
+                       "extra_workloads": None if extra is None else [e["workload"] for e in extra]},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "kernel": "k_fused_single<4,%d,float,float>" % (1 if args.method == "dlt" else 0),
-                         "kernel_ms_mean": kernel_ms, "kernel_ms_min": kernel_ms_min,
+                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic, "traffic_note": traffic_note,
+                         "kernel": kernel_name, "streams": 1,
+                         "how": "HIP events around each launch on the launch stream, launches back to back on one stream",
+                         "kernel_ms_mean": kernel_ms, "kernel_ms_min": kernel_ms_min, "launches": len(kms),
                          "algorithmic_bytes_per_launch": bpf * F, "bytes_per_joint": bpf / (Pout * J)},
-            # the roof that actually binds this kernel: fp64 VALU issue.  422 VALU wave-instructions
-            # per 64 joints (rocprofv3 SQ_INSTS_VALU, profiles/), 4 issue cycles each, 1024 SIMDs at the 2.4 GHz peak clock.
+            "roofline_region": {"bound": "hbm", "achieved": ach_region, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                "frac": ach_region / HBM_PEAK_GBS, "streams": nstreams,
+                                "how": "algorithmic bytes per step / ms_per_step of the timed region (per GPU; "
+                                       f"steps issued round-robin on {nstreams} streams, so consecutive launches overlap)"},
+            # the roof that actually binds this kernel: fp64 VALU issue.  VALU wave-instructions
+            # per 64 joints from rocprofv3 SQ_INSTS_VALU (profiles/), 4 issue cycles each, 1024 SIMDs at the 2.4 GHz peak clock.
             "fp64_valu_issue": None if args.method != "pairwise" else {
-                "valu_insts_per_64_joints": 422, "simds": 1024, "peak_clock_GHz": 2.4,
-                "frac_this_launch": (F * Pout * J / 64.0 * 422 * 4) / (kernel_ms * 1e-3) / (1024 * 2.4e9),
-                "frac_large_batch": None if large is None else (large["joints_per_s"] / 64.0 * 422 * 4) / (1024 * 2.4e9)},
+                "valu_insts_per_64_joints": valu_per_64, "simds": 1024, "peak_clock_GHz": 2.4,
+                "frac_this_launch": (F * Pout * J / 64.0 * valu_per_64 * 4) / (kernel_ms * 1e-3) / (1024 * 2.4e9),
+                "frac_large_batch": None if large is None else (large["joints_per_s"] / 64.0 * valu_per_64 * 4) / (1024 * 2.4e9)},
             "cpu_baseline": cpu,
             "with_track_allgather": with_gather,
             "large_batch": large,
+            "extra_workloads": extra,
             "ray_pair_solves_per_s": value * (C * (C - 1) // 2),
         }
     for b_ in bts:
@@ -305,6 +424,53 @@ def main():
         if world > 1:
             time.sleep(1.0)                                # let the other ranks' exit-time output drain first
         print(json.dumps(line), flush=True)
+
+
+def extra_workloads(torch, dev, device_index):
+    """The multi-person configurations of BASELINE.json on this GPU (k_frame_recompute): configs[2] = 8 cameras x
+    4 persons x 10 000 frames, and one GPU's share of configs[4] = 16 cameras x 8 persons x 12 500 frames.  A few
+    hundred distinct frames are generated on the host and tiled on the device (frames are independent; the kernel
+    is fp64-VALU-bound, SURVEY 8d, so cache residency of the tiled input does not help it).  Roofline: fp64 VALU,
+    algorithmic flops = frames x candidates x joints x 90 flop (one pair solve + score per candidate joint; the
+    kernel's second solve of surviving clusters is not credited)."""
+    from snowmocap_amd import synth
+    from snowmocap_amd.batch import BatchTriangulator
+    res = []
+    for cfg, F, gen_frames, pout, label in (
+            (3, 10000, 1000, 16, "BASELINE configs[2]: 8 cameras x 4 persons x 133 joints x 10 000 frames"),
+            (5, 12500, 250, 32, "BASELINE configs[4] per-GPU share: 16 cameras x 8 persons x 133 joints x 12 500 frames")):
+        wl = synth.config_workload(cfg, gen_frames)
+        K, R, t = wl["rig"]
+        C, P = K.shape[0], wl["kpts"].shape[2]
+        rep = F // gen_frames
+        kp = torch.from_numpy(wl["kpts"]).to(dev).repeat(rep, 1, 1, 1, 1).contiguous()
+        npers = torch.from_numpy(wl["n_persons"]).to(dev).repeat(rep, 1).contiguous()
+        bt = BatchTriangulator(K, R, t, wl["params"], pout_max=pout, out_dtype=np.float32, device=device_index)
+        out = bt.run_torch(kp, npers)
+        torch.cuda.synchronize(dev)
+        bt.ctx.set_timing(True)
+        ms = []
+        for _ in range(5):
+            bt.run_torch(kp, npers, out=out)
+            ms.append(bt.ctx.last_kernel_ms()[0])
+        bt.ctx.set_timing(False)
+        cnt = out["count"].cpu().numpy()
+        m = float(np.median(ms[1:]))
+        kc = C * (C - 1) // 2 * P * P
+        solves = F * kc * J / (m * 1e-3)
+        persons = float(cnt.mean())
+        bpf = 12 * C * P * J + 16 * persons * J
+        tflops = solves * FLOP_PER_SOLVE / 1e12
+        res.append({"workload": label, "kernel": "k_frame_recompute<0,float,float>", "frames": F, "kernel_ms": m,
+                    "kernel_ms_all": ms[1:], "frames_per_s": F / (m * 1e-3),
+                    "output_joints_per_s": float(cnt.clip(max=pout).sum()) * J / (m * 1e-3),
+                    "pair_solves_per_s": solves, "mean_persons_per_frame": persons,
+                    "roofline": {"bound": "fp64_valu", "achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": tflops / FP64_VALU_PEAK_TFLOPS,
+                                 "hbm_GBs": bpf * F / (m * 1e-3) / 1e9, "hbm_frac": bpf * F / (m * 1e-3) / 1e9 / HBM_PEAK_GBS}})
+        bt.close()
+        del kp, npers, out
+    return res
 
 
 if __name__ == "__main__":

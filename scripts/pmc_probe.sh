@@ -4,7 +4,7 @@
 LIB=${1:-snowmocap_amd/libsnowtri.so}; TAG=${2:-probe}
 ROOT=$PWD; OUT=$ROOT/gpurun_out/pmc_$TAG; mkdir -p $OUT
 export TMPDIR=/tmp SNOWTRI_LIB=$ROOT/$LIB
-BENCH="python $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --large-frames 500000"
+BENCH="python $ROOT/bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extra --repeats 3 --large-frames 500000"
 cd /tmp
 rocprofv3 -L 2>/dev/null | grep -oE "\b(SQ_[A-Z0-9_]+|GRBM_[A-Z_]+|TCC_[A-Z0-9_]+\b|TCP_[A-Z0-9_]+)" | sort -u > $OUT/counters.txt
 rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace -d $OUT/a -o a -- $BENCH > $OUT/a.log 2>&1

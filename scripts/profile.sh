@@ -7,8 +7,8 @@ OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 # the bench command whose JSON line the numbers below belong to (configs[1]: 10 000 frames per launch)
-BENCH="python $ROOT/bench.py --streams 1 --steps 200 --warmup 20 --no-cpu-baseline --large-frames 0"   # one stream: launches do not overlap, so the trace duration is the kernel duration
-LARGE="python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --large-frames 2000000"
+BENCH="python $ROOT/bench.py --streams 1 --steps 200 --warmup 20 --no-cpu-baseline --no-extra --repeats 3 --large-frames 0"   # one stream: launches do not overlap, so the trace duration is the kernel duration
+LARGE="python $ROOT/bench.py --steps 5 --warmup 2 --no-cpu-baseline --no-extra --repeats 3 --large-frames 2000000"
 cd /tmp
 # 1. per-kernel time (no counters)
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats -o stats -- $BENCH > $OUT/stats_bench.log 2>&1
