@@ -14,7 +14,10 @@ SIZES = ((3, 2000, 16), (5, 256, 32)) if "--small" in sys.argv else ((3, 10000, 
 REPEAT = {5: 6} if "--full" in sys.argv else {}   # cfg5: 2 000 generated frames tiled to 12 000 = its per-GPU share
 MODES = ("2", "1") if "--spill" in sys.argv else ("2",)
 METHOD = _lib.DLT if "--dlt" in sys.argv else _lib.PAIRWISE
+ONLY = [int(a.split("=")[1]) for a in sys.argv if a.startswith("--only=")]
 for cfg, F, pout in SIZES:
+    if ONLY and cfg not in ONLY:
+        continue
     wl = synth.config_workload(cfg, F)
     K, R, t = wl["rig"]
     C, P = K.shape[0], wl["kpts"].shape[2]

@@ -1,5 +1,5 @@
 #!/bin/bash
-# Dev aid (GPU box): multi-person parity tests + throughput of the BASELINE multi-person shapes.
-timeout 900 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "multi or recompute or g3 or general or cfg or scenario or dlt" 2>&1 | tail -3
-timeout 600 python scripts/bench_configs.py 2>/dev/null | grep '"kernel"'
-timeout 600 python scripts/bench_configs.py 2>/dev/null | grep '"kernel"'
+# GPU box: the multi-person kernel (k_frame_recompute): its parity tests, then the BASELINE multi-person shapes.
+mkdir -p gpurun_out/multi
+timeout 1200 python -m pytest tests/test_gpu_parity.py -x -q -m gpu -k "multi or random or general or workloads or golden or special or dlt" > gpurun_out/multi/tests.log 2>&1; echo "tests rc=$?"; tail -4 gpurun_out/multi/tests.log
+python scripts/bench_configs.py --full 2>&1 | grep "^{"

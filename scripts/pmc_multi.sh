@@ -3,12 +3,16 @@
 ROOT=$PWD; OUT=$ROOT/gpurun_out/pmc_multi; mkdir -p $OUT
 export TMPDIR=/tmp
 cd /tmp
-rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace -d $OUT/a -o a -- python $ROOT/scripts/bench_configs.py > $OUT/a.log 2>&1
-rocprofv3 --output-format csv --pmc GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_SMEM --kernel-trace -d $OUT/b -o b -- python $ROOT/scripts/bench_configs.py > $OUT/b.log 2>&1
+for CFG in 3 5; do
+rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace -d $OUT/a$CFG -o a -- python $ROOT/scripts/bench_configs.py --full --only=$CFG > $OUT/a$CFG.log 2>&1
+rocprofv3 --output-format csv --pmc GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_SMEM --kernel-trace -d $OUT/b$CFG -o b -- python $ROOT/scripts/bench_configs.py --full --only=$CFG > $OUT/b$CFG.log 2>&1
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/s$CFG -o s -- python $ROOT/scripts/bench_configs.py --full --only=$CFG > $OUT/s$CFG.log 2>&1
+cp $(find $OUT/s$CFG -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_cfg$CFG.csv
+done
 cd $ROOT
 python - <<PY
 import csv, glob, collections
-for tag in "ab":
+for tag in ("a3", "b3", "a5", "b5"):
     for path in glob.glob("$OUT/%s/**/*counter_collection.csv" % tag, recursive=True):
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(path)):
@@ -18,5 +22,6 @@ for tag in "ab":
         for g, c in acc.items():
             print(tag, g, {k: "%.4g" % (sum(v) / len(v)) for k, v in c.items()}, "n=%d" % len(next(iter(c.values()))))
 PY
-grep -h "^{" $OUT/a.log | head -8
-rm -rf $OUT/a $OUT/b
+grep -h "^{" $OUT/a3.log $OUT/a5.log | head -8
+for t in a3 b3 a5 b5; do mkdir -p $OUT/csv; cp $(find $OUT/$t -name "*counter_collection.csv" | head -1) $OUT/csv/pmc_$t.csv 2>/dev/null; done
+rm -rf $OUT/a3 $OUT/b3 $OUT/a5 $OUT/b5 $OUT/s3 $OUT/s5

@@ -1135,7 +1135,9 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax
     const int64_t Kc = snowtri_num_candidate_slots(ctx->C, Pmax);
     const int R = ctx->C * Pmax;
     const size_t per_block = recompute_scratch_bytes(Kc, R, prm.kn);
-    const size_t lds = recompute_lds_bytes(R, J, prm.kn, (int)sizeof(TIn));
+    // three workgroups per CU share the 160 KB of LDS: each takes 52 KB, what the ray chunk and the tables leave
+    // of it holds the member words of phase 3
+    const size_t lds = std::max<size_t>(recompute_lds_bytes(R, J, prm.kn, (int)sizeof(TIn), ctx->npairs), (size_t)52 * 1024);
     auto kern = k_frame_recompute<METHOD, TIn, TOut>;
     if (lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1143,6 +1145,7 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax
     // they pull frames from an atomic counter until none are left
     int per_cu = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, lds));
+    if (getenv("SNOWTRI_DEBUG")) fprintf(stderr, "k_frame_recompute: R %d Kc %lld lds %zu occupancy/CU %d\n", R, (long long)Kc, lds, per_cu);
     if (const char *e = getenv("SNOWTRI_RECOMPUTE_WG_PER_CU")) per_cu = atoi(e);
     int64_t grid = std::min<int64_t>(F, (int64_t)ctx->num_cus * std::max(1, per_cu));
     grid = std::max<int64_t>(1, std::min<int64_t>(grid, (int64_t)(kMaxScratchBytes / per_block)));
@@ -1151,7 +1154,7 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax
     unsigned long long *next_frame = ctx->d_counters + 2;
     HIP_TRY(hipMemsetAsync(next_frame, 0, sizeof(unsigned long long), st));
     hipLaunchKernelGGL(kern, dim3((int)grid), dim3(kBlock), lds, st, F, Pmax, J, (int)Kc, ctx->rig(), d_kpts, d_np,
-                       prm, Pout, d_xyzs, d_ps, d_cnt, d_fl, (char *)ctx->work.p, per_block, next_frame);
+                       prm, Pout, d_xyzs, d_ps, d_cnt, d_fl, (char *)ctx->work.p, per_block, next_frame, (int)lds);
     HIP_TRY(hipGetLastError());
     return SNOWTRI_OK;
 }
@@ -1175,7 +1178,9 @@ int fused_dispatch(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax, int J,
     int rc;
     if (method == SNOWTRI_DLT && (Pmax > 1 || C > 8)) {
         // several detections per camera: the reference's association (phases 1-2), then DLT per cluster
-        if (prm.kn > kRecomputeMaxKn || recompute_chunk_joints(C * Pmax, J, (int)sizeof(TIn)) < 1) return SNOWTRI_ERR_BAD_ARG;
+        if (prm.kn > kRecomputeMaxKn || recompute_chunk_joints(C * Pmax, J, (int)sizeof(TIn)) < 1 || C * Pmax > 1024 ||
+            ctx->npairs > kPairTabMaxPairs)
+            return SNOWTRI_ERR_BAD_ARG;
         rc = launch_frame_recompute<1, TIn, TOut>(ctx, st, F, Pmax, J, d_kpts, d_np, prm, Pout, d_xyzs, d_ps, d_cnt, d_fl);
     } else if (method == SNOWTRI_DLT) {
         switch (C) {  // one detection per camera: no association needed
@@ -1230,7 +1235,8 @@ int fused_dispatch(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax, int J,
 #undef SNOWTRI_CASE
             default: rc = SNOWTRI_ERR_BAD_ARG;
         }
-    } else if (prm.kn <= kRecomputeMaxKn && recompute_chunk_joints(C * Pmax, J, (int)sizeof(TIn)) >= 1 &&
+    } else if (prm.kn <= kRecomputeMaxKn && recompute_chunk_joints(C * Pmax, J, (int)sizeof(TIn)) >= 1 && C * Pmax <= 1024 &&
+               ctx->npairs <= kPairTabMaxPairs &&
                ctx->general_mode != 1) {
         rc = launch_frame_recompute<0, TIn, TOut>(ctx, st, F, Pmax, J, d_kpts, d_np, prm, Pout, d_xyzs, d_ps, d_cnt, d_fl);
     } else {

@@ -20,7 +20,8 @@
 namespace snowtri {
 
 constexpr int kRecomputeMaxKn = 256;          // keypoint_num bound: one thread per joint in the DLT phase, chunk joints x groups <= 256
-constexpr int kRayChunkBytes = 48 * 1024;     // LDS budget for one chunk of rays (3 workgroups per CU: 3 x 48.3 KB <= 160 KB)
+constexpr int kRayChunkBytes = 40 * 1024;     // LDS budget for one chunk of rays + scores (the power-of-two joint count rarely needs more); the tables follow at this fixed offset
+constexpr int kPairTabMaxPairs = 120;         // camera pairs whose constants (d, t_m + t_s, camera indices) also live in LDS: <= 16 cameras
 
 constexpr int kRecomputeSlotTile = 64;        // fused persons whose joint scores are parked per sweep (phase 3)
 
@@ -31,19 +32,116 @@ __host__ __device__ constexpr size_t recompute_scratch_bytes(int64_t Kc, int R, 
 // LDS layout of one joint chunk (Jc joints): rays[R][Jc] with a row stride of 32 Jc + 16 bytes and scores[R][Jc | 1]:
 // a lane walks the joints of ITS candidate's two rows with compile-time offsets (no address arithmetic in the
 // solve loop), and the odd strides (in 16-byte / 4-byte units) spread the rows of neighbouring lanes over the banks.
+// Joints per chunk: what fits the budget, rounded DOWN to a power of two -- phase 3 maps thread = (joint of the chunk,
+// member group of G lanes) with G a power of two and joints x G <= 256, so only a power-of-two chunk fills the workgroup
+// (42 joints x 4 lanes = 168 of 256 threads at 8 cameras x 4 persons; 32 x 8 = 256).
 __host__ __device__ inline int recompute_chunk_joints(int R, int J, int score_bytes) {
     const int per_row = kRayChunkBytes / R - 16 - score_bytes;
     int jc = per_row / (32 + score_bytes);
-    return jc < 1 ? 0 : (jc > J ? J : jc);
+    if (jc < 1) return 0;
+    int p2 = 1;
+    while (2 * p2 <= jc && 2 * p2 <= 256) p2 *= 2;
+    return p2 > J ? J : p2;
 }
 __host__ __device__ inline size_t recompute_ray_stride(int Jc) { return (size_t)32 * Jc + 16; }
 __host__ __device__ inline int recompute_score_stride(int Jc) { return Jc | 1; }
 
-__host__ __device__ inline size_t recompute_lds_bytes(int R, int J, int kn, int score_bytes) {
-    const int jc = recompute_chunk_joints(R, J, score_bytes);
-    const size_t chunk = (size_t)R * (recompute_ray_stride(jc) + (size_t)recompute_score_stride(jc) * score_bytes);
-    (void)kn;
-    return ((chunk + 15) & ~(size_t)15) + 256;   // + block-reduction slots and flags
+// bytes of the LDS pair table (6 doubles + 2 int32 per pair); the kernel needs npairs <= kPairTabMaxPairs
+__host__ __device__ inline size_t recompute_pairtab_bytes(int npairs) { return (size_t)npairs * 56; }
+// LDS of k_frame_recompute: [ray chunk: kRayChunkBytes][reduction slots + flags: 256 B][pair table: 56 B per pair]
+// [member words of phase 3: the rest].
+// The launcher asks for at least 52 KB (three workgroups per CU share 160 KB).
+__host__ __device__ inline size_t recompute_lds_bytes(int R, int J, int kn, int score_bytes, int npairs) {
+    (void)J; (void)kn; (void)score_bytes;
+    (void)R;
+    return (size_t)kRayChunkBytes + 256 + recompute_pairtab_bytes(npairs) + 16;
+}
+
+// ---- phase-1 work of ONE candidate on one joint chunk: sum over the chunk's joints of 2000 x the pair score
+// (triangulation.py:70-78 without the 1/2000 of :72, applied by the caller).
+//   EXACT = true   the arithmetic the kernel has always used: 1/dist by v_rsq_f64 + one Newton step (2e-14), exact
+//                  intersection -> inf, four joints share one reciprocal unless their determinants' product leaves the
+//                  normal range (singular pairs are detected there).
+//   EXACT = false  the same solves with the raw v_rsq_f64 (2^-22 relative) and no range check -- 36 instead of 57 VALU
+//                  instructions per solve.  Its sum decides only whether the candidate is KEPT (:79-81; the scores that
+//                  are output come from phase 3): the caller re-does a candidate with EXACT = true when its mean is not
+//                  finite (singular pair, exact intersection, NaN input) or lies within 1e-6 relative of
+//                  average_score_threshold, so the decision is always taken on the accurate sum.  The gates (:73-74)
+//                  do not involve 1/dist and d2 is computed identically in both variants: a sum of exactly 0 is exact.
+template <bool EXACT, typename TIn>
+__device__ __forceinline__ double candidate_chunk_sum(const RayRec *__restrict__ ra, const RayRec *__restrict__ rb,
+                                                      const TIn *__restrict__ sa, const TIn *__restrict__ sb, int nj,
+                                                      const Vec3 &d, const Params &prm, bool &sing) {
+    double acc = 0.0;
+    // one solve, reciprocal of the determinant supplied (A2 + the score of :72-74)
+    auto finish = [&](const RayRec &a, const RayRec &b, double bq, double e, double g, double inv, TIn sm, TIn ss) {
+        const double S0 = fma(b.a, e, -(bq * g)) * inv;
+        const double S1 = fma(a.a, g, -(bq * e)) * inv;
+        const Vec3 df = {fma(b.x, S1, fma(a.x, S0, -d.x)), fma(b.y, S1, fma(a.y, S0, -d.y)),
+                         fma(b.z, S1, fma(a.z, S0, -d.z))};
+        const double d2 = dot3(df, df);
+        const bool kp_ = !below_kthr(sm, prm) && !below_kthr(ss, prm) && !(d2 > prm.dthr2);  // :73-74
+        if constexpr (EXACT) {
+            double idist = rsq_nr1(d2);
+            idist = (d2 == 0.0) ? __builtin_inf() : idist;
+            // the gate ASSIGNS 0 (:73-74): select after the product, 0 * inf (exact intersection) would be NaN
+            acc += kp_ ? sum_score(sm, ss) * idist : 0.0;                                     // :72
+        } else {
+            // 0 * inf / 0 * NaN leave NaN in the sum: the caller then re-does the candidate exactly
+            acc = fma(gated_sum(sm, ss, kp_), __builtin_amdgcn_rsq(d2), acc);
+        }
+    };
+    int jj = 0;
+    // four joints at a time share ONE reciprocal (Montgomery): v_rcp_f64 issues at quarter rate.
+    for (; jj + 4 <= nj; jj += 4) {
+        RayRec a[4], b[4];
+        TIn sm[4], ss[4];
+        double bq[4], e[4], g[4], det[4], inv[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            a[u] = ra[jj + u];
+            b[u] = rb[jj + u];
+            sm[u] = sa[jj + u];
+            ss[u] = sb[jj + u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            bq[u] = fma(a[u].z, b[u].z, fma(a[u].y, b[u].y, a[u].x * b[u].x));
+            e[u] = fma(a[u].z, d.z, fma(a[u].y, d.y, a[u].x * d.x));
+            g[u] = fma(b[u].z, d.z, fma(b[u].y, d.y, b[u].x * d.x));
+            det[u] = fma(a[u].a, b[u].a, -(bq[u] * bq[u]));
+        }
+        const double p01 = det[0] * det[1], p012 = p01 * det[2], p0123 = p012 * det[3];
+        // EXACT: a product outside the normal range (a singular or wildly conditioned pair in the group) falls back to
+        // four separate reciprocals; the fast variant lets it poison the sum instead
+        if (!EXACT || (fabs(p0123) > 1e-250 && fabs(p0123) < 1e250)) {
+            double run = rcp_nr2(p0123);
+            inv[3] = run * p012;
+            run *= det[3];
+            inv[2] = run * p01;
+            run *= det[2];
+            inv[1] = run * det[0];
+            inv[0] = run * det[1];
+        } else {   // includes every exactly singular pair (product 0): flagged here, off the common path
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                inv[u] = rcp_nr2(det[u]);
+                sing |= det[u] == 0.0;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) finish(a[u], b[u], bq[u], e[u], g[u], inv[u], sm[u], ss[u]);
+    }
+    for (; jj < nj; jj++) {
+        const RayRec a = ra[jj], b = rb[jj];
+        const double bq = fma(a.z, b.z, fma(a.y, b.y, a.x * b.x));
+        const double e = fma(a.z, d.z, fma(a.y, d.y, a.x * d.x));
+        const double g = fma(b.z, d.z, fma(b.y, d.y, b.x * d.x));
+        const double det = fma(a.a, b.a, -(bq * bq));
+        if (EXACT) sing |= det == 0.0;
+        finish(a, b, bq, e, g, rcp_nr2(det), sa[jj], sb[jj]);
+    }
+    return acc;
 }
 
 // Dynamic LDS = recompute_lds_bytes(R, J, kn, sizeof(TIn)); scratch = gridDim.x slabs of
@@ -72,7 +170,7 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
                                                             int32_t *__restrict__ out_count,
                                                             uint32_t *__restrict__ out_flags, char *scratch,
                                                             size_t scratch_per_block,
-                                                            unsigned long long *next_frame) {
+                                                            unsigned long long *next_frame, int lds_total) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int C = rig.C, R = C * Pmax, pp = Pmax * Pmax;
@@ -82,9 +180,18 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
     const int sstride = recompute_score_stride(Jc);             // elements between the score rows
     char *rays = smem;                                          // [R] rows of Jc RayRec (+16 B pad)
     TIn *rsc = reinterpret_cast<TIn *>(smem + (size_t)R * rstride);                      // [R][sstride]
-    double *red = reinterpret_cast<double *>(
-        smem + ((((size_t)R * (rstride + (size_t)sstride * sizeof(TIn))) + 15) & ~(size_t)15));  // [4] + misc
+    double *red = reinterpret_cast<double *>(smem + kRayChunkBytes);  // [4] + misc, at a fixed offset behind the chunk
     int32_t *misc = reinterpret_cast<int32_t *>(red + kBlock / 64);
+    // camera-pair constants in LDS: d = t_s - t_m, t_m + t_s (6 doubles) and the two camera indices -- the solve loops
+    // index them per lane (host-checked: npairs <= kPairTabMaxPairs, i.e. <= 16 cameras; larger rigs take k_frame_general)
+    double *pairc = reinterpret_cast<double *>(reinterpret_cast<char *>(red) + 256);
+    int32_t *pairs = reinterpret_cast<int32_t *>(pairc + 6 * rig.npairs);
+    for (int i = tid; i < 6 * rig.npairs; i += kBlock) pairc[i] = rig.pairc[i];
+    for (int i = tid; i < 2 * rig.npairs; i += kBlock) pairs[i] = rig.pairs[i];
+    // what is left of the workgroup's LDS allocation holds the member words of phase 3
+    uint32_t *lmem_lds = reinterpret_cast<uint32_t *>(pairs + 2 * rig.npairs);
+    const int lmem_cap = (int)((lds_total - (int)(reinterpret_cast<char *>(lmem_lds) - smem)) / 4);
+    const bool exact_only = prm.kthr < 0.0;   // negative scores may pass the keypoint gate: no relative error bound on a sum
 
     // per-workgroup bookkeeping slab (global, reused frame after frame)
     char *slab = scratch + (size_t)blockIdx.x * scratch_per_block;
@@ -97,6 +204,10 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
     int32_t *members = cseed + Kc;                                  // [Kc] kept indices grouped by cluster
     int32_t *cstart = members + Kc;                                 // [Kc + 1]
     uint8_t *keep = reinterpret_cast<uint8_t *>(cstart + Kc + 1);   // [Kc]
+    // [Kc] this frame's candidates: ray rows rm | rs << 10 and camera pair q << 20 (host-checked: R <= 1024,
+    // npairs <= kPairTabMaxPairs), or kNoCand where a camera lists fewer persons than the slot's
+    uint32_t *cw = reinterpret_cast<uint32_t *>(slab + (((size_t)Kc * 57 + 4 + 3) & ~(size_t)3));
+    constexpr uint32_t kNoCand = 0xffffffffu;
     int32_t *rowlist = reinterpret_cast<int32_t *>(slab + (((size_t)Kc * 64 + 1024) & ~(size_t)7));  // [R] (DLT)
     int32_t *rowflag = rowlist + R;                                                                   // [R] (DLT)
     double *osbuf = reinterpret_cast<double *>(rowflag + R);   // [kRecomputeSlotTile][kn] fused joint scores
@@ -115,7 +226,15 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
         if (f >= F) break;
         const int32_t *np_f = n_persons ? n_persons + f * C : nullptr;
         const Kp3<TIn> *kpf = kp3 + f * (int64_t)R * J;
-        for (int k = tid; k < Kc; k += kBlock) sum[k] = 0.0;
+        for (int k = tid; k < Kc; k += kBlock) {
+            sum[k] = 0.0;
+            // candidate order of triangulation.py:56-65: camera pair, person of the first camera, person of the second
+            const int q = k / pp, rr = k - q * pp, pm = rr / Pmax, ps = rr - pm * Pmax;
+            const int mc = pairs[2 * q], sc = pairs[2 * q + 1];
+            const int nm = np_f ? np_f[mc] : Pmax, ns = np_f ? np_f[sc] : Pmax;
+            cw[k] = (pm < nm && ps < ns) ? ((uint32_t)(mc * Pmax + pm) | ((uint32_t)(sc * Pmax + ps) << 10) | ((uint32_t)q << 20))
+                                         : kNoCand;
+        }
         if (tid == 0 && out_flags) out_flags[f] = 0u;
         bool sing = false;
 
@@ -135,96 +254,76 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
             }
             __syncthreads();
             for (int k = tid; k < Kc; k += kBlock) {
-                const int q = k / pp, rr = k - q * pp, pm = rr / Pmax, ps = rr - pm * Pmax;
-                const int mc = rig.pairs[2 * q], sc = rig.pairs[2 * q + 1];
-                const int nm = np_f ? np_f[mc] : Pmax, ns = np_f ? np_f[sc] : Pmax;
-                if (pm >= nm || ps >= ns) continue;
-                const int rm = mc * Pmax + pm, rs = sc * Pmax + ps;
-                const double *pc = rig.pairc + 6 * q;
+                const uint32_t w = cw[k];
+                if (w == kNoCand) continue;
+                const int rm = (int)(w & 1023u), rs = (int)((w >> 10) & 1023u), q = (int)(w >> 20);
+                const double *pc = pairc + 6 * q;
                 const Vec3 d = {pc[0], pc[1], pc[2]};
                 const RayRec *ra = reinterpret_cast<const RayRec *>(rays + rm * rstride);
                 const RayRec *rb = reinterpret_cast<const RayRec *>(rays + rs * rstride);
                 const TIn *sa = rsc + rm * sstride, *sb = rsc + rs * sstride;
-                double acc = 0.0;
-                // one solve, reciprocal of the determinant supplied (A2 + the score of :72-74)
-                auto finish = [&](const RayRec &a, const RayRec &b, double bq, double e, double g, double inv, TIn sm,
-                                  TIn ss) {
-                    const double S0 = fma(b.a, e, -(bq * g)) * inv;
-                    const double S1 = fma(a.a, g, -(bq * e)) * inv;
-                    const Vec3 df = {fma(b.x, S1, fma(a.x, S0, -d.x)), fma(b.y, S1, fma(a.y, S0, -d.y)),
-                                     fma(b.z, S1, fma(a.z, S0, -d.z))};
-                    const double d2 = dot3(df, df);
-                    double idist = rsq_nr1(d2);
-                    idist = (d2 == 0.0) ? __builtin_inf() : idist;
-                    const bool kp_ = !below_kthr(sm, prm) && !below_kthr(ss, prm) && !(d2 > prm.dthr2);  // :73-74
-                    // the gate ASSIGNS 0 (:73-74): select after the product, 0 * inf (exact intersection) would be NaN
-                    acc += kp_ ? sum_score(sm, ss) * (idist * 0.0005) : 0.0;                         // :72
-                };
-                int jj = 0;
-                // four joints at a time share ONE reciprocal (Montgomery): v_rcp_f64 issues at quarter rate.
-                // A product outside the normal range (a singular or wildly conditioned pair in the group)
-                // falls back to four separate reciprocals.
-                for (; jj + 4 <= nj; jj += 4) {
-                    RayRec a[4], b[4];
-                    TIn sm[4], ss[4];
-                    double bq[4], e[4], g[4], det[4], inv[4];
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        a[u] = ra[jj + u];
-                        b[u] = rb[jj + u];
-                        sm[u] = sa[jj + u];
-                        ss[u] = sb[jj + u];
+                const double acc = exact_only ? candidate_chunk_sum<true>(ra, rb, sa, sb, nj, d, prm, sing)
+                                              : candidate_chunk_sum<false>(ra, rb, sa, sb, nj, d, prm, sing);
+                sum[k] += acc * 0.0005;   // the 1 / (2 * 1000) of :72
+            }
+        }
+        // candidates whose fast sum cannot decide :80-81 (see candidate_chunk_sum): not finite, or within 1e-6 relative
+        // of average_score_threshold (the fast sum is within 2.4e-7 of the accurate one).  Rare: a second sweep over the
+        // joint chunks re-does just those with the accurate arithmetic; exactly singular pairs are flagged there.
+        int redo_any = 0;
+        if (!exact_only) {
+            __syncthreads();
+            for (int k = tid; k < Kc; k += kBlock) {
+                const double s_ = sum[k], mean = s_ / (double)J;
+                const bool redo = !(fabs(mean) < 1e300) || (s_ != 0.0 && fabs(mean - prm.avg_thr) <= 1e-6 * fabs(mean));
+                keep[k] = redo ? 2 : 0;      // (invalid slots hold sum 0: never re-done)
+                redo_any |= redo ? 1 : 0;
+            }
+            redo_any = __syncthreads_or(redo_any);
+        }
+        if (redo_any) {
+            for (int k = tid; k < Kc; k += kBlock)
+                if (keep[k] == 2) sum[k] = 0.0;
+            for (int j0 = 0; j0 < J; j0 += Jc) {
+                const int nj = (J - j0) < Jc ? (J - j0) : Jc;
+                __syncthreads();
+                for (int i = tid; i < R * nj; i += kBlock) {
+                    const int r = i / nj, jj = i - r * nj;
+                    const int c = r / Pmax, p = r - c * Pmax;
+                    const int nc = np_f ? np_f[c] : Pmax;
+                    if (p < nc) {
+                        const Kp3<TIn> kp = kpf[(size_t)r * J + j0 + jj];
+                        *reinterpret_cast<RayRec *>(rays + r * rstride + 32 * jj) = make_ray(rig.M + 9 * c, kp.u, kp.v);
+                        rsc[r * sstride + jj] = kp.s;
                     }
-#pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        bq[u] = fma(a[u].z, b[u].z, fma(a[u].y, b[u].y, a[u].x * b[u].x));
-                        e[u] = fma(a[u].z, d.z, fma(a[u].y, d.y, a[u].x * d.x));
-                        g[u] = fma(b[u].z, d.z, fma(b[u].y, d.y, b[u].x * d.x));
-                        det[u] = fma(a[u].a, b[u].a, -(bq[u] * bq[u]));
-                    }
-                    const double p01 = det[0] * det[1], p012 = p01 * det[2], p0123 = p012 * det[3];
-                    if (fabs(p0123) > 1e-250 && fabs(p0123) < 1e250) {
-                        double run = rcp_nr2(p0123);
-                        inv[3] = run * p012;
-                        run *= det[3];
-                        inv[2] = run * p01;
-                        run *= det[2];
-                        inv[1] = run * det[0];
-                        inv[0] = run * det[1];
-                    } else {   // includes every exactly singular pair (product 0): flagged here, off the common path
-#pragma unroll
-                        for (int u = 0; u < 4; u++) {
-                            inv[u] = rcp_nr2(det[u]);
-                            sing |= det[u] == 0.0;
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; u++) finish(a[u], b[u], bq[u], e[u], g[u], inv[u], sm[u], ss[u]);
                 }
-                for (; jj < nj; jj++) {
-                    const RayRec a = ra[jj], b = rb[jj];
-                    const double bq = fma(a.z, b.z, fma(a.y, b.y, a.x * b.x));
-                    const double e = fma(a.z, d.z, fma(a.y, d.y, a.x * d.x));
-                    const double g = fma(b.z, d.z, fma(b.y, d.y, b.x * d.x));
-                    const double det = fma(a.a, b.a, -(bq * bq));
-                    sing |= det == 0.0;
-                    finish(a, b, bq, e, g, rcp_nr2(det), sa[jj], sb[jj]);
+                __syncthreads();
+                for (int k = tid; k < Kc; k += kBlock) {
+                    if (keep[k] != 2) continue;
+                    const uint32_t w = cw[k];
+                    const int rm = (int)(w & 1023u), rs = (int)((w >> 10) & 1023u), q = (int)(w >> 20);
+                    const double *pc = pairc + 6 * q;
+                    const Vec3 d = {pc[0], pc[1], pc[2]};
+                    sum[k] += candidate_chunk_sum<true>(reinterpret_cast<const RayRec *>(rays + rm * rstride),
+                                                        reinterpret_cast<const RayRec *>(rays + rs * rstride), rsc + rm * sstride,
+                                                        rsc + rs * sstride, nj, d, prm, sing) * 0.0005;
                 }
-                sum[k] += acc;
             }
         }
         __syncthreads();
         if (sing && out_flags) atomicOr(&out_flags[f], 1u /*SNOWTRI_FLAG_SINGULAR*/);
         for (int k = tid; k < Kc; k += kBlock) {
-            const int q = k / pp, rr = k - q * pp, pm = rr / Pmax, ps = rr - pm * Pmax;
-            const int mc = rig.pairs[2 * q], sc = rig.pairs[2 * q + 1];
-            const int nm = np_f ? np_f[mc] : Pmax, ns = np_f ? np_f[sc] : Pmax;
-            const bool valid = pm < nm && ps < ns;
+            const bool valid = cw[k] != kNoCand;
             const double mean = sum[k] / (double)J;                                               // :79
             keep[k] = (valid && !(mean < prm.avg_thr)) ? 1 : 0;                                   // :80-81
         }
         __syncthreads();
 
+#ifdef SNOWTRI_REC_STOP_AFTER_P1  // dev experiment (timing only, outputs are wrong): phase 1 alone
+        if (tid == 0) out_count[f] = 0;
+        __syncthreads();
+        continue;
+#endif
         // ---------------- phase 2: kept list, centre joints, greedy clustering -------------------
         if (tid < 64) {
             int n = 0;
@@ -242,16 +341,16 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
         // The clustering below is one wave walking the kept list: every step is a dependent load, so it runs
         // at memory LATENCY.  While it runs the ray chunk is idle: if the centres (24 B) and cluster ids (4 B) of
         // the n kept candidates fit there they live in LDS (~8x lower latency than the L2-resident slab).
-        const size_t chunk_bytes = (size_t)R * (rstride + (size_t)sstride * sizeof(TIn));
+        const size_t chunk_bytes = (size_t)kRayChunkBytes;
         const bool in_lds = (size_t)n * 28 + 16 <= chunk_bytes;
         auto phase2 = [&](int32_t *cof, double *cen) {
             for (int i = tid; i < n; i += kBlock) {
-                const int k = kidx[i];
-                const int q = k / pp, rr = k - q * pp, pm = rr / Pmax, ps = rr - pm * Pmax;
-                const int mc = rig.pairs[2 * q], sc = rig.pairs[2 * q + 1];
-                const Kp3<TIn> km = kpf[(size_t)(mc * Pmax + pm) * J + ci], ks = kpf[(size_t)(sc * Pmax + ps) * J + ci];
+                const uint32_t w = cw[kidx[i]];
+                const int rm = (int)(w & 1023u), rs = (int)((w >> 10) & 1023u), q = (int)(w >> 20);
+                const int mc = pairs[2 * q], sc = pairs[2 * q + 1];
+                const Kp3<TIn> km = kpf[(size_t)rm * J + ci], ks = kpf[(size_t)rs * J + ci];
                 const RayRec a = make_ray(rig.M + 9 * mc, km.u, km.v), b = make_ray(rig.M + 9 * sc, ks.u, ks.v);
-                const double *pc = rig.pairc + 6 * q;
+                const double *pc = pairc + 6 * q;
                 const PairSolve o = pair_solve_fast<true>(a, b, Vec3{pc[0], pc[1], pc[2]}, Vec3{pc[3], pc[4], pc[5]});
                 cen[3 * i] = 0.5 * o.sw.x;
                 cen[3 * i + 1] = 0.5 * o.sw.y;
@@ -321,6 +420,11 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
         __syncthreads();
         const int ncl = misc[1];
 
+#ifdef SNOWTRI_REC_STOP_AFTER_P2  // dev experiment (timing only, outputs are wrong): phases 1 + 2
+        if (tid == 0) out_count[f] = 0;
+        __syncthreads();
+        continue;
+#endif
         // ---------------- phase 3: fusion per surviving cluster ------------------------------
         int nout = 0;
         if constexpr (METHOD == 1) {
@@ -335,8 +439,8 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
                 for (int mi = tid; mi < size; mi += kBlock) {
                     const int k = kidx[members[m0 + mi]];
                     const int q = k / pp, rr = k - q * pp, pm = rr / Pmax, ps = rr - pm * Pmax;
-                    rowflag[rig.pairs[2 * q] * Pmax + pm] = 1;
-                    rowflag[rig.pairs[2 * q + 1] * Pmax + ps] = 1;
+                    rowflag[pairs[2 * q] * Pmax + pm] = 1;
+                    rowflag[pairs[2 * q + 1] * Pmax + ps] = 1;
                 }
                 __syncthreads();
                 if (tid < 64) {
@@ -396,16 +500,21 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
             // traffic and NO barrier per cluster.  Joints go straight to their output slot, assigned in cluster
             // order to the clusters that pass the size filter; their scores are parked in `osbuf` (up to
             // kRecomputeSlotTile persons per sweep) for the mean-score filter, applied at the end by compacting.
-            int32_t *crows = reinterpret_cast<int32_t *>(centre);   // [n]  rm | rs << 16, cluster-member order
-            int32_t *cq = crows + Kc;                               // [n]  camera pair
-            int32_t *cslot = cq + Kc;                               // [ncl] preliminary output slot or -1
+            // One word per member (its candidate word), cluster-member order; in LDS when the list fits what the
+            // workgroup's allocation has left (read once per member solve: from the L2-resident slab every one of
+            // them costs a memory round trip), else in the slab.
+            uint32_t *cmem = reinterpret_cast<uint32_t *>(centre);    // [n]
+            int32_t *cslot = reinterpret_cast<int32_t *>(cmem + Kc);  // [ncl] preliminary output slot or -1
             const int nmem = cstart[ncl];   // members of all clusters (<= n: the last candidate never seeds, :107)
+            const bool mem_in_lds = nmem <= lmem_cap;
             for (int pos = tid; pos < nmem; pos += kBlock) {
-                const int k = kidx[members[pos]];
-                const int q = k / pp, rr = k - q * pp, pm = rr / Pmax, ps = rr - pm * Pmax;
-                crows[pos] = (rig.pairs[2 * q] * Pmax + pm) | ((rig.pairs[2 * q + 1] * Pmax + ps) << 16);
-                cq[pos] = q;
+                const uint32_t w = cw[kidx[members[pos]]];
+                if (mem_in_lds)
+                    lmem_lds[pos] = w;
+                else
+                    cmem[pos] = w;
             }
+            const uint32_t *memw = mem_in_lds ? lmem_lds : cmem;   // generic pointer
             if (tid < 64) {
                 int ns = 0;
                 for (int base = 0; base < ncl; base += 64) {
@@ -448,20 +557,42 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
                         const int size = csize[cid], m0 = cstart[cid];
                         double aS = 0.0, aX = 0.0, aY = 0.0, aZ = 0.0;
                         for (int mi = g; mi < size && active; mi += G) {
-                            const int rw = crows[m0 + mi], q = cq[m0 + mi];
-                            const int rm = rw & 0xffff, rs = rw >> 16;
-                            const double *pc = rig.pairc + 6 * q;
+                            const uint32_t mw = memw[m0 + mi];
+                            const int rm = (int)(mw & 1023u), rs = (int)((mw >> 10) & 1023u), q = (int)(mw >> 20);
+                            const double *pc = pairc + 6 * q;
                             const Vec3 d = {pc[0], pc[1], pc[2]}, tsum = {pc[3], pc[4], pc[5]};
                             const RayRec a = *reinterpret_cast<const RayRec *>(rays + rm * rstride + 32 * jc);
                             const RayRec b = *reinterpret_cast<const RayRec *>(rays + rs * rstride + 32 * jc);
                             const TIn sm = rsc[rm * sstride + jc], ss = rsc[rs * sstride + jc];
-                            const PairSolve o = pair_solve_fast<true>(a, b, d, tsum);
-                            const bool kp_ = !below_kthr(sm, prm) && !below_kthr(ss, prm) && !(o.d2 > prm.dthr2);
-                            const double sq = kp_ ? sum_score(sm, ss) * (0.5 * o.score_base) : 0.0;    // gate assigns 0
+                            double sq;
+                            Vec3 sw;
+                            if constexpr (sizeof(TOut) == 4) {
+                                // float32 outputs: 1/dist is the raw v_rsq_f64 (2^-22 relative, below the float32 rounding
+                                // of the stored score: same contract as k_fused_lean); sq = 2000 x the score of :72
+                                const double bq = fma(a.z, b.z, fma(a.y, b.y, a.x * b.x));
+                                const double e = fma(a.z, d.z, fma(a.y, d.y, a.x * d.x));
+                                const double g_ = fma(b.z, d.z, fma(b.y, d.y, b.x * d.x));
+                                const double inv = rcp_nr2(fma(a.a, b.a, -(bq * bq)));
+                                const double S0 = fma(b.a, e, -(bq * g_)) * inv;
+                                const double S1 = fma(a.a, g_, -(bq * e)) * inv;
+                                const double fx = fma(b.x, S1, fma(a.x, S0, -d.x)), fy = fma(b.y, S1, fma(a.y, S0, -d.y)),
+                                             fz = fma(b.z, S1, fma(a.z, S0, -d.z));
+                                const double d2 = fma(fz, fz, fma(fy, fy, fx * fx));
+                                const bool kp_ = !below_kthr(sm, prm) && !below_kthr(ss, prm) && !(d2 > prm.dthr2);
+                                // the gate ASSIGNS 0 (:73-74): select after the product (0 * inf at an exact intersection)
+                                sq = kp_ ? sum_score(sm, ss) * __builtin_amdgcn_rsq(d2) : 0.0;
+                                sw = {fma(-b.x, S1, fma(a.x, S0, tsum.x)), fma(-b.y, S1, fma(a.y, S0, tsum.y)),
+                                      fma(-b.z, S1, fma(a.z, S0, tsum.z))};
+                            } else {
+                                const PairSolve o = pair_solve_fast<true>(a, b, d, tsum);
+                                const bool kp_ = !below_kthr(sm, prm) && !below_kthr(ss, prm) && !(o.d2 > prm.dthr2);
+                                sq = kp_ ? sum_score(sm, ss) * (0.5 * o.score_base) : 0.0;             // gate assigns 0
+                                sw = o.sw;
+                            }
                             aS += sq;                                                              // :141
-                            aX = fma(sq, o.sw.x, aX);                                              // :144-147
-                            aY = fma(sq, o.sw.y, aY);
-                            aZ = fma(sq, o.sw.z, aZ);
+                            aX = fma(sq, sw.x, aX);                                                // :144-147
+                            aY = fma(sq, sw.y, aY);
+                            aZ = fma(sq, sw.z, aZ);
                         }
                         for (int off = G >> 1; off > 0; off >>= 1) {   // the G lanes of a joint are adjacent
                             aS += __shfl_xor(aS, off, 64);
@@ -472,11 +603,19 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
                         if (active && g == 0) {
                             double ox = 0.0, oy = 0.0, oz = 0.0, os = 0.0;
                             if (!(aS == 0.0)) {                                                    // :142-143
-                                const double r = 0.5 / aS;
-                                ox = aX * r;
-                                oy = aY * r;
-                                oz = aZ * r;
-                                os = aS / (double)size;                                            // :148
+                                if constexpr (sizeof(TOut) == 4) {
+                                    const double r = 0.5 * rcp_nr2(aS);   // (an IEEE divide is ~30 instructions for the whole wave)
+                                    ox = aX * r;
+                                    oy = aY * r;
+                                    oz = aZ * r;
+                                    os = aS * (0.0005 * rcp_nr2((double)size));   // :148; this branch sums 2000 x the score
+                                } else {
+                                    const double r = 0.5 / aS;
+                                    ox = aX * r;
+                                    oy = aY * r;
+                                    oz = aZ * r;
+                                    os = aS / (double)size;                                        // :148
+                                }
                             }
                             if (slot < Pout) wr.joint(f, Pout, kn, slot, j0 + jj, ox, oy, oz, os);
                             osbuf[(size_t)(slot - sbase) * kn + j0 + jj] = os;
