@@ -505,6 +505,7 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
             // them costs a memory round trip), else in the slab.
             uint32_t *cmem = reinterpret_cast<uint32_t *>(centre);    // [n]
             int32_t *cslot = reinterpret_cast<int32_t *>(cmem + Kc);  // [ncl] preliminary output slot or -1
+            int32_t *cid_of_slot = cslot + Kc;                        // [nsurv] its inverse
             const int nmem = cstart[ncl];   // members of all clusters (<= n: the last candidate never seeds, :107)
             const bool mem_in_lds = nmem <= lmem_cap;
             for (int pos = tid; pos < nmem; pos += kBlock) {
@@ -521,7 +522,9 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
                     const int c = base + lane;
                     const bool in = c < ncl && !((double)csize[c] < prm.num_tol);                  // :132-134
                     const unsigned long long m = __ballot(in);
-                    if (c < ncl) cslot[c] = in ? ns + __popcll(m & ((1ull << lane) - 1ull)) : -1;
+                    const int sl = ns + __popcll(m & ((1ull << lane) - 1ull));
+                    if (c < ncl) cslot[c] = in ? sl : -1;
+                    if (in) cid_of_slot[sl] = c;
                     ns += __popcll(m);
                 }
                 if (lane == 0) misc[5] = ns;
@@ -546,19 +549,30 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
                         }
                     }
                     __syncthreads();
-                    int G = 64;                                   // largest power of two with nj * G <= 256
-                    while (G > 1 && nj * G > kBlock) G >>= 1;
-                    const int jj = tid / G, g = tid & (G - 1);
-                    const bool active = jj < nj;
-                    const int jc = active ? jj : 0;
-                    for (int cid = 0; cid < ncl; cid++) {
-                        const int slot = cslot[cid];
-                        if (slot < sbase || slot >= sbase + kRecomputeSlotTile) continue;
-                        const int size = csize[cid], m0 = cstart[cid];
+                    // thread = (joint jj of the chunk, cluster of the sweep, member group g): the L = 256 / nj lanes of a
+                    // joint are shared by up to L clusters at once, G = L / clusters (power of two) lanes each; a lane
+                    // walks members g, g + G, ... of ITS cluster, the G partial sums sit in adjacent lanes and are added
+                    // with shuffles.  (One cluster after the other, 64 lanes each, left every lane with 3-4 solves
+                    // between a 5-step reduction and the next cluster's set-up: 3x the time of the solves themselves.)
+                    int L = 1;                                    // largest power of two with nj * L <= 256, within one wave
+                    while (2 * L * nj <= kBlock && L < 64) L *= 2;
+                    const int nsw = (nsurv - sbase) < kRecomputeSlotTile ? (nsurv - sbase) : kRecomputeSlotTile;  // clusters of this sweep
+                    int CB = 1;                                   // clusters side by side: power of two <= L covering nsw if it can
+                    while (CB < nsw && CB < L) CB *= 2;
+                    const int G = L / CB;
+                    const int jj = tid / L, li = tid & (L - 1), ci = li / G, g = li & (G - 1);
+                    const int jc = jj < nj ? jj : 0;
+                    for (int cb = 0; cb < nsw; cb += CB) {
+                        const bool active = jj < nj && cb + ci < nsw;
+                        const int slot = sbase + cb + ci;
+                        const int cid = active ? cid_of_slot[slot] : 0;
+                        const int size = active ? csize[cid] : 0, m0 = active ? cstart[cid] : 0;
                         double aS = 0.0, aX = 0.0, aY = 0.0, aZ = 0.0;
-                        for (int mi = g; mi < size && active; mi += G) {
-                            const uint32_t mw = memw[m0 + mi];
+                        uint32_t mw = g < size ? memw[m0 + g] : 0u;
+                        for (int mi = g; mi < size; mi += G) {
+                            const uint32_t mw_next = (mi + G < size) ? memw[m0 + mi + G] : 0u;   // in flight during this solve
                             const int rm = (int)(mw & 1023u), rs = (int)((mw >> 10) & 1023u), q = (int)(mw >> 20);
+                            mw = mw_next;
                             const double *pc = pairc + 6 * q;
                             const Vec3 d = {pc[0], pc[1], pc[2]}, tsum = {pc[3], pc[4], pc[5]};
                             const RayRec a = *reinterpret_cast<const RayRec *>(rays + rm * rstride + 32 * jc);
@@ -594,7 +608,7 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
                             aY = fma(sq, sw.y, aY);
                             aZ = fma(sq, sw.z, aZ);
                         }
-                        for (int off = G >> 1; off > 0; off >>= 1) {   // the G lanes of a joint are adjacent
+                        for (int off = G >> 1; off > 0; off >>= 1) {   // the G lanes of a (joint, cluster) are adjacent
                             aS += __shfl_xor(aS, off, 64);
                             aX += __shfl_xor(aX, off, 64);
                             aY += __shfl_xor(aY, off, 64);
@@ -649,6 +663,7 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
                     moved |= __ballot(in && fin != slot) != 0ull;
                     moved |= __ballot(slot >= 0 && !in) != 0ull;
                     if (c < ncl) cslot[c] = in ? fin : -1;           // the slots of pass 1, if there is one
+                    if (in) cid_of_slot[fin] = c;
                     nf_ += __popcll(m);
                 }
                 if (lane == 0) {
