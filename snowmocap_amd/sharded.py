@@ -3,9 +3,12 @@
 Frames are independent through triangulate + condense (the reference reads only the current
 frame's detections: triangulation.py:50-162; state is cleared per frame, main.py:106), so the batch
 is split into contiguous frame blocks, one per rank, with NO data-path collective inside the
-kernels; one all-gather (RCCL over xGMI when the backend is "nccl") hands every rank the whole
+kernels; an all-gather (RCCL over xGMI when the backend is "nccl") hands every rank the whole
 3D track, which is what the next stage -- temporal smoothing, a recurrence over frames
-(triangulation.py:164-186) -- needs.  Results are bit-identical to the single-GPU run.
+(triangulation.py:164-186) -- needs.  The shard is computed in a few pieces and the gather of a piece
+(all of its outputs in one buffer, one collective) runs on a side stream under the next piece's kernel:
+the gather moves 16 B/joint over xGMI against 64 B/joint over HBM at ~1/20 of the bandwidth, so it is
+what bounds the end-to-end time.  Results are bit-identical to the single-GPU run.
 
 The sharding / gather logic is backend-agnostic (tests run it on CPU with gloo, world_size 2).
 """
@@ -36,23 +39,116 @@ def gather_track(local, F_total, group=None):
     return full[:F_total]
 
 
-class ShardedTriangulator:
-    """One instance per rank (one process per GPU).  `run(kpts_local)` triangulates this rank's frame
-    block on its GPU and returns the gathered track."""
+def _align(n, a=16):
+    return (n + a - 1) // a * a
 
-    def __init__(self, K, R, t, params, pout_max=1, device=0, group=None):
+
+def gather_track_chunked(compute_block, n_local, F_total, regions, chunks=4, group=None, device=None):
+    """Frame-sharded results -> the whole track on every rank, gathered WHILE the shard is still being computed.
+
+    The rank's block of `per = ceil(F_total / world)` frame slots is cut into `chunks` pieces.  For piece i,
+    `compute_block(lo, hi, views)` fills `views[name][: hi - lo]` for the local frames [lo, hi) (launching
+    asynchronously on the current stream); every output of the piece lives in ONE flat buffer (regions back to back,
+    16-byte aligned), which is all-gathered with ONE collective on a side stream while piece i + 1 is computed, and
+    unpacked into the full tensors there.  Buffers rotate over two slots; a slot is rewritten only after its gather
+    has finished.  On CPU tensors (gloo tests) the same steps run in order without streams.
+
+    regions: {name: (shape_tail, torch dtype)} per frame.  Returns {name: tensor [F_total, *shape_tail]}.
+    """
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    per = (F_total + world - 1) // world
+    chunks = max(1, min(int(chunks), max(1, per)))
+    cs = (per + chunks - 1) // chunks                      # frame slots per piece (same on every rank)
+    on_gpu = device is not None and torch.device(device).type == "cuda"
+    dev = torch.device(device) if device is not None else torch.device("cpu")
+    # flat layout of one piece
+    offs, total = {}, 0
+    for name, (tail, dt) in regions.items():
+        nbytes = cs * int(torch.tensor([], dtype=dt).element_size())
+        for d in tail:
+            nbytes *= int(d)
+        offs[name] = (total, nbytes)
+        total = _align(total + nbytes)
+    full = {name: torch.empty((world * per,) + tuple(tail), dtype=dt, device=dev) for name, (tail, dt) in regions.items()}
+    send = [torch.zeros(total, dtype=torch.uint8, device=dev) for _ in range(2)]
+    recv = [torch.empty(world * total, dtype=torch.uint8, device=dev) for _ in range(2)]
+
+    def views_of(flat):
+        return {name: flat[o:o + nb].view(regions[name][1]).view((cs,) + tuple(regions[name][0]))
+                for name, (o, nb) in offs.items()}
+
+    if on_gpu:
+        main = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(device=dev)
+        gathered = [None, None]
+    for i in range((per + cs - 1) // cs):
+        slot = i & 1
+        lo = min(n_local, i * cs)
+        hi = min(n_local, (i + 1) * cs)
+        if on_gpu and gathered[slot] is not None:
+            main.wait_event(gathered[slot])              # the gather that last read this slot is done
+        if hi - lo < cs:
+            send[slot].zero_()                           # short or empty piece: deterministic padding
+        if hi > lo:
+            compute_block(lo, hi, views_of(send[slot]))
+        width = min(cs, per - i * cs)                    # frame slots of this piece that exist in the block
+
+        def gather_and_unpack():
+            dist.all_gather_into_tensor(recv[slot], send[slot], group=group)
+            got = recv[slot].view(world, total)
+            for name, (o, nb) in offs.items():
+                tail, dt = regions[name]
+                src = got[:, o:o + nb].view(dt).view((world, cs) + tuple(tail))
+                full[name].view((world, per) + tuple(tail))[:, i * cs:i * cs + width] = src[:, :width]
+
+        if on_gpu:
+            ready = torch.cuda.Event()
+            ready.record(main)
+            side.wait_event(ready)
+            with torch.cuda.stream(side):
+                gather_and_unpack()
+                done = torch.cuda.Event()
+                done.record(side)
+            gathered[slot] = done
+        else:
+            gather_and_unpack()
+    if on_gpu:
+        main.wait_stream(side)                           # results are ready for whatever the caller queues next
+    return {name: t[:F_total] for name, t in full.items()}
+
+
+class ShardedTriangulator:
+    """One instance per rank (one process per GPU).  `run(kpts_local, F_total)` triangulates this rank's frame block
+    on its GPU, piece by piece, and returns the gathered track: the all-gather of piece i (joints, person scores,
+    counts and flags in one buffer, one collective) overlaps the kernel of piece i + 1."""
+
+    def __init__(self, K, R, t, params, pout_max=1, device=0, group=None, chunks=4):
         import numpy as np
         from .batch import BatchTriangulator
         self.bt = BatchTriangulator(K, R, t, params, pout_max=pout_max, out_dtype=np.float32, device=device)
         self.group = group
+        self.chunks = chunks
+        self.device = device
 
-    def run(self, kpts_local, F_total, n_persons_local=None, gather=True):
-        out = self.bt.run_torch(kpts_local, n_persons_local)
+    def regions(self):
+        import torch
+        kn, P = self.bt.params.keypoint_num, self.bt.pout_max
+        return {"xyzs": ((P, kn, 4), torch.float32), "pscore": ((P,), torch.float32),
+                "count": ((), torch.int32), "flags": ((), torch.int32)}
+
+    def run(self, kpts_local, F_total, n_persons_local=None, gather=True, chunks=None):
         if not gather:
-            return out
-        return dict(xyzs=gather_track(out["xyzs"], F_total, self.group),
-                    count=gather_track(out["count"], F_total, self.group),
-                    flags=gather_track(out["flags"], F_total, self.group))
+            return self.bt.run_torch(kpts_local, n_persons_local)
+
+        def compute_block(lo, hi, views):
+            out = {k: v[: hi - lo] for k, v in views.items()}
+            self.bt.run_torch(kpts_local[lo:hi], None if n_persons_local is None else n_persons_local[lo:hi], out=out)
+
+        return gather_track_chunked(compute_block, int(kpts_local.shape[0]), F_total, self.regions(),
+                                    chunks=self.chunks if chunks is None else chunks, group=self.group,
+                                    device=kpts_local.device)
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -264,3 +264,39 @@ def test_lean_is_deterministic_and_split_invariant(api):
         pparts.append(o["pscore"].cpu().numpy())
     assert np.array_equal(a, np.concatenate(parts)) and np.array_equal(ps, np.concatenate(pparts))
     bt.close()
+
+
+@pytest.mark.parametrize("chunks", [1, 4, 7])
+def test_sharded_triangulator_overlapped_gather_single_rank_group(api, chunks):
+    """ShardedTriangulator.run on the GPU in a 1-rank RCCL group: the shard in pieces, the packed all-gather of piece i
+    on a side stream under the kernel of piece i + 1 -- bit-identical to one unsharded launch (sharded execution on
+    several GPUs is the driver's SCALE run; the 2-rank plumbing runs on CPU in tests/test_sharding_gloo.py)."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from snowmocap_amd import synth
+    from snowmocap_amd.sharded import ShardedTriangulator
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29650 + os.getpid() % 200))
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        F = 12501                               # not a multiple of the piece count
+        wl = synth.config_workload(2, F, seed=21)
+        K, R, t = wl["rig"]
+        dev = torch.device("cuda", 0)
+        kp = torch.from_numpy(wl["kpts"]).to(dev)
+        st = ShardedTriangulator(K, R, t, wl["params"], pout_max=1, device=0, chunks=chunks)
+        got = st.run(kp, F)
+        torch.cuda.synchronize()
+        ref = st.bt.run_torch(kp)
+        torch.cuda.synchronize()
+        for k in ("xyzs", "pscore", "count", "flags"):
+            assert got[k].shape == ref[k].shape and torch.equal(got[k], ref[k]), k
+        assert (got["count"] == 1).all()
+        st.bt.close()
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -61,6 +61,56 @@ def test_two_rank_gather_equals_unsharded(tmp_path, F):
     assert np.array_equal(np.load(tmp_path / "cnt.npy"), ref["count"])
 
 
+def _chunked_worker(rank, world, port, F, chunks, tmp):
+    sys.path.insert(0, ROOT)
+    from snowmocap_amd import synth
+    from snowmocap_amd.sharded import gather_track_chunked
+    from oracle import oracle as orc
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    wl = synth.config_workload(2, F, seed=11)
+    K, R, t = wl["rig"]
+    prm = orc.make_params(**wl["params"])
+    lo0, hi0, per = shard_bounds(F, world, rank)
+    calls = []
+
+    def compute_block(lo, hi, views):          # the oracle stands in for the kernel: this test is about the plumbing
+        calls.append((lo, hi))
+        r = orc.triangulate_condense_batch(K, R, t, wl["kpts"][lo0 + lo:lo0 + hi], wl["n_persons"][lo0 + lo:lo0 + hi], prm, 1, nthreads=1)
+        views["xyzs"][: hi - lo] = torch.from_numpy(np.concatenate([r["xyz"], r["kscore"][..., None]], axis=-1).astype(np.float32))
+        views["pscore"][: hi - lo] = torch.from_numpy(r["pscore"].astype(np.float32))
+        views["count"][: hi - lo] = torch.from_numpy(r["count"].astype(np.int32))
+        views["flags"][: hi - lo] = 4
+
+    regions = {"xyzs": ((1, 133, 4), torch.float32), "pscore": ((1,), torch.float32), "count": ((), torch.int32),
+               "flags": ((), torch.int32)}
+    out = gather_track_chunked(compute_block, hi0 - lo0, F, regions, chunks=chunks, group=None, device=None)
+    assert sum(b - a for a, b in calls) == hi0 - lo0 and all(b > a for a, b in calls)
+    if rank == 1:       # any rank holds the whole track
+        np.savez(os.path.join(tmp, "chunked.npz"), **{k: v.numpy() for k, v in out.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("F,chunks", [(37, 4), (64, 3), (5, 100), (41, 1)])
+def test_two_rank_chunked_packed_gather_equals_unsharded(tmp_path, F, chunks):
+    """ShardedTriangulator's plumbing (gather_track_chunked): the shard in pieces, every output of a piece in ONE buffer
+    and ONE collective, uneven blocks and padded last pieces -- bit-identical to the unsharded result."""
+    from snowmocap_amd import synth
+    from oracle import oracle as orc
+    port = 29000 + (os.getpid() % 400) + F + 7 * chunks
+    mp.spawn(_chunked_worker, args=(2, port, F, chunks, str(tmp_path)), nprocs=2, join=True)
+    wl = synth.config_workload(2, F, seed=11)
+    K, R, t = wl["rig"]
+    ref = orc.triangulate_condense_batch(K, R, t, wl["kpts"], wl["n_persons"], orc.make_params(**wl["params"]), 1, nthreads=1)
+    got = np.load(tmp_path / "chunked.npz")
+    want = np.concatenate([ref["xyz"], ref["kscore"][..., None]], axis=-1).astype(np.float32)
+    assert got["xyzs"].shape == want.shape and np.array_equal(got["xyzs"], want)
+    assert np.array_equal(got["pscore"], ref["pscore"].astype(np.float32))
+    assert np.array_equal(got["count"], ref["count"]) and (got["flags"] == 4).all()
+
+
 # ------------------------------------------------------------------ N1 on a sharded track: carry exchange
 def _seq_filter(x, f, z, r, dt):
     from oracle import oracle as orc
