@@ -183,6 +183,10 @@ template <int C, typename TIn>
 __device__ __forceinline__ bool pairwise_item(const Rig &rig, const double *__restrict__ Mlds,
                                               const Kp3<TIn> (&cur)[C], const Params &prm, double &ox,
                                               double &oy, double &oz, double &os) {
+    // Products that are meant to be fused are explicit fma() calls; implicit contraction is off: the item is inlined
+    // once per slot of the prefetch ring and the compiler is free to fuse `beta += x * y` differently in each copy,
+    // which made a frame's last bit depend on where in the launch it sat (found by the 125 000-frame shard test).
+#pragma clang fp contract(off)
     // Rig constants are wave-uniform and all come from LDS (broadcast reads into transient VGPRs):
     // ray matrices M[C][9], camera centres t[C][3], per-pair d = t_s - t_m.  Holding the ~70 doubles
     // in scalar registers instead overflows the SGPR file: loop-invariant scalars then live in
@@ -349,6 +353,7 @@ __device__ __forceinline__ bool pairwise_item(const Rig &rig, const double *__re
 // u P[2] - P[0], v P[2] - P[1] (scaled by w in {0, 1}) to the upper triangle of A^T A.
 template <typename PPtr>
 __device__ __forceinline__ void dlt_add_observation(double (&A)[4][4], PPtr P, double u, double v, double w) {
+#pragma clang fp contract(off)   // results must not depend on which inlined copy computes them (see pairwise_item)
     double r1[4], r2[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
@@ -371,6 +376,7 @@ __device__ __forceinline__ void dlt_add_observation(double (&A)[4][4], PPtr P, d
 // entries decay THROUGH the denormal range on their way to zero: an entry below 1e-280 is treated as already
 // zero (its rotation angle is below 1e-280 / gap, i.e. nothing), and |theta| is clamped so theta^2 stays finite.
 __device__ __forceinline__ void dlt_min_eigenvector(double (&A)[4][4], double (&e)[4]) {
+#pragma clang fp contract(off)   // results must not depend on which inlined copy computes them (see pairwise_item)
 #pragma unroll
     for (int i = 1; i < 4; i++)
 #pragma unroll
@@ -437,6 +443,7 @@ __device__ __forceinline__ void dlt_min_eigenvector(double (&A)[4][4], double (&
 // are not by SNOWTRI_DLT_INVIT steps (gross outliers: eigenvalue ratio above ~0.02) report false and the caller
 // re-solves them with Jacobi.  `live` = false lanes (fewer than two cameras) never block.
 __device__ __forceinline__ bool dlt_inverse_iteration(const double (&A)[4][4], bool live, double (&e)[4]) {
+#pragma clang fp contract(off)   // results must not depend on which inlined copy computes them (see pairwise_item)
     const double mu = (A[0][0] + A[1][1] + A[2][2] + A[3][3]) * (64.0 * 2.220446049250313e-16);
     double L[4][4], inv[4];  // L strictly-lower entries, inv[i] = 1 / L[i][i]
 #pragma unroll
@@ -479,7 +486,7 @@ __device__ __forceinline__ bool dlt_inverse_iteration(const double (&A)[4][4], b
         for (int i = 0; i < 4; i++) {
             const double xn = z[i] * rn;
             diff = fmax(diff, fabs(xn - x[i]));
-            x[i] = xn;
+            x[i] = conv ? x[i] : xn;   // a settled lane keeps its answer: it must not depend on how long its wave iterates
         }
         // linear convergence with ratio r = diff / prev: the error left after this step is ~ diff * r
         conv = conv || (diff * diff < 1e-14 * prev);
@@ -505,6 +512,7 @@ __device__ __forceinline__ void dlt_solve(double (&A)[4][4], bool live, double (
 template <int C, typename TIn>
 __device__ __forceinline__ void dlt_item(const double *__restrict__ Plds, const Kp3<TIn> (&cur)[C], const int32_t *np_f,
                                          const Params &prm, double &ox, double &oy, double &oz, double &os) {
+#pragma clang fp contract(off)   // (same reason as in pairwise_item)
     // world->pixel matrices P[C][12] come from LDS (broadcast reads), like the ray matrices of the pairwise
     // item: 96 doubles in scalar registers overflow the SGPR file and come back as v_readlane traffic
     double Pp[12 * C];

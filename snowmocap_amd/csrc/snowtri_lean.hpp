@@ -66,6 +66,10 @@ __device__ __forceinline__ bool lean_item(const double *__restrict__ Mlds, const
                                           const double (&dS)[3 * (C * (C - 1) / 2)],
                                           const Kp3<TIn> (&cur)[C], float kthr_f32, double kthr, double dthr2,
                                           float &ox, float &oy, float &oz, double &os) {
+    // Every product-sum below that is meant to be fused is an explicit fma().  Implicit contraction is switched off:
+    // the item is inlined three times (the prefetch ring) and the compiler may fuse `beta += x * y` differently in each
+    // copy -- a frame's result would then depend (in the last bit) on which ring slot its position in the launch maps to.
+#pragma clang fp contract(off)
     constexpr int NPc = C * (C - 1) / 2;
 #if SNOWTRI_LEAN_M_VGPR  // dev experiment: ray matrices resident in VGPRs for the whole launch (passed in Mres)
     const double (&Mp)[9 * C] = Mres;
