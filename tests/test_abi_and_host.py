@@ -189,3 +189,41 @@ def test_header_is_plain_c_and_links(tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True)
     if _lib.lib().snowtri_device_count() <= 0:
         assert out.returncode == 0 and "no device" in out.stdout
+
+
+def test_every_entry_rejects_bad_arguments_under_asan(tmp_path):
+    """`make asan` (host AddressSanitizer build of the C ABI) + tests/abi_badargs.c: null contexts, impossible sizes,
+    bad enum values, context creation failing with SNOWTRI_ERR_NO_DEVICE -- every entry reports, none reads through a
+    bad pointer.  (With a GPU the same driver goes on to a real context: tests/test_gpu_parity.py.)"""
+    import subprocess
+    csrc = os.path.join(ROOT, "snowmocap_amd", "csrc")
+    so = os.path.join(csrc, "build", "libsnowtri_asan.so")
+    subprocess.check_call(["make", "-C", csrc, "-s", "asan"])
+    clang = "/opt/rocm/lib/llvm/bin/clang"
+    exe = str(tmp_path / "abi_badargs")
+    subprocess.check_call([clang, "-std=c99", "-fsanitize=address", "-g", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "abi_badargs.c"), "-o", exe, so, "-Wl,-rpath," + os.path.dirname(so)])
+    env = dict(os.environ, ASAN_OPTIONS="detect_leaks=0:abort_on_error=0", HIP_VISIBLE_DEVICES="", ROCR_VISIBLE_DEVICES="")
+    p = subprocess.run([exe], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and "0 failure(s)" in p.stdout, p.stdout[-3000:] + p.stderr[-3000:]
+    assert "AddressSanitizer" not in p.stderr, p.stderr[-3000:]
+
+
+def test_compat_snowvision_package_serves_main_py_imports():
+    """compat/snowvision on PYTHONPATH: `from snowvision import *` (main.py:6) yields every name main.py uses
+    (main.py:14-106), bound to the snowmocap_amd implementations -- no sys.modules alias, main.py unchanged."""
+    import subprocess
+    import sys
+    code = ("from snowvision import *\n"
+            "import snowvision, snowmocap_amd\n"
+            "names = ['Load_Config_Json', 'CameraGroup', 'Load_Video', 'Check_If_File_Exist', 'Human_Triangulation',"
+            " 'Human_Triangulation_Condense', 'Human_Triangulation_Smooth', 'Human_Triangulation_Blender',"
+            " 'Human_Triangulation_Blender_Smooth', 'Human_Triangulation_To_Blender_Result', 'save_blender_result',"
+            " 'Draw_Camera_Group', 'Draw_Skeleton']\n"
+            "missing = [n for n in names if n not in globals()]\n"
+            "assert not missing, missing\n"
+            "assert CameraGroup is snowmocap_amd.CameraGroup and snowvision.triangulation is snowmocap_amd.triangulation\n"
+            "print('ok')\n")
+    env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "compat"), ROOT]))
+    p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert p.returncode == 0 and "ok" in p.stdout, p.stdout + p.stderr

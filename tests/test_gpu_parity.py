@@ -1218,3 +1218,20 @@ def test_plain_c_consumer_runs(api, tmp_path):
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "c abi ok" in out.stdout
+
+
+def test_every_entry_rejects_bad_arguments_on_a_real_context(api, tmp_path):
+    """tests/abi_badargs.c against libsnowtri.so on the GPU: besides the null-context cases of the CPU run, a real
+    context with wrong shapes / dtype codes / memory spaces / method, center_point_index and keypoint_num out of range
+    (the reference raises IndexError), missing pointers, a camera index out of range, too few Blender joints, a
+    singular K (LinAlgError in the reference) -- each reports its status code."""
+    import os
+    import subprocess
+    from conftest import ROOT
+    lib_dir = os.path.join(ROOT, "snowmocap_amd")
+    exe = str(tmp_path / "abi_badargs")
+    subprocess.check_call(["gcc", "-std=c99", "-O1", "-I", os.path.join(ROOT, "include"),
+                           os.path.join(ROOT, "tests", "abi_badargs.c"), "-o", exe, "-L", lib_dir, "-lsnowtri",
+                           "-Wl,-rpath," + lib_dir])
+    out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "0 failure(s)" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
