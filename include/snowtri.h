@@ -100,6 +100,15 @@ int snowtri_ctx_synchronize(snowtri_ctx *ctx);
 int snowtri_fastmath_probe(snowtri_ctx *ctx, int64_t n, const double *x, double *rcp_nr2_out,
                            double *rcp_nr1_out, double *rsq_nr1_out);
 
+/* Test hook: the RAW v_rcp_f64 / v_rsq_f64 results (no Newton step) on x[n]; host pointers.  The float32-output
+ * kernels use the raw 1/sqrt for 1/dist: tests pin its accuracy (<= 2^-23 relative over the normal range). */
+int snowtri_fastmath_probe_raw(snowtri_ctx *ctx, int64_t n, const double *x, double *rcp_raw_out, double *rsq_raw_out);
+/* Measurement aid: streams a KNOWN number of bytes with the access shapes of the fused kernels -- read_bytes from src
+ * as 12-byte records per lane, write_bytes to dst as 16-byte records per lane (device pointers; either may be 0) --
+ * so that HBM counters (rocprofv3 FETCH_SIZE / WRITE_SIZE) are calibrated on a kernel other than the one measured. */
+int snowtri_calib_stream(snowtri_ctx *ctx, const void *src, int64_t read_bytes, void *dst, int64_t write_bytes,
+                         void *stream);
+
 /* A1  CameraGroup.add_human_2D_points (camera.py:234-253): uv[n][2] pixels of camera `cam`
  * -> rays[n][3] = R . inv(K) . [u, v, 1] (un-normalised, world frame).  Host pointers, fp64. */
 int snowtri_rays_from_pixels(snowtri_ctx *ctx, int32_t cam, int64_t n, const double *uv, double *rays);

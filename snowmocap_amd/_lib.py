@@ -64,6 +64,8 @@ _SIGNATURES = {
     "snowtri_ctx_ray_matrices": (ct.c_int, [_c_p, _c_p]),
     "snowtri_ctx_synchronize": (ct.c_int, [_c_p]),
     "snowtri_fastmath_probe": (ct.c_int, [_c_p, ct.c_int64, _c_p, _c_p, _c_p, _c_p]),
+    "snowtri_fastmath_probe_raw": (ct.c_int, [_c_p, ct.c_int64, _c_p, _c_p, _c_p]),
+    "snowtri_calib_stream": (ct.c_int, [_c_p, _c_p, ct.c_int64, _c_p, ct.c_int64, _c_p]),
     "snowtri_rays_from_pixels": (ct.c_int, [_c_p, ct.c_int32, ct.c_int64, _c_p, _c_p]),
     "snowtri_skew_ray_batch": (ct.c_int, [_c_p, ct.c_int64, _c_p, _c_p, _c_p, _c_p, _c_p, _c_p,
                                           ct.POINTER(ct.c_int64)]),

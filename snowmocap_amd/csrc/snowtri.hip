@@ -362,9 +362,44 @@ int snowtri_fastmath_probe(snowtri_ctx *ctx, int64_t n, const double *x, double 
     return SNOWTRI_OK;
 }
 
+int snowtri_fastmath_probe_raw(snowtri_ctx *ctx, int64_t n, const double *x, double *rcp_raw_out, double *rsq_raw_out) {
+    if (!ctx || n < 1 || !x || !rcp_raw_out || !rsq_raw_out) return SNOWTRI_ERR_BAD_ARG;
+    ENTER_DEVICE(ctx->device);
+    const size_t b = sizeof(double) * n;
+    int rc = ctx->in.ensure(b);
+    if (rc) return rc;
+    rc = ctx->out.ensure(2 * b);
+    if (rc) return rc;
+    HIP_TRY(hipMemcpy(ctx->in.p, x, b, hipMemcpyHostToDevice));
+    double *o = (double *)ctx->out.p;
+    hipLaunchKernelGGL(k_fastmath_probe_raw, dim3(grid_for(n, kBlock, ctx->num_cus * 8)), dim3(kBlock), 0, 0, n,
+                       (const double *)ctx->in.p, o, o + n);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpy(rcp_raw_out, o, b, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(rsq_raw_out, o + n, b, hipMemcpyDeviceToHost));
+    return SNOWTRI_OK;
+}
+
+int snowtri_calib_stream(snowtri_ctx *ctx, const void *src, int64_t read_bytes, void *dst, int64_t write_bytes, void *stream) {
+    if (!ctx || read_bytes < 0 || write_bytes < 0 || (read_bytes > 0 && !src) || (write_bytes > 0 && !dst)) return SNOWTRI_ERR_BAD_ARG;
+    ENTER_DEVICE(ctx->device);
+    hipStream_t st = (hipStream_t)stream;
+    if (read_bytes >= 12) {
+        int rc = ctx->misc.ensure(64);
+        if (rc) return rc;
+        hipLaunchKernelGGL(k_calib_read12, dim3(ctx->num_cus * 8), dim3(kBlock), 0, st, read_bytes / 12, (const Rec12 *)src,
+                           (float *)ctx->misc.p);
+    }
+    if (write_bytes >= 16)
+        hipLaunchKernelGGL(k_calib_write16, dim3(ctx->num_cus * 8), dim3(kBlock), 0, st, write_bytes / 16, (float4 *)dst);
+    HIP_TRY(hipGetLastError());
+    return SNOWTRI_OK;
+}
+
 // ------------------------------------------------------------------------------------------ A1
 int snowtri_rays_from_pixels(snowtri_ctx *ctx, int32_t cam, int64_t n, const double *uv, double *rays) {
-    if (!ctx || cam < 0 || cam >= ctx->C || n < 0 || (n > 0 && (!uv || !rays))) return SNOWTRI_ERR_BAD_ARG;
+    if (!ctx || n < 0 || (n > 0 && (!uv || !rays))) return SNOWTRI_ERR_BAD_ARG;
+    if (cam < 0 || cam >= ctx->C) return SNOWTRI_ERR_BAD_INDEX;   // cameras[camera_index] raises IndexError (camera.py:236)
     if (n == 0) return SNOWTRI_OK;
     ENTER_DEVICE(ctx->device);
     int rc = ctx->in.ensure(sizeof(double) * 2 * n);

@@ -62,7 +62,7 @@ __host__ __device__ inline size_t recompute_lds_bytes(int R, int J, int kn, int 
 //   EXACT = true   the arithmetic the kernel has always used: 1/dist by v_rsq_f64 + one Newton step (2e-14), exact
 //                  intersection -> inf, four joints share one reciprocal unless their determinants' product leaves the
 //                  normal range (singular pairs are detected there).
-//   EXACT = false  the same solves with the raw v_rsq_f64 (2^-22 relative) and no range check -- 36 instead of 57 VALU
+//   EXACT = false  the same solves with the raw v_rsq_f64 (measured 5.2e-8 = 2^-24.2 relative, tests pin <= 2^-23) and no range check -- 36 instead of 57 VALU
 //                  instructions per solve.  Its sum decides only whether the candidate is KEPT (:79-81; the scores that
 //                  are output come from phase 3): the caller re-does a candidate with EXACT = true when its mean is not
 //                  finite (singular pair, exact intersection, NaN input) or lies within 1e-6 relative of
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
                             double sq;
                             Vec3 sw;
                             if constexpr (sizeof(TOut) == 4) {
-                                // float32 outputs: 1/dist is the raw v_rsq_f64 (2^-22 relative, below the float32 rounding
+                                // float32 outputs: 1/dist is the raw v_rsq_f64 (measured 2^-24.2 relative, below the float32 rounding
                                 // of the stored score: same contract as k_fused_lean); sq = 2000 x the score of :72
                                 const double bq = fma(a.z, b.z, fma(a.y, b.y, a.x * b.x));
                                 const double e = fma(a.z, d.z, fma(a.y, d.y, a.x * d.x));

@@ -56,6 +56,36 @@ __global__ __launch_bounds__(kBlock) void k_fastmath_probe(int64_t n, const doub
     }
 }
 
+// Raw hardware approximations (no Newton step): what k_fused_lean / the float32 branch of k_frame_recompute use for
+// 1/dist.  Probed so that the accuracy the float32 score contract relies on is a measured number.
+__global__ __launch_bounds__(kBlock) void k_fastmath_probe_raw(int64_t n, const double *__restrict__ x,
+                                                               double *__restrict__ rcp_raw, double *__restrict__ rsq_raw) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        rcp_raw[i] = __builtin_amdgcn_rcp(x[i]);
+        rsq_raw[i] = __builtin_amdgcn_rsq(x[i]);
+    }
+}
+
+// HBM-counter calibration (measurement aid): streams with the access shapes of the fused kernels and a KNOWN byte
+// count -- 12-byte records read per lane (global_load_dwordx3, consecutive lanes = consecutive records) and 16-byte
+// records written per lane (global_store_dwordx4) -- so that rocprofv3's FETCH_SIZE / WRITE_SIZE can be scaled on a
+// kernel other than the one being measured (scripts/profile.sh).
+struct Rec12 {
+    float a, b, c;
+};
+__global__ __launch_bounds__(kBlock) void k_calib_read12(int64_t nrec, const Rec12 *__restrict__ src, float *__restrict__ sink) {
+    float acc = 0.0f;
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nrec; i += (int64_t)gridDim.x * blockDim.x) {
+        const Rec12 r = src[i];
+        acc += r.a + r.b + r.c;
+    }
+    if (acc == 123.456f) sink[0] = acc;   // keeps the loads alive; practically never true
+}
+__global__ __launch_bounds__(kBlock) void k_calib_write16(int64_t nrec, float4 *__restrict__ dst) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < nrec; i += (int64_t)gridDim.x * blockDim.x)
+        dst[i] = make_float4((float)i, 1.0f, 2.0f, 3.0f);
+}
+
 // Rig constants resident in HBM (<= 1.5 KB, L2/scalar-cache resident): M[C][9], t[C][3],
 // pair table [npairs][2] in the reference's loop order mc < sc (triangulation.py:56-58).
 struct Rig {

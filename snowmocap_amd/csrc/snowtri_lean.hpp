@@ -13,7 +13,7 @@
 //     resolve are re-done by general_frame.
 //   * Tiles are cut so that every wave of the launch gets the same number of frames +-1 (a 10 000-frame
 //     launch no longer leaves a fifth of the chip idle behind the 25-frame tiles of 400 workgroups).
-//   * A shorter item (lean_item): 1/dist is the raw v_rsq_f64 (2^-23 relative, below the float32 rounding
+//   * A shorter item (lean_item): 1/dist is the raw v_rsq_f64 (measured 2^-24.2 relative, below the float32 rounding
 //     of the stored score); the 1/2000 of triangulation.py:72 is applied once to the score sum; the keypoint
 //     gate (:73) is evaluated once per camera into a lane mask; exact intersection / singular pair / NaN are
 //     detected on the score sum; the per-pair offsets d = t_s - t_m live in scalar registers (one SGPR operand
