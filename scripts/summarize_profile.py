@@ -21,7 +21,7 @@ for path in find("*kernel_stats.csv"):
         keep.append({k: r.get(k) for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")})
     summary["kernel_stats"] = keep
 
-for tag in ("pmc_fetch", "pmc_write", "pmc_sq"):
+for tag in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
     files = [p for p in find("*counter_collection.csv") if f"/{tag}/" in p]
     for path in files:
         acc = defaultdict(lambda: defaultdict(list))
@@ -36,4 +36,40 @@ for tag in ("pmc_fetch", "pmc_write", "pmc_sq"):
             n = len(next(iter(ctrs.values())))
             print(f"  {kname}  launches={n}  " + "  ".join(f"{c}={x:.6g}" for c, x in line.items()))
             summary.setdefault(tag, {})[kname] = dict(launches=n, **line)
+
+# HBM bytes per fused launch, scaled by the calibration streams of the same passes (known byte counts, same access shapes)
+def mean_of(tag, needle, counter):
+    for kname, line in summary.get(tag, {}).items():
+        if needle in kname:
+            return line.get(counter)
+    return None
+
+
+try:
+    known = None
+    for ln in open(os.path.join(out, "pmc_fetch.log")):
+        if ln.startswith("known_bytes"):
+            _, rb, wb, _, frames = ln.split()
+            known = (int(rb), int(wb), int(frames))
+    fr_cal, fr_k = mean_of("pmc_fetch", "k_calib_read12", "FETCH_SIZE"), mean_of("pmc_fetch", "k_fused_lean", "FETCH_SIZE")
+    wr_cal, wr_k = mean_of("pmc_write", "k_calib_write16", "WRITE_SIZE"), mean_of("pmc_write", "k_fused_lean", "WRITE_SIZE")
+    if known and fr_cal and wr_cal and fr_k and wr_k:
+        sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+        import bench
+        scale_r, scale_w = known[0] / (fr_cal * 1024.0), known[1] / (wr_cal * 1024.0)
+        traffic = {"kernel": "k_fused_lean<4,float,133>", "frames_per_launch": known[2],
+                   "workload": "BASELINE configs[1]: %d frames per launch" % known[2],
+                   "FETCH_SIZE_KB_raw": fr_k, "WRITE_SIZE_KB_raw": wr_k,
+                   "calibration": {"how": "snowtri_calib_stream in the same rocprofv3 pass: 12-byte records read per lane / 16-byte records "
+                                          "written per lane, known byte counts", "read_bytes": known[0], "FETCH_SIZE_KB_raw": fr_cal,
+                                   "read_scale": scale_r, "write_bytes": known[1], "WRITE_SIZE_KB_raw": wr_cal, "write_scale": scale_w},
+                   "hbm_read_bytes_per_launch": fr_k * 1024.0 * scale_r, "hbm_write_bytes_per_launch": wr_k * 1024.0 * scale_w,
+                   "hbm_bytes_per_launch": fr_k * 1024.0 * scale_r + wr_k * 1024.0 * scale_w,
+                   "algorithmic_bytes_per_launch": 8512 * known[2], "source_sha256": bench.kernel_source_hash()}
+        json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
+        print("== HBM traffic per fused launch: %.2f MB read + %.2f MB written = %.2f MB vs %.2f MB algorithmic (read scale %.3f, write scale %.3f)" % (
+            traffic["hbm_read_bytes_per_launch"] / 1e6, traffic["hbm_write_bytes_per_launch"] / 1e6, traffic["hbm_bytes_per_launch"] / 1e6,
+            traffic["algorithmic_bytes_per_launch"] / 1e6, scale_r, scale_w))
+except Exception as e:      # a summary without the traffic block is still useful
+    print("traffic summary failed:", repr(e))
 json.dump(summary, open(os.path.join(out, "summary.json"), "w"), indent=1)
