@@ -144,6 +144,63 @@ __device__ __forceinline__ double candidate_chunk_sum(const RayRec *__restrict__
     return acc;
 }
 
+// ---- the fast phase-1 arithmetic for GS candidates that share their FIRST ray: one person of camera m against GS
+// persons of camera s.  The first ray, its score and e = h_m . d are read / computed once per joint instead of once per
+// candidate (LDS reads per solve 6 -> 3.75 at GS = 4), and the GS solves of a joint share one reciprocal, so any joint
+// count works without a tail.  The lane walks joints jsub, jsub + JS, ...; acc[u] += 2000 x score of candidate u.
+// Same solves, gates and raw 1/sqrt as candidate_chunk_sum<false>: the caller's re-do rule applies unchanged.
+template <int GS, typename TIn>
+__device__ __forceinline__ void rowgroup_chunk_sums(const RayRec *__restrict__ ra, const TIn *__restrict__ sa,
+                                                    const RayRec *const (&rb)[GS], const TIn *const (&sb)[GS], int jsub, int JS,
+                                                    int nj, const Vec3 &d, const Params &prm, double (&acc)[GS]) {
+    for (int jj = jsub; jj < nj; jj += JS) {
+        const RayRec a = ra[jj];
+        const TIn sm = sa[jj];
+        const double e = fma(a.z, d.z, fma(a.y, d.y, a.x * d.x));
+        const bool okm = !below_kthr(sm, prm);
+        RayRec b[GS];
+        TIn ss[GS];
+        double bq[GS], g[GS], det[GS], inv[GS];
+#pragma unroll
+        for (int u = 0; u < GS; u++) {
+            b[u] = rb[u][jj];
+            ss[u] = sb[u][jj];
+        }
+#pragma unroll
+        for (int u = 0; u < GS; u++) {
+            bq[u] = fma(a.z, b[u].z, fma(a.y, b[u].y, a.x * b[u].x));
+            g[u] = fma(b[u].z, d.z, fma(b[u].y, d.y, b[u].x * d.x));
+            det[u] = fma(a.a, b[u].a, -(bq[u] * bq[u]));
+        }
+        // one reciprocal for the GS determinants; a singular pair poisons the group's sums (NaN): re-done exactly
+        if constexpr (GS == 4) {
+            const double p01 = det[0] * det[1], p012 = p01 * det[2];
+            double run = rcp_nr2(p012 * det[3]);
+            inv[3] = run * p012;
+            run *= det[3];
+            inv[2] = run * p01;
+            run *= det[2];
+            inv[1] = run * det[0];
+            inv[0] = run * det[1];
+        } else {
+            static_assert(GS == 2, "groups of two or four persons");
+            const double run = rcp_nr2(det[0] * det[1]);
+            inv[0] = run * det[1];
+            inv[1] = run * det[0];
+        }
+#pragma unroll
+        for (int u = 0; u < GS; u++) {
+            const double S0 = fma(b[u].a, e, -(bq[u] * g[u])) * inv[u];
+            const double S1 = fma(a.a, g[u], -(bq[u] * e)) * inv[u];
+            const double fx = fma(b[u].x, S1, fma(a.x, S0, -d.x)), fy = fma(b[u].y, S1, fma(a.y, S0, -d.y)),
+                         fz = fma(b[u].z, S1, fma(a.z, S0, -d.z));
+            const double d2 = fma(fz, fz, fma(fy, fy, fx * fx));
+            const bool kp_ = okm && !below_kthr(ss[u], prm) && !(d2 > prm.dthr2);   // :73-74
+            acc[u] = fma(gated_sum(sm, ss[u], kp_), __builtin_amdgcn_rsq(d2), acc[u]);
+        }
+    }
+}
+
 // Dynamic LDS = recompute_lds_bytes(R, J, kn, sizeof(TIn)); scratch = gridDim.x slabs of
 // recompute_scratch_bytes(Kc, R, kn).  R = C * Pmax ray rows.  Requires keypoint_num <= kRecomputeMaxKn.
 #ifndef SNOWTRI_RECOMPUTE_WAVES
@@ -226,6 +283,7 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
         if (f >= F) break;
         const int32_t *np_f = n_persons ? n_persons + f * C : nullptr;
         const Kp3<TIn> *kpf = kp3 + f * (int64_t)R * J;
+        bool ragged = false;
         for (int k = tid; k < Kc; k += kBlock) {
             sum[k] = 0.0;
             // candidate order of triangulation.py:56-65: camera pair, person of the first camera, person of the second
@@ -234,9 +292,14 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
             const int nm = np_f ? np_f[mc] : Pmax, ns = np_f ? np_f[sc] : Pmax;
             cw[k] = (pm < nm && ps < ns) ? ((uint32_t)(mc * Pmax + pm) | ((uint32_t)(sc * Pmax + ps) << 10) | ((uint32_t)q << 20))
                                          : kNoCand;
+            ragged |= !(pm < nm && ps < ns);
         }
         if (tid == 0 && out_flags) out_flags[f] = 0u;
         bool sing = false;
+        // every camera lists Pmax persons (and Pmax is even): phase 1 runs on groups of candidates that share their
+        // first ray (rowgroup_chunk_sums); a ragged frame keeps one lane per candidate
+        const int GS = (Pmax & 3) == 0 ? 4 : ((Pmax & 1) == 0 ? 2 : 0);
+        const bool grouped = !exact_only && GS != 0 && !__syncthreads_or(ragged ? 1 : 0);
 
         // ---------------- phase 1: candidate score sums, joint chunk by joint chunk -------------
         for (int j0 = 0; j0 < J; j0 += Jc) {
@@ -253,18 +316,68 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
                 }
             }
             __syncthreads();
-            for (int k = tid; k < Kc; k += kBlock) {
-                const uint32_t w = cw[k];
-                if (w == kNoCand) continue;
-                const int rm = (int)(w & 1023u), rs = (int)((w >> 10) & 1023u), q = (int)(w >> 20);
-                const double *pc = pairc + 6 * q;
-                const Vec3 d = {pc[0], pc[1], pc[2]};
-                const RayRec *ra = reinterpret_cast<const RayRec *>(rays + rm * rstride);
-                const RayRec *rb = reinterpret_cast<const RayRec *>(rays + rs * rstride);
-                const TIn *sa = rsc + rm * sstride, *sb = rsc + rs * sstride;
-                const double acc = exact_only ? candidate_chunk_sum<true>(ra, rb, sa, sb, nj, d, prm, sing)
-                                              : candidate_chunk_sum<false>(ra, rb, sa, sb, nj, d, prm, sing);
-                sum[k] += acc * 0.0005;   // the 1 / (2 * 1000) of :72
+            if (grouped) {
+                // item = (camera pair q, person pm of its first camera, group of GS persons of its second); JS lanes
+                // share an item (interleaved joints) when there are fewer items than threads
+                const int NG = Pmax / GS, per_q = Pmax * NG, nitems = rig.npairs * per_q;
+                int JS = 1;
+                while (JS < 8 && 2 * JS * nitems <= kBlock) JS *= 2;
+                const int total = nitems * JS;
+                for (int base = 0; base < total; base += kBlock) {   // same trip count for every lane: shuffles below
+                    const int idx = base + tid;
+                    const bool live = idx < total;
+                    const int item = live ? idx / JS : 0, jsub = live ? idx - item * JS : 0;
+                    const int q = item / per_q, r2 = item - q * per_q, pm = r2 / NG, ps0 = (r2 - pm * NG) * GS;
+                    const int k0 = q * pp + pm * Pmax + ps0;
+                    const int rm = pairs[2 * q] * Pmax + pm, rs0 = pairs[2 * q + 1] * Pmax + ps0;
+                    const double *pc = pairc + 6 * q;
+                    const Vec3 d = {pc[0], pc[1], pc[2]};
+                    const RayRec *ra = reinterpret_cast<const RayRec *>(rays + rm * rstride);
+                    const TIn *sa = rsc + rm * sstride;
+                    const int njl = live ? nj : 0;
+                    if (GS == 4) {
+                        const RayRec *const rb[4] = {reinterpret_cast<const RayRec *>(rays + (rs0 + 0) * rstride),
+                                                     reinterpret_cast<const RayRec *>(rays + (rs0 + 1) * rstride),
+                                                     reinterpret_cast<const RayRec *>(rays + (rs0 + 2) * rstride),
+                                                     reinterpret_cast<const RayRec *>(rays + (rs0 + 3) * rstride)};
+                        const TIn *const sb[4] = {rsc + (rs0 + 0) * sstride, rsc + (rs0 + 1) * sstride, rsc + (rs0 + 2) * sstride,
+                                                  rsc + (rs0 + 3) * sstride};
+                        double acc[4] = {0.0, 0.0, 0.0, 0.0};
+                        rowgroup_chunk_sums<4>(ra, sa, rb, sb, jsub, JS, njl, d, prm, acc);
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            double v = acc[u];
+                            for (int off = JS >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+                            if (live && jsub == 0) sum[k0 + u] += v * 0.0005;   // the 1 / (2 * 1000) of :72
+                        }
+                    } else {
+                        const RayRec *const rb[2] = {reinterpret_cast<const RayRec *>(rays + (rs0 + 0) * rstride),
+                                                     reinterpret_cast<const RayRec *>(rays + (rs0 + 1) * rstride)};
+                        const TIn *const sb[2] = {rsc + (rs0 + 0) * sstride, rsc + (rs0 + 1) * sstride};
+                        double acc[2] = {0.0, 0.0};
+                        rowgroup_chunk_sums<2>(ra, sa, rb, sb, jsub, JS, njl, d, prm, acc);
+#pragma unroll
+                        for (int u = 0; u < 2; u++) {
+                            double v = acc[u];
+                            for (int off = JS >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+                            if (live && jsub == 0) sum[k0 + u] += v * 0.0005;
+                        }
+                    }
+                }
+            } else {
+                for (int k = tid; k < Kc; k += kBlock) {
+                    const uint32_t w = cw[k];
+                    if (w == kNoCand) continue;
+                    const int rm = (int)(w & 1023u), rs = (int)((w >> 10) & 1023u), q = (int)(w >> 20);
+                    const double *pc = pairc + 6 * q;
+                    const Vec3 d = {pc[0], pc[1], pc[2]};
+                    const RayRec *ra = reinterpret_cast<const RayRec *>(rays + rm * rstride);
+                    const RayRec *rb = reinterpret_cast<const RayRec *>(rays + rs * rstride);
+                    const TIn *sa = rsc + rm * sstride, *sb = rsc + rs * sstride;
+                    const double acc = exact_only ? candidate_chunk_sum<true>(ra, rb, sa, sb, nj, d, prm, sing)
+                                                  : candidate_chunk_sum<false>(ra, rb, sa, sb, nj, d, prm, sing);
+                    sum[k] += acc * 0.0005;   // the 1 / (2 * 1000) of :72
+                }
             }
         }
         // candidates whose fast sum cannot decide :80-81 (see candidate_chunk_sum): not finite, or within 1e-6 relative
