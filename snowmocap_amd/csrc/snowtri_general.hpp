@@ -233,7 +233,7 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
     const int C = rig.C, R = C * Pmax, pp = Pmax * Pmax;
     const int kn = prm.kn, ci = prm.center;
     const int Jc = recompute_chunk_joints(R, J, (int)sizeof(TIn));
-    const size_t rstride = recompute_ray_stride(Jc);            // bytes between the ray rows
+    const int rstride = (int)recompute_ray_stride(Jc);          // bytes between the ray rows (32-bit LDS offsets)
     const int sstride = recompute_score_stride(Jc);             // elements between the score rows
     char *rays = smem;                                          // [R] rows of Jc RayRec (+16 B pad)
     TIn *rsc = reinterpret_cast<TIn *>(smem + (size_t)R * rstride);                      // [R][sstride]
@@ -628,7 +628,8 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
                 else
                     cmem[pos] = w;
             }
-            const uint32_t *memw = mem_in_lds ? lmem_lds : cmem;   // generic pointer
+            // (two explicit address spaces: a generic pointer costs a flat load and 64-bit address arithmetic per member)
+            auto member_word = [&](int pos) -> uint32_t { return mem_in_lds ? lmem_lds[pos] : cmem[pos]; };
             if (tid < 64) {
                 int ns = 0;
                 for (int base = 0; base < ncl; base += 64) {
@@ -681,9 +682,9 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
                         const int cid = active ? cid_of_slot[slot] : 0;
                         const int size = active ? csize[cid] : 0, m0 = active ? cstart[cid] : 0;
                         double aS = 0.0, aX = 0.0, aY = 0.0, aZ = 0.0;
-                        uint32_t mw = g < size ? memw[m0 + g] : 0u;
+                        uint32_t mw = g < size ? member_word(m0 + g) : 0u;
                         for (int mi = g; mi < size; mi += G) {
-                            const uint32_t mw_next = (mi + G < size) ? memw[m0 + mi + G] : 0u;   // in flight during this solve
+                            const uint32_t mw_next = (mi + G < size) ? member_word(m0 + mi + G) : 0u;   // in flight during this solve
                             const int rm = (int)(mw & 1023u), rs = (int)((mw >> 10) & 1023u), q = (int)(mw >> 20);
                             mw = mw_next;
                             const double *pc = pairc + 6 * q;
