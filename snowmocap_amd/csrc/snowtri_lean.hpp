@@ -28,7 +28,7 @@ namespace snowtri {
 #ifndef SNOWTRI_LEAN_TW
 #define SNOWTRI_LEAN_TW 12
 #endif
-constexpr int kLeanTw = SNOWTRI_LEAN_TW;  // frames per wave tile (12 x 133 = 24.94 passes of 64 lanes)
+constexpr int kLeanTw = SNOWTRI_LEAN_TW;  // frames per wave tile (12 x 133 = 24.94 passes of 64 lanes; 10 would make the single-cluster check one pass of 60 lanes instead of two, measured: the same 348 instructions per item)
 constexpr int kLeanWaves = kBlock / 64;  // waves per workgroup
 constexpr int kLeanSlowShift = 4;        // slow-frame bit index = (tile ordinal of the workgroup << 4) | frame in tile
 
@@ -251,6 +251,7 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean(
     for (int i = 0; i < 3 * NP; i++) dS[i] = uniform_f64(rig.pairc[6 * (i / 3) + i % 3]);
     const float kthr_f32 = prm.kthr_f32;
     const double kthr = prm.kthr, dthr2 = prm.dthr2;
+    const double ctol2_lo = prm.ctol < 0.0 ? -1.0 : prm.ctol * prm.ctol * (1.0 - 1e-12);   // single-cluster check, see there
     __syncthreads();  // constants and the cleared slow-frame bits are visible to every wave
     double Mres[9 * C];
 #if SNOWTRI_LEAN_M_VGPR
@@ -348,14 +349,22 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean(
                 ks = p[sc * JC];
             }
             const double *tm = Mlds + 9 * C + 3 * mc, *ts = Mlds + 9 * C + 3 * sc, *dq = Mlds + 12 * C + 3 * qq;
-            const PairSolve o = pair_solve_fast<true>(make_ray(Mlds + 9 * mc, km.u, km.v), make_ray(Mlds + 9 * sc, ks.u, ks.v),
-                                                      Vec3{dq[0], dq[1], dq[2]},
-                                                      Vec3{tm[0] + ts[0], tm[1] + ts[1], tm[2] + ts[2]});
+            // only the midpoint is needed here: A2 without the distance (sw = Wm + Ws = 2 W)
+            const RayRec a = make_ray(Mlds + 9 * mc, km.u, km.v), b = make_ray(Mlds + 9 * sc, ks.u, ks.v);
+            const double bq = fma(a.z, b.z, fma(a.y, b.y, a.x * b.x));
+            const double e = fma(a.z, dq[2], fma(a.y, dq[1], a.x * dq[0]));
+            const double g = fma(b.z, dq[2], fma(b.y, dq[1], b.x * dq[0]));
+            const double inv = rcp_nr2(fma(a.a, b.a, -(bq * bq)));
+            const double S0 = fma(b.a, e, -(bq * g)) * inv, S1 = fma(a.a, g, -(bq * e)) * inv;
+            const double swx = fma(-b.x, S1, fma(a.x, S0, tm[0] + ts[0])), swy = fma(-b.y, S1, fma(a.y, S0, tm[1] + ts[1])),
+                         swz = fma(-b.z, S1, fma(a.z, S0, tm[2] + ts[2]));
             const int src = lane - qq;  // the frame's pair 0, same pass
-            const double w0x = __shfl(o.sw.x, src, 64), w0y = __shfl(o.sw.y, src, 64), w0z = __shfl(o.sw.z, src, 64);
-            const double ex = 0.5 * (w0x - o.sw.x), ey = 0.5 * (w0y - o.sw.y), ez = 0.5 * (w0z - o.sw.z);
-            const double cd = sqrt(fma(ez, ez, fma(ey, ey, ex * ex)));  // :124
-            if (live && qq > 0 && cd > prm.ctol) {                       // :125
+            const double w0x = __shfl(swx, src, 64), w0y = __shfl(swy, src, 64), w0z = __shfl(swz, src, 64);
+            const double ex = 0.5 * (w0x - swx), ey = 0.5 * (w0y - swy), ez = 0.5 * (w0z - swz);
+            // :124-125 `norm > tol` on the squares, with a 1e-12 guard band: whatever comes near the tolerance (or is
+            // NaN) is left to the exact routine, which takes the square root as the reference does
+            const double c2 = fma(ez, ez, fma(ey, ey, ex * ex));
+            if (live && qq > 0 && !(c2 < ctol2_lo)) {
                 const unsigned bit = slow_base + (unsigned)w;
                 atomicOr(&slowbits[bit >> 5], 1u << (bit & 31u));
             }
