@@ -680,10 +680,70 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
                         const bool active = jj < nj && cb + ci < nsw;
                         const int slot = sbase + cb + ci;
                         const int cid = active ? cid_of_slot[slot] : 0;
+#ifdef SNOWTRI_P3_NOSOLVE   // dev experiment (timing only, outputs are wrong): phase 3 without its member solves
+                        const int size = 0, m0 = 0;
+#else
                         const int size = active ? csize[cid] : 0, m0 = active ? cstart[cid] : 0;
+#endif
                         double aS = 0.0, aX = 0.0, aY = 0.0, aZ = 0.0;
-                        uint32_t mw = g < size ? member_word(m0 + g) : 0u;
-                        for (int mi = g; mi < size; mi += G) {
+                        if constexpr (sizeof(TOut) == 4) {
+                            // float32 outputs, TWO members per iteration: the member loop is a chain of dependent LDS reads
+                            // (member word -> pair constants and two ray rows at per-lane addresses) and of a dependent
+                            // solve; two independent chains in flight hide half of that latency, and the pair shares one
+                            // reciprocal.  1/dist is the raw v_rsq_f64 (measured 2^-24.2 relative, below the float32
+                            // rounding of the stored score: same contract as k_fused_lean); sq = 2000 x the score of :72.
+                            struct Half {
+                                RayRec a, b;
+                                Vec3 d, tsum;
+                                TIn sm, ss;
+                                double bq, e, g, det;
+                            };
+                            auto front = [&](uint32_t w) {
+                                Half h;
+                                const int rm = (int)(w & 1023u), rs = (int)((w >> 10) & 1023u), q = (int)(w >> 20);
+                                const double *pc = pairc + 6 * q;
+                                h.d = {pc[0], pc[1], pc[2]};
+                                h.tsum = {pc[3], pc[4], pc[5]};
+                                h.a = *reinterpret_cast<const RayRec *>(rays + rm * rstride + 32 * jc);
+                                h.b = *reinterpret_cast<const RayRec *>(rays + rs * rstride + 32 * jc);
+                                h.sm = rsc[rm * sstride + jc];
+                                h.ss = rsc[rs * sstride + jc];
+                                h.bq = fma(h.a.z, h.b.z, fma(h.a.y, h.b.y, h.a.x * h.b.x));
+                                h.e = fma(h.a.z, h.d.z, fma(h.a.y, h.d.y, h.a.x * h.d.x));
+                                h.g = fma(h.b.z, h.d.z, fma(h.b.y, h.d.y, h.b.x * h.d.x));
+                                h.det = fma(h.a.a, h.b.a, -(h.bq * h.bq));
+                                return h;
+                            };
+                            auto back = [&](const Half &h, double inv, bool use) {
+                                const double S0 = fma(h.b.a, h.e, -(h.bq * h.g)) * inv;
+                                const double S1 = fma(h.a.a, h.g, -(h.bq * h.e)) * inv;
+                                const double fx = fma(h.b.x, S1, fma(h.a.x, S0, -h.d.x)), fy = fma(h.b.y, S1, fma(h.a.y, S0, -h.d.y)),
+                                             fz = fma(h.b.z, S1, fma(h.a.z, S0, -h.d.z));
+                                const double d2 = fma(fz, fz, fma(fy, fy, fx * fx));
+                                const bool kp_ = use && !below_kthr(h.sm, prm) && !below_kthr(h.ss, prm) && !(d2 > prm.dthr2);
+                                // the gate ASSIGNS 0 (:73-74): select after the product (0 * inf at an exact intersection)
+                                const double sq = kp_ ? sum_score(h.sm, h.ss) * __builtin_amdgcn_rsq(d2) : 0.0;
+                                aS += sq;                                                          // :141
+                                aX = fma(sq, fma(-h.b.x, S1, fma(h.a.x, S0, h.tsum.x)), aX);       // :144-147
+                                aY = fma(sq, fma(-h.b.y, S1, fma(h.a.y, S0, h.tsum.y)), aY);
+                                aZ = fma(sq, fma(-h.b.z, S1, fma(h.a.z, S0, h.tsum.z)), aZ);
+                            };
+                            uint32_t w0 = g < size ? member_word(m0 + g) : 0u;
+                            uint32_t w1 = g + G < size ? member_word(m0 + g + G) : w0;
+                            for (int mi = g; mi < size; mi += 2 * G) {
+                                const bool two = mi + G < size;
+                                const uint32_t n0 = (mi + 2 * G < size) ? member_word(m0 + mi + 2 * G) : 0u;   // in flight during the solves
+                                const uint32_t n1 = (mi + 3 * G < size) ? member_word(m0 + mi + 3 * G) : n0;
+                                const Half h0 = front(w0), h1 = front(w1);   // (w1 repeats w0 when the cluster has no second member left)
+                                const double run = rcp_nr2(h0.det * h1.det);
+                                back(h0, run * h1.det, true);
+                                back(h1, run * h0.det, two);
+                                w0 = n0;
+                                w1 = n1;
+                            }
+                        }
+                        uint32_t mw = (sizeof(TOut) != 4 && g < size) ? member_word(m0 + g) : 0u;
+                        for (int mi = g; sizeof(TOut) != 4 && mi < size; mi += G) {
                             const uint32_t mw_next = (mi + G < size) ? member_word(m0 + mi + G) : 0u;   // in flight during this solve
                             const int rm = (int)(mw & 1023u), rs = (int)((mw >> 10) & 1023u), q = (int)(mw >> 20);
                             mw = mw_next;
