@@ -7,6 +7,7 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 import snowmocap_amd as api
 import test_gpu_parity as T
+import test_gpu_lean as TL
 
 real_rng = np.random.default_rng
 
@@ -23,7 +24,9 @@ sweeps = [("small_rigs auto", lambda e: T.test_random_small_rigs_against_oracle(
           ("special spill", lambda e: T.test_random_special_values_against_oracle(api, "spill", e)),
           ("single person", lambda e: T.test_random_single_person_fast_path_and_fallback(api)),
           ("dlt multi", lambda e: T.test_random_small_rigs_dlt_against_oracle(api)),
-          ("per-frame api", lambda e: T.test_random_small_rigs_per_frame_api(api))]
+          ("per-frame api", lambda e: T.test_random_small_rigs_per_frame_api(api)),
+          ("lean thresholds", lambda e: TL.test_lean_random_thresholds_and_person_lists(api)),
+          ("lean special", lambda e: TL.test_lean_special_values(api))]
 fails = 0
 t0 = time.time()
 for r in range(rounds):

@@ -551,9 +551,12 @@ def test_random_small_rigs_dlt_against_oracle(api):
         bt.close()
         msg = f"trial {trial}: C={C} P={P} J={J} F={F} {prm} pout={pout} n={npers.tolist()}"
         np.testing.assert_array_equal(out["count"], wcnt, err_msg=msg)
-        err = np.abs(out["xyzs"][..., :3] - want[..., :3])
         # 1e-9 m when a cluster is one person; persons merged by a wide condense_distance_tol make the smallest
-        # eigenvalue of A^T A poorly separated, and A^T A (kernel) vs the SVD of A (oracle) then differ by ~1e-7 m
+        # eigenvalue of A^T A poorly separated, and A^T A (kernel) vs the SVD of A (oracle) then differ by ~1e-7 m.
+        # Such a merged "person" can also sit near the plane at infinity (w ~ 0: |X| = 5e5 m in soak round 38), so
+        # the bound is relative to the point's size beyond 1 m.
+        size = np.maximum(1.0, np.abs(want[..., :3]).max(axis=-1, keepdims=True))
+        err = np.abs(out["xyzs"][..., :3] - want[..., :3]) / size
         assert err.max() < 1e-6, msg + f" max err {err.max():.3e} at {np.unravel_index(err.argmax(), err.shape)}"
         np.testing.assert_allclose(out["xyzs"][..., 3], want[..., 3], rtol=1e-12, err_msg=msg)
         np.testing.assert_allclose(out["pscore"], wps, rtol=1e-12, err_msg=msg)
