@@ -18,8 +18,10 @@
 //     gate (:73) is evaluated once per camera into a lane mask; exact intersection / singular pair / NaN are
 //     detected on the score sum; the per-pair offsets d = t_s - t_m live in scalar registers (one SGPR operand
 //     per v_fma_f64, no LDS read, no VGPR); item -> (frame, joint) uses the compile-time J; loads and stores
-//     take a scalar base + 32-bit lane offset; lanes past the end of a tile recompute its last item instead
-//     of branching around the stores.
+//     go through BUFFER instructions whose descriptor covers exactly the wave's tile: the byte offset of item
+//     lane + 64 k inside a tile is the same for every tile, so it comes from a small LDS table (no division, no
+//     64-bit address arithmetic, no clamp), lanes past the end of the tile read zeros and their stores are
+//     dropped by the range check of the hardware.
 #pragma once
 #include "snowtri_fused.hpp"
 
@@ -32,10 +34,42 @@ constexpr int kLeanTw = SNOWTRI_LEAN_TW;  // frames per wave tile (12 x 133 = 24
 constexpr int kLeanWaves = kBlock / 64;  // waves per workgroup
 constexpr int kLeanSlowShift = 4;        // slow-frame bit index = (tile ordinal of the workgroup << 4) | frame in tile
 
+__host__ __device__ constexpr int lean_items_pad(int JC) { return (kLeanTw * JC + 63) / 64 * 64; }   // item slots of a wave tile, whole passes
+__host__ __device__ constexpr int lean_table_entries(int JC) { return lean_items_pad(JC) + 256; }      // + the prefetch distance past the last pass
+__host__ __device__ constexpr int lean_const_doubles(int C) { return (12 * C + 4 * (C * (C - 1) / 2) + 1) & ~1; }  // M[C][9], t[C][3], d[NP][3], pairs[NP][2] (int32)
+
 __host__ __device__ constexpr size_t lean_lds_bytes(int C, int JC, int slow_words) {
-    const size_t stash = (size_t)kLeanWaves * kLeanTw * JC * 8;              // fused joint scores, per wave
-    const size_t consts = (size_t)8 * ((12 * C + 4 * (C * (C - 1) / 2) + 1) & ~1);  // M[C][9], t[C][3], d[NP][3], pairs[NP][2] (int32)
-    return ((stash + consts + (size_t)4 * slow_words) + 15) & ~(size_t)15;
+    const size_t stash = (size_t)kLeanWaves * lean_items_pad(JC) * 4;        // fused joint scores (float32 as stored), per wave
+    const size_t table = (size_t)4 * lean_table_entries(JC);                 // item -> byte offset of its camera-0 keypoint in the tile
+    return (((size_t)8 * lean_const_doubles(C) + table + stash + (size_t)4 * slow_words) + 15) & ~(size_t)15;
+}
+
+// Raw buffer descriptor (stride 0, range-checked on the byte offset) over [base, base + bytes)
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t lean_rsrc(const void *base, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
+}
+
+typedef unsigned lean_u3 __attribute__((ext_vector_type(3)));
+typedef unsigned lean_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned lean_u2 __attribute__((ext_vector_type(2)));
+
+// one keypoint record at byte offset voff + soff of the buffer (zeros when out of range)
+template <typename TIn>
+__device__ __forceinline__ Kp3<TIn> lean_load_kp3(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
+    Kp3<TIn> k;
+    if constexpr (sizeof(TIn) == 4) {
+        const lean_u3 w = __builtin_amdgcn_raw_buffer_load_b96(r, (int)voff, (int)soff, 0);
+        k.u = __uint_as_float(w.x);
+        k.v = __uint_as_float(w.y);
+        k.s = __uint_as_float(w.z);
+    } else {
+        const lean_u4 w = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
+        const lean_u2 z = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff + 16, (int)soff, 0);
+        k.u = __hiloint2double((int)w.y, (int)w.x);
+        k.v = __hiloint2double((int)w.w, (int)w.z);
+        k.s = __hiloint2double((int)z.y, (int)z.x);
+    }
+    return k;
 }
 
 __device__ __forceinline__ double uniform_f64(double x) {  // wave-uniform value -> scalar registers
@@ -201,15 +235,19 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean(
     int32_t *__restrict__ out_count, uint32_t *__restrict__ out_flags, char *scratch, size_t scratch_per_block) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NP = C * (C - 1) / 2;
-    constexpr int kItemsMax = kLeanTw * JC;
-    constexpr int kConstDoubles = (12 * C + 4 * NP + 1) & ~1;
+    constexpr int kItemsPad = lean_items_pad(JC);
+    constexpr int kTable = lean_table_entries(JC);
+    constexpr int kConstDoubles = lean_const_doubles(C);
+    constexpr unsigned kRec = (unsigned)sizeof(Kp3<TIn>);       // bytes of one keypoint record
+    constexpr unsigned kCamStride = (unsigned)JC * kRec;        // camera c of a frame is c * kCamStride past camera 0
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // scalar: tile bookkeeping and loop control stay on the SALU
-    // LDS: [rig constants | per-wave stash of fused joint scores | slow-frame bit words]; the constants sit at
-    // offset 0 so that every ds_read of them is base + immediate
+    // LDS: [rig constants | item -> input offset table | per-wave stash of fused joint scores | slow-frame bit words];
+    // the constants sit at offset 0 so that every ds_read of them is base + immediate
     double *Mlds = reinterpret_cast<double *>(smem);
-    double *stash = Mlds + kConstDoubles + wave * kItemsMax;
-    uint32_t *slowbits = reinterpret_cast<uint32_t *>(Mlds + kConstDoubles + kLeanWaves * kItemsMax);
+    uint32_t *table = reinterpret_cast<uint32_t *>(Mlds + kConstDoubles);
+    float *stash = reinterpret_cast<float *>(table + kTable) + wave * kItemsPad;
+    uint32_t *slowbits = reinterpret_cast<uint32_t *>(reinterpret_cast<float *>(table + kTable) + kLeanWaves * kItemsPad);
     const Kp3<TIn> *kp3 = reinterpret_cast<const Kp3<TIn> *>(kpts);
     const int64_t wstride = (int64_t)gridDim.x * kLeanWaves;
 #if SNOWTRI_LEAN_RING == 3
@@ -218,26 +256,27 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean(
     Kp3<TIn> bufA[C], bufB[C];
 #endif
 
-    // lane's k-th item of a tile: i = lane + 64 k, clamped to the tile's last item (lanes past the end redo it:
-    // same inputs, same outputs, same addresses -- no branch around the stores); input record of camera c is
-    // tile_in[(i + (i / JC) (C-1) JC) + c JC]
-    auto fetch = [&](Kp3<TIn>(&dst)[C], const Kp3<TIn> *tile_in, unsigned i, unsigned last) {
-        i = i < last ? i : last;
-        const unsigned off = i + (i / (unsigned)JC) * (unsigned)((C - 1) * JC);
-        const char *p = reinterpret_cast<const char *>(tile_in) + (size_t)(off * (unsigned)sizeof(Kp3<TIn>));
+    // Item i = lane + 64 k of a tile is joint i % JC of the tile's frame i / JC; its camera-c record sits at byte
+    // (i + (i / JC) (C-1) JC + c JC) kRec of the tile.  The part that does not depend on c is the same for every tile:
+    // table[i].  Cameras come in pairs: an even camera goes into the scalar offset, the odd one adds an immediate.
+    auto fetch = [&](Kp3<TIn>(&dst)[C], __amdgpu_buffer_rsrc_t rin, unsigned voff) {
 #pragma unroll
-        for (int c = 0; c < C; c++) dst[c] = *reinterpret_cast<const Kp3<TIn> *>(p + (size_t)c * JC * sizeof(Kp3<TIn>));
+        for (int c = 0; c < C; c++)
+            dst[c] = lean_load_kp3<TIn>(rin, voff + (unsigned)(c & 1) * kCamStride, (unsigned)(c & ~1) * kCamStride);
     };
+    // offsets of the lane's first two items, the same in every tile
+    const unsigned i0 = (unsigned)lane, i1 = (unsigned)lane + 64u;
+    const unsigned voff0 = (i0 + (i0 / (unsigned)JC) * (unsigned)((C - 1) * JC)) * kRec;
+    const unsigned voff1 = (i1 + (i1 / (unsigned)JC) * (unsigned)((C - 1) * JC)) * kRec;
 
     int64_t tile = (int64_t)blockIdx.x * kLeanWaves + wave;
     int64_t f0 = 0;
     int nf = 0;
     if (tile < ntiles) {
         lean_tile_range(tile, tile_base, tile_rem, f0, nf);
-        const Kp3<TIn> *tile_in = kp3 + f0 * (int64_t)(C * JC);
-        const unsigned last = (unsigned)(nf * JC - 1);
-        fetch(bufA, tile_in, (unsigned)lane, last);
-        fetch(bufB, tile_in, (unsigned)lane + 64u, last);
+        const __amdgpu_buffer_rsrc_t rin = lean_rsrc(kp3 + f0 * (int64_t)(C * JC), (unsigned)(nf * C * JC) * kRec);
+        fetch(bufA, rin, voff0);
+        fetch(bufB, rin, voff1);
     }
     // (the first keypoints are in flight while the constants are set up)
     if (tid < 9 * C) Mlds[tid] = rig.M[tid];
@@ -245,6 +284,8 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean(
     if (tid < 3 * NP) Mlds[12 * C + tid] = rig.pairc[6 * (tid / 3) + tid % 3];
     int32_t *pairs_lds = reinterpret_cast<int32_t *>(Mlds + 12 * C + 3 * NP);
     if (tid < 2 * NP) pairs_lds[tid] = rig.pairs[tid];
+    for (unsigned i = (unsigned)tid; i < (unsigned)kTable; i += kBlock)
+        table[i] = (i + (i / (unsigned)JC) * (unsigned)((C - 1) * JC)) * kRec;
     for (int i = tid; i < slow_words; i += kBlock) slowbits[i] = 0u;
     double dS[3 * NP];  // per-pair d = t_s - t_m, wave-uniform -> scalar registers
 #pragma unroll
@@ -252,7 +293,7 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean(
     const float kthr_f32 = prm.kthr_f32;
     const double kthr = prm.kthr, dthr2 = prm.dthr2;
     const double ctol2_lo = prm.ctol < 0.0 ? -1.0 : prm.ctol * prm.ctol * (1.0 - 1e-12);   // single-cluster check, see there
-    __syncthreads();  // constants and the cleared slow-frame bits are visible to every wave
+    __syncthreads();  // constants, table and the cleared slow-frame bits are visible to every wave
     double Mres[9 * C];
 #if SNOWTRI_LEAN_M_VGPR
 #pragma unroll
@@ -260,8 +301,9 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean(
 #endif
 
     for (int ord = 0; tile < ntiles; tile += wstride, ord++) {
-        const Kp3<TIn> *tile_in = kp3 + f0 * (int64_t)(C * JC);
-        float4 *tile_out = reinterpret_cast<float4 *>(out4) + f0 * (int64_t)JC;
+        const __amdgpu_buffer_rsrc_t rin = lean_rsrc(kp3 + f0 * (int64_t)(C * JC), (unsigned)(nf * C * JC) * kRec);
+        const __amdgpu_buffer_rsrc_t rout =
+            lean_rsrc(reinterpret_cast<float4 *>(out4) + f0 * (int64_t)JC, (unsigned)(nf * JC) * 16u);
         const unsigned last = (unsigned)(nf * JC - 1);
 #ifdef SNOWTRI_LEAN_NOLOOP  // dev experiment (timing only, outputs are wrong): fixed cost of a launch without its items
         const int npass = 0;
@@ -281,38 +323,57 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean(
             cks[pass] = p[pairs_lds[2 * qq + 1] * JC];
         }
 
-        auto solve_store = [&](const Kp3<TIn>(&buf)[C], unsigned i) {
-            i = i < last ? i : last;
+        // item `is` + 64 k of the lane: output record at byte 16 (is + 64 k), stash slot is + 64 k.  Lanes past the
+        // tile's last item work on zeros; their store is out of the descriptor's range and their stash slot is padding.
+        auto solve_store = [&](const Kp3<TIn>(&buf)[C], unsigned out_off, float *stash_slot) {
             float ox, oy, oz;
             double os;
             const bool bad = lean_item<C>(Mlds, Mres, dS, buf, kthr_f32, kthr, dthr2, ox, oy, oz, os);
-            *reinterpret_cast<float4 *>(reinterpret_cast<char *>(tile_out) + (size_t)(i * 16u)) =
-                make_float4(ox, oy, oz, (float)os);
-            stash[i] = os;
+            const float osf = (float)os;
+            lean_u4 rec;
+            rec.x = __float_as_uint(ox);
+            rec.y = __float_as_uint(oy);
+            rec.z = __float_as_uint(oz);
+            rec.w = __float_as_uint(osf);
+            __builtin_amdgcn_raw_buffer_store_b128(rec, rout, (int)out_off, 0, 0);
+            *stash_slot = osf;
             if (__ballot(bad)) {  // rare, wave-uniform branch
+                unsigned o = out_off;
+                asm volatile("" : "+v"(o));  // (keeps the bit arithmetic below inside the branch)
+                const unsigned i = o >> 4;
                 const unsigned bit = slow_base + i / (unsigned)JC;
-                if (bad) atomicOr(&slowbits[bit >> 5], 1u << (bit & 31u));
+                if (bad && i <= last) atomicOr(&slowbits[bit >> 5], 1u << (bit & 31u));
             }
         };
         // ---- item loop: a ring of three register buffers keeps the keypoints of the next two items in flight
-        unsigned is = (unsigned)lane;  // item being solved; the one being fetched is two passes ahead
+        unsigned out_off = (unsigned)lane * 16u;           // 16 x (item being solved); the one being fetched is two passes ahead
+        float *sp = stash + lane;                          // its stash slot
+        const uint32_t *tp = table + lane;                 // its table entry
 #if SNOWTRI_LEAN_RING == 3
+        unsigned t0 = tp[128], t1 = tp[192], t2 = tp[256];  // (read one iteration ahead of their use)
         for (int k = 0; k < npass; k += 3) {
-            fetch(bufC, tile_in, is + 128u, last);
-            solve_store(bufA, is);
-            fetch(bufA, tile_in, is + 192u, last);
-            if (k + 1 < npass) solve_store(bufB, is + 64u);
-            fetch(bufB, tile_in, is + 256u, last);
-            if (k + 2 < npass) solve_store(bufC, is + 128u);
-            is += 192u;
+            fetch(bufC, rin, t0);
+            solve_store(bufA, out_off, sp);
+            fetch(bufA, rin, t1);
+            if (k + 1 < npass) solve_store(bufB, out_off + 1024u, sp + 64);
+            fetch(bufB, rin, t2);
+            if (k + 2 < npass) solve_store(bufC, out_off + 2048u, sp + 128);
+            tp += 192;
+            t0 = tp[128];
+            t1 = tp[192];
+            t2 = tp[256];
+            out_off += 3072u;
+            sp += 192;
         }
 #else  // two buffers: the solved one is refilled at once (fetch distance still two passes)
         for (int k = 0; k < npass; k += 2) {
-            solve_store(bufA, is);
-            fetch(bufA, tile_in, is + 128u, last);
-            if (k + 1 < npass) solve_store(bufB, is + 64u);
-            fetch(bufB, tile_in, is + 192u, last);
-            is += 128u;
+            solve_store(bufA, out_off, sp);
+            fetch(bufA, rin, tp[128]);
+            if (k + 1 < npass) solve_store(bufB, out_off + 1024u, sp + 64);
+            fetch(bufB, rin, tp[192]);
+            tp += 128;
+            out_off += 2048u;
+            sp += 128;
         }
 #endif
         // this wave's next tile: its first two fetches fly during the epilogue
@@ -321,10 +382,9 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean(
         const int64_t nt = tile + wstride;
         if (nt < ntiles) {
             lean_tile_range(nt, tile_base, tile_rem, f0, nf);
-            const Kp3<TIn> *next_in = kp3 + f0 * (int64_t)(C * JC);
-            const unsigned nlast = (unsigned)(nf * JC - 1);
-            fetch(bufA, next_in, (unsigned)lane, nlast);
-            fetch(bufB, next_in, (unsigned)lane + 64u, nlast);
+            const __amdgpu_buffer_rsrc_t rnext = lean_rsrc(kp3 + f0 * (int64_t)(C * JC), (unsigned)(nf * C * JC) * kRec);
+            fetch(bufA, rnext, voff0);
+            fetch(bufB, rnext, voff1);
         }
 
         // ---- single-cluster check (:116-130): every candidate's centre joint within condense_distance_tol of
@@ -378,18 +438,18 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean(
             const int64_t f = f0_cur + (live ? w : 0);
             double sum = 0.0;
             if (live) {
-                const double *row = stash + w * JC;
+                const float *row = stash + w * JC;
                 double s1 = 0.0, s2 = 0.0, s3 = 0.0;
                 int b = sub;
 #pragma unroll 2
                 for (; b + 3 * G < JC; b += 4 * G) {
-                    const double v0 = row[b], v1 = row[b + G], v2 = row[b + 2 * G], v3 = row[b + 3 * G];
+                    const double v0 = (double)row[b], v1 = (double)row[b + G], v2 = (double)row[b + 2 * G], v3 = (double)row[b + 3 * G];
                     sum += v0;
                     s1 += v1;
                     s2 += v2;
                     s3 += v3;
                 }
-                for (; b < JC; b += G) sum += row[b];
+                for (; b < JC; b += G) sum += (double)row[b];
                 sum = (sum + s1) + (s2 + s3);
             }
             int not_one = 0;
@@ -403,7 +463,10 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean(
             if (live && sub == 0) {
                 const double avg = sum / (double)JC;
                 const unsigned bit = slow_base + (unsigned)w;
-                const bool slow = ((slowbits[bit >> 5] >> (bit & 31u)) & 1u) != 0u || (avg < prm.score_tol) || not_one != 0;  // :151-152
+                // :151-152; the mean is taken over the joint scores as stored (float32): a mean within 1e-6 of the
+                // tolerance is decided by the exact routine on the float64 scores
+                const bool slow = ((slowbits[bit >> 5] >> (bit & 31u)) & 1u) != 0u || !(avg >= prm.score_tol) ||
+                                  fabs(avg - prm.score_tol) < 1e-6 * fabs(prm.score_tol) || not_one != 0;
                 if (slow) {
                     atomicOr(&slowbits[bit >> 5], 1u << (bit & 31u));
                 } else {
