@@ -95,6 +95,7 @@ _SIGNATURES = {
     "snowtri_set_timing": (ct.c_int, [_c_p, ct.c_int]),
     "snowtri_timing_collect": (ct.c_int, [_c_p, _c_p, ct.c_int32]),
     "snowtri_last_slow_frames": (ct.c_int64, [_c_p]),
+    "snowtri_last_handover_persons": (ct.c_int64, [_c_p, _c_p]),
 }
 
 _lib = None
@@ -237,6 +238,13 @@ class Context:
 
     def last_slow_frames(self):
         return int(lib().snowtri_last_slow_frames(self.handle))
+
+    def last_handover_persons(self):
+        """(persons fused as complete-graph clusters, persons fused from member lists) of the last multi-person call,
+        (-1, -1) if it did not arm the hand-over."""
+        other = ct.c_int64(-1)
+        n = int(lib().snowtri_last_handover_persons(self.handle, ct.byref(other)))
+        return n, int(other.value)
 
 
 _scratch_ctx = {}

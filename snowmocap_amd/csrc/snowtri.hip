@@ -18,6 +18,7 @@
 
 #include "snowtri_fused.hpp"
 #include "snowtri_lean.hpp"
+#include "snowtri_cluster.hpp"
 #include "snowtri_general.hpp"
 #include "snowtri_smooth.hpp"
 #include "snowtri_blender.hpp"
@@ -125,7 +126,7 @@ struct snowtri_ctx {
     double *dM = nullptr, *dt = nullptr, *dpairc = nullptr, *dP = nullptr;
     int32_t *dpairs = nullptr;
     unsigned long long *d_counters = nullptr;  // [0] singular pairs, [1] slow frames, [2..] spare
-    Scratch in, out, work, misc, aux;
+    Scratch in, out, work, misc, aux, desc;   // desc: cluster descriptors handed from k_frame_recompute to k_cluster_fuse
     // measurement
     bool timing = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -134,8 +135,10 @@ struct snowtri_ctx {
     std::vector<hipEvent_t> ev_ring;  // 2 events per recorded fused call (begin, end), kTimingRing calls deep
     int64_t ev_count = 0;             // fused calls recorded since the last snowtri_timing_collect
     int64_t last_slow_frames = 0;
+    bool last_handover = false;  // the last fused call went through k_frame_recompute with the cluster hand-over armed
     int general_mode = 0;  // dev/test knob: 0 auto, 1 force the spill kernel, 2 force the recompute kernel
     int lean_mode = 1;     // dev/test knob: 0 keeps float32-output batches on k_fused_single (A/B against k_fused_lean)
+    int handover_mode = 1; // dev/test knob: 0 keeps phase 3 of the multi-person path inside k_frame_recompute (A/B against k_cluster_fuse)
     Rig rig() const { return Rig{dM, dt, dpairs, dpairc, dP, C, npairs}; }
 };
 
@@ -175,6 +178,7 @@ int snowtri_ctx_create(int32_t C, const double *K, const double *R, const double
     ctx->C = C;
     if (const char *gm = getenv("SNOWTRI_GENERAL_MODE")) ctx->general_mode = atoi(gm);
     if (const char *lm = getenv("SNOWTRI_LEAN_MODE")) ctx->lean_mode = atoi(lm);
+    if (const char *hm = getenv("SNOWTRI_HANDOVER_MODE")) ctx->handover_mode = atoi(hm);
     ctx->hM.resize((size_t)C * 9);
     ctx->ht.assign(t, t + (size_t)C * 3);
     ctx->hK.assign(K, K + (size_t)C * 9);
@@ -272,6 +276,7 @@ int snowtri_ctx_destroy(snowtri_ctx *ctx) {
     ctx->work.release();
     ctx->misc.release();
     ctx->aux.release();
+    ctx->desc.release();
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
     for (auto &e : ctx->ev_ring)
@@ -335,6 +340,17 @@ int snowtri_last_kernel_ms(snowtri_ctx *ctx, float kernel_ms[2]) {
 }
 
 int64_t snowtri_last_slow_frames(snowtri_ctx *ctx) { return ctx ? ctx->last_slow_frames : -1; }
+
+int64_t snowtri_last_handover_persons(snowtri_ctx *ctx, int64_t *n_other) {
+    if (n_other) *n_other = -1;
+    if (!ctx || !ctx->last_handover) return -1;
+    DeviceGuard guard(ctx->device);
+    unsigned long long n[2] = {0, 0};   // complete-graph clusters, clusters of any other shape
+    if (hipDeviceSynchronize() != hipSuccess) return -1;
+    if (hipMemcpy(n, ctx->d_counters + 3, sizeof(n), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (n_other) *n_other = (int64_t)n[1];
+    return (int64_t)n[0];
+}
 
 int64_t snowtri_num_candidate_slots(int32_t C, int32_t Pmax) {
     if (C < 0 || Pmax < 0) return -1;
@@ -1162,13 +1178,32 @@ int launch_frame_general(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax, 
     return SNOWTRI_OK;
 }
 
+// The streaming kernels for the descriptors a k_frame_recompute launch over Fs frames left behind (snowtri_cluster.hpp):
+// `cnt[0]` complete-graph clusters in desc[0, cap), `cnt[1]` clusters of any other shape in desc[cap, 2 cap) with their
+// member words in `words`.
+template <int C, typename TIn>
+int launch_cluster_fuse(snowtri_ctx *ctx, hipStream_t st, int64_t Fs, int Pmax, int J, const TIn *d_kpts, const Params &prm,
+                        int Pout, float *d_xyzs, const ClusterDesc *desc, const uint32_t *words,
+                        const unsigned long long *cnt, uint32_t cap) {
+    const int64_t passes_max = (Fs * Pout * (int64_t)J + 63) / 64;
+    int ppw = 24;   // passes per wave when every frame fills its Pout slots
+    if (const char *e = getenv("SNOWTRI_CLUSTER_PASSES_PER_WAVE")) ppw = std::max(1, atoi(e));
+    const int64_t W = std::max<int64_t>((passes_max + ppw - 1) / ppw, std::min<int64_t>(passes_max, (int64_t)ctx->num_cus * 8));
+    const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((W + kBlock / 64 - 1) / (kBlock / 64), (int64_t)ctx->num_cus * 64));
+    const unsigned long long jmagic = (((unsigned long long)1 << 40) + (unsigned long long)J - 1) / (unsigned long long)J;
+    hipLaunchKernelGGL((k_cluster_fuse<C, TIn>), dim3(grid), dim3(kBlock), cluster_lds_bytes(C), st, desc, words, cnt, cap, ctx->rig(),
+                       d_kpts, prm, Pmax, J, jmagic, Pout, d_xyzs);
+    HIP_TRY(hipGetLastError());
+    return SNOWTRI_OK;
+}
+
 // Multi-person path without HBM candidate spill (snowtri_general.hpp).
 template <int METHOD, typename TIn, typename TOut>
 int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax, int J, const TIn *d_kpts,
                            const int32_t *d_np, const Params &prm, int Pout, TOut *d_xyzs, TOut *d_ps,
                            int32_t *d_cnt, uint32_t *d_fl) {
     const int64_t Kc = snowtri_num_candidate_slots(ctx->C, Pmax);
-    const int R = ctx->C * Pmax;
+    const int C = ctx->C, R = C * Pmax;
     const size_t per_block = recompute_scratch_bytes(Kc, R, prm.kn);
     // three workgroups per CU share the 160 KB of LDS: each takes 52 KB, what the ray chunk and the tables leave
     // of it holds the member words of phase 3
@@ -1182,15 +1217,67 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, lds));
     if (getenv("SNOWTRI_DEBUG")) fprintf(stderr, "k_frame_recompute: R %d Kc %lld lds %zu occupancy/CU %d\n", R, (long long)Kc, lds, per_cu);
     if (const char *e = getenv("SNOWTRI_RECOMPUTE_WG_PER_CU")) per_cu = atoi(e);
-    int64_t grid = std::min<int64_t>(F, (int64_t)ctx->num_cus * std::max(1, per_cu));
-    grid = std::max<int64_t>(1, std::min<int64_t>(grid, (int64_t)(kMaxScratchBytes / per_block)));
-    int rc = ctx->work.ensure(per_block * (size_t)grid);
-    if (rc) return rc;
-    unsigned long long *next_frame = ctx->d_counters + 2;
-    HIP_TRY(hipMemsetAsync(next_frame, 0, sizeof(unsigned long long), st));
-    hipLaunchKernelGGL(kern, dim3((int)grid), dim3(kBlock), lds, st, F, Pmax, J, (int)Kc, ctx->rig(), d_kpts, d_np,
-                       prm, Pout, d_xyzs, d_ps, d_cnt, d_fl, (char *)ctx->work.p, per_block, next_frame, (int)lds);
-    HIP_TRY(hipGetLastError());
+    // Hand-over of complete-graph clusters to k_cluster_fuse (snowtri_cluster.hpp): float32 outputs, pairwise method,
+    // register-resident rays (<= 8 cameras), 4-bit person fields, a person's mean score derivable from the candidate
+    // means (keypoint_num == J, non-negative scores), descriptors staged in the ray chunk.
+    const bool handover = METHOD == 0 && sizeof(TOut) == 4 && ctx->handover_mode != 0 && C >= 2 && C <= kClusterMaxCams &&
+                          Pmax <= kClusterMaxPersons && prm.kn == J && J <= 256 && prm.kthr >= 0.0 && Pout >= 1 &&
+                          (size_t)Pout * 24 + 80 <= (size_t)kRayChunkBytes;
+    // the two descriptor lists hold Pout persons for every frame of a segment (<= 2 M entries each, 64 MB together), the
+    // member list Kc words per frame (<= 32 M words, 128 MB); row indices are 32-bit
+    const int64_t seg_frames = !handover ? F : std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(((int64_t)2 << 20) / Pout, ((int64_t)32 << 20) / Kc),
+                                                                                      ((int64_t)1 << 31) / R));
+    unsigned long long *next_frame = ctx->d_counters + 2, *hand_counters = ctx->d_counters + 3;
+    for (int64_t s0 = 0; s0 < F; s0 += seg_frames) {
+        const int64_t Fs = std::min<int64_t>(seg_frames, F - s0);
+        int64_t grid = std::min<int64_t>(Fs, (int64_t)ctx->num_cus * std::max(1, per_cu));
+        grid = std::max<int64_t>(1, std::min<int64_t>(grid, (int64_t)(kMaxScratchBytes / per_block)));
+        int rc = ctx->work.ensure(per_block * (size_t)grid);
+        if (rc) return rc;
+        uint32_t cap = 0, word_cap = 0;
+        ClusterDesc *desc = nullptr;
+        uint32_t *words = nullptr;
+        if (handover) {
+            ctx->last_handover = true;
+            cap = (uint32_t)(Fs * Pout);
+            word_cap = (uint32_t)(Fs * Kc);
+            rc = ctx->desc.ensure((size_t)2 * cap * sizeof(ClusterDesc) + (size_t)word_cap * 4);
+            if (rc) return rc;
+            desc = (ClusterDesc *)ctx->desc.p;
+            words = (uint32_t *)(desc + (size_t)2 * cap);
+        }
+        HIP_TRY(hipMemsetAsync(next_frame, 0, 4 * sizeof(unsigned long long), st));   // next_frame + the three hand-over counters
+        const TIn *kp_seg = d_kpts + s0 * (int64_t)R * J * 3;
+        TOut *xyz_seg = d_xyzs + s0 * (int64_t)Pout * prm.kn * 4;
+        hipLaunchKernelGGL(kern, dim3((int)grid), dim3(kBlock), lds, st, Fs, Pmax, J, (int)Kc, ctx->rig(), kp_seg,
+                           d_np ? d_np + s0 * C : nullptr, prm, Pout, xyz_seg, d_ps ? d_ps + s0 * Pout : nullptr, d_cnt + s0,
+                           d_fl ? d_fl + s0 : nullptr, (char *)ctx->work.p, per_block, next_frame, (int)lds,
+                           desc, words, hand_counters, cap, word_cap);
+        HIP_TRY(hipGetLastError());
+        if constexpr (METHOD == 0 && sizeof(TOut) == 4) {
+            if (handover) {
+                switch (C) {
+#define SNOWTRI_CASE(CC)                                                                                                       \
+    case CC:                                                                                                                   \
+        rc = launch_cluster_fuse<CC, TIn>(ctx, st, Fs, Pmax, J, kp_seg, prm, Pout, (float *)xyz_seg, desc, words,             \
+                                          hand_counters, cap);                                                                 \
+        break;
+#ifndef SNOWTRI_DEV_MIN
+                    SNOWTRI_CASE(2)
+                    SNOWTRI_CASE(3)
+                    SNOWTRI_CASE(5)
+                    SNOWTRI_CASE(6)
+                    SNOWTRI_CASE(7)
+#endif
+                    SNOWTRI_CASE(4)
+                    SNOWTRI_CASE(8)
+#undef SNOWTRI_CASE
+                    default: rc = SNOWTRI_ERR_BAD_ARG;
+                }
+                if (rc) return rc;
+            }
+        }
+    }
     return SNOWTRI_OK;
 }
 
@@ -1345,6 +1432,7 @@ extern "C" int snowtri_triangulate_condense(snowtri_ctx *ctx, int64_t F, int32_t
     }
     // no memsets: the kernels own every output word, including the per-frame flags
     ctx->last_slow_frames = -1;
+    ctx->last_handover = false;
     if (in_dtype == SNOWTRI_F32 && out_dtype == SNOWTRI_F32)
         rc = fused_dispatch<float, float>(ctx, st, F, Pmax, J, d_kpts, d_np, prm, Pout_max, d_xyzs, d_ps, d_cnt, d_fl, method);
 #ifdef SNOWTRI_DEV_MIN  // kernel-development builds (scripts/ab_build.sh): float32 I/O, 4 cameras only

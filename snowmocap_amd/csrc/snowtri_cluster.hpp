@@ -1,0 +1,397 @@
+// snowtri_cluster.hpp -- k_cluster_fuse: phase 3 of the multi-person path (triangulation.py:136-152) for the clusters
+// k_frame_recompute could hand over, as a separate streaming kernel.
+//
+// After its association (phases 1-2) k_frame_recompute knows the clusters of a frame.  In a clean recording every
+// person is seen by every camera and its cluster is the COMPLETE graph over one detection per camera: C(C,2) member
+// candidates, one per camera pair, every camera with the same person in all of its pairs.  Such a cluster is exactly
+// the input of the single-person item of k_fused_lean -- C rays, all pair solves, fusion regrouped per ray -- so
+// instead of walking its members one by one from LDS-staged rays (64 VALU per member solve, a second sweep over the
+// frame's ray chunks, barriers) the frame emits one 16-byte descriptor per output person and skips phase 3; this kernel
+// then runs (descriptor, joint) items at the fast kernel's cost per pair.  Clusters of any other shape (ghost candidates
+// that form a cluster of their own, a person one camera missed, two persons merged) take cluster_member_passes in the
+// same launch, which walks the member list of the cluster per (descriptor, joint) lane -- the arithmetic of phase 3, without its ray
+// staging.  Frames whose filter decisions are not safe on the fast arithmetic keep the in-kernel phase 3
+// (snowtri_general.hpp).
+//
+// The descriptor carries everything that depends on the association: frame, output slot, the person index of every
+// camera.  out_count / out_ps / flags / the zero-fill of unused slots are written by k_frame_recompute (the person's
+// mean score is the mean of its members' candidate means, which phase 1 already has).  float32 outputs only: 1/dist is
+// the raw v_rsq_f64 as in k_fused_lean (same numerics contract).
+#pragma once
+#include <type_traits>
+#include <utility>
+
+#include "snowtri_lean.hpp"
+
+namespace snowtri {
+
+struct ClusterDesc {
+    uint32_t frame;    // frame index inside the launch
+    uint32_t persons;  // complete graph: 4 bits per camera, the person of camera c that belongs to this cluster;
+                       // any other cluster: index of its first member word in the launch's member list
+    uint32_t slot;     // output slot (< Pout); 0xffffffff = voided entry
+    uint32_t size;     // 0 = complete graph, else the number of members
+};
+constexpr int kClusterMaxCams = 8;      // 4-bit person fields in one word, register-resident rays
+constexpr int kClusterMaxPersons = 16;
+
+// camera pair q = (m, s) in the candidate order of triangulation.py:56-57, as compile-time tables (indexed by the
+// unrolled pair counter: a loop that searches for q would leave the ray arrays dynamically indexed, i.e. in scratch)
+template <int C>
+struct ClusterPairs {
+    static constexpr int NP = C * (C - 1) / 2;
+    struct Tab {
+        int m[NP > 0 ? NP : 1], s[NP > 0 ? NP : 1];
+    };
+    static constexpr Tab make() {
+        Tab t{};
+        int k = 0;
+        for (int m = 0; m < C - 1; m++)
+            for (int s = m + 1; s < C; s++, k++) {
+                t.m[k] = m;
+                t.s[k] = s;
+            }
+        return t;
+    }
+    static constexpr Tab tab = make();
+};
+__host__ __device__ constexpr int cluster_const_doubles(int C) { return 12 * C + 3 * (C * (C - 1) / 2); }  // M[C][9], t[C][3], d[NP][3]
+__host__ __device__ constexpr size_t cluster_lds_bytes(int C) {   // + pairc[NP][6], pairs[NP][2] (int32) for the member lists
+    return (size_t)8 * (cluster_const_doubles(C) + 6 * (C * (C - 1) / 2)) + (size_t)8 * (C * (C - 1) / 2) + 16;
+}
+
+// compile-time loop: f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N - 1>)
+template <typename F, int... I>
+__device__ __forceinline__ void cluster_static_for_impl(F &&f, std::integer_sequence<int, I...>) {
+    (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, typename F>
+__device__ __forceinline__ void cluster_static_for(F &&f) {
+    cluster_static_for_impl(f, std::make_integer_sequence<int, N>{});
+}
+
+// One (cluster, joint): the item of k_fused_lean with the pair offsets read from LDS (28 pairs x 3 doubles do not fit
+// the scalar registers) and the determinants inverted four at a time.  K = [M | t | d] in LDS at offset 0.
+// Returns true if the joint needs the sequential routine (exact intersection, singular pair, NaN).
+template <int C, typename TIn>
+__device__ __forceinline__ bool cluster_item(const double *__restrict__ K, const Kp3<TIn> (&cur)[C], float kthr_f32, double kthr,
+                                             double dthr2, float &ox, float &oy, float &oz, float &os) {
+#pragma clang fp contract(off)
+    constexpr int NP = C * (C - 1) / 2;
+    constexpr int kGroup = 4;
+    Vec3 h[C];
+    double a[C], alpha[C], beta[C];
+    bool okc[C];
+    cluster_static_for<C>([&](auto CC) {
+        constexpr int c = CC;
+        const double *M = K + 9 * c;
+        const double u = (double)cur[c].u, v = (double)cur[c].v;
+        h[c].x = fma(M[0], u, fma(M[1], v, M[2]));   // A1, camera.py:241-243 with M = R inv(K)
+        h[c].y = fma(M[3], u, fma(M[4], v, M[5]));
+        h[c].z = fma(M[6], u, fma(M[7], v, M[8]));
+        a[c] = dot3(h[c], h[c]);
+        if constexpr (sizeof(TIn) == 4)
+            okc[c] = !((float)cur[c].s < kthr_f32);   // triangulation.py:73, once per camera
+        else
+            okc[c] = !((double)cur[c].s < kthr);
+        alpha[c] = 0.0;
+        beta[c] = 0.0;
+    });
+    cluster_static_for<(NP + kGroup - 1) / kGroup>([&](auto GG) {
+        constexpr int q0 = kGroup * GG;
+        constexpr int n = NP - q0 < kGroup ? NP - q0 : kGroup;
+        __builtin_amdgcn_sched_barrier(0);   // a group's LDS reads and temporaries stay inside the group (register budget)
+        double bq[n], det[n], pre[n], inv[n];
+        cluster_static_for<n>([&](auto UU) {
+            constexpr int u = UU, mc = ClusterPairs<C>::tab.m[q0 + u], sc = ClusterPairs<C>::tab.s[q0 + u];
+            bq[u] = dot3(h[mc], h[sc]);
+            det[u] = fma(a[mc], a[sc], -(bq[u] * bq[u]));
+            if constexpr (u == 0)
+                pre[0] = det[0];
+            else
+                pre[u] = pre[u - 1] * det[u];
+        });
+        {
+            double run = rcp_nr1(pre[n - 1]);   // one reciprocal for the group's determinants (2^-46: 1e-13 m on the point)
+            cluster_static_for<n - 1>([&](auto UU) {
+                constexpr int u = n - 1 - UU;   // n - 1 ... 1
+                inv[u] = run * pre[u - 1];
+                run *= det[u];
+            });
+            inv[0] = run;
+        }
+        cluster_static_for<n>([&](auto UU) {
+            constexpr int u = UU, q = q0 + u, mc = ClusterPairs<C>::tab.m[q], sc = ClusterPairs<C>::tab.s[q];
+            const Vec3 &hm = h[mc], &hs = h[sc];
+            const double *dq = K + 12 * C + 3 * q;
+            const double dx = dq[0], dy = dq[1], dz = dq[2];
+            const double b = bq[u];
+            // A2 (triangulation.py:24-31)
+            const double e = fma(hm.z, dz, fma(hm.y, dy, hm.x * dx));
+            const double g = fma(hs.z, dz, fma(hs.y, dy, hs.x * dx));
+            const double S0 = fma(a[sc], e, -(b * g)) * inv[u];
+            const double S1 = fma(a[mc], g, -(b * e)) * inv[u];
+            const double fx = fma(hs.x, S1, fma(hm.x, S0, -dx));
+            const double fy = fma(hs.y, S1, fma(hm.y, S0, -dy));
+            const double fz = fma(hs.z, S1, fma(hm.z, S0, -dz));
+            const double d2 = fma(fz, fz, fma(fy, fy, fx * fx));
+            const double idist = __builtin_amdgcn_rsq(d2);
+            // :72-74, sq = 2000 x the pair score; the gates select the score sum before the product (plain selects here: 28
+            // lane masks held for an inline v_cndmask, as in k_fused_lean, overflow the scalar registers)
+            const bool keep = okc[mc] && okc[sc] && !(d2 > dthr2);
+            double sq;
+            if constexpr (sizeof(TIn) == 4)
+                sq = (double)(keep ? (float)cur[mc].s + (float)cur[sc].s : 0.0f) * idist;   // float32 sum as NumPy
+            else
+                sq = (keep ? (double)cur[mc].s + (double)cur[sc].s : 0.0) * idist;
+            alpha[mc] = fma(sq, S0, alpha[mc]);
+            alpha[sc] = fma(-sq, S1, alpha[sc]);
+            beta[mc] += sq;
+            beta[sc] += sq;
+        });
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    const double *tp = K + 9 * C;
+    double sx = 0.0, sy = 0.0, sz = 0.0, sb = 0.0;
+    cluster_static_for<C>([&](auto CC) {
+        constexpr int c = CC;
+        sx = fma(alpha[c], h[c].x, fma(beta[c], tp[3 * c + 0], sx));
+        sy = fma(alpha[c], h[c].y, fma(beta[c], tp[3 * c + 1], sy));
+        sz = fma(alpha[c], h[c].z, fma(beta[c], tp[3 * c + 2], sz));
+        sb += beta[c];
+    });
+    // sb = 2 x 2000 x sum_q s_q (:141); sum == 0 -> (0,0,0)/0 (:142-143): sx = sy = sz = 0 then
+    const double r = rcp_nr1(fmax(sb, 1e-300));
+    ox = (float)(sx * r);   // :144-147 as (sum s (Wm+Ws)) / (2 sum s)
+    oy = (float)(sy * r);
+    oz = (float)(sz * r);
+    os = (float)(sb * (0.00025 / (double)NP));   // :148
+    return !(sb < 1e300);
+}
+
+// The same joint member by member, in the order and with the select semantics of phase 3 of k_frame_recompute
+// (float32 outputs): for the rare joints cluster_item cannot finish (0 x inf at an exact intersection whose confidence
+// is gated, inf / NaN sums, a singular pair).
+template <typename TIn>
+__device__ __noinline__ void cluster_joint_sequential(const Rig &rig, const Kp3<TIn> *__restrict__ kp3, int64_t frame0, uint32_t persons,
+                                                      int Pmax, int J, int j, const Params &prm, float &ox, float &oy, float &oz,
+                                                      float &os) {
+    const int C = rig.C, NP = rig.npairs;
+    double aS = 0.0, aX = 0.0, aY = 0.0, aZ = 0.0;
+    for (int q = 0; q < NP; q++) {
+        const int mc = rig.pairs[2 * q], sc = rig.pairs[2 * q + 1];
+        const int64_t rm = (frame0 * C + mc) * Pmax + (int)((persons >> (4 * mc)) & 15u);
+        const int64_t rs = (frame0 * C + sc) * Pmax + (int)((persons >> (4 * sc)) & 15u);
+        const Kp3<TIn> km = kp3[rm * J + j], ks = kp3[rs * J + j];
+        const RayRec a = make_ray(rig.M + 9 * mc, km.u, km.v), b = make_ray(rig.M + 9 * sc, ks.u, ks.v);
+        const double *pc = rig.pairc + 6 * q;
+        const double bq = fma(a.z, b.z, fma(a.y, b.y, a.x * b.x));
+        const double e = fma(a.z, pc[2], fma(a.y, pc[1], a.x * pc[0]));
+        const double g = fma(b.z, pc[2], fma(b.y, pc[1], b.x * pc[0]));
+        const double inv = rcp_nr2(fma(a.a, b.a, -(bq * bq)));
+        const double S0 = fma(b.a, e, -(bq * g)) * inv;
+        const double S1 = fma(a.a, g, -(bq * e)) * inv;
+        const double fx = fma(b.x, S1, fma(a.x, S0, -pc[0])), fy = fma(b.y, S1, fma(a.y, S0, -pc[1])),
+                     fz = fma(b.z, S1, fma(a.z, S0, -pc[2]));
+        const double d2 = fma(fz, fz, fma(fy, fy, fx * fx));
+        const bool kp_ = !below_kthr(km.s, prm) && !below_kthr(ks.s, prm) && !(d2 > prm.dthr2);
+        // the gate ASSIGNS 0 (:73-74): select after the product (0 * inf at an exact intersection)
+        const double sq = kp_ ? sum_score(km.s, ks.s) * __builtin_amdgcn_rsq(d2) : 0.0;
+        aS += sq;                                                              // :141
+        aX = fma(sq, fma(-b.x, S1, fma(a.x, S0, pc[3])), aX);                  // :144-147
+        aY = fma(sq, fma(-b.y, S1, fma(a.y, S0, pc[4])), aY);
+        aZ = fma(sq, fma(-b.z, S1, fma(a.z, S0, pc[5])), aZ);
+    }
+    double x = 0.0, y = 0.0, z = 0.0, s = 0.0;
+    if (!(aS == 0.0)) {                                                        // :142-143
+        const double r = 0.5 * rcp_nr2(aS);
+        x = aX * r;
+        y = aY * r;
+        z = aZ * r;
+        s = aS * (0.0005 * rcp_nr2((double)NP));                              // :148
+    }
+    ox = (float)x;
+    oy = (float)y;
+    oz = (float)z;
+    os = (float)s;
+}
+
+// Clusters of any shape: lane = (descriptor, joint), one loop over the cluster's member words (rm | rs << 10 | q << 20,
+// the candidate words of k_frame_recompute); arithmetic, order and select semantics of its phase 3 for float32 outputs.
+// Called by every wave of k_cluster_fuse after its own passes (these clusters are few: ghost candidates, partly seen
+// persons; a pass is a chain of dependent loads that hides behind the other waves' complete-graph items).
+//   Ml [C][9] ray matrices, pc [NP][6] pair constants (d, t_m + t_s), pairs [NP][2] camera indices: in LDS.
+template <typename TIn>
+__device__ __forceinline__ void cluster_member_passes(const ClusterDesc *__restrict__ desc, uint32_t ndesc,
+                                                      const uint32_t *__restrict__ words, const double *__restrict__ Ml,
+                                                      const double *__restrict__ pc, const int32_t *__restrict__ pairs, int R,
+                                                      const Kp3<TIn> *__restrict__ kp3, const Params &prm, int J,
+                                                      unsigned long long jmagic, int Pout, float *__restrict__ out4, uint32_t p0, uint32_t W) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t total = ndesc * (uint32_t)J;
+    const uint32_t npass = (total + 63u) >> 6;
+    for (uint32_t p = p0; p < npass; p += W) {
+        const uint32_t i = (p << 6) + (uint32_t)lane;
+        bool valid = i < total;
+        const uint32_t ic = valid ? i : 0u;
+        const uint32_t di = (uint32_t)(((unsigned long long)ic * jmagic) >> 40);
+        const uint32_t j = ic - di * (uint32_t)J;
+        uint4 d = make_uint4(0u, 0u, 0u, 0u);
+        if (valid) d = *reinterpret_cast<const uint4 *>(desc + di);
+        valid = valid && d.z < (uint32_t)Pout;
+        const int size = valid ? (int)d.w : 0;
+        const uint64_t row0 = (uint64_t)d.x * (uint32_t)R;
+        double aS = 0.0, aX = 0.0, aY = 0.0, aZ = 0.0;
+        for (int m = 0; __ballot(m < size) != 0ull; m++) {
+            if (m < size) {
+                const uint32_t w = words[d.y + (uint32_t)m];
+                const int rm = (int)(w & 1023u), rs = (int)((w >> 10) & 1023u), q = (int)(w >> 20);
+                const Kp3<TIn> km = kp3[(row0 + (uint32_t)rm) * (uint32_t)J + j], ks = kp3[(row0 + (uint32_t)rs) * (uint32_t)J + j];
+                const RayRec a = make_ray(Ml + 9 * pairs[2 * q], km.u, km.v), b = make_ray(Ml + 9 * pairs[2 * q + 1], ks.u, ks.v);
+                const double *c6 = pc + 6 * q;
+                const double bq = fma(a.z, b.z, fma(a.y, b.y, a.x * b.x));
+                const double e = fma(a.z, c6[2], fma(a.y, c6[1], a.x * c6[0]));
+                const double g = fma(b.z, c6[2], fma(b.y, c6[1], b.x * c6[0]));
+                const double inv = rcp_nr2(fma(a.a, b.a, -(bq * bq)));
+                const double S0 = fma(b.a, e, -(bq * g)) * inv;
+                const double S1 = fma(a.a, g, -(bq * e)) * inv;
+                const double fx = fma(b.x, S1, fma(a.x, S0, -c6[0])), fy = fma(b.y, S1, fma(a.y, S0, -c6[1])),
+                             fz = fma(b.z, S1, fma(a.z, S0, -c6[2]));
+                const double d2 = fma(fz, fz, fma(fy, fy, fx * fx));
+                const bool kp_ = !below_kthr(km.s, prm) && !below_kthr(ks.s, prm) && !(d2 > prm.dthr2);
+                // the gate ASSIGNS 0 (:73-74): select after the product (0 * inf at an exact intersection)
+                const double sq = kp_ ? sum_score(km.s, ks.s) * __builtin_amdgcn_rsq(d2) : 0.0;
+                aS += sq;                                                              // :141
+                aX = fma(sq, fma(-b.x, S1, fma(a.x, S0, c6[3])), aX);                  // :144-147
+                aY = fma(sq, fma(-b.y, S1, fma(a.y, S0, c6[4])), aY);
+                aZ = fma(sq, fma(-b.z, S1, fma(a.z, S0, c6[5])), aZ);
+            }
+        }
+        if (valid) {
+            double x = 0.0, y = 0.0, z = 0.0, sc = 0.0;
+            if (!(aS == 0.0)) {                                                        // :142-143
+                const double r = 0.5 * rcp_nr2(aS);
+                x = aX * r;
+                y = aY * r;
+                z = aZ * r;
+                sc = aS * (0.0005 * rcp_nr2((double)size));                           // :148
+            }
+            float4 *o = reinterpret_cast<float4 *>(out4) + ((uint64_t)d.x * (uint32_t)Pout + d.z) * (uint64_t)(uint32_t)J + j;
+            *o = make_float4((float)x, (float)y, (float)z, (float)sc);
+        }
+    }
+}
+
+// Grid: any number of workgroups.  Wave gw takes 64-item passes gw, gw + W, ... of the ndesc x J items
+// (item = descriptor * J + joint); the descriptor of the pass after next and the keypoints of the next pass are in
+// flight while a pass is solved.  Then the same for the clusters of any other shape (cluster_member_passes).
+// cnt[0], cnt[1]: descriptors in desc[0, cap) (complete graphs) and desc[cap, 2 cap) (member lists).
+// Dynamic LDS: cluster_lds_bytes(C).
+//   jmagic = ceil(2^40 / J): item / J = (item * jmagic) >> 40 for item < 2^31, J <= 256.
+#ifndef SNOWTRI_CLUSTER_WAVES
+#define SNOWTRI_CLUSTER_WAVES 2
+#endif
+template <int C, typename TIn>
+__global__ __launch_bounds__(kBlock, SNOWTRI_CLUSTER_WAVES) void k_cluster_fuse(const ClusterDesc *__restrict__ desc,
+                                                          const uint32_t *__restrict__ words,
+                                                          const unsigned long long *__restrict__ cnt, uint32_t desc_cap,
+                                                          Rig rig, const TIn *__restrict__ kpts, Params prm, int Pmax, int J,
+                                                          unsigned long long jmagic, int Pout, float *__restrict__ out4) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NP = C * (C - 1) / 2;
+    double *K = reinterpret_cast<double *>(smem);   // [M | t | d] for cluster_item, then [pairc | pairs] for the member lists
+    double *pc = K + cluster_const_doubles(C);
+    int32_t *pairs_l = reinterpret_cast<int32_t *>(pc + 6 * NP);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    for (int i = tid; i < 9 * C; i += kBlock) K[i] = rig.M[i];
+    if (tid < 3 * C) K[9 * C + tid] = rig.t[tid];
+    if (tid < 3 * NP) K[12 * C + tid] = rig.pairc[6 * (tid / 3) + tid % 3];
+    for (int i = tid; i < 6 * NP; i += kBlock) pc[i] = rig.pairc[i];
+    if (tid < 2 * NP) pairs_l[tid] = rig.pairs[tid];
+    const unsigned long long nd64 = cnt[0], ng64 = cnt[1];
+    const uint32_t ndesc = nd64 < (unsigned long long)desc_cap ? (uint32_t)nd64 : desc_cap;
+    const uint32_t ngen = ng64 < (unsigned long long)desc_cap ? (uint32_t)ng64 : desc_cap;
+    const uint32_t total = ndesc * (uint32_t)J;
+    const uint32_t npass = (total + 63u) >> 6;
+    const uint32_t W = gridDim.x * (uint32_t)(kBlock / 64);
+    const Kp3<TIn> *kp3 = reinterpret_cast<const Kp3<TIn> *>(kpts);
+    const float kthr_f32 = prm.kthr_f32;
+    const double kthr = prm.kthr, dthr2 = prm.dthr2;
+    __syncthreads();
+
+    struct Item {
+        uint32_t frame, persons, slot, j;
+        bool valid;
+    };
+    auto locate = [&](uint32_t pass) {
+        Item it;
+        const uint32_t i = (pass << 6) + (uint32_t)lane;
+        it.valid = pass < npass && i < total;
+        const uint32_t ic = it.valid ? i : 0u;
+        const uint32_t di = (uint32_t)(((unsigned long long)ic * jmagic) >> 40);
+        it.j = ic - di * (uint32_t)J;
+        it.frame = 0u;
+        it.persons = 0u;
+        it.slot = 0u;
+        if (it.valid) {
+            const uint4 d = *reinterpret_cast<const uint4 *>(desc + di);
+            it.frame = d.x;
+            it.persons = d.y;
+            it.slot = d.z;
+            it.valid = d.z < (uint32_t)Pout;   // (a voided entry, see the hand-over in k_frame_recompute)
+        }
+        return it;
+    };
+    auto fetch = [&](Kp3<TIn>(&dst)[C], const Item &it) {
+        if (it.valid) {
+#pragma unroll
+            for (int c = 0; c < C; c++) {
+                const uint32_t row = (it.frame * (uint32_t)C + (uint32_t)c) * (uint32_t)Pmax + ((it.persons >> (4 * c)) & 15u);
+                dst[c] = kp3[(uint64_t)row * (uint32_t)J + it.j];
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < C; c++) dst[c] = Kp3<TIn>{(TIn)0, (TIn)0, (TIn)0};
+        }
+    };
+
+    const uint32_t p_first = blockIdx.x * (uint32_t)(kBlock / 64) + (uint32_t)wave;
+    uint32_t p = p_first;
+    if (p < npass) {
+    Kp3<TIn> cur[C], nxt[C];
+    Item it0 = locate(p);
+    fetch(cur, it0);
+    Item it1 = locate(p + W);
+    for (; p < npass; p += W) {
+        fetch(nxt, it1);
+        const Item it2 = locate(p + 2 * W);
+        float ox, oy, oz, os;
+        asm volatile("" ::: "memory");   // the rig constants are re-read from LDS in every pass (hoisted out of the loop they would take 360 registers)
+        const bool bad = cluster_item<C, TIn>(K, cur, kthr_f32, kthr, dthr2, ox, oy, oz, os);
+        if (__ballot(bad && it0.valid)) {   // rare, wave-uniform branch
+            if (bad && it0.valid)
+                cluster_joint_sequential<TIn>(rig, kp3, (int64_t)it0.frame, it0.persons, Pmax, J, (int)it0.j, prm, ox, oy, oz, os);
+        }
+#ifdef SNOWTRI_DEBUG_CLUSTER
+        if (p == 0 && lane < 2)
+            printf("lane %d: ndesc %u total %u frame %u persons %x slot %u j %u valid %d | kp0 %g %g %g kp1 %g %g %g | K %g %g %g d0 %g %g %g | out %g %g %g %g bad %d\n",
+                   lane, ndesc, total, it0.frame, it0.persons, it0.slot, it0.j, (int)it0.valid, (double)cur[0].u, (double)cur[0].v, (double)cur[0].s,
+                   (double)cur[1].u, (double)cur[1].v, (double)cur[1].s, K[0], K[1], K[2], K[12 * C], K[12 * C + 1], K[12 * C + 2], (double)ox, (double)oy, (double)oz, (double)os, (int)bad);
+#endif
+        if (it0.valid) {
+            float4 *o = reinterpret_cast<float4 *>(out4) + ((uint64_t)it0.frame * (uint32_t)Pout + it0.slot) * (uint64_t)(uint32_t)J + it0.j;
+            *o = make_float4(ox, oy, oz, os);
+        }
+#pragma unroll
+        for (int c = 0; c < C; c++) cur[c] = nxt[c];
+        it0 = it1;
+        it1 = it2;
+    }
+    }
+    // the waves that ran the fewest complete-graph passes start on the member lists first
+    cluster_member_passes<TIn>(desc + desc_cap, ngen, words, K, pc, pairs_l, C * Pmax, kp3, prm, J, jmagic, Pout, out4,
+                               (p_first + W - (npass % W)) % W, W);
+}
+
+}  // namespace snowtri

@@ -15,7 +15,7 @@
 // Only O(Kc) bookkeeping (57 B per candidate slot) and the fused joint scores of up to 64 persons
 // live in a per-workgroup scratch slab.
 #pragma once
-#include "snowtri_fused.hpp"
+#include "snowtri_cluster.hpp"
 
 namespace snowtri {
 
@@ -227,7 +227,10 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
                                                             int32_t *__restrict__ out_count,
                                                             uint32_t *__restrict__ out_flags, char *scratch,
                                                             size_t scratch_per_block,
-                                                            unsigned long long *next_frame, int lds_total) {
+                                                            unsigned long long *next_frame, int lds_total,
+                                                            ClusterDesc *__restrict__ desc, uint32_t *__restrict__ hand_words,
+                                                            unsigned long long *hand_counters, uint32_t desc_cap,
+                                                            uint32_t word_cap) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int C = rig.C, R = C * Pmax, pp = Pmax * Pmax;
@@ -616,6 +619,145 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
             // One word per member (its candidate word), cluster-member order; in LDS when the list fits what the
             // workgroup's allocation has left (read once per member solve: from the L2-resident slab every one of
             // them costs a memory round trip), else in the slab.
+            // ---- hand-over (snowtri_cluster.hpp): when the mean-score filter (:150-152) of every cluster that passes the size
+            // filter can be decided from the candidate means of phase 1, the frame's output persons become descriptors
+            // for the streaming kernels and phase 3 is skipped: a cluster that is the complete graph over one detection
+            // per camera becomes a complete-graph descriptor (persons packed in one word), any other a member-list descriptor (its member
+            // words are appended to a global list).  The host passes `desc` only when the shape allows it (float32 outputs,
+            // <= 8 cameras, <= 16 persons per camera, keypoint_num == J so that a person's mean score (:150) is the mean of
+            // its members' candidate means (:79), keypoint threshold >= 0, the staging fits the idle ray chunk).
+            bool handed = false;
+            if constexpr (sizeof(TOut) == 4) {
+                if (desc != nullptr) {
+                    const size_t pq = ((size_t)Pout * 4 + 15) & ~(size_t)15;
+                    uint32_t *st_a = reinterpret_cast<uint32_t *>(smem);            // [Pout] persons word | first member (cstart)
+                    int32_t *st_size = reinterpret_cast<int32_t *>(smem + pq);      // [Pout] 0: complete graph, else members
+                    uint32_t *st_idx = reinterpret_cast<uint32_t *>(smem + 2 * pq);  // [Pout] index inside its descriptor list
+                    uint32_t *st_word = reinterpret_cast<uint32_t *>(smem + 3 * pq); // [Pout] offset of its member words
+                    double *st_avg = reinterpret_cast<double *>(smem + 4 * pq);     // [Pout]
+                    // the clusters' sizes / starts, member words and candidate score sums, fetched by the whole workgroup at
+                    // once: the decisions below are then one wave walking LDS (from the L2-resident slab every step is a
+                    // chain of dependent loads: 15 us per frame)
+                    const int nmem = cstart[ncl];
+                    double *l_sum = st_avg + Pout;                                   // [nmem]
+                    uint32_t *l_word = reinterpret_cast<uint32_t *>(l_sum + nmem);   // [nmem]
+                    int32_t *l_size = reinterpret_cast<int32_t *>(l_word + nmem);    // [ncl]
+                    int32_t *l_start = l_size + ncl;                                 // [ncl]
+                    const bool fits = 4 * pq + (size_t)Pout * 8 + (size_t)nmem * 12 + (size_t)ncl * 8 <= (size_t)kRayChunkBytes;
+                    if (fits) {
+                        for (int pos = tid; pos < nmem; pos += kBlock) {
+                            const int k = kidx[members[pos]];
+                            l_word[pos] = cw[k];
+                            l_sum[pos] = sum[k];
+                        }
+                        for (int c = tid; c < ncl; c += kBlock) {
+                            l_size[c] = csize[c];
+                            l_start[c] = cstart[c];
+                        }
+                    }
+                    __syncthreads();
+                    if (tid < 64) {
+                        const int NPq = rig.npairs;
+                        int ok = fits ? 1 : 0, no = 0;            // wave-uniform
+                        uint32_t ncomp = 0, ngen = 0, nwords = 0;
+                        for (int cid = 0; ok && cid < ncl; cid++) {
+                            const int size = l_size[cid];
+                            if ((double)size < prm.num_tol) continue;                                  // :132-134
+                            const int m0 = l_start[cid];
+                            double ssum = 0.0;
+                            for (int base = 0; base < size; base += 64) ssum += base + lane < size ? l_sum[m0 + base + lane] : 0.0;
+                            const double avg = wave_sum(ssum) / ((double)size * (double)J);               // :150 from :79
+                            // (a sum that is not finite, or a mean within 1e-6 of the tolerance -- the fast sums of phase 1
+                            // are within 6e-8 -- is left to phase 3)
+                            if (!(fabs(avg) < 1e300) || fabs(avg - prm.score_tol) <= 1e-6 * fabs(avg)) {
+                                ok = 0;
+                                break;
+                            }
+                            if (avg < prm.score_tol) continue;                                         // :151-152
+                            if (no < Pout) {
+                                bool complete = false;
+                                uint32_t nib = 0u;
+                                if (size == NPq) {
+                                    // members are in candidate order (camera pair major): in a complete graph member i IS pair
+                                    // i; the row of camera 0 is the first row of pair (0,1) = member 0, the row of camera c >= 1
+                                    // the second row of pair (0,c) = member c - 1, and every other member must repeat them.
+                                    // (Shuffles stay outside selects: a lane masked off during ds_bpermute is read as 0.)
+                                    const bool act = lane < size;
+                                    const uint32_t w = act ? l_word[m0 + lane] : 0u;
+                                    const int rm = (int)(w & 1023u), rs = (int)((w >> 10) & 1023u), q = (int)(w >> 20);
+                                    const int mc = act ? pairs[2 * lane] : 0, sc = act ? pairs[2 * lane + 1] : 1;
+                                    const int row0 = __shfl(rm, 0, 64);
+                                    const int via_m = __shfl(rs, mc > 0 ? mc - 1 : 0, 64), via_s = __shfl(rs, sc - 1, 64);
+                                    const bool good = !act || (q == lane && rm == (mc == 0 ? row0 : via_m) && rs == via_s);
+                                    complete = __ballot(!good) == 0ull;
+                                    const int via = __shfl(rs, lane > 0 ? lane - 1 : 0, 64);
+                                    const int rowc = lane == 0 ? row0 : via;           // lane c < C: row of camera c
+                                    nib = (complete && lane < C) ? (uint32_t)(rowc - lane * Pmax) << (4 * lane) : 0u;
+#pragma unroll
+                                    for (int off = 4; off > 0; off >>= 1) nib |= (uint32_t)__shfl_xor((int)nib, off, 64);
+                                }
+                                if (lane == 0) {
+                                    st_a[no] = complete ? nib : (uint32_t)m0;
+                                    st_size[no] = complete ? 0 : size;
+                                    st_idx[no] = complete ? ncomp : ngen;
+                                    st_word[no] = nwords;
+                                    st_avg[no] = avg;
+                                }
+                                if (complete) {
+                                    ncomp++;
+                                } else {
+                                    ngen++;
+                                    nwords += (uint32_t)size;
+                                }
+                            }
+                            no++;
+                        }
+                        if (lane == 0) {
+                            unsigned long long bc = 0ull, bg = 0ull, bw = 0ull;
+                            if (ok) {
+                                if (ncomp) bc = atomicAdd(hand_counters, (unsigned long long)ncomp);
+                                if (ngen) bg = atomicAdd(hand_counters + 1, (unsigned long long)ngen);
+                                if (nwords) bw = atomicAdd(hand_counters + 2, (unsigned long long)nwords);
+                                if (bc + ncomp > (unsigned long long)desc_cap || bg + ngen > (unsigned long long)desc_cap ||
+                                    bw + nwords > (unsigned long long)word_cap) {
+                                    // (cannot happen: the host sizes the lists for Pout persons and Kc members of every frame)
+                                    // -- void the reserved descriptors that exist and keep the frame here
+                                    for (unsigned long long i = bc; i < bc + ncomp && i < (unsigned long long)desc_cap; i++)
+                                        desc[i] = ClusterDesc{0u, 0u, 0xffffffffu, 0u};
+                                    for (unsigned long long i = bg; i < bg + ngen && i < (unsigned long long)desc_cap; i++)
+                                        desc[(unsigned long long)desc_cap + i] = ClusterDesc{0u, 0u, 0xffffffffu, 0u};
+                                    ok = 0;
+                                }
+                            }
+                            misc[7] = ok;
+                            misc[8] = no;
+                            misc[9] = (int32_t)(uint32_t)bc;
+                            misc[10] = (int32_t)(uint32_t)bg;
+                            misc[11] = (int32_t)(uint32_t)bw;
+                        }
+                    }
+                    __syncthreads();
+                    if (misc[7]) {
+                        handed = true;
+                        nout = misc[8];
+                        const uint32_t bc = (uint32_t)misc[9], bg = (uint32_t)misc[10], bw = (uint32_t)misc[11];
+                        const int nsl = nout < Pout ? nout : Pout;
+                        for (int sl = tid; sl < nsl; sl += kBlock) {
+                            if (st_size[sl] == 0)
+                                desc[bc + st_idx[sl]] = ClusterDesc{(uint32_t)f, st_a[sl], (uint32_t)sl, 0u};
+                            else
+                                desc[desc_cap + bg + st_idx[sl]] = ClusterDesc{(uint32_t)f, bw + st_word[sl], (uint32_t)sl, (uint32_t)st_size[sl]};
+                            wr.person(f, Pout, sl, st_avg[sl]);
+                        }
+                        for (int sl = 0; sl < nsl; sl++) {
+                            const int size = st_size[sl], m0 = (int)st_a[sl];
+                            for (int i = tid; i < size; i += kBlock) hand_words[bw + st_word[sl] + (uint32_t)i] = l_word[m0 + i];
+                        }
+                    }
+                    __syncthreads();   // the staging area is the ray chunk of the next frame (or of phase 3 below)
+                }
+            }
+            if (!handed) {
             uint32_t *cmem = reinterpret_cast<uint32_t *>(centre);    // [n]
             int32_t *cslot = reinterpret_cast<int32_t *>(cmem + Kc);  // [ncl] preliminary output slot or -1
             int32_t *cid_of_slot = cslot + Kc;                        // [nsurv] its inverse
@@ -850,6 +992,7 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
             if (!misc[6]) break;
             __syncthreads();   // misc[5] (= survivors of pass 1) is read at the top of the loop
             }
+            }   // !handed
         }
         for (int slot = nout; slot < Pout; slot++) {
             for (int b = tid; b < kn; b += kBlock) wr.joint(f, Pout, kn, slot, b, 0.0, 0.0, 0.0, 0.0);

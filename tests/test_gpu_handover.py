@@ -1,0 +1,224 @@
+"""Hand-over of the clusters from k_frame_recompute to k_cluster_fuse (snowtri_cluster.hpp): the
+multi-person path with float32 outputs and keypoint_num == J, against the CPU oracle and against the same launch with
+the hand-over switched off (SNOWTRI_HANDOVER_MODE=0: phase 3 stays inside k_frame_recompute), through the C ABI.
+
+What the cases aim at: clusters that are complete graphs (k_cluster_fuse), persons missing in a camera or ragged person
+lists (clusters of another shape: its member-list passes, in the SAME launch), persons dropped by the mean-score filter
+(slots move up), more persons than Pout_max (overflow flag, only the first Pout_max written), every camera count the
+cluster kernel is instantiated for, float64 inputs, exact intersections with a gated confidence (the joints the fast
+item cannot finish), determinism.
+
+Tolerances (tests/test_gpu_parity.py): float32 outputs <= 2e-6 m, scores <= 3e-7 relative.
+"""
+import numpy as np
+import pytest
+
+from conftest import assert_scores_close, assert_xyz_close
+
+pytestmark = pytest.mark.gpu
+
+XYZ_F32 = 2e-6
+PRM = dict(keypoint_score_threshold=3.0, average_score_threshold=0.3, distance_threshold=0.05, condense_distance_tol=0.3,
+           condense_person_num_tol=2, condense_score_tol=0.0, center_point_index=0)
+
+
+@pytest.fixture(scope="module")
+def api():
+    import snowmocap_amd as sm
+    from snowmocap_amd import _lib
+    assert _lib.lib().snowtri_device_count() > 0, "these tests need the HIP device"
+    return sm
+
+
+def _run(api, K, R, t, prm, kp, npers, pout, monkeypatch, handover=True):
+    monkeypatch.setenv("SNOWTRI_HANDOVER_MODE", "1" if handover else "0")
+    bt = api.BatchTriangulator(K, R, t, prm, pout_max=pout, out_dtype=np.float32)
+    out = bt.run_host(kp, npers)      # (overflow / singular come back as out["status"], not as exceptions)
+    out["handed"] = bt.ctx.last_handover_persons()
+    bt.close()
+    monkeypatch.delenv("SNOWTRI_HANDOVER_MODE")
+    return out
+
+
+def _check(out, ref, pout, J, msg):
+    np.testing.assert_array_equal(out["count"], ref["count"], err_msg=msg)
+    for f in range(len(ref["count"])):
+        m = min(int(ref["count"][f]), pout)
+        assert not out["xyzs"][f, m:].any(), f"{msg} frame {f}: unused slots must be zero"
+        if m:
+            assert_scores_close(out["xyzs"][f, :m, :, 3], ref["kscore"][f, :m], rtol=3e-7, what=f"{msg} kscore frame {f}")
+            assert_xyz_close(out["xyzs"][f, :m, :, :3], ref["xyz"][f, :m], XYZ_F32, score_ref=ref["kscore"][f, :m],
+                             what=f"{msg} xyz frame {f}")
+            assert_scores_close(out["pscore"][f, :m], ref["pscore"][f, :m], rtol=3e-7, nterms=J, what=f"{msg} pscore frame {f}")
+
+
+def _same(a, b, msg):
+    """hand-over on vs off: same counts, same NaN pattern, values within the float32 tolerances of both."""
+    np.testing.assert_array_equal(a["count"], b["count"], err_msg=msg)
+    xa, xb = a["xyzs"].astype(np.float64), b["xyzs"].astype(np.float64)
+    assert np.array_equal(np.isnan(xa), np.isnan(xb)), msg
+    fin = np.isfinite(xa) & np.isfinite(xb)
+    assert np.abs(xa[..., :3] - xb[..., :3])[fin[..., :3]].max(initial=0.0) < 2 * XYZ_F32, msg
+    sa, sb = xa[..., 3][fin[..., 3]], xb[..., 3][fin[..., 3]]
+    assert np.all(np.abs(sa - sb) <= 6e-7 * np.abs(sb)), msg
+
+
+@pytest.mark.parametrize("C,P,in_dtype", [(8, 4, np.float32), (4, 3, np.float64), (2, 2, np.float32), (3, 4, np.float32),
+                                          (5, 2, np.float32), (6, 3, np.float64), (7, 2, np.float32), (8, 2, np.float64)])
+def test_complete_clusters_are_handed_over_and_match_the_oracle(api, C, P, in_dtype, monkeypatch):
+    from snowmocap_amd import synth
+    from oracle import oracle as orc
+    rng = np.random.default_rng(100 * C + P)
+    F, J = 12, 133 if C in (8, 4) else 40
+    K, R, t = synth.ring_rig(C, radius=4.5)
+    X = synth.make_people(rng, F, P, J=J)
+    kp, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=0.7, score_range=(3.5, 9.0), permute_persons=True, dtype=in_dtype)
+    prm = dict(PRM, keypoint_num=J, condense_person_num_tol=1 if C == 2 else 2)
+    ref = orc.triangulate_condense_batch(K, R, t, kp, npers, orc.make_params(**prm), 64)
+    pout = P + 1
+    out = _run(api, K, R, t, prm, kp, npers, pout, monkeypatch)
+    off = _run(api, K, R, t, prm, kp, npers, pout, monkeypatch, handover=False)
+    msg = f"C={C} P={P}"
+    _check(out, ref, pout, J, msg)
+    _check(off, ref, pout, J, msg + " (hand-over off)")
+    _same(out, off, msg)
+    assert off["handed"] == (-1, -1)
+    # clean synthetic people, everyone seen by every camera: (nearly) every output person is a complete-graph cluster; a
+    # ghost candidate that joins a cluster (or forms its own) makes a cluster of another shape
+    assert sum(out["handed"]) == int(np.minimum(ref["count"], pout).sum()), (out["handed"], ref["count"])
+    assert out["handed"][0] >= 0.6 * sum(out["handed"]) > 0, out["handed"]
+
+
+def test_mixed_launch_incomplete_and_ragged_frames_stay_in_phase3(api, monkeypatch):
+    """One launch, three kinds of frames: complete clusters (k_cluster_fuse), a person whose detection in one camera is
+    below the keypoint threshold everywhere or missing from the list (its cluster has fewer members: a member-list descriptor),
+    empty frames."""
+    from snowmocap_amd import synth
+    from oracle import oracle as orc
+    rng = np.random.default_rng(5)
+    C, P, F, J = 6, 3, 40, 133
+    K, R, t = synth.ring_rig(C, radius=5.0)
+    X = synth.make_people(rng, F, P, J=J)
+    kp, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=0.7, score_range=(3.5, 9.0), permute_persons=True, dtype=np.float32)
+    npers = npers.copy()
+    kinds = {}
+    for f in range(F):
+        k = f % 5
+        if k == 1:      # one camera lists one person less
+            npers[f, rng.integers(0, C)] = P - 1
+            kinds[f] = "ragged"
+        elif k == 2:    # one detection has no confidence at all: its candidates are dropped by the mean-score gate
+            kp[f, rng.integers(0, C), rng.integers(0, P), :, 2] = 0.0
+            kinds[f] = "occluded"
+        elif k == 3 and f % 10 == 3:
+            npers[f] = 0
+            kinds[f] = "empty"
+    prm = dict(PRM, keypoint_num=J)
+    ref = orc.triangulate_condense_batch(K, R, t, kp, npers, orc.make_params(**prm), 64)
+    out = _run(api, K, R, t, prm, kp, npers, P, monkeypatch)
+    off = _run(api, K, R, t, prm, kp, npers, P, monkeypatch, handover=False)
+    _check(out, ref, P, J, "mixed launch")
+    _same(out, off, "mixed launch")
+    full = int(np.minimum(ref["count"], P).sum())
+    n_complete, n_other = out["handed"]
+    assert n_complete + n_other == full, (out["handed"], full)
+    # every "ragged" / "occluded" frame has a person seen by one camera less: C(C-1, 2) members instead of C(C, 2)
+    assert n_other >= sum(1 for k in kinds.values() if k != "empty") and n_complete >= 2 * n_other, out["handed"]
+
+
+@pytest.mark.parametrize("score_tol,pout", [(0.0, 2), (1.2, 4), (1.2, 1), (50.0, 4)])
+def test_mean_score_filter_and_overflow_with_handover(api, score_tol, pout, monkeypatch):
+    """condense_score_tol in the middle of the persons' mean scores: some clusters are dropped and the later ones move up
+    (the slots are decided by the association kernel from the candidate means); pout < persons: overflow flag, only
+    the first pout persons written."""
+    from snowmocap_amd import synth
+    from oracle import oracle as orc
+    rng = np.random.default_rng(17)
+    C, P, F, J = 4, 4, 24, 133
+    K, R, t = synth.ring_rig(C, radius=4.0)
+    X = synth.make_people(rng, F, P, J=J)
+    kp, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=0.5, score_range=(3.5, 9.0), permute_persons=False, dtype=np.float32)
+    prm = dict(PRM, keypoint_num=J, condense_score_tol=0.0)
+    ref0 = orc.triangulate_condense_batch(K, R, t, kp, npers, orc.make_params(**prm), 64)
+    assert (ref0["count"] >= P).all(), ref0["count"]
+    # a tolerance in the middle of the persons' mean scores (they are ~1/dist: they differ a lot from person to person)
+    ps = np.concatenate([ref0["pscore"][f, :ref0["count"][f]] for f in range(F)])
+    tol = {0.0: 0.0, 1.2: float(np.median(ps)), 50.0: float(ps.max() * 2)}[score_tol]
+    prm["condense_score_tol"] = tol
+    ref = orc.triangulate_condense_batch(K, R, t, kp, npers, orc.make_params(**prm), 64)
+    if score_tol == 1.2:    # the filter really fires, and not for the last persons only: later ones move up
+        assert 0.3 * len(ps) < ref["count"].sum() < 0.7 * len(ps), (ref["count"], ref0["count"])
+        assert any((ref0["pscore"][f, 0] < tol) and ref["count"][f] > 0 for f in range(F))
+    out = _run(api, K, R, t, prm, kp, npers, pout, monkeypatch)
+    off = _run(api, K, R, t, prm, kp, npers, pout, monkeypatch, handover=False)
+    msg = f"score_tol={score_tol} pout={pout}"
+    _check(out, ref, pout, J, msg)
+    _same(out, off, msg)
+    np.testing.assert_array_equal(out["flags"] & 2, np.where(ref["count"] > pout, 2, 0), err_msg=msg)
+    # (the median tolerance IS one person's mean score: that frame is "undecided" on the fast sums and stays in phase 3)
+    total = int(np.minimum(ref["count"], pout).sum())
+    assert total - (P if score_tol == 1.2 else 0) <= sum(out["handed"]) <= total, (out["handed"], ref["count"])
+
+
+def test_exact_intersections_and_gated_confidences_in_handed_over_clusters(api, monkeypatch):
+    """dist == 0 gives an inf pair score (triangulation.py:72); a confidence below the threshold ASSIGNS 0 to that pair
+    (:73-74).  The fast item multiplies (0 * inf = NaN) and must re-do such joints member by member.  Exactly
+    representable geometry (K = R = I) so that rays really intersect."""
+    from oracle import oracle as orc
+    C, P, J = 3, 2, 6
+    K = np.tile(np.eye(3), (C, 1, 1)); R = np.tile(np.eye(3), (C, 1, 1))
+    t = np.array([[0.0, 0, 0], [2.0, 0, 0], [0, 2.0, 0]])
+    X = np.array([[[1.0, 0.0, 4.0], [0.5, 0.5, 2.0], [1.0, 1.0, 4.0], [0.0, 1.0, 2.0], [0.25, 0.75, 2.0], [1.5, 0.5, 4.0]],
+                  [[3.0, 2.0, 8.0], [2.5, 2.5, 4.0], [3.0, 3.0, 8.0], [2.0, 3.0, 4.0], [2.25, 2.75, 4.0], [3.5, 2.5, 8.0]]])
+    rng = np.random.default_rng(3)
+    F = 6
+    kp = np.zeros((F, C, P, J, 3), np.float32)
+    for f in range(F):
+        for c in range(C):
+            for p in range(P):
+                kp[f, c, p, :, 0] = (X[p, :, 0] - t[c, 0]) / X[p, :, 2]
+                kp[f, c, p, :, 1] = (X[p, :, 1] - t[c, 1]) / X[p, :, 2]
+                kp[f, c, p, :, 2] = 5.0
+        # inexact joints (a real distance) mixed with the exact ones, and some gated confidences on exact joints
+        kp[f, :, :, 4:, :2] += rng.normal(0, 1e-3, (C, P, J - 4, 2)).astype(np.float32)
+        kp[f, rng.integers(0, C), 0, 1, 2] = 1.0
+        kp[f, rng.integers(0, C), 1, 2, 2] = 1.0
+    npers = np.full((F, C), P, np.int32)
+    prm = dict(keypoint_score_threshold=3.0, average_score_threshold=0.0, distance_threshold=0.05, condense_distance_tol=0.5,
+               condense_person_num_tol=0, condense_score_tol=0.0, center_point_index=4, keypoint_num=J)
+    ref = orc.triangulate_condense_batch(K, R, t, kp, npers, orc.make_params(**prm), 64)
+    out = _run(api, K, R, t, prm, kp, npers, 4, monkeypatch)
+    off = _run(api, K, R, t, prm, kp, npers, 4, monkeypatch, handover=False)
+    np.testing.assert_array_equal(out["count"], ref["count"])
+    np.testing.assert_array_equal(off["count"], ref["count"])
+    for name, o in (("hand-over", out), ("phase 3", off)):
+        for f in range(F):
+            m = min(int(ref["count"][f]), 4)
+            got, want = o["xyzs"][f, :m].astype(np.float64), np.concatenate([ref["xyz"][f, :m], ref["kscore"][f, :m][..., None]], -1)
+            bad = np.argwhere((np.isnan(got) != np.isnan(want)) | (np.isinf(got) != np.isinf(want)))
+            assert len(bad) == 0, (name, f, bad[:4].tolist(), [(got[tuple(b[:2])].tolist(), want[tuple(b[:2])].tolist()) for b in bad[:3]])
+            fin = np.isfinite(want)
+            assert np.abs(got[fin] - want[fin]).max() < 1e-5 * max(1.0, np.abs(want[fin]).max())
+
+
+def test_handover_is_deterministic_and_independent_of_the_batch_split(api, monkeypatch):
+    """The descriptor list is filled in whatever order the workgroups finish their frames; the outputs must not
+    depend on it, nor on how the frames are split over launches."""
+    from snowmocap_amd import synth
+    rng = np.random.default_rng(23)
+    C, P, F, J = 8, 4, 300, 133
+    K, R, t = synth.ring_rig(C, radius=5.0)
+    X = synth.make_people(rng, 30, P, J=J)
+    kp, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=0.7, score_range=(3.5, 9.0), permute_persons=True, dtype=np.float32)
+    kp = np.tile(kp, (F // 30, 1, 1, 1, 1)); npers = np.tile(npers, (F // 30, 1))
+    prm = dict(PRM, keypoint_num=J)
+    a = _run(api, K, R, t, prm, kp, npers, P, monkeypatch)
+    b = _run(api, K, R, t, prm, kp, npers, P, monkeypatch)
+    assert a["handed"] == b["handed"] and sum(a["handed"]) == int(np.minimum(a["count"], P).sum())
+    for key in ("xyzs", "pscore", "count"):
+        assert np.array_equal(a[key], b[key]), key
+    # the frames repeat with period 30: so must the outputs, wherever a frame sits in the launch
+    assert np.array_equal(a["xyzs"][:30], a["xyzs"][270:])
+    parts = [_run(api, K, R, t, prm, kp[s:e], npers[s:e], P, monkeypatch) for s, e in ((0, 7), (7, 130), (130, 300))]
+    assert np.array_equal(np.concatenate([p["xyzs"] for p in parts]), a["xyzs"])
+    assert np.array_equal(np.concatenate([p["pscore"] for p in parts]), a["pscore"])
