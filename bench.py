@@ -293,7 +293,7 @@ def main():
 
     lean = method == _lib.PAIRWISE and os.environ.get("SNOWTRI_LEAN_MODE", "1") != "0" and F > 0
     kernel_name = ("k_fused_lean<4,float,133>" if lean else "k_fused_single<4,%d,float,float>" % (1 if args.method == "dlt" else 0))
-    valu_per_64 = 347 if lean else 422      # rocprofv3 SQ_INSTS_VALU per 64 joints (profiles/)
+    valu_per_64 = 337 if lean else 422      # rocprofv3 SQ_INSTS_VALU per 64 joints (profiles/)
 
     large = None
     if args.large_frames and rank == 0 and world == 1:

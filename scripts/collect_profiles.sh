@@ -17,7 +17,7 @@ for t in ("a3", "b3", "a5", "b5"):
     src = f"gpurun_out/pmc_multi/csv/pmc_{t}.csv"
     if not os.path.exists(src):
         continue
-    keep = [r for r in csv.DictReader(open(src)) if "k_frame_recompute" in r["Kernel_Name"]]
+    keep = [r for r in csv.DictReader(open(src)) if "k_frame_recompute" in r["Kernel_Name"] or "k_cluster_fuse" in r["Kernel_Name"]]
     cfg = {"3": "cfg3_8x4_10000", "5": "cfg5_16x8_12000"}[t[1]]
     dst = f"$DST/pmc_multi_{cfg}_{'sq' if t[0] == 'a' else 'lds'}.csv"
     with open(dst, "w", newline="") as fh:

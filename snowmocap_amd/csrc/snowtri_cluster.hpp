@@ -291,6 +291,9 @@ __device__ __forceinline__ void cluster_member_passes(const ClusterDesc *__restr
 #ifndef SNOWTRI_CLUSTER_WAVES
 #define SNOWTRI_CLUSTER_WAVES 2
 #endif
+#ifndef SNOWTRI_CLUSTER_PREFETCH
+#define SNOWTRI_CLUSTER_PREFETCH 1   // 0: no register prefetch of the next pass (dev A/B: fewer registers, more waves)
+#endif
 template <int C, typename TIn>
 __global__ __launch_bounds__(kBlock, SNOWTRI_CLUSTER_WAVES) void k_cluster_fuse(const ClusterDesc *__restrict__ desc,
                                                           const uint32_t *__restrict__ words,
@@ -359,35 +362,40 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_CLUSTER_WAVES) void k_cluster_fuse(
     const uint32_t p_first = blockIdx.x * (uint32_t)(kBlock / 64) + (uint32_t)wave;
     uint32_t p = p_first;
     if (p < npass) {
-    Kp3<TIn> cur[C], nxt[C];
-    Item it0 = locate(p);
-    fetch(cur, it0);
-    Item it1 = locate(p + W);
-    for (; p < npass; p += W) {
-        fetch(nxt, it1);
-        const Item it2 = locate(p + 2 * W);
-        float ox, oy, oz, os;
-        asm volatile("" ::: "memory");   // the rig constants are re-read from LDS in every pass (hoisted out of the loop they would take 360 registers)
-        const bool bad = cluster_item<C, TIn>(K, cur, kthr_f32, kthr, dthr2, ox, oy, oz, os);
-        if (__ballot(bad && it0.valid)) {   // rare, wave-uniform branch
-            if (bad && it0.valid)
-                cluster_joint_sequential<TIn>(rig, kp3, (int64_t)it0.frame, it0.persons, Pmax, J, (int)it0.j, prm, ox, oy, oz, os);
-        }
-#ifdef SNOWTRI_DEBUG_CLUSTER
-        if (p == 0 && lane < 2)
-            printf("lane %d: ndesc %u total %u frame %u persons %x slot %u j %u valid %d | kp0 %g %g %g kp1 %g %g %g | K %g %g %g d0 %g %g %g | out %g %g %g %g bad %d\n",
-                   lane, ndesc, total, it0.frame, it0.persons, it0.slot, it0.j, (int)it0.valid, (double)cur[0].u, (double)cur[0].v, (double)cur[0].s,
-                   (double)cur[1].u, (double)cur[1].v, (double)cur[1].s, K[0], K[1], K[2], K[12 * C], K[12 * C + 1], K[12 * C + 2], (double)ox, (double)oy, (double)oz, (double)os, (int)bad);
+#if SNOWTRI_CLUSTER_PREFETCH
+        Kp3<TIn> cur[C], nxt[C];
+        Item it0 = locate(p);
+        fetch(cur, it0);
+        Item it1 = locate(p + W);
+#else
+        Kp3<TIn> cur[C];
 #endif
-        if (it0.valid) {
-            float4 *o = reinterpret_cast<float4 *>(out4) + ((uint64_t)it0.frame * (uint32_t)Pout + it0.slot) * (uint64_t)(uint32_t)J + it0.j;
-            *o = make_float4(ox, oy, oz, os);
-        }
+        for (; p < npass; p += W) {
+#if SNOWTRI_CLUSTER_PREFETCH
+            fetch(nxt, it1);
+            const Item it2 = locate(p + 2 * W);
+#else
+            const Item it0 = locate(p);
+            fetch(cur, it0);
+#endif
+            float ox, oy, oz, os;
+            asm volatile("" ::: "memory");   // the rig constants are re-read from LDS in every pass (hoisted out of the loop they would take 360 registers)
+            const bool bad = cluster_item<C, TIn>(K, cur, kthr_f32, kthr, dthr2, ox, oy, oz, os);
+            if (__ballot(bad && it0.valid)) {   // rare, wave-uniform branch
+                if (bad && it0.valid)
+                    cluster_joint_sequential<TIn>(rig, kp3, (int64_t)it0.frame, it0.persons, Pmax, J, (int)it0.j, prm, ox, oy, oz, os);
+            }
+            if (it0.valid) {
+                float4 *o = reinterpret_cast<float4 *>(out4) + ((uint64_t)it0.frame * (uint32_t)Pout + it0.slot) * (uint64_t)(uint32_t)J + it0.j;
+                *o = make_float4(ox, oy, oz, os);
+            }
+#if SNOWTRI_CLUSTER_PREFETCH
 #pragma unroll
-        for (int c = 0; c < C; c++) cur[c] = nxt[c];
-        it0 = it1;
-        it1 = it2;
-    }
+            for (int c = 0; c < C; c++) cur[c] = nxt[c];
+            it0 = it1;
+            it1 = it2;
+#endif
+        }
     }
     // the waves that ran the fewest complete-graph passes start on the member lists first
     cluster_member_passes<TIn>(desc + desc_cap, ngen, words, K, pc, pairs_l, C * Pmax, kp3, prm, J, jmagic, Pout, out4,
