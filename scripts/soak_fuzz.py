@@ -8,6 +8,7 @@ import numpy as np
 import snowmocap_amd as api
 import test_gpu_parity as T
 import test_gpu_lean as TL
+import test_gpu_handover as TH
 
 real_rng = np.random.default_rng
 
@@ -15,6 +16,11 @@ real_rng = np.random.default_rng
 class Env:                       # minimal stand-in for pytest's monkeypatch
     def setenv(self, k, v): os.environ[k] = v
     def undo(self): os.environ.pop("SNOWTRI_GENERAL_MODE", None)
+
+
+class MP:                        # monkeypatch stand-in for the hand-over sweep
+    def setenv(self, k, v): os.environ[k] = v
+    def delenv(self, k): os.environ.pop(k, None)
 
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
@@ -26,7 +32,8 @@ sweeps = [("small_rigs auto", lambda e: T.test_random_small_rigs_against_oracle(
           ("dlt multi", lambda e: T.test_random_small_rigs_dlt_against_oracle(api)),
           ("per-frame api", lambda e: T.test_random_small_rigs_per_frame_api(api)),
           ("lean thresholds", lambda e: TL.test_lean_random_thresholds_and_person_lists(api)),
-          ("lean special", lambda e: TL.test_lean_special_values(api))]
+          ("lean special", lambda e: TL.test_lean_special_values(api)),
+          ("handover", lambda e: TH.test_random_rigs_with_handover_against_oracle_and_phase3(api, MP()))]
 fails = 0
 t0 = time.time()
 for r in range(rounds):

@@ -222,3 +222,46 @@ def test_handover_is_deterministic_and_independent_of_the_batch_split(api, monke
     parts = [_run(api, K, R, t, prm, kp[s:e], npers[s:e], P, monkeypatch) for s, e in ((0, 7), (7, 130), (130, 300))]
     assert np.array_equal(np.concatenate([p["xyzs"] for p in parts]), a["xyzs"])
     assert np.array_equal(np.concatenate([p["pscore"] for p in parts]), a["pscore"])
+
+
+def test_random_rigs_with_handover_against_oracle_and_phase3(api, monkeypatch):
+    """Randomised sweep of what the hand-over can meet: 2..8 cameras, 2..4 detections per camera with ragged (also empty)
+    person lists, 5..40 joints, thresholds that switch every filter on and off, ghost candidates that form clusters of
+    their own, persons merged by a wide condense_distance_tol, Pout_max below and above the person count -- float32
+    outputs, keypoint_num == J.  Against the oracle, and against the same launch with phase 3 kept in the kernel."""
+    from snowmocap_amd import synth
+    from oracle import oracle as orc
+    rng = np.random.default_rng(4242)
+    routes = np.zeros(2, np.int64)
+    checked = 0
+    for trial in range(40):
+        C = int(rng.integers(2, 9))
+        P = int(rng.integers(2, 5))
+        J = int(rng.choice([5, 20, 33, 40]))
+        F = int(rng.integers(1, 7))
+        K, R, t = synth.ring_rig(C, radius=float(rng.uniform(3, 6)))
+        X = synth.make_people(rng, F, P, J=J)
+        kp, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=float(rng.choice([0.3, 1.0, 3.0])), score_range=(2.0, 8.0),
+                                         permute_persons=True, dtype=np.float64 if trial % 3 == 0 else np.float32)
+        npers = npers.copy()
+        for _ in range(int(rng.integers(0, 3))):                          # ragged / empty person lists
+            npers[rng.integers(0, F), rng.integers(0, C)] = rng.integers(0, P + 1)
+        prm = dict(keypoint_score_threshold=float(rng.choice([0.0, 3.0, 3.0, 5.0])),
+                   average_score_threshold=float(rng.choice([0.0, 0.0, 0.3, 1.5])),
+                   distance_threshold=float(rng.choice([0.02, 0.05, 1.0])),
+                   condense_distance_tol=float(rng.choice([0.05, 0.3, 10.0])),
+                   condense_person_num_tol=int(rng.choice([0, 0, 1, 2])),
+                   condense_score_tol=float(rng.choice([0.0, 0.0, 0.3, 2.0])),
+                   center_point_index=int(rng.integers(0, J)), keypoint_num=J)
+        pout = int(rng.choice([1, 4, 16]))
+        ref = orc.triangulate_condense_batch(K, R, t, kp, npers, orc.make_params(**prm), 64)
+        out = _run(api, K, R, t, prm, kp, npers, pout, monkeypatch)
+        off = _run(api, K, R, t, prm, kp, npers, pout, monkeypatch, handover=False)
+        msg = f"trial {trial}: C={C} P={P} J={J} F={F} {prm} pout={pout} n={npers.tolist()}"
+        _check(out, ref, pout, J, msg)
+        _same(out, off, msg)
+        assert out["handed"][0] >= 0 and sum(out["handed"]) <= int(np.minimum(ref["count"], pout).sum()), (msg, out["handed"])
+        routes += out["handed"]
+        checked += int(np.minimum(ref["count"], pout).sum())
+    # both routes of the streaming kernel are exercised, and most persons take one of them
+    assert routes[0] > 20 and routes[1] > 20 and routes.sum() > 0.5 * checked, (routes, checked)
