@@ -145,6 +145,7 @@ int snowtri_condense(snowtri_ctx *ctx, int64_t F, int32_t N, int32_t J, const do
  * add_human_2D_points x (C*P) -> Human_Triangulation -> Human_Triangulation_Condense of
  * main.py:50-71,106.  No candidate list ever reaches HBM on the fast path.
  *   kpts [F][C][Pmax][J][3] of in_dtype;  out_xyzs [F][Pout_max][kn][4] of out_dtype
+ *   (SNOWTRI_DEVICE: kpts aligned to its element size, out_xyzs to 16 bytes -- else SNOWTRI_ERR_BAD_ARG)
  *   out_pscore [F][Pout_max] of out_dtype (may be NULL), out_count[F] int32, out_flags[F] (may be NULL)
  * Entries of persons >= out_count[f] are zero-filled.  Returns OK / ERR_SINGULAR / ERR_OVERFLOW only
  * for SNOWTRI_HOST calls (device calls are asynchronous: inspect out_flags). */

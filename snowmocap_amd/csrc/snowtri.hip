@@ -1227,9 +1227,12 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax
     // member list Kc words per frame (<= 32 M words, 128 MB); row indices are 32-bit
     const int64_t seg_frames = !handover ? F : std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(((int64_t)2 << 20) / Pout, ((int64_t)32 << 20) / Kc),
                                                                                       ((int64_t)1 << 31) / R));
+    int64_t seg_cap = seg_frames;
+    if (const char *e = getenv("SNOWTRI_HANDOVER_SEG_FRAMES")) seg_cap = std::max(1, atoi(e));   // test knob: short segments
+    const int64_t seg = handover ? std::min(seg_frames, seg_cap) : F;
     unsigned long long *next_frame = ctx->d_counters + 2, *hand_counters = ctx->d_counters + 3;
-    for (int64_t s0 = 0; s0 < F; s0 += seg_frames) {
-        const int64_t Fs = std::min<int64_t>(seg_frames, F - s0);
+    for (int64_t s0 = 0; s0 < F; s0 += seg) {
+        const int64_t Fs = std::min<int64_t>(seg, F - s0);
         int64_t grid = std::min<int64_t>(Fs, (int64_t)ctx->num_cus * std::max(1, per_cu));
         grid = std::max<int64_t>(1, std::min<int64_t>(grid, (int64_t)(kMaxScratchBytes / per_block)));
         int rc = ctx->work.ensure(per_block * (size_t)grid);
@@ -1393,6 +1396,9 @@ extern "C" int snowtri_triangulate_condense(snowtri_ctx *ctx, int64_t F, int32_t
     if (method == SNOWTRI_DLT && ctx->C < 2) return SNOWTRI_ERR_BAD_ARG;
     if (F == 0) return SNOWTRI_OK;
     if (!kpts || !out_xyzs || !out_count) return SNOWTRI_ERR_BAD_ARG;
+    // device buffers: keypoints aligned to their element, joint records [x, y, z, s] to 16 bytes (vector stores)
+    if (memspace == SNOWTRI_DEVICE && (((uintptr_t)kpts & (dtype_size(in_dtype) - 1)) != 0 || ((uintptr_t)out_xyzs & 15) != 0))
+        return SNOWTRI_ERR_BAD_ARG;
     Params prm;
     int rc = validate_params(params, J, &prm, true);
     if (rc) return rc;

@@ -994,10 +994,9 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
             }
             }   // !handed
         }
-        for (int slot = nout; slot < Pout; slot++) {
-            for (int b = tid; b < kn; b += kBlock) wr.joint(f, Pout, kn, slot, b, 0.0, 0.0, 0.0, 0.0);
-            if (tid == 0) wr.person(f, Pout, slot, 0.0);
-        }
+        // unused slots: one flat sweep of 16-byte stores
+        for (int i = tid; i < (Pout - nout) * kn; i += kBlock) wr.zero_joint(f, Pout, kn, nout + i / kn, i % kn);
+        for (int slot = nout + tid; slot < Pout; slot += kBlock) wr.person(f, Pout, slot, 0.0);
         if (tid == 0) {
             out_count[f] = nout;
             if (out_flags && nout > Pout) atomicOr(&out_flags[f], 2u /*SNOWTRI_FLAG_OVERFLOW*/);

@@ -193,6 +193,16 @@ struct PackedWriter {
         o[2] = (TOut)z;
         o[3] = (TOut)s;
     }
+    // an unused slot's joint: one 16-byte store (xyzs is 16-byte aligned: checked at the ABI)
+    __device__ __forceinline__ void zero_joint(int64_t f, int Pout, int kn, int slot, int b) const {
+        TOut *o = xyzs + ((f * Pout + slot) * (int64_t)kn + b) * 4;
+        if constexpr (sizeof(TOut) == 4) {
+            *reinterpret_cast<float4 *>(o) = make_float4(0.0f, 0.0f, 0.0f, 0.0f);
+        } else {
+            *reinterpret_cast<double2 *>(o) = make_double2(0.0, 0.0);
+            *reinterpret_cast<double2 *>(o + 2) = make_double2(0.0, 0.0);
+        }
+    }
     __device__ __forceinline__ void person(int64_t f, int Pout, int slot, double s) const {
         if (pscore) pscore[f * Pout + slot] = (TOut)s;
     }

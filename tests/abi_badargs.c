@@ -41,7 +41,7 @@ static snowtri_params good_params(int J) {
 
 int main(void) {
     double buf[4096];
-    float fbuf[4096];
+    float fbuf[4096] __attribute__((aligned(16)));
     int32_t ibuf[64];
     uint32_t ubuf[64];
     uint8_t bbuf[256];
@@ -162,6 +162,9 @@ int main(void) {
         EXPECT(FUSED(1, 1, J, fbuf, SNOWTRI_F32, &prm, SNOWTRI_PAIRWISE, 1, fbuf, SNOWTRI_F32, NULL, SNOWTRI_HOST), SNOWTRI_ERR_BAD_ARG);
         EXPECT(FUSED(1, 1, J, fbuf, SNOWTRI_F32, NULL, SNOWTRI_PAIRWISE, 1, fbuf, SNOWTRI_F32, ibuf, SNOWTRI_HOST), SNOWTRI_ERR_BAD_ARG);
         EXPECT(FUSED(0, 1, J, NULL, SNOWTRI_F32, &prm, SNOWTRI_PAIRWISE, 1, NULL, SNOWTRI_F32, NULL, SNOWTRI_HOST), SNOWTRI_OK); /* empty batch */
+        /* device buffers: joint records must be 16-byte aligned, keypoints element-aligned (checked before any launch) */
+        EXPECT(FUSED(1, 1, J, fbuf, SNOWTRI_F32, &prm, SNOWTRI_PAIRWISE, 1, (char *)fbuf + 4, SNOWTRI_F32, ibuf, SNOWTRI_DEVICE), SNOWTRI_ERR_BAD_ARG);
+        EXPECT(FUSED(1, 1, J, (char *)fbuf + 2, SNOWTRI_F32, &prm, SNOWTRI_PAIRWISE, 1, fbuf, SNOWTRI_F32, ibuf, SNOWTRI_DEVICE), SNOWTRI_ERR_BAD_ARG);
         prm.center_point_index = J;   /* reference: IndexError */
         EXPECT(FUSED(1, 1, J, fbuf, SNOWTRI_F32, &prm, SNOWTRI_PAIRWISE, 1, fbuf, SNOWTRI_F32, ibuf, SNOWTRI_HOST), SNOWTRI_ERR_BAD_INDEX);
         prm = good_params(J);

@@ -265,3 +265,26 @@ def test_random_rigs_with_handover_against_oracle_and_phase3(api, monkeypatch):
         checked += int(np.minimum(ref["count"], pout).sum())
     # both routes of the streaming kernel are exercised, and most persons take one of them
     assert routes[0] > 20 and routes[1] > 20 and routes.sum() > 0.5 * checked, (routes, checked)
+
+
+def test_long_batches_are_cut_into_segments(api, monkeypatch):
+    """The descriptor and member lists are sized per segment of a long batch (<= 2 M persons, 32 M member words); the
+    test knob SNOWTRI_HANDOVER_SEG_FRAMES makes the segments 7 frames short: same outputs, bit for bit."""
+    from snowmocap_amd import synth
+    rng = np.random.default_rng(8)
+    C, P, F, J = 5, 3, 45, 40
+    K, R, t = synth.ring_rig(C, radius=4.5)
+    X = synth.make_people(rng, F, P, J=J)
+    kp, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=0.7, score_range=(3.5, 9.0), permute_persons=True, dtype=np.float32)
+    npers = npers.copy()
+    npers[::6, 1] = P - 1
+    prm = dict(PRM, keypoint_num=J)
+    whole = _run(api, K, R, t, prm, kp, npers, P, monkeypatch)
+    monkeypatch.setenv("SNOWTRI_HANDOVER_SEG_FRAMES", "7")
+    cut = _run(api, K, R, t, prm, kp, npers, P, monkeypatch)
+    monkeypatch.delenv("SNOWTRI_HANDOVER_SEG_FRAMES")
+    for key in ("xyzs", "pscore", "count", "flags"):
+        assert np.array_equal(whole[key], cut[key]), key
+    assert sum(whole["handed"]) == int(np.minimum(whole["count"], P).sum())
+    # (the counters read back belong to the LAST segment: frames 42..44)
+    assert sum(cut["handed"]) == int(np.minimum(whole["count"][42:], P).sum())
