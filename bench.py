@@ -461,7 +461,10 @@ def extra_workloads(torch, dev, device_index):
         persons = float(cnt.mean())
         bpf = 12 * C * P * J + 16 * persons * J
         tflops = solves * FLOP_PER_SOLVE / 1e12
-        res.append({"workload": label, "kernel": "k_frame_recompute<0,float,float>", "frames": F, "kernel_ms": m,
+        # <= 8 cameras: the fusion of the clusters runs in the streaming kernel behind the association kernel (one fused
+        # call = both launches; kernel_ms = HIP events around the call); 16 cameras keep it inside k_frame_recompute
+        kernels = ("k_frame_recompute<0,float,float> + k_cluster_fuse<%d,float>" % C) if C <= 8 else "k_frame_recompute<0,float,float>"
+        res.append({"workload": label, "kernel": kernels, "frames": F, "kernel_ms": m,
                     "kernel_ms_all": ms[1:], "frames_per_s": F / (m * 1e-3),
                     "output_joints_per_s": float(cnt.clip(max=pout).sum()) * J / (m * 1e-3),
                     "pair_solves_per_s": solves, "mean_persons_per_frame": persons,
