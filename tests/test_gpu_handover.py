@@ -288,3 +288,47 @@ def test_long_batches_are_cut_into_segments(api, monkeypatch):
     assert sum(whole["handed"]) == int(np.minimum(whole["count"], P).sum())
     # (the counters read back belong to the LAST segment: frames 42..44)
     assert sum(cut["handed"]) == int(np.minimum(whole["count"][42:], P).sum())
+
+
+@pytest.mark.parametrize("chunks", [1, 5])
+def test_sharded_multi_person_batch_with_handover_single_rank_group(api, chunks):
+    """The device-pointer route: ShardedTriangulator.run (1-rank RCCL group) cuts a multi-person shard into pieces whose
+    inputs / outputs are slices of larger device buffers, each piece = association kernel + cluster kernel on the
+    current stream, gathered on a side stream -- bit-identical to one unsharded launch, and equal to the host route."""
+    import os
+    import torch
+    import torch.distributed as dist
+    from snowmocap_amd import synth
+    from snowmocap_amd.sharded import ShardedTriangulator
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(29450 + os.getpid() % 200))
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        rng = np.random.default_rng(61)
+        C, P, F, J = 6, 3, 203, 133
+        K, R, t = synth.ring_rig(C, radius=5.0)
+        X = synth.make_people(rng, 29, P, J=J)
+        kp, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=0.7, score_range=(3.5, 9.0), permute_persons=True, dtype=np.float32)
+        kp = np.tile(kp, (7, 1, 1, 1, 1)); npers = np.tile(npers, (7, 1)).copy()
+        npers[::9, 2] = P - 1                   # some ragged frames: member-list descriptors
+        prm = dict(PRM, keypoint_num=J)
+        dev = torch.device("cuda", 0)
+        kpd, npd = torch.from_numpy(kp).to(dev), torch.from_numpy(npers).to(dev)
+        st = ShardedTriangulator(K, R, t, prm, pout_max=P + 1, device=0, chunks=chunks)
+        got = st.run(kpd, F, npd)
+        torch.cuda.synchronize()
+        ref = st.bt.run_torch(kpd, npd)
+        torch.cuda.synchronize()
+        handed = st.bt.ctx.last_handover_persons()
+        host = st.bt.run_host(kp, npers)
+        for k in ("xyzs", "pscore", "count", "flags"):
+            assert got[k].shape == ref[k].shape and torch.equal(got[k], ref[k]), k
+            assert np.array_equal(ref[k].cpu().numpy().astype(host[k].dtype), host[k], equal_nan=True), k
+        assert sum(handed) == int(np.minimum(host["count"], P + 1).sum()) and handed[1] > 0, handed
+        st.bt.close()
+    finally:
+        if created:
+            dist.destroy_process_group()
