@@ -332,3 +332,28 @@ def test_sharded_multi_person_batch_with_handover_single_rank_group(api, chunks)
     finally:
         if created:
             dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("C,P,armed", [(4, 16, True), (8, 16, True), (3, 17, False)])
+def test_person_index_limits_of_the_descriptor(api, C, P, armed, monkeypatch):
+    """The descriptor packs one 4-bit person index per camera: 16 detections per camera is the last shape that is handed
+    over (person 15 must survive the packing), 17 keeps phase 3 in the association kernel."""
+    from snowmocap_amd import synth
+    from oracle import oracle as orc
+    rng = np.random.default_rng(1000 + C * P)
+    F, J = 2, 8
+    K, R, t = synth.ring_rig(C, radius=9.0)
+    X = synth.make_people(rng, F, P, J=J)
+    X[..., 0] += np.linspace(-6, 6, P)[None, :, None]       # spread the crowd out: most persons form their own cluster
+    kp, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=0.3, score_range=(3.5, 9.0), permute_persons=True, dtype=np.float32)
+    prm = dict(PRM, keypoint_num=J, condense_person_num_tol=1)
+    ref = orc.triangulate_condense_batch(K, R, t, kp, npers, orc.make_params(**prm), 128)
+    out = _run(api, K, R, t, prm, kp, npers, 128, monkeypatch)
+    off = _run(api, K, R, t, prm, kp, npers, 128, monkeypatch, handover=False)
+    msg = f"C={C} P={P}"
+    _check(out, ref, 128, J, msg)
+    _same(out, off, msg)
+    if armed:
+        assert sum(out["handed"]) == int(ref["count"].sum()) and out["handed"][0] >= P, (out["handed"], ref["count"])
+    else:
+        assert out["handed"] == (-1, -1)
