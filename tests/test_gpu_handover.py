@@ -357,3 +357,23 @@ def test_person_index_limits_of_the_descriptor(api, C, P, armed, monkeypatch):
         assert sum(out["handed"]) == int(ref["count"].sum()) and out["handed"][0] >= P, (out["handed"], ref["count"])
     else:
         assert out["handed"] == (-1, -1)
+
+
+def test_frames_whose_member_lists_do_not_fit_the_staging_stay_in_phase3(api, monkeypatch):
+    """Every filter off and a huge condense_distance_tol: all 7 168 candidates of an 8 x 16 frame are kept and fall into
+    one cluster.  Its member list does not fit the LDS staging of the hand-over: the frame keeps phase 3 (nothing handed
+    over although the hand-over is armed), results as the oracle's."""
+    from snowmocap_amd import synth
+    from oracle import oracle as orc
+    rng = np.random.default_rng(77)
+    C, P, F, J = 8, 16, 2, 5
+    K, R, t = synth.ring_rig(C, radius=9.0)
+    X = synth.make_people(rng, F, P, J=J)
+    kp, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=0.3, score_range=(3.5, 9.0), permute_persons=True, dtype=np.float32)
+    prm = dict(keypoint_score_threshold=0.0, average_score_threshold=0.0, distance_threshold=1e9, condense_distance_tol=1e9,
+               condense_person_num_tol=0, condense_score_tol=0.0, center_point_index=0, keypoint_num=J)
+    ref = orc.triangulate_condense_batch(K, R, t, kp, npers, orc.make_params(**prm), 4)
+    assert (ref["count"] == 1).all()
+    out = _run(api, K, R, t, prm, kp, npers, 4, monkeypatch)
+    _check(out, ref, 4, J, "one cluster of 7 168 members")
+    assert out["handed"] == (0, 0), out["handed"]
