@@ -1205,9 +1205,9 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax
     const int64_t Kc = snowtri_num_candidate_slots(ctx->C, Pmax);
     const int C = ctx->C, R = C * Pmax;
     const size_t per_block = recompute_scratch_bytes(Kc, R, prm.kn);
-    // three workgroups per CU share the 160 KB of LDS: each takes 52 KB, what the ray chunk and the tables leave
-    // of it holds the member words of phase 3
-    const size_t lds = std::max<size_t>(recompute_lds_bytes(R, J, prm.kn, (int)sizeof(TIn), ctx->npairs), (size_t)52 * 1024);
+    // three workgroups per CU share the 160 KB of LDS (snowtri_general.hpp: the arena behind the tables is reused
+    // phase by phase)
+    const size_t lds = recompute_launch_lds(C, ctx->npairs);
     auto kern = k_frame_recompute<METHOD, TIn, TOut>;
     if (lds > 48 * 1024)
         HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1303,8 +1303,7 @@ int fused_dispatch(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax, int J,
     int rc;
     if (method == SNOWTRI_DLT && (Pmax > 1 || C > 8)) {
         // several detections per camera: the reference's association (phases 1-2), then DLT per cluster
-        if (prm.kn > kRecomputeMaxKn || recompute_chunk_joints(C * Pmax, J, (int)sizeof(TIn)) < 1 || C * Pmax > 1024 ||
-            ctx->npairs > kPairTabMaxPairs)
+        if (prm.kn > kRecomputeMaxKn || !recompute_shape_ok(C, Pmax, J, ctx->npairs, (int)sizeof(TIn)))
             return SNOWTRI_ERR_BAD_ARG;
         rc = launch_frame_recompute<1, TIn, TOut>(ctx, st, F, Pmax, J, d_kpts, d_np, prm, Pout, d_xyzs, d_ps, d_cnt, d_fl);
     } else if (method == SNOWTRI_DLT) {
@@ -1360,8 +1359,7 @@ int fused_dispatch(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax, int J,
 #undef SNOWTRI_CASE
             default: rc = SNOWTRI_ERR_BAD_ARG;
         }
-    } else if (prm.kn <= kRecomputeMaxKn && recompute_chunk_joints(C * Pmax, J, (int)sizeof(TIn)) >= 1 && C * Pmax <= 1024 &&
-               ctx->npairs <= kPairTabMaxPairs &&
+    } else if (prm.kn <= kRecomputeMaxKn && recompute_shape_ok(C, Pmax, J, ctx->npairs, (int)sizeof(TIn)) &&
                ctx->general_mode != 1) {
         rc = launch_frame_recompute<0, TIn, TOut>(ctx, st, F, Pmax, J, d_kpts, d_np, prm, Pout, d_xyzs, d_ps, d_cnt, d_fl);
     } else {

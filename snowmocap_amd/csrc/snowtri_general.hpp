@@ -29,12 +29,19 @@ __host__ __device__ constexpr size_t recompute_scratch_bytes(int64_t Kc, int R, 
     return (((size_t)Kc * 64) + (size_t)R * 8 + 1024 + (size_t)kRecomputeSlotTile * kn * 8 + 255) & ~(size_t)255;
 }
 
-// LDS layout of one joint chunk (Jc joints): rays[R][Jc] with a row stride of 32 Jc + 16 bytes and scores[R][Jc | 1]:
-// a lane walks the joints of ITS candidate's two rows with compile-time offsets (no address arithmetic in the
-// solve loop), and the odd strides (in 16-byte / 4-byte units) spread the rows of neighbouring lanes over the banks.
-// Joints per chunk: what fits the budget, rounded DOWN to a power of two -- phase 3 maps thread = (joint of the chunk,
-// member group of G lanes) with G a power of two and joints x G <= 256, so only a power-of-two chunk fills the workgroup
-// (42 joints x 4 lanes = 168 of 256 threads at 8 cameras x 4 persons; 32 x 8 = 256).
+// ---- LDS map of k_frame_recompute -------------------------------------------------------------------------------
+//   [0, 256)            reduction slots + flags
+//   [256, ...)          camera-pair table (56 B per pair) and the ray matrices M[C][9]
+//   [arena_off, total)  the ARENA, reused phase by phase:
+//       phase 1   candidate score sums (when they fit, see p1_sums_in_lds) + one joint chunk of ray records (below)
+//       phase 2   centres and cluster ids of the kept candidates
+//       hand-over descriptor staging
+//       phase 3   (frames that are not handed over) ray rows of a joint chunk in the row-major layout of
+//                 recompute_chunk_joints (<= kRayChunkBytes) + the clusters' member words behind it
+//
+// Phase-3 chunk (row-major): rays[R][Jc] with a row stride of 32 Jc + 16 bytes and scores[R][Jc | 1].  Joints per
+// chunk: what fits kRayChunkBytes, rounded DOWN to a power of two -- phase 3 maps thread = (joint of the chunk, member
+// group of G lanes) with G a power of two and joints x G <= 256.
 __host__ __device__ inline int recompute_chunk_joints(int R, int J, int score_bytes) {
     const int per_row = kRayChunkBytes / R - 16 - score_bytes;
     int jc = per_row / (32 + score_bytes);
@@ -48,30 +55,111 @@ __host__ __device__ inline int recompute_score_stride(int Jc) { return Jc | 1; }
 
 // bytes of the LDS pair table (6 doubles + 2 int32 per pair); the kernel needs npairs <= kPairTabMaxPairs
 __host__ __device__ inline size_t recompute_pairtab_bytes(int npairs) { return (size_t)npairs * 56; }
-// LDS of k_frame_recompute: [ray chunk: kRayChunkBytes][reduction slots + flags: 256 B][pair table: 56 B per pair]
-// [member words of phase 3: the rest].
-// The launcher asks for at least 52 KB (three workgroups per CU share 160 KB).
-__host__ __device__ inline size_t recompute_lds_bytes(int R, int J, int kn, int score_bytes, int npairs) {
-    (void)J; (void)kn; (void)score_bytes;
-    (void)R;
-    return (size_t)kRayChunkBytes + 256 + recompute_pairtab_bytes(npairs) + 16;
+__host__ __device__ inline size_t recompute_arena_offset(int C, int npairs) {
+    return ((size_t)256 + recompute_pairtab_bytes(npairs) + (size_t)72 * C + 15) & ~(size_t)15;
+}
+// LDS of k_frame_recompute; the launcher asks for at least kRecomputeLdsBytes (three workgroups per CU share 160 KB).
+constexpr int kRecomputeLdsBytes = 53 * 1024;
+__host__ __device__ inline size_t recompute_lds_bytes(int C, int npairs) {
+    return recompute_arena_offset(C, npairs) + (size_t)kRayChunkBytes + 16;
 }
 
-// ---- phase-1 work of ONE candidate on one joint chunk: sum over the chunk's joints of 2000 x the pair score
-// (triangulation.py:70-78 without the 1/2000 of :72, applied by the caller).
-//   EXACT = true   the arithmetic the kernel has always used: 1/dist by v_rsq_f64 + one Newton step (2e-14), exact
-//                  intersection -> inf, four joints share one reciprocal unless their determinants' product leaves the
-//                  normal range (singular pairs are detected there).
-//   EXACT = false  the same solves with the raw v_rsq_f64 (measured 5.2e-8 = 2^-24.2 relative, tests pin <= 2^-23) and no range check -- 36 instead of 57 VALU
-//                  instructions per solve.  Its sum decides only whether the candidate is KEPT (:79-81; the scores that
-//                  are output come from phase 3): the caller re-does a candidate with EXACT = true when its mean is not
-//                  finite (singular pair, exact intersection, NaN input) or lies within 1e-6 relative of
-//                  average_score_threshold, so the decision is always taken on the accurate sum.  The gates (:73-74)
-//                  do not involve 1/dist and d2 is computed identically in both variants: a sum of exactly 0 is exact.
-template <bool EXACT, typename TIn>
-__device__ __forceinline__ double candidate_chunk_sum(const RayRec *__restrict__ ra, const RayRec *__restrict__ rb,
-                                                      const TIn *__restrict__ sa, const TIn *__restrict__ sb, int nj,
-                                                      const Vec3 &d, const Params &prm, bool &sing) {
+// Phase-1 chunk (joint-major): one 40-byte record {x, y, z, |h|^2, score} per (joint of the chunk, ray row),
+//   address = jj * (40 R + 8) + 40 r.
+// A phase-1 lane reads the records of ITS rows for the same joint jj as every other lane of its wave: 8-byte slot
+// (5 r + field) mod 32 -- rows that differ mod 32 never share a bank, equal rows broadcast (conflict-free ds_read_b64
+// for every rig of <= 32 rows, and for the row sets one wave touches on larger rigs); the rows of one camera are 40 B
+// apart, so the GS second rays of a lane's group sit at compile-time offsets from one address register.  The 8 bytes
+// of padding per joint spread the fill's writes (lanes = consecutive joints of one row) over the banks.
+constexpr int kP1Rec = 40;
+__host__ __device__ inline int p1_joint_stride(int R) { return kP1Rec * R + 8; }
+// item = (camera pair, person of its first camera, group of GS persons of its second); JS = how many ways a chunk's
+// joints are split over the waves when one pass of the workgroup has spare waves (wave-uniform: whole waves take a
+// joint sub-range, so the lanes of a wave still read the same joint)
+__host__ __device__ inline int p1_joint_split(int nitems) {
+    const int iw = (nitems + 63) >> 6;
+    return iw <= 1 ? 4 : (iw == 2 ? 2 : 1);
+}
+__host__ __device__ inline int p1_group_size(int Pmax) { return (Pmax & 3) == 0 ? 4 : ((Pmax & 1) == 0 ? 2 : 1); }
+// the candidate score sums live in LDS while phase 1 runs when JS x Kc doubles take <= 8 KB
+__host__ __device__ inline bool p1_sums_in_lds(int npairs, int Pmax) {
+    const int gs = p1_group_size(Pmax);
+    const long long kc = (long long)npairs * Pmax * Pmax;
+    return kc * p1_joint_split((int)(kc / gs > 0x7fffffff ? 0x7fffffff : kc / gs)) <= 1024;
+}
+__host__ __device__ inline int p1_sum_bytes(int npairs, int Pmax) {
+    if (!p1_sums_in_lds(npairs, Pmax)) return 0;
+    const int gs = p1_group_size(Pmax);
+    const int kc = npairs * Pmax * Pmax;
+    return kc * p1_joint_split(kc / gs) * 8;
+}
+// joints per phase-1 chunk: as many as the arena holds, then evened out over the chunks (133 joints: 34+33+33+33
+// instead of 4 x 32 + 5)
+__host__ __device__ inline int p1_chunk_joints(int R, int J, int arena_bytes, int sum_bytes) {
+    const int cap = (arena_bytes - sum_bytes) / p1_joint_stride(R);
+    if (cap < 1) return 0;
+    const int jmax = cap > 64 ? 64 : cap;
+    const int nch = (J + jmax - 1) / jmax;
+    return (J + nch - 1) / nch;
+}
+
+// host + device: the LDS a launch asks for, and whether both chunk layouts hold at least one joint
+__host__ __device__ inline size_t recompute_launch_lds(int C, int npairs) {
+    const size_t need = recompute_lds_bytes(C, npairs);
+    return need > (size_t)kRecomputeLdsBytes ? need : (size_t)kRecomputeLdsBytes;
+}
+__host__ __device__ inline bool recompute_shape_ok(int C, int Pmax, int J, int npairs, int score_bytes) {
+    const int R = C * Pmax;
+    if (R > 1024 || npairs > kPairTabMaxPairs) return false;
+    const int arena = (int)(recompute_launch_lds(C, npairs) - recompute_arena_offset(C, npairs));
+    return recompute_chunk_joints(R, J, score_bytes) >= 1 && p1_chunk_joints(R, J, arena, p1_sum_bytes(npairs, Pmax)) >= 1;
+}
+
+// ---- phase-1 records in LDS ------------------------------------------------------------------------------------
+template <typename TIn>
+__device__ __forceinline__ void p1_store_record(char *rec, const RayRec &h, TIn s) {
+    double *p = reinterpret_cast<double *>(rec);
+    p[0] = h.x;
+    p[1] = h.y;
+    p[2] = h.z;
+    p[3] = h.a;
+    if constexpr (sizeof(TIn) == 4)
+        *reinterpret_cast<unsigned long long *>(rec + 32) = (unsigned long long)__float_as_uint((float)s);   // one 8-byte slot
+    else
+        p[4] = (double)s;
+}
+// Reads of the solve loops: single ds_read_b64 each (2 LDS cycles per wave-instruction, 32-lane groups over 32 8-byte
+// bank pairs).  Volatile keeps the compiler from pairing neighbouring fields into ds_read2_b64 -- which the LDS serves as
+// two passes of 4 x 16 lanes, at HALF the bytes per clock -- and from narrowing the score slot to a 4-byte read (its
+// 4-byte banks alias rows 16 apart).
+typedef __attribute__((address_space(3))) const volatile double *lds_cv_f64;                // (explicit LDS address space:
+typedef __attribute__((address_space(3))) const volatile unsigned long long *lds_cv_u64;   //  a volatile generic access is a flat load)
+template <typename TIn>
+__device__ __forceinline__ TIn p1_load_score(const char *rec) {
+    if constexpr (sizeof(TIn) == 4)
+        return (TIn)__uint_as_float((uint32_t)*(lds_cv_u64)(rec + 32));
+    else
+        return (TIn) * (lds_cv_f64)(rec + 32);
+}
+__device__ __forceinline__ RayRec p1_load_ray(const char *rec) {
+    lds_cv_f64 p = (lds_cv_f64)rec;
+    RayRec r;
+    r.x = p[0];
+    r.y = p[1];
+    r.z = p[2];
+    r.a = p[3];
+    return r;
+}
+
+// ---- the accurate phase-1 sum of ONE candidate over the joints [0, nj) of a chunk: sum of 2000 x the pair score
+// (triangulation.py:70-78 without the 1/2000 of :72, applied by the caller).  1/dist by v_rsq_f64 + one Newton step
+// (2e-14), exact intersection -> inf, four joints share one reciprocal unless their determinants' product leaves the
+// normal range (singular pairs are detected there).  Used for the candidates the fast sums of p1_item_sums cannot
+// decide, and for every candidate when negative confidences may pass the keypoint gate.
+//   ra, rb: records of the candidate's two ray rows for the chunk's first joint; consecutive joints are jstr bytes apart
+template <typename TIn>
+__device__ __forceinline__ double candidate_chunk_sum_exact(const char *__restrict__ ra, const char *__restrict__ rb, int jstr, int nj,
+                                                            const Vec3 &d, const Params &prm, bool &sing) {
     double acc = 0.0;
     // one solve, reciprocal of the determinant supplied (A2 + the score of :72-74)
     auto finish = [&](const RayRec &a, const RayRec &b, double bq, double e, double g, double inv, TIn sm, TIn ss) {
@@ -81,15 +169,10 @@ __device__ __forceinline__ double candidate_chunk_sum(const RayRec *__restrict__
                          fma(b.z, S1, fma(a.z, S0, -d.z))};
         const double d2 = dot3(df, df);
         const bool kp_ = !below_kthr(sm, prm) && !below_kthr(ss, prm) && !(d2 > prm.dthr2);  // :73-74
-        if constexpr (EXACT) {
-            double idist = rsq_nr1(d2);
-            idist = (d2 == 0.0) ? __builtin_inf() : idist;
-            // the gate ASSIGNS 0 (:73-74): select after the product, 0 * inf (exact intersection) would be NaN
-            acc += kp_ ? sum_score(sm, ss) * idist : 0.0;                                     // :72
-        } else {
-            // 0 * inf / 0 * NaN leave NaN in the sum: the caller then re-does the candidate exactly
-            acc = fma(gated_sum(sm, ss, kp_), __builtin_amdgcn_rsq(d2), acc);
-        }
+        double idist = rsq_nr1(d2);
+        idist = (d2 == 0.0) ? __builtin_inf() : idist;
+        // the gate ASSIGNS 0 (:73-74): select after the product, 0 * inf (exact intersection) would be NaN
+        acc += kp_ ? sum_score(sm, ss) * idist : 0.0;                                     // :72
     };
     int jj = 0;
     // four joints at a time share ONE reciprocal (Montgomery): v_rcp_f64 issues at quarter rate.
@@ -99,10 +182,10 @@ __device__ __forceinline__ double candidate_chunk_sum(const RayRec *__restrict__
         double bq[4], e[4], g[4], det[4], inv[4];
 #pragma unroll
         for (int u = 0; u < 4; u++) {
-            a[u] = ra[jj + u];
-            b[u] = rb[jj + u];
-            sm[u] = sa[jj + u];
-            ss[u] = sb[jj + u];
+            a[u] = p1_load_ray(ra + (jj + u) * jstr);
+            b[u] = p1_load_ray(rb + (jj + u) * jstr);
+            sm[u] = p1_load_score<TIn>(ra + (jj + u) * jstr);
+            ss[u] = p1_load_score<TIn>(rb + (jj + u) * jstr);
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) {
@@ -112,9 +195,9 @@ __device__ __forceinline__ double candidate_chunk_sum(const RayRec *__restrict__
             det[u] = fma(a[u].a, b[u].a, -(bq[u] * bq[u]));
         }
         const double p01 = det[0] * det[1], p012 = p01 * det[2], p0123 = p012 * det[3];
-        // EXACT: a product outside the normal range (a singular or wildly conditioned pair in the group) falls back to
-        // four separate reciprocals; the fast variant lets it poison the sum instead
-        if (!EXACT || (fabs(p0123) > 1e-250 && fabs(p0123) < 1e250)) {
+        // a product outside the normal range (a singular or wildly conditioned pair in the group) falls back to
+        // four separate reciprocals
+        if (fabs(p0123) > 1e-250 && fabs(p0123) < 1e250) {
             double run = rcp_nr2(p0123);
             inv[3] = run * p012;
             run *= det[3];
@@ -133,70 +216,58 @@ __device__ __forceinline__ double candidate_chunk_sum(const RayRec *__restrict__
         for (int u = 0; u < 4; u++) finish(a[u], b[u], bq[u], e[u], g[u], inv[u], sm[u], ss[u]);
     }
     for (; jj < nj; jj++) {
-        const RayRec a = ra[jj], b = rb[jj];
+        const RayRec a = p1_load_ray(ra + jj * jstr), b = p1_load_ray(rb + jj * jstr);
         const double bq = fma(a.z, b.z, fma(a.y, b.y, a.x * b.x));
         const double e = fma(a.z, d.z, fma(a.y, d.y, a.x * d.x));
         const double g = fma(b.z, d.z, fma(b.y, d.y, b.x * d.x));
         const double det = fma(a.a, b.a, -(bq * bq));
-        if (EXACT) sing |= det == 0.0;
-        finish(a, b, bq, e, g, rcp_nr2(det), sa[jj], sb[jj]);
+        sing |= det == 0.0;
+        finish(a, b, bq, e, g, rcp_nr2(det), p1_load_score<TIn>(ra + jj * jstr), p1_load_score<TIn>(rb + jj * jstr));
     }
     return acc;
 }
 
-// ---- the fast phase-1 arithmetic for GS candidates that share their FIRST ray: one person of camera m against GS
-// persons of camera s.  The first ray, its score and e = h_m . d are read / computed once per joint instead of once per
-// candidate (LDS reads per solve 6 -> 3.75 at GS = 4), and the GS solves of a joint share one reciprocal, so any joint
-// count works without a tail.  The lane walks joints jsub, jsub + JS, ...; acc[u] += 2000 x score of candidate u.
-// Same solves, gates and raw 1/sqrt as candidate_chunk_sum<false>: the caller's re-do rule applies unchanged.
+// ---- the fast phase-1 arithmetic: GS candidates that share their FIRST ray -- one person of camera m against GS
+// consecutive persons of camera s -- over the joints [0, nj) of a chunk; acc[u] += 2000 x score of candidate u (:72-74).
+//
+// What phase 1 needs of a pair solve is only the DISTANCE of the two rays (the 3D point is needed for the centre joint
+// and for the candidates that survive: phase 2 / phase 3).  For rays t_m + S0 a and t_s - S1 b the closest approach the
+// reference computes with its 2x2 solve (triangulation.py:24-31) is the distance of two skew lines:
+//     dist = |d . (a x b)| / |a x b|,      d = t_s - t_m,    |a x b|^2 = |a|^2 |b|^2 - (a.b)^2 = det(H^T H).
+// With c = d x a per FIRST ray (shared by the GS candidates): d . (a x b) = c . b, so a solve is two dot products, the
+// determinant, and ONE transcendental:  1/dist = det * rsq((c.b)^2 det)  -- 20 VALU instead of 41, no reciprocal
+// of the determinant, nothing shared between joints (any joint count, no tail).  Conditioning: c.b cancels to
+// dist |a x b| from terms of size |d| |a| |b|, i.e. a relative error of 1e-16 |d| / dist ~ 5e-13 at 1 mm -- the reference's own
+// ||Wm - Ws|| cancels from 5 m coordinates to the same distance (1e-12).
+// The distance gate dist > dthr (:74) is taken on accurately rounded products, (c.b)^2 det > dthr^2 det^2 (both sides
+// x det > 0); a determinant that is 0, negative (rounding of nearly parallel rays) or NaN fails that test, so its
+// 0 x inf / rsq(< 0) reaches the sum as NaN, an exact intersection as inf -- and a sum that is not finite is re-done by
+// candidate_chunk_sum_exact, which also flags singular pairs.  The raw v_rsq_f64 (measured 2^-24.2 relative) only scales a
+// score: the caller re-does candidates whose mean lies within 1e-6 of average_score_threshold (:79-81).
+//   pa: record of the first ray's row, pb: record of the FIRST of the GS second rows (rows are kP1Rec bytes apart)
 template <int GS, typename TIn>
-__device__ __forceinline__ void rowgroup_chunk_sums(const RayRec *__restrict__ ra, const TIn *__restrict__ sa,
-                                                    const RayRec *const (&rb)[GS], const TIn *const (&sb)[GS], int jsub, int JS,
-                                                    int nj, const Vec3 &d, const Params &prm, double (&acc)[GS]) {
-    for (int jj = jsub; jj < nj; jj += JS) {
-        const RayRec a = ra[jj];
-        const TIn sm = sa[jj];
-        const double e = fma(a.z, d.z, fma(a.y, d.y, a.x * d.x));
-        const bool okm = !below_kthr(sm, prm);
+__device__ __forceinline__ void p1_item_sums(const char *__restrict__ pa, const char *__restrict__ pb, int jstr, int nj,
+                                             const Vec3 &d, const Params &prm, double (&acc)[GS]) {
+    for (int t = 0; t < nj; t++, pa += jstr, pb += jstr) {
+        const RayRec a = p1_load_ray(pa);
+        const TIn sm = p1_load_score<TIn>(pa);
         RayRec b[GS];
         TIn ss[GS];
-        double bq[GS], g[GS], det[GS], inv[GS];
 #pragma unroll
         for (int u = 0; u < GS; u++) {
-            b[u] = rb[u][jj];
-            ss[u] = sb[u][jj];
+            b[u] = p1_load_ray(pb + kP1Rec * u);
+            ss[u] = p1_load_score<TIn>(pb + kP1Rec * u);
         }
+        const double cx = fma(d.y, a.z, -(d.z * a.y)), cy = fma(d.z, a.x, -(d.x * a.z)), cz = fma(d.x, a.y, -(d.y * a.x));
+        const bool okm = !below_kthr(sm, prm);
 #pragma unroll
         for (int u = 0; u < GS; u++) {
-            bq[u] = fma(a.z, b[u].z, fma(a.y, b[u].y, a.x * b[u].x));
-            g[u] = fma(b[u].z, d.z, fma(b[u].y, d.y, b[u].x * d.x));
-            det[u] = fma(a.a, b[u].a, -(bq[u] * bq[u]));
-        }
-        // one reciprocal for the GS determinants; a singular pair poisons the group's sums (NaN): re-done exactly
-        if constexpr (GS == 4) {
-            const double p01 = det[0] * det[1], p012 = p01 * det[2];
-            double run = rcp_nr2(p012 * det[3]);
-            inv[3] = run * p012;
-            run *= det[3];
-            inv[2] = run * p01;
-            run *= det[2];
-            inv[1] = run * det[0];
-            inv[0] = run * det[1];
-        } else {
-            static_assert(GS == 2, "groups of two or four persons");
-            const double run = rcp_nr2(det[0] * det[1]);
-            inv[0] = run * det[1];
-            inv[1] = run * det[0];
-        }
-#pragma unroll
-        for (int u = 0; u < GS; u++) {
-            const double S0 = fma(b[u].a, e, -(bq[u] * g[u])) * inv[u];
-            const double S1 = fma(a.a, g[u], -(bq[u] * e)) * inv[u];
-            const double fx = fma(b[u].x, S1, fma(a.x, S0, -d.x)), fy = fma(b[u].y, S1, fma(a.y, S0, -d.y)),
-                         fz = fma(b[u].z, S1, fma(a.z, S0, -d.z));
-            const double d2 = fma(fz, fz, fma(fy, fy, fx * fx));
-            const bool kp_ = okm && !below_kthr(ss[u], prm) && !(d2 > prm.dthr2);   // :73-74
-            acc[u] = fma(gated_sum(sm, ss[u], kp_), __builtin_amdgcn_rsq(d2), acc[u]);
+            const double bq = fma(a.z, b[u].z, fma(a.y, b[u].y, a.x * b[u].x));
+            const double det = fma(a.a, b[u].a, -(bq * bq));
+            const double dn = fma(cz, b[u].z, fma(cy, b[u].y, cx * b[u].x));
+            const double x = (dn * dn) * det;
+            const bool kp_ = okm && !below_kthr(ss[u], prm) && !(x > (det * det) * prm.dthr2);   // :73-74
+            acc[u] = fma(gated_sum(sm, ss[u], kp_), det * __builtin_amdgcn_rsq(x), acc[u]);
         }
     }
 }
@@ -235,22 +306,37 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
     const int tid = threadIdx.x, lane = tid & 63;
     const int C = rig.C, R = C * Pmax, pp = Pmax * Pmax;
     const int kn = prm.kn, ci = prm.center;
-    const int Jc = recompute_chunk_joints(R, J, (int)sizeof(TIn));
-    const int rstride = (int)recompute_ray_stride(Jc);          // bytes between the ray rows (32-bit LDS offsets)
-    const int sstride = recompute_score_stride(Jc);             // elements between the score rows
-    char *rays = smem;                                          // [R] rows of Jc RayRec (+16 B pad)
-    TIn *rsc = reinterpret_cast<TIn *>(smem + (size_t)R * rstride);                      // [R][sstride]
-    double *red = reinterpret_cast<double *>(smem + kRayChunkBytes);  // [4] + misc, at a fixed offset behind the chunk
+    // ---- LDS map (see the top of this file)
+    double *red = reinterpret_cast<double *>(smem);             // [4] + misc
     int32_t *misc = reinterpret_cast<int32_t *>(red + kBlock / 64);
     // camera-pair constants in LDS: d = t_s - t_m, t_m + t_s (6 doubles) and the two camera indices -- the solve loops
     // index them per lane (host-checked: npairs <= kPairTabMaxPairs, i.e. <= 16 cameras; larger rigs take k_frame_general)
-    double *pairc = reinterpret_cast<double *>(reinterpret_cast<char *>(red) + 256);
+    double *pairc = reinterpret_cast<double *>(smem + 256);
     int32_t *pairs = reinterpret_cast<int32_t *>(pairc + 6 * rig.npairs);
+    double *Ml = reinterpret_cast<double *>(pairs + 2 * rig.npairs);    // [C][9] ray matrices (per-lane camera in the fill)
     for (int i = tid; i < 6 * rig.npairs; i += kBlock) pairc[i] = rig.pairc[i];
     for (int i = tid; i < 2 * rig.npairs; i += kBlock) pairs[i] = rig.pairs[i];
-    // what is left of the workgroup's LDS allocation holds the member words of phase 3
-    uint32_t *lmem_lds = reinterpret_cast<uint32_t *>(pairs + 2 * rig.npairs);
-    const int lmem_cap = (int)((lds_total - (int)(reinterpret_cast<char *>(lmem_lds) - smem)) / 4);
+    for (int i = tid; i < 9 * C; i += kBlock) Ml[i] = rig.M[i];
+    const int arena_off = (int)recompute_arena_offset(C, rig.npairs);
+    char *arena = smem + arena_off;
+    const int arena_bytes = lds_total - arena_off;
+    // phase-3 chunk geometry (row-major rays + scores, <= kRayChunkBytes); what the arena has left behind it holds the
+    // member words of phase 3
+    const int Jc = recompute_chunk_joints(R, J, (int)sizeof(TIn));
+    const int rstride = (int)recompute_ray_stride(Jc);          // bytes between the ray rows (32-bit LDS offsets)
+    const int sstride = recompute_score_stride(Jc);             // elements between the score rows
+    char *rays = arena;                                         // [R] rows of Jc RayRec (+16 B pad)
+    TIn *rsc = reinterpret_cast<TIn *>(arena + (size_t)R * rstride);                     // [R][sstride]
+    uint32_t *lmem_lds = reinterpret_cast<uint32_t *>(arena + kRayChunkBytes);
+    const int lmem_cap = arena_bytes > kRayChunkBytes ? (arena_bytes - kRayChunkBytes) / 4 : 0;
+    // phase-1 geometry (joint-major records)
+    const int gs_full = p1_group_size(Pmax);                    // candidates per item when every camera lists Pmax persons
+    const int sum_bytes = p1_sum_bytes(rig.npairs, Pmax);
+    double *lsum = reinterpret_cast<double *>(arena);           // [JS][Kc] raw score sums of phase 1, if sum_bytes != 0
+    char *p1rec = arena + sum_bytes;
+    const int jstr = p1_joint_stride(R);
+    const int Jc1 = p1_chunk_joints(R, J, arena_bytes, sum_bytes);
+    const unsigned long long magic_pmax = (((unsigned long long)1 << 40) + (unsigned)Pmax - 1) / (unsigned)Pmax;
     const bool exact_only = prm.kthr < 0.0;   // negative scores may pass the keypoint gate: no relative error bound on a sum
 
     // per-workgroup bookkeeping slab (global, reused frame after frame)
@@ -288,7 +374,6 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
         const Kp3<TIn> *kpf = kp3 + f * (int64_t)R * J;
         bool ragged = false;
         for (int k = tid; k < Kc; k += kBlock) {
-            sum[k] = 0.0;
             // candidate order of triangulation.py:56-65: camera pair, person of the first camera, person of the second
             const int q = k / pp, rr = k - q * pp, pm = rr / Pmax, ps = rr - pm * Pmax;
             const int mc = pairs[2 * q], sc = pairs[2 * q + 1];
@@ -299,118 +384,128 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
         }
         if (tid == 0 && out_flags) out_flags[f] = 0u;
         bool sing = false;
-        // every camera lists Pmax persons (and Pmax is even): phase 1 runs on groups of candidates that share their
-        // first ray (rowgroup_chunk_sums); a ragged frame keeps one lane per candidate
-        const int GS = (Pmax & 3) == 0 ? 4 : ((Pmax & 1) == 0 ? 2 : 0);
-        const bool grouped = !exact_only && GS != 0 && !__syncthreads_or(ragged ? 1 : 0);
+        // every camera lists Pmax persons: phase 1 runs on groups of GS candidates that share their first ray; a ragged
+        // frame (or an odd Pmax) keeps one candidate per lane.  (The barrier also orders cw[] before its readers.)
+        const int GS = __syncthreads_or(ragged ? 1 : 0) ? 1 : gs_full;
+        const int NG = Pmax / GS, per_q = Pmax * NG, nitems = rig.npairs * per_q;
+        const int JS = sum_bytes ? p1_joint_split(Kc / gs_full) : 1;   // (the sums' LDS is sized for the full-frame split)
+        const int wpg = (kBlock / 64) / JS;                            // waves that share a joint sub-range
+        const int wv = tid >> 6, jsub = wv / wpg, iw = wv - jsub * wpg;
+        // raw sums (2000 x the score of :72), [JS][Kc]: in LDS if they fit, else in the slab (two explicit address
+        // spaces: a generic pointer costs flat accesses and 64-bit address arithmetic)
+        const bool acc_lds = sum_bytes != 0;
+        auto acc_get = [&](int idx) -> double { return acc_lds ? lsum[idx] : sum[idx]; };
+        auto acc_put = [&](int idx, double v) {
+            if (acc_lds)
+                lsum[idx] = v;
+            else
+                sum[idx] = v;
+        };
+        for (int k = tid; k < (acc_lds ? JS * Kc : Kc); k += kBlock) acc_put(k, 0.0);
 
         // ---------------- phase 1: candidate score sums, joint chunk by joint chunk -------------
-        for (int j0 = 0; j0 < J; j0 += Jc) {
-            const int nj = (J - j0) < Jc ? (J - j0) : Jc;
+        for (int j0 = 0; j0 < J; j0 += Jc1) {
+            const int nj = (J - j0) < Jc1 ? (J - j0) : Jc1;
+            const unsigned long long magic_nj = (((unsigned long long)1 << 40) + (unsigned)nj - 1) / (unsigned)nj;
             __syncthreads();
+            // fill: one record per (ray row, joint of the chunk); lanes = consecutive joints of a row (coalesced reads)
             for (int i = tid; i < R * nj; i += kBlock) {
-                const int r = i / nj, jj = i - r * nj;
-                const int c = r / Pmax, p = r - c * Pmax;
+                const int r = (int)(((unsigned long long)(unsigned)i * magic_nj) >> 40), jj = i - r * nj;
+                const int c = (int)(((unsigned long long)(unsigned)r * magic_pmax) >> 40), p = r - c * Pmax;
                 const int nc = np_f ? np_f[c] : Pmax;
                 if (p < nc) {
                     const Kp3<TIn> kp = kpf[(size_t)r * J + j0 + jj];
-                    *reinterpret_cast<RayRec *>(rays + r * rstride + 32 * jj) = make_ray(rig.M + 9 * c, kp.u, kp.v);
-                    rsc[r * sstride + jj] = kp.s;
+                    p1_store_record<TIn>(p1rec + jj * jstr + kP1Rec * r, make_ray(Ml + 9 * c, kp.u, kp.v), kp.s);
                 }
             }
             __syncthreads();
-            if (grouped) {
-                // item = (camera pair q, person pm of its first camera, group of GS persons of its second); JS lanes
-                // share an item (interleaved joints) when there are fewer items than threads
-                const int NG = Pmax / GS, per_q = Pmax * NG, nitems = rig.npairs * per_q;
-                int JS = 1;
-                while (JS < 8 && 2 * JS * nitems <= kBlock) JS *= 2;
-                const int total = nitems * JS;
-                for (int base = 0; base < total; base += kBlock) {   // same trip count for every lane: shuffles below
-                    const int idx = base + tid;
-                    const bool live = idx < total;
-                    const int item = live ? idx / JS : 0, jsub = live ? idx - item * JS : 0;
-                    const int q = item / per_q, r2 = item - q * per_q, pm = r2 / NG, ps0 = (r2 - pm * NG) * GS;
-                    const int k0 = q * pp + pm * Pmax + ps0;
-                    const int rm = pairs[2 * q] * Pmax + pm, rs0 = pairs[2 * q + 1] * Pmax + ps0;
-                    const double *pc = pairc + 6 * q;
-                    const Vec3 d = {pc[0], pc[1], pc[2]};
-                    const RayRec *ra = reinterpret_cast<const RayRec *>(rays + rm * rstride);
-                    const TIn *sa = rsc + rm * sstride;
-                    const int njl = live ? nj : 0;
-                    if (GS == 4) {
-                        const RayRec *const rb[4] = {reinterpret_cast<const RayRec *>(rays + (rs0 + 0) * rstride),
-                                                     reinterpret_cast<const RayRec *>(rays + (rs0 + 1) * rstride),
-                                                     reinterpret_cast<const RayRec *>(rays + (rs0 + 2) * rstride),
-                                                     reinterpret_cast<const RayRec *>(rays + (rs0 + 3) * rstride)};
-                        const TIn *const sb[4] = {rsc + (rs0 + 0) * sstride, rsc + (rs0 + 1) * sstride, rsc + (rs0 + 2) * sstride,
-                                                  rsc + (rs0 + 3) * sstride};
-                        double acc[4] = {0.0, 0.0, 0.0, 0.0};
-                        rowgroup_chunk_sums<4>(ra, sa, rb, sb, jsub, JS, njl, d, prm, acc);
-#pragma unroll
-                        for (int u = 0; u < 4; u++) {
-                            double v = acc[u];
-                            for (int off = JS >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-                            if (live && jsub == 0) sum[k0 + u] += v * 0.0005;   // the 1 / (2 * 1000) of :72
-                        }
-                    } else {
-                        const RayRec *const rb[2] = {reinterpret_cast<const RayRec *>(rays + (rs0 + 0) * rstride),
-                                                     reinterpret_cast<const RayRec *>(rays + (rs0 + 1) * rstride)};
-                        const TIn *const sb[2] = {rsc + (rs0 + 0) * sstride, rsc + (rs0 + 1) * sstride};
-                        double acc[2] = {0.0, 0.0};
-                        rowgroup_chunk_sums<2>(ra, sa, rb, sb, jsub, JS, njl, d, prm, acc);
-#pragma unroll
-                        for (int u = 0; u < 2; u++) {
-                            double v = acc[u];
-                            for (int off = JS >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-                            if (live && jsub == 0) sum[k0 + u] += v * 0.0005;
-                        }
-                    }
-                }
-            } else {
+            if (exact_only) {
                 for (int k = tid; k < Kc; k += kBlock) {
                     const uint32_t w = cw[k];
                     if (w == kNoCand) continue;
                     const int rm = (int)(w & 1023u), rs = (int)((w >> 10) & 1023u), q = (int)(w >> 20);
                     const double *pc = pairc + 6 * q;
                     const Vec3 d = {pc[0], pc[1], pc[2]};
-                    const RayRec *ra = reinterpret_cast<const RayRec *>(rays + rm * rstride);
-                    const RayRec *rb = reinterpret_cast<const RayRec *>(rays + rs * rstride);
-                    const TIn *sa = rsc + rm * sstride, *sb = rsc + rs * sstride;
-                    const double acc = exact_only ? candidate_chunk_sum<true>(ra, rb, sa, sb, nj, d, prm, sing)
-                                                  : candidate_chunk_sum<false>(ra, rb, sa, sb, nj, d, prm, sing);
-                    sum[k] += acc * 0.0005;   // the 1 / (2 * 1000) of :72
+                    acc_put(k, acc_get(k) + candidate_chunk_sum_exact<TIn>(p1rec + kP1Rec * rm, p1rec + kP1Rec * rs, jstr, nj, d, prm, sing));
+                }
+            } else {
+                // the waves of joint sub-range jsub walk joints [jlo, jhi) of the chunk; item = base + lane of the round
+#ifdef SNOWTRI_P1_NOSOLVE   // dev experiment (timing only, outputs are wrong): phase 1 without its solves
+                const int jlo = 0, jhi = 0;
+#else
+                const int jlo = jsub * nj / JS, jhi = (jsub + 1) * nj / JS;
+#endif
+                const unsigned long long magic_pq = (((unsigned long long)1 << 40) + (unsigned)per_q - 1) / (unsigned)per_q;
+                const unsigned long long magic_ng = (((unsigned long long)1 << 40) + (unsigned)NG - 1) / (unsigned)NG;
+                for (int base = iw * 64; base < nitems; base += wpg * 64) {
+                    const int item = base + lane;
+                    const bool live = item < nitems;
+                    const int it = live ? item : 0;
+                    const int q = (int)(((unsigned long long)(unsigned)it * magic_pq) >> 40), r2 = it - q * per_q;
+                    const int pm = (int)(((unsigned long long)(unsigned)r2 * magic_ng) >> 40), ps0 = (r2 - pm * NG) * GS;
+                    const int k0 = q * pp + pm * Pmax + ps0;
+                    const int rm = pairs[2 * q] * Pmax + pm, rs0 = pairs[2 * q + 1] * Pmax + ps0;
+                    const double *pc = pairc + 6 * q;
+                    const Vec3 d = {pc[0], pc[1], pc[2]};
+                    const char *pa = p1rec + jlo * jstr + kP1Rec * rm, *pb = p1rec + jlo * jstr + kP1Rec * rs0;
+                    const int dst = jsub * Kc + k0;
+                    if (GS == 4) {
+                        double old[4], acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int u = 0; u < 4; u++) old[u] = live ? acc_get(dst + u) : 0.0;   // (in flight during the solves)
+                        p1_item_sums<4, TIn>(pa, pb, jstr, live ? jhi - jlo : 0, d, prm, acc);
+                        if (live) {
+#pragma unroll
+                            for (int u = 0; u < 4; u++) acc_put(dst + u, old[u] + acc[u]);
+                        }
+                    } else if (GS == 2) {
+                        double old[2], acc[2] = {0.0, 0.0};
+#pragma unroll
+                        for (int u = 0; u < 2; u++) old[u] = live ? acc_get(dst + u) : 0.0;
+                        p1_item_sums<2, TIn>(pa, pb, jstr, live ? jhi - jlo : 0, d, prm, acc);
+                        if (live) {
+#pragma unroll
+                            for (int u = 0; u < 2; u++) acc_put(dst + u, old[u] + acc[u]);
+                        }
+                    } else {
+                        const bool cand = live && cw[k0] != kNoCand;   // a ragged frame's empty slots stay at sum 0
+                        double acc[1] = {0.0};
+                        const double old = cand ? acc_get(dst) : 0.0;
+                        p1_item_sums<1, TIn>(pa, pb, jstr, cand ? jhi - jlo : 0, d, prm, acc);
+                        if (cand) acc_put(dst, old + acc[0]);
+                    }
                 }
             }
         }
-        // candidates whose fast sum cannot decide :80-81 (see candidate_chunk_sum): not finite, or within 1e-6 relative
-        // of average_score_threshold (the fast sum is within 2.4e-7 of the accurate one).  Rare: a second sweep over the
-        // joint chunks re-does just those with the accurate arithmetic; exactly singular pairs are flagged there.
+        // the 1 / (2 * 1000) of :72 and the JS partial sums of a candidate; then the candidates whose fast sum cannot
+        // decide :80-81 (see p1_item_sums): not finite, or within 1e-6 relative of average_score_threshold (the fast sum
+        // is within 2.4e-7 of the accurate one).  Rare: a second sweep over the joint chunks re-does just those with the
+        // accurate arithmetic; exactly singular pairs are flagged there.  (Thread tid owns slots tid, tid + 256, ... in
+        // every loop below.)
+        __syncthreads();
         int redo_any = 0;
-        if (!exact_only) {
-            __syncthreads();
-            for (int k = tid; k < Kc; k += kBlock) {
-                const double s_ = sum[k], mean = s_ / (double)J;
-                const bool redo = !(fabs(mean) < 1e300) || (s_ != 0.0 && fabs(mean - prm.avg_thr) <= 1e-6 * fabs(mean));
-                keep[k] = redo ? 2 : 0;      // (invalid slots hold sum 0: never re-done)
-                redo_any |= redo ? 1 : 0;
-            }
-            redo_any = __syncthreads_or(redo_any);
+        for (int k = tid; k < Kc; k += kBlock) {
+            double v = acc_get(k);
+            for (int s_ = 1; s_ < JS; s_++) v += acc_get(s_ * Kc + k);
+            const double s_ = v * 0.0005, mean = s_ / (double)J;
+            const bool redo = !exact_only && (!(fabs(mean) < 1e300) || (s_ != 0.0 && fabs(mean - prm.avg_thr) <= 1e-6 * fabs(mean)));
+            sum[k] = redo ? 0.0 : s_;
+            keep[k] = redo ? 2 : 0;      // (invalid slots hold sum 0: never re-done)
+            redo_any |= redo ? 1 : 0;
         }
+        redo_any = __syncthreads_or(redo_any);   // (also: the sums in the arena are consumed)
         if (redo_any) {
-            for (int k = tid; k < Kc; k += kBlock)
-                if (keep[k] == 2) sum[k] = 0.0;
-            for (int j0 = 0; j0 < J; j0 += Jc) {
-                const int nj = (J - j0) < Jc ? (J - j0) : Jc;
+            for (int j0 = 0; j0 < J; j0 += Jc1) {
+                const int nj = (J - j0) < Jc1 ? (J - j0) : Jc1;
+                const unsigned long long magic_nj = (((unsigned long long)1 << 40) + (unsigned)nj - 1) / (unsigned)nj;
                 __syncthreads();
                 for (int i = tid; i < R * nj; i += kBlock) {
-                    const int r = i / nj, jj = i - r * nj;
-                    const int c = r / Pmax, p = r - c * Pmax;
+                    const int r = (int)(((unsigned long long)(unsigned)i * magic_nj) >> 40), jj = i - r * nj;
+                    const int c = (int)(((unsigned long long)(unsigned)r * magic_pmax) >> 40), p = r - c * Pmax;
                     const int nc = np_f ? np_f[c] : Pmax;
                     if (p < nc) {
                         const Kp3<TIn> kp = kpf[(size_t)r * J + j0 + jj];
-                        *reinterpret_cast<RayRec *>(rays + r * rstride + 32 * jj) = make_ray(rig.M + 9 * c, kp.u, kp.v);
-                        rsc[r * sstride + jj] = kp.s;
+                        p1_store_record<TIn>(p1rec + jj * jstr + kP1Rec * r, make_ray(Ml + 9 * c, kp.u, kp.v), kp.s);
                     }
                 }
                 __syncthreads();
@@ -420,11 +515,11 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
                     const int rm = (int)(w & 1023u), rs = (int)((w >> 10) & 1023u), q = (int)(w >> 20);
                     const double *pc = pairc + 6 * q;
                     const Vec3 d = {pc[0], pc[1], pc[2]};
-                    sum[k] += candidate_chunk_sum<true>(reinterpret_cast<const RayRec *>(rays + rm * rstride),
-                                                        reinterpret_cast<const RayRec *>(rays + rs * rstride), rsc + rm * sstride,
-                                                        rsc + rs * sstride, nj, d, prm, sing) * 0.0005;
+                    sum[k] += candidate_chunk_sum_exact<TIn>(p1rec + kP1Rec * rm, p1rec + kP1Rec * rs, jstr, nj, d, prm, sing);
                 }
             }
+            for (int k = tid; k < Kc; k += kBlock)
+                if (keep[k] == 2) sum[k] *= 0.0005;
         }
         __syncthreads();
         if (sing && out_flags) atomicOr(&out_flags[f], 1u /*SNOWTRI_FLAG_SINGULAR*/);
@@ -457,15 +552,14 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
         // The clustering below is one wave walking the kept list: every step is a dependent load, so it runs
         // at memory LATENCY.  While it runs the ray chunk is idle: if the centres (24 B) and cluster ids (4 B) of
         // the n kept candidates fit there they live in LDS (~8x lower latency than the L2-resident slab).
-        const size_t chunk_bytes = (size_t)kRayChunkBytes;
-        const bool in_lds = (size_t)n * 28 + 16 <= chunk_bytes;
+        const bool in_lds = (size_t)n * 28 + 16 <= (size_t)arena_bytes;
         auto phase2 = [&](int32_t *cof, double *cen) {
             for (int i = tid; i < n; i += kBlock) {
                 const uint32_t w = cw[kidx[i]];
                 const int rm = (int)(w & 1023u), rs = (int)((w >> 10) & 1023u), q = (int)(w >> 20);
                 const int mc = pairs[2 * q], sc = pairs[2 * q + 1];
                 const Kp3<TIn> km = kpf[(size_t)rm * J + ci], ks = kpf[(size_t)rs * J + ci];
-                const RayRec a = make_ray(rig.M + 9 * mc, km.u, km.v), b = make_ray(rig.M + 9 * sc, ks.u, ks.v);
+                const RayRec a = make_ray(Ml + 9 * mc, km.u, km.v), b = make_ray(Ml + 9 * sc, ks.u, ks.v);
                 const double *pc = pairc + 6 * q;
                 const PairSolve o = pair_solve_fast<true>(a, b, Vec3{pc[0], pc[1], pc[2]}, Vec3{pc[3], pc[4], pc[5]});
                 cen[3 * i] = 0.5 * o.sw.x;
@@ -530,7 +624,7 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
             }
         };
         if (in_lds)
-            phase2(reinterpret_cast<int32_t *>(smem + (((size_t)n * 24 + 15) & ~(size_t)15)), reinterpret_cast<double *>(smem));
+            phase2(reinterpret_cast<int32_t *>(arena + (((size_t)n * 24 + 15) & ~(size_t)15)), reinterpret_cast<double *>(arena));
         else
             phase2(cluster_of, centre);
         __syncthreads();
@@ -630,11 +724,11 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
             if constexpr (sizeof(TOut) == 4) {
                 if (desc != nullptr) {
                     const size_t pq = ((size_t)Pout * 4 + 15) & ~(size_t)15;
-                    uint32_t *st_a = reinterpret_cast<uint32_t *>(smem);            // [Pout] persons word | first member (cstart)
-                    int32_t *st_size = reinterpret_cast<int32_t *>(smem + pq);      // [Pout] 0: complete graph, else members
-                    uint32_t *st_idx = reinterpret_cast<uint32_t *>(smem + 2 * pq);  // [Pout] index inside its descriptor list
-                    uint32_t *st_word = reinterpret_cast<uint32_t *>(smem + 3 * pq); // [Pout] offset of its member words
-                    double *st_avg = reinterpret_cast<double *>(smem + 4 * pq);     // [Pout]
+                    uint32_t *st_a = reinterpret_cast<uint32_t *>(arena);            // [Pout] persons word | first member (cstart)
+                    int32_t *st_size = reinterpret_cast<int32_t *>(arena + pq);      // [Pout] 0: complete graph, else members
+                    uint32_t *st_idx = reinterpret_cast<uint32_t *>(arena + 2 * pq);  // [Pout] index inside its descriptor list
+                    uint32_t *st_word = reinterpret_cast<uint32_t *>(arena + 3 * pq); // [Pout] offset of its member words
+                    double *st_avg = reinterpret_cast<double *>(arena + 4 * pq);     // [Pout]
                     // the clusters' sizes / starts, member words and candidate score sums, fetched by the whole workgroup at
                     // once: the decisions below are then one wave walking LDS (from the L2-resident slab every step is a
                     // chain of dependent loads: 15 us per frame)
@@ -643,7 +737,7 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
                     uint32_t *l_word = reinterpret_cast<uint32_t *>(l_sum + nmem);   // [nmem]
                     int32_t *l_size = reinterpret_cast<int32_t *>(l_word + nmem);    // [ncl]
                     int32_t *l_start = l_size + ncl;                                 // [ncl]
-                    const bool fits = 4 * pq + (size_t)Pout * 8 + (size_t)nmem * 12 + (size_t)ncl * 8 <= (size_t)kRayChunkBytes;
+                    const bool fits = 4 * pq + (size_t)Pout * 8 + (size_t)nmem * 12 + (size_t)ncl * 8 <= (size_t)arena_bytes;
                     if (fits) {
                         for (int pos = tid; pos < nmem; pos += kBlock) {
                             const int k = kidx[members[pos]];
@@ -800,7 +894,7 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
                         const int nc = np_f ? np_f[c] : Pmax;
                         if (p < nc) {
                             const Kp3<TIn> kp = kpf[(size_t)r * J + j0 + jj];
-                            *reinterpret_cast<RayRec *>(rays + r * rstride + 32 * jj) = make_ray(rig.M + 9 * c, kp.u, kp.v);
+                            *reinterpret_cast<RayRec *>(rays + r * rstride + 32 * jj) = make_ray(Ml + 9 * c, kp.u, kp.v);
                             rsc[r * sstride + jj] = kp.s;
                         }
                     }
