@@ -47,6 +47,8 @@ for cfg, F, pout in SIZES:
                           "pair_solves_per_s": F * kc * J / (m * 1e-3), "mean_persons": float(cnt.mean())}))
         bt.close()
     os.environ.pop("SNOWTRI_GENERAL_MODE", None)
+    if "--no-oracle" in sys.argv:
+        continue
     nf = 8 if cfg == 3 else 2
     t0 = time.perf_counter()
     ref = orc.triangulate_condense_batch(K, R, t, wl["kpts"][:nf], wl["n_persons"][:nf], orc.make_params(**wl["params"]), pout, nthreads=1)

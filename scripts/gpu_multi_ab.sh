@@ -5,9 +5,9 @@ mkdir -p gpurun_out/multi
 if [ "$1" != "notest" ]; then
   timeout 1200 python -m pytest tests/test_gpu_parity.py tests/test_gpu_shard_sizes.py tests/test_gpu_handover.py -x -q -m gpu > gpurun_out/multi/tests.log 2>&1; echo "tests rc=$?"; tail -15 gpurun_out/multi/tests.log
 fi
-for hm in 1 0; do
+for hm in 1 2 0; do
   echo "== SNOWTRI_HANDOVER_MODE=$hm"
-  SNOWTRI_HANDOVER_MODE=$hm python scripts/bench_configs.py --full 2>&1 | grep "^{" | python -c "
+  SNOWTRI_HANDOVER_MODE=$hm python scripts/bench_configs.py --full --no-oracle 2>&1 | grep "^{" | python -c "
 import sys, json
 for ln in sys.stdin:
     d = json.loads(ln)

@@ -12,5 +12,5 @@ for ln in sys.stdin:
 for so in snowmocap_amd/libsnowtri.so snowmocap_amd/csrc/ab/libsnowtri_*.so; do
   [ -f "$so" ] || continue
   echo "== $so"
-  for c in $CFGS; do SNOWTRI_LIB=$PWD/$so python scripts/bench_configs.py --full --only=$c 2>&1 | show; done
+  for c in $CFGS; do SNOWTRI_LIB=$PWD/$so python scripts/bench_configs.py --full --no-oracle --only=$c 2>&1 | show; done
 done

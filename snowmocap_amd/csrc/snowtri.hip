@@ -20,6 +20,7 @@
 #include "snowtri_lean.hpp"
 #include "snowtri_cluster.hpp"
 #include "snowtri_general.hpp"
+#include "snowtri_assoc.hpp"
 #include "snowtri_smooth.hpp"
 #include "snowtri_blender.hpp"
 #include "snowtri_undistort.hpp"
@@ -126,7 +127,8 @@ struct snowtri_ctx {
     double *dM = nullptr, *dt = nullptr, *dpairc = nullptr, *dP = nullptr;
     int32_t *dpairs = nullptr;
     unsigned long long *d_counters = nullptr;  // [0] singular pairs, [1] slow frames, [2..] spare
-    Scratch in, out, work, misc, aux, desc;   // desc: cluster descriptors handed from k_frame_recompute to k_cluster_fuse
+    Scratch in, out, work, misc, aux, desc;   // desc: cluster descriptors handed from k_frame_recompute / k_associate to k_cluster_fuse
+    Scratch sums;                             // candidate sums of k_candidate_sums [frames][Kc] + the frames k_associate left behind
     // measurement
     bool timing = false;
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -138,7 +140,16 @@ struct snowtri_ctx {
     bool last_handover = false;  // the last fused call went through k_frame_recompute with the cluster hand-over armed
     int general_mode = 0;  // dev/test knob: 0 auto, 1 force the spill kernel, 2 force the recompute kernel
     int lean_mode = 1;     // dev/test knob: 0 keeps float32-output batches on k_fused_single (A/B against k_fused_lean)
-    int handover_mode = 1; // dev/test knob: 0 keeps phase 3 of the multi-person path inside k_frame_recompute (A/B against k_cluster_fuse)
+    int handover_mode = 1; // dev/test knob: 1 streaming association (k_candidate_sums / k_associate / k_cluster_fuse), 2 hand-over from
+                           // inside k_frame_recompute, 0 the whole multi-person path inside k_frame_recompute
+    int sums_threads = 0, sums_lds_kb = 0, assoc_wg_per_cu = 16;   // dev knobs of the streaming association (0: automatic)
+    int recompute_wg_per_cu = 0, cluster_ppw = 24, debug = 0;
+    int tile_frames = 0, lean_wg_per_cu = 2, lean_tiles_per_wave = 0, lean_scratch_mb = 256, handover_seg_frames = 0;   // dev / test knobs
+    struct OccCache {
+        size_t lds = 0;
+        int per_cu = -1;
+    } recompute_occ[8];   // resident workgroups per CU of the k_frame_recompute instantiations (queried once per LDS size)
+    int64_t last_stream_slow = -1;   // frames the streaming association left to k_frame_recompute in the last call (-1: not used)
     Rig rig() const { return Rig{dM, dt, dpairs, dpairc, dP, C, npairs}; }
 };
 
@@ -179,6 +190,18 @@ int snowtri_ctx_create(int32_t C, const double *K, const double *R, const double
     if (const char *gm = getenv("SNOWTRI_GENERAL_MODE")) ctx->general_mode = atoi(gm);
     if (const char *lm = getenv("SNOWTRI_LEAN_MODE")) ctx->lean_mode = atoi(lm);
     if (const char *hm = getenv("SNOWTRI_HANDOVER_MODE")) ctx->handover_mode = atoi(hm);
+    // every environment knob is read HERE, once: nothing on the launch path calls getenv
+    if (const char *e = getenv("SNOWTRI_SUMS_THREADS")) ctx->sums_threads = atoi(e);
+    if (const char *e = getenv("SNOWTRI_SUMS_LDS_KB")) ctx->sums_lds_kb = atoi(e);
+    if (const char *e = getenv("SNOWTRI_ASSOC_WG_PER_CU")) ctx->assoc_wg_per_cu = std::max(1, atoi(e));
+    if (const char *e = getenv("SNOWTRI_RECOMPUTE_WG_PER_CU")) ctx->recompute_wg_per_cu = atoi(e);
+    if (const char *e = getenv("SNOWTRI_CLUSTER_PASSES_PER_WAVE")) ctx->cluster_ppw = std::max(1, atoi(e));
+    if (getenv("SNOWTRI_DEBUG")) ctx->debug = 1;
+    if (const char *e = getenv("SNOWTRI_TILE_FRAMES")) ctx->tile_frames = atoi(e);
+    if (const char *e = getenv("SNOWTRI_LEAN_WG_PER_CU")) ctx->lean_wg_per_cu = std::max(1, atoi(e));
+    if (const char *e = getenv("SNOWTRI_LEAN_TILES_PER_WAVE")) ctx->lean_tiles_per_wave = std::max(1, atoi(e));
+    if (const char *e = getenv("SNOWTRI_LEAN_SCRATCH_MB")) ctx->lean_scratch_mb = std::max(1, atoi(e));
+    if (const char *e = getenv("SNOWTRI_HANDOVER_SEG_FRAMES")) ctx->handover_seg_frames = std::max(1, atoi(e));   // test knob: short segments
     ctx->hM.resize((size_t)C * 9);
     ctx->ht.assign(t, t + (size_t)C * 3);
     ctx->hK.assign(K, K + (size_t)C * 9);
@@ -277,6 +300,7 @@ int snowtri_ctx_destroy(snowtri_ctx *ctx) {
     ctx->misc.release();
     ctx->aux.release();
     ctx->desc.release();
+    ctx->sums.release();
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
     for (auto &e : ctx->ev_ring)
@@ -1048,11 +1072,8 @@ constexpr size_t kMaxScratchBytes = (size_t)8 << 30;
 // 256-wide passes) x (balance of the tiles over the CUs -- the kernel is fp64-VALU-bound, so a CU
 // with one more tile than its neighbours sets the launch time), under the LDS budget.  Prefer
 // >= 2 workgroups per CU (latency hiding) unless that costs more than 5 %.
-int choose_tile_frames(int64_t F, int J, int kn, int NP, int num_cus) {
-    if (const char *e = getenv("SNOWTRI_TILE_FRAMES")) {
-        const int T = atoi(e);
-        if (T >= 1 && T <= 64 && fused_single_lds_bytes(T, kn, NP) <= 64 * 1024) return T;
-    }
+int choose_tile_frames(int64_t F, int J, int kn, int NP, int num_cus, int forced) {
+    if (forced >= 1 && forced <= 64 && fused_single_lds_bytes(forced, kn, NP) <= 64 * 1024) return forced;
     int best = 1;
     double best_score = -1.0;
     for (int T = 1; T <= 64; T++) {
@@ -1079,7 +1100,7 @@ int launch_fused_single(snowtri_ctx *ctx, hipStream_t st, int64_t F, int J, cons
                         int32_t *d_cnt, uint32_t *d_fl) {
     constexpr int NP = C * (C - 1) / 2;
     const int resident = ctx->num_cus * 4;  // 2 workgroups per CU are resident; 2 more queued ones even out the tail (measured)
-    const int T = choose_tile_frames(F, J, prm.kn, NP, ctx->num_cus);
+    const int T = choose_tile_frames(F, J, prm.kn, NP, ctx->num_cus, ctx->tile_frames);
     const int64_t ntiles = (F + T - 1) / T;
     const int grid = (int)std::min<int64_t>(ntiles, resident);
     const size_t per_block = general_scratch_bytes(NP, J);
@@ -1108,9 +1129,7 @@ template <int C, typename TIn>
 int launch_fused_lean(snowtri_ctx *ctx, hipStream_t st, int64_t F, const TIn *d_kpts, const int32_t *d_np,
                       const Params &prm, float *d_xyzs, float *d_ps, int32_t *d_cnt, uint32_t *d_fl) {
     constexpr int NP = C * (C - 1) / 2;
-    int wg_small = 2, tpw = kLeanTilesPerWave;
-    if (const char *e = getenv("SNOWTRI_LEAN_WG_PER_CU")) wg_small = std::max(1, atoi(e));
-    if (const char *e = getenv("SNOWTRI_LEAN_TILES_PER_WAVE")) tpw = std::max(1, atoi(e));
+    const int wg_small = ctx->lean_wg_per_cu, tpw = ctx->lean_tiles_per_wave > 0 ? ctx->lean_tiles_per_wave : kLeanTilesPerWave;
     const size_t per_block = general_scratch_bytes(NP, kLeanJ);
     auto kern = k_fused_lean<C, TIn, kLeanJ>;
     const int64_t W_small = (int64_t)ctx->num_cus * wg_small * kLeanWaves;
@@ -1125,8 +1144,7 @@ int launch_fused_lean(snowtri_ctx *ctx, hipStream_t st, int64_t F, const TIn *d_
             W = std::max<int64_t>(W_small, (tiles0 + tpw - 1) / tpw);
         }
         // every workgroup owns a slab for the frames it has to re-do: keep that scratch under 256 MB
-        size_t scratch_mb = 256;
-        if (const char *e = getenv("SNOWTRI_LEAN_SCRATCH_MB")) scratch_mb = (size_t)std::max(1, atoi(e));
+        const size_t scratch_mb = (size_t)ctx->lean_scratch_mb;
         const int64_t grid_cap = std::max<int64_t>((int64_t)ctx->num_cus * 6, (int64_t)((scratch_mb << 20) / per_block));
         const int grid = (int)std::min<int64_t>(grid_cap, (W + kLeanWaves - 1) / kLeanWaves);
         W = (int64_t)grid * kLeanWaves;
@@ -1140,7 +1158,7 @@ int launch_fused_lean(snowtri_ctx *ctx, hipStream_t st, int64_t F, const TIn *d_
         if (rc) return rc;
         if (lds > 48 * 1024)
             HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        if (getenv("SNOWTRI_DEBUG")) {
+        if (ctx->debug) {
             int occ = 0;
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, kBlock, lds);
             fprintf(stderr, "k_fused_lean: F %lld grid %d tiles %lld (%d frames +1 for %lld) lds %zu occupancy/CU %d\n",
@@ -1186,8 +1204,7 @@ int launch_cluster_fuse(snowtri_ctx *ctx, hipStream_t st, int64_t Fs, int Pmax, 
                         int Pout, float *d_xyzs, const ClusterDesc *desc, const uint32_t *words,
                         const unsigned long long *cnt, uint32_t cap) {
     const int64_t passes_max = (Fs * Pout * (int64_t)J + 63) / 64;
-    int ppw = 24;   // passes per wave when every frame fills its Pout slots
-    if (const char *e = getenv("SNOWTRI_CLUSTER_PASSES_PER_WAVE")) ppw = std::max(1, atoi(e));
+    const int ppw = ctx->cluster_ppw;   // passes per wave when every frame fills its Pout slots
     const int64_t W = std::max<int64_t>((passes_max + ppw - 1) / ppw, std::min<int64_t>(passes_max, (int64_t)ctx->num_cus * 8));
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((W + kBlock / 64 - 1) / (kBlock / 64), (int64_t)ctx->num_cus * 64));
     const unsigned long long jmagic = (((unsigned long long)1 << 40) + (unsigned long long)J - 1) / (unsigned long long)J;
@@ -1197,7 +1214,28 @@ int launch_cluster_fuse(snowtri_ctx *ctx, hipStream_t st, int64_t Fs, int Pmax, 
     return SNOWTRI_OK;
 }
 
-// Multi-person path without HBM candidate spill (snowtri_general.hpp).
+// Launch shape of k_candidate_sums for a rig: threads per workgroup, LDS per workgroup, workgroups per CU.
+struct SumsLaunch {
+    int threads, lds, per_cu;
+    SumsGeom geo;
+};
+SumsLaunch sums_launch_shape(const snowtri_ctx *ctx, int Pmax, int J) {
+    const int C = ctx->C, gs = p1_group_size(Pmax);
+    const int64_t nitems = (int64_t)ctx->npairs * Pmax * (Pmax / gs);
+    SumsLaunch L;
+    // one pass over the items should keep every wave busy: 256 threads for the small rigs, the whole CU for the large
+    L.threads = ctx->sums_threads > 0 ? ctx->sums_threads : (nitems <= 256 ? 256 : (nitems <= 768 ? 512 : 1024));
+    L.threads = std::max(64, std::min(1024, (L.threads / 64) * 64));
+    L.lds = ctx->sums_lds_kb > 0 ? ctx->sums_lds_kb * 1024 : (L.threads <= 256 ? 52 * 1024 : (L.threads <= 512 ? 80 * 1024 : 160 * 1024));
+    L.lds = std::min(L.lds, 160 * 1024);
+    L.per_cu = std::max(1, std::min((160 * 1024) / L.lds, 2048 / L.threads));
+    L.geo = sums_geometry(C, Pmax, J, ctx->npairs, L.threads, L.lds);
+    return L;
+}
+
+// Multi-person path without HBM candidate spill: k_frame_recompute (snowtri_general.hpp), or -- float32 outputs,
+// pairwise method, <= 16 cameras -- the streaming association of snowtri_assoc.hpp with k_frame_recompute for the frames
+// it leaves behind.
 template <int METHOD, typename TIn, typename TOut>
 int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax, int J, const TIn *d_kpts,
                            const int32_t *d_np, const Params &prm, int Pout, TOut *d_xyzs, TOut *d_ps,
@@ -1209,28 +1247,45 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax
     // phase by phase)
     const size_t lds = recompute_launch_lds(C, ctx->npairs);
     auto kern = k_frame_recompute<METHOD, TIn, TOut>;
-    if (lds > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-    // exactly the workgroups that are resident at once (registers and the ~50 KB of LDS decide: 3 per CU);
-    // they pull frames from an atomic counter until none are left
-    int per_cu = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kern, kBlock, lds));
-    if (getenv("SNOWTRI_DEBUG")) fprintf(stderr, "k_frame_recompute: R %d Kc %lld lds %zu occupancy/CU %d\n", R, (long long)Kc, lds, per_cu);
-    if (const char *e = getenv("SNOWTRI_RECOMPUTE_WG_PER_CU")) per_cu = atoi(e);
-    // Hand-over of complete-graph clusters to k_cluster_fuse (snowtri_cluster.hpp): float32 outputs, pairwise method,
-    // register-resident rays (<= 8 cameras), 4-bit person fields, a person's mean score derivable from the candidate
-    // means (keypoint_num == J, non-negative scores), descriptors staged in the ray chunk.
-    const bool handover = METHOD == 0 && sizeof(TOut) == 4 && ctx->handover_mode != 0 && C >= 2 && C <= kClusterMaxCams &&
-                          Pmax <= kClusterMaxPersons && prm.kn == J && J <= 256 && prm.kthr >= 0.0 && Pout >= 1 &&
-                          (size_t)Pout * 24 + 80 <= (size_t)kRayChunkBytes;
+    snowtri_ctx::OccCache &oc = ctx->recompute_occ[METHOD * 4 + (sizeof(TIn) == 8 ? 2 : 0) + (sizeof(TOut) == 8 ? 1 : 0)];
+    if (oc.per_cu < 0 || oc.lds != lds) {
+        // exactly the workgroups that are resident at once (registers and the ~50 KB of LDS decide: 3 per CU);
+        // they pull frames from an atomic counter until none are left
+        if (lds > 48 * 1024)
+            HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        int q = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, kern, kBlock, lds));
+        oc.lds = lds;
+        oc.per_cu = q;
+        if (ctx->debug) fprintf(stderr, "k_frame_recompute: R %d Kc %lld lds %zu occupancy/CU %d\n", R, (long long)Kc, lds, q);
+    }
+    int per_cu = oc.per_cu;
+    if (ctx->recompute_wg_per_cu > 0) per_cu = ctx->recompute_wg_per_cu;
+    // Hand-over of the output persons to the streaming fusion kernels (snowtri_cluster.hpp): float32 outputs, pairwise
+    // method, 4-bit person fields, a person's mean score derivable from the candidate means (keypoint_num == J,
+    // non-negative scores).  handover_mode 1: the streaming association (<= 16 cameras); 2: descriptors written by
+    // k_frame_recompute itself (<= 8 cameras: register-resident rays in k_cluster_fuse), staged in its arena.
+    const bool can_hand = METHOD == 0 && sizeof(TOut) == 4 && C >= 2 && Pmax <= kClusterMaxPersons && prm.kn == J && J <= 256 &&
+                          prm.kthr >= 0.0 && Pout >= 1 && (size_t)Pout * 24 + 80 <= (size_t)kRayChunkBytes;
+    SumsLaunch SL{};
+    bool stream = can_hand && ctx->handover_mode == 1 && C <= 16 && Kc < ((int64_t)1 << 24) && Pout <= 1024;
+    if (stream) {
+        SL = sums_launch_shape(ctx, Pmax, J);
+        stream = SL.geo.Jc >= 1;
+    }
+    const bool handover = !stream && can_hand && ctx->handover_mode != 0 && C <= kClusterMaxCams;
     // the two descriptor lists hold Pout persons for every frame of a segment (<= 2 M entries each, 64 MB together), the
-    // member list Kc words per frame (<= 32 M words, 128 MB); row indices are 32-bit
-    const int64_t seg_frames = !handover ? F : std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(((int64_t)2 << 20) / Pout, ((int64_t)32 << 20) / Kc),
-                                                                                      ((int64_t)1 << 31) / R));
-    int64_t seg_cap = seg_frames;
-    if (const char *e = getenv("SNOWTRI_HANDOVER_SEG_FRAMES")) seg_cap = std::max(1, atoi(e));   // test knob: short segments
-    const int64_t seg = handover ? std::min(seg_frames, seg_cap) : F;
-    unsigned long long *next_frame = ctx->d_counters + 2, *hand_counters = ctx->d_counters + 3;
+    // member list Kc words per frame (<= 32 M words, 128 MB); row indices are 32-bit; the candidate sums of the
+    // streaming association 8 Kc bytes per frame (<= 512 MB)
+    int64_t seg_frames = F;
+    if (stream || handover)
+        seg_frames = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(((int64_t)2 << 20) / Pout, ((int64_t)32 << 20) / Kc),
+                                                          ((int64_t)1 << 31) / R));
+    if (stream) seg_frames = std::max<int64_t>(1, std::min<int64_t>(seg_frames, ((int64_t)64 << 20) / Kc));
+    const int64_t seg_cap = ctx->handover_seg_frames > 0 ? ctx->handover_seg_frames : seg_frames;
+    const int64_t seg = (stream || handover) ? std::min(seg_frames, seg_cap) : F;
+    unsigned long long *next_frame = ctx->d_counters + 2, *hand_counters = ctx->d_counters + 3, *slow_count = ctx->d_counters + 6;
+    const unsigned long long jmagic = (((unsigned long long)1 << 40) + (unsigned long long)J - 1) / (unsigned long long)J;
     for (int64_t s0 = 0; s0 < F; s0 += seg) {
         const int64_t Fs = std::min<int64_t>(seg, F - s0);
         int64_t grid = std::min<int64_t>(Fs, (int64_t)ctx->num_cus * std::max(1, per_cu));
@@ -1240,7 +1295,7 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax
         uint32_t cap = 0, word_cap = 0;
         ClusterDesc *desc = nullptr;
         uint32_t *words = nullptr;
-        if (handover) {
+        if (stream || handover) {
             ctx->last_handover = true;
             cap = (uint32_t)(Fs * Pout);
             word_cap = (uint32_t)(Fs * Kc);
@@ -1249,16 +1304,53 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax
             desc = (ClusterDesc *)ctx->desc.p;
             words = (uint32_t *)(desc + (size_t)2 * cap);
         }
-        HIP_TRY(hipMemsetAsync(next_frame, 0, 4 * sizeof(unsigned long long), st));   // next_frame + the three hand-over counters
+        HIP_TRY(hipMemsetAsync(next_frame, 0, 5 * sizeof(unsigned long long), st));   // next_frame, the three hand-over counters, slow frames
         const TIn *kp_seg = d_kpts + s0 * (int64_t)R * J * 3;
+        const int32_t *np_seg = d_np ? d_np + s0 * C : nullptr;
         TOut *xyz_seg = d_xyzs + s0 * (int64_t)Pout * prm.kn * 4;
-        hipLaunchKernelGGL(kern, dim3((int)grid), dim3(kBlock), lds, st, Fs, Pmax, J, (int)Kc, ctx->rig(), kp_seg,
-                           d_np ? d_np + s0 * C : nullptr, prm, Pout, xyz_seg, d_ps ? d_ps + s0 * Pout : nullptr, d_cnt + s0,
-                           d_fl ? d_fl + s0 : nullptr, (char *)ctx->work.p, per_block, next_frame, (int)lds,
-                           desc, words, hand_counters, cap, word_cap);
-        HIP_TRY(hipGetLastError());
+        TOut *ps_seg = d_ps ? d_ps + s0 * Pout : nullptr;
+        uint32_t *fl_seg = d_fl ? d_fl + s0 : nullptr;
         if constexpr (METHOD == 0 && sizeof(TOut) == 4) {
-            if (handover) {
+            if (stream) {
+                // ---- k_candidate_sums -> k_associate -> k_cluster_fuse, then k_frame_recompute on the frames left behind
+                const size_t sum_bytes = ((size_t)Fs * Kc * 8 + 255) & ~(size_t)255;
+                rc = ctx->sums.ensure(sum_bytes + (size_t)Fs * 4 + 256);
+                if (rc) return rc;
+                double *csum = (double *)ctx->sums.p;
+                uint32_t *slow_list = (uint32_t *)((char *)ctx->sums.p + sum_bytes);
+                auto k1 = k_candidate_sums<TIn>;
+                auto k2 = k_associate<TIn>;
+                const size_t lds2 = associate_lds_bytes(C, Pout, Kc);
+                if (SL.lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)k1, hipFuncAttributeMaxDynamicSharedMemorySize, SL.lds));
+                const int grid1 = (int)std::min<int64_t>(Fs, (int64_t)ctx->num_cus * SL.per_cu);
+                if (ctx->debug) {
+                    for (int kb = 48; kb <= 56; kb++) {
+                        int q = 0;
+                        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k1, SL.threads, (size_t)kb * 1024);
+                        fprintf(stderr, "  k_candidate_sums occupancy at %d KB LDS, %d threads: %d per CU\n", kb, SL.threads, q);
+                    }
+                }
+                if (ctx->debug)
+                    fprintf(stderr, "k_candidate_sums: threads %d lds %d per_cu %d grid %d GS %d JS %d Jc %d sums_in_lds %d | k_associate lds %zu\n",
+                            SL.threads, SL.lds, SL.per_cu, grid1, SL.geo.GS, SL.geo.JS, SL.geo.Jc, SL.geo.sum_bytes, lds2);
+                hipLaunchKernelGGL(k1, dim3(grid1), dim3(SL.threads), SL.lds, st, Fs, Pmax, J, (int)Kc, ctx->rig(), kp_seg, np_seg, prm, csum,
+                                   fl_seg, SL.lds);
+                HIP_TRY(hipGetLastError());
+                const int grid2 = (int)std::min<int64_t>(Fs, (int64_t)ctx->num_cus * ctx->assoc_wg_per_cu);
+                hipLaunchKernelGGL(k2, dim3(grid2), dim3(64), lds2, st, Fs, Pmax, J, (int)Kc, ctx->rig(), kp_seg, np_seg, prm, Pout, csum,
+                                   (float *)xyz_seg, (float *)ps_seg, d_cnt + s0, fl_seg, desc, words, hand_counters, cap, word_cap, slow_list,
+                                   slow_count, (int)lds2, C <= kClusterMaxCams ? 1 : 0);
+                HIP_TRY(hipGetLastError());
+            }
+        }
+        if (!stream) {
+            hipLaunchKernelGGL(kern, dim3((int)grid), dim3(kBlock), lds, st, Fs, Pmax, J, (int)Kc, ctx->rig(), kp_seg, np_seg, prm, Pout,
+                               xyz_seg, ps_seg, d_cnt + s0, fl_seg, (char *)ctx->work.p, per_block, next_frame, (int)lds, desc, words,
+                               hand_counters, cap, word_cap, (const uint32_t *)nullptr, (const unsigned long long *)nullptr);
+            HIP_TRY(hipGetLastError());
+        }
+        if constexpr (METHOD == 0 && sizeof(TOut) == 4) {
+            if (stream || handover) {
                 switch (C) {
 #define SNOWTRI_CASE(CC)                                                                                                       \
     case CC:                                                                                                                   \
@@ -1275,9 +1367,25 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax
                     SNOWTRI_CASE(4)
                     SNOWTRI_CASE(8)
 #undef SNOWTRI_CASE
-                    default: rc = SNOWTRI_ERR_BAD_ARG;
+                    default: {   // more than 8 cameras: every person is a member-list descriptor
+                        const int64_t passes_max = (Fs * Pout * (int64_t)J + 63) / 64;
+                        const int gridm = (int)std::max<int64_t>(1, std::min<int64_t>((passes_max + 3) / 4, (int64_t)ctx->num_cus * 16));
+                        hipLaunchKernelGGL((k_cluster_members<TIn>), dim3(gridm), dim3(kBlock), cluster_members_lds_bytes(C, ctx->npairs), st,
+                                           desc, words, hand_counters, cap, ctx->rig(), kp_seg, prm, Pmax, J, jmagic, Pout, (float *)xyz_seg);
+                        rc = hipGetLastError() == hipSuccess ? SNOWTRI_OK : SNOWTRI_ERR_HIP;
+                    }
                 }
                 if (rc) return rc;
+            }
+            if (stream) {
+                // the frames k_associate listed (slow_count of them, known on the device only): phase 3 inside the kernel
+                const int gridr = (int)std::max<int64_t>(1, std::min<int64_t>(grid, ctx->num_cus));
+                hipLaunchKernelGGL(kern, dim3(gridr), dim3(kBlock), lds, st, Fs, Pmax, J, (int)Kc, ctx->rig(), kp_seg, np_seg, prm, Pout,
+                                   xyz_seg, ps_seg, d_cnt + s0, fl_seg, (char *)ctx->work.p, per_block, next_frame, (int)lds,
+                                   (ClusterDesc *)nullptr, (uint32_t *)nullptr, hand_counters, 0u, 0u,
+                                   (const uint32_t *)((char *)ctx->sums.p + (((size_t)Fs * Kc * 8 + 255) & ~(size_t)255)),
+                                   (const unsigned long long *)slow_count);
+                HIP_TRY(hipGetLastError());
             }
         }
     }

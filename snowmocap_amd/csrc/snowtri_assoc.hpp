@@ -1,0 +1,617 @@
+// snowtri_assoc.hpp -- the multi-person association as STREAMING kernels (float32 outputs, pairwise method):
+//
+//   k_candidate_sums   A3  per frame and candidate: sum over the joints of the pair score       (triangulation.py:56-81)
+//   k_associate        A4  per frame: kept list, centre joints, greedy clustering, filters; every output person becomes
+//                          a descriptor for k_cluster_fuse                                       (triangulation.py:95-135,150-152)
+//   k_cluster_fuse*    A4  per (output person, joint): score-weighted fusion                     (triangulation.py:136-149)
+//
+// k_frame_recompute (snowtri_general.hpp) runs the same three phases for one frame per workgroup: its candidate pass
+// shares the CU with a one-wave clustering and with chains of dependent loads on its bookkeeping slab, and every phase
+// pays the registers of the largest one.  Here every phase is a kernel of its own shape: the candidate pass keeps all
+// waves of a workgroup in the solve loop (keypoints of the next joint chunk in flight in registers), the association
+// is one WAVE per frame (thousands of frames in flight hide its dependent loads), the fusion streams (person, joint)
+// items.  Between them: one double per candidate slot (Kc x 8 B per frame, against 12 C P J B of keypoints) and one
+// 16-byte descriptor per output person.  Frames whose filter decisions are not safe on the fast arithmetic are listed
+// and re-done by k_frame_recompute.
+#pragma once
+#include "snowtri_general.hpp"
+
+namespace snowtri {
+
+// ---------------------------------------------------------------------------------------------- k_candidate_sums
+// LDS: [0, 320) flags + the list of candidates to re-do | per camera pair d = t_s - t_m and the two camera indices (32 B) |
+// ray matrices | arena = [candidate sums, if they fit] + one joint chunk of ray records (layout and bank map:
+// snowtri_general.hpp, p1_joint_stride).
+constexpr int kSumsHeadBytes = 320;
+constexpr int kSumsRedoMax = 64;            // candidates re-done one per lane; more than that: the whole frame exactly
+constexpr int kSumsPrefetch = 6;            // records of the next chunk a thread holds in registers
+constexpr int kSumsLdsSumBudget = 8 * 1024;
+
+__host__ __device__ inline size_t sums_arena_offset(int C, int npairs) {
+    return ((size_t)kSumsHeadBytes + (size_t)32 * npairs + (size_t)72 * C + 15) & ~(size_t)15;
+}
+// item = (camera pair, person of its first camera, group of GS persons of its second); JS = how many ways a chunk's
+// joints are split over the workgroup's NW waves when one pass over the items leaves waves idle (whole waves take a
+// joint sub-range: the lanes of a wave still read the same joint)
+__host__ __device__ inline int sums_joint_split(int nitems, int NW) {
+    const int iw = (nitems + 63) >> 6;
+    int js = 1;
+    while (2 * js * iw <= NW) js *= 2;
+    return js;
+}
+struct SumsGeom {
+    int GS, JS, sum_bytes, Jc;   // candidates per item (full frames), joint split, LDS bytes of the sums (0: global), joints per chunk
+};
+__host__ __device__ inline SumsGeom sums_geometry(int C, int Pmax, int J, int npairs, int threads, int lds_total) {
+    SumsGeom g;
+    const int R = C * Pmax, NW = threads / 64;
+    const long long kc = (long long)npairs * Pmax * Pmax;
+    g.GS = p1_group_size(Pmax);
+    g.JS = sums_joint_split((int)((kc / g.GS) > 0x3fffffff ? 0x3fffffff : (kc / g.GS)), NW);
+    if ((long long)g.JS * kc * 8 > kSumsLdsSumBudget) g.JS = 1;
+    g.sum_bytes = kc * 8 <= kSumsLdsSumBudget ? (int)(g.JS * kc * 8) : 0;
+    const int arena = lds_total - (int)sums_arena_offset(C, npairs) - g.sum_bytes;
+    int cap = arena / p1_joint_stride(R);
+    const int pf = kSumsPrefetch * threads / R;   // every record of a chunk prefetched
+    if (cap > pf) cap = pf;
+    if (cap > 64) cap = 64;
+    if (cap < 1) {
+        g.Jc = 0;
+        return g;
+    }
+    const int nch = (J + cap - 1) / cap;
+    g.Jc = (J + nch - 1) / nch;   // evened out: 133 joints -> 34 + 33 + 33 + 33, not 4 x 32 + 5
+    return g;
+}
+
+// csum[f][k] = sum over the joints of the score of candidate slot k (J x the mean of :79; 0 for a slot whose cameras
+// list fewer persons); out_flags[f] = SNOWTRI_FLAG_SINGULAR or 0.  Frames are dealt round-robin to the workgroups
+// (every frame costs the same here).  blockDim.x = 64 NW, a multiple of 64 up to 1024; dynamic LDS = lds_total.
+template <typename TIn>
+__global__ __launch_bounds__(1024) void k_candidate_sums(int64_t F, int Pmax, int J, int Kc, Rig rig,
+                                                         const TIn *__restrict__ kpts, const int32_t *__restrict__ n_persons,
+                                                         Params prm, double *__restrict__ csum, uint32_t *__restrict__ out_flags,
+                                                         int lds_total) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, B = blockDim.x, NW = B >> 6;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int C = rig.C, R = C * Pmax, pp = Pmax * Pmax;
+    int32_t *head = reinterpret_cast<int32_t *>(smem);          // [0] re-do count, [1] singular, [2] ragged; [16..80) re-do list
+    int32_t *redo_list = head + 16;
+    double *paird = reinterpret_cast<double *>(smem + kSumsHeadBytes);      // [npairs][3]
+    int32_t *pairs = reinterpret_cast<int32_t *>(paird + 3 * rig.npairs);  // [npairs][2]
+    double *Ml = reinterpret_cast<double *>(pairs + 2 * rig.npairs);
+    for (int i = tid; i < 3 * rig.npairs; i += B) paird[i] = rig.pairc[6 * (i / 3) + i % 3];
+    for (int i = tid; i < 2 * rig.npairs; i += B) pairs[i] = rig.pairs[i];
+    for (int i = tid; i < 9 * C; i += B) Ml[i] = rig.M[i];
+    const SumsGeom geo = sums_geometry(C, Pmax, J, rig.npairs, B, lds_total);
+    char *arena = smem + sums_arena_offset(C, rig.npairs);
+    double *lsum = reinterpret_cast<double *>(arena);           // [JS][Kc] raw sums (2000 x the score of :72) if sum_bytes
+    char *rec = arena + geo.sum_bytes;
+    const int jstr = p1_joint_stride(R), Jc = geo.Jc, JS = geo.JS;
+    const bool acc_lds = geo.sum_bytes != 0;
+    const bool exact_only = prm.kthr < 0.0;   // negative scores may pass the keypoint gate: no relative error bound on a sum
+    const unsigned long long magic_pmax = (((unsigned long long)1 << 40) + (unsigned)Pmax - 1) / (unsigned)Pmax;
+    const unsigned long long magic_pp = (((unsigned long long)1 << 40) + (unsigned)pp - 1) / (unsigned)pp;
+    const Kp3<TIn> *kp3 = reinterpret_cast<const Kp3<TIn> *>(kpts);
+
+    for (int64_t f = blockIdx.x; f < F; f += gridDim.x) {
+        const int32_t *np_f = n_persons ? n_persons + f * C : nullptr;
+        const Kp3<TIn> *kpf = kp3 + f * (int64_t)R * J;
+        double *cs_f = csum + f * (int64_t)Kc;
+        if (tid == 0) head[0] = head[1] = head[2] = 0;
+        __syncthreads();   // (also: the previous frame's readers of the arena are done)
+        if (np_f) {
+            bool rg = false;
+            for (int c = tid; c < C; c += B) rg |= np_f[c] != Pmax;
+            if (rg) head[2] = 1;
+        }
+        // candidate slot k -> valid?  (candidate order of triangulation.py:56-65: camera pair, person of the first camera,
+        // person of the second)
+        auto slot_rows = [&](int k, int &rm, int &rs, int &q) -> bool {
+            q = (int)(((unsigned long long)(unsigned)k * magic_pp) >> 40);
+            const int rr = k - q * pp, pm = (int)(((unsigned long long)(unsigned)rr * magic_pmax) >> 40), ps = rr - pm * Pmax;
+            const int mc = pairs[2 * q], sc = pairs[2 * q + 1];
+            rm = mc * Pmax + pm;
+            rs = sc * Pmax + ps;
+            return !np_f || (pm < np_f[mc] && ps < np_f[sc]);
+        };
+        auto acc_get = [&](int idx) -> double { return acc_lds ? lsum[idx] : cs_f[idx]; };
+        auto acc_put = [&](int idx, double v) {
+            if (acc_lds)
+                lsum[idx] = v;
+            else
+                cs_f[idx] = v;
+        };
+        for (int k = tid; k < (acc_lds ? JS * Kc : Kc); k += B) acc_put(k, 0.0);
+
+        // ---- the records of a joint chunk: keypoints fetched into registers (one chunk ahead), then ray + |h|^2 + score
+        // into LDS.  Lanes = consecutive joints of a row: coalesced 12-byte reads.  Rows a camera does not list are
+        // filled with whatever the buffer holds: no valid candidate reads them.
+        Kp3<TIn> pre[kSumsPrefetch];
+        int pre_off[kSumsPrefetch];   // LDS byte offset of the record | camera << 20, or -1
+        auto fetch = [&](int j0, int nj) {
+            const unsigned long long magic_nj = (((unsigned long long)1 << 40) + (unsigned)nj - 1) / (unsigned)nj;
+#pragma unroll
+            for (int n = 0; n < kSumsPrefetch; n++) {
+                const int i = tid + n * B;
+                pre_off[n] = -1;
+                if (i < R * nj) {
+                    const int r = (int)(((unsigned long long)(unsigned)i * magic_nj) >> 40), jj = i - r * nj;
+                    const int c = (int)(((unsigned long long)(unsigned)r * magic_pmax) >> 40);
+                    pre[n] = kpf[(size_t)r * J + j0 + jj];
+                    pre_off[n] = (jj * jstr + kP1Rec * r) | (c << 20);
+                }
+            }
+        };
+        auto commit = [&]() {
+#pragma unroll
+            for (int n = 0; n < kSumsPrefetch; n++)
+                if (pre_off[n] >= 0)
+                    p1_store_record<TIn>(rec + (pre_off[n] & 0xfffff), make_ray(Ml + 9 * (pre_off[n] >> 20), pre[n].u, pre[n].v), pre[n].s);
+        };
+        __syncthreads();
+        const int GS = head[2] ? 1 : geo.GS;   // a ragged frame keeps one candidate per lane
+        const int NG = Pmax / GS, per_q = Pmax * NG, nitems = rig.npairs * per_q;
+        const int wpg = NW / JS;               // waves that share a joint sub-range
+        const int jsub = wv / wpg, iw = wv - jsub * wpg;
+        const unsigned long long magic_pq = (((unsigned long long)1 << 40) + (unsigned)per_q - 1) / (unsigned)per_q;
+        const unsigned long long magic_ng = (((unsigned long long)1 << 40) + (unsigned)NG - 1) / (unsigned)NG;
+        bool sing = false;
+
+        if (!exact_only) {
+            fetch(0, J < Jc ? J : Jc);
+            for (int j0 = 0; j0 < J; j0 += Jc) {
+                const int nj = (J - j0) < Jc ? (J - j0) : Jc;
+                if (j0) __syncthreads();   // the previous chunk's solves are done
+                commit();
+                __syncthreads();
+                if (j0 + Jc < J) fetch(j0 + Jc, (J - j0 - Jc) < Jc ? (J - j0 - Jc) : Jc);   // in flight during the solves
+                // the waves of joint sub-range jsub walk joints [jlo, jhi) of the chunk; item = base + lane of the round
+                const int jlo = jsub * nj / JS, jhi = (jsub + 1) * nj / JS;
+                for (int base = iw * 64; base < nitems; base += wpg * 64) {
+                    const int item = base + lane;
+                    const bool live = item < nitems;
+                    const int it = live ? item : 0;
+                    const int q = (int)(((unsigned long long)(unsigned)it * magic_pq) >> 40), r2 = it - q * per_q;
+                    const int pm = (int)(((unsigned long long)(unsigned)r2 * magic_ng) >> 40), ps0 = (r2 - pm * NG) * GS;
+                    const int k0 = q * pp + pm * Pmax + ps0;
+                    const int mc = pairs[2 * q], sc = pairs[2 * q + 1];
+                    const int rm = mc * Pmax + pm, rs0 = sc * Pmax + ps0;
+                    const double *pc = paird + 3 * q;
+                    const Vec3 d = {pc[0], pc[1], pc[2]};
+                    const char *pa = rec + jlo * jstr + kP1Rec * rm, *pb = rec + jlo * jstr + kP1Rec * rs0;
+                    const int dst = jsub * Kc + k0;
+                    if (GS == 4) {
+                        double old[4], acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                        for (int u = 0; u < 4; u++) old[u] = live ? acc_get(dst + u) : 0.0;   // (in flight during the solves)
+                        p1_item_sums<4, TIn>(pa, pb, jstr, live ? jhi - jlo : 0, d, prm, acc);
+                        if (live) {
+#pragma unroll
+                            for (int u = 0; u < 4; u++) acc_put(dst + u, old[u] + acc[u]);
+                        }
+                    } else if (GS == 2) {
+                        double old[2], acc[2] = {0.0, 0.0};
+#pragma unroll
+                        for (int u = 0; u < 2; u++) old[u] = live ? acc_get(dst + u) : 0.0;
+                        p1_item_sums<2, TIn>(pa, pb, jstr, live ? jhi - jlo : 0, d, prm, acc);
+                        if (live) {
+#pragma unroll
+                            for (int u = 0; u < 2; u++) acc_put(dst + u, old[u] + acc[u]);
+                        }
+                    } else {
+                        const bool cand = live && (!np_f || (pm < np_f[mc] && ps0 < np_f[sc]));   // empty slots stay at 0
+                        double acc[1] = {0.0};
+                        const double old = cand ? acc_get(dst) : 0.0;
+                        p1_item_sums<1, TIn>(pa, pb, jstr, cand ? jhi - jlo : 0, d, prm, acc);
+                        if (cand) acc_put(dst, old + acc[0]);
+                    }
+                }
+            }
+            // the 1 / (2 * 1000) of :72 and the JS partial sums; candidates whose fast sum cannot decide :80-81 (see
+            // p1_item_sums) -- not finite, or within 1e-6 relative of average_score_threshold -- are listed for the exact sweep
+            __syncthreads();
+            for (int k = tid; k < Kc; k += B) {
+                double v = acc_get(k);
+                for (int s_ = 1; s_ < JS; s_++) v += acc_get(s_ * Kc + k);
+                const double s_ = v * 0.0005, mean = s_ / (double)J;
+                cs_f[k] = s_;
+                if (!(fabs(mean) < 1e300) || (s_ != 0.0 && fabs(mean - prm.avg_thr) <= 1e-6 * fabs(mean))) {
+                    const int at = atomicAdd(&head[0], 1);
+                    if (at < kSumsRedoMax) redo_list[at] = k;
+                }
+            }
+            __syncthreads();
+        }
+        // ---- exact sweep (rare): the listed candidates one per lane, or every candidate of the frame
+        const int nredo = exact_only ? kSumsRedoMax + 1 : head[0];
+        if (nredo) {
+            const bool all = nredo > kSumsRedoMax;
+            int my_k = -1, rm = 0, rs = 0, q = 0;
+            double acc = 0.0;
+            if (!all && tid < nredo) {
+                my_k = redo_list[tid];
+                slot_rows(my_k, rm, rs, q);
+            }
+            if (all)
+                for (int k = tid; k < Kc; k += B) cs_f[k] = 0.0;
+            for (int j0 = 0; j0 < J; j0 += Jc) {
+                const int nj = (J - j0) < Jc ? (J - j0) : Jc;
+                __syncthreads();
+                for (int i0 = 0; i0 < R * nj; i0 += kSumsPrefetch * B) {
+                    const unsigned long long magic_nj = (((unsigned long long)1 << 40) + (unsigned)nj - 1) / (unsigned)nj;
+                    for (int i = i0 + tid; i < R * nj && i < i0 + kSumsPrefetch * B; i += B) {
+                        const int r = (int)(((unsigned long long)(unsigned)i * magic_nj) >> 40), jj = i - r * nj;
+                        const int c = (int)(((unsigned long long)(unsigned)r * magic_pmax) >> 40);
+                        const Kp3<TIn> kp = kpf[(size_t)r * J + j0 + jj];
+                        p1_store_record<TIn>(rec + jj * jstr + kP1Rec * r, make_ray(Ml + 9 * c, kp.u, kp.v), kp.s);
+                    }
+                }
+                __syncthreads();
+                if (all) {
+                    for (int k = tid; k < Kc; k += B) {
+                        int rm2, rs2, q2;
+                        if (!slot_rows(k, rm2, rs2, q2)) continue;
+                        const double *pc = paird + 3 * q2;
+                        cs_f[k] += candidate_chunk_sum_exact<TIn>(rec + kP1Rec * rm2, rec + kP1Rec * rs2, jstr, nj,
+                                                                  Vec3{pc[0], pc[1], pc[2]}, prm, sing);
+                    }
+                } else if (my_k >= 0) {
+                    const double *pc = paird + 3 * q;
+                    acc += candidate_chunk_sum_exact<TIn>(rec + kP1Rec * rm, rec + kP1Rec * rs, jstr, nj, Vec3{pc[0], pc[1], pc[2]},
+                                                          prm, sing);
+                }
+            }
+            if (all) {
+                for (int k = tid; k < Kc; k += B) cs_f[k] *= 0.0005;
+            } else if (my_k >= 0) {
+                cs_f[my_k] = acc * 0.0005;
+            }
+            if (sing) head[1] = 1;
+            __syncthreads();
+        }
+        if (tid == 0 && out_flags) out_flags[f] = head[1] ? 1u /*SNOWTRI_FLAG_SINGULAR*/ : 0u;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------- k_associate
+// One WAVE per frame (64-thread workgroups dealt round-robin): phases 2 and the filters of k_frame_recompute on the
+// candidate sums of k_candidate_sums, every step a few dependent loads -- hidden by the thousands of frames in flight
+// instead of by the three idle waves of a frame's workgroup.  Per frame:
+//   kept list in candidate order (:79-81) -> centre joints (one fast solve per kept candidate) -> greedy clustering
+//   (:107-130) -> members grouped by cluster -> per cluster the size filter (:132-134) and the mean-score filter
+//   (:150-152; a person's mean score is the mean of its members' candidate means because keypoint_num == J) ->
+//   out_count, out_pscore, zero-filled unused slots, and one descriptor per output person: a cluster that is the
+//   complete graph over one detection per camera carries the person index of every camera (4 bits x 16), any other its
+//   member words (rm | rs << 10 | q << 20, as in k_frame_recompute).
+// A frame whose decisions are not safe here -- a mean that is not finite or within 1e-6 of condense_score_tol, more kept
+// candidates or clusters than the wave's LDS holds -- is appended to slow_list and left to k_frame_recompute.
+// LDS: [0, 64) scalars | staging of the output persons (~24 B each) | rows of the cameras (complete-graph test, 4 B x C) |
+// arena: kept index (4 B), cluster id (4 B), centre (24 B) per kept candidate, then 12 B per cluster.
+__host__ __device__ inline size_t associate_arena_offset(int C, int Pout) {
+    const size_t pq = ((size_t)Pout * 4 + 15) & ~(size_t)15;   // four 4-byte arrays padded to 16 bytes + one of doubles
+    return ((size_t)64 + 4 * pq + (size_t)8 * Pout + (size_t)4 * C + 15) & ~(size_t)15;
+}
+__host__ inline size_t associate_lds_bytes(int C, int Pout, int64_t Kc) {
+    const size_t want = associate_arena_offset(C, Pout) + (size_t)44 * (size_t)(Kc < 256 ? Kc : (Kc / 4 < 256 ? 256 : Kc / 4)) + 64;
+    const size_t cap = 48 * 1024;
+    return want > cap ? cap : (want < 4096 ? 4096 : want);
+}
+
+template <typename TIn>
+__global__ __launch_bounds__(64) void k_associate(int64_t F, int Pmax, int J, int Kc, Rig rig, const TIn *__restrict__ kpts,
+                                                  const int32_t *__restrict__ n_persons, Params prm, int Pout,
+                                                  const double *__restrict__ csum, float *__restrict__ out4,
+                                                  float *__restrict__ out_ps, int32_t *__restrict__ out_count,
+                                                  uint32_t *__restrict__ out_flags, ClusterDesc *__restrict__ desc,
+                                                  uint32_t *__restrict__ hand_words, unsigned long long *hand_counters,
+                                                  uint32_t desc_cap, uint32_t word_cap, uint32_t *__restrict__ slow_list,
+                                                  unsigned long long *slow_count, int lds_total, int allow_complete) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int lane = threadIdx.x;
+    const int C = rig.C, R = C * Pmax, pp = Pmax * Pmax, NPq = rig.npairs;
+    const int ci = prm.center;
+    const size_t pq = ((size_t)Pout * 4 + 15) & ~(size_t)15;
+    uint32_t *st_a = reinterpret_cast<uint32_t *>(smem + 64);             // [Pout] persons (low word) | first member
+    int32_t *st_size = reinterpret_cast<int32_t *>(smem + 64 + pq);       // [Pout] 0: complete graph, else members
+    uint32_t *st_idx = reinterpret_cast<uint32_t *>(smem + 64 + 2 * pq);  // [Pout] index inside its descriptor list
+    uint32_t *st_word = reinterpret_cast<uint32_t *>(smem + 64 + 3 * pq); // [Pout] persons (high word) | offset of its member words
+    double *st_avg = reinterpret_cast<double *>(smem + 64 + 4 * pq);      // [Pout]
+    const int arena_off = (int)associate_arena_offset(C, Pout);
+    int32_t *rowc = reinterpret_cast<int32_t *>(smem + arena_off) - C;     // [C] (just below the arena)
+    char *arena = smem + arena_off;
+    const int arena_bytes = lds_total - arena_off;
+    const int n_cap = arena_bytes > 64 ? (arena_bytes - 64) / 32 : 0;
+    const unsigned long long magic_pmax = (((unsigned long long)1 << 40) + (unsigned)Pmax - 1) / (unsigned)Pmax;
+    const unsigned long long magic_pp = (((unsigned long long)1 << 40) + (unsigned)pp - 1) / (unsigned)pp;
+    const Kp3<TIn> *kp3 = reinterpret_cast<const Kp3<TIn> *>(kpts);
+    const PackedWriter<float> wr{out4, out_ps};
+    const int kn = prm.kn;   // == J (host-checked)
+
+    for (int64_t f = blockIdx.x; f < F; f += gridDim.x) {
+        const int32_t *np_f = n_persons ? n_persons + f * C : nullptr;
+        const Kp3<TIn> *kpf = kp3 + f * (int64_t)R * J;
+        const double *cs_f = csum + f * (int64_t)Kc;
+        // candidate slot k -> ray rows, camera pair; false if a camera lists fewer persons than the slot's
+        auto slot_rows = [&](int k, int &rm, int &rs, int &q) -> bool {
+            q = (int)(((unsigned long long)(unsigned)k * magic_pp) >> 40);
+            const int rr = k - q * pp, pm = (int)(((unsigned long long)(unsigned)rr * magic_pmax) >> 40), ps = rr - pm * Pmax;
+            const int mc = rig.pairs[2 * q], sc = rig.pairs[2 * q + 1];
+            rm = mc * Pmax + pm;
+            rs = sc * Pmax + ps;
+            return !np_f || (pm < np_f[mc] && ps < np_f[sc]);
+        };
+        bool slow = false;   // wave-uniform
+        __syncthreads();     // (the previous frame's LDS is dead)
+        bool ragged = false;
+        if (np_f) {
+            bool rg = false;
+            for (int c = lane; c < C; c += 64) rg |= np_f[c] != Pmax;
+            ragged = __ballot(rg) != 0ull;
+        }
+        // ---- kept list in candidate order (:79-81)
+        int32_t *kidx = reinterpret_cast<int32_t *>(arena);
+        int n = 0;
+        for (int base = 0; base < Kc; base += 64) {
+            const int k = base + lane;
+            bool kp_ = k < Kc;
+            const double s_ = kp_ ? cs_f[k] : 0.0;
+            if (kp_ && ragged) {
+                int rm, rs, q;
+                kp_ = slot_rows(k, rm, rs, q);
+            }
+            kp_ = kp_ && !(s_ / (double)J < prm.avg_thr);
+            const unsigned long long m = __ballot(kp_);
+            const int cnt = __popcll(m);
+            if (n + cnt > n_cap) {
+                slow = true;
+                break;
+            }
+            if (kp_) kidx[n + __popcll(m & ((1ull << lane) - 1ull))] = k;
+            n += cnt;
+        }
+        int nout = 0;
+        if (!slow) {
+            int32_t *cof = kidx + n;
+            double *cen = reinterpret_cast<double *>(arena + (((size_t)n * 8 + 15) & ~(size_t)15));
+            int32_t *csize = reinterpret_cast<int32_t *>(cen + 3 * (size_t)n);
+            const int ncl_rem = arena_bytes - (int)(reinterpret_cast<char *>(csize) - arena);
+            const int ncl_cap = ncl_rem >= 16 ? (ncl_rem - 4) / 12 : 0;   // csize, cseed [ncl_cap], cstart [ncl_cap + 1]
+            __syncthreads();
+            // ---- centre joints of the kept candidates
+            for (int i = lane; i < n; i += 64) {
+                int rm, rs, q;
+                slot_rows(kidx[i], rm, rs, q);
+                const int mc = rig.pairs[2 * q], sc = rig.pairs[2 * q + 1];
+                const Kp3<TIn> km = kpf[(size_t)rm * J + ci], ks = kpf[(size_t)rs * J + ci];
+                const RayRec a = make_ray(rig.M + 9 * mc, km.u, km.v), b = make_ray(rig.M + 9 * sc, ks.u, ks.v);
+                const double *pc = rig.pairc + 6 * q;
+                const PairSolve o = pair_solve_fast<true>(a, b, Vec3{pc[0], pc[1], pc[2]}, Vec3{pc[3], pc[4], pc[5]});
+                cen[3 * i] = 0.5 * o.sw.x;
+                cen[3 * i + 1] = 0.5 * o.sw.y;
+                cen[3 * i + 2] = 0.5 * o.sw.z;
+                cof[i] = -1;
+            }
+            __syncthreads();
+            // ---- triangulation.py:107-130 -- seeds in list order, the last candidate never seeds, distance to the SEED's
+            // centre, `dist > tol` skips (NaN absorbs)
+            int ncl = 0;
+            {
+                int32_t *cseed = csize + ncl_cap;
+                if (ncl_cap < 1) slow = true;
+                for (int next = 0; !slow;) {
+                    int mc = -1;
+                    for (int base = next & ~63; base < n - 1 && mc < 0; base += 64) {
+                        const int i = base + lane;
+                        const unsigned long long m = __ballot(i >= next && i < n - 1 && cof[i] == -1);
+                        if (m) mc = base + __ffsll((long long)m) - 1;
+                    }
+                    if (mc < 0) break;
+                    if (ncl >= ncl_cap) {
+                        slow = true;
+                        break;
+                    }
+                    const double mx = cen[3 * mc], my = cen[3 * mc + 1], mz = cen[3 * mc + 2];
+                    int cnt = 0;
+                    for (int base = mc + 1; base < n; base += 64) {
+                        const int sc = base + lane;
+                        bool ab = false;
+                        if (sc < n && cof[sc] == -1) {
+                            const double dx = mx - cen[3 * sc], dy = my - cen[3 * sc + 1], dz = mz - cen[3 * sc + 2];
+                            const double dist = sqrt(fma(dz, dz, fma(dy, dy, dx * dx)));
+                            if (!(dist > prm.ctol)) {
+                                cof[sc] = ncl;
+                                ab = true;
+                            }
+                        }
+                        cnt += __popcll(__ballot(ab));
+                    }
+                    if (lane == 0) {
+                        cof[mc] = ncl;
+                        csize[ncl] = cnt + 1;
+                        cseed[ncl] = mc;
+                    }
+                    ncl++;
+                    next = mc + 1;
+                    __syncthreads();
+                }
+            }
+            if (!slow) {
+                int32_t *cseed = csize + ncl_cap;
+                int32_t *cstart = cseed + ncl_cap;                    // [ncl + 1]
+                int32_t *members = reinterpret_cast<int32_t *>(cen);  // [n] kept indices grouped by cluster (the centres are dead)
+                __syncthreads();
+                // members grouped by cluster, list order inside each cluster
+                int off = 0;
+                for (int c = 0; c < ncl; c++) {
+                    if (lane == 0) cstart[c] = off;
+                    for (int base = cseed[c]; base < n; base += 64) {
+                        const int i = base + lane;
+                        const bool in = i < n && cof[i] == c;
+                        const unsigned long long m = __ballot(in);
+                        if (in) members[off + __popcll(m & ((1ull << lane) - 1ull))] = kidx[i];
+                        off += __popcll(m);
+                    }
+                }
+                if (lane == 0) cstart[ncl] = off;
+                __syncthreads();
+                // ---- filters and descriptors, cluster by cluster
+                uint32_t ncomp = 0, ngen = 0, nwords = 0;
+                for (int cid = 0; cid < ncl; cid++) {
+                    const int size = csize[cid];
+                    if ((double)size < prm.num_tol) continue;                                  // :132-134
+                    const int m0 = cstart[cid];
+                    double ssum = 0.0;
+                    for (int base = 0; base < size; base += 64) ssum += base + lane < size ? cs_f[members[m0 + base + lane]] : 0.0;
+                    ssum = wave_sum(ssum);
+                    const double avg = ssum / ((double)size * (double)J);                       // :150 from :79
+                    // (a sum that is not finite, or a mean within 1e-6 of the tolerance -- the fast sums are within 6e-8 --
+                    // is left to k_frame_recompute; a sum of exactly 0 is exact)
+                    if (!(fabs(avg) < 1e300) || (ssum != 0.0 && fabs(avg - prm.score_tol) <= 1e-6 * fabs(avg))) {
+                        slow = true;
+                        break;
+                    }
+                    if (avg < prm.score_tol) continue;                                         // :151-152
+                    if (nout < Pout) {
+                        bool complete = false;
+                        uint32_t nib_lo = 0u, nib_hi = 0u;
+                        if (size == NPq && allow_complete) {
+                            // members are in candidate order (camera pair major): in a complete graph member i IS pair i; the
+                            // row of camera 0 is the first row of pair (0,1) = member 0, the row of camera c >= 1 the second
+                            // row of pair (0,c) = member c - 1, and every member must repeat the rows of its two cameras.
+                            for (int c = lane; c < C; c += 64) {
+                                int rm, rs, q;
+                                slot_rows(members[m0 + (c == 0 ? 0 : c - 1)], rm, rs, q);
+                                rowc[c] = c == 0 ? rm : rs;
+                            }
+                            __syncthreads();
+                            bool bad = false;
+                            for (int base = 0; base < size; base += 64) {
+                                const int i = base + lane;
+                                if (i < size) {
+                                    int rm, rs, q;
+                                    slot_rows(members[m0 + i], rm, rs, q);
+                                    const int mc = rig.pairs[2 * i], sc = rig.pairs[2 * i + 1];
+                                    bad |= !(q == i && rm == rowc[mc] && rs == rowc[sc]);
+                                }
+                            }
+                            complete = __ballot(bad) == 0ull;
+                            if (complete) {
+                                uint32_t lo = 0u, hi = 0u;
+                                if (lane < C) {
+                                    const uint32_t p = (uint32_t)(rowc[lane] - lane * Pmax);
+                                    if (lane < 8)
+                                        lo = p << (4 * lane);
+                                    else
+                                        hi = p << (4 * (lane - 8));
+                                }
+#pragma unroll
+                                for (int o = 8; o > 0; o >>= 1) {
+                                    lo |= (uint32_t)__shfl_xor((int)lo, o, 64);
+                                    hi |= (uint32_t)__shfl_xor((int)hi, o, 64);
+                                }
+                                nib_lo = (uint32_t)__shfl((int)lo, 0, 64);
+                                nib_hi = (uint32_t)__shfl((int)hi, 0, 64);
+                            }
+                            __syncthreads();
+                        }
+                        if (lane == 0) {
+                            st_a[nout] = complete ? nib_lo : (uint32_t)m0;
+                            st_size[nout] = complete ? 0 : size;
+                            st_idx[nout] = complete ? ncomp : ngen;
+                            st_word[nout] = complete ? nib_hi : nwords;
+                            st_avg[nout] = avg;
+                        }
+                        if (complete) {
+                            ncomp++;
+                        } else {
+                            ngen++;
+                            nwords += (uint32_t)size;
+                        }
+                    }
+                    nout++;
+                }
+                if (!slow) {
+                    unsigned long long bc = 0ull, bg = 0ull, bw = 0ull;
+                    if (lane == 0) {
+                        if (ncomp) bc = atomicAdd(hand_counters, (unsigned long long)ncomp);
+                        if (ngen) bg = atomicAdd(hand_counters + 1, (unsigned long long)ngen);
+                        if (nwords) bw = atomicAdd(hand_counters + 2, (unsigned long long)nwords);
+                    }
+                    bc = (unsigned long long)__shfl((long long)bc, 0, 64);
+                    bg = (unsigned long long)__shfl((long long)bg, 0, 64);
+                    bw = (unsigned long long)__shfl((long long)bw, 0, 64);
+                    // (cannot happen: the host sizes the lists for Pout persons and Kc members of every frame)
+                    if (bc + ncomp > (unsigned long long)desc_cap || bg + ngen > (unsigned long long)desc_cap ||
+                        bw + nwords > (unsigned long long)word_cap) {
+                        for (unsigned long long i = bc + lane; i < bc + ncomp && i < (unsigned long long)desc_cap; i += 64)
+                            desc[i] = ClusterDesc{0u, 0u, 0xffffffffu, 0u};
+                        for (unsigned long long i = bg + lane; i < bg + ngen && i < (unsigned long long)desc_cap; i += 64)
+                            desc[(unsigned long long)desc_cap + i] = ClusterDesc{0u, 0u, 0xffffffffu, 0u};
+                        slow = true;
+                    }
+                    __syncthreads();
+                    if (!slow) {
+                        const int nsl = nout < Pout ? nout : Pout;
+                        for (int sl = lane; sl < nsl; sl += 64) {
+                            if (st_size[sl] == 0)
+                                desc[(uint32_t)bc + st_idx[sl]] = ClusterDesc{(uint32_t)f, st_a[sl], (uint32_t)sl, st_word[sl]};
+                            else
+                                desc[desc_cap + (uint32_t)bg + st_idx[sl]] =
+                                    ClusterDesc{(uint32_t)f, (uint32_t)bw + st_word[sl], (uint32_t)sl, (uint32_t)st_size[sl]};
+                            wr.person(f, Pout, sl, st_avg[sl]);
+                        }
+                        for (int sl = 0; sl < nsl; sl++) {
+                            const int size = st_size[sl], m0 = (int)st_a[sl];
+                            for (int i = lane; i < size; i += 64) {
+                                int rm, rs, q;
+                                slot_rows(members[m0 + i], rm, rs, q);
+                                hand_words[(uint32_t)bw + st_word[sl] + (uint32_t)i] = (uint32_t)rm | ((uint32_t)rs << 10) | ((uint32_t)q << 20);
+                            }
+                        }
+                    }
+                }
+            }
+        }
+        if (slow) {
+            if (lane == 0) slow_list[atomicAdd(slow_count, 1ull)] = (uint32_t)f;
+            continue;
+        }
+        // unused slots: one flat sweep of 16-byte stores
+        for (int i = lane; i < (Pout - nout) * kn; i += 64) wr.zero_joint(f, Pout, kn, nout + i / kn, i % kn);
+        for (int slot = nout + lane; slot < Pout; slot += 64) wr.person(f, Pout, slot, 0.0);
+        if (lane == 0) {
+            out_count[f] = nout;
+            if (out_flags && nout > Pout) atomicOr(&out_flags[f], 2u /*SNOWTRI_FLAG_OVERFLOW*/);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------- k_cluster_members
+// The member-list descriptors alone (cluster_member_passes of snowtri_cluster.hpp) for rigs k_cluster_fuse has no
+// instantiation for: any camera count up to kPairTabMaxPairs pairs.  Dynamic LDS: cluster_members_lds_bytes(C, npairs).
+__host__ __device__ inline size_t cluster_members_lds_bytes(int C, int npairs) { return (size_t)72 * C + (size_t)56 * npairs + 16; }
+
+template <typename TIn>
+__global__ __launch_bounds__(kBlock) void k_cluster_members(const ClusterDesc *__restrict__ desc, const uint32_t *__restrict__ words,
+                                                            const unsigned long long *__restrict__ cnt, uint32_t desc_cap, Rig rig,
+                                                            const TIn *__restrict__ kpts, Params prm, int Pmax, int J,
+                                                            unsigned long long jmagic, int Pout, float *__restrict__ out4) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int C = rig.C, NP = rig.npairs, tid = threadIdx.x;
+    double *Ml = reinterpret_cast<double *>(smem);
+    double *pc = Ml + 9 * C;
+    int32_t *pairs_l = reinterpret_cast<int32_t *>(pc + 6 * NP);
+    for (int i = tid; i < 9 * C; i += kBlock) Ml[i] = rig.M[i];
+    for (int i = tid; i < 6 * NP; i += kBlock) pc[i] = rig.pairc[i];
+    for (int i = tid; i < 2 * NP; i += kBlock) pairs_l[i] = rig.pairs[i];
+    const unsigned long long ng64 = cnt[1];
+    const uint32_t ngen = ng64 < (unsigned long long)desc_cap ? (uint32_t)ng64 : desc_cap;
+    __syncthreads();
+    const uint32_t W = gridDim.x * (uint32_t)(kBlock / 64);
+    cluster_member_passes<TIn>(desc + desc_cap, ngen, words, Ml, pc, pairs_l, C * Pmax, reinterpret_cast<const Kp3<TIn> *>(kpts), prm, J,
+                               jmagic, Pout, out4, blockIdx.x * (uint32_t)(kBlock / 64) + (uint32_t)(tid >> 6), W);
+}
+
+}  // namespace snowtri

@@ -59,7 +59,9 @@ __host__ __device__ inline size_t recompute_arena_offset(int C, int npairs) {
     return ((size_t)256 + recompute_pairtab_bytes(npairs) + (size_t)72 * C + 15) & ~(size_t)15;
 }
 // LDS of k_frame_recompute; the launcher asks for at least kRecomputeLdsBytes (three workgroups per CU share 160 KB).
-constexpr int kRecomputeLdsBytes = 53 * 1024;
+// (52 KB, not 53: the occupancy API still answers 3 at 53 KB, but the hardware then admits only two -- measured as
+// wave lifetimes of half the kernel's duration; the LDS is handed out in granules that 54 272 B does not fill evenly.)
+constexpr int kRecomputeLdsBytes = 52 * 1024;
 __host__ __device__ inline size_t recompute_lds_bytes(int C, int npairs) {
     return recompute_arena_offset(C, npairs) + (size_t)kRayChunkBytes + 16;
 }
@@ -301,7 +303,8 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
                                                             unsigned long long *next_frame, int lds_total,
                                                             ClusterDesc *__restrict__ desc, uint32_t *__restrict__ hand_words,
                                                             unsigned long long *hand_counters, uint32_t desc_cap,
-                                                            uint32_t word_cap) {
+                                                            uint32_t word_cap, const uint32_t *__restrict__ frame_list,
+                                                            const unsigned long long *__restrict__ frame_list_count) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int C = rig.C, R = C * Pmax, pp = Pmax * Pmax;
@@ -368,7 +371,12 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
             misc[3] = (int32_t)(nf >> 32);
         }
         __syncthreads();
-        const int64_t f = (int64_t)(((unsigned long long)(uint32_t)misc[3] << 32) | (uint32_t)misc[2]);
+        int64_t f = (int64_t)(((unsigned long long)(uint32_t)misc[3] << 32) | (uint32_t)misc[2]);
+        // (frame_list: only the listed frames -- the ones k_associate left behind, snowtri_assoc.hpp)
+        if (frame_list) {
+            if ((unsigned long long)f >= *frame_list_count) break;
+            f = (int64_t)frame_list[f];
+        }
         if (f >= F) break;
         const int32_t *np_f = n_persons ? n_persons + f * C : nullptr;
         const Kp3<TIn> *kpf = kp3 + f * (int64_t)R * J;
@@ -760,10 +768,11 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
                             const int m0 = l_start[cid];
                             double ssum = 0.0;
                             for (int base = 0; base < size; base += 64) ssum += base + lane < size ? l_sum[m0 + base + lane] : 0.0;
-                            const double avg = wave_sum(ssum) / ((double)size * (double)J);               // :150 from :79
+                            ssum = wave_sum(ssum);
+                            const double avg = ssum / ((double)size * (double)J);                         // :150 from :79
                             // (a sum that is not finite, or a mean within 1e-6 of the tolerance -- the fast sums of phase 1
-                            // are within 6e-8 -- is left to phase 3)
-                            if (!(fabs(avg) < 1e300) || fabs(avg - prm.score_tol) <= 1e-6 * fabs(avg)) {
+                            // are within 6e-8 -- is left to phase 3; a sum of exactly 0 is exact)
+                            if (!(fabs(avg) < 1e300) || (ssum != 0.0 && fabs(avg - prm.score_tol) <= 1e-6 * fabs(avg))) {
                                 ok = 0;
                                 break;
                             }
