@@ -149,6 +149,14 @@ struct snowtri_ctx {
         size_t lds = 0;
         int per_cu = -1;
     } recompute_occ[8];   // resident workgroups per CU of the k_frame_recompute instantiations (queried once per LDS size)
+    std::vector<std::pair<const void *, int>> lds_attr;   // kernels whose dynamic-LDS limit has been raised (and to what)
+    int raise_lds(const void *kern, int lds) {             // hipFuncSetAttribute once per (kernel, size), not once per launch
+        for (auto &e : lds_attr)
+            if (e.first == kern && e.second >= lds) return 0;
+        if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return 1;
+        lds_attr.emplace_back(kern, lds);
+        return 0;
+    }
     int64_t last_stream_slow = -1;   // frames the streaming association left to k_frame_recompute in the last call (-1: not used)
     Rig rig() const { return Rig{dM, dt, dpairs, dpairc, dP, C, npairs}; }
 };
@@ -1216,8 +1224,7 @@ int launch_cluster_fuse(snowtri_ctx *ctx, hipStream_t st, int64_t Fs, int Pmax, 
 
 // Launch shape of k_candidate_sums for a rig: threads per workgroup, LDS per workgroup, workgroups per CU.
 struct SumsLaunch {
-    int threads, lds, per_cu;
-    SumsGeom geo;
+    int threads, lds, per_cu, Jc;
 };
 SumsLaunch sums_launch_shape(const snowtri_ctx *ctx, int Pmax, int J) {
     const int C = ctx->C, gs = p1_group_size(Pmax);
@@ -1227,9 +1234,11 @@ SumsLaunch sums_launch_shape(const snowtri_ctx *ctx, int Pmax, int J) {
     L.threads = ctx->sums_threads > 0 ? ctx->sums_threads : (nitems <= 256 ? 256 : (nitems <= 768 ? 512 : 1024));
     L.threads = std::max(64, std::min(1024, (L.threads / 64) * 64));
     L.lds = ctx->sums_lds_kb > 0 ? ctx->sums_lds_kb * 1024 : (L.threads <= 256 ? 52 * 1024 : (L.threads <= 512 ? 80 * 1024 : 160 * 1024));
+    L.threads = L.threads <= 256 ? 256 : (L.threads <= 512 ? 512 : 1024);   // the instantiated shapes
     L.lds = std::min(L.lds, 160 * 1024);
     L.per_cu = std::max(1, std::min((160 * 1024) / L.lds, 2048 / L.threads));
-    L.geo = sums_geometry(C, Pmax, J, ctx->npairs, L.threads, L.lds);
+    const int pf = L.threads == 256 ? SumsShape<256>::kPrefetch : (L.threads == 512 ? SumsShape<512>::kPrefetch : SumsShape<1024>::kPrefetch);
+    L.Jc = sums_chunk_joints(C, Pmax, J, ctx->npairs, L.threads, pf, L.lds);
     return L;
 }
 
@@ -1271,7 +1280,7 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax
     bool stream = can_hand && ctx->handover_mode == 1 && C <= 16 && Kc < ((int64_t)1 << 24) && Pout <= 1024;
     if (stream) {
         SL = sums_launch_shape(ctx, Pmax, J);
-        stream = SL.geo.Jc >= 1;
+        stream = SL.Jc >= 1;
     }
     const bool handover = !stream && can_hand && ctx->handover_mode != 0 && C <= kClusterMaxCams;
     // the two descriptor lists hold Pout persons for every frame of a segment (<= 2 M entries each, 64 MB together), the
@@ -1284,7 +1293,8 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax
     if (stream) seg_frames = std::max<int64_t>(1, std::min<int64_t>(seg_frames, ((int64_t)64 << 20) / Kc));
     const int64_t seg_cap = ctx->handover_seg_frames > 0 ? ctx->handover_seg_frames : seg_frames;
     const int64_t seg = (stream || handover) ? std::min(seg_frames, seg_cap) : F;
-    unsigned long long *next_frame = ctx->d_counters + 2, *hand_counters = ctx->d_counters + 3, *slow_count = ctx->d_counters + 6;
+    unsigned long long *next_frame = ctx->d_counters + 2, *hand_counters = ctx->d_counters + 3, *slow_count = ctx->d_counters + 6,
+                       *exact_count = ctx->d_counters + 7;
     const unsigned long long jmagic = (((unsigned long long)1 << 40) + (unsigned long long)J - 1) / (unsigned long long)J;
     for (int64_t s0 = 0; s0 < F; s0 += seg) {
         const int64_t Fs = std::min<int64_t>(seg, F - s0);
@@ -1304,7 +1314,7 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax
             desc = (ClusterDesc *)ctx->desc.p;
             words = (uint32_t *)(desc + (size_t)2 * cap);
         }
-        HIP_TRY(hipMemsetAsync(next_frame, 0, 5 * sizeof(unsigned long long), st));   // next_frame, the three hand-over counters, slow frames
+        HIP_TRY(hipMemsetAsync(next_frame, 0, 6 * sizeof(unsigned long long), st));   // next_frame, the three hand-over counters, slow / exact frames
         const TIn *kp_seg = d_kpts + s0 * (int64_t)R * J * 3;
         const int32_t *np_seg = d_np ? d_np + s0 * C : nullptr;
         TOut *xyz_seg = d_xyzs + s0 * (int64_t)Pout * prm.kn * 4;
@@ -1314,27 +1324,31 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax
             if (stream) {
                 // ---- k_candidate_sums -> k_associate -> k_cluster_fuse, then k_frame_recompute on the frames left behind
                 const size_t sum_bytes = ((size_t)Fs * Kc * 8 + 255) & ~(size_t)255;
-                rc = ctx->sums.ensure(sum_bytes + (size_t)Fs * 4 + 256);
+                rc = ctx->sums.ensure(sum_bytes + (size_t)Fs * 8 + 256);   // + the frames left behind + the frames to re-do exactly
                 if (rc) return rc;
                 double *csum = (double *)ctx->sums.p;
                 uint32_t *slow_list = (uint32_t *)((char *)ctx->sums.p + sum_bytes);
-                auto k1 = k_candidate_sums<TIn>;
                 auto k2 = k_associate<TIn>;
                 const size_t lds2 = associate_lds_bytes(C, Pout, Kc);
-                if (SL.lds > 48 * 1024) HIP_TRY(hipFuncSetAttribute((const void *)k1, hipFuncAttributeMaxDynamicSharedMemorySize, SL.lds));
                 const int grid1 = (int)std::min<int64_t>(Fs, (int64_t)ctx->num_cus * SL.per_cu);
-                if (ctx->debug) {
-                    for (int kb = 48; kb <= 56; kb++) {
-                        int q = 0;
-                        (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, k1, SL.threads, (size_t)kb * 1024);
-                        fprintf(stderr, "  k_candidate_sums occupancy at %d KB LDS, %d threads: %d per CU\n", kb, SL.threads, q);
-                    }
-                }
                 if (ctx->debug)
-                    fprintf(stderr, "k_candidate_sums: threads %d lds %d per_cu %d grid %d GS %d JS %d Jc %d sums_in_lds %d | k_associate lds %zu\n",
-                            SL.threads, SL.lds, SL.per_cu, grid1, SL.geo.GS, SL.geo.JS, SL.geo.Jc, SL.geo.sum_bytes, lds2);
-                hipLaunchKernelGGL(k1, dim3(grid1), dim3(SL.threads), SL.lds, st, Fs, Pmax, J, (int)Kc, ctx->rig(), kp_seg, np_seg, prm, csum,
-                                   fl_seg, SL.lds);
+                    fprintf(stderr, "k_candidate_sums: threads %d lds %d per_cu %d grid %d Jc %d | k_associate lds %zu\n", SL.threads, SL.lds,
+                            SL.per_cu, grid1, SL.Jc, lds2);
+                uint32_t *exact_list = slow_list + Fs;
+#define SNOWTRI_SUMS(TT)                                                                                                             \
+    {                                                                                                                                \
+        auto k1 = k_candidate_sums<TIn, TT>;                                                                                         \
+        if (SL.lds > 48 * 1024 && ctx->raise_lds((const void *)k1, SL.lds)) return SNOWTRI_ERR_HIP;                                 \
+        hipLaunchKernelGGL(k1, dim3(grid1), dim3(TT), SL.lds, st, Fs, Pmax, J, (int)Kc, ctx->rig(), kp_seg, np_seg, prm, csum, fl_seg, \
+                           exact_list, exact_count, SL.lds);                                                                         \
+    }
+                if (SL.threads == 256) SNOWTRI_SUMS(256) else if (SL.threads == 512) SNOWTRI_SUMS(512) else SNOWTRI_SUMS(1024)
+#undef SNOWTRI_SUMS
+                HIP_TRY(hipGetLastError());
+                // the frames it listed (exact_count of them, known on the device only; normally none)
+                hipLaunchKernelGGL((k_candidate_sums_exact<TIn>), dim3((int)std::min<int64_t>(Fs, ctx->num_cus)), dim3(kBlock), 0, st, Pmax, J,
+                                   (int)Kc, ctx->rig(), kp_seg, np_seg, prm, csum, fl_seg, (const uint32_t *)exact_list,
+                                   (const unsigned long long *)exact_count);
                 HIP_TRY(hipGetLastError());
                 const int grid2 = (int)std::min<int64_t>(Fs, (int64_t)ctx->num_cus * ctx->assoc_wg_per_cu);
                 hipLaunchKernelGGL(k2, dim3(grid2), dim3(64), lds2, st, Fs, Pmax, J, (int)Kc, ctx->rig(), kp_seg, np_seg, prm, Pout, csum,

@@ -19,16 +19,20 @@
 namespace snowtri {
 
 // ---------------------------------------------------------------------------------------------- k_candidate_sums
-// LDS: [0, 320) flags + the list of candidates to re-do | per camera pair d = t_s - t_m and the two camera indices (32 B) |
-// ray matrices | arena = [candidate sums, if they fit] + one joint chunk of ray records (layout and bank map:
-// snowtri_general.hpp, p1_joint_stride).
-constexpr int kSumsHeadBytes = 320;
-constexpr int kSumsRedoMax = 64;            // candidates re-done one per lane; more than that: the whole frame exactly
-constexpr int kSumsPrefetch = 6;            // records of the next chunk a thread holds in registers
-constexpr int kSumsLdsSumBudget = 8 * 1024;
+// LDS: [0, 64) flags | n_persons of the frame (4 B x C) | per camera pair d = t_s - t_m and the two camera indices (32 B) |
+// ray matrices | arena = one joint chunk of ray records (layout and bank map: snowtri_general.hpp, p1_joint_stride); at
+// the end of a frame the arena holds the partial sums of the joint sub-ranges.
+constexpr int kSumsHeadBytes = 64;
+// workgroup shapes (threads, waves per SIMD the registers must allow, records of the next chunk a thread holds in
+// registers): 256 threads x 3 workgroups per CU for the small rigs, 512 x 2 or 1024 x 1 for the large ones
+template <int THREADS>
+struct SumsShape {
+    static constexpr int kWavesPerSimd = THREADS == 256 ? 3 : 4;
+    static constexpr int kPrefetch = THREADS == 256 ? 5 : 4;
+};
 
 __host__ __device__ inline size_t sums_arena_offset(int C, int npairs) {
-    return ((size_t)kSumsHeadBytes + (size_t)32 * npairs + (size_t)72 * C + 15) & ~(size_t)15;
+    return ((size_t)kSumsHeadBytes + (size_t)4 * C + (size_t)32 * npairs + (size_t)72 * C + 15) & ~(size_t)15;
 }
 // item = (camera pair, person of its first camera, group of GS persons of its second); JS = how many ways a chunk's
 // joints are split over the workgroup's NW waves when one pass over the items leaves waves idle (whole waves take a
@@ -39,239 +43,270 @@ __host__ __device__ inline int sums_joint_split(int nitems, int NW) {
     while (2 * js * iw <= NW) js *= 2;
     return js;
 }
-struct SumsGeom {
-    int GS, JS, sum_bytes, Jc;   // candidates per item (full frames), joint split, LDS bytes of the sums (0: global), joints per chunk
-};
-__host__ __device__ inline SumsGeom sums_geometry(int C, int Pmax, int J, int npairs, int threads, int lds_total) {
-    SumsGeom g;
-    const int R = C * Pmax, NW = threads / 64;
-    const long long kc = (long long)npairs * Pmax * Pmax;
-    g.GS = p1_group_size(Pmax);
-    g.JS = sums_joint_split((int)((kc / g.GS) > 0x3fffffff ? 0x3fffffff : (kc / g.GS)), NW);
-    if ((long long)g.JS * kc * 8 > kSumsLdsSumBudget) g.JS = 1;
-    g.sum_bytes = kc * 8 <= kSumsLdsSumBudget ? (int)(g.JS * kc * 8) : 0;
-    const int arena = lds_total - (int)sums_arena_offset(C, npairs) - g.sum_bytes;
+// joints per chunk: what the arena holds and the threads can prefetch, evened out over the chunks
+__host__ __device__ inline int sums_chunk_joints(int C, int Pmax, int J, int npairs, int threads, int prefetch, int lds_total) {
+    const int R = C * Pmax;
+    const int arena = lds_total - (int)sums_arena_offset(C, npairs);
     int cap = arena / p1_joint_stride(R);
-    const int pf = kSumsPrefetch * threads / R;   // every record of a chunk prefetched
+    const int pf = prefetch * threads / R;   // every record of a chunk prefetched
     if (cap > pf) cap = pf;
     if (cap > 64) cap = 64;
-    if (cap < 1) {
-        g.Jc = 0;
-        return g;
-    }
+    if (cap < 1) return 0;
     const int nch = (J + cap - 1) / cap;
-    g.Jc = (J + nch - 1) / nch;   // evened out: 133 joints -> 34 + 33 + 33 + 33, not 4 x 32 + 5
-    return g;
+    return (J + nch - 1) / nch;   // 133 joints -> 34 + 33 + 33 + 33, not 4 x 32 + 5
 }
 
 // csum[f][k] = sum over the joints of the score of candidate slot k (J x the mean of :79; 0 for a slot whose cameras
-// list fewer persons); out_flags[f] = SNOWTRI_FLAG_SINGULAR or 0.  Frames are dealt round-robin to the workgroups
-// (every frame costs the same here).  blockDim.x = 64 NW, a multiple of 64 up to 1024; dynamic LDS = lds_total.
-template <typename TIn>
-__global__ __launch_bounds__(1024) void k_candidate_sums(int64_t F, int Pmax, int J, int Kc, Rig rig,
-                                                         const TIn *__restrict__ kpts, const int32_t *__restrict__ n_persons,
-                                                         Params prm, double *__restrict__ csum, uint32_t *__restrict__ out_flags,
-                                                         int lds_total) {
+// list fewer persons), with the fast arithmetic of p1_item_sums; a frame with a candidate whose fast sum cannot decide
+// :80-81 -- not finite, or within 1e-6 relative of average_score_threshold -- is appended to exact_list and re-done by
+// k_candidate_sums_exact.  out_flags[f] = 0.  Frames are dealt round-robin to the workgroups (every frame costs the same
+// here).  Host-checked: keypoint_score_threshold >= 0.  Dynamic LDS = lds_total.
+//
+// Per frame: the items are dealt to the lanes once.  If one pass of the workgroup covers them (SINGLE: items x JS <=
+// threads -- 8 cameras x 4 persons: 112 items, two joint sub-ranges, 224 of 256 lanes) a lane keeps the sums of its GS
+// candidates in registers over all joint chunks; larger rigs walk the items in rounds and add a chunk's sums to csum
+// (loaded at the start of the round, stored at its end: in flight during the solves).
+template <typename TIn, int THREADS>
+__global__ __launch_bounds__(THREADS, SumsShape<THREADS>::kWavesPerSimd) void k_candidate_sums(
+    int64_t F, int Pmax, int J, int Kc, Rig rig, const TIn *__restrict__ kpts, const int32_t *__restrict__ n_persons, Params prm,
+    double *__restrict__ csum, uint32_t *__restrict__ out_flags, uint32_t *__restrict__ exact_list, unsigned long long *exact_count,
+    int lds_total) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63, B = blockDim.x, NW = B >> 6;
+    constexpr int B = THREADS, NW = THREADS / 64, NPF = SumsShape<THREADS>::kPrefetch;
+    const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int C = rig.C, R = C * Pmax, pp = Pmax * Pmax;
-    int32_t *head = reinterpret_cast<int32_t *>(smem);          // [0] re-do count, [1] singular, [2] ragged; [16..80) re-do list
-    int32_t *redo_list = head + 16;
-    double *paird = reinterpret_cast<double *>(smem + kSumsHeadBytes);      // [npairs][3]
+    int32_t *head = reinterpret_cast<int32_t *>(smem);          // [0] a candidate needs the exact sum, [1] ragged frame
+    int32_t *np_l = reinterpret_cast<int32_t *>(smem + kSumsHeadBytes);    // [C] persons listed by the cameras in this frame
+    double *paird = reinterpret_cast<double *>(np_l + C + (C & 1));        // [npairs][3]
     int32_t *pairs = reinterpret_cast<int32_t *>(paird + 3 * rig.npairs);  // [npairs][2]
     double *Ml = reinterpret_cast<double *>(pairs + 2 * rig.npairs);
     for (int i = tid; i < 3 * rig.npairs; i += B) paird[i] = rig.pairc[6 * (i / 3) + i % 3];
     for (int i = tid; i < 2 * rig.npairs; i += B) pairs[i] = rig.pairs[i];
     for (int i = tid; i < 9 * C; i += B) Ml[i] = rig.M[i];
-    const SumsGeom geo = sums_geometry(C, Pmax, J, rig.npairs, B, lds_total);
-    char *arena = smem + sums_arena_offset(C, rig.npairs);
-    double *lsum = reinterpret_cast<double *>(arena);           // [JS][Kc] raw sums (2000 x the score of :72) if sum_bytes
-    char *rec = arena + geo.sum_bytes;
-    const int jstr = p1_joint_stride(R), Jc = geo.Jc, JS = geo.JS;
-    const bool acc_lds = geo.sum_bytes != 0;
-    const bool exact_only = prm.kthr < 0.0;   // negative scores may pass the keypoint gate: no relative error bound on a sum
+    char *rec = smem + sums_arena_offset(C, rig.npairs);
+    double *lsum = reinterpret_cast<double *>(rec);             // [JS][Kc] at the end of a SINGLE frame
+    const int arena_bytes = lds_total - (int)sums_arena_offset(C, rig.npairs);
+    const int jstr = p1_joint_stride(R), Jc = sums_chunk_joints(C, Pmax, J, rig.npairs, B, NPF, lds_total);
     const unsigned long long magic_pmax = (((unsigned long long)1 << 40) + (unsigned)Pmax - 1) / (unsigned)Pmax;
-    const unsigned long long magic_pp = (((unsigned long long)1 << 40) + (unsigned)pp - 1) / (unsigned)pp;
     const Kp3<TIn> *kp3 = reinterpret_cast<const Kp3<TIn> *>(kpts);
 
     for (int64_t f = blockIdx.x; f < F; f += gridDim.x) {
         const int32_t *np_f = n_persons ? n_persons + f * C : nullptr;
         const Kp3<TIn> *kpf = kp3 + f * (int64_t)R * J;
         double *cs_f = csum + f * (int64_t)Kc;
-        if (tid == 0) head[0] = head[1] = head[2] = 0;
+        if (tid == 0) head[0] = head[1] = 0;
         __syncthreads();   // (also: the previous frame's readers of the arena are done)
-        if (np_f) {
-            bool rg = false;
-            for (int c = tid; c < C; c += B) rg |= np_f[c] != Pmax;
-            if (rg) head[2] = 1;
+        for (int c = tid; c < C; c += B) {
+            const int v = np_f ? np_f[c] : Pmax;
+            np_l[c] = v;
+            if (v != Pmax) head[1] = 1;
         }
-        // candidate slot k -> valid?  (candidate order of triangulation.py:56-65: camera pair, person of the first camera,
-        // person of the second)
-        auto slot_rows = [&](int k, int &rm, int &rs, int &q) -> bool {
-            q = (int)(((unsigned long long)(unsigned)k * magic_pp) >> 40);
-            const int rr = k - q * pp, pm = (int)(((unsigned long long)(unsigned)rr * magic_pmax) >> 40), ps = rr - pm * Pmax;
-            const int mc = pairs[2 * q], sc = pairs[2 * q + 1];
-            rm = mc * Pmax + pm;
-            rs = sc * Pmax + ps;
-            return !np_f || (pm < np_f[mc] && ps < np_f[sc]);
-        };
-        auto acc_get = [&](int idx) -> double { return acc_lds ? lsum[idx] : cs_f[idx]; };
-        auto acc_put = [&](int idx, double v) {
-            if (acc_lds)
-                lsum[idx] = v;
-            else
-                cs_f[idx] = v;
-        };
-        for (int k = tid; k < (acc_lds ? JS * Kc : Kc); k += B) acc_put(k, 0.0);
 
         // ---- the records of a joint chunk: keypoints fetched into registers (one chunk ahead), then ray + |h|^2 + score
         // into LDS.  Lanes = consecutive joints of a row: coalesced 12-byte reads.  Rows a camera does not list are
         // filled with whatever the buffer holds: no valid candidate reads them.
-        Kp3<TIn> pre[kSumsPrefetch];
-        int pre_off[kSumsPrefetch];   // LDS byte offset of the record | camera << 20, or -1
+        Kp3<TIn> pre[NPF];
+        int pre_off[NPF];   // LDS byte offset of the record | camera << 20, or -1
         auto fetch = [&](int j0, int nj) {
             const unsigned long long magic_nj = (((unsigned long long)1 << 40) + (unsigned)nj - 1) / (unsigned)nj;
 #pragma unroll
-            for (int n = 0; n < kSumsPrefetch; n++) {
-                const int i = tid + n * B;
-                pre_off[n] = -1;
-                if (i < R * nj) {
-                    const int r = (int)(((unsigned long long)(unsigned)i * magic_nj) >> 40), jj = i - r * nj;
-                    const int c = (int)(((unsigned long long)(unsigned)r * magic_pmax) >> 40);
-                    pre[n] = kpf[(size_t)r * J + j0 + jj];
-                    pre_off[n] = (jj * jstr + kP1Rec * r) | (c << 20);
-                }
+            for (int n = 0; n < NPF; n++) {
+                // (every slot loads, past the chunk's end the last record again: a load inside a branch would have to be
+                // waited for where the branch joins)
+                const int i = tid + n * B, ic = i < R * nj ? i : R * nj - 1;
+                const int r = (int)(((unsigned long long)(unsigned)ic * magic_nj) >> 40), jj = ic - r * nj;
+                const int c = (int)(((unsigned long long)(unsigned)r * magic_pmax) >> 40);
+                pre[n] = kpf[(size_t)r * J + j0 + jj];
+                pre_off[n] = i < R * nj ? ((jj * jstr + kP1Rec * r) | (c << 20)) : -1;
             }
         };
         auto commit = [&]() {
 #pragma unroll
-            for (int n = 0; n < kSumsPrefetch; n++)
+            for (int n = 0; n < NPF; n++)
                 if (pre_off[n] >= 0)
                     p1_store_record<TIn>(rec + (pre_off[n] & 0xfffff), make_ray(Ml + 9 * (pre_off[n] >> 20), pre[n].u, pre[n].v), pre[n].s);
         };
+        fetch(0, J < Jc ? J : Jc);
         __syncthreads();
-        const int GS = head[2] ? 1 : geo.GS;   // a ragged frame keeps one candidate per lane
+        const int GS = head[1] ? 1 : p1_group_size(Pmax);   // a ragged frame keeps one candidate per lane
         const int NG = Pmax / GS, per_q = Pmax * NG, nitems = rig.npairs * per_q;
+        int JS = sums_joint_split(nitems, NW);
+        const bool single = nitems * JS <= B && (size_t)JS * Kc * 8 <= (size_t)arena_bytes;
+        if (!single) JS = 1;
         const int wpg = NW / JS;               // waves that share a joint sub-range
         const int jsub = wv / wpg, iw = wv - jsub * wpg;
         const unsigned long long magic_pq = (((unsigned long long)1 << 40) + (unsigned)per_q - 1) / (unsigned)per_q;
         const unsigned long long magic_ng = (((unsigned long long)1 << 40) + (unsigned)NG - 1) / (unsigned)NG;
-        bool sing = false;
+        if (!single)
+            for (int k = tid; k < Kc; k += B) cs_f[k] = 0.0;
 
-        if (!exact_only) {
-            fetch(0, J < Jc ? J : Jc);
+        // one loop nest per (candidates per item, SINGLE): the variants share no registers with loads in flight
+        auto frame_body = [&](auto gs_c, auto single_c) {
+            constexpr int GSC = decltype(gs_c)::value;
+            constexpr bool SINGLE = decltype(single_c)::value;
+            // item of (round base, lane) -> first candidate slot, record offsets of its rows, pair offset; live?
+            struct Item {
+                int k0, oa, ob;
+                Vec3 d;
+                bool cand;
+            };
+            auto locate = [&](int base) {
+                Item t;
+                const int item = base + lane;
+                const bool live = item < nitems;
+                const int it = live ? item : 0;
+                const int q = (int)(((unsigned long long)(unsigned)it * magic_pq) >> 40), r2 = it - q * per_q;
+                const int pm = (int)(((unsigned long long)(unsigned)r2 * magic_ng) >> 40), ps0 = (r2 - pm * NG) * GSC;
+                const int mc = pairs[2 * q], sc = pairs[2 * q + 1];
+                const double *pc = paird + 3 * q;
+                t.k0 = q * pp + pm * Pmax + ps0;
+                t.oa = kP1Rec * (mc * Pmax + pm);
+                t.ob = kP1Rec * (sc * Pmax + ps0);
+                t.d = {pc[0], pc[1], pc[2]};
+                t.cand = live;
+                if constexpr (GSC == 1) t.cand = live && pm < np_l[mc] && ps0 < np_l[sc];   // empty slots stay at 0
+                return t;
+            };
+            Item mine{};
+            double tot[GSC];
+            if constexpr (SINGLE) {
+                mine = locate(iw * 64);
+#pragma unroll
+                for (int u = 0; u < GSC; u++) tot[u] = 0.0;
+            }
             for (int j0 = 0; j0 < J; j0 += Jc) {
                 const int nj = (J - j0) < Jc ? (J - j0) : Jc;
                 if (j0) __syncthreads();   // the previous chunk's solves are done
+#ifndef SNOWTRI_K1_NOFILL   // dev experiment (timing only, outputs are wrong)
                 commit();
+#endif
                 __syncthreads();
-                if (j0 + Jc < J) fetch(j0 + Jc, (J - j0 - Jc) < Jc ? (J - j0 - Jc) : Jc);   // in flight during the solves
-                // the waves of joint sub-range jsub walk joints [jlo, jhi) of the chunk; item = base + lane of the round
+                // the next chunk's keypoints: in flight during the solves.  (Rounds: issued behind the first round's loads
+                // of csum -- the memory counter is in order, and those loads are waited for at the end of the round.)
+                bool fetched = false;
+                auto fetch_next = [&]() {
+#ifndef SNOWTRI_K1_NOFILL
+                    if (!fetched && j0 + Jc < J) fetch(j0 + Jc, (J - j0 - Jc) < Jc ? (J - j0 - Jc) : Jc);
+#endif
+                    fetched = true;
+                };
+                if constexpr (SINGLE) fetch_next();
+                // the waves of joint sub-range jsub walk joints [jlo, jhi) of the chunk
+#ifdef SNOWTRI_K1_NOSOLVE   // dev experiment (timing only, outputs are wrong)
+                const int jlo = 0, jhi = 0;
+#else
                 const int jlo = jsub * nj / JS, jhi = (jsub + 1) * nj / JS;
-                for (int base = iw * 64; base < nitems; base += wpg * 64) {
-                    const int item = base + lane;
-                    const bool live = item < nitems;
-                    const int it = live ? item : 0;
-                    const int q = (int)(((unsigned long long)(unsigned)it * magic_pq) >> 40), r2 = it - q * per_q;
-                    const int pm = (int)(((unsigned long long)(unsigned)r2 * magic_ng) >> 40), ps0 = (r2 - pm * NG) * GS;
-                    const int k0 = q * pp + pm * Pmax + ps0;
-                    const int mc = pairs[2 * q], sc = pairs[2 * q + 1];
-                    const int rm = mc * Pmax + pm, rs0 = sc * Pmax + ps0;
-                    const double *pc = paird + 3 * q;
-                    const Vec3 d = {pc[0], pc[1], pc[2]};
-                    const char *pa = rec + jlo * jstr + kP1Rec * rm, *pb = rec + jlo * jstr + kP1Rec * rs0;
-                    const int dst = jsub * Kc + k0;
-                    if (GS == 4) {
-                        double old[4], acc[4] = {0.0, 0.0, 0.0, 0.0};
+#endif
+                if constexpr (SINGLE) {
+                    p1_item_sums<GSC, TIn>(rec + jlo * jstr + mine.oa, rec + jlo * jstr + mine.ob, jstr, mine.cand ? jhi - jlo : 0, mine.d, prm, tot);
+                } else {
+                    for (int base = iw * 64; base < nitems; base += wpg * 64) {
+                        const Item t = locate(base);
+                        double old[GSC], acc[GSC];
 #pragma unroll
-                        for (int u = 0; u < 4; u++) old[u] = live ? acc_get(dst + u) : 0.0;   // (in flight during the solves)
-                        p1_item_sums<4, TIn>(pa, pb, jstr, live ? jhi - jlo : 0, d, prm, acc);
-                        if (live) {
-#pragma unroll
-                            for (int u = 0; u < 4; u++) acc_put(dst + u, old[u] + acc[u]);
+                        for (int u = 0; u < GSC; u++) {
+                            acc[u] = 0.0;
+                            old[u] = t.cand ? cs_f[t.k0 + u] : 0.0;   // (in flight during the solves)
                         }
-                    } else if (GS == 2) {
-                        double old[2], acc[2] = {0.0, 0.0};
+                        fetch_next();
+                        p1_item_sums<GSC, TIn>(rec + jlo * jstr + t.oa, rec + jlo * jstr + t.ob, jstr, t.cand ? jhi - jlo : 0, t.d, prm, acc);
+                        if (t.cand) {
 #pragma unroll
-                        for (int u = 0; u < 2; u++) old[u] = live ? acc_get(dst + u) : 0.0;
-                        p1_item_sums<2, TIn>(pa, pb, jstr, live ? jhi - jlo : 0, d, prm, acc);
-                        if (live) {
-#pragma unroll
-                            for (int u = 0; u < 2; u++) acc_put(dst + u, old[u] + acc[u]);
+                            for (int u = 0; u < GSC; u++) cs_f[t.k0 + u] = old[u] + acc[u];
                         }
-                    } else {
-                        const bool cand = live && (!np_f || (pm < np_f[mc] && ps0 < np_f[sc]));   // empty slots stay at 0
-                        double acc[1] = {0.0};
-                        const double old = cand ? acc_get(dst) : 0.0;
-                        p1_item_sums<1, TIn>(pa, pb, jstr, cand ? jhi - jlo : 0, d, prm, acc);
-                        if (cand) acc_put(dst, old + acc[0]);
                     }
+                    fetch_next();   // (a wave without items)
                 }
             }
-            // the 1 / (2 * 1000) of :72 and the JS partial sums; candidates whose fast sum cannot decide :80-81 (see
-            // p1_item_sums) -- not finite, or within 1e-6 relative of average_score_threshold -- are listed for the exact sweep
-            __syncthreads();
-            for (int k = tid; k < Kc; k += B) {
-                double v = acc_get(k);
-                for (int s_ = 1; s_ < JS; s_++) v += acc_get(s_ * Kc + k);
-                const double s_ = v * 0.0005, mean = s_ / (double)J;
-                cs_f[k] = s_;
-                if (!(fabs(mean) < 1e300) || (s_ != 0.0 && fabs(mean - prm.avg_thr) <= 1e-6 * fabs(mean))) {
-                    const int at = atomicAdd(&head[0], 1);
-                    if (at < kSumsRedoMax) redo_list[at] = k;
+            if constexpr (SINGLE) {   // the partial sums of the joint sub-ranges meet in the arena
+                __syncthreads();
+                for (int k = tid; k < JS * Kc; k += B) lsum[k] = 0.0;
+                __syncthreads();
+                if (mine.cand) {
+#pragma unroll
+                    for (int u = 0; u < GSC; u++) lsum[jsub * Kc + mine.k0 + u] = tot[u];
                 }
             }
-            __syncthreads();
+        };
+        if (single) {
+            if (GS == 4)
+                frame_body(std::integral_constant<int, 4>{}, std::true_type{});
+            else if (GS == 2)
+                frame_body(std::integral_constant<int, 2>{}, std::true_type{});
+            else
+                frame_body(std::integral_constant<int, 1>{}, std::true_type{});
+        } else {
+            if (GS == 4)
+                frame_body(std::integral_constant<int, 4>{}, std::false_type{});
+            else if (GS == 2)
+                frame_body(std::integral_constant<int, 2>{}, std::false_type{});
+            else
+                frame_body(std::integral_constant<int, 1>{}, std::false_type{});
         }
-        // ---- exact sweep (rare): the listed candidates one per lane, or every candidate of the frame
-        const int nredo = exact_only ? kSumsRedoMax + 1 : head[0];
-        if (nredo) {
-            const bool all = nredo > kSumsRedoMax;
-            int my_k = -1, rm = 0, rs = 0, q = 0;
+        // the 1 / (2 * 1000) of :72 (and the JS partial sums of a SINGLE frame)
+        __syncthreads();
+        bool redo = false;
+        for (int k = tid; k < Kc; k += B) {
+            double v;
+            if (single) {
+                v = lsum[k];
+                for (int s_ = 1; s_ < JS; s_++) v += lsum[s_ * Kc + k];
+            } else {
+                v = cs_f[k];
+            }
+            const double s_ = v * 0.0005, mean = s_ / (double)J;
+            cs_f[k] = s_;
+            redo |= !(fabs(mean) < 1e300) || (s_ != 0.0 && fabs(mean - prm.avg_thr) <= 1e-6 * fabs(mean));
+        }
+        if (redo) head[0] = 1;
+        __syncthreads();
+        if (tid == 0) {
+            if (out_flags) out_flags[f] = 0u;
+            if (head[0]) exact_list[atomicAdd(exact_count, 1ull)] = (uint32_t)f;
+        }
+    }
+}
+
+// The frames k_candidate_sums listed: every candidate sum again with the accurate arithmetic (1/dist by v_rsq_f64 + one
+// Newton step, exact intersection -> inf, the gate assigns 0 AFTER the product as :72-74 do; singular pairs flagged).
+// One workgroup per listed frame, one wave per candidate slot, lanes = joints; keypoints straight from global memory.
+template <typename TIn>
+__global__ __launch_bounds__(kBlock) void k_candidate_sums_exact(int Pmax, int J, int Kc, Rig rig, const TIn *__restrict__ kpts,
+                                                                 const int32_t *__restrict__ n_persons, Params prm,
+                                                                 double *__restrict__ csum, uint32_t *__restrict__ out_flags,
+                                                                 const uint32_t *__restrict__ exact_list,
+                                                                 const unsigned long long *__restrict__ exact_count) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int C = rig.C, R = C * Pmax, pp = Pmax * Pmax;
+    const Kp3<TIn> *kp3 = reinterpret_cast<const Kp3<TIn> *>(kpts);
+    const unsigned long long n = *exact_count;
+    for (unsigned long long e = blockIdx.x; e < n; e += gridDim.x) {
+        const int64_t f = (int64_t)exact_list[e];
+        const int32_t *np_f = n_persons ? n_persons + f * C : nullptr;
+        const Kp3<TIn> *kpf = kp3 + f * (int64_t)R * J;
+        bool sing = false;
+        for (int k = wv; k < Kc; k += kBlock / 64) {
+            const int q = k / pp, rr = k - q * pp, pm = rr / Pmax, ps = rr - pm * Pmax;
+            const int mc = rig.pairs[2 * q], sc = rig.pairs[2 * q + 1];
             double acc = 0.0;
-            if (!all && tid < nredo) {
-                my_k = redo_list[tid];
-                slot_rows(my_k, rm, rs, q);
-            }
-            if (all)
-                for (int k = tid; k < Kc; k += B) cs_f[k] = 0.0;
-            for (int j0 = 0; j0 < J; j0 += Jc) {
-                const int nj = (J - j0) < Jc ? (J - j0) : Jc;
-                __syncthreads();
-                for (int i0 = 0; i0 < R * nj; i0 += kSumsPrefetch * B) {
-                    const unsigned long long magic_nj = (((unsigned long long)1 << 40) + (unsigned)nj - 1) / (unsigned)nj;
-                    for (int i = i0 + tid; i < R * nj && i < i0 + kSumsPrefetch * B; i += B) {
-                        const int r = (int)(((unsigned long long)(unsigned)i * magic_nj) >> 40), jj = i - r * nj;
-                        const int c = (int)(((unsigned long long)(unsigned)r * magic_pmax) >> 40);
-                        const Kp3<TIn> kp = kpf[(size_t)r * J + j0 + jj];
-                        p1_store_record<TIn>(rec + jj * jstr + kP1Rec * r, make_ray(Ml + 9 * c, kp.u, kp.v), kp.s);
-                    }
-                }
-                __syncthreads();
-                if (all) {
-                    for (int k = tid; k < Kc; k += B) {
-                        int rm2, rs2, q2;
-                        if (!slot_rows(k, rm2, rs2, q2)) continue;
-                        const double *pc = paird + 3 * q2;
-                        cs_f[k] += candidate_chunk_sum_exact<TIn>(rec + kP1Rec * rm2, rec + kP1Rec * rs2, jstr, nj,
-                                                                  Vec3{pc[0], pc[1], pc[2]}, prm, sing);
-                    }
-                } else if (my_k >= 0) {
-                    const double *pc = paird + 3 * q;
-                    acc += candidate_chunk_sum_exact<TIn>(rec + kP1Rec * rm, rec + kP1Rec * rs, jstr, nj, Vec3{pc[0], pc[1], pc[2]},
-                                                          prm, sing);
+            if (!np_f || (pm < np_f[mc] && ps < np_f[sc])) {
+                const double *pc = rig.pairc + 6 * q;
+                const Vec3 d = {pc[0], pc[1], pc[2]}, ts = {pc[3], pc[4], pc[5]};
+                for (int j = lane; j < J; j += 64) {
+                    const Kp3<TIn> km = kpf[(size_t)(mc * Pmax + pm) * J + j], ks = kpf[(size_t)(sc * Pmax + ps) * J + j];
+                    const RayRec a = make_ray(rig.M + 9 * mc, km.u, km.v), b = make_ray(rig.M + 9 * sc, ks.u, ks.v);
+                    const PairSolve o = pair_solve_fast<false>(a, b, d, ts);
+                    sing |= o.singular;
+                    const bool kp_ = !below_kthr(km.s, prm) && !below_kthr(ks.s, prm) && !(o.d2 > prm.dthr2);   // :73-74
+                    // the gate ASSIGNS 0: select after the product, 0 * inf (exact intersection) would be NaN
+                    acc += kp_ ? sum_score(km.s, ks.s) * (0.5 * o.score_base) : 0.0;                             // :72
                 }
             }
-            if (all) {
-                for (int k = tid; k < Kc; k += B) cs_f[k] *= 0.0005;
-            } else if (my_k >= 0) {
-                cs_f[my_k] = acc * 0.0005;
-            }
-            if (sing) head[1] = 1;
-            __syncthreads();
+            acc = wave_sum(acc);
+            if (lane == 0) csum[f * (int64_t)Kc + k] = acc;
         }
-        if (tid == 0 && out_flags) out_flags[f] = head[1] ? 1u /*SNOWTRI_FLAG_SINGULAR*/ : 0u;
+        if (sing && out_flags) atomicOr(&out_flags[f], 1u /*SNOWTRI_FLAG_SINGULAR*/);
     }
 }
 
