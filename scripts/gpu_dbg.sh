@@ -1,5 +1,3 @@
 #!/bin/bash
-for so in snowmocap_amd/csrc/ab/libsnowtri_*.so; do
-  echo "== $so"
-  SNOWTRI_LIB=$PWD/$so bash scripts/gpu_multi_stats.sh 3 2>&1 | grep "snowtri::k_cand"
-done
+timeout 1500 python -m pytest tests -x -q -m gpu 2>&1 | grep "passed\|failed\|Error\|error" | tail -5
+python scripts/bench_configs.py --full --no-oracle 2>&1 | grep "^{" | cut -c1-120

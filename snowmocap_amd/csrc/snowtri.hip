@@ -1329,7 +1329,7 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax
                 double *csum = (double *)ctx->sums.p;
                 uint32_t *slow_list = (uint32_t *)((char *)ctx->sums.p + sum_bytes);
                 auto k2 = k_associate<TIn>;
-                const size_t lds2 = associate_lds_bytes(C, Pout, Kc);
+                const size_t lds2 = associate_lds_bytes(C, ctx->npairs, Pout, Kc);
                 const int grid1 = (int)std::min<int64_t>(Fs, (int64_t)ctx->num_cus * SL.per_cu);
                 if (ctx->debug)
                     fprintf(stderr, "k_candidate_sums: threads %d lds %d per_cu %d grid %d Jc %d | k_associate lds %zu\n", SL.threads, SL.lds,

@@ -311,10 +311,12 @@ __global__ __launch_bounds__(kBlock) void k_candidate_sums_exact(int Pmax, int J
 }
 
 // ---------------------------------------------------------------------------------------------------- k_associate
-// One WAVE per frame (64-thread workgroups dealt round-robin): phases 2 and the filters of k_frame_recompute on the
-// candidate sums of k_candidate_sums, every step a few dependent loads -- hidden by the thousands of frames in flight
-// instead of by the three idle waves of a frame's workgroup.  Per frame:
-//   kept list in candidate order (:79-81) -> centre joints (one fast solve per kept candidate) -> greedy clustering
+// One WAVE per frame (64-thread workgroups dealt round-robin): phase 2 and the filters of k_frame_recompute on the
+// candidate sums of k_candidate_sums.  Every step is a handful of dependent loads: they are hidden by the thousands of
+// frames in flight, and everything a frame needs more than once is fetched ONCE, by all lanes in parallel, into LDS.
+// Per frame:
+//   kept list in candidate order (:79-81; eight 64-candidate loads of csum in flight at a time) -> per kept candidate, in
+//   parallel: its ray rows + camera pair (one word), its score sum, its centre joint (one fast solve) -> greedy clustering
 //   (:107-130) -> members grouped by cluster -> per cluster the size filter (:132-134) and the mean-score filter
 //   (:150-152; a person's mean score is the mean of its members' candidate means because keypoint_num == J) ->
 //   out_count, out_pscore, zero-filled unused slots, and one descriptor per output person: a cluster that is the
@@ -323,19 +325,23 @@ __global__ __launch_bounds__(kBlock) void k_candidate_sums_exact(int Pmax, int J
 // A frame whose decisions are not safe here -- a mean that is not finite or within 1e-6 of condense_score_tol, more kept
 // candidates or clusters than the wave's LDS holds -- is appended to slow_list and left to k_frame_recompute.
 // LDS: [0, 64) scalars | staging of the output persons (~24 B each) | rows of the cameras (complete-graph test, 4 B x C) |
-// arena: kept index (4 B), cluster id (4 B), centre (24 B) per kept candidate, then 12 B per cluster.
-__host__ __device__ inline size_t associate_arena_offset(int C, int Pout) {
+// camera indices of the pairs (8 B each) | arena: kept index, cluster id, word (4 B each), score sum (8 B), centre (24 B)
+// per kept candidate, then 12 B per cluster.
+__host__ __device__ inline size_t associate_arena_offset(int C, int npairs, int Pout) {
     const size_t pq = ((size_t)Pout * 4 + 15) & ~(size_t)15;   // four 4-byte arrays padded to 16 bytes + one of doubles
-    return ((size_t)64 + 4 * pq + (size_t)8 * Pout + (size_t)4 * C + 15) & ~(size_t)15;
+    return ((size_t)64 + 4 * pq + (size_t)8 * Pout + (size_t)4 * C + (size_t)8 * npairs + 15) & ~(size_t)15;
 }
-__host__ inline size_t associate_lds_bytes(int C, int Pout, int64_t Kc) {
-    const size_t want = associate_arena_offset(C, Pout) + (size_t)44 * (size_t)(Kc < 256 ? Kc : (Kc / 4 < 256 ? 256 : Kc / 4)) + 64;
+constexpr int kAssocKeptBytes = 44;
+__host__ inline size_t associate_lds_bytes(int C, int npairs, int Pout, int64_t Kc) {
+    // room for every slot of a small rig, for a quarter of the slots (>= 256) of a large one: the reference's own
+    // workloads keep 25 % (8 x 4) and 13 % (16 x 8) of their candidates
+    const size_t want = associate_arena_offset(C, npairs, Pout) + (size_t)(kAssocKeptBytes + 6) * (size_t)(Kc < 256 ? Kc : (Kc / 4 < 256 ? 256 : Kc / 4)) + 64;
     const size_t cap = 48 * 1024;
     return want > cap ? cap : (want < 4096 ? 4096 : want);
 }
 
 template <typename TIn>
-__global__ __launch_bounds__(64) void k_associate(int64_t F, int Pmax, int J, int Kc, Rig rig, const TIn *__restrict__ kpts,
+__global__ __launch_bounds__(64, 4) void k_associate(int64_t F, int Pmax, int J, int Kc, Rig rig, const TIn *__restrict__ kpts,
                                                   const int32_t *__restrict__ n_persons, Params prm, int Pout,
                                                   const double *__restrict__ csum, float *__restrict__ out4,
                                                   float *__restrict__ out_ps, int32_t *__restrict__ out_count,
@@ -353,16 +359,18 @@ __global__ __launch_bounds__(64) void k_associate(int64_t F, int Pmax, int J, in
     uint32_t *st_idx = reinterpret_cast<uint32_t *>(smem + 64 + 2 * pq);  // [Pout] index inside its descriptor list
     uint32_t *st_word = reinterpret_cast<uint32_t *>(smem + 64 + 3 * pq); // [Pout] persons (high word) | offset of its member words
     double *st_avg = reinterpret_cast<double *>(smem + 64 + 4 * pq);      // [Pout]
-    const int arena_off = (int)associate_arena_offset(C, Pout);
-    int32_t *rowc = reinterpret_cast<int32_t *>(smem + arena_off) - C;     // [C] (just below the arena)
+    int32_t *rowc = reinterpret_cast<int32_t *>(st_avg + Pout);           // [C]
+    int32_t *pairs = rowc + C;                                            // [npairs][2]
+    const int arena_off = (int)associate_arena_offset(C, NPq, Pout);
     char *arena = smem + arena_off;
     const int arena_bytes = lds_total - arena_off;
-    const int n_cap = arena_bytes > 64 ? (arena_bytes - 64) / 32 : 0;
+    const int n_cap = arena_bytes > 64 ? (arena_bytes - 64) / kAssocKeptBytes : 0;
     const unsigned long long magic_pmax = (((unsigned long long)1 << 40) + (unsigned)Pmax - 1) / (unsigned)Pmax;
     const unsigned long long magic_pp = (((unsigned long long)1 << 40) + (unsigned)pp - 1) / (unsigned)pp;
     const Kp3<TIn> *kp3 = reinterpret_cast<const Kp3<TIn> *>(kpts);
     const PackedWriter<float> wr{out4, out_ps};
     const int kn = prm.kn;   // == J (host-checked)
+    for (int i = lane; i < 2 * NPq; i += 64) pairs[i] = rig.pairs[i];
 
     for (int64_t f = blockIdx.x; f < F; f += gridDim.x) {
         const int32_t *np_f = n_persons ? n_persons + f * C : nullptr;
@@ -372,13 +380,13 @@ __global__ __launch_bounds__(64) void k_associate(int64_t F, int Pmax, int J, in
         auto slot_rows = [&](int k, int &rm, int &rs, int &q) -> bool {
             q = (int)(((unsigned long long)(unsigned)k * magic_pp) >> 40);
             const int rr = k - q * pp, pm = (int)(((unsigned long long)(unsigned)rr * magic_pmax) >> 40), ps = rr - pm * Pmax;
-            const int mc = rig.pairs[2 * q], sc = rig.pairs[2 * q + 1];
+            const int mc = pairs[2 * q], sc = pairs[2 * q + 1];
             rm = mc * Pmax + pm;
             rs = sc * Pmax + ps;
             return !np_f || (pm < np_f[mc] && ps < np_f[sc]);
         };
         bool slow = false;   // wave-uniform
-        __syncthreads();     // (the previous frame's LDS is dead)
+        __syncthreads();     // (the previous frame's LDS is dead; the pair table is there)
         bool ragged = false;
         if (np_f) {
             bool rg = false;
@@ -388,92 +396,109 @@ __global__ __launch_bounds__(64) void k_associate(int64_t F, int Pmax, int J, in
         // ---- kept list in candidate order (:79-81)
         int32_t *kidx = reinterpret_cast<int32_t *>(arena);
         int n = 0;
-        for (int base = 0; base < Kc; base += 64) {
-            const int k = base + lane;
-            bool kp_ = k < Kc;
-            const double s_ = kp_ ? cs_f[k] : 0.0;
-            if (kp_ && ragged) {
-                int rm, rs, q;
-                kp_ = slot_rows(k, rm, rs, q);
+        for (int base0 = 0; base0 < Kc && !slow; base0 += 512) {
+            double v[8];
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int k = base0 + 64 * u + lane;
+                v[u] = k < Kc ? cs_f[k] : 0.0;
             }
-            kp_ = kp_ && !(s_ / (double)J < prm.avg_thr);
-            const unsigned long long m = __ballot(kp_);
-            const int cnt = __popcll(m);
-            if (n + cnt > n_cap) {
-                slow = true;
-                break;
+#pragma unroll
+            for (int u = 0; u < 8; u++) {
+                const int k = base0 + 64 * u + lane;
+                bool kp_ = k < Kc;
+                if (kp_ && ragged) {
+                    int rm, rs, q;
+                    kp_ = slot_rows(k, rm, rs, q);
+                }
+                kp_ = kp_ && !(v[u] / (double)J < prm.avg_thr);
+                const unsigned long long m = __ballot(kp_);
+                const int cnt = __popcll(m);
+                if (n + cnt > n_cap) slow = true;
+                if (kp_ && !slow) kidx[n + __popcll(m & ((1ull << lane) - 1ull))] = k;
+                n += cnt;
             }
-            if (kp_) kidx[n + __popcll(m & ((1ull << lane) - 1ull))] = k;
-            n += cnt;
         }
         int nout = 0;
         if (!slow) {
             int32_t *cof = kidx + n;
-            double *cen = reinterpret_cast<double *>(arena + (((size_t)n * 8 + 15) & ~(size_t)15));
+            uint32_t *lword = reinterpret_cast<uint32_t *>(cof + n);
+            double *lsum = reinterpret_cast<double *>(arena + (((size_t)n * 12 + 15) & ~(size_t)15));
+            double *cen = lsum + n;
             int32_t *csize = reinterpret_cast<int32_t *>(cen + 3 * (size_t)n);
             const int ncl_rem = arena_bytes - (int)(reinterpret_cast<char *>(csize) - arena);
             const int ncl_cap = ncl_rem >= 16 ? (ncl_rem - 4) / 12 : 0;   // csize, cseed [ncl_cap], cstart [ncl_cap + 1]
             __syncthreads();
-            // ---- centre joints of the kept candidates
-            for (int i = lane; i < n; i += 64) {
-                int rm, rs, q;
-                slot_rows(kidx[i], rm, rs, q);
-                const int mc = rig.pairs[2 * q], sc = rig.pairs[2 * q + 1];
-                const Kp3<TIn> km = kpf[(size_t)rm * J + ci], ks = kpf[(size_t)rs * J + ci];
-                const RayRec a = make_ray(rig.M + 9 * mc, km.u, km.v), b = make_ray(rig.M + 9 * sc, ks.u, ks.v);
-                const double *pc = rig.pairc + 6 * q;
-                const PairSolve o = pair_solve_fast<true>(a, b, Vec3{pc[0], pc[1], pc[2]}, Vec3{pc[3], pc[4], pc[5]});
-                cen[3 * i] = 0.5 * o.sw.x;
-                cen[3 * i + 1] = 0.5 * o.sw.y;
-                cen[3 * i + 2] = 0.5 * o.sw.z;
-                cof[i] = -1;
+            // ---- per kept candidate: word, score sum, centre joint.  Two candidates per lane and step: their keypoint loads
+            // are in flight together.
+            for (int i0 = 0; i0 < n; i0 += 128) {
+                const int ia = i0 + lane, ib = i0 + 64 + lane;
+                const bool va = ia < n, vb = ib < n;
+                const int ka = va ? kidx[ia] : 0, kb = vb ? kidx[ib] : 0;
+                int rma, rsa, qa, rmb, rsb, qb;
+                slot_rows(ka, rma, rsa, qa);
+                slot_rows(kb, rmb, rsb, qb);
+                const Kp3<TIn> kma = kpf[(size_t)rma * J + ci], ksa = kpf[(size_t)rsa * J + ci];
+                const Kp3<TIn> kmb = kpf[(size_t)rmb * J + ci], ksb = kpf[(size_t)rsb * J + ci];
+                const double sa = cs_f[ka], sb = cs_f[kb];
+                auto centre = [&](int i, int rm, int rs, int q, const Kp3<TIn> &km, const Kp3<TIn> &ks, double s_) {
+                    const int mc = pairs[2 * q], sc = pairs[2 * q + 1];
+                    const RayRec a = make_ray(rig.M + 9 * mc, km.u, km.v), b = make_ray(rig.M + 9 * sc, ks.u, ks.v);
+                    const double *pc = rig.pairc + 6 * q;
+                    const PairSolve o = pair_solve_fast<true>(a, b, Vec3{pc[0], pc[1], pc[2]}, Vec3{pc[3], pc[4], pc[5]});
+                    cen[3 * i] = 0.5 * o.sw.x;
+                    cen[3 * i + 1] = 0.5 * o.sw.y;
+                    cen[3 * i + 2] = 0.5 * o.sw.z;
+                    cof[i] = -1;
+                    lword[i] = (uint32_t)rm | ((uint32_t)rs << 10) | ((uint32_t)q << 20);
+                    lsum[i] = s_;
+                };
+                if (va) centre(ia, rma, rsa, qa, kma, ksa, sa);
+                if (vb) centre(ib, rmb, rsb, qb, kmb, ksb, sb);
             }
             __syncthreads();
             // ---- triangulation.py:107-130 -- seeds in list order, the last candidate never seeds, distance to the SEED's
             // centre, `dist > tol` skips (NaN absorbs)
             int ncl = 0;
-            {
-                int32_t *cseed = csize + ncl_cap;
-                if (ncl_cap < 1) slow = true;
-                for (int next = 0; !slow;) {
-                    int mc = -1;
-                    for (int base = next & ~63; base < n - 1 && mc < 0; base += 64) {
-                        const int i = base + lane;
-                        const unsigned long long m = __ballot(i >= next && i < n - 1 && cof[i] == -1);
-                        if (m) mc = base + __ffsll((long long)m) - 1;
-                    }
-                    if (mc < 0) break;
-                    if (ncl >= ncl_cap) {
-                        slow = true;
-                        break;
-                    }
-                    const double mx = cen[3 * mc], my = cen[3 * mc + 1], mz = cen[3 * mc + 2];
-                    int cnt = 0;
-                    for (int base = mc + 1; base < n; base += 64) {
-                        const int sc = base + lane;
-                        bool ab = false;
-                        if (sc < n && cof[sc] == -1) {
-                            const double dx = mx - cen[3 * sc], dy = my - cen[3 * sc + 1], dz = mz - cen[3 * sc + 2];
-                            const double dist = sqrt(fma(dz, dz, fma(dy, dy, dx * dx)));
-                            if (!(dist > prm.ctol)) {
-                                cof[sc] = ncl;
-                                ab = true;
-                            }
-                        }
-                        cnt += __popcll(__ballot(ab));
-                    }
-                    if (lane == 0) {
-                        cof[mc] = ncl;
-                        csize[ncl] = cnt + 1;
-                        cseed[ncl] = mc;
-                    }
-                    ncl++;
-                    next = mc + 1;
-                    __syncthreads();
+            int32_t *cseed = csize + ncl_cap;
+            if (ncl_cap < 1) slow = true;
+            for (int next = 0; !slow;) {
+                int mc = -1;
+                for (int base = next & ~63; base < n - 1 && mc < 0; base += 64) {
+                    const int i = base + lane;
+                    const unsigned long long m = __ballot(i >= next && i < n - 1 && cof[i] == -1);
+                    if (m) mc = base + __ffsll((long long)m) - 1;
                 }
+                if (mc < 0) break;
+                if (ncl >= ncl_cap) {
+                    slow = true;
+                    break;
+                }
+                const double mx = cen[3 * mc], my = cen[3 * mc + 1], mz = cen[3 * mc + 2];
+                int cnt = 0;
+                for (int base = mc + 1; base < n; base += 64) {
+                    const int sc = base + lane;
+                    bool ab = false;
+                    if (sc < n && cof[sc] == -1) {
+                        const double dx = mx - cen[3 * sc], dy = my - cen[3 * sc + 1], dz = mz - cen[3 * sc + 2];
+                        const double dist = sqrt(fma(dz, dz, fma(dy, dy, dx * dx)));
+                        if (!(dist > prm.ctol)) {
+                            cof[sc] = ncl;
+                            ab = true;
+                        }
+                    }
+                    cnt += __popcll(__ballot(ab));
+                }
+                if (lane == 0) {
+                    cof[mc] = ncl;
+                    csize[ncl] = cnt + 1;
+                    cseed[ncl] = mc;
+                }
+                ncl++;
+                next = mc + 1;
+                __syncthreads();
             }
             if (!slow) {
-                int32_t *cseed = csize + ncl_cap;
                 int32_t *cstart = cseed + ncl_cap;                    // [ncl + 1]
                 int32_t *members = reinterpret_cast<int32_t *>(cen);  // [n] kept indices grouped by cluster (the centres are dead)
                 __syncthreads();
@@ -485,20 +510,20 @@ __global__ __launch_bounds__(64) void k_associate(int64_t F, int Pmax, int J, in
                         const int i = base + lane;
                         const bool in = i < n && cof[i] == c;
                         const unsigned long long m = __ballot(in);
-                        if (in) members[off + __popcll(m & ((1ull << lane) - 1ull))] = kidx[i];
+                        if (in) members[off + __popcll(m & ((1ull << lane) - 1ull))] = i;
                         off += __popcll(m);
                     }
                 }
                 if (lane == 0) cstart[ncl] = off;
                 __syncthreads();
-                // ---- filters and descriptors, cluster by cluster
+                // ---- filters and descriptors, cluster by cluster (LDS only)
                 uint32_t ncomp = 0, ngen = 0, nwords = 0;
                 for (int cid = 0; cid < ncl; cid++) {
                     const int size = csize[cid];
                     if ((double)size < prm.num_tol) continue;                                  // :132-134
                     const int m0 = cstart[cid];
                     double ssum = 0.0;
-                    for (int base = 0; base < size; base += 64) ssum += base + lane < size ? cs_f[members[m0 + base + lane]] : 0.0;
+                    for (int base = 0; base < size; base += 64) ssum += base + lane < size ? lsum[members[m0 + base + lane]] : 0.0;
                     ssum = wave_sum(ssum);
                     const double avg = ssum / ((double)size * (double)J);                       // :150 from :79
                     // (a sum that is not finite, or a mean within 1e-6 of the tolerance -- the fast sums are within 6e-8 --
@@ -516,19 +541,17 @@ __global__ __launch_bounds__(64) void k_associate(int64_t F, int Pmax, int J, in
                             // row of camera 0 is the first row of pair (0,1) = member 0, the row of camera c >= 1 the second
                             // row of pair (0,c) = member c - 1, and every member must repeat the rows of its two cameras.
                             for (int c = lane; c < C; c += 64) {
-                                int rm, rs, q;
-                                slot_rows(members[m0 + (c == 0 ? 0 : c - 1)], rm, rs, q);
-                                rowc[c] = c == 0 ? rm : rs;
+                                const uint32_t w = lword[members[m0 + (c == 0 ? 0 : c - 1)]];
+                                rowc[c] = c == 0 ? (int)(w & 1023u) : (int)((w >> 10) & 1023u);
                             }
                             __syncthreads();
                             bool bad = false;
                             for (int base = 0; base < size; base += 64) {
                                 const int i = base + lane;
                                 if (i < size) {
-                                    int rm, rs, q;
-                                    slot_rows(members[m0 + i], rm, rs, q);
-                                    const int mc = rig.pairs[2 * i], sc = rig.pairs[2 * i + 1];
-                                    bad |= !(q == i && rm == rowc[mc] && rs == rowc[sc]);
+                                    const uint32_t w = lword[members[m0 + i]];
+                                    const int rm = (int)(w & 1023u), rs = (int)((w >> 10) & 1023u), q = (int)(w >> 20);
+                                    bad |= !(q == i && rm == rowc[pairs[2 * i]] && rs == rowc[pairs[2 * i + 1]]);
                                 }
                             }
                             complete = __ballot(bad) == 0ull;
@@ -568,15 +591,13 @@ __global__ __launch_bounds__(64) void k_associate(int64_t F, int Pmax, int J, in
                     nout++;
                 }
                 if (!slow) {
-                    unsigned long long bc = 0ull, bg = 0ull, bw = 0ull;
-                    if (lane == 0) {
-                        if (ncomp) bc = atomicAdd(hand_counters, (unsigned long long)ncomp);
-                        if (ngen) bg = atomicAdd(hand_counters + 1, (unsigned long long)ngen);
-                        if (nwords) bw = atomicAdd(hand_counters + 2, (unsigned long long)nwords);
-                    }
-                    bc = (unsigned long long)__shfl((long long)bc, 0, 64);
-                    bg = (unsigned long long)__shfl((long long)bg, 0, 64);
-                    bw = (unsigned long long)__shfl((long long)bw, 0, 64);
+                    // lanes 0..2 reserve room in the three lists at once
+                    const unsigned long long want = lane == 0 ? ncomp : (lane == 1 ? ngen : (lane == 2 ? nwords : 0u));
+                    unsigned long long got = 0ull;
+                    if (want) got = atomicAdd(hand_counters + lane, want);
+                    const unsigned long long bc = (unsigned long long)__shfl((long long)got, 0, 64),
+                                             bg = (unsigned long long)__shfl((long long)got, 1, 64),
+                                             bw = (unsigned long long)__shfl((long long)got, 2, 64);
                     // (cannot happen: the host sizes the lists for Pout persons and Kc members of every frame)
                     if (bc + ncomp > (unsigned long long)desc_cap || bg + ngen > (unsigned long long)desc_cap ||
                         bw + nwords > (unsigned long long)word_cap) {
@@ -599,11 +620,7 @@ __global__ __launch_bounds__(64) void k_associate(int64_t F, int Pmax, int J, in
                         }
                         for (int sl = 0; sl < nsl; sl++) {
                             const int size = st_size[sl], m0 = (int)st_a[sl];
-                            for (int i = lane; i < size; i += 64) {
-                                int rm, rs, q;
-                                slot_rows(members[m0 + i], rm, rs, q);
-                                hand_words[(uint32_t)bw + st_word[sl] + (uint32_t)i] = (uint32_t)rm | ((uint32_t)rs << 10) | ((uint32_t)q << 20);
-                            }
+                            for (int i = lane; i < size; i += 64) hand_words[(uint32_t)bw + st_word[sl] + (uint32_t)i] = lword[members[m0 + i]];
                         }
                     }
                 }

@@ -241,11 +241,12 @@ __device__ __forceinline__ double candidate_chunk_sum_exact(const char *__restri
 // of the determinant, nothing shared between joints (any joint count, no tail).  Conditioning: c.b cancels to
 // dist |a x b| from terms of size |d| |a| |b|, i.e. a relative error of 1e-16 |d| / dist ~ 5e-13 at 1 mm -- the reference's own
 // ||Wm - Ws|| cancels from 5 m coordinates to the same distance (1e-12).
-// The distance gate dist > dthr (:74) is taken on accurately rounded products, (c.b)^2 det > dthr^2 det^2 (both sides
-// x det > 0); a determinant that is 0, negative (rounding of nearly parallel rays) or NaN fails that test, so its
-// 0 x inf / rsq(< 0) reaches the sum as NaN, an exact intersection as inf -- and a sum that is not finite is re-done by
-// candidate_chunk_sum_exact, which also flags singular pairs.  The raw v_rsq_f64 (measured 2^-24.2 relative) only scales a
-// score: the caller re-does candidates whose mean lies within 1e-6 of average_score_threshold (:79-81).
+// The distance gate dist > dthr (:74) is taken on accurately rounded products, (c.b)^2 > dthr^2 det (both sides x det > 0).
+// A determinant that is 0, negative (rounding of nearly parallel rays) or NaN makes 1/dist itself NaN (0 x inf, rsq of
+// a negative number), and a NaN factor reaches the sum whatever the gates select (0 x NaN); an exact intersection gives
+// inf -- and a sum that is not finite is re-done with the accurate arithmetic, which also flags singular pairs.  The raw
+// v_rsq_f64 (measured 2^-24.2 relative) only scales a score: the caller re-does candidates whose mean lies within 1e-6 of
+// average_score_threshold (:79-81).
 //   pa: record of the first ray's row, pb: record of the FIRST of the GS second rows (rows are kP1Rec bytes apart)
 template <int GS, typename TIn>
 __device__ __forceinline__ void p1_item_sums(const char *__restrict__ pa, const char *__restrict__ pb, int jstr, int nj,
@@ -267,9 +268,9 @@ __device__ __forceinline__ void p1_item_sums(const char *__restrict__ pa, const 
             const double bq = fma(a.z, b[u].z, fma(a.y, b[u].y, a.x * b[u].x));
             const double det = fma(a.a, b[u].a, -(bq * bq));
             const double dn = fma(cz, b[u].z, fma(cy, b[u].y, cx * b[u].x));
-            const double x = (dn * dn) * det;
-            const bool kp_ = okm && !below_kthr(ss[u], prm) && !(x > (det * det) * prm.dthr2);   // :73-74
-            acc[u] = fma(gated_sum(sm, ss[u], kp_), det * __builtin_amdgcn_rsq(x), acc[u]);
+            const double dn2 = dn * dn;
+            const bool kp_ = okm && !below_kthr(ss[u], prm) && !(dn2 > det * prm.dthr2);   // :73-74
+            acc[u] = fma(gated_sum_sel(sm, ss[u], kp_), det * __builtin_amdgcn_rsq(dn2 * det), acc[u]);
         }
     }
 }

@@ -54,6 +54,14 @@ __device__ __forceinline__ double sum_score(double sm, double ss) { return sm + 
 __device__ __forceinline__ double gated_sum(float sm, float ss, bool keep) { return (double)(keep ? sm + ss : 0.0f); }
 __device__ __forceinline__ double gated_sum(double sm, double ss, bool keep) { return keep ? sm + ss : 0.0; }
 
+// the same with the select pinned BEFORE the widening (one v_cndmask on the float instead of two on the double)
+__device__ __forceinline__ double gated_sum_sel(float sm, float ss, bool keep) {
+    float t = keep ? sm + ss : 0.0f;
+    asm volatile("" : "+v"(t));
+    return (double)t;
+}
+__device__ __forceinline__ double gated_sum_sel(double sm, double ss, bool keep) { return keep ? sm + ss : 0.0; }
+
 struct SkewOut {
     Vec3 W;       // midpoint (Wm + Ws) / 2
     double dist;  // ||Wm - Ws||
