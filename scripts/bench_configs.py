@@ -38,13 +38,14 @@ for cfg, F, pout in SIZES:
         for _ in range(3):
             bt.run_torch(kp, npers, out=out)
             ms.append(bt.ctx.last_kernel_ms()[0])
+        handed = bt.ctx.last_handover_persons()
         cnt = out["count"].cpu().numpy()
         joints = int(cnt.clip(max=pout).sum()) * J
         kc = C * (C - 1) // 2 * P * P
         m = float(np.median(ms))
         print(json.dumps({"cfg": cfg, "frames": F, "kernel": ("recompute" if mode == "2" else "spill") + (" dlt" if METHOD == _lib.DLT else ""), "ms": m,
                           "frames_per_s": F / (m * 1e-3), "output_joints_per_s": joints / (m * 1e-3),
-                          "pair_solves_per_s": F * kc * J / (m * 1e-3), "mean_persons": float(cnt.mean())}))
+                          "pair_solves_per_s": F * kc * J / (m * 1e-3), "mean_persons": float(cnt.mean()), "handed_last_segment": handed}))
         bt.close()
     os.environ.pop("SNOWTRI_GENERAL_MODE", None)
     if "--no-oracle" in sys.argv:

@@ -1353,7 +1353,7 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax
                 const int grid2 = (int)std::min<int64_t>(Fs, (int64_t)ctx->num_cus * ctx->assoc_wg_per_cu);
                 hipLaunchKernelGGL(k2, dim3(grid2), dim3(64), lds2, st, Fs, Pmax, J, (int)Kc, ctx->rig(), kp_seg, np_seg, prm, Pout, csum,
                                    (float *)xyz_seg, (float *)ps_seg, d_cnt + s0, fl_seg, desc, words, hand_counters, cap, word_cap, slow_list,
-                                   slow_count, (int)lds2, C <= kClusterMaxCams ? 1 : 0);
+                                   slow_count, (int)lds2, 1);
                 HIP_TRY(hipGetLastError());
             }
         }
@@ -1381,9 +1381,20 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax
                     SNOWTRI_CASE(4)
                     SNOWTRI_CASE(8)
 #undef SNOWTRI_CASE
-                    default: {   // more than 8 cameras: every person is a member-list descriptor
+                    default: {   // more than 8 cameras: complete graphs with their rays in LDS, then the member lists
                         const int64_t passes_max = (Fs * Pout * (int64_t)J + 63) / 64;
                         const int gridm = (int)std::max<int64_t>(1, std::min<int64_t>((passes_max + 3) / 4, (int64_t)ctx->num_cus * 16));
+                        if (stream) {
+                            auto kw = k_cluster_fuse_wide<TIn>;
+                            const size_t ldsw = cluster_wide_lds_bytes(C);
+                            if (ldsw > 48 * 1024 && ctx->raise_lds((const void *)kw, (int)ldsw)) return SNOWTRI_ERR_HIP;
+                            const int64_t wpasses = (Fs * Pout * (int64_t)J + 15) / 16;   // 16 items per wave pass
+                            const int gridw = (int)std::max<int64_t>(1, std::min<int64_t>((wpasses + 4 * ctx->cluster_ppw - 1) / (4 * ctx->cluster_ppw),
+                                                                                         (int64_t)ctx->num_cus * 64));
+                            hipLaunchKernelGGL(kw, dim3(gridw), dim3(kBlock), ldsw, st, desc, hand_counters, cap, ctx->rig(), kp_seg, prm, Pmax, J,
+                                               jmagic, Pout, (float *)xyz_seg);
+                            HIP_TRY(hipGetLastError());
+                        }
                         hipLaunchKernelGGL((k_cluster_members<TIn>), dim3(gridm), dim3(kBlock), cluster_members_lds_bytes(C, ctx->npairs), st,
                                            desc, words, hand_counters, cap, ctx->rig(), kp_seg, prm, Pmax, J, jmagic, Pout, (float *)xyz_seg);
                         rc = hipGetLastError() == hipSuccess ? SNOWTRI_OK : SNOWTRI_ERR_HIP;

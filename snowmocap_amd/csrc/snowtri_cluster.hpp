@@ -402,4 +402,273 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_CLUSTER_WAVES) void k_cluster_fuse(
                                (p_first + W - (npass % W)) % W, W);
 }
 
+
+// ------------------------------------------------------------------------------------------- k_cluster_fuse_wide
+// Complete-graph clusters of rigs with more than 8 cameras (<= 16): the C rays of an item do not fit a lane's registers
+// (16 rays x 4 doubles), so an item = (descriptor, joint) is shared by FOUR adjacent lanes and its rays live in LDS.
+//   wave pass = 16 items; lane = 4 item + g.
+//   build   lane g fetches the keypoints of cameras g, g + 4, ... of its item (12 B each, prefetched one pass ahead) and
+//           writes ray, |h|^2 and score to the wave's own LDS tile [camera][field][item]: 8-byte slots, camera stride 704 B.
+//   solve   lane g owns first cameras m = g, g + 4, ... and walks the second camera CYCLICALLY, s = (m + delta) mod C for
+//           delta = 1 .. C/2 (delta = C/2 of an even C only for m < C/2): every unordered pair once, C(C-1)/8 per lane.
+//           At any step the four lanes of an item read cameras that differ mod 4 (C a multiple of 4) and the 8 items of a
+//           32-lane group read 64 contiguous bytes each: with the 704-byte camera stride (= -64 mod 256) the four
+//           cameras fall into the four quarters of the 64 banks -- conflict-free ds_read_b64.  A pair that wraps (s < m)
+//           is solved with the roles of its rays exchanged: d = t_s - t_m comes from an ORDERED table [m][s], the solve is
+//           symmetric under that exchange (same distance, same midpoint; last-bit rounding only, float32 outputs).
+//           Fusion accumulates sum s (d + a S0 - b S1) per pair and adds 2 t_m sum s once per first camera
+//           (t_m + t_s = 2 t_m + d), so the camera centres are read once per run, not per pair.
+//   reduce  the four lanes' partial sums meet through two quad shuffles; lane g = 0 stores the joint.
+// Arithmetic per pair as cluster_item (raw v_rsq_f64 for 1/dist, gates select the float32 score sum before the product);
+// one reciprocal per pair (rcp + one Newton step).  Joints whose sum is not finite take cluster_joint_sequential.
+// Member-list descriptors of the same launch are left to k_cluster_members.
+// Dynamic LDS: cluster_wide_lds_bytes(C).
+constexpr int kWideRayStride = 704;    // 5 fields x 16 items x 8 B = 640, padded to -64 mod 256
+constexpr int kWideFieldStride = 128;
+__host__ __device__ constexpr size_t cluster_wide_lds_bytes(int C) {
+    return (size_t)72 * C + (size_t)24 * C + (size_t)24 * C * C + (size_t)(kBlock / 64) * C * kWideRayStride + 16;
+}
+
+// the sequential routine for 64-bit person words (4 bits per camera, 16 cameras)
+template <typename TIn>
+__device__ __noinline__ void cluster_joint_sequential_wide(const Rig &rig, const Kp3<TIn> *__restrict__ kp3, int64_t frame0, uint32_t plo,
+                                                           uint32_t phi, int Pmax, int J, int j, const Params &prm, float &ox, float &oy,
+                                                           float &oz, float &os) {
+    const int C = rig.C, NP = rig.npairs;
+    auto person = [&](int c) { return (int)(((c < 8 ? plo : phi) >> (4 * (c & 7))) & 15u); };
+    double aS = 0.0, aX = 0.0, aY = 0.0, aZ = 0.0;
+    for (int q = 0; q < NP; q++) {
+        const int mc = rig.pairs[2 * q], sc = rig.pairs[2 * q + 1];
+        const int64_t rm = (frame0 * C + mc) * Pmax + person(mc);
+        const int64_t rs = (frame0 * C + sc) * Pmax + person(sc);
+        const Kp3<TIn> km = kp3[rm * J + j], ks = kp3[rs * J + j];
+        const RayRec a = make_ray(rig.M + 9 * mc, km.u, km.v), b = make_ray(rig.M + 9 * sc, ks.u, ks.v);
+        const double *pc = rig.pairc + 6 * q;
+        const double bq = fma(a.z, b.z, fma(a.y, b.y, a.x * b.x));
+        const double e = fma(a.z, pc[2], fma(a.y, pc[1], a.x * pc[0]));
+        const double g = fma(b.z, pc[2], fma(b.y, pc[1], b.x * pc[0]));
+        const double inv = rcp_nr2(fma(a.a, b.a, -(bq * bq)));
+        const double S0 = fma(b.a, e, -(bq * g)) * inv;
+        const double S1 = fma(a.a, g, -(bq * e)) * inv;
+        const double fx = fma(b.x, S1, fma(a.x, S0, -pc[0])), fy = fma(b.y, S1, fma(a.y, S0, -pc[1])),
+                     fz = fma(b.z, S1, fma(a.z, S0, -pc[2]));
+        const double d2 = fma(fz, fz, fma(fy, fy, fx * fx));
+        const bool kp_ = !below_kthr(km.s, prm) && !below_kthr(ks.s, prm) && !(d2 > prm.dthr2);
+        // the gate ASSIGNS 0 (:73-74): select after the product (0 * inf at an exact intersection)
+        const double sq = kp_ ? sum_score(km.s, ks.s) * __builtin_amdgcn_rsq(d2) : 0.0;
+        aS += sq;                                                              // :141
+        aX = fma(sq, fma(-b.x, S1, fma(a.x, S0, pc[3])), aX);                  // :144-147
+        aY = fma(sq, fma(-b.y, S1, fma(a.y, S0, pc[4])), aY);
+        aZ = fma(sq, fma(-b.z, S1, fma(a.z, S0, pc[5])), aZ);
+    }
+    double x = 0.0, y = 0.0, z = 0.0, s = 0.0;
+    if (!(aS == 0.0)) {                                                        // :142-143
+        const double r = 0.5 * rcp_nr2(aS);
+        x = aX * r;
+        y = aY * r;
+        z = aZ * r;
+        s = aS * (0.0005 * rcp_nr2((double)NP));                              // :148
+    }
+    ox = (float)x;
+    oy = (float)y;
+    oz = (float)z;
+    os = (float)s;
+}
+
+#ifndef SNOWTRI_WIDE_WAVES
+#define SNOWTRI_WIDE_WAVES 3
+#endif
+template <typename TIn>
+__global__ __launch_bounds__(kBlock, SNOWTRI_WIDE_WAVES) void k_cluster_fuse_wide(const ClusterDesc *__restrict__ desc,
+                                                                                 const unsigned long long *__restrict__ cnt,
+                                                                                 uint32_t desc_cap, Rig rig, const TIn *__restrict__ kpts,
+                                                                                 Params prm, int Pmax, int J, unsigned long long jmagic,
+                                                                                 int Pout, float *__restrict__ out4) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int kMaxOwn = 4;                        // first cameras per lane: C <= 16
+    const int C = rig.C, NP = rig.npairs;
+    const int tid = threadIdx.x, lane = tid & 63, g = lane & 3, it = lane >> 2;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    double *Ml = reinterpret_cast<double *>(smem);                        // [C][9]
+    double *tl = Ml + 9 * C;                                              // [C][3]
+    double *dl = tl + 3 * C;                                              // [C][C][3]: t_s - t_m for the ORDERED pair (m, s)
+    char *tile = reinterpret_cast<char *>(dl + 3 * C * C) + (size_t)wave * C * kWideRayStride;   // this wave's rays
+    for (int i = tid; i < 9 * C; i += kBlock) Ml[i] = rig.M[i];
+    for (int i = tid; i < 3 * C; i += kBlock) tl[i] = rig.t[i];
+    for (int i = tid; i < 3 * C * C; i += kBlock) {
+        const int m = i / (3 * C), r = i - m * 3 * C, s = r / 3, k = r - 3 * s;
+        // the host's d of the pair in its candidate order, negated for the reverse direction (bit-identical to the
+        // pair table the other kernels use)
+        double v = 0.0;
+        if (m != s) {
+            const int lo = m < s ? m : s, hi = m < s ? s : m;
+            const int q = lo * C - lo * (lo + 1) / 2 + (hi - lo - 1);   // index of (lo, hi) in triangulation.py:56-57 order
+            v = rig.pairc[6 * q + k];
+            if (m > s) v = -v;
+        }
+        dl[i] = v;
+    }
+    const unsigned long long nd64 = cnt[0];
+    const uint32_t ndesc = nd64 < (unsigned long long)desc_cap ? (uint32_t)nd64 : desc_cap;
+    const uint32_t total = ndesc * (uint32_t)J;
+    const uint32_t npass = (total + 15u) >> 4;
+    const uint32_t W = gridDim.x * (uint32_t)(kBlock / 64);
+    const Kp3<TIn> *kp3 = reinterpret_cast<const Kp3<TIn> *>(kpts);
+    const float kthr_f32 = prm.kthr_f32;
+    const double kthr = prm.kthr, dthr2 = prm.dthr2;
+    const int half = C >> 1;
+    const bool even = (C & 1) == 0;
+    __syncthreads();
+
+    struct Item {
+        uint32_t frame, plo, phi, slot, j;
+        bool valid;
+    };
+    auto locate = [&](uint32_t pass) {
+        Item t;
+        const uint32_t i = (pass << 4) + (uint32_t)it;
+        t.valid = pass < npass && i < total;
+        const uint32_t ic = t.valid ? i : 0u;
+        const uint32_t di = (uint32_t)(((unsigned long long)ic * jmagic) >> 40);
+        t.j = ic - di * (uint32_t)J;
+        t.frame = t.plo = t.phi = t.slot = 0u;
+        if (t.valid) {
+            const uint4 d = *reinterpret_cast<const uint4 *>(desc + di);
+            t.frame = d.x;
+            t.plo = d.y;
+            t.slot = d.z;
+            t.phi = d.w;
+            t.valid = d.z < (uint32_t)Pout;   // (a voided entry)
+        }
+        return t;
+    };
+    auto fetch = [&](Kp3<TIn>(&dst)[kMaxOwn], const Item &t) {
+#pragma unroll
+        for (int i = 0; i < kMaxOwn; i++) {
+            const int c = g + 4 * i;
+            dst[i] = Kp3<TIn>{(TIn)0, (TIn)0, (TIn)0};
+            if (t.valid && c < C) {
+                const uint32_t p = ((c < 8 ? t.plo : t.phi) >> (4 * (c & 7))) & 15u;
+                const uint32_t row = (t.frame * (uint32_t)C + (uint32_t)c) * (uint32_t)Pmax + p;
+                dst[i] = kp3[(uint64_t)row * (uint32_t)J + t.j];
+            }
+        }
+    };
+    auto score_of = [&](const char *rec) -> TIn {
+        if constexpr (sizeof(TIn) == 4)
+            return (TIn)__uint_as_float((uint32_t)*(lds_cv_u64)(rec + 4 * kWideFieldStride));
+        else
+            return (TIn) * (lds_cv_f64)(rec + 4 * kWideFieldStride);
+    };
+
+    uint32_t p = blockIdx.x * (uint32_t)(kBlock / 64) + (uint32_t)wave;
+    if (p >= npass) return;
+    Kp3<TIn> cur[kMaxOwn], nxt[kMaxOwn];
+    Item it0 = locate(p);
+    fetch(cur, it0);
+    Item it1 = locate(p + W);
+    for (; p < npass; p += W) {
+        fetch(nxt, it1);
+        const Item it2 = locate(p + 2 * W);
+        // ---- build: this lane's cameras of its item -> the wave's tile
+#pragma unroll
+        for (int i = 0; i < kMaxOwn; i++) {
+            const int c = g + 4 * i;
+            if (c < C) {
+                const RayRec h = make_ray(Ml + 9 * c, cur[i].u, cur[i].v);
+                char *rec = tile + c * kWideRayStride + it * 8;
+                *reinterpret_cast<double *>(rec) = h.x;
+                *reinterpret_cast<double *>(rec + kWideFieldStride) = h.y;
+                *reinterpret_cast<double *>(rec + 2 * kWideFieldStride) = h.z;
+                *reinterpret_cast<double *>(rec + 3 * kWideFieldStride) = h.a;
+                if constexpr (sizeof(TIn) == 4)
+                    *reinterpret_cast<unsigned long long *>(rec + 4 * kWideFieldStride) = (unsigned long long)__float_as_uint((float)cur[i].s);
+                else
+                    *reinterpret_cast<double *>(rec + 4 * kWideFieldStride) = (double)cur[i].s;
+            }
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        // ---- solve: first cameras m = g, g + 4, ...; second camera cyclic
+        double aS = 0.0, aX = 0.0, aY = 0.0, aZ = 0.0;
+        for (int m = g; m < C; m += 4) {
+            const char *ra = tile + m * kWideRayStride + it * 8;
+            lds_cv_f64 pa = (lds_cv_f64)ra;
+            const double ax = pa[0], ay = pa[kWideFieldStride / 8], az = pa[2 * kWideFieldStride / 8], aa = pa[3 * kWideFieldStride / 8];
+            const TIn sm = score_of(ra);
+            bool okm;
+            if constexpr (sizeof(TIn) == 4)
+                okm = !((float)sm < kthr_f32);
+            else
+                okm = !((double)sm < kthr);
+            double rS = 0.0, rX = 0.0, rY = 0.0, rZ = 0.0;   // this first camera's run
+            const int dmax = (even && m >= half) ? half - 1 : half;
+            int s = m;
+            for (int dd = 1; dd <= dmax; dd++) {
+                s = s + 1 == C ? 0 : s + 1;
+                const char *rb = tile + s * kWideRayStride + it * 8;
+                lds_cv_f64 pb = (lds_cv_f64)rb;
+                const double bx = pb[0], by = pb[kWideFieldStride / 8], bz = pb[2 * kWideFieldStride / 8], bb = pb[3 * kWideFieldStride / 8];
+                const TIn ss = score_of(rb);
+                const double *dq = dl + 3 * (m * C + s);
+                const double dx = dq[0], dy = dq[1], dz = dq[2];
+                // A2 (triangulation.py:24-31)
+                const double bq = fma(az, bz, fma(ay, by, ax * bx));
+                const double det = fma(aa, bb, -(bq * bq));
+                const double e = fma(az, dz, fma(ay, dy, ax * dx));
+                const double gg = fma(bz, dz, fma(by, dy, bx * dx));
+                const double inv = rcp_nr1(det);   // (2^-46: 1e-13 m on the point)
+                const double S0 = fma(bb, e, -(bq * gg)) * inv;
+                const double S1 = fma(aa, gg, -(bq * e)) * inv;
+                const double fx = fma(bx, S1, fma(ax, S0, -dx)), fy = fma(by, S1, fma(ay, S0, -dy)), fz = fma(bz, S1, fma(az, S0, -dz));
+                const double d2 = fma(fz, fz, fma(fy, fy, fx * fx));
+                // :72-74, sq = 2000 x the pair score; the gates select the score sum before the product
+                bool keep;
+                if constexpr (sizeof(TIn) == 4)
+                    keep = okm && !((float)ss < kthr_f32) && !(d2 > dthr2);
+                else
+                    keep = okm && !((double)ss < kthr) && !(d2 > dthr2);
+                const double sq = gated_sum_sel(sm, ss, keep) * __builtin_amdgcn_rsq(d2);
+                rS += sq;
+                rX = fma(sq, fma(-bx, S1, fma(ax, S0, dx)), rX);   // d + a S0 - b S1
+                rY = fma(sq, fma(-by, S1, fma(ay, S0, dy)), rY);
+                rZ = fma(sq, fma(-bz, S1, fma(az, S0, dz)), rZ);
+            }
+            const double *tm = tl + 3 * m;
+            aS += rS;
+            aX += fma(2.0 * rS, tm[0], rX);    // sum s (t_m + t_s + a S0 - b S1) with t_m + t_s = 2 t_m + d
+            aY += fma(2.0 * rS, tm[1], rY);
+            aZ += fma(2.0 * rS, tm[2], rZ);
+        }
+        // ---- reduce over the four lanes of the item
+        aS += __shfl_xor(aS, 1, 64);
+        aX += __shfl_xor(aX, 1, 64);
+        aY += __shfl_xor(aY, 1, 64);
+        aZ += __shfl_xor(aZ, 1, 64);
+        aS += __shfl_xor(aS, 2, 64);
+        aX += __shfl_xor(aX, 2, 64);
+        aY += __shfl_xor(aY, 2, 64);
+        aZ += __shfl_xor(aZ, 2, 64);
+        // aS = 2000 x sum_q s_q (:141); sum == 0 -> (0,0,0)/0 (:142-143): aX = aY = aZ = 0 then
+        const double r = 0.5 * rcp_nr1(fmax(aS, 1e-300));
+        float ox = (float)(aX * r), oy = (float)(aY * r), oz = (float)(aZ * r);   // :144-147
+        float os = (float)(aS * (0.0005 / (double)NP));                            // :148
+        const bool bad = !(aS < 1e300) && it0.valid;
+        if (__ballot(bad)) {   // rare, wave-uniform branch
+            if (bad && g == 0)
+                cluster_joint_sequential_wide<TIn>(rig, kp3, (int64_t)it0.frame, it0.plo, it0.phi, Pmax, J, (int)it0.j, prm, ox, oy, oz, os);
+        }
+        if (it0.valid && g == 0) {
+            float4 *o = reinterpret_cast<float4 *>(out4) + ((uint64_t)it0.frame * (uint32_t)Pout + it0.slot) * (uint64_t)(uint32_t)J + it0.j;
+            *o = make_float4(ox, oy, oz, os);
+        }
+        __builtin_amdgcn_wave_barrier();   // the tile is rewritten by the next pass
+#pragma unroll
+        for (int i = 0; i < kMaxOwn; i++) cur[i] = nxt[i];
+        it0 = it1;
+        it1 = it2;
+    }
+}
+
 }  // namespace snowtri

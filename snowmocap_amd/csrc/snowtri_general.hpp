@@ -134,8 +134,7 @@ __device__ __forceinline__ void p1_store_record(char *rec, const RayRec &h, TIn 
 // bank pairs).  Volatile keeps the compiler from pairing neighbouring fields into ds_read2_b64 -- which the LDS serves as
 // two passes of 4 x 16 lanes, at HALF the bytes per clock -- and from narrowing the score slot to a 4-byte read (its
 // 4-byte banks alias rows 16 apart).
-typedef __attribute__((address_space(3))) const volatile double *lds_cv_f64;                // (explicit LDS address space:
-typedef __attribute__((address_space(3))) const volatile unsigned long long *lds_cv_u64;   //  a volatile generic access is a flat load)
+// (lds_cv_f64 / lds_cv_u64: snowtri_math.hpp -- explicit LDS address space, a volatile generic access is a flat load)
 template <typename TIn>
 __device__ __forceinline__ TIn p1_load_score(const char *rec) {
     if constexpr (sizeof(TIn) == 4)

@@ -133,6 +133,11 @@ __device__ __forceinline__ double rsq_nr1(double x) {
     return fma(y * 0.5, e, y);               // y (1 + e/2)
 }
 
+// volatile LDS reads in an explicit address space: single ds_read_b64 each (the compiler pairs neighbouring plain reads
+// into ds_read2_b64, which the LDS serves at half the bytes per clock; a volatile GENERIC access would be a flat load)
+typedef __attribute__((address_space(3))) const volatile double *lds_cv_f64;
+typedef __attribute__((address_space(3))) const volatile unsigned long long *lds_cv_u64;
+
 struct alignas(16) RayRec {  // one world ray in LDS: direction (un-normalised) and its squared norm
     double x, y, z, a;
 };
