@@ -87,6 +87,31 @@ struct Scratch {
     }
 };
 
+// Page-locked host staging for the small per-frame calls: one H2D and one D2H per call, both truly asynchronous
+// (a pageable copy is staged and synchronised by the runtime, ~10-20 us each).
+struct PinnedScratch {
+    void *p = nullptr;
+    size_t cap = 0;
+    int ensure(size_t bytes) {
+        if (bytes <= cap) return SNOWTRI_OK;
+        if (p) {
+            HIP_TRY(hipHostFree(p));
+            p = nullptr;
+            cap = 0;
+        }
+        size_t want = std::max(bytes, (size_t)64 << 10);
+        HIP_TRY(hipHostMalloc(&p, want, hipHostMallocDefault));
+        cap = want;
+        return SNOWTRI_OK;
+    }
+    void release() {
+        if (p) (void)hipHostFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+constexpr size_t kPinnedMaxBytes = (size_t)4 << 20;   // larger host batches keep the direct copies
+
 int inv3(const double *m, double *o) {
     const double c00 = m[4] * m[8] - m[5] * m[7];
     const double c01 = m[5] * m[6] - m[3] * m[8];
@@ -128,6 +153,7 @@ struct snowtri_ctx {
     int32_t *dpairs = nullptr;
     unsigned long long *d_counters = nullptr;  // [0] singular pairs, [1] slow frames, [2..] spare
     Scratch in, out, work, misc, aux, desc;   // desc: cluster descriptors handed from k_frame_recompute / k_associate to k_cluster_fuse
+    PinnedScratch pin_in, pin_out;            // host staging of the per-frame calls
     Scratch sums;                             // candidate sums of k_candidate_sums [frames][Kc] + the frames k_associate left behind
     // measurement
     bool timing = false;
@@ -309,6 +335,8 @@ int snowtri_ctx_destroy(snowtri_ctx *ctx) {
     ctx->aux.release();
     ctx->desc.release();
     ctx->sums.release();
+    ctx->pin_in.release();
+    ctx->pin_out.release();
     for (auto &e : ctx->ev)
         if (e) (void)hipEventDestroy(e);
     for (auto &e : ctx->ev_ring)
@@ -530,11 +558,11 @@ size_t dtype_size(int dt) { return dt == SNOWTRI_F32 ? 4 : 8; }
 template <typename TIn>
 void launch_triangulate(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax, int J, int Kc,
                         const void *kpts, const int32_t *n_persons, const Params &prm, double *cxyz,
-                        double *cks, double *cps, uint8_t *ckeep) {
+                        double *cks, double *cps, uint8_t *ckeep, unsigned long long *n_singular) {
     const int64_t total = F * (int64_t)Kc * J;
     hipLaunchKernelGGL((k_triangulate<TIn>), dim3(grid_for(total, kBlock, ctx->num_cus * 16)), dim3(kBlock), 0,
                        st, F, Pmax, J, Kc, ctx->rig(), (const TIn *)kpts, n_persons, prm, cxyz, cks,
-                       ctx->d_counters);
+                       n_singular);
     hipLaunchKernelGGL(k_cand_mean, dim3(grid_for(F * (int64_t)Kc, kBlock / 64, ctx->num_cus * 16)),
                        dim3(kBlock), 0, st, F, Pmax, J, Kc, ctx->rig(), n_persons, prm, (const double *)cks,
                        cps, ckeep);
@@ -584,39 +612,64 @@ int snowtri_triangulate(snowtri_ctx *ctx, int64_t F, int32_t Pmax, int32_t J, co
     const int32_t *d_np = n_persons;
     double *d_xyz = cand_xyz, *d_ks = cand_kscore, *d_ps = cand_pscore;
     uint8_t *d_keep = cand_keep;
-    HIP_TRY(hipMemsetAsync(ctx->d_counters, 0, sizeof(unsigned long long), st));
-    if (memspace == SNOWTRI_HOST) {
-        rc = ctx->in.ensure(in_bytes + np_bytes + 16);
+    unsigned long long *d_nsing = ctx->d_counters;
+    const size_t in_np_off = (in_bytes + 15) & ~(size_t)15;
+    const size_t out_bytes = sizeof(double) * (nx * 4 + (size_t)F * Kc) + (size_t)F * Kc;
+    const size_t out_ns_off = (out_bytes + 15) & ~(size_t)15;          // the singular-pair counter rides behind the outputs
+    const bool host = memspace == SNOWTRI_HOST;
+    const bool pinned = host && in_np_off + np_bytes <= kPinnedMaxBytes && out_ns_off + 8 <= kPinnedMaxBytes;
+    if (host) {
+        rc = ctx->in.ensure(in_np_off + np_bytes + 16);
         if (rc) return rc;
-        const size_t out_bytes = sizeof(double) * (nx * 4 + (size_t)F * Kc) + (size_t)F * Kc;
-        rc = ctx->out.ensure(out_bytes + 64);
+        rc = ctx->out.ensure(out_ns_off + 64);
         if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(ctx->in.p, kpts, in_bytes, hipMemcpyHostToDevice, st));
         d_kpts = ctx->in.p;
-        if (n_persons) {
-            int32_t *p = (int32_t *)((char *)ctx->in.p + ((in_bytes + 15) & ~(size_t)15));
-            HIP_TRY(hipMemcpyAsync(p, n_persons, np_bytes, hipMemcpyHostToDevice, st));
-            d_np = p;
-        }
+        if (n_persons) d_np = (int32_t *)((char *)ctx->in.p + in_np_off);
         d_xyz = (double *)ctx->out.p;
         d_ks = d_xyz + nx * 3;
         d_ps = d_ks + nx;
         d_keep = (uint8_t *)(d_ps + (size_t)F * Kc);
-        HIP_TRY(hipMemsetAsync(d_xyz, 0, out_bytes, st));  // invalid slots read back as zeros
+        d_nsing = (unsigned long long *)((char *)ctx->out.p + out_ns_off);
+        if (pinned) {   // one staged upload
+            rc = ctx->pin_in.ensure(in_np_off + np_bytes);
+            if (rc) return rc;
+            rc = ctx->pin_out.ensure(out_ns_off + 8);
+            if (rc) return rc;
+            std::memcpy(ctx->pin_in.p, kpts, in_bytes);
+            if (n_persons) std::memcpy((char *)ctx->pin_in.p + in_np_off, n_persons, np_bytes);
+            HIP_TRY(hipMemcpyAsync(ctx->in.p, ctx->pin_in.p, in_np_off + np_bytes, hipMemcpyHostToDevice, st));
+        } else {
+            HIP_TRY(hipMemcpyAsync(ctx->in.p, kpts, in_bytes, hipMemcpyHostToDevice, st));
+            if (n_persons) HIP_TRY(hipMemcpyAsync((void *)d_np, n_persons, np_bytes, hipMemcpyHostToDevice, st));
+        }
+        HIP_TRY(hipMemsetAsync(d_xyz, 0, out_ns_off + 8, st));  // invalid slots read back as zeros; counter = 0
+    } else {
+        HIP_TRY(hipMemsetAsync(d_nsing, 0, sizeof(unsigned long long), st));
     }
     if (in_dtype == SNOWTRI_F32)
-        launch_triangulate<float>(ctx, st, F, Pmax, J, (int)Kc, d_kpts, d_np, prm, d_xyz, d_ks, d_ps, d_keep);
+        launch_triangulate<float>(ctx, st, F, Pmax, J, (int)Kc, d_kpts, d_np, prm, d_xyz, d_ks, d_ps, d_keep, d_nsing);
     else
-        launch_triangulate<double>(ctx, st, F, Pmax, J, (int)Kc, d_kpts, d_np, prm, d_xyz, d_ks, d_ps, d_keep);
+        launch_triangulate<double>(ctx, st, F, Pmax, J, (int)Kc, d_kpts, d_np, prm, d_xyz, d_ks, d_ps, d_keep, d_nsing);
     HIP_TRY(hipGetLastError());
-    if (memspace == SNOWTRI_HOST) {
-        HIP_TRY(hipMemcpyAsync(cand_xyz, d_xyz, sizeof(double) * nx * 3, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(cand_kscore, d_ks, sizeof(double) * nx, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(cand_pscore, d_ps, sizeof(double) * F * Kc, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(cand_keep, d_keep, (size_t)F * Kc, hipMemcpyDeviceToHost, st));
+    if (host) {
         unsigned long long ns = 0;
-        HIP_TRY(hipMemcpyAsync(&ns, ctx->d_counters, sizeof(ns), hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+        if (pinned) {   // one staged download
+            HIP_TRY(hipMemcpyAsync(ctx->pin_out.p, ctx->out.p, out_ns_off + 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            const char *o = (const char *)ctx->pin_out.p;
+            std::memcpy(cand_xyz, o, sizeof(double) * nx * 3);
+            std::memcpy(cand_kscore, o + sizeof(double) * nx * 3, sizeof(double) * nx);
+            std::memcpy(cand_pscore, o + sizeof(double) * nx * 4, sizeof(double) * F * Kc);
+            std::memcpy(cand_keep, o + sizeof(double) * (nx * 4 + (size_t)F * Kc), (size_t)F * Kc);
+            std::memcpy(&ns, o + out_ns_off, sizeof(ns));
+        } else {
+            HIP_TRY(hipMemcpyAsync(cand_xyz, d_xyz, sizeof(double) * nx * 3, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(cand_kscore, d_ks, sizeof(double) * nx, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(cand_pscore, d_ps, sizeof(double) * F * Kc, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(cand_keep, d_keep, (size_t)F * Kc, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(&ns, d_nsing, sizeof(ns), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+        }
         if (ns) return SNOWTRI_ERR_SINGULAR;
     }
     return SNOWTRI_OK;
@@ -645,22 +698,38 @@ int snowtri_condense(snowtri_ctx *ctx, int64_t F, int32_t N, int32_t J, const do
     double *o_xyz = out_xyz, *o_ks = out_kscore, *o_ps = out_pscore;
     int32_t *o_cnt = out_count;
     uint32_t *o_fl = out_flags;
-    if (memspace == SNOWTRI_HOST) {
-        rc = ctx->in.ensure(sizeof(double) * nx * 4 + (size_t)F * N + 64);
+    const bool host = memspace == SNOWTRI_HOST;
+    const size_t in_total = sizeof(double) * nx * 4 + (size_t)F * N;
+    const size_t out_total = sizeof(double) * (no * 4 + (size_t)F * Pout_max) + 8 * (size_t)F;
+    const bool pinned = host && in_total <= kPinnedMaxBytes && out_total <= kPinnedMaxBytes;
+    if (host) {
+        rc = ctx->in.ensure(in_total + 64);
         if (rc) return rc;
-        rc = ctx->out.ensure(sizeof(double) * (no * 4 + (size_t)F * Pout_max) + 8 * (size_t)F + 64);
+        rc = ctx->out.ensure(out_total + 64);
         if (rc) return rc;
         double *p = (double *)ctx->in.p;
-        if (nx) {
-            HIP_TRY(hipMemcpyAsync(p, cand_xyz, sizeof(double) * nx * 3, hipMemcpyHostToDevice, st));
-            HIP_TRY(hipMemcpyAsync(p + nx * 3, cand_kscore, sizeof(double) * nx, hipMemcpyHostToDevice, st));
-        }
         d_xyz = p;
         d_ks = p + nx * 3;
-        if (cand_keep && N) {
-            uint8_t *k = (uint8_t *)(p + nx * 4);
-            HIP_TRY(hipMemcpyAsync(k, cand_keep, (size_t)F * N, hipMemcpyHostToDevice, st));
-            d_keep = k;
+        if (cand_keep && N) d_keep = (uint8_t *)(p + nx * 4);
+        if (pinned) {   // one staged upload
+            rc = ctx->pin_in.ensure(in_total + 16);
+            if (rc) return rc;
+            rc = ctx->pin_out.ensure(out_total + 16);
+            if (rc) return rc;
+            char *h = (char *)ctx->pin_in.p;
+            if (nx) {
+                std::memcpy(h, cand_xyz, sizeof(double) * nx * 3);
+                std::memcpy(h + sizeof(double) * nx * 3, cand_kscore, sizeof(double) * nx);
+            }
+            if (cand_keep && N) std::memcpy(h + sizeof(double) * nx * 4, cand_keep, (size_t)F * N);
+            const size_t up = sizeof(double) * nx * 4 + ((cand_keep && N) ? (size_t)F * N : 0);
+            if (up) HIP_TRY(hipMemcpyAsync(p, h, up, hipMemcpyHostToDevice, st));
+        } else {
+            if (nx) {
+                HIP_TRY(hipMemcpyAsync(p, cand_xyz, sizeof(double) * nx * 3, hipMemcpyHostToDevice, st));
+                HIP_TRY(hipMemcpyAsync(p + nx * 3, cand_kscore, sizeof(double) * nx, hipMemcpyHostToDevice, st));
+            }
+            if (cand_keep && N) HIP_TRY(hipMemcpyAsync((void *)d_keep, cand_keep, (size_t)F * N, hipMemcpyHostToDevice, st));
         }
         o_xyz = (double *)ctx->out.p;
         o_ks = o_xyz + no * 3;
@@ -672,15 +741,28 @@ int snowtri_condense(snowtri_ctx *ctx, int64_t F, int32_t N, int32_t J, const do
     rc = launch_condense(ctx, st, F, N, J, d_xyz, d_ks, d_keep, prm, Pout_max, SplitWriter{o_xyz, o_ks, o_ps},
                          o_cnt, o_fl);
     if (rc) return rc;
-    if (memspace == SNOWTRI_HOST) {
-        if (no) {
-            HIP_TRY(hipMemcpyAsync(out_xyz, o_xyz, sizeof(double) * no * 3, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipMemcpyAsync(out_kscore, o_ks, sizeof(double) * no, hipMemcpyDeviceToHost, st));
+    if (host) {
+        if (pinned) {   // one staged download
+            HIP_TRY(hipMemcpyAsync(ctx->pin_out.p, ctx->out.p, out_total, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            const char *o = (const char *)ctx->pin_out.p;
+            if (no) {
+                std::memcpy(out_xyz, o, sizeof(double) * no * 3);
+                std::memcpy(out_kscore, o + sizeof(double) * no * 3, sizeof(double) * no);
+            }
+            std::memcpy(out_pscore, o + sizeof(double) * no * 4, sizeof(double) * F * Pout_max);
+            std::memcpy(out_count, o + sizeof(double) * (no * 4 + (size_t)F * Pout_max), sizeof(int32_t) * F);
+            if (out_flags) std::memcpy(out_flags, o + sizeof(double) * (no * 4 + (size_t)F * Pout_max) + sizeof(int32_t) * F, sizeof(uint32_t) * F);
+        } else {
+            if (no) {
+                HIP_TRY(hipMemcpyAsync(out_xyz, o_xyz, sizeof(double) * no * 3, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipMemcpyAsync(out_kscore, o_ks, sizeof(double) * no, hipMemcpyDeviceToHost, st));
+            }
+            HIP_TRY(hipMemcpyAsync(out_pscore, o_ps, sizeof(double) * F * Pout_max, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(out_count, o_cnt, sizeof(int32_t) * F, hipMemcpyDeviceToHost, st));
+            if (out_flags) HIP_TRY(hipMemcpyAsync(out_flags, o_fl, sizeof(uint32_t) * F, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
         }
-        HIP_TRY(hipMemcpyAsync(out_pscore, o_ps, sizeof(double) * F * Pout_max, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(out_count, o_cnt, sizeof(int32_t) * F, hipMemcpyDeviceToHost, st));
-        if (out_flags) HIP_TRY(hipMemcpyAsync(out_flags, o_fl, sizeof(uint32_t) * F, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
         for (int64_t f = 0; f < F; f++)
             if (out_count[f] > Pout_max) return SNOWTRI_ERR_OVERFLOW;
     }
@@ -1545,22 +1627,33 @@ extern "C" int snowtri_triangulate_condense(snowtri_ctx *ctx, int64_t F, int32_t
     void *d_xyzs = out_xyzs, *d_ps = out_pscore;
     int32_t *d_cnt = out_count;
     uint32_t *d_fl = out_flags;
+    const size_t np_off = (in_bytes + 15) & ~(size_t)15;
+    const size_t ps_off = (o4 + 15) & ~(size_t)15, cnt_off = ps_off + ((ops + 15) & ~(size_t)15);
+    const size_t out_total = cnt_off + 8 * (size_t)F;
+    const bool pinned = memspace == SNOWTRI_HOST && np_off + np_bytes <= kPinnedMaxBytes && out_total <= kPinnedMaxBytes;
     if (memspace == SNOWTRI_HOST) {
-        rc = ctx->in.ensure(in_bytes + np_bytes + 64);
+        rc = ctx->in.ensure(np_off + np_bytes + 64);
         if (rc) return rc;
-        rc = ctx->out.ensure(o4 + ops + 8 * (size_t)F + 256);
+        rc = ctx->out.ensure(out_total + 256);
         if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(ctx->in.p, kpts, in_bytes, hipMemcpyHostToDevice, st));
         d_kpts = ctx->in.p;
-        if (n_persons) {
-            int32_t *p = (int32_t *)((char *)ctx->in.p + ((in_bytes + 15) & ~(size_t)15));
-            HIP_TRY(hipMemcpyAsync(p, n_persons, np_bytes, hipMemcpyHostToDevice, st));
-            d_np = p;
+        if (n_persons) d_np = (int32_t *)((char *)ctx->in.p + np_off);
+        if (pinned) {   // one staged upload (page-locked: truly asynchronous)
+            rc = ctx->pin_in.ensure(np_off + np_bytes);
+            if (rc) return rc;
+            rc = ctx->pin_out.ensure(out_total);
+            if (rc) return rc;
+            std::memcpy(ctx->pin_in.p, kpts, in_bytes);
+            if (n_persons) std::memcpy((char *)ctx->pin_in.p + np_off, n_persons, np_bytes);
+            HIP_TRY(hipMemcpyAsync(ctx->in.p, ctx->pin_in.p, np_off + np_bytes, hipMemcpyHostToDevice, st));
+        } else {
+            HIP_TRY(hipMemcpyAsync(ctx->in.p, kpts, in_bytes, hipMemcpyHostToDevice, st));
+            if (n_persons) HIP_TRY(hipMemcpyAsync((void *)d_np, n_persons, np_bytes, hipMemcpyHostToDevice, st));
         }
         char *o = (char *)ctx->out.p;
         d_xyzs = o;
-        d_ps = o + ((o4 + 15) & ~(size_t)15);
-        d_cnt = (int32_t *)((char *)d_ps + ((ops + 15) & ~(size_t)15));
+        d_ps = o + ps_off;
+        d_cnt = (int32_t *)(o + cnt_off);
         d_fl = (uint32_t *)(d_cnt + F);
     } else if (!d_fl) {
         rc = ctx->misc.ensure(sizeof(uint32_t) * F);
@@ -1585,17 +1678,30 @@ extern "C" int snowtri_triangulate_condense(snowtri_ctx *ctx, int64_t F, int32_t
 #endif
     if (rc) return rc;
     if (memspace == SNOWTRI_HOST) {
-        HIP_TRY(hipMemcpyAsync(out_xyzs, d_xyzs, o4, hipMemcpyDeviceToHost, st));
-        if (out_pscore) HIP_TRY(hipMemcpyAsync(out_pscore, d_ps, ops, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipMemcpyAsync(out_count, d_cnt, sizeof(int32_t) * F, hipMemcpyDeviceToHost, st));
         std::vector<uint32_t> fl_host;
         uint32_t *fl = out_flags;
-        if (!fl) {
-            fl_host.resize(F);
-            fl = fl_host.data();
+        if (pinned) {   // one staged download
+            HIP_TRY(hipMemcpyAsync(ctx->pin_out.p, ctx->out.p, out_total, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            const char *o = (const char *)ctx->pin_out.p;
+            std::memcpy(out_xyzs, o, o4);
+            if (out_pscore) std::memcpy(out_pscore, o + ps_off, ops);
+            std::memcpy(out_count, o + cnt_off, sizeof(int32_t) * F);
+            if (out_flags)
+                std::memcpy(out_flags, o + cnt_off + sizeof(int32_t) * F, sizeof(uint32_t) * F);
+            else
+                fl = (uint32_t *)(o + cnt_off + sizeof(int32_t) * F);
+        } else {
+            HIP_TRY(hipMemcpyAsync(out_xyzs, d_xyzs, o4, hipMemcpyDeviceToHost, st));
+            if (out_pscore) HIP_TRY(hipMemcpyAsync(out_pscore, d_ps, ops, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(out_count, d_cnt, sizeof(int32_t) * F, hipMemcpyDeviceToHost, st));
+            if (!fl) {
+                fl_host.resize(F);
+                fl = fl_host.data();
+            }
+            HIP_TRY(hipMemcpyAsync(fl, d_fl, sizeof(uint32_t) * F, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
         }
-        HIP_TRY(hipMemcpyAsync(fl, d_fl, sizeof(uint32_t) * F, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
         uint32_t any = 0;
         int64_t slow = 0;
         for (int64_t f = 0; f < F; f++) {
