@@ -34,6 +34,14 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with these extra
                     configs[4] (16 x 8, 12 500 frames): multi-person kernel, fp64-VALU roofline each
   cpu_baseline      the oracle (oracle/snowtri_oracle.c, OpenMP over frames) on the host cores, on a
                     bounded sample of the same workload (rank 0, N = 1 only), and its distance to the GPU result
+  per_frame_api     the path main.py really calls, one frame at a time (reference main.py:50-71,106): median wall time
+                    of add_human_2D_points x 4 -> Human_Triangulation -> Human_Triangulation_Condense ->
+                    clear_2D_points on the floor rig (configs[0] shape, 300 frames), and of ONE F = 1 host call of
+                    the fused entry, beside the reference's 24.9 ms per frame
+  with_track_allgather  N > 1 (or --force-dist): the same K steps through the PRODUCT's sharded entry,
+                    ShardedTriangulator.run (snowmocap_amd/sharded.py): the shard computed in --chunks pieces, every
+                    output of a piece packed in one buffer and all-gathered with one RCCL collective on a side stream
+                    under the next piece's kernel; every rank's kernel time is listed (a slow rank shows)
 """
 import argparse
 import hashlib
@@ -119,10 +127,55 @@ def dry_run(args):
     seen = [None] * world
     dist.all_gather_object(seen, {"rank": rank, "local_rank": int(os.environ.get("LOCAL_RANK", "0")), "pid": os.getpid()})
     dist.barrier()
+    # the gather leg of the real run (gather_leg -> snowmocap_amd.sharded.gather_track_chunked), with a stand-in for the
+    # kernels: every rank fills its frame block with values that name (rank, local frame); checked on the gathered track
+    import torch
+    F = max(1, args.frames if args.frames < 1000 else 37)
+    gather = {}
+    for chunks in args.chunks:
+        def fake_compute(lo, hi, views, _r=rank):
+            views["xyzs"][: hi - lo] = (_r * 1000.0 + torch.arange(lo, hi, dtype=torch.float32)).view(-1, 1, 1, 1)
+            views["pscore"][: hi - lo] = float(_r)
+            views["count"][: hi - lo] = 1
+            views["flags"][: hi - lo] = 4
+        regions = {"xyzs": ((1, J, 4), torch.float32), "pscore": ((1,), torch.float32), "count": ((), torch.int32),
+                   "flags": ((), torch.int32)}
+        dt, full = gather_leg(dist, torch, None, lambda b, ch: sharded_run_generic(fake_compute, F, world * F, regions, ch, None),
+                              steps=2, warmup=1, chunks=chunks)
+        want = torch.cat([r * 1000.0 + torch.arange(F, dtype=torch.float32) for r in range(world)])
+        ok = bool(torch.equal(full["xyzs"][:, 0, 0, 0], want)) and bool((full["count"] == 1).all())
+        gather[str(chunks)] = {"ok": ok, "frames_gathered": int(full["xyzs"].shape[0]), "s_per_step": dt / 2}
     if rank == 0:
         print(json.dumps({"dry_run": True, "n_gpus": world, "rccl_ranks": dist.get_world_size(), "backend": "gloo",
-                          "ranks": seen}), flush=True)
+                          "ranks": seen, "gather_leg": gather}), flush=True)
     dist.destroy_process_group()
+
+
+def sharded_run_generic(compute_block, n_local, F_total, regions, chunks, device):
+    from snowmocap_amd.sharded import gather_track_chunked
+    return gather_track_chunked(compute_block, n_local, F_total, regions, chunks=chunks, device=device)
+
+
+def gather_leg(dist, torch, dev, run_step, steps, warmup, chunks):
+    """`warmup` + `steps` calls of run_step(i, chunks) -- the product's sharded entry: compute the rank's shard in
+    pieces, all-gather every piece -- between fences (synchronize + barrier); returns (seconds MAX over ranks, the last
+    gathered track)."""
+    def fence():
+        if dev is not None:
+            torch.cuda.synchronize(dev)
+        dist.barrier()
+    full = None
+    for i in range(warmup):
+        full = run_step(i, chunks)
+    fence()
+    t0 = time.perf_counter()
+    for i in range(steps):
+        full = run_step(warmup + i, chunks)
+    fence()
+    dt = time.perf_counter() - t0
+    tt = torch.tensor([dt], dtype=torch.float64, device=dev if dev is not None else "cpu")
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return float(tt.item()), full
 
 
 def main():
@@ -139,6 +192,10 @@ def main():
                     help="HIP streams the steps are issued on round-robin (one context each); 2 lets the ramp-up / "
                          "tail of consecutive 10 000-frame launches overlap")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the RCCL all-gather of the track")
+    ap.add_argument("--chunks", type=lambda v: [max(1, int(x)) for x in v.split(",")], default=[4],
+                    help="pieces the shard is cut into for the overlapped all-gather (ShardedTriangulator.run); a comma-separated "
+                         "list times each (the first is reported as with_track_allgather, all of them in its `sweep`)")
+    ap.add_argument("--no-per-frame", action="store_true", help="skip the per-frame API latency (main.py's own call sequence)")
     ap.add_argument("--method", choices=["pairwise", "dlt"], default="pairwise",
                     help="pairwise = the reference's algorithm (the metric); dlt = N-view DLT (row N3), for comparison only")
     ap.add_argument("--force-dist", action="store_true",
@@ -209,30 +266,14 @@ def main():
             pool.append((base + jitter).contiguous())
     outs = [bt.alloc_outputs(F, dev) for _ in range(len(pool))]
     can_gather = dist is not None and not args.no_gather
-    if can_gather:
-        gbuf = [torch.empty((world * F, Pout, J, 4), dtype=torch.float32, device=dev) for _ in range(2)]
-        side = torch.cuda.Stream(device=dev)
 
-    def timed_region(gather_on):
-        """W warm-up + K timed steps; returns seconds (MAX over ranks).  gather_on adds, per step, the RCCL
-        all-gather of this step's track shard, issued on a side stream so it overlaps the next kernels."""
-        gathered = [None] * len(pool)      # event: the all-gather that last read outs[b] has finished
-
+    def timed_region():
+        """W warm-up + K timed steps of the path itself (no collective: frames are independent); returns seconds (MAX
+        over ranks)."""
         def step(i):
             b = i % len(pool)
             k = i % nstreams
-            if gather_on and gathered[b] is not None:
-                streams[k].wait_event(gathered[b])      # do not overwrite a shard that is still being gathered
             bts[k].run_torch(pool[b], None, out=outs[b], stream=streams[k].cuda_stream)
-            if gather_on:
-                ready = torch.cuda.Event()
-                ready.record(streams[k])
-                side.wait_event(ready)
-                with torch.cuda.stream(side):
-                    dist.all_gather_into_tensor(gbuf[i & 1], outs[b]["xyzs"])
-                    done = torch.cuda.Event()
-                    done.record(side)
-                gathered[b] = done
 
         def fence():
             torch.cuda.synchronize(dev)        # every stream of this device, side stream included
@@ -254,7 +295,7 @@ def main():
         return dt
 
     # `value`: frames sharded across ranks, no data-path collective (frames are independent: SURVEY 8e).
-    regions = [timed_region(False) for _ in range(max(1, args.repeats))]
+    regions = [timed_region() for _ in range(max(1, args.repeats))]
     elapsed = float(np.median(regions))
     joints_per_step = F * Pout * J * world
     value = joints_per_step * K_steps / elapsed
@@ -263,10 +304,27 @@ def main():
     # beside `value` (it is xGMI-bandwidth-bound: 16 B/joint over the links vs 64 B/joint over HBM).
     with_gather = None
     if can_gather:
-        e2 = float(np.median([timed_region(True) for _ in range(max(1, min(3, args.repeats)))]))
-        with_gather = {"value": joints_per_step * K_steps / e2, "ms_per_step": e2 / K_steps * 1e3,
-                       "what": "same steps + one RCCL all_gather_into_tensor of the step's track shard "
-                               f"({F * Pout * J * 16 / 1e6:.1f} MB per rank) per step, overlapped on a side stream"}
+        # the PRODUCT's sharded entry (snowmocap_amd/sharded.py): per step, ShardedTriangulator.run computes this rank's
+        # shard in `chunks` pieces into one packed buffer per piece (joints, person scores, counts, flags) and all-gathers
+        # each piece with ONE collective on a side stream under the next piece's kernel; buffers are reused step to step
+        from snowmocap_amd.sharded import ShardedTriangulator
+        sht = ShardedTriangulator(Kc, Rc, tc, params, pout_max=Pout, device=local_rank, chunks=args.chunks[0], reuse_buffers=True)
+        sweep = []
+        for chunks in args.chunks:
+            e2s = []
+            for _ in range(max(1, min(3, args.repeats))):
+                e2, full = gather_leg(dist, torch, dev, lambda i, ch: sht.run(pool[i % len(pool)], world * F, chunks=ch),
+                                      steps=K_steps, warmup=min(W_steps, 5), chunks=chunks)
+                e2s.append(e2)
+            e2 = float(np.median(e2s))
+            ok = tuple(full["xyzs"].shape) == (world * F, Pout, J, 4) and bool((full["count"] == 1).all())
+            sweep.append({"chunks": chunks, "value": joints_per_step * K_steps / e2, "ms_per_step": e2 / K_steps * 1e3,
+                          "gathered_track_ok": ok})
+        sht.bt.close()
+        with_gather = dict(sweep[0], sweep=sweep,
+                           what="same steps through ShardedTriangulator.run: the shard in `chunks` pieces, each piece's outputs "
+                                f"(joints, person scores, counts, flags: {(F * Pout * (J * 16 + 4) + 8 * F) / 1e6:.1f} MB per rank per step) "
+                                "packed and all-gathered with one RCCL collective on a side stream under the next piece's kernel")
 
     # dominant-kernel duration: HIP events bracketing each launch on the launch stream
     # (snowtri_set_timing records them inside the C ABI around the fused kernel only).
@@ -291,9 +349,13 @@ def main():
             flg = o["flags"].cpu().numpy()
             assert (cnt == 1).all() and ((flg & _lib.FLAG_FASTPATH) != 0).all(), "bench output is not the expected fast path"
 
-    lean = method == _lib.PAIRWISE and os.environ.get("SNOWTRI_LEAN_MODE", "1") != "0" and F > 0
-    kernel_name = ("k_fused_lean<4,float,133>" if lean else "k_fused_single<4,%d,float,float>" % (1 if args.method == "dlt" else 0))
-    valu_per_64 = 337 if lean else 422      # rocprofv3 SQ_INSTS_VALU per 64 joints (profiles/)
+    kernel_name = bt.ctx.last_kernel_names()      # what the fused call really launched (snowtri_last_kernel_names)
+    # every rank's kernel time (a slow rank would otherwise hide behind rank 0's)
+    kernel_ms_ranks = [kernel_ms]
+    if dist is not None:
+        kt = torch.zeros(world, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(kt, torch.tensor([kernel_ms], dtype=torch.float64, device=dev))
+        kernel_ms_ranks = [float(x) for x in kt.cpu()]
 
     large = None
     if args.large_frames and rank == 0 and world == 1:
@@ -354,17 +416,31 @@ def main():
     # HBM bytes per launch from the PMC counters (rocprofv3 FETCH_SIZE / WRITE_SIZE passes, scripts/profile.sh):
     # only quoted while the kernels are the ones it was measured on.
     traffic, traffic_note = None, "no PMC measurement on file"
+    valu_per_64, valu_note = None, "no SQ_INSTS_VALU measurement of these kernel sources on file"
     pmc_path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc_path) and args.method != "dlt":
         try:
             pj = json.load(open(pmc_path))
-            if pj.get("source_sha256") == kernel_source_hash() and pj.get("frames_per_launch") == F:
-                traffic = pj.get("hbm_bytes_per_launch")
-                traffic_note = "rocprofv3 PMC passes of this kernel source (profiles/pmc_traffic.json: source_sha256 matches)"
+            if pj.get("source_sha256") == kernel_source_hash() and pj.get("kernel") == kernel_name:
+                if pj.get("frames_per_launch") == F:
+                    traffic = pj.get("hbm_bytes_per_launch")
+                    traffic_note = "rocprofv3 PMC passes of this kernel source (profiles/pmc_traffic.json: source_sha256 matches)"
+                else:
+                    traffic_note = "profiles/pmc_traffic.json was measured on another launch size: not quoted"
+                if pj.get("valu", {}).get("per_64_joints"):
+                    valu_per_64 = float(pj["valu"]["per_64_joints"])
+                    valu_note = ("rocprofv3 SQ_INSTS_VALU of this kernel source on a %d-frame launch / wave-items "
+                                 "(profiles/pmc_traffic.json: source_sha256 matches)" % pj["valu"].get("frames", 0))
             else:
-                traffic_note = "profiles/pmc_traffic.json was measured on other kernel sources or another launch size: not quoted"
+                traffic_note = "profiles/pmc_traffic.json was measured on other kernel sources: not quoted"
         except Exception:
             pass
+
+    per_frame = None
+    if rank == 0 and world == 1 and not args.no_per_frame and args.method == "pairwise":
+        sys.path.insert(0, os.path.join(ROOT, "scripts"))
+        from bench_per_frame import per_frame_api
+        per_frame = per_frame_api(frames=300, warm=20)
 
     line = None
     if rank == 0:
@@ -391,18 +467,23 @@ def main():
                          "kernel": kernel_name, "streams": 1,
                          "how": "HIP events around each launch on the launch stream, launches back to back on one stream",
                          "kernel_ms_mean": kernel_ms, "kernel_ms_min": kernel_ms_min, "launches": len(kms),
+                         "kernel_ms_mean_per_rank": kernel_ms_ranks,
                          "algorithmic_bytes_per_launch": bpf * F, "bytes_per_joint": bpf / (Pout * J)},
             "roofline_region": {"bound": "hbm", "achieved": ach_region, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": ach_region / HBM_PEAK_GBS, "streams": nstreams,
                                 "how": "algorithmic bytes per step / ms_per_step of the timed region (per GPU; "
                                        f"steps issued round-robin on {nstreams} streams, so consecutive launches overlap)"},
-            # the roof that actually binds this kernel: fp64 VALU issue.  VALU wave-instructions
-            # per 64 joints from rocprofv3 SQ_INSTS_VALU (profiles/), 4 issue cycles each, 1024 SIMDs at the 2.4 GHz peak clock.
+            # the roof that actually binds this kernel: fp64 VALU issue.  VALU wave-instructions per 64 joints
+            # MEASURED (rocprofv3 SQ_INSTS_VALU, quoted only while profiles/pmc_traffic.json carries the hash of these kernel
+            # sources), 4 issue cycles each, 1024 SIMDs at the 2.4 GHz peak clock.
             "fp64_valu_issue": None if args.method != "pairwise" else {
-                "valu_insts_per_64_joints": valu_per_64, "simds": 1024, "peak_clock_GHz": 2.4,
-                "frac_this_launch": (F * Pout * J / 64.0 * valu_per_64 * 4) / (kernel_ms * 1e-3) / (1024 * 2.4e9),
-                "frac_large_batch": None if large is None else (large["joints_per_s"] / 64.0 * valu_per_64 * 4) / (1024 * 2.4e9)},
+                "valu_insts_per_64_joints": valu_per_64, "source": valu_note, "simds": 1024, "peak_clock_GHz": 2.4,
+                "frac_this_launch": None if valu_per_64 is None else
+                    (F * Pout * J / 64.0 * valu_per_64 * 4) / (kernel_ms * 1e-3) / (1024 * 2.4e9),
+                "frac_large_batch": None if large is None or valu_per_64 is None else
+                    (large["joints_per_s"] / 64.0 * valu_per_64 * 4) / (1024 * 2.4e9)},
             "cpu_baseline": cpu,
+            "per_frame_api": per_frame,
             "with_track_allgather": with_gather,
             "large_batch": large,
             "extra_workloads": extra,
@@ -427,12 +508,13 @@ def main():
 
 
 def extra_workloads(torch, dev, device_index):
-    """The multi-person configurations of BASELINE.json on this GPU (k_frame_recompute): configs[2] = 8 cameras x
+    """The multi-person configurations of BASELINE.json on this GPU (the streaming association): configs[2] = 8 cameras x
     4 persons x 10 000 frames, and one GPU's share of configs[4] = 16 cameras x 8 persons x 12 500 frames.  A few
     hundred distinct frames are generated on the host and tiled on the device (frames are independent; the kernel
     is fp64-VALU-bound, SURVEY 8d, so cache residency of the tiled input does not help it).  Roofline: fp64 VALU,
-    algorithmic flops = frames x candidates x joints x 90 flop (one pair solve + score per candidate joint; the
-    kernel's second solve of surviving clusters is not credited)."""
+    algorithmic flops = frames x candidates x joints x 90 flop (SURVEY 8d: one pair solve + score per candidate joint;
+    the second solve of the surviving clusters in the fusion kernels is not credited, and neither is the shorter
+    distance-only solve the candidate sums really use -- the figure prices the reference's work, not the kernel's)."""
     from snowmocap_amd import synth
     from snowmocap_amd.batch import BatchTriangulator
     res = []
@@ -461,10 +543,12 @@ def extra_workloads(torch, dev, device_index):
         persons = float(cnt.mean())
         bpf = 12 * C * P * J + 16 * persons * J
         tflops = solves * FLOP_PER_SOLVE / 1e12
-        # <= 8 cameras: the fusion of the clusters runs in the streaming kernel behind the association kernel (one fused
-        # call = both launches; kernel_ms = HIP events around the call); 16 cameras keep it inside k_frame_recompute
-        kernels = ("k_frame_recompute<0,float,float> + k_cluster_fuse<%d,float>" % C) if C <= 8 else "k_frame_recompute<0,float,float>"
+        # one fused call = the launches of the streaming association (snowtri_last_kernel_names lists them);
+        # kernel_ms = HIP events around the whole call
+        kernels = bt.ctx.last_kernel_names()
+        handed = bt.ctx.last_handover_persons()
         res.append({"workload": label, "kernel": kernels, "frames": F, "kernel_ms": m,
+                    "persons_handed_to_cluster_kernels_last_segment": {"complete_graph": handed[0], "member_list": handed[1]},
                     "kernel_ms_all": ms[1:], "frames_per_s": F / (m * 1e-3),
                     "output_joints_per_s": float(cnt.clip(max=pout).sum()) * J / (m * 1e-3),
                     "pair_solves_per_s": solves, "mean_persons_per_frame": persons,

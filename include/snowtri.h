@@ -231,11 +231,16 @@ int snowtri_set_timing(snowtri_ctx *ctx, int enabled);
  * lack SNOWTRI_FLAG_FASTPATH instead). */
 int64_t snowtri_last_slow_frames(snowtri_ctx *ctx);
 
+/* Diagnostics: the kernels the LAST snowtri_triangulate_condense call on this context launched, in launch order,
+ * as their template names joined by " + " (e.g. "k_fused_lean<4,float,133>"); "" before the first call.  The string
+ * stays valid until the next fused call on this context.  bench.py names the kernel its roofline belongs to with it. */
+const char *snowtri_last_kernel_names(const snowtri_ctx *ctx);
+
 /* Test / diagnostics hook for the multi-person path: output persons of the last snowtri_triangulate_condense call
  * (its last segment) whose fusion (triangulation.py:136-152) was handed from the association kernel to the streaming
  * cluster kernels.  Returns the persons whose cluster is the complete graph over one detection per camera, and in
  * *n_other (may be NULL) those of any other shape; -1 / -1 if that call did not arm the hand-over (single-person
- * batches, float64 outputs, DLT, keypoint_num < J, more than 8 cameras or 16 persons per camera).  Synchronises
+ * batches, float64 outputs, DLT, keypoint_num < J, more than 16 cameras or 16 persons per camera).  Synchronises
  * the device. */
 int64_t snowtri_last_handover_persons(snowtri_ctx *ctx, int64_t *n_other);
 

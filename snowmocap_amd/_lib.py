@@ -96,6 +96,7 @@ _SIGNATURES = {
     "snowtri_timing_collect": (ct.c_int, [_c_p, _c_p, ct.c_int32]),
     "snowtri_last_slow_frames": (ct.c_int64, [_c_p]),
     "snowtri_last_handover_persons": (ct.c_int64, [_c_p, _c_p]),
+    "snowtri_last_kernel_names": (ct.c_char_p, [_c_p]),
 }
 
 _lib = None
@@ -238,6 +239,10 @@ class Context:
 
     def last_slow_frames(self):
         return int(lib().snowtri_last_slow_frames(self.handle))
+
+    def last_kernel_names(self):
+        """Template names of the kernels the last fused call launched, in launch order."""
+        return (lib().snowtri_last_kernel_names(self.handle) or b"").decode()
 
     def last_handover_persons(self):
         """(persons fused as complete-graph clusters, persons fused from member lists) of the last multi-person call,

@@ -184,6 +184,11 @@ struct snowtri_ctx {
         return 0;
     }
     int64_t last_stream_slow = -1;   // frames the streaming association left to k_frame_recompute in the last call (-1: not used)
+    // names of the kernels the last fused call launched (snowtri_last_kernel_names): a pointer to a string that lives as
+    // long as the library (one per template instantiation) or to `names_buf`, rebuilt only when the route changes
+    const char *last_kernels = "";
+    std::string names_buf;
+    long long names_key = -1;
     Rig rig() const { return Rig{dM, dt, dpairs, dpairc, dP, C, npairs}; }
 };
 
@@ -411,6 +416,8 @@ int64_t snowtri_last_handover_persons(snowtri_ctx *ctx, int64_t *n_other) {
     if (n_other) *n_other = (int64_t)n[1];
     return (int64_t)n[0];
 }
+
+const char *snowtri_last_kernel_names(const snowtri_ctx *ctx) { return ctx ? ctx->last_kernels : ""; }
 
 int64_t snowtri_num_candidate_slots(int32_t C, int32_t Pmax) {
     if (C < 0 || Pmax < 0) return -1;
@@ -1158,6 +1165,11 @@ namespace {
 
 constexpr size_t kMaxScratchBytes = (size_t)8 << 30;
 
+template <typename T>
+const char *type_name() {
+    return sizeof(T) == 4 ? "float" : "double";
+}
+
 // Frames per tile for the fast kernel: maximise (lane utilisation of the item loop: T*J items in
 // 256-wide passes) x (balance of the tiles over the CUs -- the kernel is fp64-VALU-bound, so a CU
 // with one more tile than its neighbours sets the launch time), under the LDS budget.  Prefer
@@ -1203,6 +1215,9 @@ int launch_fused_single(snowtri_ctx *ctx, hipStream_t st, int64_t F, int J, cons
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, st, F, J, T, ctx->rig(), d_kpts, d_np, prm, Pout,
                        d_xyzs, d_ps, d_cnt, d_fl, (char *)ctx->work.p, per_block);
     HIP_TRY(hipGetLastError());
+    static const std::string name = std::string("k_fused_single<") + std::to_string(C) + "," + std::to_string(METHOD) + "," +
+                                    type_name<TIn>() + "," + type_name<TOut>() + ">";
+    ctx->last_kernels = name.c_str();
     return SNOWTRI_OK;
 }
 
@@ -1260,6 +1275,9 @@ int launch_fused_lean(snowtri_ctx *ctx, hipStream_t st, int64_t F, const TIn *d_
                            d_fl ? d_fl + s0 : nullptr, (char *)ctx->work.p, per_block);
         HIP_TRY(hipGetLastError());
     }
+    static const std::string name = std::string("k_fused_lean<") + std::to_string(C) + "," + type_name<TIn>() + "," +
+                                    std::to_string(kLeanJ) + ">";
+    ctx->last_kernels = name.c_str();
     return SNOWTRI_OK;
 }
 
@@ -1283,6 +1301,8 @@ int launch_frame_general(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax, 
     hipLaunchKernelGGL(kern, dim3((int)grid), dim3(kBlock), lds, st, F, Pmax, J, (int)Kc, ctx->rig(), d_kpts, d_np,
                        prm, Pout, d_xyzs, d_ps, d_cnt, d_fl, (char *)ctx->work.p, per_block);
     HIP_TRY(hipGetLastError());
+    static const std::string name = std::string("k_frame_general<") + type_name<TIn>() + "," + type_name<TOut>() + ">";
+    ctx->last_kernels = name.c_str();
     return SNOWTRI_OK;
 }
 
@@ -1377,6 +1397,25 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax
     const int64_t seg = (stream || handover) ? std::min(seg_frames, seg_cap) : F;
     unsigned long long *next_frame = ctx->d_counters + 2, *hand_counters = ctx->d_counters + 3, *slow_count = ctx->d_counters + 6,
                        *exact_count = ctx->d_counters + 7;
+    {   // the kernels of this route, in launch order (rebuilt only when the route changes)
+        const long long key = ((long long)C << 8) | (METHOD << 7) | ((int)sizeof(TIn) << 3) | ((int)sizeof(TOut) >> 2 << 2) |
+                              (stream ? 2 : 0) | (handover ? 1 : 0) | ((long long)SL.threads << 16);
+        if (key != ctx->names_key) {
+            const std::string tin = type_name<TIn>(), tout = type_name<TOut>();
+            const std::string rec = "k_frame_recompute<" + std::to_string(METHOD) + "," + tin + "," + tout + ">";
+            const std::string fuse = C <= kClusterMaxCams ? "k_cluster_fuse<" + std::to_string(C) + "," + tin + ">"
+                                                           : "k_cluster_fuse_wide<" + tin + "> + k_cluster_members<" + tin + ">";
+            if (stream)
+                ctx->names_buf = "k_candidate_sums<" + tin + "," + std::to_string(SL.threads) + "> + k_candidate_sums_exact<" + tin +
+                                 "> + k_associate<" + tin + "> + " + fuse + " + " + rec + " (frames left behind)";
+            else if (handover)
+                ctx->names_buf = rec + " + " + fuse;
+            else
+                ctx->names_buf = rec;
+            ctx->names_key = key;
+        }
+        ctx->last_kernels = ctx->names_buf.c_str();
+    }
     const unsigned long long jmagic = (((unsigned long long)1 << 40) + (unsigned long long)J - 1) / (unsigned long long)J;
     for (int64_t s0 = 0; s0 < F; s0 += seg) {
         const int64_t Fs = std::min<int64_t>(seg, F - s0);

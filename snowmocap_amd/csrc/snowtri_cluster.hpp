@@ -82,6 +82,7 @@ __device__ __forceinline__ bool cluster_item(const double *__restrict__ K, const
     Vec3 h[C];
     double a[C], alpha[C], beta[C];
     bool okc[C];
+    bool out_of_range = false;   // a group's determinant product outside what its shared reciprocal is good for
     cluster_static_for<C>([&](auto CC) {
         constexpr int c = CC;
         const double *M = K + 9 * c;
@@ -113,6 +114,8 @@ __device__ __forceinline__ bool cluster_item(const double *__restrict__ K, const
         });
         {
             double run = rcp_nr1(pre[n - 1]);   // one reciprocal for the group's determinants (2^-46: 1e-13 m on the point)
+            const double pabs = fabs(pre[n - 1]);
+            out_of_range |= !(pabs > 1e-250 && pabs < 1e250);
             cluster_static_for<n - 1>([&](auto UU) {
                 constexpr int u = n - 1 - UU;   // n - 1 ... 1
                 inv[u] = run * pre[u - 1];
@@ -166,7 +169,7 @@ __device__ __forceinline__ bool cluster_item(const double *__restrict__ K, const
     oy = (float)(sy * r);
     oz = (float)(sz * r);
     os = (float)(sb * (0.00025 / (double)NP));   // :148
-    return !(sb < 1e300);
+    return !(sb < 1e300) || out_of_range;
 }
 
 // The same joint member by member, in the order and with the select semantics of phase 3 of k_frame_recompute

@@ -216,8 +216,11 @@ __device__ __forceinline__ bool lean_item(const double *__restrict__ Mlds, const
     oz = (float)(sz * r);
     os = sb * (0.00025 / (double)NPc);  // :148
     // dist == 0 (1/dist = inf), a singular pair (1/prod(det) poisons every pair) or NaN input leave sum s
-    // inf or NaN: the IEEE-exact routine decides those frames
-    return !(sb < 1e300);
+    // inf or NaN: the IEEE-exact routine decides those frames.  So does a product of determinants that left the range
+    // its shared reciprocal is good for (overflow -> every inverse 0, underflow -> inf: all pairs would be gated and the
+    // joint emitted as zeros without any NaN to betray it).
+    const double pabs = fabs(pre[NPc - 1]);
+    return !(sb < 1e300) || !(pabs > 1e-250 && pabs < 1e250);
 }
 
 // frames [f0, f0 + nf) of tile `t` when F frames are cut into ntiles tiles of base or base + 1 frames

@@ -43,7 +43,7 @@ def _align(n, a=16):
     return (n + a - 1) // a * a
 
 
-def gather_track_chunked(compute_block, n_local, F_total, regions, chunks=4, group=None, device=None):
+def gather_track_chunked(compute_block, n_local, F_total, regions, chunks=4, group=None, device=None, workspace=None):
     """Frame-sharded results -> the whole track on every rank, gathered WHILE the shard is still being computed.
 
     The rank's block of `per = ceil(F_total / world)` frame slots is cut into `chunks` pieces.  For piece i,
@@ -54,15 +54,23 @@ def gather_track_chunked(compute_block, n_local, F_total, regions, chunks=4, gro
     has finished.  On CPU tensors (gloo tests) the same steps run in order without streams.
 
     regions: {name: (shape_tail, torch dtype)} per frame.  Returns {name: tensor [F_total, *shape_tail]}.
+    workspace: a dict the caller keeps between calls -- the gathered tensors, the two send / receive slots and the side
+    stream are then allocated once and reused (steady state without allocations; the tensors returned by one call are
+    overwritten by the next).
     """
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
     per = (F_total + world - 1) // world
+    dev = torch.device(device) if device is not None else torch.device("cpu")
+    if F_total <= 0:                                       # an empty track: nothing to compute, nothing to gather
+        return {name: torch.empty((0,) + tuple(tail), dtype=dt, device=dev) for name, (tail, dt) in regions.items()}
+    if not 0 <= n_local <= per:
+        raise ValueError(f"gather_track_chunked: a rank holds {n_local} frames but contiguous blocks of "
+                         f"ceil({F_total} / {world}) = {per} frames are what is gathered (use shard_bounds)")
     chunks = max(1, min(int(chunks), max(1, per)))
     cs = (per + chunks - 1) // chunks                      # frame slots per piece (same on every rank)
-    on_gpu = device is not None and torch.device(device).type == "cuda"
-    dev = torch.device(device) if device is not None else torch.device("cpu")
+    on_gpu = dev.type == "cuda"
     # flat layout of one piece
     offs, total = {}, 0
     for name, (tail, dt) in regions.items():
@@ -71,9 +79,16 @@ def gather_track_chunked(compute_block, n_local, F_total, regions, chunks=4, gro
             nbytes *= int(d)
         offs[name] = (total, nbytes)
         total = _align(total + nbytes)
-    full = {name: torch.empty((world * per,) + tuple(tail), dtype=dt, device=dev) for name, (tail, dt) in regions.items()}
-    send = [torch.zeros(total, dtype=torch.uint8, device=dev) for _ in range(2)]
-    recv = [torch.empty(world * total, dtype=torch.uint8, device=dev) for _ in range(2)]
+    key = (world, per, cs, total, str(dev), tuple((n, tuple(t), str(d)) for n, (t, d) in regions.items()))
+    ws = workspace if workspace is not None else {}
+    if ws.get("key") != key:
+        ws.clear()
+        ws["key"] = key
+        ws["full"] = {name: torch.empty((world * per,) + tuple(tail), dtype=dt, device=dev) for name, (tail, dt) in regions.items()}
+        ws["send"] = [torch.zeros(total, dtype=torch.uint8, device=dev) for _ in range(2)]
+        ws["recv"] = [torch.empty(world * total, dtype=torch.uint8, device=dev) for _ in range(2)]
+        ws["side"] = torch.cuda.Stream(device=dev) if on_gpu else None
+    full, send, recv = ws["full"], ws["send"], ws["recv"]
 
     def views_of(flat):
         return {name: flat[o:o + nb].view(regions[name][1]).view((cs,) + tuple(regions[name][0]))
@@ -81,7 +96,8 @@ def gather_track_chunked(compute_block, n_local, F_total, regions, chunks=4, gro
 
     if on_gpu:
         main = torch.cuda.current_stream(dev)
-        side = torch.cuda.Stream(device=dev)
+        side = ws["side"]
+        side.wait_stream(main)                           # a reused workspace: earlier readers of `full` / the slots come first
         gathered = [None, None]
     for i in range((per + cs - 1) // cs):
         slot = i & 1
@@ -124,13 +140,16 @@ class ShardedTriangulator:
     on its GPU, piece by piece, and returns the gathered track: the all-gather of piece i (joints, person scores,
     counts and flags in one buffer, one collective) overlaps the kernel of piece i + 1."""
 
-    def __init__(self, K, R, t, params, pout_max=1, device=0, group=None, chunks=4):
+    def __init__(self, K, R, t, params, pout_max=1, device=0, group=None, chunks=4, reuse_buffers=False):
+        """reuse_buffers: keep the gathered tensors, the send / receive slots and the side stream between calls (no
+        allocation in steady state); the track returned by one run() is then overwritten by the next."""
         import numpy as np
         from .batch import BatchTriangulator
         self.bt = BatchTriangulator(K, R, t, params, pout_max=pout_max, out_dtype=np.float32, device=device)
         self.group = group
         self.chunks = chunks
         self.device = device
+        self._ws = {} if reuse_buffers else None
 
     def regions(self):
         import torch
@@ -148,7 +167,7 @@ class ShardedTriangulator:
 
         return gather_track_chunked(compute_block, int(kpts_local.shape[0]), F_total, self.regions(),
                                     chunks=self.chunks if chunks is None else chunks, group=self.group,
-                                    device=kpts_local.device)
+                                    device=kpts_local.device, workspace=self._ws)
 
 
 # ---------------------------------------------------------------------------------------------------

@@ -101,6 +101,7 @@ int main(void) {
     EXPECT(snowtri_set_timing(NULL, 1), SNOWTRI_ERR_BAD_ARG);
     EXPECT(snowtri_last_slow_frames(NULL), -1);
     EXPECT(snowtri_last_handover_persons(NULL, NULL), -1);
+    EXPECT(snowtri_last_kernel_names(NULL)[0], 0);
 
     /* ---- context creation with bad arguments -------------------------------------------------------------- */
     {

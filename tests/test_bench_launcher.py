@@ -27,6 +27,21 @@ def test_bench_self_launches_two_ranks():
     assert len({r["pid"] for r in d["ranks"]}) == 2          # two processes, one per (would-be) GPU
 
 
+def test_bench_gather_leg_is_the_products_sharded_entry():
+    """`with_track_allgather` goes through snowmocap_amd.sharded.gather_track_chunked (what ShardedTriangulator.run
+    calls): the dry run drives bench.gather_leg over two gloo ranks with a stand-in for the kernels, for every piece
+    count of a --chunks sweep, and checks the gathered track names every (rank, frame) once, in order."""
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--chunks", "1,3,4", "--frames", "41"],
+                       env=_env(), capture_output=True, text=True, timeout=240)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert sorted(d["gather_leg"]) == ["1", "3", "4"]
+    for chunks, g in d["gather_leg"].items():
+        assert g["ok"] and g["frames_gathered"] == 2 * 41, (chunks, g)
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "ShardedTriangulator" in src and "all_gather_into_tensor(gbuf" not in src      # no private gather in the bench
+
+
 def test_bench_refuses_a_world_size_mismatch():
     env = _env()
     env.update(RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1", MASTER_PORT="29571")

@@ -30,8 +30,10 @@ def api():
     return sm
 
 
-def _run(api, K, R, t, prm, kp, npers, pout, monkeypatch, handover=True):
-    monkeypatch.setenv("SNOWTRI_HANDOVER_MODE", "1" if handover else "0")
+def _run(api, K, R, t, prm, kp, npers, pout, monkeypatch, handover=True, mode=None):
+    """mode 1 (default): the streaming association (k_candidate_sums -> k_associate -> cluster kernels, <= 16 cameras);
+    mode 2: descriptors written by k_frame_recompute itself (<= 8 cameras); mode 0: everything inside k_frame_recompute."""
+    monkeypatch.setenv("SNOWTRI_HANDOVER_MODE", str(mode) if mode is not None else ("1" if handover else "0"))
     bt = api.BatchTriangulator(K, R, t, prm, pout_max=pout, out_dtype=np.float32)
     out = bt.run_host(kp, npers)      # (overflow / singular come back as out["status"], not as exceptions)
     out["handed"] = bt.ctx.last_handover_persons()
@@ -83,10 +85,85 @@ def test_complete_clusters_are_handed_over_and_match_the_oracle(api, C, P, in_dt
     _check(off, ref, pout, J, msg + " (hand-over off)")
     _same(out, off, msg)
     assert off["handed"] == (-1, -1)
+    # the second hand-over route (descriptors written by k_frame_recompute): same persons handed over, same results
+    in_kernel = _run(api, K, R, t, prm, kp, npers, pout, monkeypatch, mode=2)
+    _check(in_kernel, ref, pout, J, msg + " (hand-over from k_frame_recompute)")
+    _same(in_kernel, off, msg + " (hand-over from k_frame_recompute)")
+    assert sum(in_kernel["handed"]) == sum(out["handed"]), (in_kernel["handed"], out["handed"])
     # clean synthetic people, everyone seen by every camera: (nearly) every output person is a complete-graph cluster; a
     # ghost candidate that joins a cluster (or forms its own) makes a cluster of another shape
     assert sum(out["handed"]) == int(np.minimum(ref["count"], pout).sum()), (out["handed"], ref["count"])
     assert out["handed"][0] >= 0.6 * sum(out["handed"]) > 0, out["handed"]
+
+
+@pytest.mark.parametrize("C,P,J,in_dtype", [(9, 3, 133, np.float32), (12, 2, 133, np.float64), (16, 3, 133, np.float32),
+                                            (16, 8, 133, np.float32), (13, 2, 40, np.float32), (10, 4, 20, np.float32)])
+def test_wide_rigs_hand_their_clusters_to_the_lds_resident_kernel(api, C, P, J, in_dtype, monkeypatch):
+    """9-16 cameras (BASELINE configs[4] is 16 x 8): the streaming association hands complete-graph clusters to
+    k_cluster_fuse_wide (rays in LDS, four lanes per (person, joint)) and every other cluster to k_cluster_members.
+    Against the oracle, against the same launch with phase 3 inside k_frame_recompute, with the routes read back.
+    Some frames get a person one camera missed and a ragged list, so both kernels have work in the same launch."""
+    from snowmocap_amd import synth
+    from oracle import oracle as orc
+    rng = np.random.default_rng(1600 + 10 * C + P)
+    F = 3 if P == 8 else 6
+    K, R, t = synth.ring_rig(C, radius=5.0)
+    X = synth.make_people(rng, F, P, J=J)
+    kp, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=0.7, score_range=(3.5, 9.0), permute_persons=True, dtype=in_dtype)
+    npers = npers.copy()
+    kp[1, 2, 0, :, 2] = 0.0            # frame 1: one detection of camera 2 has no confidence -> a cluster with fewer members
+    npers[2, C - 1] = P - 1            # frame 2: the last camera lists one person less
+    prm = dict(PRM, keypoint_num=J, condense_person_num_tol=10)
+    ref = orc.triangulate_condense_batch(K, R, t, kp, npers, orc.make_params(**prm), 64)
+    pout = P + 2
+    out = _run(api, K, R, t, prm, kp, npers, pout, monkeypatch)
+    off = _run(api, K, R, t, prm, kp, npers, pout, monkeypatch, handover=False)
+    msg = f"C={C} P={P} J={J}"
+    _check(out, ref, pout, J, msg)
+    _check(off, ref, pout, J, msg + " (hand-over off)")
+    _same(out, off, msg)
+    assert off["handed"] == (-1, -1)
+    n_complete, n_other = out["handed"]
+    assert n_complete + n_other == int(np.minimum(ref["count"], pout).sum()), (out["handed"], ref["count"])
+    assert n_complete >= (F - 2) * P and n_other >= 2, out["handed"]
+
+
+def test_random_wide_rigs_against_oracle_and_phase3(api, monkeypatch):
+    """Randomised sweep over 9..16 cameras: 1..3 detections per camera with ragged lists, thresholds that switch the
+    filters on and off, float32 / float64 keypoints, Pout_max below and above the person count."""
+    from snowmocap_amd import synth
+    from oracle import oracle as orc
+    rng = np.random.default_rng(91600)
+    routes = np.zeros(2, np.int64)
+    for trial in range(14):
+        C = int(rng.integers(9, 17))
+        P = int(rng.integers(1, 4))
+        J = int(rng.choice([5, 33, 40, 133]))
+        F = int(rng.integers(1, 5))
+        K, R, t = synth.ring_rig(C, radius=float(rng.uniform(4, 6)))
+        X = synth.make_people(rng, F, P, J=J)
+        kp, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=float(rng.choice([0.3, 1.0, 3.0])), score_range=(2.0, 8.0),
+                                         permute_persons=True, dtype=np.float64 if trial % 3 == 0 else np.float32)
+        npers = npers.copy()
+        for _ in range(int(rng.integers(0, 3))):
+            npers[rng.integers(0, F), rng.integers(0, C)] = rng.integers(0, P + 1)
+        prm = dict(keypoint_score_threshold=float(rng.choice([0.0, 3.0, 3.0, 5.0])),
+                   average_score_threshold=float(rng.choice([0.0, 0.3, 1.5])),
+                   distance_threshold=float(rng.choice([0.02, 0.05, 1.0])),
+                   condense_distance_tol=float(rng.choice([0.05, 0.3, 10.0])),
+                   condense_person_num_tol=int(rng.choice([0, 2, 10])),
+                   condense_score_tol=float(rng.choice([0.0, 0.0, 0.3, 2.0])),
+                   center_point_index=int(rng.integers(0, J)), keypoint_num=J)
+        pout = int(rng.choice([1, 4, 16]))
+        ref = orc.triangulate_condense_batch(K, R, t, kp, npers, orc.make_params(**prm), 64)
+        out = _run(api, K, R, t, prm, kp, npers, pout, monkeypatch)
+        off = _run(api, K, R, t, prm, kp, npers, pout, monkeypatch, handover=False)
+        msg = f"trial {trial}: C={C} P={P} J={J} F={F} {prm} pout={pout} n={npers.tolist()}"
+        _check(out, ref, pout, J, msg)
+        _same(out, off, msg)
+        assert out["handed"][0] >= 0 and sum(out["handed"]) <= int(np.minimum(ref["count"], pout).sum()), (msg, out["handed"])
+        routes += out["handed"]
+    assert routes[0] > 5 and routes[1] > 5, routes
 
 
 def test_mixed_launch_incomplete_and_ragged_frames_stay_in_phase3(api, monkeypatch):

@@ -166,3 +166,46 @@ def test_carry_combination_reproduces_sequential_filter(cuts):
         start = combine_carries(payloads, q, A, cxd)
         got.append(locs[q][0] + _homogeneous(len(sh), q == 0, start, A))
     np.testing.assert_allclose(np.concatenate(got), want, rtol=0, atol=1e-11)
+
+
+def _edge_worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    from snowmocap_amd.sharded import gather_track_chunked
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    regions = {"xyzs": ((1, 5, 4), torch.float32), "count": ((), torch.int32)}
+    never = lambda lo, hi, views: (_ for _ in ()).throw(AssertionError("nothing to compute"))
+    empty = gather_track_chunked(never, 0, 0, regions, chunks=4)                      # an empty track
+    ok = empty["xyzs"].shape == (0, 1, 5, 4) and empty["count"].shape == (0,) and empty["count"].dtype == torch.int32
+    try:                                                                              # 6 frames on 2 ranks: blocks of 3
+        gather_track_chunked(never, 4, 6, regions, chunks=2)
+        refused = False
+    except ValueError as e:
+        refused = "contiguous blocks" in str(e)
+    # a reused workspace: two calls, the second overwrites the first's tensors in place; results as without it
+    ws = {}
+    outs = []
+    for call in range(2):
+        def compute_block(lo, hi, views, _c=call):
+            views["xyzs"][: hi - lo] = float(100 * _c + 10 * rank) + torch.arange(lo, hi, dtype=torch.float32).view(-1, 1, 1, 1)
+            views["count"][: hi - lo] = 1 + _c
+        lo, hi, per = shard_bounds(7, world, rank)
+        got = gather_track_chunked(compute_block, hi - lo, 7, regions, chunks=3, workspace=ws)
+        outs.append((got["xyzs"].data_ptr(), got["xyzs"][:, 0, 0, 0].clone(), got["count"].clone()))
+    same_buffer = outs[0][0] == outs[1][0]
+    want1 = torch.tensor([100.0, 101, 102, 103, 110, 111, 112])
+    good = torch.equal(outs[1][1], want1) and torch.equal(outs[0][1], want1 - 100) and bool((outs[1][2] == 2).all())
+    if rank == 0:
+        np.save(os.path.join(tmp, "edge.npy"), np.array([ok, refused, same_buffer, good]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_chunked_gather_edges_empty_track_oversized_block_reused_workspace(tmp_path):
+    """gather_track_chunked: F_total == 0 returns empty tensors (no division by zero), a rank that holds more than its
+    contiguous block is refused instead of silently truncated, a caller-kept workspace is reused without changing
+    results."""
+    port = 29900 + (os.getpid() % 90)
+    mp.spawn(_edge_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    assert np.load(tmp_path / "edge.npy").all(), np.load(tmp_path / "edge.npy")
