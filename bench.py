@@ -132,6 +132,7 @@ def dry_run(args):
     import torch
     F = max(1, args.frames if args.frames < 1000 else 37)
     gather = {}
+    from snowmocap_amd.sharded import auto_chunks
     for chunks in args.chunks:
         def fake_compute(lo, hi, views, _r=rank):
             views["xyzs"][: hi - lo] = (_r * 1000.0 + torch.arange(lo, hi, dtype=torch.float32)).view(-1, 1, 1, 1)
@@ -141,7 +142,7 @@ def dry_run(args):
         regions = {"xyzs": ((1, J, 4), torch.float32), "pscore": ((1,), torch.float32), "count": ((), torch.int32),
                    "flags": ((), torch.int32)}
         dt, full = gather_leg(dist, torch, None, lambda b, ch: sharded_run_generic(fake_compute, F, world * F, regions, ch, None),
-                              steps=2, warmup=1, chunks=chunks)
+                              steps=2, warmup=1, chunks=auto_chunks(F) if chunks == "auto" else chunks)
         want = torch.cat([r * 1000.0 + torch.arange(F, dtype=torch.float32) for r in range(world)])
         ok = bool(torch.equal(full["xyzs"][:, 0, 0, 0], want)) and bool((full["count"] == 1).all())
         gather[str(chunks)] = {"ok": ok, "frames_gathered": int(full["xyzs"].shape[0]), "s_per_step": dt / 2}
@@ -192,9 +193,10 @@ def main():
                     help="HIP streams the steps are issued on round-robin (one context each); 2 lets the ramp-up / "
                          "tail of consecutive 10 000-frame launches overlap")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the RCCL all-gather of the track")
-    ap.add_argument("--chunks", type=lambda v: [max(1, int(x)) for x in v.split(",")], default=[4],
-                    help="pieces the shard is cut into for the overlapped all-gather (ShardedTriangulator.run); a comma-separated "
-                         "list times each (the first is reported as with_track_allgather, all of them in its `sweep`)")
+    ap.add_argument("--chunks", type=lambda v: [x if x == "auto" else max(1, int(x)) for x in v.split(",")], default=["auto"],
+                    help="pieces the shard is cut into for the overlapped all-gather (ShardedTriangulator.run): `auto` (pieces of "
+                         ">= 32 768 frames, at most 8: one piece for a 10 000-frame shard) or a number; a comma-separated list "
+                         "times each (the first is reported as with_track_allgather, all of them in its `sweep`)")
     ap.add_argument("--no-per-frame", action="store_true", help="skip the per-frame API latency (main.py's own call sequence)")
     ap.add_argument("--method", choices=["pairwise", "dlt"], default="pairwise",
                     help="pairwise = the reference's algorithm (the metric); dlt = N-view DLT (row N3), for comparison only")
@@ -318,7 +320,7 @@ def main():
                 e2s.append(e2)
             e2 = float(np.median(e2s))
             ok = tuple(full["xyzs"].shape) == (world * F, Pout, J, 4) and bool((full["count"] == 1).all())
-            sweep.append({"chunks": chunks, "value": joints_per_step * K_steps / e2, "ms_per_step": e2 / K_steps * 1e3,
+            sweep.append({"chunks": chunks, "pieces": sht.last_chunks, "value": joints_per_step * K_steps / e2, "ms_per_step": e2 / K_steps * 1e3,
                           "gathered_track_ok": ok})
         sht.bt.close()
         with_gather = dict(sweep[0], sweep=sweep,

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Copy the summaries of scripts/profile.sh <tag> + scripts/pmc_multi.sh (under gpurun_out/) into profiles/<tag>/.
-TAG=${1:-r02}; SRC=gpurun_out/prof_$TAG; DST=profiles/$TAG; mkdir -p $DST
+TAG=${1:-r03}; SRC=gpurun_out/prof_$TAG; DST=profiles/$TAG; mkdir -p $DST
 cp $SRC/summary.txt $SRC/summary.json $SRC/bench_lines.jsonl $SRC/next_rows.jsonl $SRC/pmc_traffic.json $DST/
 cp $SRC/kernel_stats_stats.csv $DST/kernel_stats_cfg2_10k.csv
 cp $SRC/kernel_stats_stats_large.csv $DST/kernel_stats_large_2M.csv
@@ -17,7 +17,7 @@ for t in ("a3", "b3", "a5", "b5"):
     src = f"gpurun_out/pmc_multi/csv/pmc_{t}.csv"
     if not os.path.exists(src):
         continue
-    keep = [r for r in csv.DictReader(open(src)) if "k_frame_recompute" in r["Kernel_Name"] or "k_cluster_fuse" in r["Kernel_Name"]]
+    keep = [r for r in csv.DictReader(open(src)) if any(k in r["Kernel_Name"] for k in ("k_frame_recompute", "k_cluster_", "k_candidate_", "k_associate"))]
     cfg = {"3": "cfg3_8x4_10000", "5": "cfg5_16x8_12000"}[t[1]]
     dst = f"$DST/pmc_multi_{cfg}_{'sq' if t[0] == 'a' else 'lds'}.csv"
     with open(dst, "w", newline="") as fh:

@@ -16,7 +16,7 @@ for tag in ("a3", "b3", "a5", "b5"):
     for path in glob.glob("$OUT/%s/**/*counter_collection.csv" % tag, recursive=True):
         acc = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in csv.DictReader(open(path)):
-            if "k_frame_" in r["Kernel_Name"] or "k_cluster_" in r["Kernel_Name"]:
+            if any(k in r["Kernel_Name"] for k in ("k_frame_", "k_cluster_", "k_candidate_", "k_associate")):
                 key = r["Kernel_Name"].split("snowtri::")[1].split("(")[0][:40] + " grid=" + str(r.get("Grid_Size"))
                 acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for g, c in acc.items():

@@ -1,14 +1,14 @@
 #!/bin/bash
 # GPU box: rocprofv3 kernel stats + HBM-traffic counters for the bench workload and the other kernels.
 # usage: gpurun --timeout 1500 -- bash scripts/profile.sh <tag>      (outputs under gpurun_out/prof_<tag>/)
-TAG=${1:-r02}
+TAG=${1:-r03}
 ROOT=$PWD
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 # the bench commands whose JSON lines the numbers below belong to (configs[1]: 10 000 frames per launch)
-BENCH="python $ROOT/bench.py --streams 1 --steps 200 --warmup 20 --repeats 3 --no-cpu-baseline --no-extra --large-frames 0"   # one stream: launches do not overlap, so the trace duration is the kernel duration
-LARGE="python $ROOT/bench.py --steps 5 --warmup 2 --repeats 1 --no-cpu-baseline --no-extra --large-frames 2000000"
+BENCH="python $ROOT/bench.py --streams 1 --steps 200 --warmup 20 --repeats 3 --no-cpu-baseline --no-extra --no-per-frame --large-frames 0"   # one stream: launches do not overlap, so the trace duration is the kernel duration
+LARGE="python $ROOT/bench.py --steps 5 --warmup 2 --repeats 1 --no-cpu-baseline --no-extra --no-per-frame --large-frames 2000000"
 cd /tmp
 # 1. per-kernel time (no counters)
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/stats -o stats -- $BENCH > $OUT/stats_bench.log 2>&1

@@ -19,7 +19,7 @@ for path in find("*kernel_stats.csv"):
         name = r.get("Name", "")[:90]
         print(f"  {name:90s} calls={r.get('Calls')} avg_ns={r.get('AverageNs')} total_ns={r.get('TotalDurationNs')} pct={r.get('Percentage')}")
         keep.append({k: r.get(k) for k in ("Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs")})
-    summary["kernel_stats"] = keep
+    summary.setdefault("kernel_stats", {})[os.path.relpath(path, out).split(os.sep)[0]] = keep
 
 for tag in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
     files = [p for p in find("*counter_collection.csv") if f"/{tag}/" in p]
@@ -66,6 +66,22 @@ try:
                    "hbm_read_bytes_per_launch": fr_k * 1024.0 * scale_r, "hbm_write_bytes_per_launch": wr_k * 1024.0 * scale_w,
                    "hbm_bytes_per_launch": fr_k * 1024.0 * scale_r + wr_k * 1024.0 * scale_w,
                    "algorithmic_bytes_per_launch": 8512 * known[2], "source_sha256": bench.kernel_source_hash()}
+        # VALU wave-instructions per 64 joints, from the SQ pass on the large launch (its frame count from that run's bench line)
+        try:
+            frames_large = None
+            for ln in open(os.path.join(out, "pmc_sq.log")):
+                if ln.startswith("{") and '"large_batch"' in ln:
+                    frames_large = json.loads(ln)["large_batch"]["frames"]
+            insts = None
+            for kname, line in summary.get("pmc_sq", {}).items():
+                if "k_fused_lean" in kname and (insts is None or line.get("SQ_INSTS_VALU", 0) > insts):
+                    insts = line.get("SQ_INSTS_VALU")          # the large launch is the one with the most instructions
+            if frames_large and insts:
+                items = frames_large * 133 / 64.0
+                traffic["valu"] = {"SQ_INSTS_VALU_per_launch": insts, "frames": frames_large, "wave_items": items, "per_64_joints": insts / items}
+                print("== VALU wave-instructions per 64 joints: %.1f (SQ_INSTS_VALU %.6g on %d frames)" % (insts / items, insts, frames_large))
+        except Exception as e:
+            print("valu summary failed:", repr(e))
         json.dump(traffic, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
         print("== HBM traffic per fused launch: %.2f MB read + %.2f MB written = %.2f MB vs %.2f MB algorithmic (read scale %.3f, write scale %.3f)" % (
             traffic["hbm_read_bytes_per_launch"] / 1e6, traffic["hbm_write_bytes_per_launch"] / 1e6, traffic["hbm_bytes_per_launch"] / 1e6,

