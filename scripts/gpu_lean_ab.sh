@@ -12,6 +12,7 @@ run() {
   env "$@" python bench.py --steps 200 --warmup 20 --no-cpu-baseline --no-extra --no-per-frame --repeats 3 2>&1 | tail -1 | show
 }
 run SNOWTRI_LEAN_MODE=0
+run SNOWTRI_LEAN_WG_PER_CU=1
 run SNOWTRI_LEAN_WG_PER_CU=2
 run SNOWTRI_LEAN_WG_PER_CU=3
 run SNOWTRI_LEAN_WG_PER_CU=4

@@ -288,7 +288,7 @@ int snowtri_ctx_create(int32_t C, const double *K, const double *R, const double
     CTX_TRY(hipMalloc(&ctx->dM, sizeof(double) * std::max<size_t>(9, ctx->hM.size())));
     CTX_TRY(hipMalloc(&ctx->dt, sizeof(double) * std::max<size_t>(3, ctx->ht.size())));
     CTX_TRY(hipMalloc(&ctx->dpairs, sizeof(int32_t) * std::max<size_t>(2, ctx->hpairs.size())));
-    CTX_TRY(hipMalloc(&ctx->d_counters, sizeof(unsigned long long) * 8));
+    CTX_TRY(hipMalloc(&ctx->d_counters, sizeof(unsigned long long) * 16));
     CTX_TRY(hipMalloc(&ctx->dpairc, sizeof(double) * std::max<size_t>(6, hpairc.size())));
     {   // world->pixel matrices P_c = K_c [R_c^T | -R_c^T t_c] for the DLT method
         std::vector<double> hP((size_t)std::max(1, C) * 12, 0.0);
@@ -314,7 +314,7 @@ int snowtri_ctx_create(int32_t C, const double *K, const double *R, const double
     }
     if (ctx->npairs > 0)
         CTX_TRY(hipMemcpy(ctx->dpairs, ctx->hpairs.data(), sizeof(int32_t) * ctx->hpairs.size(), hipMemcpyHostToDevice));
-    CTX_TRY(hipMemset(ctx->d_counters, 0, sizeof(unsigned long long) * 8));
+    CTX_TRY(hipMemset(ctx->d_counters, 0, sizeof(unsigned long long) * 16));
     for (auto &e : ctx->ev) CTX_TRY(hipEventCreate(&e));
 #undef CTX_TRY
     *out = ctx;
@@ -1396,7 +1396,9 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax
     const int64_t seg_cap = ctx->handover_seg_frames > 0 ? ctx->handover_seg_frames : seg_frames;
     const int64_t seg = (stream || handover) ? std::min(seg_frames, seg_cap) : F;
     unsigned long long *next_frame = ctx->d_counters + 2, *hand_counters = ctx->d_counters + 3, *slow_count = ctx->d_counters + 6,
-                       *exact_count = ctx->d_counters + 7;
+                       *exact_count = ctx->d_counters + 7, *slow_count2 = ctx->d_counters + 8;
+    const uint32_t *final_slow_list = nullptr;                 // what the streaming association leaves to k_frame_recompute
+    const unsigned long long *final_slow_count = nullptr;
     {   // the kernels of this route, in launch order (rebuilt only when the route changes)
         const long long key = ((long long)C << 8) | (METHOD << 7) | ((int)sizeof(TIn) << 3) | ((int)sizeof(TOut) >> 2 << 2) |
                               (stream ? 2 : 0) | (handover ? 1 : 0) | ((long long)SL.threads << 16);
@@ -1435,7 +1437,7 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax
             desc = (ClusterDesc *)ctx->desc.p;
             words = (uint32_t *)(desc + (size_t)2 * cap);
         }
-        HIP_TRY(hipMemsetAsync(next_frame, 0, 6 * sizeof(unsigned long long), st));   // next_frame, the three hand-over counters, slow / exact frames
+        HIP_TRY(hipMemsetAsync(next_frame, 0, 7 * sizeof(unsigned long long), st));   // next_frame, the three hand-over counters, slow / exact / slow (second pass) frames
         const TIn *kp_seg = d_kpts + s0 * (int64_t)R * J * 3;
         const int32_t *np_seg = d_np ? d_np + s0 * C : nullptr;
         TOut *xyz_seg = d_xyzs + s0 * (int64_t)Pout * prm.kn * 4;
@@ -1445,7 +1447,7 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax
             if (stream) {
                 // ---- k_candidate_sums -> k_associate -> k_cluster_fuse, then k_frame_recompute on the frames left behind
                 const size_t sum_bytes = ((size_t)Fs * Kc * 8 + 255) & ~(size_t)255;
-                rc = ctx->sums.ensure(sum_bytes + (size_t)Fs * 8 + 256);   // + the frames left behind + the frames to re-do exactly
+                rc = ctx->sums.ensure(sum_bytes + (size_t)Fs * 12 + 256);   // + the frames left behind (two passes) + the frames to re-do exactly
                 if (rc) return rc;
                 double *csum = (double *)ctx->sums.p;
                 uint32_t *slow_list = (uint32_t *)((char *)ctx->sums.p + sum_bytes);
@@ -1474,8 +1476,26 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax
                 const int grid2 = (int)std::min<int64_t>(Fs, (int64_t)ctx->num_cus * ctx->assoc_wg_per_cu);
                 hipLaunchKernelGGL(k2, dim3(grid2), dim3(64), lds2, st, Fs, Pmax, J, (int)Kc, ctx->rig(), kp_seg, np_seg, prm, Pout, csum,
                                    (float *)xyz_seg, (float *)ps_seg, d_cnt + s0, fl_seg, desc, words, hand_counters, cap, word_cap, slow_list,
-                                   slow_count, (int)lds2, 1);
+                                   slow_count, (int)lds2, 1, (const uint32_t *)nullptr, (const unsigned long long *)nullptr);
                 HIP_TRY(hipGetLastError());
+                // the frames whose kept candidates did not fit that LDS (slow_count of them, known on the device only; none on
+                // the reference's workloads): again with room for every slot, one wave per CU; what this launch lists is
+                // left to k_frame_recompute
+                final_slow_list = slow_list;
+                final_slow_count = slow_count;
+                const size_t lds2_full = associate_lds_bytes_full(C, ctx->npairs, Pout, Kc);
+                if (lds2_full > lds2) {
+                    if (lds2_full > 48 * 1024 && ctx->raise_lds((const void *)k2, (int)lds2_full)) return SNOWTRI_ERR_HIP;
+                    uint32_t *slow_list2 = exact_list + Fs;
+                    const int per_cu2 = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds2_full));
+                    hipLaunchKernelGGL(k2, dim3((int)std::min<int64_t>(Fs, (int64_t)ctx->num_cus * per_cu2)), dim3(64), lds2_full, st, Fs, Pmax, J,
+                                       (int)Kc, ctx->rig(), kp_seg, np_seg, prm, Pout, csum, (float *)xyz_seg, (float *)ps_seg, d_cnt + s0, fl_seg,
+                                       desc, words, hand_counters, cap, word_cap, slow_list2, slow_count2, (int)lds2_full, 1,
+                                       (const uint32_t *)slow_list, (const unsigned long long *)slow_count);
+                    HIP_TRY(hipGetLastError());
+                    final_slow_list = slow_list2;
+                    final_slow_count = slow_count2;
+                }
             }
         }
         if (!stream) {
@@ -1529,8 +1549,7 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax
                 hipLaunchKernelGGL(kern, dim3(gridr), dim3(kBlock), lds, st, Fs, Pmax, J, (int)Kc, ctx->rig(), kp_seg, np_seg, prm, Pout,
                                    xyz_seg, ps_seg, d_cnt + s0, fl_seg, (char *)ctx->work.p, per_block, next_frame, (int)lds,
                                    (ClusterDesc *)nullptr, (uint32_t *)nullptr, hand_counters, 0u, 0u,
-                                   (const uint32_t *)((char *)ctx->sums.p + (((size_t)Fs * Kc * 8 + 255) & ~(size_t)255)),
-                                   (const unsigned long long *)slow_count);
+                                   final_slow_list, final_slow_count);
                 HIP_TRY(hipGetLastError());
             }
         }

@@ -323,7 +323,8 @@ __global__ __launch_bounds__(kBlock) void k_candidate_sums_exact(int Pmax, int J
 //   complete graph over one detection per camera carries the person index of every camera (4 bits x 16), any other its
 //   member words (rm | rs << 10 | q << 20, as in k_frame_recompute).
 // A frame whose decisions are not safe here -- a mean that is not finite or within 1e-6 of condense_score_tol, more kept
-// candidates or clusters than the wave's LDS holds -- is appended to slow_list and left to k_frame_recompute.
+// candidates or clusters than the wave's LDS holds -- is appended to slow_list: the host runs the listed frames through a
+// second launch with LDS for every candidate slot (one wave per CU), and what that leaves behind through k_frame_recompute.
 // LDS: [0, 64) scalars | staging of the output persons (~24 B each) | rows of the cameras (complete-graph test, 4 B x C) |
 // camera indices of the pairs (8 B each) | arena: kept index, cluster id, word (4 B each), score sum (8 B), centre (24 B)
 // per kept candidate, then 12 B per cluster.
@@ -345,6 +346,13 @@ __host__ inline size_t associate_lds_bytes(int C, int npairs, int Pout, int64_t 
     return want > cap ? cap : (want < 4096 ? 4096 : want);
 }
 
+// LDS that holds EVERY candidate slot of a frame (second launch, for the frames whose kept list did not fit the first)
+__host__ inline size_t associate_lds_bytes_full(int C, int npairs, int Pout, int64_t Kc) {
+    const size_t want = associate_arena_offset(C, npairs, Pout) + (size_t)(kAssocKeptBytes + 6) * (size_t)Kc + 64;
+    const size_t cap = 160 * 1024;
+    return want > cap ? cap : (want < 4096 ? 4096 : want);
+}
+
 template <typename TIn>
 __global__ __launch_bounds__(64, 4) void k_associate(int64_t F, int Pmax, int J, int Kc, Rig rig, const TIn *__restrict__ kpts,
                                                   const int32_t *__restrict__ n_persons, Params prm, int Pout,
@@ -353,7 +361,8 @@ __global__ __launch_bounds__(64, 4) void k_associate(int64_t F, int Pmax, int J,
                                                   uint32_t *__restrict__ out_flags, ClusterDesc *__restrict__ desc,
                                                   uint32_t *__restrict__ hand_words, unsigned long long *hand_counters,
                                                   uint32_t desc_cap, uint32_t word_cap, uint32_t *__restrict__ slow_list,
-                                                  unsigned long long *slow_count, int lds_total, int allow_complete) {
+                                                  unsigned long long *slow_count, int lds_total, int allow_complete,
+                                                  const uint32_t *__restrict__ frame_list, const unsigned long long *frame_count) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
     const int C = rig.C, R = C * Pmax, pp = Pmax * Pmax, NPq = rig.npairs;
@@ -377,7 +386,10 @@ __global__ __launch_bounds__(64, 4) void k_associate(int64_t F, int Pmax, int J,
     const int kn = prm.kn;   // == J (host-checked)
     for (int i = lane; i < 2 * NPq; i += 64) pairs[i] = rig.pairs[i];
 
-    for (int64_t f = blockIdx.x; f < F; f += gridDim.x) {
+    // frame_list: the frames a first launch with less LDS left behind (frame_count of them, known on the device only)
+    const int64_t nframes = frame_list ? (int64_t)*frame_count : F;
+    for (int64_t fi = blockIdx.x; fi < nframes; fi += gridDim.x) {
+        const int64_t f = frame_list ? (int64_t)frame_list[fi] : fi;
         const int32_t *np_f = n_persons ? n_persons + f * C : nullptr;
         const Kp3<TIn> *kpf = kp3 + f * (int64_t)R * J;
         const double *cs_f = csum + f * (int64_t)Kc;

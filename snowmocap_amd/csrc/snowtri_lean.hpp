@@ -51,7 +51,8 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t lean_rsrc(const void *base, un
 
 // cache-policy bits of the buffer instructions (gfx942 / gfx950: 1 = sc0, 2 = nt, 16 = sc1): development knobs
 #ifndef SNOWTRI_LEAN_STORE_AUX
-#define SNOWTRI_LEAN_STORE_AUX 0
+#define SNOWTRI_LEAN_STORE_AUX 2   // non-temporal output stores: the 21 MB a 10 000-frame launch writes leave the L2 while the launch
+                                   // runs instead of as one write-back at its end (measured: 32.2 -> 31.3 us per launch)
 #endif
 #ifndef SNOWTRI_LEAN_LOAD_AUX
 #define SNOWTRI_LEAN_LOAD_AUX 0
@@ -95,8 +96,8 @@ __device__ __forceinline__ float select_by_mask(float x, unsigned long long mask
 }
 
 // One (frame, joint): C rays, all C(C,2) pair solves, score-weighted fusion (see pairwise_item for the
-// algebra: fusion regrouped per ray, one reciprocal for all determinants).  Returns true if the item needs
-// the IEEE-exact routine.
+// algebra of the fusion regrouped per ray; here the determinants cancel out of it: no reciprocal per pair).  Returns
+// true if the item needs the IEEE-exact routine.
 #ifndef SNOWTRI_LEAN_M_VGPR
 #define SNOWTRI_LEAN_M_VGPR 0
 #endif
@@ -139,70 +140,61 @@ __device__ __forceinline__ bool lean_item(const double *__restrict__ Mlds, const
         else
             okm[c] = __ballot(!((double)cur[c].s < kthr));
     }
-    double bq[NPc], detq[NPc], pre[NPc], invq[NPc], prod_inv;
+    // A2 + :72-74 per camera pair WITHOUT a reciprocal of the determinant.  For rays t_m + S0 h_m and t_s - S1 h_s:
+    //   S0 = N0 / det, S1 = N1 / det,  N0 = a_s e - b g,  N1 = a_m g - b e,  det = a_m a_s - b^2 = |h_m x h_s|^2,
+    //   dist = |d . (h_m x h_s)| / |h_m x h_s| = |n| / sqrt(det)        (distance of two skew lines; d = t_s - t_m)
+    // so with rho = rsq(n^2 det):  1 / dist = rho det, and the pair's weight 2000 x score = ssum / dist = (ssum rho) det:
+    //   sq S0 = (ssum rho) N0,   sq S1 = (ssum rho) N1,   sq = (ssum rho) det
+    // -- the determinant cancels out of the fused point's numerators: one VALU instruction per pair less and no shared
+    // reciprocal (no chain over the pairs, no range of a product to watch).  Conditioning: n cancels to dist |h_m x h_s|
+    // from terms of size |d| |h_m| |h_s|, 1e-16 |d| / dist relative -- the same cancellation as ||Wm - Ws|| from
+    // 5 m coordinates in the reference.  The gate dist > dthr (:74) is taken on n^2 > dthr^2 det (both sides x det > 0).
+    // A singular pair (det = 0 => n = 0) or an exact intersection (n = 0) give rho = inf, a negative (rounding of
+    // nearly parallel rays) or NaN determinant rho = NaN: they reach the score sum, whatever the gates select.
     int q = 0;
-#pragma unroll
-    for (int mc = 0; mc < C - 1; mc++)
-#pragma unroll
-        for (int sc = mc + 1; sc < C; sc++, q++) {
-            bq[q] = dot3(h[mc], h[sc]);
-            detq[q] = fma(a[mc], a[sc], -(bq[q] * bq[q]));
-            pre[q] = q == 0 ? detq[0] : pre[q - 1] * detq[q];
-        }
-    {
-        double run = rcp_nr1(pre[NPc - 1]);  // 2^-46: 1e-13 m on the 3D point, far below its float32 rounding
-        prod_inv = run;
-#pragma unroll
-        for (int k = NPc - 1; k > 0; k--) {
-            invq[k] = run * pre[k - 1];
-            run *= detq[k];
-        }
-        invq[0] = run;
-    }
-    q = 0;
 #pragma unroll
     for (int mc = 0; mc < C - 1; mc++) {
 #pragma unroll
         for (int sc = mc + 1; sc < C; sc++, q++) {
-            // A2 (triangulation.py:24-31): per-ray norms hoisted, d = ts - tm in scalar registers
             const Vec3 &hm = h[mc], &hs = h[sc];
             const double dx = dS[3 * q], dy = dS[3 * q + 1], dz = dS[3 * q + 2];
-            const double b = bq[q], inv = invq[q];
+            const double b = dot3(hm, hs);
+            const double det = fma(a[mc], a[sc], -(b * b));
             const double e = fma(hm.z, dz, fma(hm.y, dy, hm.x * dx));
             const double g = fma(hs.z, dz, fma(hs.y, dy, hs.x * dx));
-            const double S0 = fma(a[sc], e, -(b * g)) * inv;
-            const double S1 = fma(a[mc], g, -(b * e)) * inv;
-            // Wm - Ws = hm S0 + hs S1 - d
-            const double fx = fma(hs.x, S1, fma(hm.x, S0, -dx));
-            const double fy = fma(hs.y, S1, fma(hm.y, S0, -dy));
-            const double fz = fma(hs.z, S1, fma(hm.z, S0, -dz));
-            const double d2 = fma(fz, fz, fma(fy, fy, fx * fx));
-            const double idist = __builtin_amdgcn_rsq(d2);
-            // :72-74  score = ((sm+ss)/2) / (dist*1000), zeroed by the three gates; sq = 2000 x that score
-            const unsigned long long keep = okm[mc] & okm[sc] & __ballot(!(d2 > dthr2));
-            double sq;
+            const double N0 = fma(a[sc], e, -(b * g));
+            const double N1 = fma(a[mc], g, -(b * e));
+            // n = h_m . (h_s x d)
+            const double cx = fma(hs.y, dz, -(hs.z * dy)), cy = fma(hs.z, dx, -(hs.x * dz)), cz = fma(hs.x, dy, -(hs.y * dx));
+            const double n = fma(hm.z, cz, fma(hm.y, cy, hm.x * cx));
+            const double n2 = n * n;
+            const double rho = __builtin_amdgcn_rsq(n2 * det);
+            // :72-74  score = ((sm+ss)/2) / (dist*1000), zeroed by the three gates; w det = 2000 x that score
+            const unsigned long long keep = okm[mc] & okm[sc] & __ballot(!(n2 > dthr2 * det));
+            double w;
             if constexpr (sizeof(TIn) == 4) {
-                sq = (double)select_by_mask((float)cur[mc].s + (float)cur[sc].s, keep) * idist;  // float32 sum as NumPy
+                w = (double)select_by_mask((float)cur[mc].s + (float)cur[sc].s, keep) * rho;  // float32 sum as NumPy
             } else {
                 const double ssum = (double)cur[mc].s + (double)cur[sc].s;
-                sq = __hiloint2double(__float_as_int(select_by_mask(__int_as_float(__double2hiint(ssum)), keep)),
-                                      __float_as_int(select_by_mask(__int_as_float(__double2loint(ssum)), keep))) * idist;
+                w = __hiloint2double(__float_as_int(select_by_mask(__int_as_float(__double2hiint(ssum)), keep)),
+                                     __float_as_int(select_by_mask(__int_as_float(__double2loint(ssum)), keep))) * rho;
             }
+            // alpha_m += sq S0, alpha_s -= sq S1, beta_m, beta_s += sq  with  sq S0 = w N0, sq S1 = w N1, sq = w det
             if (mc == 0) {
-                alpha[sc] = -sq * S1;
-                beta[sc] = sq;
+                alpha[sc] = -w * N1;
+                beta[sc] = w * det;
                 if (sc == 1) {
-                    alpha[0] = sq * S0;
-                    beta[0] = sq;
+                    alpha[0] = w * N0;
+                    beta[0] = beta[1];
                 } else {
-                    alpha[0] = fma(sq, S0, alpha[0]);
-                    beta[0] += sq;
+                    alpha[0] = fma(w, N0, alpha[0]);
+                    beta[0] = fma(w, det, beta[0]);
                 }
             } else {
-                alpha[mc] = fma(sq, S0, alpha[mc]);
-                alpha[sc] = fma(-sq, S1, alpha[sc]);
-                beta[mc] += sq;
-                beta[sc] += sq;
+                alpha[mc] = fma(w, N0, alpha[mc]);
+                alpha[sc] = fma(-w, N1, alpha[sc]);
+                beta[mc] = fma(w, det, beta[mc]);
+                beta[sc] = fma(w, det, beta[sc]);
             }
         }
     }
@@ -224,12 +216,9 @@ __device__ __forceinline__ bool lean_item(const double *__restrict__ Mlds, const
     oy = (float)(sy * r);
     oz = (float)(sz * r);
     os = sb * (0.00025 / (double)NPc);  // :148
-    // dist == 0 (1/dist = inf), a singular pair or NaN input leave sum s inf or NaN: the IEEE-exact routine decides
-    // those frames.  So does a product of determinants outside the range of its shared reciprocal: a product that
-    // overflowed (inf) or underflowed (0) turns rcp_nr1's Newton step into NaN (inf x 0), which reaches every pair and
-    // the sum; what is left is the narrow band where the reciprocal itself is flushed to 0 -- product x reciprocal is
-    // then 0 instead of 1 (one multiply, one compare).
-    return !(sb < 1e300) || !(pre[NPc - 1] * prod_inv > 0.5);
+    // dist == 0 or a singular pair (rho = inf), a negative determinant or NaN input (rho = NaN) leave sum s inf or NaN:
+    // the IEEE-exact routine decides those frames
+    return !(sb < 1e300);
 }
 
 // frames [f0, f0 + nf) of tile `t` when F frames are cut into ntiles tiles of base or base + 1 frames

@@ -233,8 +233,9 @@ def test_lean_agrees_with_fused_single(api, monkeypatch):
     assert (a["count"] == 1).all()
     assert np.abs(a["xyzs"][..., :3].astype(np.float64) - b["xyzs"][..., :3]).max() < XYZ_F32
     s0, s1 = a["xyzs"][..., 3].astype(np.float64), b["xyzs"][..., 3].astype(np.float64)
-    assert np.abs(s0 - s1).max() <= 3e-7 * np.abs(s1).max()
-    assert np.allclose(a["pscore"], b["pscore"], rtol=3e-7)
+    # each kernel is within 3e-7 of the float64 score (float32 rounding + its own raw v_rsq_f64 of a different argument)
+    assert np.abs(s0 - s1).max() <= 6e-7 * np.abs(s1).max()
+    assert np.allclose(a["pscore"], b["pscore"], rtol=6e-7)
 
 
 def test_lean_is_deterministic_and_split_invariant(api):
