@@ -1,7 +1,7 @@
 #!/bin/bash
 # Copy the summaries of scripts/profile.sh <tag> + scripts/pmc_multi.sh (under gpurun_out/) into profiles/<tag>/.
 TAG=${1:-r03}; SRC=gpurun_out/prof_$TAG; DST=profiles/$TAG; mkdir -p $DST
-cp $SRC/summary.txt $SRC/summary.json $SRC/bench_lines.jsonl $SRC/next_rows.jsonl $SRC/pmc_traffic.json $DST/
+cp $SRC/summary.txt $SRC/bench_lines.jsonl $SRC/next_rows.jsonl $SRC/pmc_traffic.json $DST/
 cp $SRC/kernel_stats_stats.csv $DST/kernel_stats_cfg2_10k.csv
 cp $SRC/kernel_stats_stats_large.csv $DST/kernel_stats_large_2M.csv
 cp $SRC/kernel_stats_stats_next.csv $DST/kernel_stats_next_rows.csv
@@ -9,8 +9,7 @@ cp $SRC/pmc_traffic.json profiles/pmc_traffic.json
 cp gpurun_out/pmc_multi/kernel_stats_cfg3.csv $DST/kernel_stats_multi_cfg3_8x4_10000.csv
 cp gpurun_out/pmc_multi/kernel_stats_cfg5.csv $DST/kernel_stats_multi_cfg5_16x8_12000.csv
 grep "^a\|^b\|^{" gpurun_out/pmc_multi_stdout.txt > $DST/multi_person_counters.txt
-[ -f gpurun_out/bench_default.json ] && cp gpurun_out/bench_default.json $DST/bench_default.json
-[ -f gpurun_out/bench_driver_like.json ] && cp gpurun_out/bench_driver_like.json $DST/bench_steps20.json
+cp $SRC/bench_default.json $SRC/bench_steps20.json $SRC/large_launches.json $DST/
 python - <<PY
 import csv, os
 for t in ("a3", "b3", "a5", "b5"):
@@ -26,4 +25,8 @@ for t in ("a3", "b3", "a5", "b5"):
         for r in keep:
             r = dict(r); r["Kernel_Name"] = r["Kernel_Name"][:60]; w.writerow(r)
 PY
+
+cp $SRC/summary.json $DST/counters.json
+python scripts/build_summary.py $TAG
+python scripts/make_tables.py --write
 ls $DST | wc -l

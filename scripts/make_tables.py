@@ -1,0 +1,114 @@
+#!/usr/bin/env python3
+"""The measured tables of README.md, DESIGN.md and profiles/README.md, rendered from profiles/<tag>/summary.json.
+
+    python scripts/make_tables.py --write      rewrite the blocks between `<!-- BEGIN measured:... -->` / `<!-- END ... -->`
+    python scripts/make_tables.py --check      exit 1 if a document's block differs from what summary.json renders to
+
+tests/test_docs_tables.py runs the check, so a number in a table cannot drift from the committed evidence.
+"""
+import json
+import os
+import re
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TAG = "r03"
+DOCS = {"README.md": ["headline"], "DESIGN.md": ["headline", "detail"], os.path.join("profiles", "README.md"): ["detail"]}
+
+
+def load(tag=TAG):
+    return json.load(open(os.path.join(ROOT, "profiles", tag, "summary.json")))
+
+
+def e(x, nd=2):
+    """1.23e10 style"""
+    return ("%." + str(nd) + "e") % x
+
+
+def headline(s):
+    b, b20 = s["bench_default"], s["bench_steps20"]
+    k10, k2m = s["fast_kernel_10k"], s["fast_kernel_2M"]
+    m3, m5 = s["multi"]["cfg3"], s["multi"]["cfg5"]
+    rows = [
+        ("`value`, BASELINE configs[1] (10 000 frames per launch, 2 streams, median of 7 regions)",
+         "%s joints/s (`python bench.py`), %s (`--steps 20 --warmup 5`, the driver's command); regions %.4f-%.4f ms per step"
+         % (e(b["value"]), e(b20["value"]), b["ms_per_step_min"], b["ms_per_step_max"])),
+        ("`roofline` (one stream, launches back to back): `%s`" % k10["kernel"],
+         "%.2f us per launch by rocprofv3 (%d launches), %.2f us by HIP events -> %.0f GB/s = **%.3f of 8 TB/s** (`roofline.frac` %.3f / %.3f in the two bench lines)"
+         % (k10["avg_us"], k10["calls"], b["kernel_us_mean"], 85.12e6 / (k10["avg_us"] * 1e-6) / 1e9, k10["hbm_frac"], b["roofline_frac"], b20["roofline_frac"])),
+        ("`roofline_region` (two streams, consecutive launches overlap)", "%.3f / %.3f of 8 TB/s" % (b["roofline_region_frac"], b20["roofline_region_frac"])),
+        ("one 2 000 000-frame launch (SURVEY 8d's roofline run)",
+         "%.2f ms (rocprofv3, %d launches: %.2f-%.2f) -> %s joints/s, **%.3f of 8 TB/s**; `large_batch.frac` %.3f"
+         % (k2m["avg_ms"], k2m["launches"], k2m["min_ms"], k2m["max_ms"], e(k2m["joints_per_s"]), k2m["hbm_frac"], b["large"]["frac"])),
+        ("HBM traffic per 10 000-frame launch (PMC, calibrated in the same pass)",
+         "%.2f MB read + %.2f MB written = %.2f MB against %.2f MB algorithmic (x %.3f)"
+         % (s["traffic"]["read_MB"], s["traffic"]["write_MB"], s["traffic"]["total_MB"], s["traffic"]["algorithmic_MB"], s["traffic"]["ratio"])),
+        ("VALU wave-instructions per 64 joints (`SQ_INSTS_VALU`, 2 000 000 frames)",
+         "%.0f; VALU busy %.0f %% at %.2f GHz" % (s["valu_per_64_joints"], 100 * s["fast_kernel_2M_counters"]["valu_busy"], s["fast_kernel_2M_counters"]["clock_GHz"])),
+        ("multi-person, 8 cameras x 4 persons, 10 000 frames (BASELINE configs[2])",
+         "%s frames/s, %s pair solves/s = %.3f of the fp64 vector peak (`extra_workloads[0]`); sum of the kernels under rocprofv3 %.3f ms"
+         % (e(b["extra"][0]["frames_per_s"]), e(b["extra"][0]["pair_solves_per_s"]), b["extra"][0]["frac"], m3["sum_of_kernels_ms_per_call"])),
+        ("multi-person, 16 x 8, 12 500 frames (one GPU's share of configs[4])",
+         "%s frames/s, %s pair solves/s = %.3f of the fp64 vector peak (`extra_workloads[1]`); 12 000 frames under rocprofv3: %.2f ms"
+         % (e(b["extra"][1]["frames_per_s"]), e(b["extra"][1]["pair_solves_per_s"]), b["extra"][1]["frac"], m5["sum_of_kernels_ms_per_call"])),
+        ("per-frame API (`main.py:50-71,106`, floor rig, 300 frames one by one)",
+         "%.0f us per frame through the reference-named calls, %.0f us as one F = 1 fused host call (reference: %.1f ms per frame)"
+         % (b["per_frame"]["api_sequence_us"], b["per_frame"]["fused_host_call_us"], b["per_frame"]["reference_ms"])),
+        ("CPU oracle on the box (OpenMP, %d threads)" % b["cpu"]["cores"],
+         "%s joints/s; GPU batch vs oracle %.1e m" % (e(b["cpu"]["value"]), b["cpu"]["gpu_vs_oracle_max_abs_m"])),
+    ]
+    out = ["| Quantity | Round 3 (`profiles/%s/`) |" % s["tag"], "|---|---|"]
+    out += ["| %s | %s |" % r for r in rows]
+    return "\n".join(out)
+
+
+def detail(s):
+    out = ["| Config | Kernel | calls | avg us | share | VALU busy | LDS conflict cycles / active LDS cycles |", "|---|---|---|---|---|---|---|"]
+    for cfg, label in (("cfg3", "8 x 4, 10 000 frames"), ("cfg5", "16 x 8, 12 000 frames")):
+        m = s["multi"][cfg]
+        tot = sum(k["total_ms"] for k in m["kernels"].values())
+        for name, k in sorted(m["kernels"].items(), key=lambda kv: -kv[1]["total_ms"]):
+            c = m.get("counters", {}).get(name, {})
+            out.append("| %s | `%s` | %d | %.1f | %.1f %% | %s | %s |" % (
+                label, name, k["calls"], k["avg_us"], 100 * k["total_ms"] / tot,
+                ("%.0f %%" % (100 * c["valu_busy"])) if "valu_busy" in c else "-",
+                ("%.3f" % c["lds_conflict_ratio"]) if "lds_conflict_ratio" in c else "-"))
+    return "\n".join(out)
+
+
+RENDER = {"headline": headline, "detail": detail}
+
+
+def blocks(s):
+    return {name: "<!-- BEGIN measured:%s (generated by scripts/make_tables.py from profiles/%s/summary.json: do not edit) -->\n%s\n<!-- END measured:%s -->"
+                  % (name, s["tag"], fn(s), name) for name, fn in RENDER.items()}
+
+
+def main():
+    s = load()
+    want = blocks(s)
+    bad = []
+    for doc, names in DOCS.items():
+        path = os.path.join(ROOT, doc)
+        text = open(path).read()
+        new = text
+        for name in names:
+            rx = re.compile(r"<!-- BEGIN measured:%s .*?<!-- END measured:%s -->" % (name, name), re.S)
+            if not rx.search(new):
+                bad.append("%s: no block `measured:%s`" % (doc, name))
+                continue
+            new = rx.sub(lambda m: want[name], new)
+        if new != text:
+            if "--write" in sys.argv:
+                open(path, "w").write(new)
+                print("updated", doc)
+            else:
+                bad.append("%s: a measured table differs from profiles/%s/summary.json (run scripts/make_tables.py --write)" % (doc, s["tag"]))
+    if bad:
+        print("\n".join(bad))
+        return 1
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

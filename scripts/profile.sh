@@ -26,6 +26,22 @@ python scripts/summarize_profile.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/summary.txt
 grep -h '"metric"' $OUT/stats_bench.log $OUT/stats_large_bench.log > $OUT/bench_lines.jsonl
 grep -h "^{" $OUT/stats_next.log > $OUT/next_rows.jsonl
+# the individual durations of the large launches (the stats CSV averages them with the small warm-up launches)
+python - <<PY
+import csv, glob, json
+rows = []
+for path in glob.glob("$OUT/stats_large/**/*kernel_trace.csv", recursive=True):
+    for r in csv.DictReader(open(path)):
+        if "k_fused_lean" in r["Kernel_Name"] or "k_fused_single" in r["Kernel_Name"]:
+            rows.append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+big = [d for d in rows if d > 1000000]
+json.dump({"what": "rocprofv3 --kernel-trace durations (ns) of the 2 000 000-frame launches of bench.py --large-frames 2000000",
+           "durations_ns": big, "small_launches_in_the_same_trace": len(rows) - len(big)}, open("$OUT/large_launches.json", "w"))
+print("large launches:", big)
+PY
+# the bench lines without the profiler: the default run and the driver's command
+python bench.py 2>/dev/null | tail -1 > $OUT/bench_default.json
+python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/bench_steps20.json
 # keep the merge small: drop raw traces, keep CSV summaries
 for d in stats stats_large stats_next; do cp $(find $OUT/$d -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_$d.csv 2>/dev/null; done
 find $OUT -name "*.db" -delete 2>/dev/null

@@ -33,7 +33,8 @@ sweeps = [("small_rigs auto", lambda e: T.test_random_small_rigs_against_oracle(
           ("per-frame api", lambda e: T.test_random_small_rigs_per_frame_api(api)),
           ("lean thresholds", lambda e: TL.test_lean_random_thresholds_and_person_lists(api)),
           ("lean special", lambda e: TL.test_lean_special_values(api)),
-          ("handover", lambda e: TH.test_random_rigs_with_handover_against_oracle_and_phase3(api, MP()))]
+          ("handover", lambda e: TH.test_random_rigs_with_handover_against_oracle_and_phase3(api, MP())),
+          ("handover wide rigs", lambda e: TH.test_random_wide_rigs_against_oracle_and_phase3(api, MP()))]
 fails = 0
 t0 = time.time()
 for r in range(rounds):
