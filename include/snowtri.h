@@ -68,7 +68,12 @@ typedef enum snowtri_method {
     SNOWTRI_PAIRWISE = 0, /* the reference's algorithm: pairwise skew-ray midpoints, score-weighted */
     SNOWTRI_DLT = 1       /* N-view DLT (A^T A smallest eigenvector; NOT reference behaviour).  One detection
                            * per camera: no association.  Several: the reference's association (candidates +
-                           * greedy clustering), then one DLT per cluster over its distinct observations. */
+                           * greedy clustering), then one DLT per cluster over its distinct observations.
+                           * Shape limits of that multi-detection route (and of DLT with more than 8 cameras):
+                           * at most 16 cameras, C * Pmax <= 1024 detections per frame, keypoint_num <= 256;
+                           * beyond them snowtri_triangulate_condense returns SNOWTRI_ERR_BAD_ARG and
+                           * snowtri_last_error() says why.  SNOWTRI_PAIRWISE has no such limit (larger rigs
+                           * fall back to the kernel that spills its candidates to HBM). */
 } snowtri_method;
 
 /* per-frame flag bits written to out_flags */

@@ -1576,8 +1576,12 @@ int fused_dispatch(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax, int J,
     int rc;
     if (method == SNOWTRI_DLT && (Pmax > 1 || C > 8)) {
         // several detections per camera: the reference's association (phases 1-2), then DLT per cluster
-        if (prm.kn > kRecomputeMaxKn || !recompute_shape_ok(C, Pmax, J, ctx->npairs, (int)sizeof(TIn)))
+        if (prm.kn > kRecomputeMaxKn || !recompute_shape_ok(C, Pmax, J, ctx->npairs, (int)sizeof(TIn))) {
+            g_last_error = "SNOWTRI_DLT with several detections per camera (or more than 8 cameras) supports at most 16 cameras, "
+                           "C * Pmax <= 1024 detections per frame and keypoint_num <= 256 (include/snowtri.h); the pairwise method "
+                           "has no such limit";
             return SNOWTRI_ERR_BAD_ARG;
+        }
         rc = launch_frame_recompute<1, TIn, TOut>(ctx, st, F, Pmax, J, d_kpts, d_np, prm, Pout, d_xyzs, d_ps, d_cnt, d_fl);
     } else if (method == SNOWTRI_DLT) {
         switch (C) {  // one detection per camera: no association needed

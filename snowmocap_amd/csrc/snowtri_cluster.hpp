@@ -71,7 +71,7 @@ __device__ __forceinline__ void cluster_static_for(F &&f) {
 }
 
 // One (cluster, joint): the item of k_fused_lean with the pair offsets read from LDS (28 pairs x 3 doubles do not fit
-// the scalar registers) and the determinants inverted four at a time.  K = [M | t | d] in LDS at offset 0.
+// the scalar registers), pairs in groups of four (register budget).  K = [M | t | d] in LDS at offset 0.
 // Returns true if the joint needs the sequential routine (exact intersection, singular pair, NaN).
 template <int C, typename TIn>
 __device__ __forceinline__ bool cluster_item(const double *__restrict__ K, const Kp3<TIn> (&cur)[C], float kthr_f32, double kthr,
@@ -82,7 +82,6 @@ __device__ __forceinline__ bool cluster_item(const double *__restrict__ K, const
     Vec3 h[C];
     double a[C], alpha[C], beta[C];
     bool okc[C];
-    bool out_of_range = false;   // a group's determinant product outside what its shared reciprocal is good for
     cluster_static_for<C>([&](auto CC) {
         constexpr int c = CC;
         const double *M = K + 9 * c;
@@ -98,58 +97,41 @@ __device__ __forceinline__ bool cluster_item(const double *__restrict__ K, const
         alpha[c] = 0.0;
         beta[c] = 0.0;
     });
+    // per pair, without a reciprocal of the determinant (see lean_item): with n = h_m . (h_s x d) the distance of the two
+    // rays is |n| / sqrt(det), so 1 / dist = det rsq(n^2 det) and the pair's weight times S0, S1, 1 is w N0, w N1, w det with
+    // w = ssum rsq(n^2 det)
     cluster_static_for<(NP + kGroup - 1) / kGroup>([&](auto GG) {
         constexpr int q0 = kGroup * GG;
         constexpr int n = NP - q0 < kGroup ? NP - q0 : kGroup;
         __builtin_amdgcn_sched_barrier(0);   // a group's LDS reads and temporaries stay inside the group (register budget)
-        double bq[n], det[n], pre[n], inv[n];
-        cluster_static_for<n>([&](auto UU) {
-            constexpr int u = UU, mc = ClusterPairs<C>::tab.m[q0 + u], sc = ClusterPairs<C>::tab.s[q0 + u];
-            bq[u] = dot3(h[mc], h[sc]);
-            det[u] = fma(a[mc], a[sc], -(bq[u] * bq[u]));
-            if constexpr (u == 0)
-                pre[0] = det[0];
-            else
-                pre[u] = pre[u - 1] * det[u];
-        });
-        {
-            double run = rcp_nr1(pre[n - 1]);   // one reciprocal for the group's determinants (2^-46: 1e-13 m on the point)
-            out_of_range |= !(pre[n - 1] * run > 0.5);   // (inf and 0 already turn the Newton step into NaN; this is the band where the reciprocal is flushed to 0)
-            cluster_static_for<n - 1>([&](auto UU) {
-                constexpr int u = n - 1 - UU;   // n - 1 ... 1
-                inv[u] = run * pre[u - 1];
-                run *= det[u];
-            });
-            inv[0] = run;
-        }
         cluster_static_for<n>([&](auto UU) {
             constexpr int u = UU, q = q0 + u, mc = ClusterPairs<C>::tab.m[q], sc = ClusterPairs<C>::tab.s[q];
             const Vec3 &hm = h[mc], &hs = h[sc];
             const double *dq = K + 12 * C + 3 * q;
             const double dx = dq[0], dy = dq[1], dz = dq[2];
-            const double b = bq[u];
             // A2 (triangulation.py:24-31)
+            const double b = dot3(hm, hs);
+            const double det = fma(a[mc], a[sc], -(b * b));
             const double e = fma(hm.z, dz, fma(hm.y, dy, hm.x * dx));
             const double g = fma(hs.z, dz, fma(hs.y, dy, hs.x * dx));
-            const double S0 = fma(a[sc], e, -(b * g)) * inv[u];
-            const double S1 = fma(a[mc], g, -(b * e)) * inv[u];
-            const double fx = fma(hs.x, S1, fma(hm.x, S0, -dx));
-            const double fy = fma(hs.y, S1, fma(hm.y, S0, -dy));
-            const double fz = fma(hs.z, S1, fma(hm.z, S0, -dz));
-            const double d2 = fma(fz, fz, fma(fy, fy, fx * fx));
-            const double idist = __builtin_amdgcn_rsq(d2);
-            // :72-74, sq = 2000 x the pair score; the gates select the score sum before the product (plain selects here: 28
+            const double N0 = fma(a[sc], e, -(b * g));
+            const double N1 = fma(a[mc], g, -(b * e));
+            const double cx = fma(hs.y, dz, -(hs.z * dy)), cy = fma(hs.z, dx, -(hs.x * dz)), cz = fma(hs.x, dy, -(hs.y * dx));
+            const double nn = fma(hm.z, cz, fma(hm.y, cy, hm.x * cx));
+            const double n2 = nn * nn;
+            const double rho = __builtin_amdgcn_rsq(n2 * det);
+            // :72-74, w det = 2000 x the pair score; the gates select the score sum before the product (plain selects here: 28
             // lane masks held for an inline v_cndmask, as in k_fused_lean, overflow the scalar registers)
-            const bool keep = okc[mc] && okc[sc] && !(d2 > dthr2);
-            double sq;
+            const bool keep = okc[mc] && okc[sc] && !(n2 > dthr2 * det);
+            double w;
             if constexpr (sizeof(TIn) == 4)
-                sq = (double)(keep ? (float)cur[mc].s + (float)cur[sc].s : 0.0f) * idist;   // float32 sum as NumPy
+                w = (double)(keep ? (float)cur[mc].s + (float)cur[sc].s : 0.0f) * rho;   // float32 sum as NumPy
             else
-                sq = (keep ? (double)cur[mc].s + (double)cur[sc].s : 0.0) * idist;
-            alpha[mc] = fma(sq, S0, alpha[mc]);
-            alpha[sc] = fma(-sq, S1, alpha[sc]);
-            beta[mc] += sq;
-            beta[sc] += sq;
+                w = (keep ? (double)cur[mc].s + (double)cur[sc].s : 0.0) * rho;
+            alpha[mc] = fma(w, N0, alpha[mc]);
+            alpha[sc] = fma(-w, N1, alpha[sc]);
+            beta[mc] = fma(w, det, beta[mc]);
+            beta[sc] = fma(w, det, beta[sc]);
         });
     });
     __builtin_amdgcn_sched_barrier(0);
@@ -168,7 +150,7 @@ __device__ __forceinline__ bool cluster_item(const double *__restrict__ K, const
     oy = (float)(sy * r);
     oz = (float)(sz * r);
     os = (float)(sb * (0.00025 / (double)NP));   // :148
-    return !(sb < 1e300) || out_of_range;
+    return !(sb < 1e300);
 }
 
 // The same joint member by member, in the order and with the select semantics of phase 3 of k_frame_recompute

@@ -42,25 +42,25 @@ def _run(api, K, R, t, prm, kp, npers, pout, monkeypatch, handover=True, mode=No
     return out
 
 
-def _check(out, ref, pout, J, msg):
+def _check(out, ref, pout, J, msg, xyz_tol=XYZ_F32):
     np.testing.assert_array_equal(out["count"], ref["count"], err_msg=msg)
     for f in range(len(ref["count"])):
         m = min(int(ref["count"][f]), pout)
         assert not out["xyzs"][f, m:].any(), f"{msg} frame {f}: unused slots must be zero"
         if m:
             assert_scores_close(out["xyzs"][f, :m, :, 3], ref["kscore"][f, :m], rtol=3e-7, what=f"{msg} kscore frame {f}")
-            assert_xyz_close(out["xyzs"][f, :m, :, :3], ref["xyz"][f, :m], XYZ_F32, score_ref=ref["kscore"][f, :m],
+            assert_xyz_close(out["xyzs"][f, :m, :, :3], ref["xyz"][f, :m], xyz_tol, score_ref=ref["kscore"][f, :m],
                              what=f"{msg} xyz frame {f}")
             assert_scores_close(out["pscore"][f, :m], ref["pscore"][f, :m], rtol=3e-7, nterms=J, what=f"{msg} pscore frame {f}")
 
 
-def _same(a, b, msg):
+def _same(a, b, msg, xyz_tol=XYZ_F32):
     """hand-over on vs off: same counts, same NaN pattern, values within the float32 tolerances of both."""
     np.testing.assert_array_equal(a["count"], b["count"], err_msg=msg)
     xa, xb = a["xyzs"].astype(np.float64), b["xyzs"].astype(np.float64)
     assert np.array_equal(np.isnan(xa), np.isnan(xb)), msg
     fin = np.isfinite(xa) & np.isfinite(xb)
-    assert np.abs(xa[..., :3] - xb[..., :3])[fin[..., :3]].max(initial=0.0) < 2 * XYZ_F32, msg
+    assert np.abs(xa[..., :3] - xb[..., :3])[fin[..., :3]].max(initial=0.0) < 2 * xyz_tol, msg
     sa, sb = xa[..., 3][fin[..., 3]], xb[..., 3][fin[..., 3]]
     assert np.all(np.abs(sa - sb) <= 6e-7 * np.abs(sb)), msg
 
@@ -160,8 +160,13 @@ def test_random_wide_rigs_against_oracle_and_phase3(api, monkeypatch):
         out = _run(api, K, R, t, prm, kp, npers, pout, monkeypatch)
         off = _run(api, K, R, t, prm, kp, npers, pout, monkeypatch, handover=False)
         msg = f"trial {trial}: C={C} P={P} J={J} F={F} {prm} pout={pout} n={npers.tolist()}"
-        _check(out, ref, pout, J, msg)
-        _same(out, off, msg)
+        # float32 outputs take 1/dist from the raw v_rsq_f64 (5e-8 relative): the fused point sees it through the weights
+        # s_q / sum s, i.e. times the SPREAD of the member points.  With the distance gate practically off (1 m) a ring of
+        # 9-16 cameras fuses pairs of nearly opposite cameras whose ill-conditioned points lie tens of metres apart:
+        # 5e-8 x 50 m on top of the float32 rounding (soak: 3.2e-6 m).  The required bar is 1e-4 m.
+        tol = XYZ_F32 if prm["distance_threshold"] < 1.0 else 8e-6
+        _check(out, ref, pout, J, msg, xyz_tol=tol)
+        _same(out, off, msg, xyz_tol=tol)
         assert out["handed"][0] >= 0 and sum(out["handed"]) <= int(np.minimum(ref["count"], pout).sum()), (msg, out["handed"])
         routes += out["handed"]
     # (with 36-120 camera pairs a ghost candidate joins most clusters: complete graphs are the minority in random scenes)
