@@ -241,6 +241,17 @@ int64_t snowtri_last_slow_frames(snowtri_ctx *ctx);
  * stays valid until the next fused call on this context.  bench.py names the kernel its roofline belongs to with it. */
 const char *snowtri_last_kernel_names(const snowtri_ctx *ctx);
 
+/* Device-side bounds checks (debug builds only: `make -C snowmocap_amd/csrc debug` compiles the kernels with
+ * -DSNOWTRI_DEBUG_BOUNDS into snowmocap_amd/libsnowtri_dbg.so): every index a kernel derives -- tile and frame ranges,
+ * LDS arena offsets, candidate slots, descriptor and member-list positions, person fields -- is checked where it is
+ * used.  Returns the number of violated checks since the last call and clears it (0 = clean); *first (may be NULL)
+ * receives (check code << 32 | source line) of the first one.  -1: this library was built without the checks
+ * (the production build); -2: HIP error.  Synchronises the device. */
+int64_t snowtri_debug_faults(snowtri_ctx *ctx, uint64_t *first);
+/* Debug builds: launches one wave in which exactly three lanes violate a check with code 99, so that a test can see the
+ * mechanism report (snowtri_debug_faults then returns 3).  -1 in the production build. */
+int snowtri_debug_selftest(snowtri_ctx *ctx);
+
 /* Test / diagnostics hook for the multi-person path: output persons of the last snowtri_triangulate_condense call
  * (its last segment) whose fusion (triangulation.py:136-152) was handed from the association kernel to the streaming
  * cluster kernels.  Returns the persons whose cluster is the complete graph over one detection per camera, and in

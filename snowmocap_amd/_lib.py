@@ -97,6 +97,8 @@ _SIGNATURES = {
     "snowtri_last_slow_frames": (ct.c_int64, [_c_p]),
     "snowtri_last_handover_persons": (ct.c_int64, [_c_p, _c_p]),
     "snowtri_last_kernel_names": (ct.c_char_p, [_c_p]),
+    "snowtri_debug_faults": (ct.c_int64, [_c_p, ct.POINTER(ct.c_uint64)]),
+    "snowtri_debug_selftest": (ct.c_int, [_c_p]),
 }
 
 _lib = None
@@ -243,6 +245,13 @@ class Context:
     def last_kernel_names(self):
         """Template names of the kernels the last fused call launched, in launch order."""
         return (lib().snowtri_last_kernel_names(self.handle) or b"").decode()
+
+    def debug_faults(self):
+        """(violated device-side bounds checks since the last call, code << 32 | line of the first); (-1, 0) unless the
+        library is the -DSNOWTRI_DEBUG_BOUNDS build (libsnowtri_dbg.so)."""
+        first = ct.c_uint64(0)
+        n = int(lib().snowtri_debug_faults(self.handle, ct.byref(first)))
+        return n, int(first.value)
 
     def last_handover_persons(self):
         """(persons fused as complete-graph clusters, persons fused from member lists) of the last multi-person call,

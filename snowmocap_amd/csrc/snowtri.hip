@@ -419,6 +419,42 @@ int64_t snowtri_last_handover_persons(snowtri_ctx *ctx, int64_t *n_other) {
 
 const char *snowtri_last_kernel_names(const snowtri_ctx *ctx) { return ctx ? ctx->last_kernels : ""; }
 
+#ifdef SNOWTRI_DEBUG_BOUNDS
+namespace {
+__global__ void k_debug_selftest(int n) { SNOWTRI_DEV_CHECK((int)threadIdx.x < n, 99); }   // lanes n .. 63 violate it
+}
+#endif
+int snowtri_debug_selftest(snowtri_ctx *ctx) {
+#ifdef SNOWTRI_DEBUG_BOUNDS
+    if (!ctx) return SNOWTRI_ERR_BAD_ARG;
+    ENTER_DEVICE(ctx->device);
+    hipLaunchKernelGGL(k_debug_selftest, dim3(1), dim3(64), 0, nullptr, 61);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    return SNOWTRI_OK;
+#else
+    (void)ctx;
+    return -1;
+#endif
+}
+
+int64_t snowtri_debug_faults(snowtri_ctx *ctx, uint64_t *first) {
+    if (first) *first = 0;
+#ifdef SNOWTRI_DEBUG_BOUNDS
+    if (!ctx) return -2;
+    DeviceGuard guard(ctx->device);
+    if (guard.err != hipSuccess || hipDeviceSynchronize() != hipSuccess) return -2;
+    unsigned long long v[2] = {0ull, 0ull}, zero[2] = {0ull, 0ull};
+    if (hipMemcpyFromSymbol(v, HIP_SYMBOL(snowtri::g_dev_fault), sizeof(v)) != hipSuccess) return -2;
+    if (hipMemcpyToSymbol(HIP_SYMBOL(snowtri::g_dev_fault), zero, sizeof(zero)) != hipSuccess) return -2;
+    if (first) *first = v[1];
+    return (int64_t)v[0];
+#else
+    (void)ctx;
+    return -1;   // this build has no device-side checks
+#endif
+}
+
 int64_t snowtri_num_candidate_slots(int32_t C, int32_t Pmax) {
     if (C < 0 || Pmax < 0) return -1;
     return (int64_t)C * (C - 1) / 2 * Pmax * Pmax;

@@ -117,6 +117,7 @@ __global__ __launch_bounds__(THREADS, SumsShape<THREADS>::kWavesPerSimd) void k_
                 const int i = tid + n * B, ic = i < R * nj ? i : R * nj - 1;
                 const int r = (int)(((unsigned long long)(unsigned)ic * magic_nj) >> 40), jj = ic - r * nj;
                 const int c = (int)(((unsigned long long)(unsigned)r * magic_pmax) >> 40);
+                SNOWTRI_DEV_CHECK(r >= 0 && r < R && j0 + jj >= 0 && j0 + jj < J, 10);   // keypoint (row, joint) inside the frame
                 pre[n] = kpf[(size_t)r * J + j0 + jj];
                 pre_off[n] = i < R * nj ? ((jj * jstr + kP1Rec * r) | (c << 20)) : -1;
             }
@@ -124,8 +125,10 @@ __global__ __launch_bounds__(THREADS, SumsShape<THREADS>::kWavesPerSimd) void k_
         auto commit = [&]() {
 #pragma unroll
             for (int n = 0; n < NPF; n++)
-                if (pre_off[n] >= 0)
+                if (pre_off[n] >= 0) {
+                    SNOWTRI_DEV_CHECK((pre_off[n] & 0xfffff) + kP1Rec <= arena_bytes && (pre_off[n] >> 20) < C, 11);   // record inside the arena
                     p1_store_record<TIn>(rec + (pre_off[n] & 0xfffff), make_ray(Ml + 9 * (pre_off[n] >> 20), pre[n].u, pre[n].v), pre[n].s);
+                }
         };
         fetch(0, J < Jc ? J : Jc);
         __syncthreads();
@@ -165,6 +168,7 @@ __global__ __launch_bounds__(THREADS, SumsShape<THREADS>::kWavesPerSimd) void k_
                 t.ob = kP1Rec * (sc * Pmax + ps0);
                 t.d = {pc[0], pc[1], pc[2]};
                 t.cand = live;
+                SNOWTRI_DEV_CHECK(!live || (t.k0 >= 0 && t.k0 + GSC <= Kc && t.oa + kP1Rec <= jstr && t.ob + GSC * kP1Rec <= jstr), 12);   // slots and rows of the item
                 if constexpr (GSC == 1) t.cand = live && pm < np_l[mc] && ps0 < np_l[sc];   // empty slots stay at 0
                 return t;
             };
@@ -390,6 +394,7 @@ __global__ __launch_bounds__(64, 4) void k_associate(int64_t F, int Pmax, int J,
     const int64_t nframes = frame_list ? (int64_t)*frame_count : F;
     for (int64_t fi = blockIdx.x; fi < nframes; fi += gridDim.x) {
         const int64_t f = frame_list ? (int64_t)frame_list[fi] : fi;
+        SNOWTRI_DEV_CHECK(f >= 0 && f < F, 21);   // (a listed frame index belongs to the segment)
         const int32_t *np_f = n_persons ? n_persons + f * C : nullptr;
         const Kp3<TIn> *kpf = kp3 + f * (int64_t)R * J;
         const double *cs_f = csum + f * (int64_t)Kc;
@@ -432,6 +437,7 @@ __global__ __launch_bounds__(64, 4) void k_associate(int64_t F, int Pmax, int J,
                 const unsigned long long m = __ballot(kp_);
                 const int cnt = __popcll(m);
                 if (n + cnt > n_cap) slow = true;
+                SNOWTRI_DEV_CHECK(!(kp_ && !slow) || n + __popcll(m & ((1ull << lane) - 1ull)) < n_cap, 20);   // kept index inside the arena
                 if (kp_ && !slow) kidx[n + __popcll(m & ((1ull << lane) - 1ull))] = k;
                 n += cnt;
             }
@@ -491,6 +497,7 @@ __global__ __launch_bounds__(64, 4) void k_associate(int64_t F, int Pmax, int J,
                     slow = true;
                     break;
                 }
+                SNOWTRI_DEV_CHECK(mc >= 0 && mc < n - 1, 22);   // the seed is a kept candidate, never the last one (:107)
                 const double mx = cen[3 * mc], my = cen[3 * mc + 1], mz = cen[3 * mc + 2];
                 int cnt = 0;
                 for (int base = mc + 1; base < n; base += 64) {
@@ -628,6 +635,8 @@ __global__ __launch_bounds__(64, 4) void k_associate(int64_t F, int Pmax, int J,
                     if (!slow) {
                         const int nsl = nout < Pout ? nout : Pout;
                         for (int sl = lane; sl < nsl; sl += 64) {
+                            SNOWTRI_DEV_CHECK((st_size[sl] == 0 ? (uint32_t)bc : (uint32_t)bg) + st_idx[sl] < desc_cap, 23);   // descriptor inside its list
+                            SNOWTRI_DEV_CHECK(st_size[sl] == 0 || (unsigned long long)bw + st_word[sl] + (unsigned)st_size[sl] <= (unsigned long long)word_cap, 24);
                             if (st_size[sl] == 0)
                                 desc[(uint32_t)bc + st_idx[sl]] = ClusterDesc{(uint32_t)f, st_a[sl], (uint32_t)sl, st_word[sl]};
                             else
@@ -644,7 +653,11 @@ __global__ __launch_bounds__(64, 4) void k_associate(int64_t F, int Pmax, int J,
             }
         }
         if (slow) {
-            if (lane == 0) slow_list[atomicAdd(slow_count, 1ull)] = (uint32_t)f;
+            if (lane == 0) {
+                const unsigned long long at = atomicAdd(slow_count, 1ull);
+                SNOWTRI_DEV_CHECK(at < (unsigned long long)F, 25);   // the list holds one entry per frame of the segment
+                slow_list[at] = (uint32_t)f;
+            }
             continue;
         }
         // unused slots: one flat sweep of 16-byte stores

@@ -327,6 +327,7 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_CLUSTER_WAVES) void k_cluster_fuse(
             it.persons = d.y;
             it.slot = d.z;
             it.valid = d.z < (uint32_t)Pout;   // (a voided entry, see the hand-over in k_frame_recompute)
+            SNOWTRI_DEV_CHECK(di < ndesc && it.j < (uint32_t)J && (d.z < (uint32_t)Pout || d.z == 0xffffffffu), 30);   // descriptor and joint inside their ranges
         }
         return it;
     };
@@ -334,6 +335,7 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_CLUSTER_WAVES) void k_cluster_fuse(
         if (it.valid) {
 #pragma unroll
             for (int c = 0; c < C; c++) {
+                SNOWTRI_DEV_CHECK(((it.persons >> (4 * c)) & 15u) < (uint32_t)Pmax, 31);   // person index of camera c
                 const uint32_t row = (it.frame * (uint32_t)C + (uint32_t)c) * (uint32_t)Pmax + ((it.persons >> (4 * c)) & 15u);
                 dst[c] = kp3[(uint64_t)row * (uint32_t)J + it.j];
             }

@@ -378,6 +378,7 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
             f = (int64_t)frame_list[f];
         }
         if (f >= F) break;
+        SNOWTRI_DEV_CHECK(f >= 0 && (size_t)blockIdx.x * scratch_per_block + scratch_per_block <= (size_t)gridDim.x * scratch_per_block, 40);   // frame and slab of this workgroup
         const int32_t *np_f = n_persons ? n_persons + f * C : nullptr;
         const Kp3<TIn> *kpf = kp3 + f * (int64_t)R * J;
         bool ragged = false;

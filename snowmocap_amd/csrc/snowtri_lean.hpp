@@ -302,6 +302,8 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean(
 #endif
 
     for (int ord = 0; tile < ntiles; tile += wstride, ord++) {
+        SNOWTRI_DEV_CHECK(f0 >= 0 && nf >= 1 && nf <= kLeanTw && f0 + nf <= F, 1);                 // the tile lies inside the batch
+        SNOWTRI_DEV_CHECK((ord * kLeanWaves + wave + 1) << kLeanSlowShift <= slow_words * 32, 2);  // its slow-frame bits exist
         const __amdgpu_buffer_rsrc_t rin = lean_rsrc(kp3 + f0 * (int64_t)(C * JC), (unsigned)(nf * C * JC) * kRec);
         const __amdgpu_buffer_rsrc_t rout =
             lean_rsrc(reinterpret_cast<float4 *>(out4) + f0 * (int64_t)JC, (unsigned)(nf * JC) * 16u);

@@ -9,6 +9,23 @@
 
 namespace snowtri {
 
+// Device-side bounds checks under a debug macro (the reference has none; `make debug` builds
+// snowmocap_amd/libsnowtri_dbg.so with -DSNOWTRI_DEBUG_BOUNDS).  A violated check counts itself in g_dev_fault[0] and
+// the first one leaves (code << 32 | source line) in g_dev_fault[1]; snowtri_debug_faults() reads and clears them.
+// The production build compiles the checks out.
+#ifdef SNOWTRI_DEBUG_BOUNDS
+__device__ unsigned long long g_dev_fault[2];
+#define SNOWTRI_DEV_CHECK(cond, code)                                                                             \
+    do {                                                                                                          \
+        if (!(cond)) {                                                                                            \
+            if (atomicAdd(&::snowtri::g_dev_fault[0], 1ull) == 0ull)                                              \
+                ::snowtri::g_dev_fault[1] = ((unsigned long long)(code) << 32) | (unsigned long long)__LINE__;    \
+        }                                                                                                         \
+    } while (0)
+#else
+#define SNOWTRI_DEV_CHECK(cond, code) ((void)0)
+#endif
+
 // Device copy of snowtri_params (include/snowtri.h), already validated on the host:
 // center is wrapped into [0, J), 0 <= kn <= J.
 struct Params {

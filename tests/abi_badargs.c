@@ -102,6 +102,8 @@ int main(void) {
     EXPECT(snowtri_last_slow_frames(NULL), -1);
     EXPECT(snowtri_last_handover_persons(NULL, NULL), -1);
     EXPECT(snowtri_last_kernel_names(NULL)[0], 0);
+    EXPECT(snowtri_debug_faults(NULL, NULL) < 0, 1);
+    EXPECT(snowtri_debug_selftest(NULL) != SNOWTRI_OK, 1);
 
     /* ---- context creation with bad arguments -------------------------------------------------------------- */
     {
