@@ -166,6 +166,7 @@ struct snowtri_ctx {
     bool last_handover = false;  // the last fused call went through k_frame_recompute with the cluster hand-over armed
     int general_mode = 0;  // dev/test knob: 0 auto, 1 force the spill kernel, 2 force the recompute kernel
     int lean_mode = 1;     // dev/test knob: 0 keeps float32-output batches on k_fused_single (A/B against k_fused_lean)
+    int lean_coop = 1;     // dev/test knob: 0 keeps small launches on k_fused_lean (A/B against k_fused_lean_coop)
     int handover_mode = 1; // dev/test knob: 1 streaming association (k_candidate_sums / k_associate / k_cluster_fuse), 2 hand-over from
                            // inside k_frame_recompute, 0 the whole multi-person path inside k_frame_recompute
     int sums_threads = 0, sums_lds_kb = 0, assoc_wg_per_cu = 16;   // dev knobs of the streaming association (0: automatic)
@@ -228,6 +229,7 @@ int snowtri_ctx_create(int32_t C, const double *K, const double *R, const double
     ctx->C = C;
     if (const char *gm = getenv("SNOWTRI_GENERAL_MODE")) ctx->general_mode = atoi(gm);
     if (const char *lm = getenv("SNOWTRI_LEAN_MODE")) ctx->lean_mode = atoi(lm);
+    if (const char *lc = getenv("SNOWTRI_LEAN_COOP")) ctx->lean_coop = atoi(lc);
     if (const char *hm = getenv("SNOWTRI_HANDOVER_MODE")) ctx->handover_mode = atoi(hm);
     // every environment knob is read HERE, once: nothing on the launch path calls getenv
     if (const char *e = getenv("SNOWTRI_SUMS_THREADS")) ctx->sums_threads = atoi(e);
@@ -1275,6 +1277,27 @@ int launch_fused_lean(snowtri_ctx *ctx, hipStream_t st, int64_t F, const TIn *d_
     auto kern = k_fused_lean<C, TIn, kLeanJ>;
     const int64_t W_small = (int64_t)ctx->num_cus * wg_small * kLeanWaves;
     const int64_t seg_max = (int64_t)kLeanTw * kLeanWaves * 512 * ((int64_t)ctx->num_cus * 6);  // <= 512 tiles per wave
+    // small launch (at most kCoopMaxFrames frames per resident workgroup): workgroup tiles, passes dealt to the waves,
+    // cooperative epilogue (k_fused_lean_coop)
+    if (ctx->lean_coop != 0 && F <= (int64_t)ctx->num_cus * wg_small * kCoopMaxFrames) {
+        auto kc = k_fused_lean_coop<C, TIn, kLeanJ>;
+        const int grid = (int)std::min<int64_t>(F, (int64_t)ctx->num_cus * wg_small);
+        const int base = (int)(F / grid);
+        const int64_t rem = F % grid;
+        const int nf_max = base + (rem ? 1 : 0);
+        const size_t lds = lean_coop_lds_bytes(C, kLeanJ, nf_max);
+        int rc = ctx->work.ensure(per_block * (size_t)grid);
+        if (rc) return rc;
+        if (lds > 48 * 1024 && ctx->raise_lds((const void *)kc, (int)lds)) return SNOWTRI_ERR_HIP;
+        if (ctx->debug) fprintf(stderr, "k_fused_lean_coop: F %lld grid %d frames per tile %d (+1 for %lld) lds %zu\n", (long long)F, grid, base, (long long)rem, lds);
+        hipLaunchKernelGGL(kc, dim3(grid), dim3(kBlock), lds, st, F, base, rem, nf_max, ctx->rig(), d_kpts, d_np, prm, d_xyzs, d_ps, d_cnt, d_fl,
+                           (char *)ctx->work.p, per_block);
+        HIP_TRY(hipGetLastError());
+        static const std::string cname = std::string("k_fused_lean_coop<") + std::to_string(C) + "," + type_name<TIn>() + "," +
+                                         std::to_string(kLeanJ) + ">";
+        ctx->last_kernels = cname.c_str();
+        return SNOWTRI_OK;
+    }
     for (int64_t s0 = 0; s0 < F; s0 += seg_max) {
         const int64_t Fs = std::min<int64_t>(seg_max, F - s0);
         int64_t W;  // waves of the launch

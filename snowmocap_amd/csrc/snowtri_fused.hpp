@@ -563,7 +563,7 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_single(int
     // rig constants M[C][9], t[C][3], d[NP][3] live at the very end of the allocation
     // (general_frame reuses the front)
     double *Mlds = reinterpret_cast<double *>(smem + fused_single_lds_bytes(T, kn, NP) - kFusedConstBytes);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63;
     const PackedWriter<TOut> wr{out4, out_ps};
     const Kp3<TIn> *kp3 = reinterpret_cast<const Kp3<TIn> *>(kpts);
     if constexpr (METHOD == 1) {

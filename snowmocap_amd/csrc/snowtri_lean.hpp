@@ -221,6 +221,53 @@ __device__ __forceinline__ bool lean_item(const double *__restrict__ Mlds, const
     return !(sb < 1e300);
 }
 
+// ---- per-frame steps shared by k_fused_lean and k_fused_lean_coop (ONE definition: both kernels give the same bits) ----
+// Single-cluster check (:116-130) for lane = (frame wl of the pass, pair qq), lane = wl NP + qq: the lane solves its pair
+// at the centre joint (midpoint only) and takes candidate 0's point from the frame's first lane of the same pass.
+// Returns true if candidate qq lies farther than condense_distance_tol from candidate 0 (or cannot be decided here).
+template <int C, typename TIn>
+__device__ __forceinline__ bool lean_centre_far(const double *__restrict__ Mlds, int mc, int sc, int qq, int lane, const Kp3<TIn> &km,
+                                                const Kp3<TIn> &ks, double ctol2_lo) {
+    constexpr int NP = C * (C - 1) / 2;
+    (void)NP;
+    const double *tm = Mlds + 9 * C + 3 * mc, *ts = Mlds + 9 * C + 3 * sc, *dq = Mlds + 12 * C + 3 * qq;
+    // only the midpoint is needed here: A2 without the distance (sw = Wm + Ws = 2 W)
+    const RayRec a = make_ray(Mlds + 9 * mc, km.u, km.v), b = make_ray(Mlds + 9 * sc, ks.u, ks.v);
+    const double bq = fma(a.z, b.z, fma(a.y, b.y, a.x * b.x));
+    const double e = fma(a.z, dq[2], fma(a.y, dq[1], a.x * dq[0]));
+    const double g = fma(b.z, dq[2], fma(b.y, dq[1], b.x * dq[0]));
+    const double inv = rcp_nr2(fma(a.a, b.a, -(bq * bq)));
+    const double S0 = fma(b.a, e, -(bq * g)) * inv, S1 = fma(a.a, g, -(bq * e)) * inv;
+    const double swx = fma(-b.x, S1, fma(a.x, S0, tm[0] + ts[0])), swy = fma(-b.y, S1, fma(a.y, S0, tm[1] + ts[1])),
+                 swz = fma(-b.z, S1, fma(a.z, S0, tm[2] + ts[2]));
+    const int src = lane - qq;  // the frame's pair 0, same pass
+    const double w0x = __shfl(swx, src, 64), w0y = __shfl(swy, src, 64), w0z = __shfl(swz, src, 64);
+    const double ex = 0.5 * (w0x - swx), ey = 0.5 * (w0y - swy), ez = 0.5 * (w0z - swz);
+    // :124-125 `norm > tol` on the squares, with a 1e-12 guard band: whatever comes near the tolerance (or is
+    // NaN) is left to the exact routine, which takes the square root as the reference does
+    const double c2 = fma(ez, ez, fma(ey, ey, ex * ex));
+    return qq > 0 && !(c2 < ctol2_lo);
+}
+
+// Sum of a frame's JC fused joint scores (float32 as stored) by four lanes (sub = 0..3 takes joints sub, sub + 4, ...),
+// in double: the partial of lane `sub`; the caller adds the four partials with two xor-shuffles.
+template <int JC>
+__device__ __forceinline__ double lean_row_partial(const float *__restrict__ row, int sub) {
+    constexpr int G = 4;
+    double sum = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int b = sub;
+#pragma unroll 2
+    for (; b + 3 * G < JC; b += 4 * G) {
+        const double v0 = (double)row[b], v1 = (double)row[b + G], v2 = (double)row[b + 2 * G], v3 = (double)row[b + 3 * G];
+        sum += v0;
+        s1 += v1;
+        s2 += v2;
+        s3 += v3;
+    }
+    for (; b < JC; b += G) sum += (double)row[b];
+    return (sum + s1) + (s2 + s3);
+}
+
 // frames [f0, f0 + nf) of tile `t` when F frames are cut into ntiles tiles of base or base + 1 frames
 __device__ __forceinline__ void lean_tile_range(int64_t t, int base, int64_t rem, int64_t &f0, int &nf) {
     f0 = t * base + (t < rem ? t : rem);
@@ -411,23 +458,8 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean(
                 km = p[mc * JC];
                 ks = p[sc * JC];
             }
-            const double *tm = Mlds + 9 * C + 3 * mc, *ts = Mlds + 9 * C + 3 * sc, *dq = Mlds + 12 * C + 3 * qq;
-            // only the midpoint is needed here: A2 without the distance (sw = Wm + Ws = 2 W)
-            const RayRec a = make_ray(Mlds + 9 * mc, km.u, km.v), b = make_ray(Mlds + 9 * sc, ks.u, ks.v);
-            const double bq = fma(a.z, b.z, fma(a.y, b.y, a.x * b.x));
-            const double e = fma(a.z, dq[2], fma(a.y, dq[1], a.x * dq[0]));
-            const double g = fma(b.z, dq[2], fma(b.y, dq[1], b.x * dq[0]));
-            const double inv = rcp_nr2(fma(a.a, b.a, -(bq * bq)));
-            const double S0 = fma(b.a, e, -(bq * g)) * inv, S1 = fma(a.a, g, -(bq * e)) * inv;
-            const double swx = fma(-b.x, S1, fma(a.x, S0, tm[0] + ts[0])), swy = fma(-b.y, S1, fma(a.y, S0, tm[1] + ts[1])),
-                         swz = fma(-b.z, S1, fma(a.z, S0, tm[2] + ts[2]));
-            const int src = lane - qq;  // the frame's pair 0, same pass
-            const double w0x = __shfl(swx, src, 64), w0y = __shfl(swy, src, 64), w0z = __shfl(swz, src, 64);
-            const double ex = 0.5 * (w0x - swx), ey = 0.5 * (w0y - swy), ez = 0.5 * (w0z - swz);
-            // :124-125 `norm > tol` on the squares, with a 1e-12 guard band: whatever comes near the tolerance (or is
-            // NaN) is left to the exact routine, which takes the square root as the reference does
-            const double c2 = fma(ez, ez, fma(ey, ey, ex * ex));
-            if (live && qq > 0 && !(c2 < ctol2_lo)) {
+            const bool far = lean_centre_far<C, TIn>(Mlds, mc, sc, qq, lane, km, ks, ctol2_lo);
+            if (live && far) {
                 const unsigned bit = slow_base + (unsigned)w;
                 atomicOr(&slowbits[bit >> 5], 1u << (bit & 31u));
             }
@@ -440,21 +472,7 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean(
             const bool live = w < nf_cur;
             const int64_t f = f0_cur + (live ? w : 0);
             double sum = 0.0;
-            if (live) {
-                const float *row = stash + w * JC;
-                double s1 = 0.0, s2 = 0.0, s3 = 0.0;
-                int b = sub;
-#pragma unroll 2
-                for (; b + 3 * G < JC; b += 4 * G) {
-                    const double v0 = (double)row[b], v1 = (double)row[b + G], v2 = (double)row[b + 2 * G], v3 = (double)row[b + 3 * G];
-                    sum += v0;
-                    s1 += v1;
-                    s2 += v2;
-                    s3 += v3;
-                }
-                for (; b < JC; b += G) sum += (double)row[b];
-                sum = (sum + s1) + (s2 + s3);
-            }
+            if (live) sum = lean_row_partial<JC>(stash + w * JC, sub);
             int not_one = 0;
             if (n_persons && live)
                 for (int c = sub; c < C; c += G) not_one |= n_persons[f * C + c] != 1;
@@ -505,6 +523,209 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean(
                 general_frame<TIn>(tf0 + (bit & ((1u << kLeanSlowShift) - 1u)), 1, JC, NP, rig, kpts, n_persons, prm, 1, wr,
                                    out_count, out_flags, slab, smem);
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ k_fused_lean_coop
+// The same path for SMALL launches (one tile per wave in k_fused_lean: up to kLeanTw frames x the resident waves; the
+// bench's 10 000-frame step).  There the whole-frame tiles of k_fused_lean cost: a wave of 5 frames runs 11 passes for 10.4
+// passes of items, both waves of a SIMD run the per-tile epilogue (a pass-equivalent of instructions each), i.e.
+// 2 x (11 + 1.1) pass-equivalents per SIMD where the items alone are 20.3.  Here a WORKGROUP owns a tile of frames
+// (10 000 frames over 512 workgroups: 19-20 frames = 40-42 passes) and
+//   * its four waves split the tile's PASSES evenly (10 or 11 each; the workgroups alternate which waves take the extra
+//     pass, neighbouring workgroups rotate them by two; rotating by dispatch round instead, b / num_cus, measured the same): frames straddle waves, the fused joint
+//     scores meet in a workgroup-wide LDS stash;
+//   * after ONE barrier the epilogue of the whole tile is dealt to the waves by passes: the single-cluster check 10
+//     frames per pass, the mean scores 16 frames per pass, each pass on another wave -- a fifth of the epilogue
+//     instructions per SIMD; a second barrier, then one wave writes count / person score / flags of the frames that
+//     passed, and the frames that did not are re-done by the workgroup as in k_fused_lean.
+// Items, check and mean are the SAME functions as in k_fused_lean: a frame's bits do not depend on which kernel ran it.
+// Grid = number of tiles (tile t = frames lean_tile_range(t, tile_base, tile_rem), nf <= nf_max <= kCoopMaxFrames).
+// Dynamic LDS: lean_coop_lds_bytes(C, JC, nf_max).
+constexpr int kCoopMaxFrames = 32;   // frames per workgroup tile (one bit word of slow frames)
+__host__ __device__ constexpr int lean_coop_items_pad(int JC, int nf_max) { return (nf_max * JC + 63) / 64 * 64; }
+__host__ __device__ constexpr size_t lean_coop_lds_bytes(int C, int JC, int nf_max) {
+    // [rig constants | item -> input offset table (+ 256 entries of prefetch distance) | stash | mean per frame | slow bits]
+    return (((size_t)8 * lean_const_doubles(C) + (size_t)4 * (lean_coop_items_pad(JC, nf_max) + 256) + (size_t)4 * lean_coop_items_pad(JC, nf_max) +
+             (size_t)8 * kCoopMaxFrames + 16) + 15) & ~(size_t)15;
+}
+
+template <int C, typename TIn, int JC>
+__global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean_coop(
+    int64_t F, int tile_base, int64_t tile_rem, int nf_max, Rig rig, const TIn *__restrict__ kpts, const int32_t *__restrict__ n_persons,
+    Params prm, float *__restrict__ out4, float *__restrict__ out_ps, int32_t *__restrict__ out_count, uint32_t *__restrict__ out_flags,
+    char *scratch, size_t scratch_per_block) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int NP = C * (C - 1) / 2;
+    constexpr int kConstDoubles = lean_const_doubles(C);
+    constexpr unsigned kRec = (unsigned)sizeof(Kp3<TIn>);
+    constexpr unsigned kCamStride = (unsigned)JC * kRec;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int items_pad = lean_coop_items_pad(JC, nf_max), ntable = items_pad + 256;
+    double *Mlds = reinterpret_cast<double *>(smem);
+    uint32_t *table = reinterpret_cast<uint32_t *>(Mlds + kConstDoubles);
+    float *stash = reinterpret_cast<float *>(table + ntable);
+    double *favg = reinterpret_cast<double *>(stash + items_pad);          // [kCoopMaxFrames] mean fused score of a frame
+    uint32_t *slowbits = reinterpret_cast<uint32_t *>(favg + kCoopMaxFrames);   // one word: bit = frame of the tile
+    const Kp3<TIn> *kp3 = reinterpret_cast<const Kp3<TIn> *>(kpts);
+    Kp3<TIn> bufA[C], bufB[C], bufC[C];
+
+    int64_t f0;
+    int nf;
+    lean_tile_range((int64_t)blockIdx.x, tile_base, tile_rem, f0, nf);
+    SNOWTRI_DEV_CHECK(f0 >= 0 && nf >= 1 && nf <= nf_max && nf_max <= kCoopMaxFrames && f0 + nf <= F, 3);
+    // passes of the tile, dealt to the waves: position `pos` in the rotated wave order takes passes [p0, p0 + np)
+    const int npass_tile = (nf * JC + 63) >> 6;
+    const int pos = (wave + 2 * (int)(blockIdx.x & 1u)) & (kLeanWaves - 1);
+    const int pq = npass_tile / kLeanWaves, pr = npass_tile - pq * kLeanWaves;
+    const int p0 = pos * pq + (pos < pr ? pos : pr), npass = pq + (pos < pr ? 1 : 0);
+    const unsigned i0 = (unsigned)p0 * 64u;   // first item of the wave
+    const __amdgpu_buffer_rsrc_t rin = lean_rsrc(kp3 + f0 * (int64_t)(C * JC), (unsigned)(nf * C * JC) * kRec);
+    const __amdgpu_buffer_rsrc_t rout = lean_rsrc(reinterpret_cast<float4 *>(out4) + f0 * (int64_t)JC, (unsigned)(nf * JC) * 16u);
+    const unsigned last = (unsigned)(nf * JC - 1);
+    auto fetch = [&](Kp3<TIn>(&dst)[C], unsigned voff) {
+#pragma unroll
+        for (int c = 0; c < C; c++)
+            dst[c] = lean_load_kp3<TIn>(rin, voff + (unsigned)(c & 1) * kCamStride, (unsigned)(c & ~1) * kCamStride);
+    };
+    auto item_offset = [&](unsigned i) { return (i + (i / (unsigned)JC) * (unsigned)((C - 1) * JC)) * kRec; };
+    // the wave's first two items (offsets computed: the table is not there yet); a pass the wave does not own reads nothing
+    constexpr unsigned kNoItem = 0x40000000u;   // beyond every descriptor (and no wrap-around with the camera offsets): the load returns zeros without touching memory
+    fetch(bufA, npass > 0 ? item_offset(i0 + (unsigned)lane) : kNoItem);
+    fetch(bufB, npass > 1 ? item_offset(i0 + 64u + (unsigned)lane) : kNoItem);
+    // centre-joint keypoints of the check pass this wave will run after the barrier (pass `pos`: frames 10 pos ...)
+    constexpr int kCheckFrames = 64 / NP;
+    const int ncheck = (nf + kCheckFrames - 1) / kCheckFrames;
+    Kp3<TIn> ckm, cks;
+    int32_t *pairs_lds = reinterpret_cast<int32_t *>(Mlds + 12 * C + 3 * NP);
+    // (the first keypoints are in flight while the constants are set up)
+    if (tid < 9 * C) Mlds[tid] = rig.M[tid];
+    if (tid < 3 * C) Mlds[9 * C + tid] = rig.t[tid];
+    if (tid < 3 * NP) Mlds[12 * C + tid] = rig.pairc[6 * (tid / 3) + tid % 3];
+    if (tid < 2 * NP) pairs_lds[tid] = rig.pairs[tid];
+    for (unsigned i = (unsigned)tid; i < (unsigned)ntable; i += kBlock) table[i] = item_offset(i);
+    if (tid == 0) slowbits[0] = 0u;
+    double dS[3 * NP];
+#pragma unroll
+    for (int i = 0; i < 3 * NP; i++) dS[i] = uniform_f64(rig.pairc[6 * (i / 3) + i % 3]);
+    const float kthr_f32 = prm.kthr_f32;
+    const double kthr = prm.kthr, dthr2 = prm.dthr2;
+    const double ctol2_lo = prm.ctol < 0.0 ? -1.0 : prm.ctol * prm.ctol * (1.0 - 1e-12);
+    __syncthreads();
+    {
+        const int wl = lane / NP, qq = lane - wl * NP, w = pos * kCheckFrames + wl;
+        const bool live = pos < ncheck && wl < kCheckFrames && w < nf;
+        const Kp3<TIn> *p = kp3 + (f0 + (live ? w : 0)) * (int64_t)(C * JC) + prm.center;
+        ckm = p[pairs_lds[2 * qq] * JC];
+        cks = p[pairs_lds[2 * qq + 1] * JC];
+    }
+    double Mres[9 * C];
+#if SNOWTRI_LEAN_M_VGPR
+#pragma unroll
+    for (int i = 0; i < 9 * C; i++) Mres[i] = Mlds[i];
+#endif
+
+    auto solve_store = [&](const Kp3<TIn>(&buf)[C], unsigned out_off, float *stash_slot) {
+        float ox, oy, oz;
+        double os;
+        const bool bad = lean_item<C>(Mlds, Mres, dS, buf, kthr_f32, kthr, dthr2, ox, oy, oz, os);
+        const float osf = (float)os;
+        lean_u4 rec;
+        rec.x = __float_as_uint(ox);
+        rec.y = __float_as_uint(oy);
+        rec.z = __float_as_uint(oz);
+        rec.w = __float_as_uint(osf);
+        __builtin_amdgcn_raw_buffer_store_b128(rec, rout, (int)out_off, 0, SNOWTRI_LEAN_STORE_AUX);
+        *stash_slot = osf;
+        if (__ballot(bad)) {  // rare, wave-uniform branch
+            unsigned o = out_off;
+            asm volatile("" : "+v"(o));
+            const unsigned i = o >> 4;
+            if (bad && i <= last) atomicOr(&slowbits[0], 1u << (i / (unsigned)JC));
+        }
+    };
+    // ---- item loop over the wave's passes: the ring of three register buffers as in k_fused_lean; the fetch two passes
+    //      ahead stops at the wave's last pass (the passes behind it belong to the next wave)
+    {
+        unsigned out_off = (i0 + (unsigned)lane) * 16u;
+        float *sp = stash + i0 + lane;
+        const uint32_t *tp = table + i0 + lane;
+        for (int k = 0; k < npass; k += 3) {
+            fetch(bufC, k + 2 < npass ? tp[128] : kNoItem);
+            solve_store(bufA, out_off, sp);
+            fetch(bufA, k + 3 < npass ? tp[192] : kNoItem);
+            if (k + 1 < npass) solve_store(bufB, out_off + 1024u, sp + 64);
+            fetch(bufB, k + 4 < npass ? tp[256] : kNoItem);
+            if (k + 2 < npass) solve_store(bufC, out_off + 2048u, sp + 128);
+            tp += 192;
+            out_off += 3072u;
+            sp += 192;
+        }
+    }
+    __syncthreads();   // the tile's fused joint scores are in the stash, the `bad` bits in slowbits
+
+    // ---- epilogue of the tile, dealt to the waves by passes: check pass c on the wave at position c (mod 4), mean pass m
+    //      on the wave at position ncheck + m (mod 4)
+    for (int pass = pos; pass < ncheck; pass += kLeanWaves) {
+        const int wl = lane / NP, qq = lane - wl * NP, w = pass * kCheckFrames + wl;
+        const bool live = wl < kCheckFrames && w < nf;
+        const int mc = pairs_lds[2 * qq], sc = pairs_lds[2 * qq + 1];
+        Kp3<TIn> km = ckm, ks = cks;
+        if (pass != pos) {
+            const Kp3<TIn> *p = kp3 + (f0 + (live ? w : 0)) * (int64_t)(C * JC) + prm.center;
+            km = p[mc * JC];
+            ks = p[sc * JC];
+        }
+        const bool far = lean_centre_far<C, TIn>(Mlds, mc, sc, qq, lane, km, ks, ctol2_lo);
+        if (live && far) atomicOr(&slowbits[0], 1u << w);
+    }
+    {
+        constexpr int G = 4;
+        const int nmean = (nf + 64 / G - 1) / (64 / G);
+        for (int pass = (pos - ncheck) & (kLeanWaves - 1); pass < nmean; pass += kLeanWaves) {
+            const int w = pass * (64 / G) + lane / G, sub = lane & (G - 1);
+            const bool live = w < nf;
+            const int64_t f = f0 + (live ? w : 0);
+            double sum = 0.0;
+            if (live) sum = lean_row_partial<JC>(stash + w * JC, sub);
+            int not_one = 0;
+            if (n_persons && live)
+                for (int c = sub; c < C; c += G) not_one |= n_persons[f * C + c] != 1;
+#pragma unroll
+            for (int off = G / 2; off > 0; off >>= 1) {
+                sum += __shfl_xor(sum, off, 64);
+                not_one |= __shfl_xor(not_one, off, 64);
+            }
+            if (live && sub == 0) {
+                const double avg = sum / (double)JC;
+                favg[w] = avg;
+                // :151-152, as in k_fused_lean
+                if (!(avg >= prm.score_tol) || fabs(avg - prm.score_tol) < 1e-6 * fabs(prm.score_tol) || not_one != 0)
+                    atomicOr(&slowbits[0], 1u << w);
+            }
+        }
+    }
+    __syncthreads();   // slowbits and favg are final
+    const uint32_t slow = slowbits[0];
+    if (wave == 0 && lane < nf && !((slow >> lane) & 1u)) {
+        const int64_t f = f0 + lane;
+        out_count[f] = 1;
+        if (out_ps) out_ps[f] = (float)favg[lane];
+        if (out_flags) out_flags[f] = kFlagFast;
+    }
+    if (slow == 0u) return;   // (uniform: every thread reads the same word)
+    // ---- rare: frames the speculation could not resolve -> the reference's full algorithm, by the whole workgroup
+    {
+        const PackedWriter<float> wr{out4, out_ps};
+        double *slab = reinterpret_cast<double *>(scratch + (size_t)blockIdx.x * scratch_per_block);
+        uint32_t m = slow;
+        __syncthreads();  // general_frame reuses the front of the LDS (the finalising reads of favg are done)
+        while (m) {
+            const int bpos = __ffs((int)m) - 1;
+            m &= m - 1u;
+            general_frame<TIn>(f0 + bpos, 1, JC, NP, rig, kpts, n_persons, prm, 1, wr, out_count, out_flags, slab, smem);
         }
     }
 }

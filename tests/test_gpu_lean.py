@@ -319,3 +319,38 @@ def test_raw_rsq_accuracy_behind_the_float32_score_contract(api):
     err_rcp = np.abs(rc * x - 1.0).max()
     print(f"raw v_rsq_f64 max rel err {err_rsq:.3e} (2^{np.log2(err_rsq):.2f}), raw v_rcp_f64 {err_rcp:.3e} (2^{np.log2(err_rcp):.2f})")
     assert err_rsq <= 2.0 ** -23 and err_rcp <= 2.0 ** -23
+
+
+@pytest.mark.parametrize("F", [1, 2, 3, 5, 511, 513, 1024, 4000, 10000, 16384, 16385])
+def test_small_launches_cooperative_kernel_equals_wave_autonomous_kernel(api, F, monkeypatch):
+    """k_fused_lean_coop takes launches of up to 32 frames per resident workgroup (16 384 frames on an MI355X): a
+    workgroup tile whose PASSES are dealt to the waves (frames straddle waves), one cooperative epilogue.  Items, check
+    and mean are the functions k_fused_lean uses: the same frames through SNOWTRI_LEAN_COOP=0 are bit-identical --
+    fall-back frames (every reason, spread over the tiles) included -- and both agree with the oracle."""
+    from snowmocap_amd import synth
+    from oracle import oracle as orc
+    rng = np.random.default_rng(9000 + F)
+    wl = synth.config_workload(2, F, seed=77)
+    K, R, t = wl["rig"]
+    kp, npers = wl["kpts"].copy(), wl["n_persons"].copy()
+    broken = _break_some_frames(rng, kp, npers, F, n_each=4) if F >= 5 else {}
+    if F >= 3:
+        kp[F - 1, 2, 0, :, :2] += 400.0          # the batch's last frame (the short end of the last tile) falls back too
+        broken[F - 1] = 0
+    bt = api.BatchTriangulator(K, R, t, wl["params"], pout_max=1, out_dtype=np.float32)
+    a = bt.run_host(kp, npers)
+    names = bt.ctx.last_kernel_names()
+    bt.close()
+    assert names.startswith("k_fused_lean_coop<4,float,133>" if F <= 16384 else "k_fused_lean<4,float,133>"), names
+    b = _run(api, K, R, t, wl["params"], kp, npers, {"SNOWTRI_LEAN_COOP": "0"}, monkeypatch)
+    for key in ("xyzs", "pscore", "count", "flags"):
+        assert np.array_equal(a[key], b[key], equal_nan=True), f"F={F}: {key} differs between the two kernels"
+    from snowmocap_amd import _lib
+    fast = (a["flags"] & _lib.FLAG_FASTPATH) != 0
+    for f, kind in broken.items():
+        assert fast[f] == (kind == 4), (f, kind)
+    assert fast.sum() == F - sum(1 for k in broken.values() if k != 4)
+    check = sorted(set(list(broken)[:12]) | set(int(x) for x in rng.choice(F, size=min(F, 24), replace=False)))
+    ref = orc.triangulate_condense_batch(K, R, t, kp[check], npers[check], orc.make_params(**wl["params"]), 1)
+    sub = {k: a[k][check] for k in ("xyzs", "pscore", "count")}
+    _check_frames(sub, ref, range(len(check)), msg=f"F={F}")
