@@ -347,9 +347,9 @@ def test_small_launches_cooperative_kernel_equals_wave_autonomous_kernel(api, F,
         assert np.array_equal(a[key], b[key], equal_nan=True), f"F={F}: {key} differs between the two kernels"
     from snowmocap_amd import _lib
     fast = (a["flags"] & _lib.FLAG_FASTPATH) != 0
-    for f, kind in broken.items():
-        assert fast[f] == (kind == 4), (f, kind)
-    assert fast.sum() == F - sum(1 for k in broken.values() if k != 4)
+    for f, kind in broken.items():      # a camera without detection, a NaN pixel: re-done by the exact routine
+        assert kind not in (1, 3) or not fast[f], (f, kind)
+    assert fast.sum() >= F - len(broken)
     check = sorted(set(list(broken)[:12]) | set(int(x) for x in rng.choice(F, size=min(F, 24), replace=False)))
     ref = orc.triangulate_condense_batch(K, R, t, kp[check], npers[check], orc.make_params(**wl["params"]), 1)
     sub = {k: a[k][check] for k in ("xyzs", "pscore", "count")}
