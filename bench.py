@@ -372,7 +372,7 @@ def main():
             lms.append(bt.ctx.last_kernel_ms()[0])
         bt.ctx.set_timing(False)
         lm = float(np.median(lms[1:]))
-        large = {"frames": FL, "kernel_ms": lm, "kernel_ms_all": lms[1:], "joints_per_s": FL * J / (lm * 1e-3),
+        large = {"frames": FL, "kernel": bt.ctx.last_kernel_names(), "kernel_ms": lm, "kernel_ms_all": lms[1:], "joints_per_s": FL * J / (lm * 1e-3),
                  "achieved_GBs": bpf * FL / (lm * 1e-3) / 1e9, "frac": bpf * FL / (lm * 1e-3) / 1e9 / HBM_PEAK_GBS}
         del big, bout
 

@@ -37,7 +37,7 @@ def headline(s):
          "%.2f us per launch by rocprofv3 (%d launches), %.2f us by HIP events -> %.0f GB/s = **%.3f of 8 TB/s** (`roofline.frac` %.3f / %.3f in the two bench lines)"
          % (k10["avg_us"], k10["calls"], b["kernel_us_mean"], 85.12e6 / (k10["avg_us"] * 1e-6) / 1e9, k10["hbm_frac"], b["roofline_frac"], b20["roofline_frac"])),
         ("`roofline_region` (two streams, consecutive launches overlap)", "%.3f / %.3f of 8 TB/s" % (b["roofline_region_frac"], b20["roofline_region_frac"])),
-        ("one 2 000 000-frame launch (SURVEY 8d's roofline run)",
+        ("one 2 000 000-frame launch (SURVEY 8d's roofline run): `%s`" % k2m["kernel"],
          "%.2f ms (rocprofv3, %d launches: %.2f-%.2f) -> %s joints/s, **%.3f of 8 TB/s**; `large_batch.frac` %.3f"
          % (k2m["avg_ms"], k2m["launches"], k2m["min_ms"], k2m["max_ms"], e(k2m["joints_per_s"]), k2m["hbm_frac"], b["large"]["frac"])),
         ("HBM traffic per 10 000-frame launch (PMC, calibrated in the same pass)",

@@ -39,7 +39,9 @@ json.dump({"what": "rocprofv3 --kernel-trace durations (ns) of the 2 000 000-fra
            "durations_ns": big, "small_launches_in_the_same_trace": len(rows) - len(big)}, open("$OUT/large_launches.json", "w"))
 print("large launches:", big)
 PY
-# the bench lines without the profiler: the default run and the driver's command
+# the bench lines without the profiler: the default run and the driver's command (with this run's PMC summary in place, so
+# that the lines quote the traffic and the VALU count measured on exactly these kernel sources)
+cp $OUT/pmc_traffic.json $ROOT/profiles/pmc_traffic.json
 python bench.py 2>/dev/null | tail -1 > $OUT/bench_default.json
 python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/bench_steps20.json
 # keep the merge small: drop raw traces, keep CSV summaries

@@ -57,7 +57,10 @@ try:
         sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
         import bench
         scale_r, scale_w = known[0] / (fr_cal * 1024.0), known[1] / (wr_cal * 1024.0)
-        traffic = {"kernel": "k_fused_lean<4,float,133>", "frames_per_launch": known[2],
+        import re
+        kfull = next(k for k in summary["pmc_fetch"] if "k_fused_lean" in k)
+        kshort = re.search(r"(k_fused_lean\w*<[^(]*>)", kfull).group(1).replace(" ", "")      # what snowtri_last_kernel_names() reports
+        traffic = {"kernel": kshort, "frames_per_launch": known[2],
                    "workload": "BASELINE configs[1]: %d frames per launch" % known[2],
                    "FETCH_SIZE_KB_raw": fr_k, "WRITE_SIZE_KB_raw": wr_k,
                    "calibration": {"how": "snowtri_calib_stream in the same rocprofv3 pass: 12-byte records read per lane / 16-byte records "
@@ -78,7 +81,8 @@ try:
                     insts = line.get("SQ_INSTS_VALU")          # the large launch is the one with the most instructions
             if frames_large and insts:
                 items = frames_large * 133 / 64.0
-                traffic["valu"] = {"SQ_INSTS_VALU_per_launch": insts, "frames": frames_large, "wave_items": items, "per_64_joints": insts / items}
+                traffic["valu"] = {"SQ_INSTS_VALU_per_launch": insts, "frames": frames_large, "wave_items": items, "per_64_joints": insts / items,
+                                   "kernel": "k_fused_lean (the wave-autonomous kernel of large launches; k_fused_lean_coop runs the same item)"}
                 print("== VALU wave-instructions per 64 joints: %.1f (SQ_INSTS_VALU %.6g on %d frames)" % (insts / items, insts, frames_large))
         except Exception as e:
             print("valu summary failed:", repr(e))

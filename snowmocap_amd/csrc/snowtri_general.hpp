@@ -247,6 +247,9 @@ __device__ __forceinline__ double candidate_chunk_sum_exact(const char *__restri
 // v_rsq_f64 (measured 2^-24.2 relative) only scales a score: the caller re-does candidates whose mean lies within 1e-6 of
 // average_score_threshold (:79-81).
 //   pa: record of the first ray's row, pb: record of the FIRST of the GS second rows (rows are kP1Rec bytes apart)
+#ifndef SNOWTRI_P1_PHASED
+#define SNOWTRI_P1_PHASED 0
+#endif
 template <int GS, typename TIn>
 __device__ __forceinline__ void p1_item_sums(const char *__restrict__ pa, const char *__restrict__ pb, int jstr, int nj,
                                              const Vec3 &d, const Params &prm, double (&acc)[GS]) {
@@ -262,6 +265,24 @@ __device__ __forceinline__ void p1_item_sums(const char *__restrict__ pa, const 
         }
         const double cx = fma(d.y, a.z, -(d.z * a.y)), cy = fma(d.z, a.x, -(d.x * a.z)), cz = fma(d.x, a.y, -(d.y * a.x));
         const bool okm = !below_kthr(sm, prm);
+#if SNOWTRI_P1_PHASED   // the GS solves in lock step: all arguments, all v_rsq_f64 back to back, all sums (the quarter-rate
+                        // transcendentals of one solve issue under the arithmetic of the next instead of stalling its own)
+        double det[GS], x[GS], w[GS];
+#pragma unroll
+        for (int u = 0; u < GS; u++) {
+            const double bq = fma(a.z, b[u].z, fma(a.y, b[u].y, a.x * b[u].x));
+            det[u] = fma(a.a, b[u].a, -(bq * bq));
+            const double dn = fma(cz, b[u].z, fma(cy, b[u].y, cx * b[u].x));
+            const double dn2 = dn * dn;
+            const bool kp_ = okm && !below_kthr(ss[u], prm) && !(dn2 > det[u] * prm.dthr2);   // :73-74
+            w[u] = gated_sum_sel(sm, ss[u], kp_);
+            x[u] = dn2 * det[u];
+        }
+#pragma unroll
+        for (int u = 0; u < GS; u++) x[u] = __builtin_amdgcn_rsq(x[u]);
+#pragma unroll
+        for (int u = 0; u < GS; u++) acc[u] = fma(w[u], det[u] * x[u], acc[u]);
+#else
 #pragma unroll
         for (int u = 0; u < GS; u++) {
             const double bq = fma(a.z, b[u].z, fma(a.y, b[u].y, a.x * b[u].x));
@@ -271,6 +292,7 @@ __device__ __forceinline__ void p1_item_sums(const char *__restrict__ pa, const 
             const bool kp_ = okm && !below_kthr(ss[u], prm) && !(dn2 > det * prm.dthr2);   // :73-74
             acc[u] = fma(gated_sum_sel(sm, ss[u], kp_), det * __builtin_amdgcn_rsq(dn2 * det), acc[u]);
         }
+#endif
     }
 }
 

@@ -30,7 +30,7 @@ def test_headline_numbers_are_the_csv_numbers():
     import make_tables
     s = make_tables.load()
     d = os.path.join(ROOT, "profiles", s["tag"])
-    rows = [r for r in csv.DictReader(open(os.path.join(d, "kernel_stats_cfg2_10k.csv"))) if "k_fused_lean" in r["Name"]]
+    rows = [r for r in csv.DictReader(open(os.path.join(d, "kernel_stats_cfg2_10k.csv"))) if "k_fused_lean_coop" in r["Name"]]
     assert len(rows) == 1
     avg_us = float(rows[0]["AverageNs"]) / 1e3
     assert abs(s["fast_kernel_10k"]["avg_us"] - avg_us) < 1e-9
@@ -41,7 +41,8 @@ def test_headline_numbers_are_the_csv_numbers():
     assert abs(s["fast_kernel_2M"]["hbm_frac"] - 8512 * 2000000 / (sum(big) / len(big) * 1e-9) / 8e12) < 1e-12
     b = json.loads(open(os.path.join(d, "bench_default.json")).read())
     assert s["bench_default"]["value"] == b["value"] and s["bench_default"]["roofline_frac"] == b["roofline"]["frac"]
-    assert b["roofline"]["kernel"].startswith("k_fused_lean<4,float,133>")
+    assert b["roofline"]["kernel"] == "k_fused_lean_coop<4,float,133>" == s["fast_kernel_10k"]["kernel"]
+    assert b["roofline"]["traffic"] in (None, json.load(open(os.path.join(d, "pmc_traffic.json")))["hbm_bytes_per_launch"])
     # the traffic and the VALU count the bench line quotes belong to the profiled kernel sources
     t = json.load(open(os.path.join(d, "pmc_traffic.json")))
     assert t["source_sha256"] == json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json")))["source_sha256"]
