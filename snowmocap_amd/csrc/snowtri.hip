@@ -426,6 +426,12 @@ namespace {
 __global__ void k_debug_selftest(int n) { SNOWTRI_DEV_CHECK((int)threadIdx.x < n, 99); }   // lanes n .. 63 violate it
 }
 #endif
+#ifdef SNOWTRI_LEAN_TRACE
+extern "C" int snowtri_debug_read_scratch(snowtri_ctx *ctx, void *dst, size_t bytes) {   // dev build only: the stamps of k_fused_lean_coop
+    if (!ctx || bytes > ctx->work.cap) return SNOWTRI_ERR_BAD_ARG;
+    return hipMemcpy(dst, ctx->work.p, bytes, hipMemcpyDeviceToHost) == hipSuccess ? SNOWTRI_OK : SNOWTRI_ERR_HIP;
+}
+#endif
 int snowtri_debug_selftest(snowtri_ctx *ctx) {
 #ifdef SNOWTRI_DEBUG_BOUNDS
     if (!ctx) return SNOWTRI_ERR_BAD_ARG;

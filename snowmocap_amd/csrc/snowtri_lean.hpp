@@ -317,6 +317,14 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean(
     const unsigned voff0 = (i0 + (i0 / (unsigned)JC) * (unsigned)((C - 1) * JC)) * kRec;
     const unsigned voff1 = (i1 + (i1 / (unsigned)JC) * (unsigned)((C - 1) * JC)) * kRec;
 
+    // the rig constants are requested BEFORE the first keypoints (see k_fused_lean_coop: the vector-memory counter returns
+    // in order, a constant requested behind the keypoints would wait for their trip to HBM)
+    const double cM = rig.M[tid < 9 * C ? tid : 0], cT = rig.t[tid < 3 * C ? tid : 0];
+    const double cD = rig.pairc[tid < 3 * NP ? 6 * (tid / 3) + tid % 3 : 0];
+    const int32_t cP = rig.pairs[tid < 2 * NP ? tid : 0];
+    double dS[3 * NP];  // per-pair d = t_s - t_m, wave-uniform -> scalar registers
+#pragma unroll
+    for (int i = 0; i < 3 * NP; i++) dS[i] = rig.pairc[6 * (i / 3) + i % 3];
     int64_t tile = (int64_t)blockIdx.x * kLeanWaves + wave;
     int64_t f0 = 0;
     int nf = 0;
@@ -327,17 +335,16 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean(
         fetch(bufB, rin, voff1);
     }
     // (the first keypoints are in flight while the constants are set up)
-    if (tid < 9 * C) Mlds[tid] = rig.M[tid];
-    if (tid < 3 * C) Mlds[9 * C + tid] = rig.t[tid];
-    if (tid < 3 * NP) Mlds[12 * C + tid] = rig.pairc[6 * (tid / 3) + tid % 3];
-    int32_t *pairs_lds = reinterpret_cast<int32_t *>(Mlds + 12 * C + 3 * NP);
-    if (tid < 2 * NP) pairs_lds[tid] = rig.pairs[tid];
     for (unsigned i = (unsigned)tid; i < (unsigned)kTable; i += kBlock)
         table[i] = (i + (i / (unsigned)JC) * (unsigned)((C - 1) * JC)) * kRec;
     for (int i = tid; i < slow_words; i += kBlock) slowbits[i] = 0u;
-    double dS[3 * NP];  // per-pair d = t_s - t_m, wave-uniform -> scalar registers
+    if (tid < 9 * C) Mlds[tid] = cM;
+    if (tid < 3 * C) Mlds[9 * C + tid] = cT;
+    if (tid < 3 * NP) Mlds[12 * C + tid] = cD;
+    int32_t *pairs_lds = reinterpret_cast<int32_t *>(Mlds + 12 * C + 3 * NP);
+    if (tid < 2 * NP) pairs_lds[tid] = cP;
 #pragma unroll
-    for (int i = 0; i < 3 * NP; i++) dS[i] = uniform_f64(rig.pairc[6 * (i / 3) + i % 3]);
+    for (int i = 0; i < 3 * NP; i++) dS[i] = uniform_f64(dS[i]);
     const float kthr_f32 = prm.kthr_f32;
     const double kthr = prm.kthr, dthr2 = prm.dthr2;
     const double ctol2_lo = prm.ctol < 0.0 ? -1.0 : prm.ctol * prm.ctol * (1.0 - 1e-12);   // single-cluster check, see there
@@ -572,6 +579,21 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean_coop(
     const Kp3<TIn> *kp3 = reinterpret_cast<const Kp3<TIn> *>(kpts);
     Kp3<TIn> bufA[C], bufB[C], bufC[C];
 
+#ifdef SNOWTRI_LEAN_TRACE   // dev build: wall-clock stamps (100 MHz) of every wave at the phase boundaries, in the workgroup's scratch slab
+    unsigned long long *trace = reinterpret_cast<unsigned long long *>(scratch + (size_t)blockIdx.x * scratch_per_block) + 8 * (threadIdx.x >> 6);
+#define SNOWTRI_STAMP(i) do { if ((threadIdx.x & 63) == 0) trace[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define SNOWTRI_STAMP(i) ((void)0)
+#endif
+    SNOWTRI_STAMP(0);
+#ifdef SNOWTRI_LEAN_TRACE
+    if ((threadIdx.x & 63) == 0) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        trace[7] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
     int64_t f0;
     int nf;
     lean_tile_range((int64_t)blockIdx.x, tile_base, tile_rem, f0, nf);
@@ -591,6 +613,16 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean_coop(
             dst[c] = lean_load_kp3<TIn>(rin, voff + (unsigned)(c & 1) * kCamStride, (unsigned)(c & ~1) * kCamStride);
     };
     auto item_offset = [&](unsigned i) { return (i + (i / (unsigned)JC) * (unsigned)((C - 1) * JC)) * kRec; };
+    // The rig constants are requested BEFORE the first keypoints: the vector-memory counter returns in order, so waiting for
+    // a constant that was requested behind the keypoints would wait for the keypoints' trip to HBM (cold TLB: ~3 us) too
+    // -- measured with wall-clock stamps per wave (-DSNOWTRI_LEAN_TRACE): 4.5 us from entry to the first item that way.
+    // Unconditional loads of clamped indices: a load inside a branch is waited for where the branch joins.
+    const double cM = rig.M[tid < 9 * C ? tid : 0], cT = rig.t[tid < 3 * C ? tid : 0];
+    const double cD = rig.pairc[tid < 3 * NP ? 6 * (tid / 3) + tid % 3 : 0];
+    const int32_t cP = rig.pairs[tid < 2 * NP ? tid : 0];
+    double dS[3 * NP];
+#pragma unroll
+    for (int i = 0; i < 3 * NP; i++) dS[i] = rig.pairc[6 * (i / 3) + i % 3];
     // the wave's first two items (offsets computed: the table is not there yet); a pass the wave does not own reads nothing
     constexpr unsigned kNoItem = 0x40000000u;   // beyond every descriptor (and no wrap-around with the camera offsets): the load returns zeros without touching memory
     fetch(bufA, npass > 0 ? item_offset(i0 + (unsigned)lane) : kNoItem);
@@ -601,19 +633,20 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean_coop(
     Kp3<TIn> ckm, cks;
     int32_t *pairs_lds = reinterpret_cast<int32_t *>(Mlds + 12 * C + 3 * NP);
     // (the first keypoints are in flight while the constants are set up)
-    if (tid < 9 * C) Mlds[tid] = rig.M[tid];
-    if (tid < 3 * C) Mlds[9 * C + tid] = rig.t[tid];
-    if (tid < 3 * NP) Mlds[12 * C + tid] = rig.pairc[6 * (tid / 3) + tid % 3];
-    if (tid < 2 * NP) pairs_lds[tid] = rig.pairs[tid];
     for (unsigned i = (unsigned)tid; i < (unsigned)ntable; i += kBlock) table[i] = item_offset(i);
     if (tid == 0) slowbits[0] = 0u;
-    double dS[3 * NP];
+    if (tid < 9 * C) Mlds[tid] = cM;
+    if (tid < 3 * C) Mlds[9 * C + tid] = cT;
+    if (tid < 3 * NP) Mlds[12 * C + tid] = cD;
+    if (tid < 2 * NP) pairs_lds[tid] = cP;
 #pragma unroll
-    for (int i = 0; i < 3 * NP; i++) dS[i] = uniform_f64(rig.pairc[6 * (i / 3) + i % 3]);
+    for (int i = 0; i < 3 * NP; i++) dS[i] = uniform_f64(dS[i]);
     const float kthr_f32 = prm.kthr_f32;
     const double kthr = prm.kthr, dthr2 = prm.dthr2;
     const double ctol2_lo = prm.ctol < 0.0 ? -1.0 : prm.ctol * prm.ctol * (1.0 - 1e-12);
+    SNOWTRI_STAMP(1);
     __syncthreads();
+    SNOWTRI_STAMP(2);
     {
         const int wl = lane / NP, qq = lane - wl * NP, w = pos * kCheckFrames + wl;
         const bool live = pos < ncheck && wl < kCheckFrames && w < nf;
@@ -664,7 +697,9 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean_coop(
             sp += 192;
         }
     }
+    SNOWTRI_STAMP(3);
     __syncthreads();   // the tile's fused joint scores are in the stash, the `bad` bits in slowbits
+    SNOWTRI_STAMP(4);
 
     // ---- epilogue of the tile, dealt to the waves by passes: check pass c on the wave at position c (mod 4), mean pass m
     //      on the wave at position ncheck + m (mod 4)
@@ -707,6 +742,7 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean_coop(
             }
         }
     }
+    SNOWTRI_STAMP(5);
     __syncthreads();   // slowbits and favg are final
     const uint32_t slow = slowbits[0];
     if (wave == 0 && lane < nf && !((slow >> lane) & 1u)) {
@@ -715,6 +751,7 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean_coop(
         if (out_ps) out_ps[f] = (float)favg[lane];
         if (out_flags) out_flags[f] = kFlagFast;
     }
+    SNOWTRI_STAMP(6);
     if (slow == 0u) return;   // (uniform: every thread reads the same word)
     // ---- rare: frames the speculation could not resolve -> the reference's full algorithm, by the whole workgroup
     {
