@@ -338,12 +338,15 @@ __host__ __device__ inline size_t associate_arena_offset(int C, int npairs, int 
 }
 constexpr int kAssocKeptBytes = 44;
 __host__ inline size_t associate_lds_bytes(int C, int npairs, int Pout, int64_t Kc) {
-    // room for every slot of a small rig; for a large one, for a quarter of the slots (>= 256) and for 1.25 x the true
+    // room for a quarter of the slots (>= 64) and for 1.375 x the true
     // pairs of Pmax persons every camera sees (npairs x Pmax: a third of the slots at 3 detections per camera, half at 2):
     // the reference's own workloads keep 25 % (8 x 4) and 13 % (16 x 8) of their candidates
     const int64_t Pmax = (int64_t)(0.5 + __builtin_sqrt((double)Kc / (double)(npairs > 0 ? npairs : 1)));
-    int64_t slots = Kc / 4 < 256 ? 256 : Kc / 4;
-    if (slots < (int64_t)npairs * Pmax * 5 / 4) slots = (int64_t)npairs * Pmax * 5 / 4;
+    // (no generous minimum: the kernel is latency-bound at one wave per frame, and the frames in flight per CU are what
+    // its LDS allows -- 8 x 4: 8.5 KB instead of 13.5 KB = 16 instead of 12 waves per CU; a frame that keeps more goes
+    // through the second launch)
+    int64_t slots = Kc / 4 < 64 ? 64 : Kc / 4;
+    if (slots < (int64_t)npairs * Pmax * 11 / 8) slots = (int64_t)npairs * Pmax * 11 / 8;
     if (slots > Kc) slots = Kc;
     const size_t want = associate_arena_offset(C, npairs, Pout) + (size_t)(kAssocKeptBytes + 6) * (size_t)slots + 64;
     const size_t cap = 48 * 1024;
