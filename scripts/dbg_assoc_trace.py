@@ -22,6 +22,8 @@ raw = np.zeros(4096 * 16, dtype=np.uint64)
 assert L.snowtri_debug_read_assoc_trace(raw.ctypes.data_as(ct.c_void_p)) == 0
 st = raw.reshape(4096, 16)[:, :9].astype(np.int64)
 st = st[(st > 0).all(axis=1)]
+if len(st) == 0:
+    sys.exit("no workgroup ran a second frame (too few frames for the grid): nothing traced")
 us = (st - st[:, :1]) / 100.0
 names = ["frame start", "ragged check done", "kept list built", "centres solved", "clustered + grouped", "filters done", "list room reserved (atomics)", "descriptors written", "zero-fill + count written"]
 print("workgroups traced:", len(st))

@@ -432,6 +432,12 @@ extern "C" int snowtri_debug_read_scratch(snowtri_ctx *ctx, void *dst, size_t by
     return hipMemcpy(dst, ctx->work.p, bytes, hipMemcpyDeviceToHost) == hipSuccess ? SNOWTRI_OK : SNOWTRI_ERR_HIP;
 }
 #endif
+#ifdef SNOWTRI_ASSOC_TRACE
+extern "C" int snowtri_debug_read_assoc_trace(void *dst) {   // dev build only: the stamps of k_associate
+    (void)hipDeviceSynchronize();
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(snowtri::g_assoc_trace), sizeof(unsigned long long) * 4096 * 16) == hipSuccess ? 0 : 3;
+}
+#endif
 int snowtri_debug_selftest(snowtri_ctx *ctx) {
 #ifdef SNOWTRI_DEBUG_BOUNDS
     if (!ctx) return SNOWTRI_ERR_BAD_ARG;

@@ -360,6 +360,12 @@ __host__ inline size_t associate_lds_bytes_full(int C, int npairs, int Pout, int
     return want > cap ? cap : (want < 4096 ? 4096 : want);
 }
 
+#ifdef SNOWTRI_ASSOC_TRACE   // dev build: wall-clock stamps (100 MHz) of every workgroup's second frame at the phase boundaries (scripts/dbg_assoc_trace.py)
+__device__ unsigned long long g_assoc_trace[4096 * 16];
+#define ASSOC_STAMP(i) do { if (threadIdx.x == 0 && fi == (int64_t)blockIdx.x + (int64_t)gridDim.x && blockIdx.x < 4096) g_assoc_trace[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define ASSOC_STAMP(i) ((void)0)
+#endif
 template <typename TIn>
 __global__ __launch_bounds__(64, 4) void k_associate(int64_t F, int Pmax, int J, int Kc, Rig rig, const TIn *__restrict__ kpts,
                                                   const int32_t *__restrict__ n_persons, Params prm, int Pout,
@@ -397,6 +403,7 @@ __global__ __launch_bounds__(64, 4) void k_associate(int64_t F, int Pmax, int J,
     const int64_t nframes = frame_list ? (int64_t)*frame_count : F;
     for (int64_t fi = blockIdx.x; fi < nframes; fi += gridDim.x) {
         const int64_t f = frame_list ? (int64_t)frame_list[fi] : fi;
+        ASSOC_STAMP(0);
         SNOWTRI_DEV_CHECK(f >= 0 && f < F, 21);   // (a listed frame index belongs to the segment)
         const int32_t *np_f = n_persons ? n_persons + f * C : nullptr;
         const Kp3<TIn> *kpf = kp3 + f * (int64_t)R * J;
@@ -418,6 +425,7 @@ __global__ __launch_bounds__(64, 4) void k_associate(int64_t F, int Pmax, int J,
             for (int c = lane; c < C; c += 64) rg |= np_f[c] != Pmax;
             ragged = __ballot(rg) != 0ull;
         }
+        ASSOC_STAMP(1);
         // ---- kept list in candidate order (:79-81)
         int32_t *kidx = reinterpret_cast<int32_t *>(arena);
         int n = 0;
@@ -454,6 +462,7 @@ __global__ __launch_bounds__(64, 4) void k_associate(int64_t F, int Pmax, int J,
             int32_t *csize = reinterpret_cast<int32_t *>(cen + 3 * (size_t)n);
             const int ncl_rem = arena_bytes - (int)(reinterpret_cast<char *>(csize) - arena);
             const int ncl_cap = ncl_rem >= 16 ? (ncl_rem - 4) / 12 : 0;   // csize, cseed [ncl_cap], cstart [ncl_cap + 1]
+            ASSOC_STAMP(2);
             __syncthreads();
             // ---- per kept candidate: word, score sum, centre joint.  Two candidates per lane and step: their keypoint loads
             // are in flight together.
@@ -482,6 +491,7 @@ __global__ __launch_bounds__(64, 4) void k_associate(int64_t F, int Pmax, int J,
                 if (va) centre(ia, rma, rsa, qa, kma, ksa, sa);
                 if (vb) centre(ib, rmb, rsb, qb, kmb, ksb, sb);
             }
+            ASSOC_STAMP(3);
             __syncthreads();
             // ---- triangulation.py:107-130 -- seeds in list order, the last candidate never seeds, distance to the SEED's
             // centre, `dist > tol` skips (NaN absorbs)
@@ -543,6 +553,7 @@ __global__ __launch_bounds__(64, 4) void k_associate(int64_t F, int Pmax, int J,
                 }
                 if (lane == 0) cstart[ncl] = off;
                 __syncthreads();
+                ASSOC_STAMP(4);
                 // ---- filters and descriptors, cluster by cluster (LDS only)
                 uint32_t ncomp = 0, ngen = 0, nwords = 0;
                 for (int cid = 0; cid < ncl; cid++) {
@@ -617,6 +628,7 @@ __global__ __launch_bounds__(64, 4) void k_associate(int64_t F, int Pmax, int J,
                     }
                     nout++;
                 }
+                ASSOC_STAMP(5);
                 if (!slow) {
                     // lanes 0..2 reserve room in the three lists at once
                     const unsigned long long want = lane == 0 ? ncomp : (lane == 1 ? ngen : (lane == 2 ? nwords : 0u));
@@ -634,6 +646,7 @@ __global__ __launch_bounds__(64, 4) void k_associate(int64_t F, int Pmax, int J,
                             desc[(unsigned long long)desc_cap + i] = ClusterDesc{0u, 0u, 0xffffffffu, 0u};
                         slow = true;
                     }
+                    ASSOC_STAMP(6);
                     __syncthreads();
                     if (!slow) {
                         const int nsl = nout < Pout ? nout : Pout;
@@ -663,6 +676,7 @@ __global__ __launch_bounds__(64, 4) void k_associate(int64_t F, int Pmax, int J,
             }
             continue;
         }
+        ASSOC_STAMP(7);
         // unused slots: one flat sweep of 16-byte stores
         for (int i = lane; i < (Pout - nout) * kn; i += 64) wr.zero_joint(f, Pout, kn, nout + i / kn, i % kn);
         for (int slot = nout + lane; slot < Pout; slot += 64) wr.person(f, Pout, slot, 0.0);
@@ -670,6 +684,7 @@ __global__ __launch_bounds__(64, 4) void k_associate(int64_t F, int Pmax, int J,
             out_count[f] = nout;
             if (out_flags && nout > Pout) atomicOr(&out_flags[f], 2u /*SNOWTRI_FLAG_OVERFLOW*/);
         }
+        ASSOC_STAMP(8);
     }
 }
 
