@@ -1,0 +1,47 @@
+"""Dev aid (GPU box, SNOWTRI_LIB = a -DSNOWTRI_SUMS_TRACE build): where k_candidate_sums spends its time -- wall-clock stamps
+(100 MHz) of the first four waves of every workgroup: kernel entry / exit, and the phase boundaries of the workgroup's second
+frame; wave placement from HW_ID.   usage: dbg_sums_trace.py [cfg 3|5]"""
+import ctypes as ct, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from snowmocap_amd import synth, _lib
+from snowmocap_amd.batch import BatchTriangulator
+cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 3
+F, gen, pout = (10000, 1000, 16) if cfg == 3 else (4000, 250, 32)
+wl = synth.config_workload(cfg, gen)
+K, R, t = wl["rig"]
+dev = torch.device("cuda", 0)
+kp = torch.from_numpy(wl["kpts"]).to(dev).repeat(F // gen, 1, 1, 1, 1).contiguous()
+npers = torch.from_numpy(wl["n_persons"]).to(dev).repeat(F // gen, 1).contiguous()
+bt = BatchTriangulator(K, R, t, wl["params"], pout_max=pout, out_dtype=np.float32)
+out = bt.run_torch(kp, npers)
+for _ in range(3):
+    bt.run_torch(kp, npers, out=out)
+torch.cuda.synchronize()
+L = ct.CDLL(_lib.LIB_PATH)
+raw = np.zeros(4096 * 4 * 16, dtype=np.uint64)
+assert L.snowtri_debug_read_sums_trace(raw.ctypes.data_as(ct.c_void_p)) == 0
+st = raw.reshape(4096 * 4, 16).astype(np.int64)
+live = st[:, 12] > 0
+st = st[live]
+print("waves traced:", len(st))
+t0 = st[:, 12].min()
+entry, exit_ = (st[:, 12] - t0) / 100.0, (st[:, 13] - t0) / 100.0
+print("kernel: first entry 0, last exit %.1f us; entry median %.1f p95 %.1f max %.1f; exit min %.1f p5 %.1f median %.1f" % (
+    exit_.max(), np.median(entry), np.percentile(entry, 95), entry.max(), exit_.min(), np.percentile(exit_, 5), np.median(exit_)))
+print("wave lifetime / kernel span: mean %.3f" % ((exit_ - entry).mean() / exit_.max()))
+hw = st[:, 14]
+cu = ((hw >> 32) & 0xf) * 1000 + ((hw >> 13) & 0x7) * 100 + ((hw >> 12) & 1) * 50 + ((hw >> 8) & 0xf)   # xcc, se, sh, cu
+u, n = np.unique(cu, return_counts=True)
+print("distinct CUs %d; waves per CU: min %d median %d max %d" % (len(u), n.min(), np.median(n), n.max()))
+fr = st[(st[:, :12] > 0).all(axis=1)]
+if len(fr) == 0:
+    sys.exit("no workgroup ran a second frame")
+us = (fr[:, :12] - fr[:, :1]) / 100.0
+names = ["frame start", "first keypoints requested, barrier", "body entered", "chunk 0 in LDS", "chunk 0 solved", "chunk 1 in LDS", "chunk 1 solved",
+         "chunk 2 in LDS", "chunk 2 solved", "chunk 3 in LDS", "chunk 3 solved", "frame end"]
+prev = np.zeros(len(fr))
+for i, nme in enumerate(names):
+    v = us[:, i]
+    print("%-36s at median %7.2f us  (+%6.2f, p95 +%6.2f)" % (nme, np.median(v), np.median(v - prev), np.percentile(v - prev, 95)))
+    prev = v

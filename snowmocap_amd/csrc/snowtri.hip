@@ -432,6 +432,12 @@ extern "C" int snowtri_debug_read_scratch(snowtri_ctx *ctx, void *dst, size_t by
     return hipMemcpy(dst, ctx->work.p, bytes, hipMemcpyDeviceToHost) == hipSuccess ? SNOWTRI_OK : SNOWTRI_ERR_HIP;
 }
 #endif
+#ifdef SNOWTRI_SUMS_TRACE
+extern "C" int snowtri_debug_read_sums_trace(void *dst) {   // dev build only: the stamps of k_candidate_sums
+    (void)hipDeviceSynchronize();
+    return hipMemcpyFromSymbol(dst, HIP_SYMBOL(snowtri::g_sums_trace), sizeof(unsigned long long) * 4096 * 4 * 16) == hipSuccess ? 0 : 3;
+}
+#endif
 #ifdef SNOWTRI_ASSOC_TRACE
 extern "C" int snowtri_debug_read_assoc_trace(void *dst) {   // dev build only: the stamps of k_associate
     (void)hipDeviceSynchronize();
@@ -1467,7 +1473,7 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax
     const int64_t seg_cap = ctx->handover_seg_frames > 0 ? ctx->handover_seg_frames : seg_frames;
     const int64_t seg = (stream || handover) ? std::min(seg_frames, seg_cap) : F;
     unsigned long long *next_frame = ctx->d_counters + 2, *hand_counters = ctx->d_counters + 3, *slow_count = ctx->d_counters + 6,
-                       *exact_count = ctx->d_counters + 7, *slow_count2 = ctx->d_counters + 8;
+                       *exact_count = ctx->d_counters + 7, *slow_count2 = ctx->d_counters + 8, *sums_ticket = ctx->d_counters + 9;
     const uint32_t *final_slow_list = nullptr;                 // what the streaming association leaves to k_frame_recompute
     const unsigned long long *final_slow_count = nullptr;
     {   // the kernels of this route, in launch order (rebuilt only when the route changes)
@@ -1508,7 +1514,7 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax
             desc = (ClusterDesc *)ctx->desc.p;
             words = (uint32_t *)(desc + (size_t)2 * cap);
         }
-        HIP_TRY(hipMemsetAsync(next_frame, 0, 7 * sizeof(unsigned long long), st));   // next_frame, the three hand-over counters, slow / exact / slow (second pass) frames
+        HIP_TRY(hipMemsetAsync(next_frame, 0, 8 * sizeof(unsigned long long), st));   // next_frame, the three hand-over counters, slow / exact / slow (second pass) frames, the frame tickets of k_candidate_sums
         const TIn *kp_seg = d_kpts + s0 * (int64_t)R * J * 3;
         const int32_t *np_seg = d_np ? d_np + s0 * C : nullptr;
         TOut *xyz_seg = d_xyzs + s0 * (int64_t)Pout * prm.kn * 4;
@@ -1534,7 +1540,7 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax
         auto k1 = k_candidate_sums<TIn, TT>;                                                                                         \
         if (SL.lds > 48 * 1024 && ctx->raise_lds((const void *)k1, SL.lds)) return SNOWTRI_ERR_HIP;                                 \
         hipLaunchKernelGGL(k1, dim3(grid1), dim3(TT), SL.lds, st, Fs, Pmax, J, (int)Kc, ctx->rig(), kp_seg, np_seg, prm, csum, fl_seg, \
-                           exact_list, exact_count, SL.lds);                                                                         \
+                           exact_list, exact_count, sums_ticket, SL.lds);                                                            \
     }
                 if (SL.threads == 256) SNOWTRI_SUMS(256) else if (SL.threads == 512) SNOWTRI_SUMS(512) else SNOWTRI_SUMS(1024)
 #undef SNOWTRI_SUMS

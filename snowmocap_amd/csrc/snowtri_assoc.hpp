@@ -66,15 +66,32 @@ __host__ __device__ inline int sums_chunk_joints(int C, int Pmax, int J, int npa
 // threads -- 8 cameras x 4 persons: 112 items, two joint sub-ranges, 224 of 256 lanes) a lane keeps the sums of its GS
 // candidates in registers over all joint chunks; larger rigs walk the items in rounds and add a chunk's sums to csum
 // (loaded at the start of the round, stored at its end: in flight during the solves).
+#ifdef SNOWTRI_SUMS_TRACE   // dev build: wall-clock stamps (100 MHz) of every wave: kernel entry / exit and the phase boundaries of its second frame (scripts/dbg_sums_trace.py)
+__device__ unsigned long long g_sums_trace[4096 * 4 * 16];
+#define SUMS_STAMP_ALWAYS(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096 && threadIdx.x < 256) g_sums_trace[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define SUMS_STAMP(i) do { if (it == 1) SUMS_STAMP_ALWAYS(i); } while (0)
+#else
+#define SUMS_STAMP_ALWAYS(i) ((void)0)
+#define SUMS_STAMP(i) ((void)0)
+#endif
 template <typename TIn, int THREADS>
 __global__ __launch_bounds__(THREADS, SumsShape<THREADS>::kWavesPerSimd) void k_candidate_sums(
     int64_t F, int Pmax, int J, int Kc, Rig rig, const TIn *__restrict__ kpts, const int32_t *__restrict__ n_persons, Params prm,
     double *__restrict__ csum, uint32_t *__restrict__ out_flags, uint32_t *__restrict__ exact_list, unsigned long long *exact_count,
-    int lds_total) {
+    unsigned long long *next_frame, int lds_total) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int B = THREADS, NW = THREADS / 64, NPF = SumsShape<THREADS>::kPrefetch;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+    SUMS_STAMP_ALWAYS(12);
+#ifdef SNOWTRI_SUMS_TRACE
+    if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096 && threadIdx.x < 256) {
+        unsigned hw, xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        g_sums_trace[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + 14] = ((unsigned long long)xcc << 32) | hw;
+    }
+#endif
     const int C = rig.C, R = C * Pmax, pp = Pmax * Pmax;
     int32_t *head = reinterpret_cast<int32_t *>(smem);          // [0] a candidate needs the exact sum, [1] ragged frame
     int32_t *np_l = reinterpret_cast<int32_t *>(smem + kSumsHeadBytes);    // [C] persons listed by the cameras in this frame
@@ -91,12 +108,23 @@ __global__ __launch_bounds__(THREADS, SumsShape<THREADS>::kWavesPerSimd) void k_
     const unsigned long long magic_pmax = (((unsigned long long)1 << 40) + (unsigned)Pmax - 1) / (unsigned)Pmax;
     const Kp3<TIn> *kp3 = reinterpret_cast<const Kp3<TIn> *>(kpts);
 
-    for (int64_t f = blockIdx.x; f < F; f += gridDim.x) {
+    // Frames: the first one by workgroup index, the following ones through a ticket counter (next_frame, zeroed by the host).
+    // Every frame costs the same instructions, but the SIMDs serve their waves oldest first: with a static deal the oldest
+    // workgroup of a CU ran through its frames at nearly full speed and left (8 x 4: after 455 of 850 us, wall-clock stamps
+    // per wave, -DSNOWTRI_SUMS_TRACE), the youngest finished alone on its CU with nothing to hide its latencies behind.
+    // The ticket for the frame after this one is drawn at the frame's start (its round trip is hidden) and handed to the
+    // other threads through LDS, in alternating slots (a slot is rewritten two frames later, behind that frame's barriers).
+    int64_t f = blockIdx.x;
+    for (int it = 0; f < F; it++) {
         const int32_t *np_f = n_persons ? n_persons + f * C : nullptr;
         const Kp3<TIn> *kpf = kp3 + f * (int64_t)R * J;
         double *cs_f = csum + f * (int64_t)Kc;
-        if (tid == 0) head[0] = head[1] = 0;
+        if (tid == 0) {
+            head[0] = head[1] = 0;
+            head[2 + (it & 1)] = (int32_t)atomicAdd(next_frame, 1ull);
+        }
         __syncthreads();   // (also: the previous frame's readers of the arena are done)
+        SUMS_STAMP(0);
         for (int c = tid; c < C; c += B) {
             const int v = np_f ? np_f[c] : Pmax;
             np_l[c] = v;
@@ -132,6 +160,7 @@ __global__ __launch_bounds__(THREADS, SumsShape<THREADS>::kWavesPerSimd) void k_
         };
         fetch(0, J < Jc ? J : Jc);
         __syncthreads();
+        SUMS_STAMP(1);
         const int GS = head[1] ? 1 : p1_group_size(Pmax);   // a ragged frame keeps one candidate per lane
         const int NG = Pmax / GS, per_q = Pmax * NG, nitems = rig.npairs * per_q;
         int JS = sums_joint_split(nitems, NW);
@@ -181,11 +210,13 @@ __global__ __launch_bounds__(THREADS, SumsShape<THREADS>::kWavesPerSimd) void k_
             }
             for (int j0 = 0; j0 < J; j0 += Jc) {
                 const int nj = (J - j0) < Jc ? (J - j0) : Jc;
+                SUMS_STAMP(j0 / Jc < 4 ? 3 + 2 * (j0 / Jc) - 2 + 1 : 15);   // (2, 4, 6, 8: solves of the previous chunk done / frame body entered)
                 if (j0) __syncthreads();   // the previous chunk's solves are done
 #ifndef SNOWTRI_K1_NOFILL   // dev experiment (timing only, outputs are wrong)
                 commit();
 #endif
                 __syncthreads();
+                SUMS_STAMP(j0 / Jc < 4 ? 3 + 2 * (j0 / Jc) : 15);   // (3, 5, 7, 9: records of the chunk in LDS, solves start)
                 // the next chunk's keypoints: in flight during the solves.  (Rounds: issued behind the first round's loads
                 // of csum -- the memory counter is in order, and those loads are waited for at the end of the round.)
                 bool fetched = false;
@@ -223,6 +254,7 @@ __global__ __launch_bounds__(THREADS, SumsShape<THREADS>::kWavesPerSimd) void k_
                     fetch_next();   // (a wave without items)
                 }
             }
+            SUMS_STAMP(10);   // solves of the last chunk done
             if constexpr (SINGLE) {   // the partial sums of the joint sub-ranges meet in the arena
                 __syncthreads();
                 for (int k = tid; k < JS * Kc; k += B) lsum[k] = 0.0;
@@ -269,7 +301,10 @@ __global__ __launch_bounds__(THREADS, SumsShape<THREADS>::kWavesPerSimd) void k_
             if (out_flags) out_flags[f] = 0u;
             if (head[0]) exact_list[atomicAdd(exact_count, 1ull)] = (uint32_t)f;
         }
+        SUMS_STAMP(11);
+        f = (int64_t)gridDim.x + (int64_t)(uint32_t)head[2 + (it & 1)];
     }
+    SUMS_STAMP_ALWAYS(13);
 }
 
 // The frames k_candidate_sums listed: every candidate sum again with the accurate arithmetic (1/dist by v_rsq_f64 + one
