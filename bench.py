@@ -192,6 +192,8 @@ def main():
     ap.add_argument("--streams", type=int, default=2,
                     help="HIP streams the steps are issued on round-robin (one context each); 2 lets the ramp-up / "
                          "tail of consecutive 10 000-frame launches overlap")
+    ap.add_argument("--device-warmup-ms", type=float, default=100.0,
+                    help="untimed steps issued for this long before the first timed region (the chip's clock ramp)")
     ap.add_argument("--no-gather", action="store_true", help="N > 1: skip the RCCL all-gather of the track")
     ap.add_argument("--chunks", type=lambda v: [x if x == "auto" else max(1, int(x)) for x in v.split(",")], default=["auto"],
                     help="pieces the shard is cut into for the overlapped all-gather (ShardedTriangulator.run): `auto` (pieces of "
@@ -296,6 +298,17 @@ def main():
             dt = float(tt.item())
         return dt
 
+    # Device warm-up (untimed, the same steps): the chip leaves its idle power state over tens of milliseconds -- without it
+    # the regions of one run get faster one after the other (0.0244 ... 0.0207 ms per step over the seven regions of a
+    # default run, and the driver's `--steps 20` regions all fall into the ramp).  The timed regions below are unchanged:
+    # W warm-up steps, then exactly K steps between two fences.
+    t_w = time.perf_counter()
+    n_w = 0
+    while (time.perf_counter() - t_w) * 1e3 < args.device_warmup_ms:
+        for i in range(50):
+            bts[i % nstreams].run_torch(pool[i % len(pool)], None, out=outs[i % len(pool)], stream=streams[i % nstreams].cuda_stream)
+        torch.cuda.synchronize(dev)
+        n_w += 50
     # `value`: frames sharded across ranks, no data-path collective (frames are independent: SURVEY 8e).
     regions = [timed_region() for _ in range(max(1, args.repeats))]
     elapsed = float(np.median(regions))
@@ -452,6 +465,7 @@ def main():
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "rccl_ranks": dist.get_world_size() if dist is not None else 1,
             "ranks": ranks_seen,
+            "device_warmup": {"ms": args.device_warmup_ms, "untimed_steps": n_w},
             "repeats": {"n": len(regions), "statistic": "median", "ms_per_step_min": min(regions) / K_steps * 1e3,
                         "ms_per_step_max": max(regions) / K_steps * 1e3,
                         "ms_per_step_all": [r / K_steps * 1e3 for r in regions]},

@@ -1407,7 +1407,7 @@ struct SumsLaunch {
 };
 SumsLaunch sums_launch_shape(const snowtri_ctx *ctx, int Pmax, int J) {
     const int C = ctx->C, gs = p1_group_size(Pmax);
-    const int64_t nitems = (int64_t)ctx->npairs * Pmax * (Pmax / gs);
+    const int64_t nitems = (int64_t)ctx->npairs * (Pmax / (gs >= 2 ? SNOWTRI_SUMS_GA : 1)) * (Pmax / gs);   // (k_candidate_sums: GA x GS tiles)
     SumsLaunch L;
     // one pass over the items should keep every wave busy: 256 threads for the small rigs, the whole CU for the large
     L.threads = ctx->sums_threads > 0 ? ctx->sums_threads : (nitems <= 256 ? 256 : (nitems <= 768 ? 512 : 1024));

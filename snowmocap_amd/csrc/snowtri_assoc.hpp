@@ -19,53 +19,98 @@
 namespace snowtri {
 
 // ---------------------------------------------------------------------------------------------- k_candidate_sums
-// LDS: [0, 64) flags | n_persons of the frame (4 B x C) | per camera pair d = t_s - t_m and the two camera indices (32 B) |
-// ray matrices | arena = one joint chunk of ray records (layout and bank map: snowtri_general.hpp, p1_joint_stride); at
-// the end of a frame the arena holds the partial sums of the joint sub-ranges.
+// LDS: [0, 64) flags and tickets | n_persons of the frame (4 B x C) | per camera pair d = t_s - t_m and the two camera
+// indices (32 B) | ray matrices | arena = TWO buffers of one joint chunk of ray records each (layout and bank map:
+// snowtri_general.hpp, p1_joint_stride): the waves solve the chunk in one buffer while the records of the next chunk are
+// written to the other; at the end of a frame the buffer of its last chunk holds the partial sums of the joint sub-ranges.
 constexpr int kSumsHeadBytes = 64;
-// workgroup shapes (threads, waves per SIMD the registers must allow, records of the next chunk a thread holds in
+// workgroup shapes (threads, waves per SIMD the registers must allow, records of the coming chunk a thread holds in
 // registers): 256 threads x 3 workgroups per CU for the small rigs, 512 x 2 or 1024 x 1 for the large ones
 template <int THREADS>
 struct SumsShape {
     static constexpr int kWavesPerSimd = THREADS == 256 ? 3 : 4;
-    static constexpr int kPrefetch = THREADS == 256 ? 5 : 4;
+    static constexpr int kPrefetch = THREADS == 256 ? 3 : 2;
 };
+#ifndef SNOWTRI_SUMS_GA
+#define SNOWTRI_SUMS_GA 2   // persons of the FIRST camera per tile (when the person count is even)
+#endif
 
 __host__ __device__ inline size_t sums_arena_offset(int C, int npairs) {
     return ((size_t)kSumsHeadBytes + (size_t)4 * C + (size_t)32 * npairs + (size_t)72 * C + 15) & ~(size_t)15;
 }
-// item = (camera pair, person of its first camera, group of GS persons of its second); JS = how many ways a chunk's
-// joints are split over the workgroup's NW waves when one pass over the items leaves waves idle (whole waves take a
-// joint sub-range: the lanes of a wave still read the same joint)
+// bytes of ONE of the two chunk buffers
+__host__ __device__ inline int sums_buffer_bytes(int C, int npairs, int lds_total) {
+    return ((lds_total - (int)sums_arena_offset(C, npairs)) / 2) & ~15;
+}
+// item = tile of GA persons of a pair's first camera x GS persons of its second; JS = how many ways a chunk's joints are
+// split over the workgroup's NW waves when one pass over the items leaves waves idle (whole waves take a joint sub-range:
+// the lanes of a wave still read the same joint)
 __host__ __device__ inline int sums_joint_split(int nitems, int NW) {
     const int iw = (nitems + 63) >> 6;
     int js = 1;
     while (2 * js * iw <= NW) js *= 2;
     return js;
 }
-// joints per chunk: what the arena holds and the threads can prefetch, evened out over the chunks
+// joints per chunk: what one buffer holds and the threads can prefetch, evened out over the chunks, and a multiple of the
+// joint split of a frame whose cameras all list Pmax persons (the waves of a chunk meet at a barrier: 19 joints dealt to
+// four waves would cost every chunk the time of 5)
 __host__ __device__ inline int sums_chunk_joints(int C, int Pmax, int J, int npairs, int threads, int prefetch, int lds_total) {
     const int R = C * Pmax;
-    const int arena = lds_total - (int)sums_arena_offset(C, npairs);
-    int cap = arena / p1_joint_stride(R);
+    int cap = sums_buffer_bytes(C, npairs, lds_total) / p1_joint_stride(R);
     const int pf = prefetch * threads / R;   // every record of a chunk prefetched
     if (cap > pf) cap = pf;
     if (cap > 64) cap = 64;
     if (cap < 1) return 0;
     const int nch = (J + cap - 1) / cap;
-    return (J + nch - 1) / nch;   // 133 joints -> 34 + 33 + 33 + 33, not 4 x 32 + 5
+    int jc = (J + nch - 1) / nch;   // 133 joints, room for 40 -> 34 + 33 + 33 + 33, not 3 x 40 + 13
+    const int gs = p1_group_size(Pmax), ga = gs >= 2 ? SNOWTRI_SUMS_GA : 1;
+    const long long nitems = (long long)npairs * (Pmax / ga) * (Pmax / gs);
+    if (nitems * 2 <= threads) {
+        const int js = sums_joint_split((int)nitems, threads / 64);
+        if (jc > js) {
+            const int up = (jc + js - 1) / js * js;
+            jc = up <= cap ? up : jc / js * js;
+        }
+    }
+    return jc;
 }
 
-// csum[f][k] = sum over the joints of the score of candidate slot k (J x the mean of :79; 0 for a slot whose cameras
-// list fewer persons), with the fast arithmetic of p1_item_sums; a frame with a candidate whose fast sum cannot decide
-// :80-81 -- not finite, or within 1e-6 relative of average_score_threshold -- is appended to exact_list and re-done by
-// k_candidate_sums_exact.  out_flags[f] = 0.  Frames are dealt round-robin to the workgroups (every frame costs the same
-// here).  Host-checked: keypoint_score_threshold >= 0.  Dynamic LDS = lds_total.
-//
-// Per frame: the items are dealt to the lanes once.  If one pass of the workgroup covers them (SINGLE: items x JS <=
-// threads -- 8 cameras x 4 persons: 112 items, two joint sub-ranges, 224 of 256 lanes) a lane keeps the sums of its GS
-// candidates in registers over all joint chunks; larger rigs walk the items in rounds and add a chunk's sums to csum
-// (loaded at the start of the round, stored at its end: in flight during the solves).
+// The fast phase-1 arithmetic of p1_item_sums (snowtri_general.hpp) on a GA x GS TILE of candidates: GA consecutive persons
+// of camera m against GS consecutive persons of camera s, acc[i * GS + u] += 2000 x score of candidate (pm0 + i, ps0 + u).
+// A 2 x 4 tile reads 6 records per 8 solves where the 1 x 4 item read 5 per 4 (3.75 instead of 6.25 ds_read_b64 per solve: all
+// waves of a CU queue on one LDS pipe, and a wave waits for its reads at the top of every joint), and the keypoint gate
+// of a second ray is evaluated once per tile.  Same operations per candidate in the same order: the sums are the bits of
+// p1_item_sums.
+template <int GA, int GS, typename TIn>
+__device__ __forceinline__ void p1_tile_sums(const char *__restrict__ pa, const char *__restrict__ pb, int jstr, int nj, const Vec3 &d,
+                                             const Params &prm, double (&acc)[GA * GS]) {
+    for (int t = 0; t < nj; t++, pa += jstr, pb += jstr) {
+        RayRec b[GS];
+        TIn ss[GS];
+#pragma unroll
+        for (int u = 0; u < GS; u++) {
+            b[u] = p1_load_ray(pb + kP1Rec * u);
+            ss[u] = p1_load_score<TIn>(pb + kP1Rec * u);
+        }
+#pragma unroll
+        for (int i = 0; i < GA; i++) {
+            const RayRec a = p1_load_ray(pa + kP1Rec * i);
+            const TIn sm = p1_load_score<TIn>(pa + kP1Rec * i);
+            const double cx = fma(d.y, a.z, -(d.z * a.y)), cy = fma(d.z, a.x, -(d.x * a.z)), cz = fma(d.x, a.y, -(d.y * a.x));
+            const bool okm = !below_kthr(sm, prm);
+#pragma unroll
+            for (int u = 0; u < GS; u++) {
+                const double bq = fma(a.z, b[u].z, fma(a.y, b[u].y, a.x * b[u].x));
+                const double det = fma(a.a, b[u].a, -(bq * bq));
+                const double dn = fma(cz, b[u].z, fma(cy, b[u].y, cx * b[u].x));
+                const double dn2 = dn * dn;
+                const bool kp_ = okm && !below_kthr(ss[u], prm) && !(dn2 > det * prm.dthr2);   // :73-74
+                acc[i * GS + u] = fma(gated_sum_sel(sm, ss[u], kp_), det * __builtin_amdgcn_rsq(dn2 * det), acc[i * GS + u]);
+            }
+        }
+    }
+}
+
 #ifdef SNOWTRI_SUMS_TRACE   // dev build: wall-clock stamps (100 MHz) of every wave: kernel entry / exit and the phase boundaries of its second frame (scripts/dbg_sums_trace.py)
 __device__ unsigned long long g_sums_trace[4096 * 4 * 16];
 #define SUMS_STAMP_ALWAYS(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096 && threadIdx.x < 256) g_sums_trace[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
@@ -74,6 +119,28 @@ __device__ unsigned long long g_sums_trace[4096 * 4 * 16];
 #define SUMS_STAMP_ALWAYS(i) ((void)0)
 #define SUMS_STAMP(i) ((void)0)
 #endif
+// csum[f][k] = sum over the joints of the score of candidate slot k (J x the mean of :79; 0 for a slot whose cameras
+// list fewer persons), with the fast arithmetic of p1_tile_sums; a frame with a candidate whose fast sum cannot decide
+// :80-81 -- not finite, or within 1e-6 relative of average_score_threshold -- is appended to exact_list and re-done by
+// k_candidate_sums_exact.  out_flags[f] = 0.  Host-checked: keypoint_score_threshold >= 0, C <= 16.  Dynamic LDS = lds_total.
+//
+// Frames: the first one by workgroup index, the following ones through a ticket counter (next_frame, zeroed by the host).
+// Every frame costs the same instructions, but the SIMDs serve their waves oldest first: with a static deal the oldest
+// workgroup of a CU ran through its frames at nearly full speed and left (8 x 4: after 455 of 850 us, wall-clock stamps
+// per wave, -DSNOWTRI_SUMS_TRACE), the youngest finished alone on its CU with nothing to hide its latencies behind.
+//
+// Per frame, a software pipeline over the joint chunks with ONE barrier per chunk:
+//     solve chunk c (buffer c & 1)  ->  write the records of chunk c + 1 (other buffer; their keypoints were requested a
+//     chunk ago)  ->  request the keypoints of chunk c + 2 -- behind the frame's last chunk: of the NEXT frame's first
+//     chunk, with its n_persons (the ticket is drawn at the frame's start)  ->  barrier.
+// A wave that is done with its solves fills LDS for the next chunk instead of waiting for the others, a frame starts on
+// records that are already in registers, and what used to be two barriers and an exposed fill per chunk plus an HBM round
+// trip per frame (26 % of the kernel on 8 x 4, 19 % on 16 x 8: its time against the solve phase run N times,
+// -DSNOWTRI_K1_REPEAT) overlaps the solves.
+// The items (tiles) are dealt to the lanes once per frame.  If one pass of the workgroup covers them (SINGLE: items x JS
+// <= threads -- 8 cameras x 4 persons: 56 tiles, four joint sub-ranges, 224 of 256 lanes; 16 x 8: 960 tiles on 15 of 16
+// waves) a lane keeps the sums of its tile in registers over all joint chunks; larger rigs walk the items in rounds and
+// add a chunk's sums to csum (loaded at the start of the round, stored at its end: in flight during the solves).
 template <typename TIn, int THREADS>
 __global__ __launch_bounds__(THREADS, SumsShape<THREADS>::kWavesPerSimd) void k_candidate_sums(
     int64_t F, int Pmax, int J, int Kc, Rig rig, const TIn *__restrict__ kpts, const int32_t *__restrict__ n_persons, Params prm,
@@ -93,176 +160,198 @@ __global__ __launch_bounds__(THREADS, SumsShape<THREADS>::kWavesPerSimd) void k_
     }
 #endif
     const int C = rig.C, R = C * Pmax, pp = Pmax * Pmax;
-    int32_t *head = reinterpret_cast<int32_t *>(smem);          // [0] a candidate needs the exact sum, [1] ragged frame
+    // head: per frame parity p = it & 1: [4p] a candidate needs the exact sum, [4p + 1] ragged frame, [4p + 2] ticket of the
+    // frame after it (a slot is rewritten two frames later, behind that frame's barriers)
+    int32_t *head = reinterpret_cast<int32_t *>(smem);
     int32_t *np_l = reinterpret_cast<int32_t *>(smem + kSumsHeadBytes);    // [C] persons listed by the cameras in this frame
     double *paird = reinterpret_cast<double *>(np_l + C + (C & 1));        // [npairs][3]
     int32_t *pairs = reinterpret_cast<int32_t *>(paird + 3 * rig.npairs);  // [npairs][2]
     double *Ml = reinterpret_cast<double *>(pairs + 2 * rig.npairs);
+    if (tid < kSumsHeadBytes / 4) head[tid] = 0;
     for (int i = tid; i < 3 * rig.npairs; i += B) paird[i] = rig.pairc[6 * (i / 3) + i % 3];
     for (int i = tid; i < 2 * rig.npairs; i += B) pairs[i] = rig.pairs[i];
     for (int i = tid; i < 9 * C; i += B) Ml[i] = rig.M[i];
-    char *rec = smem + sums_arena_offset(C, rig.npairs);
-    double *lsum = reinterpret_cast<double *>(rec);             // [JS][Kc] at the end of a SINGLE frame
-    const int arena_bytes = lds_total - (int)sums_arena_offset(C, rig.npairs);
+    char *const rec0 = smem + sums_arena_offset(C, rig.npairs);
+    const int half = sums_buffer_bytes(C, rig.npairs, lds_total);   // bytes of one chunk buffer
     const int jstr = p1_joint_stride(R), Jc = sums_chunk_joints(C, Pmax, J, rig.npairs, B, NPF, lds_total);
+    const int nch = (J + Jc - 1) / Jc;
     const unsigned long long magic_pmax = (((unsigned long long)1 << 40) + (unsigned)Pmax - 1) / (unsigned)Pmax;
     const Kp3<TIn> *kp3 = reinterpret_cast<const Kp3<TIn> *>(kpts);
 
-    // Frames: the first one by workgroup index, the following ones through a ticket counter (next_frame, zeroed by the host).
-    // Every frame costs the same instructions, but the SIMDs serve their waves oldest first: with a static deal the oldest
-    // workgroup of a CU ran through its frames at nearly full speed and left (8 x 4: after 455 of 850 us, wall-clock stamps
-    // per wave, -DSNOWTRI_SUMS_TRACE), the youngest finished alone on its CU with nothing to hide its latencies behind.
-    // The ticket for the frame after this one is drawn at the frame's start (its round trip is hidden) and handed to the
-    // other threads through LDS, in alternating slots (a slot is rewritten two frames later, behind that frame's barriers).
+    // ---- the records of a joint chunk: keypoints fetched into registers (a chunk ahead), then ray + |h|^2 + score into
+    // LDS.  Lanes = consecutive joints of a row: coalesced 12-byte reads.  Rows a camera does not list are filled with
+    // whatever the buffer holds: no valid candidate reads them.
+    Kp3<TIn> pre[NPF];
+    int pre_off[NPF];   // byte offset of the record in its buffer | camera << 20, or -1
+    int npv = Pmax;     // threads < C: n_persons of the coming frame
+    auto fetch = [&](const Kp3<TIn> *kpf, int j0, int nj) {
+        const unsigned long long magic_nj = (((unsigned long long)1 << 40) + (unsigned)nj - 1) / (unsigned)nj;
+#pragma unroll
+        for (int n = 0; n < NPF; n++) {
+            // (every slot loads, past the chunk's end the last record again: a load inside a branch would have to be
+            // waited for where the branch joins)
+            const int i = tid + n * B, ic = i < R * nj ? i : R * nj - 1;
+            const int r = (int)(((unsigned long long)(unsigned)ic * magic_nj) >> 40), jj = ic - r * nj;
+            const int c = (int)(((unsigned long long)(unsigned)r * magic_pmax) >> 40);
+            SNOWTRI_DEV_CHECK(r >= 0 && r < R && j0 + jj >= 0 && j0 + jj < J, 10);   // keypoint (row, joint) inside the frame
+            pre[n] = kpf[(size_t)r * J + j0 + jj];
+            pre_off[n] = i < R * nj ? ((jj * jstr + kP1Rec * r) | (c << 20)) : -1;
+        }
+    };
+    auto fetch_frame = [&](int64_t fr) {   // first chunk and person counts of frame fr
+        fetch(kp3 + fr * (int64_t)R * J, 0, J < Jc ? J : Jc);
+        if (n_persons && tid < C) npv = n_persons[fr * C + tid];
+    };
+    auto commit = [&](char *buf) {
+#ifndef SNOWTRI_K1_NOFILL   // dev experiment (timing only, outputs are wrong)
+#pragma unroll
+        for (int n = 0; n < NPF; n++)
+            if (pre_off[n] >= 0) {
+                SNOWTRI_DEV_CHECK((pre_off[n] & 0xfffff) + kP1Rec <= half && (pre_off[n] >> 20) < C, 11);   // record inside the buffer
+                p1_store_record<TIn>(buf + (pre_off[n] & 0xfffff), make_ray(Ml + 9 * (pre_off[n] >> 20), pre[n].u, pre[n].v), pre[n].s);
+            }
+#endif
+    };
+
     int64_t f = blockIdx.x;
+    if (f < F) fetch_frame(f);
+    int par = 0;   // buffer of the frame's first chunk
+    __syncthreads();   // constants and the cleared head
     for (int it = 0; f < F; it++) {
-        const int32_t *np_f = n_persons ? n_persons + f * C : nullptr;
+        int32_t *hd = head + 4 * (it & 1);
         const Kp3<TIn> *kpf = kp3 + f * (int64_t)R * J;
         double *cs_f = csum + f * (int64_t)Kc;
-        if (tid == 0) {
-            head[0] = head[1] = 0;
-            head[2 + (it & 1)] = (int32_t)atomicAdd(next_frame, 1ull);
-        }
-        __syncthreads();   // (also: the previous frame's readers of the arena are done)
         SUMS_STAMP(0);
-        for (int c = tid; c < C; c += B) {
-            const int v = np_f ? np_f[c] : Pmax;
-            np_l[c] = v;
-            if (v != Pmax) head[1] = 1;
+        if (tid == 0) hd[2] = (int32_t)atomicAdd(next_frame, 1ull);
+        if (tid < C) {   // (the previous frame's readers of np_l are behind its barriers)
+            np_l[tid] = npv;
+            if (npv != Pmax) hd[1] = 1;
         }
-
-        // ---- the records of a joint chunk: keypoints fetched into registers (one chunk ahead), then ray + |h|^2 + score
-        // into LDS.  Lanes = consecutive joints of a row: coalesced 12-byte reads.  Rows a camera does not list are
-        // filled with whatever the buffer holds: no valid candidate reads them.
-        Kp3<TIn> pre[NPF];
-        int pre_off[NPF];   // LDS byte offset of the record | camera << 20, or -1
-        auto fetch = [&](int j0, int nj) {
-            const unsigned long long magic_nj = (((unsigned long long)1 << 40) + (unsigned)nj - 1) / (unsigned)nj;
-#pragma unroll
-            for (int n = 0; n < NPF; n++) {
-                // (every slot loads, past the chunk's end the last record again: a load inside a branch would have to be
-                // waited for where the branch joins)
-                const int i = tid + n * B, ic = i < R * nj ? i : R * nj - 1;
-                const int r = (int)(((unsigned long long)(unsigned)ic * magic_nj) >> 40), jj = ic - r * nj;
-                const int c = (int)(((unsigned long long)(unsigned)r * magic_pmax) >> 40);
-                SNOWTRI_DEV_CHECK(r >= 0 && r < R && j0 + jj >= 0 && j0 + jj < J, 10);   // keypoint (row, joint) inside the frame
-                pre[n] = kpf[(size_t)r * J + j0 + jj];
-                pre_off[n] = i < R * nj ? ((jj * jstr + kP1Rec * r) | (c << 20)) : -1;
-            }
-        };
-        auto commit = [&]() {
-#pragma unroll
-            for (int n = 0; n < NPF; n++)
-                if (pre_off[n] >= 0) {
-                    SNOWTRI_DEV_CHECK((pre_off[n] & 0xfffff) + kP1Rec <= arena_bytes && (pre_off[n] >> 20) < C, 11);   // record inside the arena
-                    p1_store_record<TIn>(rec + (pre_off[n] & 0xfffff), make_ray(Ml + 9 * (pre_off[n] >> 20), pre[n].u, pre[n].v), pre[n].s);
-                }
-        };
-        fetch(0, J < Jc ? J : Jc);
-        __syncthreads();
+        commit(rec0 + par * half);
+        if (nch >= 2) fetch(kpf, Jc, (J - Jc) < Jc ? (J - Jc) : Jc);
+        __syncthreads();   // first chunk, np_l, ragged flag and ticket are there
         SUMS_STAMP(1);
-        const int GS = head[1] ? 1 : p1_group_size(Pmax);   // a ragged frame keeps one candidate per lane
-        const int NG = Pmax / GS, per_q = Pmax * NG, nitems = rig.npairs * per_q;
+        const int64_t fnext = (int64_t)gridDim.x + (int64_t)(uint32_t)hd[2];
+        if (nch == 1 && fnext < F) fetch_frame(fnext);
+        const int GS = hd[1] ? 1 : p1_group_size(Pmax);   // a ragged frame keeps one candidate per lane
+        const int GA = GS >= 2 ? SNOWTRI_SUMS_GA : 1;      // (GS >= 2: Pmax is even)
+        const int NG = Pmax / GS, per_q = (Pmax / GA) * NG, nitems = rig.npairs * per_q;
         int JS = sums_joint_split(nitems, NW);
-        const bool single = nitems * JS <= B && (size_t)JS * Kc * 8 <= (size_t)arena_bytes;
+        const bool single = nitems * JS <= B && (JS == 1 || (size_t)JS * Kc * 8 <= (size_t)half);
         if (!single) JS = 1;
         const int wpg = NW / JS;               // waves that share a joint sub-range
         const int jsub = wv / wpg, iw = wv - jsub * wpg;
         const unsigned long long magic_pq = (((unsigned long long)1 << 40) + (unsigned)per_q - 1) / (unsigned)per_q;
         const unsigned long long magic_ng = (((unsigned long long)1 << 40) + (unsigned)NG - 1) / (unsigned)NG;
-        if (!single)
-            for (int k = tid; k < Kc; k += B) cs_f[k] = 0.0;
+        bool redo = false;
 
-        // one loop nest per (candidates per item, SINGLE): the variants share no registers with loads in flight
+        // one loop nest per (tile, SINGLE): the variants share no registers with loads in flight
         auto frame_body = [&](auto gs_c, auto single_c) {
-            constexpr int GSC = decltype(gs_c)::value;
+            constexpr int GSC = decltype(gs_c)::value, GAC = GSC >= 2 ? SNOWTRI_SUMS_GA : 1, NT = GAC * GSC;
             constexpr bool SINGLE = decltype(single_c)::value;
             // item of (round base, lane) -> first candidate slot, record offsets of its rows, pair offset; live?
             struct Item {
                 int k0, oa, ob;
                 Vec3 d;
-                bool cand;
+                bool live, cand;
             };
             auto locate = [&](int base) {
                 Item t;
                 const int item = base + lane;
                 const bool live = item < nitems;
-                const int it = live ? item : 0;
-                const int q = (int)(((unsigned long long)(unsigned)it * magic_pq) >> 40), r2 = it - q * per_q;
-                const int pm = (int)(((unsigned long long)(unsigned)r2 * magic_ng) >> 40), ps0 = (r2 - pm * NG) * GSC;
+                const int ii = live ? item : 0;
+                const int q = (int)(((unsigned long long)(unsigned)ii * magic_pq) >> 40), r2 = ii - q * per_q;
+                const int pmg = (int)(((unsigned long long)(unsigned)r2 * magic_ng) >> 40), pm = pmg * GAC, ps0 = (r2 - pmg * NG) * GSC;
                 const int mc = pairs[2 * q], sc = pairs[2 * q + 1];
                 const double *pc = paird + 3 * q;
-                t.k0 = q * pp + pm * Pmax + ps0;
+                t.k0 = q * pp + pm * Pmax + ps0;   // candidate (i, u) of the tile: slot k0 + i Pmax + u
                 t.oa = kP1Rec * (mc * Pmax + pm);
                 t.ob = kP1Rec * (sc * Pmax + ps0);
                 t.d = {pc[0], pc[1], pc[2]};
-                t.cand = live;
-                SNOWTRI_DEV_CHECK(!live || (t.k0 >= 0 && t.k0 + GSC <= Kc && t.oa + kP1Rec <= jstr && t.ob + GSC * kP1Rec <= jstr), 12);   // slots and rows of the item
+                t.live = t.cand = live;
+                SNOWTRI_DEV_CHECK(!live || (t.k0 >= 0 && t.k0 + (GAC - 1) * Pmax + GSC <= Kc && t.oa + GAC * kP1Rec <= jstr && t.ob + GSC * kP1Rec <= jstr), 12);   // slots and rows of the item
                 if constexpr (GSC == 1) t.cand = live && pm < np_l[mc] && ps0 < np_l[sc];   // empty slots stay at 0
                 return t;
             };
+            auto slot = [&](const Item &t, int u) { return t.k0 + (u / GSC) * Pmax + u % GSC; };
             Item mine{};
-            double tot[GSC];
+            double tot[NT];
             if constexpr (SINGLE) {
                 mine = locate(iw * 64);
 #pragma unroll
-                for (int u = 0; u < GSC; u++) tot[u] = 0.0;
+                for (int u = 0; u < NT; u++) tot[u] = 0.0;
             }
-            for (int j0 = 0; j0 < J; j0 += Jc) {
+            for (int c = 0, j0 = 0; c < nch; c++, j0 += Jc) {
                 const int nj = (J - j0) < Jc ? (J - j0) : Jc;
-                SUMS_STAMP(j0 / Jc < 4 ? 3 + 2 * (j0 / Jc) - 2 + 1 : 15);   // (2, 4, 6, 8: solves of the previous chunk done / frame body entered)
-                if (j0) __syncthreads();   // the previous chunk's solves are done
-#ifndef SNOWTRI_K1_NOFILL   // dev experiment (timing only, outputs are wrong)
-                commit();
-#endif
-                __syncthreads();
-                SUMS_STAMP(j0 / Jc < 4 ? 3 + 2 * (j0 / Jc) : 15);   // (3, 5, 7, 9: records of the chunk in LDS, solves start)
-                // the next chunk's keypoints: in flight during the solves.  (Rounds: issued behind the first round's loads
-                // of csum -- the memory counter is in order, and those loads are waited for at the end of the round.)
-                bool fetched = false;
-                auto fetch_next = [&]() {
-#ifndef SNOWTRI_K1_NOFILL
-                    if (!fetched && j0 + Jc < J) fetch(j0 + Jc, (J - j0 - Jc) < Jc ? (J - j0 - Jc) : Jc);
-#endif
-                    fetched = true;
-                };
-                if constexpr (SINGLE) fetch_next();
-                // the waves of joint sub-range jsub walk joints [jlo, jhi) of the chunk
+                const char *cur = rec0 + ((par ^ c) & 1) * half;
+                // the waves of joint sub-range jsub walk joints [jlo, jhi) of the chunk (the sub-ranges rotate from chunk to
+                // chunk: where the joints of a chunk do not divide by JS every wave gets the long sub-range in turn)
 #ifdef SNOWTRI_K1_NOSOLVE   // dev experiment (timing only, outputs are wrong)
                 const int jlo = 0, jhi = 0;
 #else
-                const int jlo = jsub * nj / JS, jhi = (jsub + 1) * nj / JS;
+                const int jrot = (jsub + c) & (JS - 1);
+                const int jlo = jrot * nj / JS, jhi = (jrot + 1) * nj / JS;
 #endif
                 if constexpr (SINGLE) {
-                    p1_item_sums<GSC, TIn>(rec + jlo * jstr + mine.oa, rec + jlo * jstr + mine.ob, jstr, mine.cand ? jhi - jlo : 0, mine.d, prm, tot);
+#ifdef SNOWTRI_K1_REPEAT   // dev experiment (timing only, sums x N): the solve phase N times -- its slope is the solve time alone
+                    for (int rep = 1; rep < SNOWTRI_K1_REPEAT; rep++)
+                        p1_tile_sums<GAC, GSC, TIn>(cur + jlo * jstr + mine.oa, cur + jlo * jstr + mine.ob, jstr, mine.cand ? jhi - jlo : 0, mine.d, prm, tot);
+#endif
+                    p1_tile_sums<GAC, GSC, TIn>(cur + jlo * jstr + mine.oa, cur + jlo * jstr + mine.ob, jstr, mine.cand ? jhi - jlo : 0, mine.d, prm, tot);
                 } else {
                     for (int base = iw * 64; base < nitems; base += wpg * 64) {
                         const Item t = locate(base);
-                        double old[GSC], acc[GSC];
+                        double old[NT], acc[NT];
 #pragma unroll
-                        for (int u = 0; u < GSC; u++) {
+                        for (int u = 0; u < NT; u++) {
                             acc[u] = 0.0;
-                            old[u] = t.cand ? cs_f[t.k0 + u] : 0.0;   // (in flight during the solves)
+                            old[u] = (c > 0 && t.cand) ? cs_f[slot(t, u)] : 0.0;   // (in flight during the solves)
                         }
-                        fetch_next();
-                        p1_item_sums<GSC, TIn>(rec + jlo * jstr + t.oa, rec + jlo * jstr + t.ob, jstr, t.cand ? jhi - jlo : 0, t.d, prm, acc);
-                        if (t.cand) {
+                        p1_tile_sums<GAC, GSC, TIn>(cur + jlo * jstr + t.oa, cur + jlo * jstr + t.ob, jstr, t.cand ? jhi - jlo : 0, t.d, prm, acc);
+                        // (the first chunk defines every slot of the frame, the empty ones as 0)
+                        if (t.cand || (c == 0 && t.live)) {
 #pragma unroll
-                            for (int u = 0; u < GSC; u++) cs_f[t.k0 + u] = old[u] + acc[u];
+                            for (int u = 0; u < NT; u++) cs_f[slot(t, u)] = t.cand ? old[u] + acc[u] : 0.0;
                         }
                     }
-                    fetch_next();   // (a wave without items)
                 }
+                if (c + 1 < nch) {
+                    commit(rec0 + ((par ^ (c + 1)) & 1) * half);
+                    if (c + 2 < nch)
+                        fetch(kpf, j0 + 2 * Jc, (J - j0 - 2 * Jc) < Jc ? (J - j0 - 2 * Jc) : Jc);
+                    else if (fnext < F)
+                        fetch_frame(fnext);
+                }
+                __syncthreads();   // chunk c is solved (its buffer is free), chunk c + 1 is in LDS, csum is up to date
             }
-            SUMS_STAMP(10);   // solves of the last chunk done
-            if constexpr (SINGLE) {   // the partial sums of the joint sub-ranges meet in the arena
-                __syncthreads();
-                for (int k = tid; k < JS * Kc; k += B) lsum[k] = 0.0;
-                __syncthreads();
-                if (mine.cand) {
+            SUMS_STAMP(10);
+            // the 1 / (2 * 1000) of :72, and whether a mean can decide :80-81
+            auto finish = [&](int k, double v) {
+                const double s_ = v * 0.0005, mean = s_ / (double)J;
+                cs_f[k] = s_;
+                redo |= !(fabs(mean) < 1e300) || (s_ != 0.0 && fabs(mean - prm.avg_thr) <= 1e-6 * fabs(mean));
+            };
+            if constexpr (SINGLE) {
+                if (JS == 1) {   // a lane owns its candidates' whole sums
+                    if (mine.live) {
 #pragma unroll
-                    for (int u = 0; u < GSC; u++) lsum[jsub * Kc + mine.k0 + u] = tot[u];
+                        for (int u = 0; u < NT; u++) finish(slot(mine, u), mine.cand ? tot[u] : 0.0);
+                    }
+                } else {         // the partial sums of the joint sub-ranges meet in the buffer of the last chunk
+                    double *lsum = reinterpret_cast<double *>(rec0 + ((par ^ (nch - 1)) & 1) * half);
+                    if (mine.live) {
+#pragma unroll
+                        for (int u = 0; u < NT; u++) lsum[jsub * Kc + slot(mine, u)] = mine.cand ? tot[u] : 0.0;
+                    }
+                    __syncthreads();
+                    for (int k = tid; k < Kc; k += B) {
+                        double v = lsum[k];
+                        for (int s_ = 1; s_ < JS; s_++) v += lsum[s_ * Kc + k];
+                        finish(k, v);
+                    }
                 }
+            } else {
+                for (int k = tid; k < Kc; k += B) finish(k, cs_f[k]);
             }
         };
         if (single) {
@@ -280,29 +369,16 @@ __global__ __launch_bounds__(THREADS, SumsShape<THREADS>::kWavesPerSimd) void k_
             else
                 frame_body(std::integral_constant<int, 1>{}, std::false_type{});
         }
-        // the 1 / (2 * 1000) of :72 (and the JS partial sums of a SINGLE frame)
-        __syncthreads();
-        bool redo = false;
-        for (int k = tid; k < Kc; k += B) {
-            double v;
-            if (single) {
-                v = lsum[k];
-                for (int s_ = 1; s_ < JS; s_++) v += lsum[s_ * Kc + k];
-            } else {
-                v = cs_f[k];
-            }
-            const double s_ = v * 0.0005, mean = s_ / (double)J;
-            cs_f[k] = s_;
-            redo |= !(fabs(mean) < 1e300) || (s_ != 0.0 && fabs(mean - prm.avg_thr) <= 1e-6 * fabs(mean));
-        }
-        if (redo) head[0] = 1;
+        if (redo) hd[0] = 1;
         __syncthreads();
         if (tid == 0) {
             if (out_flags) out_flags[f] = 0u;
-            if (head[0]) exact_list[atomicAdd(exact_count, 1ull)] = (uint32_t)f;
+            if (hd[0]) exact_list[atomicAdd(exact_count, 1ull)] = (uint32_t)f;
+            hd[0] = hd[1] = 0;   // (for the frame after the next one)
         }
         SUMS_STAMP(11);
-        f = (int64_t)gridDim.x + (int64_t)(uint32_t)head[2 + (it & 1)];
+        par ^= nch & 1;   // the next frame's first chunk goes where this frame's last chunk was not (its partial sums may still be read)
+        f = fnext;
     }
     SUMS_STAMP_ALWAYS(13);
 }
@@ -397,7 +473,7 @@ __host__ inline size_t associate_lds_bytes_full(int C, int npairs, int Pout, int
 
 #ifdef SNOWTRI_ASSOC_TRACE   // dev build: wall-clock stamps (100 MHz) of every workgroup's second frame at the phase boundaries (scripts/dbg_assoc_trace.py)
 __device__ unsigned long long g_assoc_trace[4096 * 16];
-#define ASSOC_STAMP(i) do { if (threadIdx.x == 0 && fi == (int64_t)blockIdx.x + (int64_t)gridDim.x && blockIdx.x < 4096) g_assoc_trace[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#define ASSOC_STAMP(i) do { if (threadIdx.x == 0 && it == 1 && blockIdx.x < 4096) g_assoc_trace[blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
 #define ASSOC_STAMP(i) ((void)0)
 #endif
@@ -436,7 +512,10 @@ __global__ __launch_bounds__(64, 4) void k_associate(int64_t F, int Pmax, int J,
 
     // frame_list: the frames a first launch with less LDS left behind (frame_count of them, known on the device only)
     const int64_t nframes = frame_list ? (int64_t)*frame_count : F;
-    for (int64_t fi = blockIdx.x; fi < nframes; fi += gridDim.x) {
+    // (frames dealt round-robin: a ticket counter as in k_candidate_sums measured WORSE here -- 8 x 4: 97 -> 128 us per launch --
+    // the ticket's round trip sits in front of the frame's first loads on the in-order memory counter)
+    int it = 0;
+    for (int64_t fi = blockIdx.x; fi < nframes; fi += gridDim.x, it++) {
         const int64_t f = frame_list ? (int64_t)frame_list[fi] : fi;
         ASSOC_STAMP(0);
         SNOWTRI_DEV_CHECK(f >= 0 && f < F, 21);   // (a listed frame index belongs to the segment)
