@@ -34,14 +34,14 @@ hw = st[:, 14]
 cu = ((hw >> 32) & 0xf) * 1000 + ((hw >> 13) & 0x7) * 100 + ((hw >> 12) & 1) * 50 + ((hw >> 8) & 0xf)   # xcc, se, sh, cu
 u, n = np.unique(cu, return_counts=True)
 print("distinct CUs %d; waves per CU: min %d median %d max %d" % (len(u), n.min(), np.median(n), n.max()))
-fr = st[(st[:, :12] > 0).all(axis=1)]
+idx = [0, 1, 10, 11]
+fr = st[(st[:, idx] > 0).all(axis=1)]
 if len(fr) == 0:
     sys.exit("no workgroup ran a second frame")
-us = (fr[:, :12] - fr[:, :1]) / 100.0
-names = ["frame start", "first keypoints requested, barrier", "body entered", "chunk 0 in LDS", "chunk 0 solved", "chunk 1 in LDS", "chunk 1 solved",
-         "chunk 2 in LDS", "chunk 2 solved", "chunk 3 in LDS", "chunk 3 solved", "frame end"]
+us = (fr[:, idx] - fr[:, :1]) / 100.0
+names = ["frame start", "first chunk written (+ barrier where the frame has them)", "last chunk solved", "frame end"]
 prev = np.zeros(len(fr))
 for i, nme in enumerate(names):
     v = us[:, i]
-    print("%-36s at median %7.2f us  (+%6.2f, p95 +%6.2f)" % (nme, np.median(v), np.median(v - prev), np.percentile(v - prev, 95)))
+    print("%-58s at median %7.2f us  (+%6.2f, p95 +%6.2f)" % (nme, np.median(v), np.median(v - prev), np.percentile(v - prev, 95)))
     prev = v

@@ -132,6 +132,10 @@ int inv3(const double *m, double *o) {
 }
 
 constexpr int kTimingRing = 1024;
+// ctx->d_counters: [0] singular pairs, [1] slow frames, [2] frame queue of k_frame_recompute, [6..9] slow / exact / slow
+// (second pass) frame counts and the frame tickets of k_candidate_sums, [16 .. 32] the two hand-over list counters
+// (snowtri_cluster.hpp: kHandComplete, kHandMembers -- 128 bytes apart)
+constexpr int kHandCountersAt = 16, kCounterWords = 48;
 
 int grid_for(int64_t work_items, int per_block, int cap_blocks) {
     int64_t b = (work_items + per_block - 1) / per_block;
@@ -290,7 +294,7 @@ int snowtri_ctx_create(int32_t C, const double *K, const double *R, const double
     CTX_TRY(hipMalloc(&ctx->dM, sizeof(double) * std::max<size_t>(9, ctx->hM.size())));
     CTX_TRY(hipMalloc(&ctx->dt, sizeof(double) * std::max<size_t>(3, ctx->ht.size())));
     CTX_TRY(hipMalloc(&ctx->dpairs, sizeof(int32_t) * std::max<size_t>(2, ctx->hpairs.size())));
-    CTX_TRY(hipMalloc(&ctx->d_counters, sizeof(unsigned long long) * 16));
+    CTX_TRY(hipMalloc(&ctx->d_counters, sizeof(unsigned long long) * kCounterWords));
     CTX_TRY(hipMalloc(&ctx->dpairc, sizeof(double) * std::max<size_t>(6, hpairc.size())));
     {   // world->pixel matrices P_c = K_c [R_c^T | -R_c^T t_c] for the DLT method
         std::vector<double> hP((size_t)std::max(1, C) * 12, 0.0);
@@ -316,7 +320,7 @@ int snowtri_ctx_create(int32_t C, const double *K, const double *R, const double
     }
     if (ctx->npairs > 0)
         CTX_TRY(hipMemcpy(ctx->dpairs, ctx->hpairs.data(), sizeof(int32_t) * ctx->hpairs.size(), hipMemcpyHostToDevice));
-    CTX_TRY(hipMemset(ctx->d_counters, 0, sizeof(unsigned long long) * 16));
+    CTX_TRY(hipMemset(ctx->d_counters, 0, sizeof(unsigned long long) * kCounterWords));
     for (auto &e : ctx->ev) CTX_TRY(hipEventCreate(&e));
 #undef CTX_TRY
     *out = ctx;
@@ -412,11 +416,11 @@ int64_t snowtri_last_handover_persons(snowtri_ctx *ctx, int64_t *n_other) {
     if (n_other) *n_other = -1;
     if (!ctx || !ctx->last_handover) return -1;
     DeviceGuard guard(ctx->device);
-    unsigned long long n[2] = {0, 0};   // complete-graph clusters, clusters of any other shape
+    unsigned long long n[kHandMembers + 1] = {0};   // [kHandComplete] complete-graph clusters, [kHandMembers] >> 32 clusters of any other shape
     if (hipDeviceSynchronize() != hipSuccess) return -1;
-    if (hipMemcpy(n, ctx->d_counters + 3, sizeof(n), hipMemcpyDeviceToHost) != hipSuccess) return -1;
-    if (n_other) *n_other = (int64_t)n[1];
-    return (int64_t)n[0];
+    if (hipMemcpy(n, ctx->d_counters + kHandCountersAt, sizeof(n), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (n_other) *n_other = (int64_t)hand_member_descs(n[kHandMembers]);
+    return (int64_t)n[kHandComplete];
 }
 
 const char *snowtri_last_kernel_names(const snowtri_ctx *ctx) { return ctx ? ctx->last_kernels : ""; }
@@ -1472,7 +1476,7 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax
     if (stream) seg_frames = std::max<int64_t>(1, std::min<int64_t>(seg_frames, ((int64_t)64 << 20) / Kc));
     const int64_t seg_cap = ctx->handover_seg_frames > 0 ? ctx->handover_seg_frames : seg_frames;
     const int64_t seg = (stream || handover) ? std::min(seg_frames, seg_cap) : F;
-    unsigned long long *next_frame = ctx->d_counters + 2, *hand_counters = ctx->d_counters + 3, *slow_count = ctx->d_counters + 6,
+    unsigned long long *next_frame = ctx->d_counters + 2, *hand_counters = ctx->d_counters + kHandCountersAt, *slow_count = ctx->d_counters + 6,
                        *exact_count = ctx->d_counters + 7, *slow_count2 = ctx->d_counters + 8, *sums_ticket = ctx->d_counters + 9;
     const uint32_t *final_slow_list = nullptr;                 // what the streaming association leaves to k_frame_recompute
     const unsigned long long *final_slow_count = nullptr;
@@ -1514,7 +1518,7 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax
             desc = (ClusterDesc *)ctx->desc.p;
             words = (uint32_t *)(desc + (size_t)2 * cap);
         }
-        HIP_TRY(hipMemsetAsync(next_frame, 0, 8 * sizeof(unsigned long long), st));   // next_frame, the three hand-over counters, slow / exact / slow (second pass) frames, the frame tickets of k_candidate_sums
+        HIP_TRY(hipMemsetAsync(next_frame, 0, (kCounterWords - 2) * sizeof(unsigned long long), st));   // next_frame, slow / exact / slow (second pass) frames, the frame tickets of k_candidate_sums, the hand-over list counters
         const TIn *kp_seg = d_kpts + s0 * (int64_t)R * J * 3;
         const int32_t *np_seg = d_np ? d_np + s0 * C : nullptr;
         TOut *xyz_seg = d_xyzs + s0 * (int64_t)Pout * prm.kn * 4;

@@ -744,13 +744,14 @@ __global__ __launch_bounds__(64, 4) void k_associate(int64_t F, int Pmax, int J,
                 }
                 ASSOC_STAMP(5);
                 if (!slow) {
-                    // lanes 0..2 reserve room in the three lists at once
-                    const unsigned long long want = lane == 0 ? ncomp : (lane == 1 ? ngen : (lane == 2 ? nwords : 0u));
+                    // lanes 0 and 1 reserve room in the lists at once: one atomic per counter (member descriptors and member
+                    // words share a word), the counters on different memory channels
+                    const unsigned long long want = lane == 0 ? (unsigned long long)ncomp
+                                                              : (lane == 1 ? ((unsigned long long)ngen << 32) | (unsigned long long)nwords : 0ull);
                     unsigned long long got = 0ull;
-                    if (want) got = atomicAdd(hand_counters + lane, want);
-                    const unsigned long long bc = (unsigned long long)__shfl((long long)got, 0, 64),
-                                             bg = (unsigned long long)__shfl((long long)got, 1, 64),
-                                             bw = (unsigned long long)__shfl((long long)got, 2, 64);
+                    if (want) got = atomicAdd(hand_counters + (lane == 0 ? kHandComplete : kHandMembers), want);
+                    const unsigned long long bc = (unsigned long long)__shfl((long long)got, 0, 64), gm = (unsigned long long)__shfl((long long)got, 1, 64),
+                                             bg = hand_member_descs(gm), bw = hand_member_words(gm);
                     // (cannot happen: the host sizes the lists for Pout persons and Kc members of every frame)
                     if (bc + ncomp > (unsigned long long)desc_cap || bg + ngen > (unsigned long long)desc_cap ||
                         bw + nwords > (unsigned long long)word_cap) {
@@ -820,7 +821,7 @@ __global__ __launch_bounds__(kBlock) void k_cluster_members(const ClusterDesc *_
     for (int i = tid; i < 9 * C; i += kBlock) Ml[i] = rig.M[i];
     for (int i = tid; i < 6 * NP; i += kBlock) pc[i] = rig.pairc[i];
     for (int i = tid; i < 2 * NP; i += kBlock) pairs_l[i] = rig.pairs[i];
-    const unsigned long long ng64 = cnt[1];
+    const unsigned long long ng64 = hand_member_descs(cnt[kHandMembers]);
     const uint32_t ngen = ng64 < (unsigned long long)desc_cap ? (uint32_t)ng64 : desc_cap;
     __syncthreads();
     const uint32_t W = gridDim.x * (uint32_t)(kBlock / 64);

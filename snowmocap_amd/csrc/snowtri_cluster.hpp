@@ -32,6 +32,14 @@ struct ClusterDesc {
     uint32_t slot;     // output slot (< Pout); 0xffffffff = voided entry
     uint32_t size;     // 0 = complete graph, else the number of members
 };
+// The two list counters of a launch (zeroed by the host), on different 128-byte lines: every frame reserves its descriptors
+// with ONE atomic per list (member descriptors and member words share a word).  (Measured on 8 x 4, wall-clock stamps of
+// k_associate: a wave waits ~17 us for its reservation whether the counters share a line or not and whether it issues two
+// atomics or three -- the round trip of a device-scope atomic under 4 096 waves, not the line.)
+//   cnt[kHandComplete]: complete-graph descriptors;  cnt[kHandMembers]: member-list descriptors << 32 | member words
+constexpr int kHandComplete = 0, kHandMembers = 16;
+__host__ __device__ inline uint32_t hand_member_descs(unsigned long long v) { return (uint32_t)(v >> 32); }
+__host__ __device__ inline uint32_t hand_member_words(unsigned long long v) { return (uint32_t)(v & 0xffffffffull); }
 constexpr int kClusterMaxCams = 8;      // 4-bit person fields in one word, register-resident rays
 constexpr int kClusterMaxPersons = 16;
 
@@ -269,7 +277,7 @@ __device__ __forceinline__ void cluster_member_passes(const ClusterDesc *__restr
 // Grid: any number of workgroups.  Wave gw takes 64-item passes gw, gw + W, ... of the ndesc x J items
 // (item = descriptor * J + joint); the descriptor of the pass after next and the keypoints of the next pass are in
 // flight while a pass is solved.  Then the same for the clusters of any other shape (cluster_member_passes).
-// cnt[0], cnt[1]: descriptors in desc[0, cap) (complete graphs) and desc[cap, 2 cap) (member lists).
+// cnt[kHandComplete], cnt[kHandMembers] >> 32: descriptors in desc[0, cap) (complete graphs) and desc[cap, 2 cap) (member lists).
 // Dynamic LDS: cluster_lds_bytes(C).
 //   jmagic = ceil(2^40 / J): item / J = (item * jmagic) >> 40 for item < 2^31, J <= 256.
 #ifndef SNOWTRI_CLUSTER_WAVES
@@ -296,7 +304,7 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_CLUSTER_WAVES) void k_cluster_fuse(
     if (tid < 3 * NP) K[12 * C + tid] = rig.pairc[6 * (tid / 3) + tid % 3];
     for (int i = tid; i < 6 * NP; i += kBlock) pc[i] = rig.pairc[i];
     if (tid < 2 * NP) pairs_l[tid] = rig.pairs[tid];
-    const unsigned long long nd64 = cnt[0], ng64 = cnt[1];
+    const unsigned long long nd64 = cnt[kHandComplete], ng64 = hand_member_descs(cnt[kHandMembers]);
     const uint32_t ndesc = nd64 < (unsigned long long)desc_cap ? (uint32_t)nd64 : desc_cap;
     const uint32_t ngen = ng64 < (unsigned long long)desc_cap ? (uint32_t)ng64 : desc_cap;
     const uint32_t total = ndesc * (uint32_t)J;
@@ -494,7 +502,7 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_WIDE_WAVES) void k_cluster_fuse_wid
         }
         dl[i] = v;
     }
-    const unsigned long long nd64 = cnt[0];
+    const unsigned long long nd64 = cnt[kHandComplete];
     const uint32_t ndesc = nd64 < (unsigned long long)desc_cap ? (uint32_t)nd64 : desc_cap;
     const uint32_t total = ndesc * (uint32_t)J;
     const uint32_t npass = (total + 15u) >> 4;

@@ -841,9 +841,12 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
                         if (lane == 0) {
                             unsigned long long bc = 0ull, bg = 0ull, bw = 0ull;
                             if (ok) {
-                                if (ncomp) bc = atomicAdd(hand_counters, (unsigned long long)ncomp);
-                                if (ngen) bg = atomicAdd(hand_counters + 1, (unsigned long long)ngen);
-                                if (nwords) bw = atomicAdd(hand_counters + 2, (unsigned long long)nwords);
+                                if (ncomp) bc = atomicAdd(hand_counters + kHandComplete, (unsigned long long)ncomp);
+                                if (ngen || nwords) {
+                                    const unsigned long long gm = atomicAdd(hand_counters + kHandMembers, ((unsigned long long)ngen << 32) | (unsigned long long)nwords);
+                                    bg = hand_member_descs(gm);
+                                    bw = hand_member_words(gm);
+                                }
                                 if (bc + ncomp > (unsigned long long)desc_cap || bg + ngen > (unsigned long long)desc_cap ||
                                     bw + nwords > (unsigned long long)word_cap) {
                                     // (cannot happen: the host sizes the lists for Pout persons and Kc members of every frame)
