@@ -173,6 +173,7 @@ struct snowtri_ctx {
     int lean_coop = 1;     // dev/test knob: 0 keeps small launches on k_fused_lean (A/B against k_fused_lean_coop)
     int handover_mode = 1; // dev/test knob: 1 streaming association (k_candidate_sums / k_associate / k_cluster_fuse), 2 hand-over from
                            // inside k_frame_recompute, 0 the whole multi-person path inside k_frame_recompute
+    int cluster_split = 1;   // dev knob (SNOWTRI_CLUSTER_SPLIT): 0 runs the member-list clusters of <= 8-camera rigs inside k_cluster_fuse
     int sums_threads = 0, sums_lds_kb = 0, assoc_wg_per_cu = 16;   // dev knobs of the streaming association (0: automatic)
     int recompute_wg_per_cu = 0, cluster_ppw = 24, debug = 0;
     int tile_frames = 0, lean_wg_per_cu = 2, lean_tiles_per_wave = 0, lean_scratch_mb = 256, handover_seg_frames = 0;   // dev / test knobs
@@ -237,6 +238,7 @@ int snowtri_ctx_create(int32_t C, const double *K, const double *R, const double
     if (const char *hm = getenv("SNOWTRI_HANDOVER_MODE")) ctx->handover_mode = atoi(hm);
     // every environment knob is read HERE, once: nothing on the launch path calls getenv
     if (const char *e = getenv("SNOWTRI_SUMS_THREADS")) ctx->sums_threads = atoi(e);
+    if (const char *e = getenv("SNOWTRI_CLUSTER_SPLIT")) ctx->cluster_split = atoi(e);
     if (const char *e = getenv("SNOWTRI_SUMS_LDS_KB")) ctx->sums_lds_kb = atoi(e);
     if (const char *e = getenv("SNOWTRI_ASSOC_WG_PER_CU")) ctx->assoc_wg_per_cu = std::max(1, atoi(e));
     if (const char *e = getenv("SNOWTRI_RECOMPUTE_WG_PER_CU")) ctx->recompute_wg_per_cu = atoi(e);
@@ -1400,8 +1402,14 @@ int launch_cluster_fuse(snowtri_ctx *ctx, hipStream_t st, int64_t Fs, int Pmax, 
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((W + kBlock / 64 - 1) / (kBlock / 64), (int64_t)ctx->num_cus * 64));
     const unsigned long long jmagic = (((unsigned long long)1 << 40) + (unsigned long long)J - 1) / (unsigned long long)J;
     hipLaunchKernelGGL((k_cluster_fuse<C, TIn>), dim3(grid), dim3(kBlock), cluster_lds_bytes(C), st, desc, words, cnt, cap, ctx->rig(),
-                       d_kpts, prm, Pmax, J, jmagic, Pout, d_xyzs);
+                       d_kpts, prm, Pmax, J, jmagic, Pout, d_xyzs, ctx->cluster_split ? 0 : 1);
     HIP_TRY(hipGetLastError());
+    if (ctx->cluster_split) {
+        const int gridm = (int)std::max<int64_t>(1, std::min<int64_t>((passes_max + 3) / 4, (int64_t)ctx->num_cus * 16));
+        hipLaunchKernelGGL((k_cluster_members<TIn>), dim3(gridm), dim3(kBlock), cluster_members_lds_bytes(C, ctx->npairs), st, desc, words, cnt,
+                           cap, ctx->rig(), d_kpts, prm, Pmax, J, jmagic, Pout, d_xyzs);
+        HIP_TRY(hipGetLastError());
+    }
     return SNOWTRI_OK;
 }
 
@@ -1486,7 +1494,7 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax
         if (key != ctx->names_key) {
             const std::string tin = type_name<TIn>(), tout = type_name<TOut>();
             const std::string rec = "k_frame_recompute<" + std::to_string(METHOD) + "," + tin + "," + tout + ">";
-            const std::string fuse = C <= kClusterMaxCams ? "k_cluster_fuse<" + std::to_string(C) + "," + tin + ">"
+            const std::string fuse = C <= kClusterMaxCams ? "k_cluster_fuse<" + std::to_string(C) + "," + tin + ">" + (ctx->cluster_split ? " + k_cluster_members<" + tin + ">" : std::string())
                                                            : "k_cluster_fuse_wide<" + tin + "> + k_cluster_members<" + tin + ">";
             if (stream)
                 ctx->names_buf = "k_candidate_sums<" + tin + "," + std::to_string(SL.threads) + "> + k_candidate_sums_exact<" + tin +

@@ -291,7 +291,7 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_CLUSTER_WAVES) void k_cluster_fuse(
                                                           const uint32_t *__restrict__ words,
                                                           const unsigned long long *__restrict__ cnt, uint32_t desc_cap,
                                                           Rig rig, const TIn *__restrict__ kpts, Params prm, int Pmax, int J,
-                                                          unsigned long long jmagic, int Pout, float *__restrict__ out4) {
+                                                          unsigned long long jmagic, int Pout, float *__restrict__ out4, int with_members) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NP = C * (C - 1) / 2;
     double *K = reinterpret_cast<double *>(smem);   // [M | t | d] for cluster_item, then [pairc | pairs] for the member lists
@@ -391,8 +391,11 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_CLUSTER_WAVES) void k_cluster_fuse(
 #endif
         }
     }
-    // the waves that ran the fewest complete-graph passes start on the member lists first
-    cluster_member_passes<TIn>(desc + desc_cap, ngen, words, K, pc, pairs_l, C * Pmax, kp3, prm, J, jmagic, Pout, out4,
+    // the waves that ran the fewest complete-graph passes start on the member lists first (with_members = 0: the member
+    // lists are left to k_cluster_members, whose waves need a third of the registers -- a member pass is a chain of dependent
+    // loads per member, and at the two waves per SIMD of this kernel nothing hides them)
+    if (with_members)
+        cluster_member_passes<TIn>(desc + desc_cap, ngen, words, K, pc, pairs_l, C * Pmax, kp3, prm, J, jmagic, Pout, out4,
                                (p_first + W - (npass % W)) % W, W);
 }
 
