@@ -175,7 +175,7 @@ struct snowtri_ctx {
                            // inside k_frame_recompute, 0 the whole multi-person path inside k_frame_recompute
     int cluster_split = 1;   // dev knob (SNOWTRI_CLUSTER_SPLIT): 0 runs the member-list clusters of <= 8-camera rigs inside k_cluster_fuse
     int sums_threads = 0, sums_lds_kb = 0, assoc_wg_per_cu = 16;   // dev knobs of the streaming association (0: automatic)
-    int recompute_wg_per_cu = 0, cluster_ppw = 24, debug = 0;
+    int recompute_wg_per_cu = 0, cluster_ppw = 0, debug = 0;   // cluster_ppw (SNOWTRI_CLUSTER_PASSES_PER_WAVE): 0 = automatic
     int tile_frames = 0, lean_wg_per_cu = 2, lean_tiles_per_wave = 0, lean_scratch_mb = 256, handover_seg_frames = 0;   // dev / test knobs
     struct OccCache {
         size_t lds = 0;
@@ -1397,7 +1397,11 @@ int launch_cluster_fuse(snowtri_ctx *ctx, hipStream_t st, int64_t Fs, int Pmax, 
                         int Pout, float *d_xyzs, const ClusterDesc *desc, const uint32_t *words,
                         const unsigned long long *cnt, uint32_t cap) {
     const int64_t passes_max = (Fs * Pout * (int64_t)J + 63) / 64;
-    const int ppw = ctx->cluster_ppw;   // passes per wave when every frame fills its Pout slots
+    // exactly the waves that are resident at once (two per SIMD at this kernel's registers), each striding over the passes:
+    // with the member lists in a kernel of their own every pass costs the same, and short-lived workgroups only added their
+    // start-up (8 x 4: 334 -> 312 us); a knob value > 0 asks for that many passes per wave when every frame fills its slots.
+    // (k_cluster_members on a second stream beside this kernel: measured, no gain -- 1.34 ms either way.)
+    const int ppw = ctx->cluster_ppw > 0 ? ctx->cluster_ppw : (1 << 30);
     const int64_t W = std::max<int64_t>((passes_max + ppw - 1) / ppw, std::min<int64_t>(passes_max, (int64_t)ctx->num_cus * 8));
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((W + kBlock / 64 - 1) / (kBlock / 64), (int64_t)ctx->num_cus * 64));
     const unsigned long long jmagic = (((unsigned long long)1 << 40) + (unsigned long long)J - 1) / (unsigned long long)J;
@@ -1619,7 +1623,8 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax
                             const size_t ldsw = cluster_wide_lds_bytes(C);
                             if (ldsw > 48 * 1024 && ctx->raise_lds((const void *)kw, (int)ldsw)) return SNOWTRI_ERR_HIP;
                             const int64_t wpasses = (Fs * Pout * (int64_t)J + 15) / 16;   // 16 items per wave pass
-                            const int gridw = (int)std::max<int64_t>(1, std::min<int64_t>((wpasses + 4 * ctx->cluster_ppw - 1) / (4 * ctx->cluster_ppw),
+                            const int ppw_wide = ctx->cluster_ppw > 0 ? ctx->cluster_ppw : 8;   // (many short-lived workgroups here: 6 -> 886, 24 -> 906, 400 -> 1042 us per 4 000 frames of 16 x 8)
+                            const int gridw = (int)std::max<int64_t>(1, std::min<int64_t>((wpasses + 4 * ppw_wide - 1) / (4 * ppw_wide),
                                                                                          (int64_t)ctx->num_cus * 64));
                             hipLaunchKernelGGL(kw, dim3(gridw), dim3(kBlock), ldsw, st, desc, hand_counters, cap, ctx->rig(), kp_seg, prm, Pmax, J,
                                                jmagic, Pout, (float *)xyz_seg);

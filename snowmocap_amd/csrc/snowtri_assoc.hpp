@@ -26,9 +26,12 @@ namespace snowtri {
 constexpr int kSumsHeadBytes = 64;
 // workgroup shapes (threads, waves per SIMD the registers must allow, records of the coming chunk a thread holds in
 // registers): 256 threads x 3 workgroups per CU for the small rigs, 512 x 2 or 1024 x 1 for the large ones
+#ifndef SNOWTRI_SUMS_WAVES256
+#define SNOWTRI_SUMS_WAVES256 3   // (4 waves per SIMD = 128 registers: the 2 x 4 tile spills, 8 x 4 measured 1027 us against 729)
+#endif
 template <int THREADS>
 struct SumsShape {
-    static constexpr int kWavesPerSimd = THREADS == 256 ? 3 : 4;
+    static constexpr int kWavesPerSimd = THREADS == 256 ? SNOWTRI_SUMS_WAVES256 : 4;
     static constexpr int kPrefetch = THREADS == 256 ? 3 : 2;
 };
 #ifndef SNOWTRI_SUMS_GA
