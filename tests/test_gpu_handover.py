@@ -461,3 +461,41 @@ def test_frames_whose_member_lists_do_not_fit_the_staging_stay_in_phase3(api, mo
     out = _run(api, K, R, t, prm, kp, npers, 4, monkeypatch)
     _check(out, ref, 4, J, "one cluster of 7 168 members")
     assert out["handed"] == (0, 0), out["handed"]
+
+
+@pytest.mark.parametrize("C,P,J,knobs", [
+    (16, 8, 133, {"SNOWTRI_SUMS_THREADS": "512"}),                                   # 960 tiles on 8 waves: two rounds through csum per chunk
+    (16, 8, 133, {"SNOWTRI_SUMS_THREADS": "256", "SNOWTRI_SUMS_LDS_KB": "64"}),      # four rounds, three joints per buffer
+    (8, 4, 133, {"SNOWTRI_SUMS_LDS_KB": "24"}),                                      # one wave of tiles, four joint sub-ranges, 8-joint chunks
+    (8, 4, 40, {"SNOWTRI_SUMS_THREADS": "1024", "SNOWTRI_SUMS_LDS_KB": "160"}),      # the whole frame in one chunk: no second buffer used
+    (6, 3, 33, {"SNOWTRI_SUMS_THREADS": "512"}),                                     # odd person count: one candidate per lane
+    (8, 4, 133, {"SNOWTRI_CLUSTER_SPLIT": "0", "SNOWTRI_CLUSTER_PASSES_PER_WAVE": "3"}),   # member lists inside k_cluster_fuse, short-lived workgroups
+])
+def test_candidate_sums_launch_shapes_against_oracle(api, C, P, J, knobs, monkeypatch):
+    """k_candidate_sums picks its workgroup shape from the rig (256 threads x 3 per CU ... 1024 x 1), keeps a tile's sums in
+    registers when one pass of the workgroup covers the tiles and walks them in rounds otherwise, and pipelines the joint
+    chunks through two LDS buffers.  The development knobs force the shapes the BASELINE rigs do not take by themselves:
+    every one of them against the oracle and against the default shape (same decisions, sums within the fast arithmetic)."""
+    from snowmocap_amd import synth
+    from oracle import oracle as orc
+    rng = np.random.default_rng(4200 + 10 * C + P + J)
+    F = 5 if C == 16 else 30
+    K, R, t = synth.ring_rig(C, radius=5.0)
+    X = synth.make_people(rng, F, P, J=J)
+    kp, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=0.7, score_range=(3.5, 9.0), permute_persons=True, dtype=np.float32)
+    npers = npers.copy()
+    npers[1, C - 1] = P - 1            # a ragged frame between full ones (one candidate per lane, every slot defined)
+    npers[F - 1, 0] = max(P - 2, 0)
+    prm = dict(PRM, keypoint_num=J, condense_person_num_tol=10 if C == 16 else 2)
+    ref = orc.triangulate_condense_batch(K, R, t, kp, npers, orc.make_params(**prm), 64)
+    pout = P + 2
+    base = _run(api, K, R, t, prm, kp, npers, pout, monkeypatch)
+    for k, v in knobs.items():
+        monkeypatch.setenv(k, v)
+    out = _run(api, K, R, t, prm, kp, npers, pout, monkeypatch)
+    for k in knobs:
+        monkeypatch.delenv(k)
+    msg = f"C={C} P={P} J={J} {knobs}"
+    _check(out, ref, pout, J, msg)
+    _same(out, base, msg)
+    assert sum(out["handed"]) == sum(base["handed"]) == int(np.minimum(ref["count"], pout).sum()), (out["handed"], base["handed"])
