@@ -229,7 +229,13 @@ int snowtri_last_kernel_ms(snowtri_ctx *ctx, float kernel_ms[2]);
  * writes up to `cap` durations (ms, oldest first) of the calls recorded since the last collect, returns how
  * many (blocks until they have finished; -1 on error). */
 int snowtri_timing_collect(snowtri_ctx *ctx, float *kernel_ms, int32_t cap);
-/* Toggle per-call event timing (off by default: it adds two event records per launch). */
+/* Toggle per-call event timing (off by default: it adds two event records per launch).  enabled = 1: the ring's pair
+ * BRACKETS the call (an event record before its first and after its last kernel: the interval includes the command
+ * processor's hand-over from the begin event to the dispatch and from the kernel's end to the end event, ~1 us).
+ * enabled = 2: when the call is ONE kernel (the single-detection fast kernels) the pair is ATTACHED to that dispatch
+ * (hipExtLaunchKernelGGL's start / stop events): the kernel's own begin and end, the duration a rocprofv3 kernel
+ * trace reports, and no event record -- a barrier packet -- sits between consecutive launches, so a timing loop stays
+ * back to back (snowtri_last_kernel_ms is not available for such a call); calls of several kernels are bracketed as with 1. */
 int snowtri_set_timing(snowtri_ctx *ctx, int enabled);
 /* Frames of the last SNOWTRI_HOST fused call that were resolved by the general routine instead of
  * the single-cluster fast path (-1 after a SNOWTRI_DEVICE call: count the frames whose out_flags

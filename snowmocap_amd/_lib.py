@@ -223,8 +223,9 @@ class Context:
                                                 None), "snowtri_undistort_keypoints")
         return out
 
-    def set_timing(self, enabled=True):
-        check(lib().snowtri_set_timing(self.handle, int(bool(enabled))), "snowtri_set_timing")
+    def set_timing(self, enabled=True, attach=False):
+        """attach: single-kernel calls carry the event pair on their dispatch (the kernel's own begin / end) instead of being bracketed."""
+        check(lib().snowtri_set_timing(self.handle, (2 if attach else 1) if enabled else 0), "snowtri_set_timing")
 
     def last_kernel_ms(self):
         arr = (ct.c_float * 2)()

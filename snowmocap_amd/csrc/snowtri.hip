@@ -5,6 +5,7 @@
 #include "../../include/snowtri.h"
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 
 #include <algorithm>
 #include <cmath>
@@ -161,6 +162,8 @@ struct snowtri_ctx {
     Scratch sums;                             // candidate sums of k_candidate_sums [frames][Kc] + the frames k_associate left behind
     // measurement
     bool timing = false;
+    bool timing_attach = false;   // snowtri_set_timing(ctx, 2): single-kernel launches carry their ring events themselves
+    bool ev_attached = false;     // the last launcher did (fused_dispatch then records no end event of its own)
     hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
     bool ev_valid = false;
     hipStream_t ev_stream = nullptr;
@@ -376,6 +379,7 @@ int snowtri_ctx_synchronize(snowtri_ctx *ctx) {
 int snowtri_set_timing(snowtri_ctx *ctx, int enabled) {
     if (!ctx) return SNOWTRI_ERR_BAD_ARG;
     ctx->timing = enabled != 0;
+    ctx->timing_attach = enabled == 2;
     ctx->ev_valid = false;
     ctx->ev_count = 0;
     if (ctx->timing && ctx->ev_ring.empty()) {
@@ -1314,13 +1318,26 @@ int launch_fused_lean(snowtri_ctx *ctx, hipStream_t st, int64_t F, const TIn *d_
         if (rc) return rc;
         if (lds > 48 * 1024 && ctx->raise_lds((const void *)kc, (int)lds)) return SNOWTRI_ERR_HIP;
         if (ctx->debug) fprintf(stderr, "k_fused_lean_coop: F %lld grid %d frames per tile %d (+1 for %lld) lds %zu\n", (long long)F, grid, base, (long long)rem, lds);
-        hipLaunchKernelGGL(kc, dim3(grid), dim3(kBlock), lds, st, F, base, rem, nf_max, ctx->rig(), d_kpts, d_np, prm, d_xyzs, d_ps, d_cnt, d_fl,
-                           (char *)ctx->work.p, per_block);
+        if (ctx->timing && ctx->timing_attach) {
+            // the ring's event pair rides on the dispatch itself: begin and end of THIS kernel as its completion signal records
+            // them (what rocprofv3's kernel trace reads), without the two barrier packets of a bracketing pair in the interval
+            const int64_t slot = ctx->ev_count % kTimingRing;
+            hipExtLaunchKernelGGL(kc, dim3(grid), dim3(kBlock), lds, st, ctx->ev_ring[2 * slot], ctx->ev_ring[2 * slot + 1], 0,
+                                  F, base, rem, nf_max, ctx->rig(), d_kpts, d_np, prm, d_xyzs, d_ps, d_cnt, d_fl, (char *)ctx->work.p, per_block);
+            ctx->ev_attached = true;
+        } else {
+            hipLaunchKernelGGL(kc, dim3(grid), dim3(kBlock), lds, st, F, base, rem, nf_max, ctx->rig(), d_kpts, d_np, prm, d_xyzs, d_ps, d_cnt, d_fl,
+                               (char *)ctx->work.p, per_block);
+        }
         HIP_TRY(hipGetLastError());
         static const std::string cname = std::string("k_fused_lean_coop<") + std::to_string(C) + "," + type_name<TIn>() + "," +
                                          std::to_string(kLeanJ) + ">";
         ctx->last_kernels = cname.c_str();
         return SNOWTRI_OK;
+    }
+    if (ctx->timing && ctx->timing_attach && F > seg_max) {   // several kernels: bracketed (fused_dispatch records the end)
+        HIP_TRY(hipEventRecord(ctx->ev[0], st));
+        HIP_TRY(hipEventRecord(ctx->ev_ring[2 * (ctx->ev_count % kTimingRing)], st));
     }
     for (int64_t s0 = 0; s0 < F; s0 += seg_max) {
         const int64_t Fs = std::min<int64_t>(seg_max, F - s0);
@@ -1352,10 +1369,18 @@ int launch_fused_lean(snowtri_ctx *ctx, hipStream_t st, int64_t F, const TIn *d_
             fprintf(stderr, "k_fused_lean: F %lld grid %d tiles %lld (%d frames +1 for %lld) lds %zu occupancy/CU %d\n",
                     (long long)Fs, grid, (long long)ntiles, base, (long long)rem, lds, occ);
         }
-        hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, st, Fs, ntiles, base, rem, slow_words, ctx->rig(),
-                           d_kpts + s0 * (int64_t)(C * kLeanJ * 3), d_np ? d_np + s0 * C : nullptr, prm,
-                           d_xyzs + s0 * (int64_t)(kLeanJ * 4), d_ps ? d_ps + s0 : nullptr, d_cnt + s0,
-                           d_fl ? d_fl + s0 : nullptr, (char *)ctx->work.p, per_block);
+        if (ctx->timing && ctx->timing_attach && Fs == F) {   // one segment = one kernel: its own begin / end (see k_fused_lean_coop above)
+            const int64_t slot = ctx->ev_count % kTimingRing;
+            hipExtLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, st, ctx->ev_ring[2 * slot], ctx->ev_ring[2 * slot + 1], 0,
+                                  Fs, ntiles, base, rem, slow_words, ctx->rig(), d_kpts, d_np, prm, d_xyzs, d_ps, d_cnt, d_fl,
+                                  (char *)ctx->work.p, per_block);
+            ctx->ev_attached = true;
+        } else {
+            hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, st, Fs, ntiles, base, rem, slow_words, ctx->rig(),
+                               d_kpts + s0 * (int64_t)(C * kLeanJ * 3), d_np ? d_np + s0 * C : nullptr, prm,
+                               d_xyzs + s0 * (int64_t)(kLeanJ * 4), d_ps ? d_ps + s0 : nullptr, d_cnt + s0,
+                               d_fl ? d_fl + s0 : nullptr, (char *)ctx->work.p, per_block);
+        }
         HIP_TRY(hipGetLastError());
     }
     static const std::string name = std::string("k_fused_lean<") + std::to_string(C) + "," + type_name<TIn>() + "," +
@@ -1663,7 +1688,14 @@ int fused_dispatch(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax, int J,
     const bool fast = Pmax == 1 && C >= 3 && C <= 8 && prm.kn >= 1 && prm.avg_thr <= 0.0 && prm.kthr >= 0.0 &&
                       !((double)ctx->npairs < prm.num_tol) && ctx->general_mode == 0;
     const int64_t ring_slot = ctx->ev_count % kTimingRing;
-    if (ctx->timing) {
+    ctx->ev_attached = false;
+    const bool lean = method != SNOWTRI_DLT && fast && std::is_same<TOut, float>::value && J == kLeanJ && prm.kn == kLeanJ && Pout == 1 &&
+                      ctx->lean_mode != 0;
+    // attached timing of a fast-kernel call: NO event record around the dispatch (a record is a barrier packet: the launches of a
+    // timing loop would no longer be back to back); launch_fused_lean attaches the ring's pair to the kernel, or brackets a
+    // call of several segments itself
+    const bool attach = ctx->timing && ctx->timing_attach && lean;
+    if (ctx->timing && !attach) {
         HIP_TRY(hipEventRecord(ctx->ev[0], st));
         HIP_TRY(hipEventRecord(ctx->ev_ring[2 * ring_slot], st));
     }
@@ -1695,8 +1727,7 @@ int fused_dispatch(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax, int J,
 #undef SNOWTRI_CASE
             default: rc = SNOWTRI_ERR_BAD_ARG;
         }
-    } else if (fast && std::is_same<TOut, float>::value && J == kLeanJ && prm.kn == kLeanJ && Pout == 1 &&
-               ctx->lean_mode != 0) {
+    } else if (lean) {
         switch (C) {
 #define SNOWTRI_CASE(CC)                                                                                          \
     case CC:                                                                                                      \
@@ -1737,7 +1768,10 @@ int fused_dispatch(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax, int J,
         rc = launch_frame_general<TIn, TOut>(ctx, st, F, Pmax, J, d_kpts, d_np, prm, Pout, d_xyzs, d_ps, d_cnt, d_fl);
     }
     if (rc) return rc;
-    if (ctx->timing) {
+    if (ctx->timing && ctx->ev_attached) {
+        ctx->ev_count++;
+        ctx->ev_valid = false;   // (snowtri_last_kernel_ms has no pair of its own for this call)
+    } else if (ctx->timing) {
         HIP_TRY(hipEventRecord(ctx->ev_ring[2 * ring_slot + 1], st));
         ctx->ev_count++;
         HIP_TRY(hipEventRecord(ctx->ev[1], st));

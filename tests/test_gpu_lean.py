@@ -354,3 +354,38 @@ def test_small_launches_cooperative_kernel_equals_wave_autonomous_kernel(api, F,
     ref = orc.triangulate_condense_batch(K, R, t, kp[check], npers[check], orc.make_params(**wl["params"]), 1)
     sub = {k: a[k][check] for k in ("xyzs", "pscore", "count")}
     _check_frames(sub, ref, range(len(check)), msg=f"F={F}")
+
+
+@pytest.mark.parametrize("F", [2000, 40000])
+def test_event_timing_attached_and_bracketed(api, F):
+    """snowtri_set_timing(ctx, 1) brackets every fused call with an event pair; (ctx, 2) attaches the pair to the dispatch of a
+    single-kernel call (hipExtLaunchKernelGGL start / stop events: the kernel's own begin and end, no event record between the
+    launches).  Both rings return one positive duration per call, the attached one not longer than the bracketed one by
+    more than noise, and the outputs do not depend on the mode.  F = 2000: k_fused_lean_coop, 40000: k_fused_lean."""
+    import torch
+    from snowmocap_amd import synth
+    wl = synth.config_workload(2, F, seed=5)
+    K, R, t = wl["rig"]
+    bt = api.BatchTriangulator(K, R, t, wl["params"], pout_max=1, out_dtype=np.float32)
+    dev = torch.device("cuda", 0)
+    kp = torch.from_numpy(wl["kpts"].astype(np.float32)).to(dev)
+    outs = {}
+    means = {}
+    for mode, attach in (("bracketed", False), ("attached", True)):
+        out = bt.alloc_outputs(F, dev)
+        for _ in range(5):
+            bt.run_torch(kp, None, out=out)
+        bt.ctx.set_timing(True, attach=attach)
+        for _ in range(40):
+            bt.run_torch(kp, None, out=out)
+        ms = bt.ctx.timing_collect()
+        bt.ctx.set_timing(False)
+        torch.cuda.synchronize(dev)
+        assert len(ms) == 40 and all(0.0 < m < 50.0 for m in ms), (mode, ms)
+        means[mode] = float(np.mean(ms))
+        outs[mode] = {k: v.cpu().numpy() for k, v in out.items()}
+    print(f"F={F}: {bt.ctx.last_kernel_names()} bracketed {means['bracketed'] * 1e3:.2f} us, attached {means['attached'] * 1e3:.2f} us")
+    assert means["attached"] <= means["bracketed"] * 1.15
+    for k in outs["attached"]:
+        assert np.array_equal(outs["attached"][k], outs["bracketed"][k], equal_nan=True), k
+    bt.close()
