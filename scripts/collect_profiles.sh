@@ -6,9 +6,12 @@ cp $SRC/kernel_stats_stats.csv $DST/kernel_stats_cfg2_10k.csv
 cp $SRC/kernel_stats_stats_large.csv $DST/kernel_stats_large_2M.csv
 cp $SRC/kernel_stats_stats_next.csv $DST/kernel_stats_next_rows.csv
 cp $SRC/pmc_traffic.json profiles/pmc_traffic.json
+cp $SRC/event_check.json $DST/ 2>/dev/null
+if [ -d gpurun_out/pmc_multi ]; then   # (scripts/pmc_multi.sh was run too: the multi-person kernels)
 cp gpurun_out/pmc_multi/kernel_stats_cfg3.csv $DST/kernel_stats_multi_cfg3_8x4_10000.csv
 cp gpurun_out/pmc_multi/kernel_stats_cfg5.csv $DST/kernel_stats_multi_cfg5_16x8_12000.csv
 grep "^a\|^b\|^{" gpurun_out/pmc_multi_stdout.txt > $DST/multi_person_counters.txt
+fi
 cp $SRC/bench_default.json $SRC/bench_steps20.json $SRC/large_launches.json $DST/
 python - <<PY
 import csv, os

@@ -34,8 +34,11 @@ def headline(s):
          "%s joints/s (`python bench.py`), %s (`--steps 20 --warmup 5`, the driver's command); regions %.4f-%.4f ms per step"
          % (e(b["value"]), e(b20["value"]), b["ms_per_step_min"], b["ms_per_step_max"])),
         ("`roofline` (one stream, launches back to back): `%s`" % k10["kernel"],
-         "%.2f us per launch by rocprofv3 (%d launches), %.2f us by HIP events -> %.0f GB/s = **%.3f of 8 TB/s** (`roofline.frac` %.3f / %.3f in the two bench lines)"
-         % (k10["avg_us"], k10["calls"], b["kernel_us_mean"], 85.12e6 / (k10["avg_us"] * 1e-6) / 1e9, k10["hbm_frac"], b["roofline_frac"], b20["roofline_frac"])),
+         "%.2f us per launch by rocprofv3 (%d launches of the one-stream command) -> %.0f GB/s = **%.3f of 8 TB/s**; HIP events of `bench.py`: "
+         "%.2f us attached to the dispatch (`roofline.frac` %.3f / %.3f in the two bench lines), %.2f us launch to launch on one stream "
+         "(%.3f), %.2f us bracketed by event records (%.3f)"
+         % (k10["avg_us"], k10["calls"], 85.12e6 / (k10["avg_us"] * 1e-6) / 1e9, k10["hbm_frac"], b["kernel_us_mean"], b["roofline_frac"],
+            b20["roofline_frac"], b["kernel_us_step_one_stream"], b["frac_step_one_stream"], b["kernel_us_bracketed"], b["frac_bracketed"])),
         ("`roofline_region` (two streams, consecutive launches overlap)", "%.3f / %.3f of 8 TB/s" % (b["roofline_region_frac"], b20["roofline_region_frac"])),
         ("one 2 000 000-frame launch (SURVEY 8d's roofline run): `%s`" % k2m["kernel"],
          "%.2f ms (rocprofv3, %d launches: %.2f-%.2f) -> %s joints/s, **%.3f of 8 TB/s**; `large_batch.frac` %.3f"

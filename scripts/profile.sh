@@ -44,6 +44,8 @@ PY
 cp $OUT/pmc_traffic.json $ROOT/profiles/pmc_traffic.json
 python bench.py 2>/dev/null | tail -1 > $OUT/bench_default.json
 python bench.py --gpus 1 --steps 20 --warmup 5 2>/dev/null | tail -1 > $OUT/bench_steps20.json
+# events against the trace of the same launches (one-stream command under the profiler, then without it)
+bash scripts/gpu_event_check.sh > $OUT/event_check.log 2>&1; cp gpurun_out/evcheck/event_check.json $OUT/event_check.json
 # keep the merge small: drop raw traces, keep CSV summaries
 for d in stats stats_large stats_next; do cp $(find $OUT/$d -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_$d.csv 2>/dev/null; done
 find $OUT -name "*.db" -delete 2>/dev/null

@@ -550,6 +550,9 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean(
 // Items, check and mean are the SAME functions as in k_fused_lean: a frame's bits do not depend on which kernel ran it.
 // Grid = number of tiles (tile t = frames lean_tile_range(t, tile_base, tile_rem), nf <= nf_max <= kCoopMaxFrames).
 // Dynamic LDS: lean_coop_lds_bytes(C, JC, nf_max).
+#ifndef SNOWTRI_COOP_PRIO
+#define SNOWTRI_COOP_PRIO 0
+#endif
 constexpr int kCoopMaxFrames = 32;   // frames per workgroup tile (one bit word of slow frames)
 __host__ __device__ constexpr int lean_coop_items_pad(int JC, int nf_max) { return (nf_max * JC + 63) / 64 * 64; }
 __host__ __device__ constexpr size_t lean_coop_lds_bytes(int C, int JC, int nf_max) {
@@ -686,6 +689,15 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean_coop(
         float *sp = stash + i0 + lane;
         const uint32_t *tp = table + i0 + lane;
         for (int k = 0; k < npass; k += 3) {
+#if SNOWTRI_COOP_PRIO
+            // issue priority by progress: a SIMD serves its waves oldest first, so the wave of the CU's older workgroup ran its
+            // passes at nearly full speed and left the younger one to finish alone, with nothing to hide its LDS and
+            // dependency stalls behind; a wave that is ahead steps down, the two stay within three passes of each other
+            if (k < 3) __builtin_amdgcn_s_setprio(3);
+            else if (k < 6) __builtin_amdgcn_s_setprio(2);
+            else if (k < 9) __builtin_amdgcn_s_setprio(1);
+            else __builtin_amdgcn_s_setprio(0);
+#endif
             fetch(bufC, k + 2 < npass ? tp[128] : kNoItem);
             solve_store(bufA, out_off, sp);
             fetch(bufA, k + 3 < npass ? tp[192] : kNoItem);
