@@ -175,8 +175,11 @@ int snowtri_smooth_track(snowtri_ctx *ctx, int64_t T, int64_t n, const double *x
  *                               filtered and the first one takes xd = 0), end_state[2n] = that response's
  *                               final (y, yd) per lane;
  *   snowtri_smooth_shard_fix    y += response of the true entering state start_state[2n].
- * snowmocap_amd/sharded.py::combine_carries turns the gathered (end_state, first/last input row, length) of the
- * preceding shards into start_state.  snowtri_smooth_coeffs returns {a00,a01,a10,a11,cx,cxd} of the update
+ * Between the two, snowtri_smooth_shard_combine turns what the ranks all-gathered -- gathered[world][4n + 1] doubles,
+ * per shard in frame order: end_state[2n] | first input row [n] | last input row [n] | its length T_q -- into the
+ * start_state[2n] of shard `rank`, on the device and on `stream` (no host round trip between the all-gather and the
+ * fix; empty shards have T_q = 0).  snowmocap_amd/sharded.py::combine_carries is the same arithmetic on the host
+ * (the gloo tests); snowtri_smooth_coeffs returns {a00,a01,a10,a11,cx,cxd} of the update
  * s_t = A s_{t-1} + (0, cx x_t + cxd (x_t - x_{t-1})) it needs. */
 int snowtri_smooth_coeffs(double f, double z, double r, double dt, double out[6]);
 int snowtri_smooth_shard_local(snowtri_ctx *ctx, int64_t T, int64_t n, const double *x, int first, double f,
@@ -184,6 +187,8 @@ int snowtri_smooth_shard_local(snowtri_ctx *ctx, int64_t T, int64_t n, const dou
                                void *stream);
 int snowtri_smooth_shard_fix(snowtri_ctx *ctx, int64_t T, int64_t n, int first, const double *start_state, double f,
                              double z, double r, double dt, double *y, int memspace, void *stream);
+int snowtri_smooth_shard_combine(snowtri_ctx *ctx, int32_t world, int32_t rank, int64_t n, const double *gathered, double f,
+                                 double z, double r, double dt, double *start_state, int memspace, void *stream);
 
 /* N2  Blender IK control points (blender.py:98-143; names and order of configs/blender_armature_profile.json:
  * root_position, root_rotation, clavicle_r_ik, clavicle_l_ik, arm_r_ik, arm_r_pole, arm_l_ik, arm_l_pole,

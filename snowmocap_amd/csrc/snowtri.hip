@@ -1029,6 +1029,36 @@ int snowtri_smooth_shard_fix(snowtri_ctx *ctx, int64_t T, int64_t n, int first, 
     return SNOWTRI_OK;
 }
 
+int snowtri_smooth_shard_combine(snowtri_ctx *ctx, int32_t world, int32_t rank, int64_t n, const double *gathered, double f,
+                                 double z, double r, double dt, double *start_state, int memspace, void *stream) {
+    if (!smooth_args_ok(ctx, 0, n, f, dt, memspace) || world < 1 || rank < 0 || rank >= world) return SNOWTRI_ERR_BAD_ARG;
+    if (n == 0) return SNOWTRI_OK;
+    if (!gathered || !start_state) return SNOWTRI_ERR_BAD_ARG;
+    ENTER_DEVICE(ctx->device);
+    hipStream_t st = (hipStream_t)stream;
+    const SmoothCoef k = smooth_coef(f, z, r, dt);
+    const size_t gbytes = sizeof(double) * (size_t)world * (4 * (size_t)n + 1), sbytes = sizeof(double) * 2 * (size_t)n;
+    const double *dg = gathered;
+    double *ds = start_state;
+    if (memspace == SNOWTRI_HOST) {
+        int rc = ctx->in.ensure(gbytes);
+        if (rc) return rc;
+        rc = ctx->misc.ensure(sbytes);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(ctx->in.p, gathered, gbytes, hipMemcpyHostToDevice, st));
+        dg = (const double *)ctx->in.p;
+        ds = (double *)ctx->misc.p;
+    }
+    hipLaunchKernelGGL(k_smooth_combine, dim3((unsigned)((n + kSmoothBlock - 1) / kSmoothBlock)), dim3(kSmoothBlock), 0, st, (int)world,
+                       (int)rank, n, dg, k, ds);
+    HIP_TRY(hipGetLastError());
+    if (memspace == SNOWTRI_HOST) {
+        HIP_TRY(hipMemcpyAsync(start_state, ds, sbytes, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return SNOWTRI_OK;
+}
+
 int snowtri_smooth_track(snowtri_ctx *ctx, int64_t T, int64_t n, const double *x, double f, double z, double r,
                          double dt, double *y, int memspace, void *stream) {
     if (!smooth_args_ok(ctx, T, n, f, dt, memspace)) return SNOWTRI_ERR_BAD_ARG;

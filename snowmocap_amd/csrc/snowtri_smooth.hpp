@@ -218,4 +218,67 @@ __global__ __launch_bounds__(kSmoothBlock) void k_smooth_shard_end(int64_t T, in
     end_out[2 * lane + 1] = vyd + E[(c * n + lane) * 2 + 1];
 }
 
+// Sharded track (snowtri_smooth_shard_local / _fix): the true state entering shard `rank` from the gathered carries of the
+// shards before it -- one lane per thread, the shards walked in frame order.  gathered[q] = 4n + 1 doubles of shard q:
+// [end state (y, yd) per lane | first input row | last input row | length T_q].  Per preceding shard
+//     start_q = S_q + A^-1 (0, cxd (x_first_q - x_last_{q-1}))     (its first frame was filtered with xd = 0)
+//     S_{q+1} = A^m start_q + E_q,   m = T_q  (T_q - 1 for the shard that starts the track: its frame 0 passes through)
+// A^m by squaring (<= 63 steps, the same for every lane).  Empty shards (T_q = 0) are skipped; no shard before `rank`
+// holds a frame -> rank starts the track and start = (x_first, 0).  (Host twin: snowmocap_amd/sharded.py::combine_carries.)
+__global__ __launch_bounds__(kSmoothBlock) void k_smooth_combine(int world, int rank, int64_t n, const double *__restrict__ gathered,
+                                                                 SmoothCoef k, double *__restrict__ start_state) {
+    const int64_t i = (int64_t)blockIdx.x * kSmoothBlock + threadIdx.x;
+    if (i >= n) return;
+    const int64_t stride = 4 * n + 1;
+    const double det = k.a00 * k.a11 - k.a01 * k.a10;
+    const double iv0 = -k.a01 / det, iv1 = k.a00 / det;   // second column of A^-1
+    bool have = false;
+    double s0 = 0.0, s1 = 0.0, x_last_prev = 0.0, o0 = 0.0, o1 = 0.0;
+    for (int q = 0; q <= rank && q < world; q++) {
+        const double *g = gathered + (int64_t)q * stride;
+        const int64_t T = (int64_t)g[4 * n];
+        if (T <= 0) continue;
+        const double x_first = g[2 * n + i], x_last = g[3 * n + i];
+        double b0, b1;
+        int64_t m;
+        if (!have) {
+            s0 = x_first;
+            s1 = 0.0;
+            have = true;
+            b0 = s0;
+            b1 = s1;
+            m = T - 1;
+        } else {
+            const double delta = k.cxd * (x_first - x_last_prev);
+            b0 = s0 + delta * iv0;
+            b1 = s1 + delta * iv1;
+            m = T;
+        }
+        if (q == rank) {
+            o0 = b0;
+            o1 = b1;
+            break;
+        }
+        if (m > 0) {
+            double p00 = 1.0, p01 = 0.0, p10 = 0.0, p11 = 1.0;              // A^m
+            double q00 = k.a00, q01 = k.a01, q10 = k.a10, q11 = k.a11;      // A^(2^j)
+            for (int64_t e = m; e > 0; e >>= 1) {
+                if (e & 1) {
+                    const double t00 = p00 * q00 + p01 * q10, t01 = p00 * q01 + p01 * q11;
+                    const double t10 = p10 * q00 + p11 * q10, t11 = p10 * q01 + p11 * q11;
+                    p00 = t00; p01 = t01; p10 = t10; p11 = t11;
+                }
+                const double u00 = q00 * q00 + q01 * q10, u01 = q00 * q01 + q01 * q11;
+                const double u10 = q10 * q00 + q11 * q10, u11 = q10 * q01 + q11 * q11;
+                q00 = u00; q01 = u01; q10 = u10; q11 = u11;
+            }
+            s0 = p00 * b0 + p01 * b1 + g[2 * i];
+            s1 = p10 * b0 + p11 * b1 + g[2 * i + 1];
+        }
+        x_last_prev = x_last;
+    }
+    start_state[2 * i] = o0;
+    start_state[2 * i + 1] = o1;
+}
+
 }  // namespace snowtri

@@ -261,10 +261,12 @@ def smooth_track_sharded(x_local, f=2, z=0.75, r=0, delta_time=1 / 30, group=Non
     dist.all_gather_into_tensor(allp, payload, group=group)             # the one exchange: 4n+1 doubles per rank
     if T == 0:
         return y
-    host = allp.cpu().numpy()
-    payloads = [(host[q, :2 * n].reshape(n, 2), host[q, 2 * n:3 * n], host[q, 3 * n:4 * n], host[q, 4 * n]) for q in range(world)]
-    A, _cx, cxd = smooth_coeffs(f, z, r, delta_time)
-    start = torch.from_numpy(combine_carries(payloads, rank, A, cxd)).to(x_local.device)
+    # the entering state of this shard from the gathered carries, ON the device and the stream (k_smooth_combine: no host
+    # round trip between the all-gather and the fix; combine_carries below is its host twin)
+    start = torch.empty((n, 2), dtype=torch.float64, device=x_local.device)
+    _lib.check(L.snowtri_smooth_shard_combine(ctx.handle, world, rank, n, ct.c_void_p(allp.data_ptr()), float(f), float(z), float(r),
+                                              float(delta_time), ct.c_void_p(start.data_ptr()), _lib.DEVICE, stream),
+               "snowtri_smooth_shard_combine")
     is_first = rank == 0
     _lib.check(L.snowtri_smooth_shard_fix(ctx.handle, T, n, 1 if is_first else 0, ct.c_void_p(start.data_ptr()), float(f),
                                           float(z), float(r), float(delta_time), ct.c_void_p(y.data_ptr()),

@@ -92,6 +92,7 @@ int main(void) {
            SNOWTRI_ERR_BAD_ARG);
     EXPECT(snowtri_smooth_shard_fix(NULL, 4, 3, 1, buf, 2.0, 0.75, 0.0, 1.0 / 30, buf, SNOWTRI_HOST, NULL),
            SNOWTRI_ERR_BAD_ARG);
+    EXPECT(snowtri_smooth_shard_combine(NULL, 2, 0, 3, buf, 2.0, 0.75, 0.0, 1.0 / 30, buf, SNOWTRI_HOST, NULL), SNOWTRI_ERR_BAD_ARG);
     EXPECT(snowtri_blender_points(NULL, 1, 133, buf, SNOWTRI_F64, buf, bbuf, SNOWTRI_HOST, NULL), SNOWTRI_ERR_BAD_ARG);
     EXPECT(snowtri_blender_smooth(NULL, 2, 1, buf, bbuf, buf, 1.0 / 30, buf, SNOWTRI_HOST, NULL), SNOWTRI_ERR_BAD_ARG);
     EXPECT(snowtri_ctx_set_distortion(NULL, buf), SNOWTRI_ERR_BAD_ARG);

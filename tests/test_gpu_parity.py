@@ -1069,6 +1069,56 @@ def test_sharded_smoothing_kernels_with_carry_exchange(api):
     np.testing.assert_allclose(np.concatenate(ys), want, rtol=0, atol=1e-9)
 
 
+def test_sharded_smoothing_device_side_carry_combine(api):
+    """snowtri_smooth_shard_combine (k_smooth_combine: the entering state of a shard from the all-gathered carries, on the
+    device) == its host twin combine_carries for every rank of a 6-shard track with a one-frame first shard, a one-frame
+    middle shard and two empty trailing shards; and local -> combine -> fix with it == the sequential oracle."""
+    import ctypes as ct
+    from snowmocap_amd import _lib
+    from snowmocap_amd.sharded import combine_carries, smooth_coeffs
+    from oracle import oracle as orc
+    rng = np.random.default_rng(12)
+    n = 399
+    f, z, r, dt = 2.5, 0.75, 0.4, 1 / 30
+    x = np.cumsum(rng.normal(0, 0.01, size=(1500, n)), axis=0) + rng.uniform(-2, 2, size=(1, n))
+    want = orc.second_order_track(x, f, z, r, dt)
+    A, cx, cxd = smooth_coeffs(f, z, r, dt)
+    ctx = _lib.scratch_context()
+    L = _lib.lib()
+    cuts = [0, 1, 700, 701, 1500, 1500, 1500]
+    world = len(cuts) - 1
+    shards = [np.ascontiguousarray(x[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+    ys, payloads = [], []
+    gathered = np.zeros((world, 4 * n + 1))
+    first_nonempty = next(q for q, sh in enumerate(shards) if sh.shape[0] > 0)
+    for q, sh in enumerate(shards):
+        y = np.empty_like(sh)
+        E = np.zeros((n, 2))
+        if sh.shape[0] > 0:
+            _lib.check(L.snowtri_smooth_shard_local(ctx.handle, sh.shape[0], n, _lib.ptr(sh), 1 if q == first_nonempty else 0, f, z, r, dt,
+                                                    _lib.ptr(y), _lib.ptr(E), _lib.HOST, None), "local")
+            gathered[q, :2 * n] = E.reshape(-1)
+            gathered[q, 2 * n:3 * n] = sh[0]
+            gathered[q, 3 * n:4 * n] = sh[-1]
+        gathered[q, 4 * n] = sh.shape[0]
+        ys.append(y)
+        payloads.append((E, gathered[q, 2 * n:3 * n].copy(), gathered[q, 3 * n:4 * n].copy(), sh.shape[0]))
+    for q, sh in enumerate(shards):
+        start = np.full((n, 2), np.nan)
+        _lib.check(L.snowtri_smooth_shard_combine(ctx.handle, world, q, n, _lib.ptr(gathered), f, z, r, dt, _lib.ptr(start), _lib.HOST, None),
+                   "combine")
+        if sh.shape[0] == 0:
+            continue
+        host = combine_carries(payloads, q, A, cxd)
+        np.testing.assert_allclose(start, host, rtol=1e-12, atol=1e-12, err_msg=f"rank {q}")
+        _lib.check(L.snowtri_smooth_shard_fix(ctx.handle, sh.shape[0], n, 1 if q == first_nonempty else 0, _lib.ptr(start), f, z, r, dt,
+                                              _lib.ptr(ys[q]), _lib.HOST, None), "fix")
+    np.testing.assert_allclose(np.concatenate(ys), want, rtol=0, atol=1e-9)
+    # bad arguments
+    assert L.snowtri_smooth_shard_combine(ctx.handle, 3, 3, n, _lib.ptr(gathered), f, z, r, dt, _lib.ptr(start), _lib.HOST, None) == _lib.ERR_BAD_ARG
+    assert L.snowtri_smooth_shard_combine(ctx.handle, 0, 0, n, _lib.ptr(gathered), f, z, r, dt, _lib.ptr(start), _lib.HOST, None) == _lib.ERR_BAD_ARG
+
+
 def test_smooth_track_sharded_single_rank_group(api):
     """The torch.distributed plumbing of smooth_track_sharded (RCCL all-gather of the carries) in a 1-rank group."""
     import os
