@@ -372,6 +372,23 @@ def main():
     kernel_ms = float(np.mean(kms))
     kernel_ms_min = float(np.min(kms))
     kernel_ms_bracketed = float(np.mean(kms_bracketed))
+    # the achieved rate also against a device-copy bandwidth MEASURED on this box (1 GiB read + 1 GiB written per
+    # copy, best of 5 after a warm-up; bytes moved = 2 x the tensor)
+    copy_GBs = None
+    if not args.dry_run:
+        csrc = torch.empty(1 << 28, dtype=torch.float32, device=dev).normal_()
+        cdst = torch.empty_like(csrc)
+        cdst.copy_(csrc)
+        best = float("inf")
+        for _ in range(5):
+            c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            c0.record()
+            cdst.copy_(csrc)
+            c1.record()
+            torch.cuda.synchronize(dev)
+            best = min(best, c0.elapsed_time(c1))
+        copy_GBs = 2.0 * csrc.numel() * 4 / (best * 1e-3) / 1e9
+        del csrc, cdst
     bpf = algorithmic_bytes_per_frame(C, P, Pout)
     ach = bpf * F / (kernel_ms * 1e-3) / 1e9
     ach_region = bpf * F / (ms_per_step * 1e-3) / 1e9          # per GPU: every rank streams its own shard
@@ -510,6 +527,8 @@ def main():
                          "kernel_ms_mean": kernel_ms, "kernel_ms_min": kernel_ms_min, "launches": len(kms),
                          "kernel_ms_mean_bracketed": kernel_ms_bracketed,
                          "frac_bracketed": bpf * F / (kernel_ms_bracketed * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                         "measured_device_copy_GBs": copy_GBs,
+                         "frac_of_measured_copy": None if not copy_GBs else ach / copy_GBs,
                          "kernel_ms_step_one_stream": kernel_ms_step,
                          "frac_step_one_stream": bpf * F / (kernel_ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "kernel_ms_mean_per_rank": kernel_ms_ranks,

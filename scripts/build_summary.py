@@ -72,6 +72,7 @@ def bench_digest(line):
            "kernel_us_mean": d["roofline"]["kernel_ms_mean"] * 1e3, "kernel_us_min": d["roofline"]["kernel_ms_min"] * 1e3,
            "kernel_us_bracketed": d["roofline"].get("kernel_ms_mean_bracketed", 0.0) * 1e3,
            "kernel_us_step_one_stream": d["roofline"].get("kernel_ms_step_one_stream", 0.0) * 1e3,
+           "copy_GBs": d["roofline"].get("measured_device_copy_GBs"), "frac_of_copy": d["roofline"].get("frac_of_measured_copy"),
            "frac_bracketed": d["roofline"].get("frac_bracketed"), "frac_step_one_stream": d["roofline"].get("frac_step_one_stream"),
            "roofline_traffic": d["roofline"]["traffic"], "roofline_region_frac": d["roofline_region"]["frac"],
            "valu_per_64": (d.get("fp64_valu_issue") or {}).get("valu_insts_per_64_joints")}

@@ -39,6 +39,8 @@ def headline(s):
          "(%.3f), %.2f us bracketed by event records (%.3f)"
          % (k10["avg_us"], k10["calls"], 85.12e6 / (k10["avg_us"] * 1e-6) / 1e9, k10["hbm_frac"], b["kernel_us_mean"], b["roofline_frac"],
             b20["roofline_frac"], b["kernel_us_step_one_stream"], b["frac_step_one_stream"], b["kernel_us_bracketed"], b["frac_bracketed"])),
+        ("the same against the device-copy bandwidth measured on the box (1 GiB `copy_`, read + written bytes)",
+         "copy %.0f GB/s -> the 10 000-frame launch runs at %.3f of it" % (b.get("copy_GBs") or 0.0, b.get("frac_of_copy") or 0.0)),
         ("`roofline_region` (two streams, consecutive launches overlap)", "%.3f / %.3f of 8 TB/s" % (b["roofline_region_frac"], b20["roofline_region_frac"])),
         ("one 2 000 000-frame launch (SURVEY 8d's roofline run): `%s`" % k2m["kernel"],
          "%.2f ms (rocprofv3, %d launches: %.2f-%.2f) -> %s joints/s, **%.3f of 8 TB/s**; `large_batch.frac` %.3f"
