@@ -1457,7 +1457,7 @@ int launch_cluster_fuse(snowtri_ctx *ctx, hipStream_t st, int64_t Fs, int Pmax, 
     // start-up (8 x 4: 334 -> 312 us); a knob value > 0 asks for that many passes per wave when every frame fills its slots.
     // (k_cluster_members on a second stream beside this kernel: measured, no gain -- 1.34 ms either way.)
     const int ppw = ctx->cluster_ppw > 0 ? ctx->cluster_ppw : (1 << 30);
-    const int64_t W = std::max<int64_t>((passes_max + ppw - 1) / ppw, std::min<int64_t>(passes_max, (int64_t)ctx->num_cus * 8));
+    const int64_t W = std::max<int64_t>((passes_max + ppw - 1) / ppw, std::min<int64_t>(passes_max, (int64_t)ctx->num_cus * 4 * SNOWTRI_CLUSTER_WAVES));
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((W + kBlock / 64 - 1) / (kBlock / 64), (int64_t)ctx->num_cus * 64));
     const unsigned long long jmagic = (((unsigned long long)1 << 40) + (unsigned long long)J - 1) / (unsigned long long)J;
     hipLaunchKernelGGL((k_cluster_fuse<C, TIn>), dim3(grid), dim3(kBlock), cluster_lds_bytes(C), st, desc, words, cnt, cap, ctx->rig(),

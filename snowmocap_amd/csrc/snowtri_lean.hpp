@@ -693,10 +693,17 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean_coop(
             // issue priority by progress: a SIMD serves its waves oldest first, so the wave of the CU's older workgroup ran its
             // passes at nearly full speed and left the younger one to finish alone, with nothing to hide its LDS and
             // dependency stalls behind; a wave that is ahead steps down, the two stay within three passes of each other
+#if SNOWTRI_COOP_PRIO == 2   // the opposite: a wave near its end steps up (a launch finishes promptly when another one overlaps it)
+            if (k < 3) __builtin_amdgcn_s_setprio(0);
+            else if (k < 6) __builtin_amdgcn_s_setprio(1);
+            else if (k < 9) __builtin_amdgcn_s_setprio(2);
+            else __builtin_amdgcn_s_setprio(3);
+#else
             if (k < 3) __builtin_amdgcn_s_setprio(3);
             else if (k < 6) __builtin_amdgcn_s_setprio(2);
             else if (k < 9) __builtin_amdgcn_s_setprio(1);
             else __builtin_amdgcn_s_setprio(0);
+#endif
 #endif
             fetch(bufC, k + 2 < npass ? tp[128] : kNoItem);
             solve_store(bufA, out_off, sp);
