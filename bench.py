@@ -350,16 +350,21 @@ def main():
     # one profiles/'s average must agree with); (2) the pair BRACKETING the launch (a record before and after: adds the command
     # processor's hand-over on both sides, ~1 us), kept in the line as `kernel_ms_mean_bracketed`.
     n_timed = min(max(K_steps, 200), 1000)
+    import snowmocap_amd.batch as _batch
+    trace_index = {}     # [first, last) ordinal of each loop's launches among this process's fused calls (scripts/gpu_event_check.sh)
     def timed_launches(attach):
         bt.ctx.set_timing(True, attach=attach)
+        first = _batch.FUSED_CALLS
         for i in range(n_timed):
             bt.run_torch(pool[i % len(pool)], None, out=outs[i % len(pool)])
+        trace_index["attached" if attach else "bracketed"] = [first, _batch.FUSED_CALLS]
         k = bt.ctx.timing_collect()
         bt.ctx.set_timing(False)
         torch.cuda.synchronize(dev)
         return k
     kms_bracketed = timed_launches(False)
     kms = timed_launches(True)
+    trace_index["step"] = [_batch.FUSED_CALLS, _batch.FUSED_CALLS + n_timed]
     # (3) the same launches with NO event in between, one pair around the whole loop: the time from one launch's end to the
     # next one's end on one stream (kernel + the command processor's hand-over to the next dispatch), `kernel_ms_step_one_stream`
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -529,6 +534,7 @@ def main():
                          "frac_bracketed": bpf * F / (kernel_ms_bracketed * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "measured_device_copy_GBs": copy_GBs,
                          "frac_of_measured_copy": None if not copy_GBs else ach / copy_GBs,
+                         "trace_index": dict(trace_index, total_fused_calls=_batch.FUSED_CALLS),
                          "kernel_ms_step_one_stream": kernel_ms_step,
                          "frac_step_one_stream": bpf * F / (kernel_ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "kernel_ms_mean_per_rank": kernel_ms_ranks,

@@ -20,16 +20,19 @@ dur = [e - s for s, e in rows]
 gap = [rows[i + 1][0] - rows[i][1] for i in range(len(rows) - 1)]
 line = json.loads([l for l in open("$OUT/bench_under_rocprof.log") if l.startswith("{")][-1])
 plain = json.load(open("$OUT/bench_plain.json"))
-n = line["roofline"]["launches"]
 mean = lambda x: sum(x) / max(1, len(x))
-res = {"launches_in_trace": len(dur), "trace_mean_all_us": mean(dur) / 1e3,
-       "trace_mean_attached_loop_us": mean(dur[-n:]) / 1e3, "trace_mean_bracketed_loop_us": mean(dur[-2 * n:-n]) / 1e3,
-       "trace_gap_attached_loop_us": mean(gap[-n + 1:]) / 1e3, "trace_gap_bracketed_loop_us": mean(gap[-2 * n + 1:-n]) / 1e3,
+ti = line["roofline"]["trace_index"]     # [first, last) ordinal of each loop's launches among the process's fused calls = the trace's order
+res = {"launches_in_trace": len(dur), "fused_calls_counted_by_bench": ti["total_fused_calls"], "trace_mean_all_us": mean(dur) / 1e3}
+for name in ("bracketed", "attached", "step"):
+    a, b = ti[name]
+    res["trace_mean_%s_loop_us" % name] = mean(dur[a:b]) / 1e3
+    res["trace_gap_%s_loop_us" % name] = mean(gap[a:b - 1]) / 1e3
+res.update({
        "events_attached_under_rocprof_us": line["roofline"]["kernel_ms_mean"] * 1e3,
        "events_bracketed_under_rocprof_us": line["roofline"]["kernel_ms_mean_bracketed"] * 1e3,
        "events_attached_plain_us": plain["roofline"]["kernel_ms_mean"] * 1e3,
        "events_bracketed_plain_us": plain["roofline"]["kernel_ms_mean_bracketed"] * 1e3,
-       "ms_per_step_one_stream_plain_us": plain["ms_per_step"] * 1e3, "ms_per_step_one_stream_under_rocprof_us": line["ms_per_step"] * 1e3}
+       "ms_per_step_one_stream_plain_us": plain["ms_per_step"] * 1e3, "ms_per_step_one_stream_under_rocprof_us": line["ms_per_step"] * 1e3})
 json.dump(res, open("$OUT/event_check.json", "w"), indent=1)
 print(json.dumps(res, indent=1))
 PY

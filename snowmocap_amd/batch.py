@@ -10,6 +10,8 @@ import numpy as np
 
 from . import _lib
 
+FUSED_CALLS = 0   # fused device calls issued through run_torch by this process (bench.py: which launches of a kernel trace belong to which loop)
+
 
 class BatchTriangulator:
     def __init__(self, K, R, t, params, pout_max=1, out_dtype=np.float32, device=0, method=_lib.PAIRWISE, D=None):
@@ -90,6 +92,8 @@ class BatchTriangulator:
                 self.ctx.handle, F, Pmax, J, ct.c_void_p(kpts.data_ptr()), ct.c_void_p(self._ukpts.data_ptr()),
                 in_code, _lib.DEVICE, ct.c_void_p(stream)), "snowtri_undistort_keypoints")
             kpts = self._ukpts
+        global FUSED_CALLS
+        FUSED_CALLS += 1
         rc = _lib.lib().snowtri_triangulate_condense(
             self.ctx.handle, F, Pmax, J, ct.c_void_p(kpts.data_ptr()), in_code,
             ct.c_void_p(n_persons.data_ptr()) if n_persons is not None else None, self.params, self.method,

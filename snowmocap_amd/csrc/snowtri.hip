@@ -154,7 +154,7 @@ struct snowtri_ctx {
     void *dBlenderTab = nullptr;          // 24 SmoothCoef of the last (fzr, dt) given to snowtri_blender_smooth
     std::vector<double> blender_key;      // that (fzr[72], dt)
     std::vector<int32_t> hpairs;
-    double *dM = nullptr, *dt = nullptr, *dpairc = nullptr, *dP = nullptr;
+    double *dM = nullptr, *dt = nullptr, *dpairc = nullptr, *dP = nullptr, *deg = nullptr;
     int32_t *dpairs = nullptr;
     unsigned long long *d_counters = nullptr;  // [0] singular pairs, [1] slow frames, [2..] spare
     Scratch in, out, work, misc, aux, desc;   // desc: cluster descriptors handed from k_frame_recompute / k_associate to k_cluster_fuse
@@ -198,7 +198,7 @@ struct snowtri_ctx {
     const char *last_kernels = "";
     std::string names_buf;
     long long names_key = -1;
-    Rig rig() const { return Rig{dM, dt, dpairs, dpairc, dP, C, npairs}; }
+    Rig rig() const { return Rig{dM, dt, dpairs, dpairc, dP, deg, C, npairs}; }
 };
 
 extern "C" {
@@ -280,6 +280,13 @@ int snowtri_ctx_create(int32_t C, const double *K, const double *R, const double
             hpairc[6 * q + 3 + i] = tm[i] + ts[i];
         }
     }
+    std::vector<double> heg((size_t)std::max(1, ctx->npairs) * 6, 0.0);   // (M_c^T d)[j] = sum_row M_c[row][j] d[row]
+    for (int q = 0; q < ctx->npairs; q++)
+        for (int side = 0; side < 2; side++) {
+            const double *Mc = &ctx->hM[9 * ctx->hpairs[2 * q + side]];
+            for (int j = 0; j < 3; j++)
+                heg[6 * q + 3 * side + j] = Mc[j] * hpairc[6 * q] + Mc[3 + j] * hpairc[6 * q + 1] + Mc[6 + j] * hpairc[6 * q + 2];
+        }
     auto fail = [&](int rc) {
         snowtri_ctx_destroy(ctx);
         return rc;
@@ -317,6 +324,8 @@ int snowtri_ctx_create(int32_t C, const double *K, const double *R, const double
         CTX_TRY(hipMalloc(&ctx->dP, sizeof(double) * hP.size()));
         CTX_TRY(hipMemcpy(ctx->dP, hP.data(), sizeof(double) * hP.size(), hipMemcpyHostToDevice));
     }
+    CTX_TRY(hipMalloc(&ctx->deg, sizeof(double) * heg.size()));
+    CTX_TRY(hipMemcpy(ctx->deg, heg.data(), sizeof(double) * heg.size(), hipMemcpyHostToDevice));
     if (ctx->npairs > 0)
         CTX_TRY(hipMemcpy(ctx->dpairc, hpairc.data(), sizeof(double) * hpairc.size(), hipMemcpyHostToDevice));
     if (C > 0) {
@@ -340,6 +349,7 @@ int snowtri_ctx_destroy(snowtri_ctx *ctx) {
     if (ctx->dt) (void)hipFree(ctx->dt);
     if (ctx->dpairs) (void)hipFree(ctx->dpairs);
     if (ctx->dpairc) (void)hipFree(ctx->dpairc);
+    if (ctx->deg) (void)hipFree(ctx->deg);
     if (ctx->dP) (void)hipFree(ctx->dP);
     if (ctx->dLens) (void)hipFree(ctx->dLens);
     if (ctx->dBlenderTab) (void)hipFree(ctx->dBlenderTab);

@@ -36,7 +36,10 @@ constexpr int kLeanSlowShift = 4;        // slow-frame bit index = (tile ordinal
 
 __host__ __device__ constexpr int lean_items_pad(int JC) { return (kLeanTw * JC + 63) / 64 * 64; }   // item slots of a wave tile, whole passes
 __host__ __device__ constexpr int lean_table_entries(int JC) { return lean_items_pad(JC) + 256; }      // + the prefetch distance past the last pass
-__host__ __device__ constexpr int lean_const_doubles(int C) { return (12 * C + 4 * (C * (C - 1) / 2) + 1) & ~1; }  // M[C][9], t[C][3], d[NP][3], pairs[NP][2] (int32)
+#ifndef SNOWTRI_LEAN_EG
+#define SNOWTRI_LEAN_EG 0   // 1: e = h_m . d and g = h_s . d as linear forms of the pixel (two FMAs with Rig::eg from LDS instead of three with the ray)
+#endif
+__host__ __device__ constexpr int lean_const_doubles(int C) { return (12 * C + 4 * (C * (C - 1) / 2) + (SNOWTRI_LEAN_EG ? 6 * (C * (C - 1) / 2) : 0) + 1) & ~1; }  // M[C][9], t[C][3], d[NP][3], pairs[NP][2] (int32), eg[NP][6]
 
 __host__ __device__ constexpr size_t lean_lds_bytes(int C, int JC, int slow_words) {
     const size_t stash = (size_t)kLeanWaves * lean_items_pad(JC) * 4;        // fused joint scores (float32 as stored), per wave
@@ -126,10 +129,18 @@ __device__ __forceinline__ bool lean_item(const double *__restrict__ Mlds, const
     Vec3 h[C];
     double a[C], alpha[C], beta[C];
     unsigned long long okm[C];
+#if SNOWTRI_LEAN_EG
+    double ud[C], vd[C];
+    const double *Eg = Mlds + 12 * C + 4 * NPc;
+#endif
 #pragma unroll
     for (int c = 0; c < C; c++) {
         // A1, camera.py:241-243 with M = R inv(K)
         const double u = (double)cur[c].u, v = (double)cur[c].v;
+#if SNOWTRI_LEAN_EG
+        ud[c] = u;
+        vd[c] = v;
+#endif
         h[c].x = fma(Mp[9 * c + 0], u, fma(Mp[9 * c + 1], v, Mp[9 * c + 2]));
         h[c].y = fma(Mp[9 * c + 3], u, fma(Mp[9 * c + 4], v, Mp[9 * c + 5]));
         h[c].z = fma(Mp[9 * c + 6], u, fma(Mp[9 * c + 7], v, Mp[9 * c + 8]));
@@ -160,8 +171,13 @@ __device__ __forceinline__ bool lean_item(const double *__restrict__ Mlds, const
             const double dx = dS[3 * q], dy = dS[3 * q + 1], dz = dS[3 * q + 2];
             const double b = dot3(hm, hs);
             const double det = fma(a[mc], a[sc], -(b * b));
+#if SNOWTRI_LEAN_EG
+            const double e = fma(Eg[6 * q], ud[mc], fma(Eg[6 * q + 1], vd[mc], Eg[6 * q + 2]));
+            const double g = fma(Eg[6 * q + 3], ud[sc], fma(Eg[6 * q + 4], vd[sc], Eg[6 * q + 5]));
+#else
             const double e = fma(hm.z, dz, fma(hm.y, dy, hm.x * dx));
             const double g = fma(hs.z, dz, fma(hs.y, dy, hs.x * dx));
+#endif
             const double N0 = fma(a[sc], e, -(b * g));
             const double N1 = fma(a[mc], g, -(b * e));
             // n = h_m . (h_s x d)
@@ -322,6 +338,9 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean(
     const double cM = rig.M[tid < 9 * C ? tid : 0], cT = rig.t[tid < 3 * C ? tid : 0];
     const double cD = rig.pairc[tid < 3 * NP ? 6 * (tid / 3) + tid % 3 : 0];
     const int32_t cP = rig.pairs[tid < 2 * NP ? tid : 0];
+#if SNOWTRI_LEAN_EG
+    const double cE = rig.eg[tid < 6 * NP ? tid : 0];
+#endif
     double dS[3 * NP];  // per-pair d = t_s - t_m, wave-uniform -> scalar registers
 #pragma unroll
     for (int i = 0; i < 3 * NP; i++) dS[i] = rig.pairc[6 * (i / 3) + i % 3];
@@ -343,6 +362,9 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean(
     if (tid < 3 * NP) Mlds[12 * C + tid] = cD;
     int32_t *pairs_lds = reinterpret_cast<int32_t *>(Mlds + 12 * C + 3 * NP);
     if (tid < 2 * NP) pairs_lds[tid] = cP;
+#if SNOWTRI_LEAN_EG
+    if (tid < 6 * NP) Mlds[12 * C + 4 * NP + tid] = cE;
+#endif
 #pragma unroll
     for (int i = 0; i < 3 * NP; i++) dS[i] = uniform_f64(dS[i]);
     const float kthr_f32 = prm.kthr_f32;
@@ -623,6 +645,9 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean_coop(
     const double cM = rig.M[tid < 9 * C ? tid : 0], cT = rig.t[tid < 3 * C ? tid : 0];
     const double cD = rig.pairc[tid < 3 * NP ? 6 * (tid / 3) + tid % 3 : 0];
     const int32_t cP = rig.pairs[tid < 2 * NP ? tid : 0];
+#if SNOWTRI_LEAN_EG
+    const double cE = rig.eg[tid < 6 * NP ? tid : 0];
+#endif
     double dS[3 * NP];
 #pragma unroll
     for (int i = 0; i < 3 * NP; i++) dS[i] = rig.pairc[6 * (i / 3) + i % 3];
@@ -642,6 +667,9 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean_coop(
     if (tid < 3 * C) Mlds[9 * C + tid] = cT;
     if (tid < 3 * NP) Mlds[12 * C + tid] = cD;
     if (tid < 2 * NP) pairs_lds[tid] = cP;
+#if SNOWTRI_LEAN_EG
+    if (tid < 6 * NP) Mlds[12 * C + 4 * NP + tid] = cE;
+#endif
 #pragma unroll
     for (int i = 0; i < 3 * NP; i++) dS[i] = uniform_f64(dS[i]);
     const float kthr_f32 = prm.kthr_f32;
