@@ -608,6 +608,26 @@ def extra_workloads(torch, dev, device_index):
         bt.ctx.set_timing(False)
         cnt = out["count"].cpu().numpy()
         m = float(np.median(ms[1:]))
+        # throughput with two calls in flight (two contexts on two streams, as the headline `value` is issued): the
+        # latency-bound kernels of one call (k_associate, the member lists) run beside the VALU-bound ones of the other
+        bt2 = BatchTriangulator(K, R, t, wl["params"], pout_max=pout, out_dtype=np.float32, device=device_index)
+        out2 = bt2.alloc_outputs(F, dev)
+        streams2 = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
+        pairs2 = ((bt, out, streams2[0]), (bt2, out2, streams2[1]))
+        def two_stream_round(calls):
+            torch.cuda.synchronize(dev)
+            t0 = time.perf_counter()
+            for i in range(calls):
+                b, o, st = pairs2[i & 1]
+                b.run_torch(kp, npers, out=o, stream=st.cuda_stream)
+            torch.cuda.synchronize(dev)
+            return (time.perf_counter() - t0) / calls
+        two_stream_round(2)
+        ms2 = [two_stream_round(6) * 1e3 for _ in range(3)]
+        m2 = float(np.median(ms2))
+        same = bool((out2["count"] == out["count"]).all()) and bool(torch.equal(out2["xyzs"], out["xyzs"]))
+        bt2.close()
+        del out2
         kc = C * (C - 1) // 2 * P * P
         solves = F * kc * J / (m * 1e-3)
         persons = float(cnt.mean())
@@ -620,6 +640,10 @@ def extra_workloads(torch, dev, device_index):
         res.append({"workload": label, "kernel": kernels, "frames": F, "kernel_ms": m,
                     "persons_handed_to_cluster_kernels_last_segment": {"complete_graph": handed[0], "member_list": handed[1]},
                     "kernel_ms_all": ms[1:], "frames_per_s": F / (m * 1e-3),
+                    "two_streams": {"ms_per_call": m2, "ms_per_call_all": ms2, "frames_per_s": F / (m2 * 1e-3),
+                                    "frac": tflops * (m / m2) / FP64_VALU_PEAK_TFLOPS, "outputs_identical_on_both_contexts": same,
+                                    "how": "two contexts on two streams, six calls alternating, wall time between two "
+                                           "device synchronisations / calls (host launch time included)"},
                     "output_joints_per_s": float(cnt.clip(max=pout).sum()) * J / (m * 1e-3),
                     "pair_solves_per_s": solves, "mean_persons_per_frame": persons,
                     "roofline": {"bound": "fp64_valu", "achieved": tflops, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -81,7 +81,9 @@ def bench_digest(line):
                         "joints_per_s": d["large_batch"]["joints_per_s"]}
     if d.get("extra_workloads"):
         out["extra"] = [{"workload": e["workload"], "kernel": e["kernel"], "frames": e["frames"], "kernel_ms": e["kernel_ms"],
-                         "frames_per_s": e["frames_per_s"], "pair_solves_per_s": e["pair_solves_per_s"], "frac": e["roofline"]["frac"]}
+                         "frames_per_s": e["frames_per_s"], "pair_solves_per_s": e["pair_solves_per_s"], "frac": e["roofline"]["frac"],
+                         "two_streams_frames_per_s": (e.get("two_streams") or {}).get("frames_per_s"),
+                         "two_streams_frac": (e.get("two_streams") or {}).get("frac")}
                         for e in d["extra_workloads"]]
     if d.get("cpu_baseline"):
         c = d["cpu_baseline"]

@@ -51,11 +51,13 @@ def headline(s):
         ("VALU wave-instructions per 64 joints (`SQ_INSTS_VALU`, 2 000 000 frames)",
          "%.0f; VALU busy %.0f %% at %.2f GHz" % (s["valu_per_64_joints"], 100 * s["fast_kernel_2M_counters"]["valu_busy"], s["fast_kernel_2M_counters"]["clock_GHz"])),
         ("multi-person, 8 cameras x 4 persons, 10 000 frames (BASELINE configs[2])",
-         "%s frames/s, %s pair solves/s = %.3f of the fp64 vector peak (`extra_workloads[0]`); sum of the kernels under rocprofv3 %.3f ms"
-         % (e(b["extra"][0]["frames_per_s"]), e(b["extra"][0]["pair_solves_per_s"]), b["extra"][0]["frac"], m3["sum_of_kernels_ms_per_call"])),
+         "%s frames/s, %s pair solves/s = %.3f of the fp64 vector peak (`extra_workloads[0]`); two calls in flight on two streams: %s frames/s (%.3f); sum of the kernels under rocprofv3 %.3f ms"
+         % (e(b["extra"][0]["frames_per_s"]), e(b["extra"][0]["pair_solves_per_s"]), b["extra"][0]["frac"],
+            e(b["extra"][0].get("two_streams_frames_per_s") or 0.0), b["extra"][0].get("two_streams_frac") or 0.0, m3["sum_of_kernels_ms_per_call"])),
         ("multi-person, 16 x 8, 12 500 frames (one GPU's share of configs[4])",
-         "%s frames/s, %s pair solves/s = %.3f of the fp64 vector peak (`extra_workloads[1]`); 12 000 frames under rocprofv3: %.2f ms"
-         % (e(b["extra"][1]["frames_per_s"]), e(b["extra"][1]["pair_solves_per_s"]), b["extra"][1]["frac"], m5["sum_of_kernels_ms_per_call"])),
+         "%s frames/s, %s pair solves/s = %.3f of the fp64 vector peak (`extra_workloads[1]`); two calls in flight: %s frames/s (%.3f); 12 000 frames under rocprofv3: %.2f ms"
+         % (e(b["extra"][1]["frames_per_s"]), e(b["extra"][1]["pair_solves_per_s"]), b["extra"][1]["frac"],
+            e(b["extra"][1].get("two_streams_frames_per_s") or 0.0), b["extra"][1].get("two_streams_frac") or 0.0, m5["sum_of_kernels_ms_per_call"])),
         ("per-frame API (`main.py:50-71,106`, floor rig, 300 frames one by one)",
          "%.0f us per frame through the reference-named calls, %.0f us as one F = 1 fused host call (reference: %.1f ms per frame)"
          % (b["per_frame"]["api_sequence_us"], b["per_frame"]["fused_host_call_us"], b["per_frame"]["reference_ms"])),
