@@ -385,7 +385,7 @@ def test_event_timing_attached_and_bracketed(api, F):
         means[mode] = float(np.mean(ms))
         outs[mode] = {k: v.cpu().numpy() for k, v in out.items()}
     print(f"F={F}: {bt.ctx.last_kernel_names()} bracketed {means['bracketed'] * 1e3:.2f} us, attached {means['attached'] * 1e3:.2f} us")
-    assert means["attached"] <= means["bracketed"] * 1.15
+    assert means["attached"] <= means["bracketed"] * 1.5      # (typically 0.75-0.92; a loose bound: the test is about the plumbing)
     for k in outs["attached"]:
         assert np.array_equal(outs["attached"][k], outs["bracketed"][k], equal_nan=True), k
     bt.close()
