@@ -529,7 +529,7 @@ def main():
                                 "command processor's hand-over on both sides, and the kernels no longer run back to back); "
                                 "kernel_ms_step_one_stream = the same launches with no event in between, one pair around the loop / launches "
                                 "(kernel + hand-over to the next dispatch: what a rocprofv3 --stats average of a one-stream run lands on)",
-                         "kernel_ms_mean": kernel_ms, "kernel_ms_min": kernel_ms_min, "launches": len(kms),
+                         "kernel_ms_mean": kernel_ms, "kernel_ms_median": float(np.median(kms)), "kernel_ms_min": kernel_ms_min, "launches": len(kms),
                          "kernel_ms_mean_bracketed": kernel_ms_bracketed,
                          "frac_bracketed": bpf * F / (kernel_ms_bracketed * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "measured_device_copy_GBs": copy_GBs,
