@@ -159,21 +159,24 @@ def sharded_run_generic(compute_block, n_local, F_total, regions, chunks, device
 
 def gather_leg(dist, torch, dev, run_step, steps, warmup, chunks):
     """`warmup` + `steps` calls of run_step(i, chunks) -- the product's sharded entry: compute the rank's shard in
-    pieces, all-gather every piece -- between fences (synchronize + barrier); returns (seconds MAX over ranks, the last
-    gathered track)."""
-    def fence():
+    pieces, all-gather every piece -- between fences (synchronize + barrier); the clock is read between a rank's own
+    device synchronisation and the barrier (as in timed_region: the barrier's latency is not the path's); returns
+    (seconds MAX over ranks, the last gathered track)."""
+    def sync():
         if dev is not None:
             torch.cuda.synchronize(dev)
-        dist.barrier()
     full = None
     for i in range(warmup):
         full = run_step(i, chunks)
-    fence()
+    sync()
+    dist.barrier()
+    sync()
     t0 = time.perf_counter()
     for i in range(steps):
         full = run_step(warmup + i, chunks)
-    fence()
+    sync()
     dt = time.perf_counter() - t0
+    dist.barrier()
     tt = torch.tensor([dt], dtype=torch.float64, device=dev if dev is not None else "cpu")
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     return float(tt.item()), full
@@ -272,31 +275,34 @@ def main():
     can_gather = dist is not None and not args.no_gather
 
     def timed_region():
-        """W warm-up + K timed steps of the path itself (no collective: frames are independent); returns seconds (MAX
-        over ranks)."""
+        """W warm-up + K timed steps of the path itself (no collective: frames are independent); returns (seconds MAX over
+        ranks, this rank's seconds).  Both fences are barrier + synchronize, but the CLOCK is read between the device
+        synchronisation and the barrier: every rank times its own K steps (start: after the barrier that lines the ranks up
+        and a synchronize that drains it; stop: right after its own synchronize) and the MAX over ranks is taken afterwards,
+        so the latency of an N-rank RCCL barrier (tens of microseconds against a 0.4 ms region) is not booked to the path."""
         def step(i):
             b = i % len(pool)
             k = i % nstreams
             bts[k].run_torch(pool[b], None, out=outs[b], stream=streams[k].cuda_stream)
 
-        def fence():
-            torch.cuda.synchronize(dev)        # every stream of this device, side stream included
-            if dist is not None:
-                dist.barrier()
-
         for i in range(W_steps):
             step(i)
-        fence()
+        torch.cuda.synchronize(dev)            # every stream of this device, side stream included
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)        # (the barrier is itself device work on RCCL's stream)
         t0 = time.perf_counter()
         for i in range(K_steps):
             step(W_steps + i)
-        fence()
-        dt = time.perf_counter() - t0
+        torch.cuda.synchronize(dev)
+        dt_own = time.perf_counter() - t0
+        dt = dt_own
         if dist is not None:
-            tt = torch.tensor([dt], dtype=torch.float64, device=dev)
+            dist.barrier()
+            tt = torch.tensor([dt_own], dtype=torch.float64, device=dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)
             dt = float(tt.item())
-        return dt
+        return dt, dt_own
 
     # Device warm-up (untimed, the same steps): the chip leaves its idle power state over tens of milliseconds -- without it
     # the regions of one run get faster one after the other (0.0244 ... 0.0207 ms per step over the seven regions of a
@@ -310,8 +316,11 @@ def main():
         torch.cuda.synchronize(dev)
         n_w += 50
     # `value`: frames sharded across ranks, no data-path collective (frames are independent: SURVEY 8e).
-    regions = [timed_region() for _ in range(max(1, args.repeats))]
+    regions_both = [timed_region() for _ in range(max(1, args.repeats))]
+    regions = [r[0] for r in regions_both]
     elapsed = float(np.median(regions))
+    # this rank's own K-step time of the median region, gathered below into `ms_per_step_per_rank`
+    own_ms_per_step = sorted(regions_both)[len(regions_both) // 2][1] / K_steps * 1e3
     joints_per_step = F * Pout * J * world
     value = joints_per_step * K_steps / elapsed
     ms_per_step = elapsed / K_steps * 1e3
@@ -408,10 +417,13 @@ def main():
     kernel_name = bt.ctx.last_kernel_names()      # what the fused call really launched (snowtri_last_kernel_names)
     # every rank's kernel time (a slow rank would otherwise hide behind rank 0's)
     kernel_ms_ranks = [kernel_ms]
+    step_ms_ranks = [own_ms_per_step]
     if dist is not None:
-        kt = torch.zeros(world, dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(kt, torch.tensor([kernel_ms], dtype=torch.float64, device=dev))
-        kernel_ms_ranks = [float(x) for x in kt.cpu()]
+        kt = torch.zeros(2 * world, dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(kt, torch.tensor([kernel_ms, own_ms_per_step], dtype=torch.float64, device=dev))
+        kt = kt.cpu().view(world, 2)
+        kernel_ms_ranks = [float(x) for x in kt[:, 0]]
+        step_ms_ranks = [float(x) for x in kt[:, 1]]
 
     large = None
     if args.large_frames and rank == 0 and world == 1:
@@ -502,7 +514,7 @@ def main():
     if rank == 0:
         line = {
             "metric": "joint-triangulations/sec", "value": value, "unit": "joints/s", "n_gpus": world,
-            "steps": K_steps, "warmup": W_steps, "ms_per_step": ms_per_step, "higher_is_better": True,
+            "steps": K_steps, "warmup": W_steps, "ms_per_step": ms_per_step, "ms_per_step_per_rank": step_ms_ranks, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "rccl_ranks": dist.get_world_size() if dist is not None else 1,
             "ranks": ranks_seen,

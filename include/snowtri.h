@@ -178,7 +178,11 @@ int snowtri_smooth_track(snowtri_ctx *ctx, int64_t T, int64_t n, const double *x
  * Between the two, snowtri_smooth_shard_combine turns what the ranks all-gathered -- gathered[world][4n + 1] doubles,
  * per shard in frame order: end_state[2n] | first input row [n] | last input row [n] | its length T_q -- into the
  * start_state[2n] of shard `rank`, on the device and on `stream` (no host round trip between the all-gather and the
- * fix; empty shards have T_q = 0).  snowmocap_amd/sharded.py::combine_carries is the same arithmetic on the host
+ * fix; empty shards have T_q = 0).  CONTRACT on `first`: combine takes the first NON-EMPTY shard of `gathered` as the
+ * start of the track (seed (x_first, 0), its frame 0 passes through), so `first != 0` must be given to _local and _fix
+ * on exactly that shard -- which is rank 0 only when no leading shard is empty (true for contiguous blocks of
+ * ceil(F / world) frames, where only trailing blocks can be empty; a caller with another layout passes first on the
+ * rank that holds frame 0).  snowmocap_amd/sharded.py::combine_carries is the same arithmetic on the host
  * (the gloo tests); snowtri_smooth_coeffs returns {a00,a01,a10,a11,cx,cxd} of the update
  * s_t = A s_{t-1} + (0, cx x_t + cxd (x_t - x_{t-1})) it needs. */
 int snowtri_smooth_coeffs(double f, double z, double r, double dt, double out[6]);

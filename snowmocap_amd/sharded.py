@@ -60,7 +60,9 @@ def gather_track_chunked(compute_block, n_local, F_total, regions, chunks=4, gro
     unpacked into the full tensors there.  Buffers rotate over two slots; a slot is rewritten only after its gather
     has finished.  On CPU tensors (gloo tests) the same steps run in order without streams.
 
-    regions: {name: (shape_tail, torch dtype)} per frame.  Returns {name: tensor [F_total, *shape_tail]}.
+    regions: {name: (shape_tail, torch dtype)} per frame.  Returns {name: tensor [F_total, *shape_tail]} plus
+    "rank_status" ([world] int32: non-zero for a rank that claimed more frames than its contiguous block -- that rank
+    raises ValueError AFTER the last collective, so no rank is left waiting in one; on CPU tensors every rank raises).
     workspace: a dict the caller keeps between calls -- the gathered tensors, the two send / receive slots and the side
     stream are then allocated once and reused (steady state without allocations; the tensors returned by one call are
     overwritten by the next).
@@ -72,9 +74,14 @@ def gather_track_chunked(compute_block, n_local, F_total, regions, chunks=4, gro
     dev = torch.device(device) if device is not None else torch.device("cpu")
     if F_total <= 0:                                       # an empty track: nothing to compute, nothing to gather
         return {name: torch.empty((0,) + tuple(tail), dtype=dt, device=dev) for name, (tail, dt) in regions.items()}
-    if not 0 <= n_local <= per:
-        raise ValueError(f"gather_track_chunked: a rank holds {n_local} frames but contiguous blocks of "
-                         f"ceil({F_total} / {world}) = {per} frames are what is gathered (use shard_bounds)")
+    # A rank whose block does not fit (n_local > per) must not simply raise: the other ranks would enter the collectives
+    # below and wait for it forever.  It takes part with an EMPTY block and a status word of 1 in every piece it sends
+    # (the last 16 bytes of a piece's buffer), and raises after the last collective; the other ranks see the word in
+    # `rank_status` (CPU tensors: they raise too; CUDA tensors: returned, not read back -- no forced synchronisation).
+    bad_local = not 0 <= n_local <= per
+    n_claimed = n_local
+    if bad_local:
+        n_local = 0
     chunks = max(1, min(int(chunks), max(1, per)))
     cs = (per + chunks - 1) // chunks                      # frame slots per piece (same on every rank)
     on_gpu = dev.type == "cuda"
@@ -86,6 +93,8 @@ def gather_track_chunked(compute_block, n_local, F_total, regions, chunks=4, gro
             nbytes *= int(d)
         offs[name] = (total, nbytes)
         total = _align(total + nbytes)
+    status_off = total
+    total += 16
     key = (world, per, cs, total, str(dev), tuple((n, tuple(t), str(d)) for n, (t, d) in regions.items()))
     ws = workspace if workspace is not None else {}
     if ws.get("key") != key:
@@ -95,7 +104,9 @@ def gather_track_chunked(compute_block, n_local, F_total, regions, chunks=4, gro
         ws["send"] = [torch.zeros(total, dtype=torch.uint8, device=dev) for _ in range(2)]
         ws["recv"] = [torch.empty(world * total, dtype=torch.uint8, device=dev) for _ in range(2)]
         ws["side"] = torch.cuda.Stream(device=dev) if on_gpu else None
-    full, send, recv = ws["full"], ws["send"], ws["recv"]
+        ws["status"] = torch.zeros(world, dtype=torch.int32, device=dev)
+    full, send, recv, status = ws["full"], ws["send"], ws["recv"], ws["status"]
+    status.zero_()
 
     def views_of(flat):
         return {name: flat[o:o + nb].view(regions[name][1]).view((cs,) + tuple(regions[name][0]))
@@ -114,6 +125,8 @@ def gather_track_chunked(compute_block, n_local, F_total, regions, chunks=4, gro
             main.wait_event(gathered[slot])              # the gather that last read this slot is done
         if hi - lo < cs:
             send[slot].zero_()                           # short or empty piece: deterministic padding
+        if bad_local:                                    # (0 otherwise: the slots are allocated zeroed and no region covers the word)
+            send[slot][status_off:status_off + 4].view(torch.int32).fill_(1)
         if hi > lo:
             compute_block(lo, hi, views_of(send[slot]))
         width = min(cs, per - i * cs)                    # frame slots of this piece that exist in the block
@@ -121,6 +134,7 @@ def gather_track_chunked(compute_block, n_local, F_total, regions, chunks=4, gro
         def gather_and_unpack():
             dist.all_gather_into_tensor(recv[slot], send[slot], group=group)
             got = recv[slot].view(world, total)
+            torch.maximum(status, got[:, status_off:status_off + 4].view(torch.int32).view(world), out=status)
             for name, (o, nb) in offs.items():
                 tail, dt = regions[name]
                 src = got[:, o:o + nb].view(dt).view((world, cs) + tuple(tail))
@@ -139,7 +153,19 @@ def gather_track_chunked(compute_block, n_local, F_total, regions, chunks=4, gro
             gather_and_unpack()
     if on_gpu:
         main.wait_stream(side)                           # results are ready for whatever the caller queues next
-    return {name: t[:F_total] for name, t in full.items()}
+    refusal = (f"gather_track_chunked: a rank holds {n_claimed} frames but contiguous blocks of "
+               f"ceil({F_total} / {world}) = {per} frames are what is gathered (use shard_bounds)")
+    if bad_local:
+        for sl in send:                                  # (a caller-kept workspace may be used again)
+            sl[status_off:status_off + 4].zero_()
+        raise ValueError(refusal)
+    if not on_gpu and bool(status.any()):
+        bad = [q for q in range(world) if int(status[q])]
+        raise ValueError(f"gather_track_chunked: rank(s) {bad} hold more frames than their contiguous block of "
+                         f"ceil({F_total} / {world}) = {per} (use shard_bounds); their blocks were gathered as zeros")
+    out = {name: t[:F_total] for name, t in full.items()}
+    out["rank_status"] = status                          # [world] int32, 0 = that rank's block is valid
+    return out
 
 
 class ShardedTriangulator:
@@ -230,45 +256,84 @@ def combine_carries(payloads, rank, A, cxd):
     return np.zeros((n, 2)) if S is None else np.ascontiguousarray(S)
 
 
-def smooth_track_sharded(x_local, f=2, z=0.75, r=0, delta_time=1 / 30, group=None, ctx=None):
+def smooth_exchange(x_local, local_fn, combine_fn, fix_fn, group=None, first=None):
+    """The sharded smoothing protocol around three callables (the product binds them to the C ABI on the shard's GPU,
+    `smooth_track_sharded`; the gloo tests bind NumPy stand-ins to drive exactly this exchange over 8 CPU ranks):
+
+        local_fn(x_local, first, y, payload)  zero-state response of the block into y, its end state into payload[:2n]
+        combine_fn(allp, rank, start)         entering state of `rank` from the gathered payloads [world, 4n + 1]
+        fix_fn(y, first, start)               y += response of the entering state
+
+    payload of a rank = (end state [n, 2], first input row [n], last input row [n], block length).  ONE all-gather.
+    `first`: does this block start the track (frame 0 passes through and seeds the filters)?  Default: rank 0 -- the
+    layout of shard_bounds, where only TRAILING blocks can be empty.  snowtri_smooth_shard_combine treats the first
+    NON-EMPTY payload as the start of the track, so a caller with an empty leading block must pass first=True on the
+    rank that holds the first frames (include/snowtri.h states the same contract)."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    T = int(x_local.shape[0])
+    n = 1
+    for d in x_local.shape[1:]:
+        n *= int(d)
+    if first is None:
+        first = rank == 0
+    y = torch.empty_like(x_local)
+    payload = torch.zeros(4 * n + 1, dtype=torch.float64, device=x_local.device)
+    payload[4 * n] = T
+    if T > 0:
+        local_fn(x_local, bool(first), y, payload)
+        payload[2 * n:3 * n] = x_local[0].reshape(-1)
+        payload[3 * n:4 * n] = x_local[-1].reshape(-1)
+    flat = torch.empty(world * (4 * n + 1), dtype=torch.float64, device=x_local.device)
+    dist.all_gather_into_tensor(flat, payload, group=group)             # the one exchange: 4n+1 doubles per rank
+    allp = flat.view(world, 4 * n + 1)
+    if T == 0:
+        return y
+    start = torch.empty((n, 2), dtype=torch.float64, device=x_local.device)
+    combine_fn(allp, rank, start)
+    fix_fn(y, bool(first), start)
+    return y
+
+
+def smooth_track_sharded(x_local, f=2, z=0.75, r=0, delta_time=1 / 30, group=None, ctx=None, F_total=None):
     """x_local: this rank's frame block [T_r, ...] (CUDA float64 tensor, frame-major) of a track sharded in
-    frame order over the ranks of `group`.  Returns the filtered block; the full track is never gathered."""
+    frame order over the ranks of `group`.  Returns the filtered block; the full track is never gathered.
+    F_total (optional): the length of the whole track -- the block is then checked against shard_bounds and "this block
+    starts the track" is derived from it instead of assumed for rank 0."""
     import ctypes as ct
-    import numpy as np
     import torch
     import torch.distributed as dist
     from . import _lib
     assert x_local.is_cuda and x_local.dtype == torch.float64 and x_local.is_contiguous()
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    T = int(x_local.shape[0])
-    lanes = tuple(x_local.shape[1:])
-    n = int(np.prod(lanes)) if lanes else 1
+    first = None
+    if F_total is not None:
+        lo, hi, _ = shard_bounds(int(F_total), world, rank)
+        if hi - lo != int(x_local.shape[0]):
+            raise ValueError(f"smooth_track_sharded: rank {rank} holds {int(x_local.shape[0])} frames, shard_bounds gives it [{lo}, {hi})")
+        first = lo == 0 and hi > lo
+    n = 1
+    for d in x_local.shape[1:]:
+        n *= int(d)
     ctx = ctx or _lib.scratch_context(x_local.device.index)     # scratch and kernels on the GPU that holds the shard
     stream = ct.c_void_p(torch.cuda.current_stream(x_local.device).cuda_stream)
     L = _lib.lib()
-    y = torch.empty_like(x_local)
-    payload = torch.zeros(4 * n + 1, dtype=torch.float64, device=x_local.device)
-    payload[4 * n] = T
-    if T > 0:
-        first = 1 if rank == 0 else 0      # shard_bounds blocks: only trailing blocks can be empty
-        _lib.check(L.snowtri_smooth_shard_local(ctx.handle, T, n, ct.c_void_p(x_local.data_ptr()), first, float(f),
-                                                float(z), float(r), float(delta_time), ct.c_void_p(y.data_ptr()),
-                                                ct.c_void_p(payload.data_ptr()), _lib.DEVICE, stream),
+    fzrd = (float(f), float(z), float(r), float(delta_time))
+
+    def local_fn(x, is_first, y, payload):
+        _lib.check(L.snowtri_smooth_shard_local(ctx.handle, int(x.shape[0]), n, ct.c_void_p(x.data_ptr()), 1 if is_first else 0, *fzrd,
+                                                ct.c_void_p(y.data_ptr()), ct.c_void_p(payload.data_ptr()), _lib.DEVICE, stream),
                    "snowtri_smooth_shard_local")
-        payload[2 * n:3 * n] = x_local[0].reshape(-1)
-        payload[3 * n:4 * n] = x_local[-1].reshape(-1)
-    allp = torch.empty((world, 4 * n + 1), dtype=torch.float64, device=x_local.device)
-    dist.all_gather_into_tensor(allp, payload, group=group)             # the one exchange: 4n+1 doubles per rank
-    if T == 0:
-        return y
-    # the entering state of this shard from the gathered carries, ON the device and the stream (k_smooth_combine: no host
-    # round trip between the all-gather and the fix; combine_carries below is its host twin)
-    start = torch.empty((n, 2), dtype=torch.float64, device=x_local.device)
-    _lib.check(L.snowtri_smooth_shard_combine(ctx.handle, world, rank, n, ct.c_void_p(allp.data_ptr()), float(f), float(z), float(r),
-                                              float(delta_time), ct.c_void_p(start.data_ptr()), _lib.DEVICE, stream),
-               "snowtri_smooth_shard_combine")
-    is_first = rank == 0
-    _lib.check(L.snowtri_smooth_shard_fix(ctx.handle, T, n, 1 if is_first else 0, ct.c_void_p(start.data_ptr()), float(f),
-                                          float(z), float(r), float(delta_time), ct.c_void_p(y.data_ptr()),
-                                          _lib.DEVICE, stream), "snowtri_smooth_shard_fix")
-    return y
+
+    def combine_fn(allp, rk, start):
+        # the entering state of this shard from the gathered carries, ON the device and the stream (k_smooth_combine: no host
+        # round trip between the all-gather and the fix; combine_carries above is its host twin)
+        _lib.check(L.snowtri_smooth_shard_combine(ctx.handle, world, rk, n, ct.c_void_p(allp.data_ptr()), *fzrd,
+                                                  ct.c_void_p(start.data_ptr()), _lib.DEVICE, stream), "snowtri_smooth_shard_combine")
+
+    def fix_fn(y, is_first, start):
+        _lib.check(L.snowtri_smooth_shard_fix(ctx.handle, int(y.shape[0]), n, 1 if is_first else 0, ct.c_void_p(start.data_ptr()), *fzrd,
+                                              ct.c_void_p(y.data_ptr()), _lib.DEVICE, stream), "snowtri_smooth_shard_fix")
+
+    return smooth_exchange(x_local, local_fn, combine_fn, fix_fn, group=group, first=first)

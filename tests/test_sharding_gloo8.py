@@ -1,0 +1,212 @@
+"""The 8-rank shapes of BASELINE configs[3] / configs[4] on CPU: world_size-8 gloo groups through the PRODUCT's sharding
+code (snowmocap_amd/sharded.py) -- frame counts that do not divide by 8, empty trailing shards through the real
+gather, `chunks = auto` on the configs[3] shard (125 000 frames per rank), a rank with an oversized block (nobody may
+hang), the sharded smoothing exchange over 8 shards with an empty one, and bench.py's 8-rank dry run.  Stand-ins
+replace the kernels (this is about the partitioning, the packing and the collectives): no GPU is needed."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import ROOT
+from snowmocap_amd.sharded import auto_chunks, shard_bounds
+
+WORLD = 8
+
+
+def _init(rank, port):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["OMP_NUM_THREADS"] = "1"
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=WORLD)
+
+
+def _port(salt):
+    return 23000 + (os.getpid() * 7 + salt * 131) % 5000
+
+
+def _gather_worker(rank, port, F, chunks, tmp):
+    _init(rank, port)
+    from snowmocap_amd.sharded import gather_track_chunked
+    lo0, hi0, per = shard_bounds(F, WORLD, rank)
+    calls = []
+
+    def compute_block(lo, hi, views):      # stand-in for the kernels: every value names its GLOBAL frame and its rank
+        calls.append((lo, hi))
+        g = torch.arange(lo0 + lo, lo0 + hi)
+        views["xyzs"][: hi - lo] = g.to(torch.float32).view(-1, 1, 1, 1) + torch.tensor([0.0, 0.25, 0.5, 0.75]).view(1, 1, 1, 4)
+        views["pscore"][: hi - lo] = float(rank)
+        views["count"][: hi - lo] = (g % 5).to(torch.int32).view(-1)
+        views["flags"][: hi - lo] = 4
+
+    regions = {"xyzs": ((1, 3, 4), torch.float32), "pscore": ((1,), torch.float32), "count": ((), torch.int32), "flags": ((), torch.int32)}
+    ch = auto_chunks(per) if chunks == "auto" else chunks
+    out = gather_track_chunked(compute_block, hi0 - lo0, F, regions, chunks=ch)
+    ok = sum(b - a for a, b in calls) == hi0 - lo0 and all(b > a for a, b in calls)
+    g = torch.arange(F)
+    ok = ok and tuple(out["xyzs"].shape) == (F, 1, 3, 4)
+    ok = ok and torch.equal(out["xyzs"][:, 0, 0, :], g.to(torch.float32).view(-1, 1) + torch.tensor([0.0, 0.25, 0.5, 0.75]))
+    ok = ok and torch.equal(out["count"], (g % 5).to(torch.int32)) and bool((out["flags"] == 4).all())
+    ok = ok and torch.equal(out["pscore"][:, 0], (g // per).to(torch.float32)) and not bool(out["rank_status"].any())
+    np.save(os.path.join(tmp, f"ok{rank}.npy"), np.array([ok, hi0 - lo0, len(calls)]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("F,chunks", [(61, 3), (9, 2), (1, 4), (1000, "auto")])
+def test_eight_rank_chunked_gather_uneven_and_empty_trailing_shards(tmp_path, F, chunks):
+    """61 frames: blocks of 8, the last rank holds 5; 9 frames: blocks of 2, rank 4 holds one frame and ranks 5-7 NONE
+    (they still take part in every collective); 1 frame: only rank 0 has work.  Every rank ends up with the whole track."""
+    mp.spawn(_gather_worker, args=(_port(F), F, chunks, str(tmp_path)), nprocs=WORLD, join=True)
+    res = [np.load(tmp_path / f"ok{r}.npy") for r in range(WORLD)]
+    assert all(r[0] for r in res), res
+    assert [int(r[1]) for r in res] == [shard_bounds(F, WORLD, q)[1] - shard_bounds(F, WORLD, q)[0] for q in range(WORLD)]
+    assert sum(int(r[1]) for r in res) == F
+
+
+def _cfg3_worker(rank, port, tmp):
+    _init(rank, port)
+    from snowmocap_amd.sharded import gather_track_chunked
+    F = 1_000_000                                    # BASELINE configs[3]: 125 000 frames per rank
+    lo0, hi0, per = shard_bounds(F, WORLD, rank)
+    pieces = []
+
+    def compute_block(lo, hi, views):
+        pieces.append(hi - lo)
+        views["xyzs"][: hi - lo] = torch.arange(lo0 + lo, lo0 + hi, dtype=torch.float32).view(-1, 1)
+        views["count"][: hi - lo] = 1
+
+    regions = {"xyzs": ((1,), torch.float32), "count": ((), torch.int32)}
+    ch = auto_chunks(per)
+    out = gather_track_chunked(compute_block, hi0 - lo0, F, regions, chunks=ch)
+    ok = per == 125000 and ch == 3 and len(pieces) == 3 and sum(pieces) == per and min(pieces) >= 32768
+    ok = ok and torch.equal(out["xyzs"][:, 0], torch.arange(F, dtype=torch.float32)) and bool((out["count"] == 1).all())
+    np.save(os.path.join(tmp, f"ok{rank}.npy"), np.array([ok]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_eight_rank_configs3_shard_is_gathered_in_auto_pieces(tmp_path):
+    """`chunks = auto` on the shard one rank holds in configs[3] (1 000 000 frames over 8 GPUs): three pieces of >= 32 768
+    frames, three collectives, the million-frame track in order on every rank."""
+    mp.spawn(_cfg3_worker, args=(_port(3), str(tmp_path)), nprocs=WORLD, join=True)
+    assert all(np.load(tmp_path / f"ok{r}.npy").all() for r in range(WORLD))
+
+
+def _oversized_worker(rank, port, tmp):
+    _init(rank, port)
+    from snowmocap_amd.sharded import gather_track_chunked
+    regions = {"xyzs": ((2,), torch.float32)}
+    F = 40                                            # blocks of 5
+    n_local = 7 if rank == 3 else 5                   # ONLY rank 3 claims more than its block
+
+    def compute_block(lo, hi, views):
+        views["xyzs"][: hi - lo] = 1.0
+
+    try:
+        gather_track_chunked(compute_block, n_local, F, regions, chunks=2)
+        raised = ""
+    except ValueError as e:
+        raised = str(e)
+    # every rank is past the collectives (none hangs) and every rank raised: the offender names its own count, the others
+    # name the offender
+    good = ("holds 7 frames" in raised) if rank == 3 else ("rank(s) [3]" in raised)
+    np.save(os.path.join(tmp, f"ok{rank}.npy"), np.array([good]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_one_rank_with_an_oversized_block_fails_everywhere_without_a_hang(tmp_path):
+    """the block-size check used to raise on the offending rank BEFORE the collective, leaving the other ranks
+    waiting in it.  The offender now takes part with an empty block and a status word; every rank raises afterwards."""
+    mp.spawn(_oversized_worker, args=(_port(5), str(tmp_path)), nprocs=WORLD, join=True)
+    assert all(np.load(tmp_path / f"ok{r}.npy").all() for r in range(WORLD))
+
+
+# ---------------------------------------------------------------------------------- sharded smoothing, 8 shards
+def _coeffs(f, z, r, dt):
+    pi = np.pi
+    k1, k2, k3 = z / (pi * f), 1 / (2 * pi * f) ** 2, r * z / (2 * pi * f)
+    A = np.array([[1.0, dt], [-dt / k2, 1 - dt * dt / k2 - dt * k1 / k2]])
+    return A, dt / k2, k3 / k2
+
+
+def _smooth_worker(rank, port, T, tmp):
+    _init(rank, port)
+    from snowmocap_amd.sharded import combine_carries, smooth_exchange
+    f, z, r, dt = 2.5, 0.75, 0.6, 1 / 30
+    A, cx, cxd = _coeffs(f, z, r, dt)
+    n = 7
+    x = np.cumsum(np.random.default_rng(3).normal(0, 0.01, size=(T, n)), axis=0) + 1.0      # the same track on every rank
+    lo, hi, _ = shard_bounds(T, WORLD, rank)
+
+    # NumPy stand-ins with the conventions of snowtri_smooth_shard_local / _fix (the host twins of the kernels)
+    def local_fn(xl, first, y, payload):
+        xv = xl.numpy()
+        s = np.zeros((n, 2))
+        yv = np.zeros_like(xv)
+        tb = 1 if first else 0
+        if first:
+            yv[0] = xv[0]
+        xp = xv[0].copy()
+        for t in range(tb, xv.shape[0]):
+            c = cx * xv[t] + cxd * (xv[t] - xp)
+            xp = xv[t]
+            s = s @ A.T + np.stack([np.zeros(n), c], axis=1)
+            yv[t] = s[:, 0]
+        y.copy_(torch.from_numpy(yv))
+        payload[: 2 * n] = torch.from_numpy(s.reshape(-1))
+
+    def combine_fn(allp, rk, start):
+        a = allp.numpy()
+        payloads = [(a[q, : 2 * n].reshape(n, 2), a[q, 2 * n:3 * n], a[q, 3 * n:4 * n], a[q, 4 * n]) for q in range(WORLD)]
+        start.copy_(torch.from_numpy(combine_carries(payloads, rk, A, cxd)))
+
+    def fix_fn(y, first, start):
+        v = start.numpy().copy()
+        yv = y.numpy()
+        for t in range(1 if first else 0, yv.shape[0]):
+            v = v @ A.T
+            yv[t] += v[:, 0]
+
+    y = smooth_exchange(torch.from_numpy(x[lo:hi].copy()), local_fn, combine_fn, fix_fn)
+    np.save(os.path.join(tmp, f"y{rank}.npy"), y.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("T", [41, 100, 3])
+def test_eight_rank_sharded_smoothing_exchange_matches_the_sequential_filter(tmp_path, T):
+    """smooth_exchange (the protocol smooth_track_sharded runs around the C ABI) over 8 gloo ranks with the host twins of
+    the kernels: 41 frames = blocks of 6, rank 6 holds 5 and rank 7 NONE; 3 frames = five empty shards.  One all-gather
+    of 4n + 1 doubles; the concatenated blocks equal the unsharded recurrence."""
+    from oracle import oracle as orc
+    mp.spawn(_smooth_worker, args=(_port(T + 11), T, str(tmp_path)), nprocs=WORLD, join=True)
+    got = np.concatenate([np.load(tmp_path / f"y{r}.npy") for r in range(WORLD)])
+    x = np.cumsum(np.random.default_rng(3).normal(0, 0.01, size=(T, 7)), axis=0) + 1.0
+    want = orc.second_order_track(x, 2.5, 0.75, 0.6, 1 / 30)
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-11)
+
+
+def test_bench_dry_run_with_eight_ranks():
+    """`python bench.py --gpus 8 --dry-run`: the launcher logic and bench's gather leg (gather_track_chunked) with the rank
+    count the driver's SCALE run uses."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    env["OMP_NUM_THREADS"] = "1"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run", "--chunks", "auto,3", "--frames", "43"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-2000:]
+    d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    assert d["dry_run"] and d["n_gpus"] == 8 and d["rccl_ranks"] == 8
+    assert sorted(r["rank"] for r in d["ranks"]) == list(range(8)) and len({r["pid"] for r in d["ranks"]}) == 8
+    for chunks, g in d["gather_leg"].items():
+        assert g["ok"] and g["frames_gathered"] == 8 * 43, (chunks, g)
