@@ -253,12 +253,14 @@ def main():
     C, P, Pout = Kc.shape[0], 1, 1
     params = wl["params"]
     method = _lib.DLT if args.method == "dlt" else _lib.PAIRWISE
+    # `bt`: one stream, for the per-kernel figures (launches back to back).  `bto`: the SAME library in its overlap mode
+    # (snowtri_ctx_set_overlap, BatchTriangulator(streams=n)): a plain loop of calls on one caller stream, issued by the
+    # library round-robin on n internal streams so that the ramp-up / tail of consecutive launches overlap -- what round 3's
+    # bench did by hand with twin contexts and its own streams is now what any caller gets.
     bt = BatchTriangulator(Kc, Rc, tc, params, pout_max=Pout, out_dtype=np.float32, device=local_rank, method=method)
-    nstreams = max(1, args.streams)
-    bts = [bt] + [BatchTriangulator(Kc, Rc, tc, params, pout_max=Pout, out_dtype=np.float32, device=local_rank,
-                                    method=method) for _ in range(nstreams - 1)]
-    streams = [torch.cuda.Stream(device=dev) for _ in range(nstreams)]
-
+    nstreams = max(1, min(4, args.streams))
+    bto = bt if nstreams == 1 else BatchTriangulator(Kc, Rc, tc, params, pout_max=Pout, out_dtype=np.float32, device=local_rank,
+                                                     method=method, streams=nstreams)
     # pool of distinct resident batches: exact projections + N(0, 1 px) noise, scores U(3.5, 8)
     base = torch.from_numpy(wl["kpts"]).to(dev)
     gen = torch.Generator(device=dev)
@@ -282,19 +284,20 @@ def main():
         so the latency of an N-rank RCCL barrier (tens of microseconds against a 0.4 ms region) is not booked to the path."""
         def step(i):
             b = i % len(pool)
-            k = i % nstreams
-            bts[k].run_torch(pool[b], None, out=outs[b], stream=streams[k].cuda_stream)
+            bto.run_torch(pool[b], None, out=outs[b])
 
         for i in range(W_steps):
             step(i)
-        torch.cuda.synchronize(dev)            # every stream of this device, side stream included
+        bto.join()
+        torch.cuda.synchronize(dev)            # every stream of this device, the library's internal ones included
         if dist is not None:
             dist.barrier()
             torch.cuda.synchronize(dev)        # (the barrier is itself device work on RCCL's stream)
         t0 = time.perf_counter()
         for i in range(K_steps):
             step(W_steps + i)
-        torch.cuda.synchronize(dev)
+        bto.join()                             # the caller's stream waits for every overlapped call ...
+        torch.cuda.synchronize(dev)            # ... and the host for the device
         dt_own = time.perf_counter() - t0
         dt = dt_own
         if dist is not None:
@@ -312,7 +315,8 @@ def main():
     n_w = 0
     while (time.perf_counter() - t_w) * 1e3 < args.device_warmup_ms:
         for i in range(50):
-            bts[i % nstreams].run_torch(pool[i % len(pool)], None, out=outs[i % len(pool)], stream=streams[i % nstreams].cuda_stream)
+            bto.run_torch(pool[i % len(pool)], None, out=outs[i % len(pool)])
+        bto.join()
         torch.cuda.synchronize(dev)
         n_w += 50
     # `value`: frames sharded across ranks, no data-path collective (frames are independent: SURVEY 8e).
@@ -510,6 +514,7 @@ def main():
         from bench_per_frame import per_frame_api
         per_frame = per_frame_api(frames=300, warm=20)
 
+    overrides = bt.ctx.overrides()
     line = None
     if rank == 0:
         line = {
@@ -529,6 +534,10 @@ def main():
                        "method": "pairwise (reference-exact)" if args.method == "pairwise" else "dlt (N-view, NOT the reference's algorithm)",
                        "io": "fp32 in / fp32 out, fp64 math",
                        "streams": nstreams,
+                       "how_issued": "one caller stream; the library's overlap mode (snowtri_ctx_set_overlap) rotates the calls over "
+                                     f"{nstreams} internal streams; join + synchronize at the end of a region" if nstreams > 1 else "one stream",
+                       "context_overrides": overrides,
+                       "build": _lib.build_info(),
                        "parallelism": f"frames sharded x{world}, no data-path collective",
                        "extra_workloads": None if extra is None else [e["workload"] for e in extra]},
             "roofline": {"bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
@@ -554,7 +563,7 @@ def main():
             "roofline_region": {"bound": "hbm", "achieved": ach_region, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                 "frac": ach_region / HBM_PEAK_GBS, "streams": nstreams,
                                 "how": "algorithmic bytes per step / ms_per_step of the timed region (per GPU; "
-                                       f"steps issued round-robin on {nstreams} streams, so consecutive launches overlap)"},
+                                       f"a plain loop of calls in the library's overlap mode over {nstreams} internal streams, so consecutive launches overlap)"},
             # the roof that actually binds this kernel: fp64 VALU issue.  VALU wave-instructions per 64 joints
             # MEASURED (rocprofv3 SQ_INSTS_VALU, quoted only while profiles/pmc_traffic.json carries the hash of these kernel
             # sources), 4 issue cycles each, 1024 SIMDs at the 2.4 GHz peak clock.
@@ -571,7 +580,7 @@ def main():
             "extra_workloads": extra,
             "ray_pair_solves_per_s": value * (C * (C - 1) // 2),
         }
-    for b_ in bts:
+    for b_ in {id(bt): bt, id(bto): bto}.values():
         b_.close()
     if dist is not None:
         dist.destroy_process_group()
@@ -612,14 +621,22 @@ def extra_workloads(torch, dev, device_index):
         bt = BatchTriangulator(K, R, t, wl["params"], pout_max=pout, out_dtype=np.float32, device=device_index)
         out = bt.run_torch(kp, npers)
         torch.cuda.synchronize(dev)
-        bt.ctx.set_timing(True)
-        ms = []
-        for _ in range(5):
+        # ONE call = one fused entry on one caller stream (inside it the library alternates the call's segments between
+        # that stream and an internal one).  Calls are queued back to back and their event pairs (the context's ring,
+        # bracketing each call) read afterwards, as for the headline kernel: a synchronize between the calls lets the chip
+        # idle and clock down, and round 3's figure of a single synchronised call was up to 10 % above the same call in a loop.
+        ncalls = 12 if cfg == 3 else 6
+        for _ in range(2):
             bt.run_torch(kp, npers, out=out)
-            ms.append(bt.ctx.last_kernel_ms()[0])
+        bt.ctx.set_timing(True)
+        for _ in range(ncalls):
+            bt.run_torch(kp, npers, out=out)
+        ms = bt.ctx.timing_collect()
         bt.ctx.set_timing(False)
+        torch.cuda.synchronize(dev)
         cnt = out["count"].cpu().numpy()
-        m = float(np.median(ms[1:]))
+        m = float(np.median(ms))
+        counts = bt.ctx.last_stream_counts()
         # throughput with two calls in flight (two contexts on two streams, as the headline `value` is issued): the
         # latency-bound kernels of one call (k_associate, the member lists) run beside the VALU-bound ones of the other
         bt2 = BatchTriangulator(K, R, t, wl["params"], pout_max=pout, out_dtype=np.float32, device=device_index)
@@ -651,7 +668,10 @@ def extra_workloads(torch, dev, device_index):
         handed = bt.ctx.last_handover_persons()
         res.append({"workload": label, "kernel": kernels, "frames": F, "kernel_ms": m,
                     "persons_handed_to_cluster_kernels_last_segment": {"complete_graph": handed[0], "member_list": handed[1]},
-                    "kernel_ms_all": ms[1:], "frames_per_s": F / (m * 1e-3),
+                    "kernel_ms_all": ms, "frames_per_s": F / (m * 1e-3),
+                    "how": f"{ncalls} calls queued back to back on one stream, HIP events around each call, median",
+                    "fall_back_frames_last_segment": {"second_association_launch": counts[0], "exact_candidate_sums": counts[1],
+                                                      "k_frame_recompute": counts[2]},
                     "two_streams": {"ms_per_call": m2, "ms_per_call_all": ms2, "frames_per_s": F / (m2 * 1e-3),
                                     "frac": tflops * (m / m2) / FP64_VALU_PEAK_TFLOPS, "outputs_identical_on_both_contexts": same,
                                     "how": "two contexts on two streams, six calls alternating, wall time between two "

@@ -88,6 +88,11 @@ const char *snowtri_last_error(void);
 /* Number of visible HIP devices (0 on a CPU-only box; never fails). */
 int snowtri_device_count(void);
 
+/* What this binary is: "version=<n>;arch=gfx950;variants=<comma-separated build variants>".  The production library
+ * reports an empty variant list; libsnowtri_dbg.so reports SNOWTRI_DEBUG_BOUNDS; development builds name their
+ * switches (snowmocap_amd/csrc/snowtri_math.hpp lists them).  Never fails; the string lives as long as the library. */
+const char *snowtri_build_info(void);
+
 /* Rig constants.  Replaces Camera.__init__/CameraGroup.__init__ state used by the path
  * (camera.py:17-44,142-157): K[C][9], R[C][9] (camera->world), t[C][3] (camera centre), fp64.
  * C == 0 gives a scratch-only context (enough for snowtri_condense / snowtri_skew_ray_batch). */
@@ -99,6 +104,30 @@ int snowtri_ctx_num_cameras(const snowtri_ctx *ctx);
 int snowtri_ctx_ray_matrices(const snowtri_ctx *ctx, double *M_out);
 /* Block until everything queued by this context has finished. */
 int snowtri_ctx_synchronize(snowtri_ctx *ctx);
+/* Test knobs.  A context reads these environment variables ONCE, at creation, and names the ones that were set as
+ * "NAME=value,..." ("" = the context runs the defaults; bench.py prints it, tests assert on it):
+ *   SNOWTRI_GENERAL_MODE=1|2        multi-person batches on the spill kernel / on k_frame_recompute
+ *   SNOWTRI_LEAN_MODE=0             float32-output single-detection batches stay on k_fused_single
+ *   SNOWTRI_LEAN_COOP=0             small launches stay on k_fused_lean
+ *   SNOWTRI_HANDOVER_MODE=0|2       0: the whole multi-person path inside k_frame_recompute; 2: its descriptors to k_cluster_fuse
+ *   SNOWTRI_HANDOVER_SEG_FRAMES=n   frames per segment of the streaming multi-person route
+ *   SNOWTRI_SPLIT_SEGMENTS=1|n      1: one multi-person call stays on the caller's stream; n >= 2: at least n segments alternating
+ *                                   between the caller's stream and an internal one, also for small batches (default: 2
+ *                                   segments once a segment holds >= 4 frames per CU)
+ *   SNOWTRI_SUMS_THREADS, SNOWTRI_SUMS_LDS_KB, SNOWTRI_LEAN_TILES_PER_WAVE   launch shapes (tests force the rare ones)
+ *   SNOWTRI_DEBUG=1                 launch shapes on stderr
+ * Results never depend on a knob (that is what the tests that set them check); only the route does. */
+const char *snowtri_ctx_overrides(const snowtri_ctx *ctx);
+
+/* OVERLAP MODE for SNOWTRI_DEVICE calls of snowtri_triangulate_condense (off = 1 by default).  With n_streams = 2..4 the
+ * context issues consecutive calls round-robin on n internal streams, each behind whatever `stream` held at the time of the
+ * call: the ramp-up of one launch overlaps the tail of the previous one (a 10 000-frame step of the single-person path:
+ * 26 -> 20 us per call), without the caller creating streams or twin contexts.  The calls must be independent (distinct
+ * output buffers; inputs ready on `stream` when the call is made).  Results become visible to the caller's stream at
+ * snowtri_ctx_join(ctx, stream) -- `stream` then waits for every call issued since the last join -- or after
+ * snowtri_ctx_synchronize.  SNOWTRI_HOST calls are synchronous and ignore the mode. */
+int snowtri_ctx_set_overlap(snowtri_ctx *ctx, int n_streams);
+int snowtri_ctx_join(snowtri_ctx *ctx, void *stream);
 
 /* Test hook (no reference counterpart): evaluates the fast reciprocal / reciprocal-square-root helpers
  * the throughput kernels use (v_rcp_f64 / v_rsq_f64 + Newton steps) on x[n]; host pointers. */
@@ -274,6 +303,12 @@ int snowtri_debug_selftest(snowtri_ctx *ctx);
  * batches, float64 outputs, DLT, keypoint_num < J, more than 16 cameras or 16 persons per camera).  Synchronises
  * the device. */
 int64_t snowtri_last_handover_persons(snowtri_ctx *ctx, int64_t *n_other);
+/* Diagnostics of the streaming multi-person route, last call (its last segment): counts[0] = frames the association
+ * kernel could not finish in its first launch (kept list larger than its LDS), counts[1] = frames with a candidate whose sum
+ * was re-done with the exact arithmetic, counts[2] = frames left to k_frame_recompute.  All three are 0 on the reference's
+ * workloads (tests assert it: a regression that sends every frame down a fall-back still passes parity, but not this);
+ * -1 each if that call did not take the route.  Synchronises the device. */
+int snowtri_last_stream_counts(snowtri_ctx *ctx, int64_t counts[3]);
 
 #ifdef __cplusplus
 }

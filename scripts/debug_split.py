@@ -39,7 +39,6 @@ diff("full vs pieces", a, p1)
 diff("pieces vs pieces again", p1, pieces(c1))
 for tpw in ("1", "2", "8", "16"):
     diff(f"full vs full tiles_per_wave={tpw}", a, full({"SNOWTRI_LEAN_TILES_PER_WAVE": tpw}))
-diff("full vs full wg_per_cu=1", a, full({"SNOWTRI_LEAN_WG_PER_CU": "1"}))
 half = pieces([0, F // 2, F])
 diff("full vs halves", a, half)
 diff("pieces vs halves", p1, half)

@@ -58,6 +58,11 @@ _SIGNATURES = {
     "snowtri_status_string": (ct.c_char_p, [ct.c_int]),
     "snowtri_last_error": (ct.c_char_p, []),
     "snowtri_device_count": (ct.c_int, []),
+    "snowtri_build_info": (ct.c_char_p, []),
+    "snowtri_ctx_overrides": (ct.c_char_p, [_c_p]),
+    "snowtri_ctx_set_overlap": (ct.c_int, [_c_p, ct.c_int]),
+    "snowtri_ctx_join": (ct.c_int, [_c_p, _c_p]),
+    "snowtri_last_stream_counts": (ct.c_int, [_c_p, ct.POINTER(ct.c_int64 * 3)]),
     "snowtri_ctx_create": (ct.c_int, [ct.c_int32, _c_p, _c_p, _c_p, ct.c_int, ct.POINTER(_c_p)]),
     "snowtri_ctx_destroy": (ct.c_int, [_c_p]),
     "snowtri_ctx_num_cameras": (ct.c_int, [_c_p]),
@@ -134,6 +139,13 @@ def lib():
             fn.argtypes = args
         _lib = handle
     return _lib
+
+
+def build_info():
+    """{"version": int, "arch": str, "variants": [build variants of the loaded binary]} (snowtri_build_info)."""
+    raw = lib().snowtri_build_info().decode()
+    d = dict(kv.split("=", 1) for kv in raw.split(";"))
+    return {"version": int(d["version"]), "arch": d["arch"], "variants": [v for v in d.get("variants", "").split(",") if v]}
 
 
 def check(status, where):
@@ -241,6 +253,25 @@ class Context:
         if n < 0:
             raise SnowtriError(ERR_HIP, "snowtri_timing_collect")
         return [float(arr[i]) for i in range(n)]
+
+    def overrides(self):
+        """Test knobs (environment) this context was created under: "" when it runs the defaults."""
+        return (lib().snowtri_ctx_overrides(self.handle) or b"").decode()
+
+    def set_overlap(self, n_streams):
+        """Overlap mode: device calls of the fused entry rotate over n internal streams (1 = off); join() before reading results."""
+        check(lib().snowtri_ctx_set_overlap(self.handle, int(n_streams)), "snowtri_ctx_set_overlap")
+
+    def join(self, stream=None):
+        """`stream` (a HIP stream handle, default the null stream) waits for every overlapped call issued since the last join."""
+        check(lib().snowtri_ctx_join(self.handle, ct.c_void_p(stream) if stream else None), "snowtri_ctx_join")
+
+    def last_stream_counts(self):
+        """(frames past the association's first launch, frames with an exactly re-done candidate sum, frames left to
+        k_frame_recompute) of the last multi-person call's last segment; (-1, -1, -1) if it did not take the streaming route."""
+        arr = (ct.c_int64 * 3)()
+        check(lib().snowtri_last_stream_counts(self.handle, ct.byref(arr)), "snowtri_last_stream_counts")
+        return int(arr[0]), int(arr[1]), int(arr[2])
 
     def last_slow_frames(self):
         return int(lib().snowtri_last_slow_frames(self.handle))

@@ -14,10 +14,17 @@ FUSED_CALLS = 0   # fused device calls issued through run_torch by this process 
 
 
 class BatchTriangulator:
-    def __init__(self, K, R, t, params, pout_max=1, out_dtype=np.float32, device=0, method=_lib.PAIRWISE, D=None):
+    def __init__(self, K, R, t, params, pout_max=1, out_dtype=np.float32, device=0, method=_lib.PAIRWISE, D=None, streams=1):
         """D (optional, [C, 5] lens coefficients): the keypoints handed to run_* were detected on RAW frames and
-        are undistorted on the GPU first (row N4, snowtri_undistort_keypoints)."""
+        are undistorted on the GPU first (row N4, snowtri_undistort_keypoints).
+        streams (1..4): OVERLAP MODE of the library (snowtri_ctx_set_overlap) -- consecutive run_torch calls are issued
+        round-robin on that many internal streams, so a plain loop of independent calls (distinct `out` buffers) overlaps the
+        tail of one launch with the ramp-up of the next; call join() before reading the results (or queueing work that
+        reads them) on the caller's stream."""
         self.ctx = _lib.Context(K, R, t, device=device)
+        self.streams = int(streams)
+        if self.streams > 1:
+            self.ctx.set_overlap(self.streams)
         self.undistort = D is not None
         if self.undistort:
             self.ctx.set_distortion(D)
@@ -104,6 +111,15 @@ class BatchTriangulator:
             raise IndexError("center_point_index / keypoint_num out of range")
         _lib.check(rc, "snowtri_triangulate_condense")
         return out
+
+    def join(self, stream=None):
+        """Overlap mode: torch's current stream (or `stream`, a HIP stream handle) waits for every call issued since the
+        last join.  A no-op with streams=1."""
+        if self.streams > 1:
+            if stream is None:
+                import torch
+                stream = torch.cuda.current_stream(torch.device("cuda", self.device)).cuda_stream
+            self.ctx.join(stream)
 
     def close(self):
         self.ctx.close()

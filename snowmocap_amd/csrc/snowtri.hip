@@ -13,6 +13,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <limits>
+#include <map>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -138,6 +140,37 @@ constexpr int kTimingRing = 1024;
 // (snowtri_cluster.hpp: kHandComplete, kHandMembers -- 128 bytes apart)
 constexpr int kHandCountersAt = 16, kCounterWords = 48;
 
+// Everything a fused call writes besides its outputs: the slabs of the fall-back routines, the hand-over lists and
+// candidate sums of the multi-person path, the frame queue / list counters, the flags of a call that did not ask for
+// them.  A context owns kMaxSets of them: set 0 is the caller's stream; the others carry an internal stream each, so that
+// (a) the segments of ONE multi-person call alternate between two sets -- the latency-bound kernels of one segment
+// (k_associate, the member lists) run beside the VALU-bound ones of the other -- and (b) in overlap mode
+// (snowtri_ctx_set_overlap) consecutive calls run on different sets, i.e. the tail of one launch overlaps the ramp-up of
+// the next without the caller managing streams.  Work on one set is ordered by its stream, so a set's scratch is never
+// shared by two launches in flight.
+struct StreamSet {
+    Scratch work, desc, sums, misc;
+    unsigned long long *d_counters = nullptr;   // kCounterWords
+    hipStream_t stream = nullptr;               // internal stream (nullptr for set 0 outside overlap mode: the caller's)
+    hipEvent_t done = nullptr;                  // recorded behind the last launch the set received
+    bool pending = false;                       // `done` has been recorded and not yet joined
+};
+constexpr int kMaxSets = 4;
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a property of the FUNCTION (per device, process-wide) and the call SETS
+// it: two contexts with different rigs in one process must not lower each other's limit.  One monotone
+// cache per (device, kernel) for the whole process.
+std::mutex g_lds_mutex;
+std::map<std::pair<int, const void *>, int> g_lds_raised;
+int raise_dynamic_lds(int device, const void *kern, int lds) {
+    std::lock_guard<std::mutex> lock(g_lds_mutex);
+    int &have = g_lds_raised[{device, kern}];
+    if (have >= lds) return 0;
+    if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return 1;
+    have = lds;
+    return 0;
+}
+
 int grid_for(int64_t work_items, int per_block, int cap_blocks) {
     int64_t b = (work_items + per_block - 1) / per_block;
     return (int)std::max<int64_t>(1, std::min<int64_t>(b, cap_blocks));
@@ -154,12 +187,34 @@ struct snowtri_ctx {
     void *dBlenderTab = nullptr;          // 24 SmoothCoef of the last (fzr, dt) given to snowtri_blender_smooth
     std::vector<double> blender_key;      // that (fzr[72], dt)
     std::vector<int32_t> hpairs;
-    double *dM = nullptr, *dt = nullptr, *dpairc = nullptr, *dP = nullptr, *deg = nullptr;
+    double *dM = nullptr, *dt = nullptr, *dpairc = nullptr, *dP = nullptr;
     int32_t *dpairs = nullptr;
-    unsigned long long *d_counters = nullptr;  // [0] singular pairs, [1] slow frames, [2..] spare
-    Scratch in, out, work, misc, aux, desc;   // desc: cluster descriptors handed from k_frame_recompute / k_associate to k_cluster_fuse
+    StreamSet sets[kMaxSets];
+    StreamSet *cur = &sets[0];        // the set the launch in progress writes to (set 0 between fused calls)
+    StreamSet *last_set = &sets[0];   // the set of the last fused call's last segment (diagnostics read its counters)
+    // set 0 under the names every other entry point uses
+    unsigned long long *&d_counters = sets[0].d_counters;  // [0] singular pairs, [1] slow frames, [2..] spare
+    Scratch &work = sets[0].work, &misc = sets[0].misc;
+    Scratch &desc = sets[0].desc;             // cluster descriptors handed from k_frame_recompute / k_associate to k_cluster_fuse
+    Scratch &sums = sets[0].sums;             // candidate sums of k_candidate_sums [frames][Kc] + the frames k_associate left behind
+    Scratch in, out, aux;
     PinnedScratch pin_in, pin_out;            // host staging of the per-frame calls
-    Scratch sums;                             // candidate sums of k_candidate_sums [frames][Kc] + the frames k_associate left behind
+    int overlap = 1;                  // snowtri_ctx_set_overlap: device calls rotate over this many sets (1 = the caller's stream)
+    int64_t call_index = 0;
+    hipEvent_t ev_fork = nullptr;     // the caller's stream at the time of a call / a split: the internal streams wait for it
+    int split_segments = 2;           // one multi-person call is cut into >= this many segments on two sets (1: no split)
+    bool split_forced = false;        // SNOWTRI_SPLIT_SEGMENTS given: also batches that would not fill the chip twice
+    int ensure_set(int k) {           // counters, stream and event of set k (set 0: counters at creation, stream on demand)
+        StreamSet &S = sets[k];
+        if (!S.d_counters) {
+            if (hipMalloc(&S.d_counters, sizeof(unsigned long long) * kCounterWords) != hipSuccess) return 1;
+            if (hipMemset(S.d_counters, 0, sizeof(unsigned long long) * kCounterWords) != hipSuccess) return 1;
+        }
+        if (!S.stream && hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking) != hipSuccess) return 1;
+        if (!S.done && hipEventCreateWithFlags(&S.done, hipEventDisableTiming) != hipSuccess) return 1;
+        if (!ev_fork && hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) return 1;
+        return 0;
+    }
     // measurement
     bool timing = false;
     bool timing_attach = false;   // snowtri_set_timing(ctx, 2): single-kernel launches carry their ring events themselves
@@ -171,34 +226,30 @@ struct snowtri_ctx {
     int64_t ev_count = 0;             // fused calls recorded since the last snowtri_timing_collect
     int64_t last_slow_frames = 0;
     bool last_handover = false;  // the last fused call went through k_frame_recompute with the cluster hand-over armed
-    int general_mode = 0;  // dev/test knob: 0 auto, 1 force the spill kernel, 2 force the recompute kernel
-    int lean_mode = 1;     // dev/test knob: 0 keeps float32-output batches on k_fused_single (A/B against k_fused_lean)
-    int lean_coop = 1;     // dev/test knob: 0 keeps small launches on k_fused_lean (A/B against k_fused_lean_coop)
-    int handover_mode = 1; // dev/test knob: 1 streaming association (k_candidate_sums / k_associate / k_cluster_fuse), 2 hand-over from
-                           // inside k_frame_recompute, 0 the whole multi-person path inside k_frame_recompute
-    int cluster_split = 1;   // dev knob (SNOWTRI_CLUSTER_SPLIT): 0 runs the member-list clusters of <= 8-camera rigs inside k_cluster_fuse
-    int sums_threads = 0, sums_lds_kb = 0, assoc_wg_per_cu = 16;   // dev knobs of the streaming association (0: automatic)
-    int recompute_wg_per_cu = 0, cluster_ppw = 0, debug = 0;   // cluster_ppw (SNOWTRI_CLUSTER_PASSES_PER_WAVE): 0 = automatic
-    int tile_frames = 0, lean_wg_per_cu = 2, lean_tiles_per_wave = 0, lean_scratch_mb = 256, handover_seg_frames = 0;   // dev / test knobs
+    // test knobs (environment, read at creation; snowtri_ctx_overrides names the ones that are set)
+    int general_mode = 0;        // SNOWTRI_GENERAL_MODE: 0 auto, 1 force the spill kernel, 2 force the recompute kernel
+    int lean_mode = 1;           // SNOWTRI_LEAN_MODE: 0 keeps float32-output batches on k_fused_single
+    int lean_coop = 1;           // SNOWTRI_LEAN_COOP: 0 keeps small launches on k_fused_lean
+    int handover_mode = 1;       // SNOWTRI_HANDOVER_MODE: 1 streaming association (k_candidate_sums / k_associate / k_cluster_fuse), 2 hand-over
+                                 // from inside k_frame_recompute, 0 the whole multi-person path inside k_frame_recompute
+    int handover_seg_frames = 0; // SNOWTRI_HANDOVER_SEG_FRAMES: short segments of the streaming route
+    int sums_threads = 0, sums_lds_kb = 0;   // SNOWTRI_SUMS_THREADS / _LDS_KB: workgroup shape of k_candidate_sums (0: automatic)
+    int lean_tiles_per_wave = 0; // SNOWTRI_LEAN_TILES_PER_WAVE
+    int debug = 0;               // SNOWTRI_DEBUG: launch shapes on stderr
+    std::string overrides;
+    static constexpr int assoc_wg_per_cu = 16, lean_wg_per_cu = 2, lean_scratch_mb = 256;   // (settled by measurement: EXPERIMENTS.md)
     struct OccCache {
         size_t lds = 0;
         int per_cu = -1;
     } recompute_occ[8];   // resident workgroups per CU of the k_frame_recompute instantiations (queried once per LDS size)
-    std::vector<std::pair<const void *, int>> lds_attr;   // kernels whose dynamic-LDS limit has been raised (and to what)
-    int raise_lds(const void *kern, int lds) {             // hipFuncSetAttribute once per (kernel, size), not once per launch
-        for (auto &e : lds_attr)
-            if (e.first == kern && e.second >= lds) return 0;
-        if (hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess) return 1;
-        lds_attr.emplace_back(kern, lds);
-        return 0;
-    }
-    int64_t last_stream_slow = -1;   // frames the streaming association left to k_frame_recompute in the last call (-1: not used)
+    int raise_lds(const void *kern, int lds) { return raise_dynamic_lds(device, kern, lds); }   // once per (device, kernel, size), process-wide
+    bool last_stream = false;        // the last fused call went through the streaming association (snowtri_last_stream_counts)
     // names of the kernels the last fused call launched (snowtri_last_kernel_names): a pointer to a string that lives as
     // long as the library (one per template instantiation) or to `names_buf`, rebuilt only when the route changes
     const char *last_kernels = "";
     std::string names_buf;
     long long names_key = -1;
-    Rig rig() const { return Rig{dM, dt, dpairs, dpairc, dP, deg, C, npairs}; }
+    Rig rig() const { return Rig{dM, dt, dpairs, dpairc, dP, C, npairs}; }
 };
 
 extern "C" {
@@ -220,6 +271,37 @@ const char *snowtri_status_string(int s) {
 
 const char *snowtri_last_error(void) { return g_last_error.c_str(); }
 
+const char *snowtri_build_info(void) {
+    // what this binary was compiled as: the production library reports no variant at all
+    static const std::string info = [] {
+        std::string v;
+        auto add = [&](const char *name) { v += (v.empty() ? "" : ",") + std::string(name); };
+        (void)add;
+#ifdef SNOWTRI_DEBUG_BOUNDS
+        add("SNOWTRI_DEBUG_BOUNDS");
+#endif
+#ifdef SNOWTRI_DEV_MIN
+        add("SNOWTRI_DEV_MIN");
+#endif
+#ifdef SNOWTRI_DEV_EXPERIMENTS
+        add("SNOWTRI_DEV_EXPERIMENTS");
+#endif
+#ifdef SNOWTRI_LEAN_TRACE
+        add("SNOWTRI_LEAN_TRACE");
+#endif
+#ifdef SNOWTRI_SUMS_TRACE
+        add("SNOWTRI_SUMS_TRACE");
+#endif
+#ifdef SNOWTRI_ASSOC_TRACE
+        add("SNOWTRI_ASSOC_TRACE");
+#endif
+        return "version=" + std::to_string(SNOWTRI_VERSION) + ";arch=gfx950;variants=" + v;
+    }();
+    return info.c_str();
+}
+
+const char *snowtri_ctx_overrides(const snowtri_ctx *ctx) { return ctx ? ctx->overrides.c_str() : ""; }
+
 int snowtri_device_count(void) {
     int n = 0;
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
@@ -235,23 +317,25 @@ int snowtri_ctx_create(int32_t C, const double *K, const double *R, const double
     if (!ctx) return SNOWTRI_ERR_BAD_ARG;
     ctx->device = device;
     ctx->C = C;
-    if (const char *gm = getenv("SNOWTRI_GENERAL_MODE")) ctx->general_mode = atoi(gm);
-    if (const char *lm = getenv("SNOWTRI_LEAN_MODE")) ctx->lean_mode = atoi(lm);
-    if (const char *lc = getenv("SNOWTRI_LEAN_COOP")) ctx->lean_coop = atoi(lc);
-    if (const char *hm = getenv("SNOWTRI_HANDOVER_MODE")) ctx->handover_mode = atoi(hm);
-    // every environment knob is read HERE, once: nothing on the launch path calls getenv
-    if (const char *e = getenv("SNOWTRI_SUMS_THREADS")) ctx->sums_threads = atoi(e);
-    if (const char *e = getenv("SNOWTRI_CLUSTER_SPLIT")) ctx->cluster_split = atoi(e);
-    if (const char *e = getenv("SNOWTRI_SUMS_LDS_KB")) ctx->sums_lds_kb = atoi(e);
-    if (const char *e = getenv("SNOWTRI_ASSOC_WG_PER_CU")) ctx->assoc_wg_per_cu = std::max(1, atoi(e));
-    if (const char *e = getenv("SNOWTRI_RECOMPUTE_WG_PER_CU")) ctx->recompute_wg_per_cu = atoi(e);
-    if (const char *e = getenv("SNOWTRI_CLUSTER_PASSES_PER_WAVE")) ctx->cluster_ppw = std::max(1, atoi(e));
-    if (getenv("SNOWTRI_DEBUG")) ctx->debug = 1;
-    if (const char *e = getenv("SNOWTRI_TILE_FRAMES")) ctx->tile_frames = atoi(e);
-    if (const char *e = getenv("SNOWTRI_LEAN_WG_PER_CU")) ctx->lean_wg_per_cu = std::max(1, atoi(e));
-    if (const char *e = getenv("SNOWTRI_LEAN_TILES_PER_WAVE")) ctx->lean_tiles_per_wave = std::max(1, atoi(e));
-    if (const char *e = getenv("SNOWTRI_LEAN_SCRATCH_MB")) ctx->lean_scratch_mb = std::max(1, atoi(e));
-    if (const char *e = getenv("SNOWTRI_HANDOVER_SEG_FRAMES")) ctx->handover_seg_frames = std::max(1, atoi(e));   // test knob: short segments
+    // Test knobs (include/snowtri.h lists them): read HERE, once -- nothing on the launch path calls getenv -- and every one
+    // that is set is named by snowtri_ctx_overrides(), so a test or a bench can see that a context does not run the defaults.
+    auto knob = [&](const char *name, int *field, int lo) {
+        if (const char *e = getenv(name)) {
+            *field = std::max(lo, atoi(e));
+            ctx->overrides += (ctx->overrides.empty() ? "" : ",") + std::string(name) + "=" + std::to_string(*field);
+        }
+    };
+    knob("SNOWTRI_GENERAL_MODE", &ctx->general_mode, 0);
+    knob("SNOWTRI_LEAN_MODE", &ctx->lean_mode, 0);
+    knob("SNOWTRI_LEAN_COOP", &ctx->lean_coop, 0);
+    knob("SNOWTRI_HANDOVER_MODE", &ctx->handover_mode, 0);
+    knob("SNOWTRI_HANDOVER_SEG_FRAMES", &ctx->handover_seg_frames, 1);
+    knob("SNOWTRI_SPLIT_SEGMENTS", &ctx->split_segments, 1);
+    ctx->split_forced = getenv("SNOWTRI_SPLIT_SEGMENTS") != nullptr && ctx->split_segments >= 2;
+    knob("SNOWTRI_SUMS_THREADS", &ctx->sums_threads, 0);
+    knob("SNOWTRI_SUMS_LDS_KB", &ctx->sums_lds_kb, 0);
+    knob("SNOWTRI_LEAN_TILES_PER_WAVE", &ctx->lean_tiles_per_wave, 1);
+    knob("SNOWTRI_DEBUG", &ctx->debug, 0);
     ctx->hM.resize((size_t)C * 9);
     ctx->ht.assign(t, t + (size_t)C * 3);
     ctx->hK.assign(K, K + (size_t)C * 9);
@@ -280,13 +364,6 @@ int snowtri_ctx_create(int32_t C, const double *K, const double *R, const double
             hpairc[6 * q + 3 + i] = tm[i] + ts[i];
         }
     }
-    std::vector<double> heg((size_t)std::max(1, ctx->npairs) * 6, 0.0);   // (M_c^T d)[j] = sum_row M_c[row][j] d[row]
-    for (int q = 0; q < ctx->npairs; q++)
-        for (int side = 0; side < 2; side++) {
-            const double *Mc = &ctx->hM[9 * ctx->hpairs[2 * q + side]];
-            for (int j = 0; j < 3; j++)
-                heg[6 * q + 3 * side + j] = Mc[j] * hpairc[6 * q] + Mc[3 + j] * hpairc[6 * q + 1] + Mc[6 + j] * hpairc[6 * q + 2];
-        }
     auto fail = [&](int rc) {
         snowtri_ctx_destroy(ctx);
         return rc;
@@ -324,8 +401,6 @@ int snowtri_ctx_create(int32_t C, const double *K, const double *R, const double
         CTX_TRY(hipMalloc(&ctx->dP, sizeof(double) * hP.size()));
         CTX_TRY(hipMemcpy(ctx->dP, hP.data(), sizeof(double) * hP.size(), hipMemcpyHostToDevice));
     }
-    CTX_TRY(hipMalloc(&ctx->deg, sizeof(double) * heg.size()));
-    CTX_TRY(hipMemcpy(ctx->deg, heg.data(), sizeof(double) * heg.size(), hipMemcpyHostToDevice));
     if (ctx->npairs > 0)
         CTX_TRY(hipMemcpy(ctx->dpairc, hpairc.data(), sizeof(double) * hpairc.size(), hipMemcpyHostToDevice));
     if (C > 0) {
@@ -349,18 +424,22 @@ int snowtri_ctx_destroy(snowtri_ctx *ctx) {
     if (ctx->dt) (void)hipFree(ctx->dt);
     if (ctx->dpairs) (void)hipFree(ctx->dpairs);
     if (ctx->dpairc) (void)hipFree(ctx->dpairc);
-    if (ctx->deg) (void)hipFree(ctx->deg);
     if (ctx->dP) (void)hipFree(ctx->dP);
     if (ctx->dLens) (void)hipFree(ctx->dLens);
     if (ctx->dBlenderTab) (void)hipFree(ctx->dBlenderTab);
-    if (ctx->d_counters) (void)hipFree(ctx->d_counters);
+    for (auto &S : ctx->sets) {
+        if (S.d_counters) (void)hipFree(S.d_counters);
+        S.work.release();
+        S.misc.release();
+        S.desc.release();
+        S.sums.release();
+        if (S.stream) (void)hipStreamDestroy(S.stream);
+        if (S.done) (void)hipEventDestroy(S.done);
+    }
+    if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
     ctx->in.release();
     ctx->out.release();
-    ctx->work.release();
-    ctx->misc.release();
     ctx->aux.release();
-    ctx->desc.release();
-    ctx->sums.release();
     ctx->pin_in.release();
     ctx->pin_out.release();
     for (auto &e : ctx->ev)
@@ -383,6 +462,31 @@ int snowtri_ctx_synchronize(snowtri_ctx *ctx) {
     if (!ctx) return SNOWTRI_ERR_BAD_ARG;
     ENTER_DEVICE(ctx->device);
     HIP_TRY(hipDeviceSynchronize());
+    return SNOWTRI_OK;
+}
+
+int snowtri_ctx_set_overlap(snowtri_ctx *ctx, int n_streams) {
+    if (!ctx || n_streams < 1 || n_streams > kMaxSets) return SNOWTRI_ERR_BAD_ARG;
+    ENTER_DEVICE(ctx->device);
+    for (auto &S : ctx->sets)   // calls still in flight on the internal streams finish under the old mode
+        if (S.pending) {
+            HIP_TRY(hipStreamSynchronize(S.stream));
+            S.pending = false;
+        }
+    ctx->overlap = n_streams;
+    ctx->call_index = 0;
+    return SNOWTRI_OK;
+}
+
+int snowtri_ctx_join(snowtri_ctx *ctx, void *stream) {
+    if (!ctx) return SNOWTRI_ERR_BAD_ARG;
+    ENTER_DEVICE(ctx->device);
+    for (auto &S : ctx->sets)
+        if (S.pending) {
+            HIP_TRY(hipEventRecord(S.done, S.stream));
+            HIP_TRY(hipStreamWaitEvent((hipStream_t)stream, S.done, 0));
+            S.pending = false;
+        }
     return SNOWTRI_OK;
 }
 
@@ -434,9 +538,23 @@ int64_t snowtri_last_handover_persons(snowtri_ctx *ctx, int64_t *n_other) {
     DeviceGuard guard(ctx->device);
     unsigned long long n[kHandMembers + 1] = {0};   // [kHandComplete] complete-graph clusters, [kHandMembers] >> 32 clusters of any other shape
     if (hipDeviceSynchronize() != hipSuccess) return -1;
-    if (hipMemcpy(n, ctx->d_counters + kHandCountersAt, sizeof(n), hipMemcpyDeviceToHost) != hipSuccess) return -1;
+    if (hipMemcpy(n, ctx->last_set->d_counters + kHandCountersAt, sizeof(n), hipMemcpyDeviceToHost) != hipSuccess) return -1;
     if (n_other) *n_other = (int64_t)hand_member_descs(n[kHandMembers]);
     return (int64_t)n[kHandComplete];
+}
+
+int snowtri_last_stream_counts(snowtri_ctx *ctx, int64_t counts[3]) {
+    if (!ctx || !counts) return SNOWTRI_ERR_BAD_ARG;
+    counts[0] = counts[1] = counts[2] = -1;
+    if (!ctx->last_stream) return SNOWTRI_OK;
+    ENTER_DEVICE(ctx->device);
+    unsigned long long n[3] = {0, 0, 0};   // d_counters[6..8]: slow frames, frames with an exact candidate sum, slow frames of the second pass
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(n, ctx->last_set->d_counters + 6, sizeof(n), hipMemcpyDeviceToHost));
+    counts[0] = (int64_t)n[0];
+    counts[1] = (int64_t)n[1];
+    counts[2] = (int64_t)n[2];
+    return SNOWTRI_OK;
 }
 
 const char *snowtri_last_kernel_names(const snowtri_ctx *ctx) { return ctx ? ctx->last_kernels : ""; }
@@ -661,7 +779,12 @@ int launch_condense(snowtri_ctx *ctx, hipStream_t st, int64_t nframes, int N, in
     const size_t lds = condense_lds_bytes(N);
     auto kern = k_condense<Writer>;
     if (lds > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        {
+            if (ctx->raise_lds((const void *)kern, (int)lds)) {
+                g_last_error = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed";
+                return SNOWTRI_ERR_HIP;
+            }
+        }
     hipLaunchKernelGGL(kern, dim3(grid_for(nframes, 1, ctx->num_cus * 8)), dim3(kBlock), lds, st, nframes, N, J,
                        cxyz, cks, ckeep, prm, Pout, wr, out_count, out_flags);
     HIP_TRY(hipGetLastError());
@@ -1308,18 +1431,23 @@ int launch_fused_single(snowtri_ctx *ctx, hipStream_t st, int64_t F, int J, cons
                         int32_t *d_cnt, uint32_t *d_fl) {
     constexpr int NP = C * (C - 1) / 2;
     const int resident = ctx->num_cus * 4;  // 2 workgroups per CU are resident; 2 more queued ones even out the tail (measured)
-    const int T = choose_tile_frames(F, J, prm.kn, NP, ctx->num_cus, ctx->tile_frames);
+    const int T = choose_tile_frames(F, J, prm.kn, NP, ctx->num_cus, 0);
     const int64_t ntiles = (F + T - 1) / T;
     const int grid = (int)std::min<int64_t>(ntiles, resident);
     const size_t per_block = general_scratch_bytes(NP, J);
-    int rc = ctx->work.ensure(per_block * (size_t)grid);
+    int rc = ctx->cur->work.ensure(per_block * (size_t)grid);
     if (rc) return rc;
     const size_t lds = fused_single_lds_bytes(T, prm.kn, NP);
     auto kern = k_fused_single<C, METHOD, TIn, TOut>;
     if (lds > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        {
+            if (ctx->raise_lds((const void *)kern, (int)lds)) {
+                g_last_error = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed";
+                return SNOWTRI_ERR_HIP;
+            }
+        }
     hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, st, F, J, T, ctx->rig(), d_kpts, d_np, prm, Pout,
-                       d_xyzs, d_ps, d_cnt, d_fl, (char *)ctx->work.p, per_block);
+                       d_xyzs, d_ps, d_cnt, d_fl, (char *)ctx->cur->work.p, per_block);
     HIP_TRY(hipGetLastError());
     static const std::string name = std::string("k_fused_single<") + std::to_string(C) + "," + std::to_string(METHOD) + "," +
                                     type_name<TIn>() + "," + type_name<TOut>() + ">";
@@ -1354,7 +1482,7 @@ int launch_fused_lean(snowtri_ctx *ctx, hipStream_t st, int64_t F, const TIn *d_
         const int64_t rem = F % grid;
         const int nf_max = base + (rem ? 1 : 0);
         const size_t lds = lean_coop_lds_bytes(C, kLeanJ, nf_max);
-        int rc = ctx->work.ensure(per_block * (size_t)grid);
+        int rc = ctx->cur->work.ensure(per_block * (size_t)grid);
         if (rc) return rc;
         if (lds > 48 * 1024 && ctx->raise_lds((const void *)kc, (int)lds)) return SNOWTRI_ERR_HIP;
         if (ctx->debug) fprintf(stderr, "k_fused_lean_coop: F %lld grid %d frames per tile %d (+1 for %lld) lds %zu\n", (long long)F, grid, base, (long long)rem, lds);
@@ -1363,11 +1491,11 @@ int launch_fused_lean(snowtri_ctx *ctx, hipStream_t st, int64_t F, const TIn *d_
             // them (what rocprofv3's kernel trace reads), without the two barrier packets of a bracketing pair in the interval
             const int64_t slot = ctx->ev_count % kTimingRing;
             hipExtLaunchKernelGGL(kc, dim3(grid), dim3(kBlock), lds, st, ctx->ev_ring[2 * slot], ctx->ev_ring[2 * slot + 1], 0,
-                                  F, base, rem, nf_max, ctx->rig(), d_kpts, d_np, prm, d_xyzs, d_ps, d_cnt, d_fl, (char *)ctx->work.p, per_block);
+                                  F, base, rem, nf_max, ctx->rig(), d_kpts, d_np, prm, d_xyzs, d_ps, d_cnt, d_fl, (char *)ctx->cur->work.p, per_block);
             ctx->ev_attached = true;
         } else {
             hipLaunchKernelGGL(kc, dim3(grid), dim3(kBlock), lds, st, F, base, rem, nf_max, ctx->rig(), d_kpts, d_np, prm, d_xyzs, d_ps, d_cnt, d_fl,
-                               (char *)ctx->work.p, per_block);
+                               (char *)ctx->cur->work.p, per_block);
         }
         HIP_TRY(hipGetLastError());
         static const std::string cname = std::string("k_fused_lean_coop<") + std::to_string(C) + "," + type_name<TIn>() + "," +
@@ -1399,10 +1527,15 @@ int launch_fused_lean(snowtri_ctx *ctx, hipStream_t st, int64_t F, const TIn *d_
         const int64_t rem = Fs % ntiles;
         const int slow_words = (int)((tiles_per_wave * kLeanWaves * (1 << kLeanSlowShift) + 31) / 32);
         const size_t lds = lean_lds_bytes(C, kLeanJ, slow_words);
-        int rc = ctx->work.ensure(per_block * (size_t)grid);
+        int rc = ctx->cur->work.ensure(per_block * (size_t)grid);
         if (rc) return rc;
         if (lds > 48 * 1024)
-            HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            {
+            if (ctx->raise_lds((const void *)kern, (int)lds)) {
+                g_last_error = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed";
+                return SNOWTRI_ERR_HIP;
+            }
+        }
         if (ctx->debug) {
             int occ = 0;
             (void)hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, kern, kBlock, lds);
@@ -1413,13 +1546,13 @@ int launch_fused_lean(snowtri_ctx *ctx, hipStream_t st, int64_t F, const TIn *d_
             const int64_t slot = ctx->ev_count % kTimingRing;
             hipExtLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, st, ctx->ev_ring[2 * slot], ctx->ev_ring[2 * slot + 1], 0,
                                   Fs, ntiles, base, rem, slow_words, ctx->rig(), d_kpts, d_np, prm, d_xyzs, d_ps, d_cnt, d_fl,
-                                  (char *)ctx->work.p, per_block);
+                                  (char *)ctx->cur->work.p, per_block);
             ctx->ev_attached = true;
         } else {
             hipLaunchKernelGGL(kern, dim3(grid), dim3(kBlock), lds, st, Fs, ntiles, base, rem, slow_words, ctx->rig(),
                                d_kpts + s0 * (int64_t)(C * kLeanJ * 3), d_np ? d_np + s0 * C : nullptr, prm,
                                d_xyzs + s0 * (int64_t)(kLeanJ * 4), d_ps ? d_ps + s0 : nullptr, d_cnt + s0,
-                               d_fl ? d_fl + s0 : nullptr, (char *)ctx->work.p, per_block);
+                               d_fl ? d_fl + s0 : nullptr, (char *)ctx->cur->work.p, per_block);
         }
         HIP_TRY(hipGetLastError());
     }
@@ -1440,14 +1573,19 @@ int launch_frame_general(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax, 
     const size_t per_block = std::max<size_t>(256, general_scratch_bytes(Kc, J));
     int64_t grid = std::min<int64_t>(F, (int64_t)ctx->num_cus * 2);
     grid = std::max<int64_t>(1, std::min<int64_t>(grid, (int64_t)(kMaxScratchBytes / per_block)));
-    int rc = ctx->work.ensure(per_block * (size_t)grid);
+    int rc = ctx->cur->work.ensure(per_block * (size_t)grid);
     if (rc) return rc;
     const size_t lds = condense_lds_bytes((int)Kc);
     auto kern = k_frame_general<TIn, TOut>;
     if (lds > 48 * 1024)
-        HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        {
+            if (ctx->raise_lds((const void *)kern, (int)lds)) {
+                g_last_error = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed";
+                return SNOWTRI_ERR_HIP;
+            }
+        }
     hipLaunchKernelGGL(kern, dim3((int)grid), dim3(kBlock), lds, st, F, Pmax, J, (int)Kc, ctx->rig(), d_kpts, d_np,
-                       prm, Pout, d_xyzs, d_ps, d_cnt, d_fl, (char *)ctx->work.p, per_block);
+                       prm, Pout, d_xyzs, d_ps, d_cnt, d_fl, (char *)ctx->cur->work.p, per_block);
     HIP_TRY(hipGetLastError());
     static const std::string name = std::string("k_frame_general<") + type_name<TIn>() + "," + type_name<TOut>() + ">";
     ctx->last_kernels = name.c_str();
@@ -1462,23 +1600,19 @@ int launch_cluster_fuse(snowtri_ctx *ctx, hipStream_t st, int64_t Fs, int Pmax, 
                         int Pout, float *d_xyzs, const ClusterDesc *desc, const uint32_t *words,
                         const unsigned long long *cnt, uint32_t cap) {
     const int64_t passes_max = (Fs * Pout * (int64_t)J + 63) / 64;
-    // exactly the waves that are resident at once (two per SIMD at this kernel's registers), each striding over the passes:
-    // with the member lists in a kernel of their own every pass costs the same, and short-lived workgroups only added their
-    // start-up (8 x 4: 334 -> 312 us); a knob value > 0 asks for that many passes per wave when every frame fills its slots.
-    // (k_cluster_members on a second stream beside this kernel: measured, no gain -- 1.34 ms either way.)
-    const int ppw = ctx->cluster_ppw > 0 ? ctx->cluster_ppw : (1 << 30);
-    const int64_t W = std::max<int64_t>((passes_max + ppw - 1) / ppw, std::min<int64_t>(passes_max, (int64_t)ctx->num_cus * 4 * SNOWTRI_CLUSTER_WAVES));
+    // exactly the waves that are resident at once (kClusterWaves per SIMD at this kernel's registers), each striding over
+    // the passes: with the member lists in a kernel of their own every pass costs the same, and short-lived workgroups only
+    // added their start-up (8 x 4: 334 -> 312 us).  (k_cluster_members on a second stream beside this kernel: measured, no gain.)
+    const int64_t W = std::min<int64_t>(passes_max, (int64_t)ctx->num_cus * 4 * kClusterWaves);
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((W + kBlock / 64 - 1) / (kBlock / 64), (int64_t)ctx->num_cus * 64));
     const unsigned long long jmagic = (((unsigned long long)1 << 40) + (unsigned long long)J - 1) / (unsigned long long)J;
-    hipLaunchKernelGGL((k_cluster_fuse<C, TIn>), dim3(grid), dim3(kBlock), cluster_lds_bytes(C), st, desc, words, cnt, cap, ctx->rig(),
-                       d_kpts, prm, Pmax, J, jmagic, Pout, d_xyzs, ctx->cluster_split ? 0 : 1);
+    hipLaunchKernelGGL((k_cluster_fuse<C, TIn>), dim3(grid), dim3(kBlock), cluster_lds_bytes(C), st, desc, cnt, cap, ctx->rig(), d_kpts, prm,
+                       Pmax, J, jmagic, Pout, d_xyzs);
     HIP_TRY(hipGetLastError());
-    if (ctx->cluster_split) {
-        const int gridm = (int)std::max<int64_t>(1, std::min<int64_t>((passes_max + 3) / 4, (int64_t)ctx->num_cus * 16));
-        hipLaunchKernelGGL((k_cluster_members<TIn>), dim3(gridm), dim3(kBlock), cluster_members_lds_bytes(C, ctx->npairs), st, desc, words, cnt,
-                           cap, ctx->rig(), d_kpts, prm, Pmax, J, jmagic, Pout, d_xyzs);
-        HIP_TRY(hipGetLastError());
-    }
+    const int gridm = (int)std::max<int64_t>(1, std::min<int64_t>((passes_max + 3) / 4, (int64_t)ctx->num_cus * 16));
+    hipLaunchKernelGGL((k_cluster_members<TIn>), dim3(gridm), dim3(kBlock), cluster_members_lds_bytes(C, ctx->npairs), st, desc, words, cnt,
+                       cap, ctx->rig(), d_kpts, prm, Pmax, J, jmagic, Pout, d_xyzs);
+    HIP_TRY(hipGetLastError());
     return SNOWTRI_OK;
 }
 
@@ -1488,7 +1622,7 @@ struct SumsLaunch {
 };
 SumsLaunch sums_launch_shape(const snowtri_ctx *ctx, int Pmax, int J) {
     const int C = ctx->C, gs = p1_group_size(Pmax);
-    const int64_t nitems = (int64_t)ctx->npairs * (Pmax / (gs >= 2 ? SNOWTRI_SUMS_GA : 1)) * (Pmax / gs);   // (k_candidate_sums: GA x GS tiles)
+    const int64_t nitems = (int64_t)ctx->npairs * (Pmax / (gs >= 2 ? kSumsGA : 1)) * (Pmax / gs);   // (k_candidate_sums: GA x GS tiles)
     SumsLaunch L;
     // one pass over the items should keep every wave busy: 256 threads for the small rigs, the whole CU for the large
     L.threads = ctx->sums_threads > 0 ? ctx->sums_threads : (nitems <= 256 ? 256 : (nitems <= 768 ? 512 : 1024));
@@ -1506,7 +1640,7 @@ SumsLaunch sums_launch_shape(const snowtri_ctx *ctx, int Pmax, int J) {
 // pairwise method, <= 16 cameras -- the streaming association of snowtri_assoc.hpp with k_frame_recompute for the frames
 // it leaves behind.
 template <int METHOD, typename TIn, typename TOut>
-int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax, int J, const TIn *d_kpts,
+int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st_call, int64_t F, int Pmax, int J, const TIn *d_kpts,
                            const int32_t *d_np, const Params &prm, int Pout, TOut *d_xyzs, TOut *d_ps,
                            int32_t *d_cnt, uint32_t *d_fl) {
     const int64_t Kc = snowtri_num_candidate_slots(ctx->C, Pmax);
@@ -1521,7 +1655,12 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax
         // exactly the workgroups that are resident at once (registers and the ~50 KB of LDS decide: 3 per CU);
         // they pull frames from an atomic counter until none are left
         if (lds > 48 * 1024)
-            HIP_TRY(hipFuncSetAttribute((const void *)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            {
+            if (ctx->raise_lds((const void *)kern, (int)lds)) {
+                g_last_error = "hipFuncSetAttribute(MaxDynamicSharedMemorySize) failed";
+                return SNOWTRI_ERR_HIP;
+            }
+        }
         int q = 0;
         HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, kern, kBlock, lds));
         oc.lds = lds;
@@ -1529,7 +1668,6 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax
         if (ctx->debug) fprintf(stderr, "k_frame_recompute: R %d Kc %lld lds %zu occupancy/CU %d\n", R, (long long)Kc, lds, q);
     }
     int per_cu = oc.per_cu;
-    if (ctx->recompute_wg_per_cu > 0) per_cu = ctx->recompute_wg_per_cu;
     // Hand-over of the output persons to the streaming fusion kernels (snowtri_cluster.hpp): float32 outputs, pairwise
     // method, 4-bit person fields, a person's mean score derivable from the candidate means (keypoint_num == J,
     // non-negative scores).  handover_mode 1: the streaming association (<= 16 cameras); 2: descriptors written by
@@ -1552,9 +1690,32 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax
                                                           ((int64_t)1 << 31) / R));
     if (stream) seg_frames = std::max<int64_t>(1, std::min<int64_t>(seg_frames, ((int64_t)64 << 20) / Kc));
     const int64_t seg_cap = ctx->handover_seg_frames > 0 ? ctx->handover_seg_frames : seg_frames;
-    const int64_t seg = (stream || handover) ? std::min(seg_frames, seg_cap) : F;
-    unsigned long long *next_frame = ctx->d_counters + 2, *hand_counters = ctx->d_counters + kHandCountersAt, *slow_count = ctx->d_counters + 6,
-                       *exact_count = ctx->d_counters + 7, *slow_count2 = ctx->d_counters + 8, *sums_ticket = ctx->d_counters + 9;
+    int64_t seg = (stream || handover) ? std::min(seg_frames, seg_cap) : F;
+    // ONE call in (at least) two segments on two stream sets: every kernel of the streaming route holds the whole chip
+    // while it runs, and a third of the route's time is latency-bound (k_associate: VALU busy ~20 %, the member lists);
+    // with the segments alternating between the caller's stream and an internal one, those kernels of one segment run
+    // beside the VALU-bound ones of the other (8 x 4: +8 % against one stream; what round 3 measured with two CALLS in
+    // flight on two contexts, now inside the call).  Outputs do not depend on the cut (tests/test_gpu_handover.py).  Not
+    // in overlap mode (whole calls already alternate over the sets) and not for batches too small to fill the chip twice.
+    StreamSet *const set_call = ctx->cur;
+    bool split = stream && ctx->split_segments >= 2 && ctx->overlap <= 1 && set_call == &ctx->sets[0];
+    if (split) {
+        int64_t nseg = std::max<int64_t>((F + seg - 1) / seg, ctx->split_segments);
+        nseg += nseg & 1;
+        const int64_t even = (F + nseg - 1) / nseg;
+        if (even >= (ctx->split_forced ? 1 : (int64_t)ctx->num_cus * 4))   // (the knob set explicitly: tests split small batches too)
+            seg = even;
+        else
+            split = false;
+    }
+    if (split) {
+        if (ctx->ensure_set(1)) {
+            g_last_error = "creating the internal stream of the multi-person split failed";
+            return SNOWTRI_ERR_HIP;
+        }
+        HIP_TRY(hipEventRecord(ctx->ev_fork, st_call));
+        HIP_TRY(hipStreamWaitEvent(ctx->sets[1].stream, ctx->ev_fork, 0));
+    }
     const uint32_t *final_slow_list = nullptr;                 // what the streaming association leaves to k_frame_recompute
     const unsigned long long *final_slow_count = nullptr;
     {   // the kernels of this route, in launch order (rebuilt only when the route changes)
@@ -1563,7 +1724,7 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax
         if (key != ctx->names_key) {
             const std::string tin = type_name<TIn>(), tout = type_name<TOut>();
             const std::string rec = "k_frame_recompute<" + std::to_string(METHOD) + "," + tin + "," + tout + ">";
-            const std::string fuse = C <= kClusterMaxCams ? "k_cluster_fuse<" + std::to_string(C) + "," + tin + ">" + (ctx->cluster_split ? " + k_cluster_members<" + tin + ">" : std::string())
+            const std::string fuse = C <= kClusterMaxCams ? "k_cluster_fuse<" + std::to_string(C) + "," + tin + "> + k_cluster_members<" + tin + ">"
                                                            : "k_cluster_fuse_wide<" + tin + "> + k_cluster_members<" + tin + ">";
             if (stream)
                 ctx->names_buf = "k_candidate_sums<" + tin + "," + std::to_string(SL.threads) + "> + k_candidate_sums_exact<" + tin +
@@ -1577,11 +1738,18 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax
         ctx->last_kernels = ctx->names_buf.c_str();
     }
     const unsigned long long jmagic = (((unsigned long long)1 << 40) + (unsigned long long)J - 1) / (unsigned long long)J;
-    for (int64_t s0 = 0; s0 < F; s0 += seg) {
+    int seg_index = 0;
+    for (int64_t s0 = 0; s0 < F; s0 += seg, seg_index++) {
         const int64_t Fs = std::min<int64_t>(seg, F - s0);
+        StreamSet &S = split && (seg_index & 1) ? ctx->sets[1] : *set_call;
+        const hipStream_t st = split && (seg_index & 1) ? S.stream : st_call;
+        ctx->cur = &S;
+        ctx->last_set = &S;
+        unsigned long long *next_frame = S.d_counters + 2, *hand_counters = S.d_counters + kHandCountersAt, *slow_count = S.d_counters + 6,
+                           *exact_count = S.d_counters + 7, *slow_count2 = S.d_counters + 8, *sums_ticket = S.d_counters + 9;
         int64_t grid = std::min<int64_t>(Fs, (int64_t)ctx->num_cus * std::max(1, per_cu));
         grid = std::max<int64_t>(1, std::min<int64_t>(grid, (int64_t)(kMaxScratchBytes / per_block)));
-        int rc = ctx->work.ensure(per_block * (size_t)grid);
+        int rc = ctx->cur->work.ensure(per_block * (size_t)grid);
         if (rc) return rc;
         uint32_t cap = 0, word_cap = 0;
         ClusterDesc *desc = nullptr;
@@ -1590,9 +1758,9 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax
             ctx->last_handover = true;
             cap = (uint32_t)(Fs * Pout);
             word_cap = (uint32_t)(Fs * Kc);
-            rc = ctx->desc.ensure((size_t)2 * cap * sizeof(ClusterDesc) + (size_t)word_cap * 4);
+            rc = ctx->cur->desc.ensure((size_t)2 * cap * sizeof(ClusterDesc) + (size_t)word_cap * 4);
             if (rc) return rc;
-            desc = (ClusterDesc *)ctx->desc.p;
+            desc = (ClusterDesc *)ctx->cur->desc.p;
             words = (uint32_t *)(desc + (size_t)2 * cap);
         }
         HIP_TRY(hipMemsetAsync(next_frame, 0, (kCounterWords - 2) * sizeof(unsigned long long), st));   // next_frame, slow / exact / slow (second pass) frames, the frame tickets of k_candidate_sums, the hand-over list counters
@@ -1605,10 +1773,10 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax
             if (stream) {
                 // ---- k_candidate_sums -> k_associate -> k_cluster_fuse, then k_frame_recompute on the frames left behind
                 const size_t sum_bytes = ((size_t)Fs * Kc * 8 + 255) & ~(size_t)255;
-                rc = ctx->sums.ensure(sum_bytes + (size_t)Fs * 12 + 256);   // + the frames left behind (two passes) + the frames to re-do exactly
+                rc = ctx->cur->sums.ensure(sum_bytes + (size_t)Fs * 12 + 256);   // + the frames left behind (two passes) + the frames to re-do exactly
                 if (rc) return rc;
-                double *csum = (double *)ctx->sums.p;
-                uint32_t *slow_list = (uint32_t *)((char *)ctx->sums.p + sum_bytes);
+                double *csum = (double *)ctx->cur->sums.p;
+                uint32_t *slow_list = (uint32_t *)((char *)ctx->cur->sums.p + sum_bytes);
                 auto k2 = k_associate<TIn>;
                 const size_t lds2 = associate_lds_bytes(C, ctx->npairs, Pout, Kc);
                 const int grid1 = (int)std::min<int64_t>(Fs, (int64_t)ctx->num_cus * SL.per_cu);
@@ -1658,7 +1826,7 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax
         }
         if (!stream) {
             hipLaunchKernelGGL(kern, dim3((int)grid), dim3(kBlock), lds, st, Fs, Pmax, J, (int)Kc, ctx->rig(), kp_seg, np_seg, prm, Pout,
-                               xyz_seg, ps_seg, d_cnt + s0, fl_seg, (char *)ctx->work.p, per_block, next_frame, (int)lds, desc, words,
+                               xyz_seg, ps_seg, d_cnt + s0, fl_seg, (char *)ctx->cur->work.p, per_block, next_frame, (int)lds, desc, words,
                                hand_counters, cap, word_cap, (const uint32_t *)nullptr, (const unsigned long long *)nullptr);
             HIP_TRY(hipGetLastError());
         }
@@ -1688,7 +1856,7 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax
                             const size_t ldsw = cluster_wide_lds_bytes(C);
                             if (ldsw > 48 * 1024 && ctx->raise_lds((const void *)kw, (int)ldsw)) return SNOWTRI_ERR_HIP;
                             const int64_t wpasses = (Fs * Pout * (int64_t)J + 15) / 16;   // 16 items per wave pass
-                            const int ppw_wide = ctx->cluster_ppw > 0 ? ctx->cluster_ppw : 8;   // (many short-lived workgroups here: 6 -> 886, 24 -> 906, 400 -> 1042 us per 4 000 frames of 16 x 8)
+                            const int ppw_wide = 8;   // (many short-lived workgroups here: 6 -> 886, 24 -> 906, 400 -> 1042 us per 4 000 frames of 16 x 8)
                             const int gridw = (int)std::max<int64_t>(1, std::min<int64_t>((wpasses + 4 * ppw_wide - 1) / (4 * ppw_wide),
                                                                                          (int64_t)ctx->num_cus * 64));
                             hipLaunchKernelGGL(kw, dim3(gridw), dim3(kBlock), ldsw, st, desc, hand_counters, cap, ctx->rig(), kp_seg, prm, Pmax, J,
@@ -1706,13 +1874,19 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax
                 // the frames k_associate listed (slow_count of them, known on the device only): phase 3 inside the kernel
                 const int gridr = (int)std::max<int64_t>(1, std::min<int64_t>(grid, ctx->num_cus));
                 hipLaunchKernelGGL(kern, dim3(gridr), dim3(kBlock), lds, st, Fs, Pmax, J, (int)Kc, ctx->rig(), kp_seg, np_seg, prm, Pout,
-                                   xyz_seg, ps_seg, d_cnt + s0, fl_seg, (char *)ctx->work.p, per_block, next_frame, (int)lds,
+                                   xyz_seg, ps_seg, d_cnt + s0, fl_seg, (char *)ctx->cur->work.p, per_block, next_frame, (int)lds,
                                    (ClusterDesc *)nullptr, (uint32_t *)nullptr, hand_counters, 0u, 0u,
                                    final_slow_list, final_slow_count);
                 HIP_TRY(hipGetLastError());
             }
         }
     }
+    ctx->cur = set_call;
+    if (split) {   // the caller's stream continues behind the internal one
+        HIP_TRY(hipEventRecord(ctx->sets[1].done, ctx->sets[1].stream));
+        HIP_TRY(hipStreamWaitEvent(st_call, ctx->sets[1].done, 0));
+    }
+    ctx->last_stream = stream;
     return SNOWTRI_OK;
 }
 
@@ -1847,6 +2021,29 @@ extern "C" int snowtri_triangulate_condense(snowtri_ctx *ctx, int64_t F, int32_t
     if (rc) return rc;
     ENTER_DEVICE(ctx->device);
     hipStream_t st = (hipStream_t)stream;
+    ctx->cur = &ctx->sets[0];
+    ctx->last_set = &ctx->sets[0];
+    ctx->last_stream = false;
+    StreamSet *oset = nullptr;
+    if (memspace == SNOWTRI_DEVICE && ctx->overlap >= 2) {
+        // overlap mode: this call runs on the next internal stream behind everything `stream` holds now; the caller's
+        // stream sees its results after snowtri_ctx_join
+        const int k = (int)(ctx->call_index++ % ctx->overlap);
+        if (ctx->ensure_set(k)) {
+            g_last_error = "creating an internal stream of the overlap mode failed";
+            return SNOWTRI_ERR_HIP;
+        }
+        oset = &ctx->sets[k];
+        // the internal stream runs behind whatever the caller's stream holds now; an idle caller stream (the usual loop of
+        // calls on resident inputs) needs no event pair: one query instead of a record + a wait per call
+        if (hipStreamQuery(st) != hipSuccess) {
+            (void)hipGetLastError();
+            HIP_TRY(hipEventRecord(ctx->ev_fork, st));
+            HIP_TRY(hipStreamWaitEvent(oset->stream, ctx->ev_fork, 0));
+        }
+        ctx->cur = ctx->last_set = oset;
+        st = oset->stream;
+    }
     const int kn = prm.kn;
     const size_t isz = dtype_size(in_dtype), osz = dtype_size(out_dtype);
     const size_t in_bytes = (size_t)F * ctx->C * Pmax * J * 3 * isz;
@@ -1886,9 +2083,9 @@ extern "C" int snowtri_triangulate_condense(snowtri_ctx *ctx, int64_t F, int32_t
         d_cnt = (int32_t *)(o + cnt_off);
         d_fl = (uint32_t *)(d_cnt + F);
     } else if (!d_fl) {
-        rc = ctx->misc.ensure(sizeof(uint32_t) * F);
+        rc = ctx->cur->misc.ensure(sizeof(uint32_t) * F);
         if (rc) return rc;
-        d_fl = (uint32_t *)ctx->misc.p;
+        d_fl = (uint32_t *)ctx->cur->misc.p;
     }
     // no memsets: the kernels own every output word, including the per-frame flags
     ctx->last_slow_frames = -1;
@@ -1906,7 +2103,9 @@ extern "C" int snowtri_triangulate_condense(snowtri_ctx *ctx, int64_t F, int32_t
     else
         rc = fused_dispatch<double, double>(ctx, st, F, Pmax, J, d_kpts, d_np, prm, Pout_max, d_xyzs, d_ps, d_cnt, d_fl, method);
 #endif
+    ctx->cur = &ctx->sets[0];
     if (rc) return rc;
+    if (oset) oset->pending = true;   // (its `done` event is recorded once, by snowtri_ctx_join)
     if (memspace == SNOWTRI_HOST) {
         std::vector<uint32_t> fl_host;
         uint32_t *fl = out_flags;

@@ -26,17 +26,13 @@ namespace snowtri {
 constexpr int kSumsHeadBytes = 64;
 // workgroup shapes (threads, waves per SIMD the registers must allow, records of the coming chunk a thread holds in
 // registers): 256 threads x 3 workgroups per CU for the small rigs, 512 x 2 or 1024 x 1 for the large ones
-#ifndef SNOWTRI_SUMS_WAVES256
-#define SNOWTRI_SUMS_WAVES256 3   // (4 waves per SIMD = 128 registers: the 2 x 4 tile spills, 8 x 4 measured 1027 us against 729)
-#endif
+constexpr int kSumsWaves256 = 3;   // (4 waves per SIMD = 128 registers: the 2 x 4 tile spills, 8 x 4 measured 1027 us against 729)
 template <int THREADS>
 struct SumsShape {
-    static constexpr int kWavesPerSimd = THREADS == 256 ? SNOWTRI_SUMS_WAVES256 : 4;
+    static constexpr int kWavesPerSimd = THREADS == 256 ? kSumsWaves256 : 4;
     static constexpr int kPrefetch = THREADS == 256 ? 3 : 2;
 };
-#ifndef SNOWTRI_SUMS_GA
-#define SNOWTRI_SUMS_GA 2   // persons of the FIRST camera per tile (when the person count is even)
-#endif
+constexpr int kSumsGA = 2;   // persons of the FIRST camera per tile (when the person count is even)
 
 __host__ __device__ inline size_t sums_arena_offset(int C, int npairs) {
     return ((size_t)kSumsHeadBytes + (size_t)4 * C + (size_t)32 * npairs + (size_t)72 * C + 15) & ~(size_t)15;
@@ -66,7 +62,7 @@ __host__ __device__ inline int sums_chunk_joints(int C, int Pmax, int J, int npa
     if (cap < 1) return 0;
     const int nch = (J + cap - 1) / cap;
     int jc = (J + nch - 1) / nch;   // 133 joints, room for 40 -> 34 + 33 + 33 + 33, not 3 x 40 + 13
-    const int gs = p1_group_size(Pmax), ga = gs >= 2 ? SNOWTRI_SUMS_GA : 1;
+    const int gs = p1_group_size(Pmax), ga = gs >= 2 ? kSumsGA : 1;
     const long long nitems = (long long)npairs * (Pmax / ga) * (Pmax / gs);
     if (nitems * 2 <= threads) {
         const int js = sums_joint_split((int)nitems, threads / 64);
@@ -206,14 +202,12 @@ __global__ __launch_bounds__(THREADS, SumsShape<THREADS>::kWavesPerSimd) void k_
         if (n_persons && tid < C) npv = n_persons[fr * C + tid];
     };
     auto commit = [&](char *buf) {
-#ifndef SNOWTRI_K1_NOFILL   // dev experiment (timing only, outputs are wrong)
 #pragma unroll
         for (int n = 0; n < NPF; n++)
             if (pre_off[n] >= 0) {
                 SNOWTRI_DEV_CHECK((pre_off[n] & 0xfffff) + kP1Rec <= half && (pre_off[n] >> 20) < C, 11);   // record inside the buffer
                 p1_store_record<TIn>(buf + (pre_off[n] & 0xfffff), make_ray(Ml + 9 * (pre_off[n] >> 20), pre[n].u, pre[n].v), pre[n].s);
             }
-#endif
     };
 
     int64_t f = blockIdx.x;
@@ -237,7 +231,7 @@ __global__ __launch_bounds__(THREADS, SumsShape<THREADS>::kWavesPerSimd) void k_
         const int64_t fnext = (int64_t)gridDim.x + (int64_t)(uint32_t)hd[2];
         if (nch == 1 && fnext < F) fetch_frame(fnext);
         const int GS = hd[1] ? 1 : p1_group_size(Pmax);   // a ragged frame keeps one candidate per lane
-        const int GA = GS >= 2 ? SNOWTRI_SUMS_GA : 1;      // (GS >= 2: Pmax is even)
+        const int GA = GS >= 2 ? kSumsGA : 1;      // (GS >= 2: Pmax is even)
         const int NG = Pmax / GS, per_q = (Pmax / GA) * NG, nitems = rig.npairs * per_q;
         int JS = sums_joint_split(nitems, NW);
         const bool single = nitems * JS <= B && (JS == 1 || (size_t)JS * Kc * 8 <= (size_t)half);
@@ -250,7 +244,7 @@ __global__ __launch_bounds__(THREADS, SumsShape<THREADS>::kWavesPerSimd) void k_
 
         // one loop nest per (tile, SINGLE): the variants share no registers with loads in flight
         auto frame_body = [&](auto gs_c, auto single_c) {
-            constexpr int GSC = decltype(gs_c)::value, GAC = GSC >= 2 ? SNOWTRI_SUMS_GA : 1, NT = GAC * GSC;
+            constexpr int GSC = decltype(gs_c)::value, GAC = GSC >= 2 ? kSumsGA : 1, NT = GAC * GSC;
             constexpr bool SINGLE = decltype(single_c)::value;
             // item of (round base, lane) -> first candidate slot, record offsets of its rows, pair offset; live?
             struct Item {
@@ -289,17 +283,9 @@ __global__ __launch_bounds__(THREADS, SumsShape<THREADS>::kWavesPerSimd) void k_
                 const char *cur = rec0 + ((par ^ c) & 1) * half;
                 // the waves of joint sub-range jsub walk joints [jlo, jhi) of the chunk (the sub-ranges rotate from chunk to
                 // chunk: where the joints of a chunk do not divide by JS every wave gets the long sub-range in turn)
-#ifdef SNOWTRI_K1_NOSOLVE   // dev experiment (timing only, outputs are wrong)
-                const int jlo = 0, jhi = 0;
-#else
                 const int jrot = (jsub + c) & (JS - 1);
                 const int jlo = jrot * nj / JS, jhi = (jrot + 1) * nj / JS;
-#endif
                 if constexpr (SINGLE) {
-#ifdef SNOWTRI_K1_REPEAT   // dev experiment (timing only, sums x N): the solve phase N times -- its slope is the solve time alone
-                    for (int rep = 1; rep < SNOWTRI_K1_REPEAT; rep++)
-                        p1_tile_sums<GAC, GSC, TIn>(cur + jlo * jstr + mine.oa, cur + jlo * jstr + mine.ob, jstr, mine.cand ? jhi - jlo : 0, mine.d, prm, tot);
-#endif
                     p1_tile_sums<GAC, GSC, TIn>(cur + jlo * jstr + mine.oa, cur + jlo * jstr + mine.ob, jstr, mine.cand ? jhi - jlo : 0, mine.d, prm, tot);
                 } else {
                     for (int base = iw * 64; base < nitems; base += wpg * 64) {

@@ -64,9 +64,7 @@ struct ClusterPairs {
     static constexpr Tab tab = make();
 };
 __host__ __device__ constexpr int cluster_const_doubles(int C) { return 12 * C + 3 * (C * (C - 1) / 2); }  // M[C][9], t[C][3], d[NP][3]
-__host__ __device__ constexpr size_t cluster_lds_bytes(int C) {   // + pairc[NP][6], pairs[NP][2] (int32) for the member lists
-    return (size_t)8 * (cluster_const_doubles(C) + 6 * (C * (C - 1) / 2)) + (size_t)8 * (C * (C - 1) / 2) + 16;
-}
+__host__ __device__ constexpr size_t cluster_lds_bytes(int C) { return (size_t)8 * cluster_const_doubles(C) + 16; }
 
 // compile-time loop: f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N - 1>)
 template <typename F, int... I>
@@ -280,33 +278,22 @@ __device__ __forceinline__ void cluster_member_passes(const ClusterDesc *__restr
 // cnt[kHandComplete], cnt[kHandMembers] >> 32: descriptors in desc[0, cap) (complete graphs) and desc[cap, 2 cap) (member lists).
 // Dynamic LDS: cluster_lds_bytes(C).
 //   jmagic = ceil(2^40 / J): item / J = (item * jmagic) >> 40 for item < 2^31, J <= 256.
-#ifndef SNOWTRI_CLUSTER_WAVES
-#define SNOWTRI_CLUSTER_WAVES 2
-#endif
-#ifndef SNOWTRI_CLUSTER_PREFETCH
-#define SNOWTRI_CLUSTER_PREFETCH 1   // 0: no register prefetch of the next pass (dev A/B: fewer registers, more waves)
-#endif
+constexpr int kClusterWaves = 3;
 template <int C, typename TIn>
-__global__ __launch_bounds__(kBlock, SNOWTRI_CLUSTER_WAVES) void k_cluster_fuse(const ClusterDesc *__restrict__ desc,
-                                                          const uint32_t *__restrict__ words,
+__global__ __launch_bounds__(kBlock, kClusterWaves) void k_cluster_fuse(const ClusterDesc *__restrict__ desc,
                                                           const unsigned long long *__restrict__ cnt, uint32_t desc_cap,
                                                           Rig rig, const TIn *__restrict__ kpts, Params prm, int Pmax, int J,
-                                                          unsigned long long jmagic, int Pout, float *__restrict__ out4, int with_members) {
+                                                          unsigned long long jmagic, int Pout, float *__restrict__ out4) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NP = C * (C - 1) / 2;
-    double *K = reinterpret_cast<double *>(smem);   // [M | t | d] for cluster_item, then [pairc | pairs] for the member lists
-    double *pc = K + cluster_const_doubles(C);
-    int32_t *pairs_l = reinterpret_cast<int32_t *>(pc + 6 * NP);
+    double *K = reinterpret_cast<double *>(smem);   // [M | t | d] for cluster_item
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     for (int i = tid; i < 9 * C; i += kBlock) K[i] = rig.M[i];
     if (tid < 3 * C) K[9 * C + tid] = rig.t[tid];
     if (tid < 3 * NP) K[12 * C + tid] = rig.pairc[6 * (tid / 3) + tid % 3];
-    for (int i = tid; i < 6 * NP; i += kBlock) pc[i] = rig.pairc[i];
-    if (tid < 2 * NP) pairs_l[tid] = rig.pairs[tid];
-    const unsigned long long nd64 = cnt[kHandComplete], ng64 = hand_member_descs(cnt[kHandMembers]);
+    const unsigned long long nd64 = cnt[kHandComplete];
     const uint32_t ndesc = nd64 < (unsigned long long)desc_cap ? (uint32_t)nd64 : desc_cap;
-    const uint32_t ngen = ng64 < (unsigned long long)desc_cap ? (uint32_t)ng64 : desc_cap;
     const uint32_t total = ndesc * (uint32_t)J;
     const uint32_t npass = (total + 63u) >> 6;
     const uint32_t W = gridDim.x * (uint32_t)(kBlock / 64);
@@ -356,22 +343,10 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_CLUSTER_WAVES) void k_cluster_fuse(
     const uint32_t p_first = blockIdx.x * (uint32_t)(kBlock / 64) + (uint32_t)wave;
     uint32_t p = p_first;
     if (p < npass) {
-#if SNOWTRI_CLUSTER_PREFETCH
-        Kp3<TIn> cur[C], nxt[C];
-        Item it0 = locate(p);
-        fetch(cur, it0);
-        Item it1 = locate(p + W);
-#else
         Kp3<TIn> cur[C];
-#endif
         for (; p < npass; p += W) {
-#if SNOWTRI_CLUSTER_PREFETCH
-            fetch(nxt, it1);
-            const Item it2 = locate(p + 2 * W);
-#else
             const Item it0 = locate(p);
             fetch(cur, it0);
-#endif
             float ox, oy, oz, os;
             asm volatile("" ::: "memory");   // the rig constants are re-read from LDS in every pass (hoisted out of the loop they would take 360 registers)
             const bool bad = cluster_item<C, TIn>(K, cur, kthr_f32, kthr, dthr2, ox, oy, oz, os);
@@ -383,20 +358,10 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_CLUSTER_WAVES) void k_cluster_fuse(
                 float4 *o = reinterpret_cast<float4 *>(out4) + ((uint64_t)it0.frame * (uint32_t)Pout + it0.slot) * (uint64_t)(uint32_t)J + it0.j;
                 *o = make_float4(ox, oy, oz, os);
             }
-#if SNOWTRI_CLUSTER_PREFETCH
-#pragma unroll
-            for (int c = 0; c < C; c++) cur[c] = nxt[c];
-            it0 = it1;
-            it1 = it2;
-#endif
         }
     }
-    // the waves that ran the fewest complete-graph passes start on the member lists first (with_members = 0: the member
-    // lists are left to k_cluster_members, whose waves need a third of the registers -- a member pass is a chain of dependent
-    // loads per member, and at the two waves per SIMD of this kernel nothing hides them)
-    if (with_members)
-        cluster_member_passes<TIn>(desc + desc_cap, ngen, words, K, pc, pairs_l, C * Pmax, kp3, prm, J, jmagic, Pout, out4,
-                               (p_first + W - (npass % W)) % W, W);
+    // (the member-list clusters of the same launch: k_cluster_members -- a member pass is a chain of dependent loads per member,
+    // which this kernel's waves hid badly: 415 -> 336 + 70 us when they moved out)
 }
 
 
@@ -472,11 +437,9 @@ __device__ __noinline__ void cluster_joint_sequential_wide(const Rig &rig, const
     os = (float)s;
 }
 
-#ifndef SNOWTRI_WIDE_WAVES
-#define SNOWTRI_WIDE_WAVES 3
-#endif
+constexpr int kWideWaves = 3;
 template <typename TIn>
-__global__ __launch_bounds__(kBlock, SNOWTRI_WIDE_WAVES) void k_cluster_fuse_wide(const ClusterDesc *__restrict__ desc,
+__global__ __launch_bounds__(kBlock, kWideWaves) void k_cluster_fuse_wide(const ClusterDesc *__restrict__ desc,
                                                                                  const unsigned long long *__restrict__ cnt,
                                                                                  uint32_t desc_cap, Rig rig, const TIn *__restrict__ kpts,
                                                                                  Params prm, int Pmax, int J, unsigned long long jmagic,

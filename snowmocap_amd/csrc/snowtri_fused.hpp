@@ -107,12 +107,7 @@ __global__ __launch_bounds__(kBlock) void k_frame_general(int64_t F, int Pmax, i
 //   (seed 0 then absorbs all: one cluster);  the fused mean score is not below condense_score_tol.
 // Minimum waves per SIMD the fast kernel is compiled for (caps its VGPR allocation: 4 -> 128).
 // Depth of the register prefetch ring of k_fused_single (2 or 3 keypoint buffers per lane).
-#ifndef SNOWTRI_RING
-#define SNOWTRI_RING 3
-#endif
-#ifndef SNOWTRI_FAST_WAVES
-#define SNOWTRI_FAST_WAVES 2
-#endif
+constexpr int kFastWaves = 2;
 
 template <typename T>
 struct Vec4T {
@@ -146,13 +141,8 @@ __device__ __forceinline__ void fetch_item(Kp3<TIn> (&dst)[C], const Kp3<TIn> *_
                                            int j, int J, unsigned last_off) {
     unsigned off = (unsigned)(fl * C * J + j);
     off = off < last_off ? off : last_off;
-#ifdef SNOWTRI_COMPUTETEST  // dev experiment: arithmetic only, keypoints synthesised from the lane offset
-#pragma unroll
-    for (int c = 0; c < C; c++) dst[c] = Kp3<TIn>{(TIn)(600 + (off & 255) + 40 * c), (TIn)(300 + (off & 127) - 30 * c), (TIn)5};
-#else
 #pragma unroll
     for (int c = 0; c < C; c++) dst[c] = tile_in[off + (unsigned)(c * J)];
-#endif
 }
 
 // first two items of this lane in tile `tile` -> bufA, bufB
@@ -193,10 +183,6 @@ __device__ __forceinline__ bool pairwise_item(const Rig &rig, const double *__re
     // VGPR-lane spills and the remainder is re-fetched with serialised scalar loads every item.
     // Issue every LDS read of M and d up front into registers (sched_barrier keeps them there): one wait
     // per item instead of ~25 scattered ones (+2.5 % measured); t is read where it is used, at the end.
-#ifdef SNOWTRI_ITEM_TIMERS
-    unsigned long long ts0 = __builtin_amdgcn_s_memtime();
-    asm volatile("" : "+s"(ts0), "+v"(Mlds) :: "memory");   // the constant reads are issued after this stamp
-#endif
     double Mp[9 * C], pc[3 * (C * (C - 1) / 2)];
 #pragma unroll
     for (int i = 0; i < 9 * C; i++) Mp[i] = Mlds[i];
@@ -204,27 +190,6 @@ __device__ __forceinline__ bool pairwise_item(const Rig &rig, const double *__re
     for (int i = 0; i < 3 * (C * (C - 1) / 2); i++) pc[i] = Mlds[12 * C + i];
     __builtin_amdgcn_sched_barrier(0);
     const double *tp = Mlds + 9 * C;
-#ifdef SNOWTRI_MEMTEST  // dev experiment: memory path only, no solves
-    {
-        double su = 0, sv = 0, ss = 0;
-#pragma unroll
-        for (int c = 0; c < C; c++) {
-            su += (double)cur[c].u;
-            sv += (double)cur[c].v;
-            ss += (double)cur[c].s;
-        }
-        ox = su;
-        oy = sv;
-        oz = ss;
-        os = su + sv;
-        return false;
-    }
-#endif
-#ifdef SNOWTRI_ITEM_TIMERS  // dev experiment: cycle stamps of the item's stages replace its outputs
-    asm volatile("" :: "v"(Mp[0]), "v"(Mp[9 * C - 1]), "v"(pc[0]), "v"(pc[3 * (C * (C - 1) / 2) - 1]) : "memory");  // constants arrived
-    unsigned long long tm0 = __builtin_amdgcn_s_memtime();
-    asm volatile("" : "+s"(tm0), "+v"(Mp[0]), "+v"(Mp[9]), "+v"(Mp[18]), "+v"(Mp[27]) :: "memory");  // rays start after it
-#endif
     Vec3 h[C];
     double a[C], alpha[C], beta[C];
 #pragma unroll
@@ -236,11 +201,6 @@ __device__ __forceinline__ bool pairwise_item(const Rig &rig, const double *__re
         h[c].z = fma(Mp[9 * c + 6], u, fma(Mp[9 * c + 7], v, Mp[9 * c + 8]));
         a[c] = dot3(h[c], h[c]);
     }
-#ifdef SNOWTRI_ITEM_TIMERS
-    asm volatile("" :: "v"(a[0]), "v"(a[C - 1]), "v"(h[C - 1].z) : "memory");   // the rays are done here
-    unsigned long long tm1 = __builtin_amdgcn_s_memtime();
-    asm volatile("" : "+s"(tm1), "+v"(h[0].x) :: "memory");                       // nothing below starts earlier
-#endif
     bool bad = false;
     int q = 0;
     // one reciprocal for all C(C,2) determinants (Montgomery's trick): 1/det_q from 1/prod(det) and prefix
@@ -307,11 +267,6 @@ __device__ __forceinline__ bool pairwise_item(const Rig &rig, const double *__re
             }
         }
     }
-#ifdef SNOWTRI_ITEM_TIMERS
-    asm volatile("" :: "v"(alpha[0]), "v"(alpha[C - 1]), "v"(beta[C - 1]), "v"(beta[0]) : "memory");
-    unsigned long long tm2 = __builtin_amdgcn_s_memtime();
-    asm volatile("" : "+s"(tm2), "+v"(alpha[0]) :: "memory");
-#endif
     double sx = alpha[0] * h[0].x, sy = alpha[0] * h[0].y, sz = alpha[0] * h[0].z, sb = beta[0];
     sx = fma(beta[0], tp[0], sx);
     sy = fma(beta[0], tp[1], sy);
@@ -331,15 +286,6 @@ __device__ __forceinline__ bool pairwise_item(const Rig &rig, const double *__re
     oy = sy * r;
     oz = sz * r;
     os = sb * (0.5 / (double)(C * (C - 1) / 2));  // :148
-#ifdef SNOWTRI_ITEM_TIMERS
-    asm volatile("" :: "v"(ox), "v"(oy), "v"(oz), "v"(os) : "memory");
-    const unsigned long long tm3 = __builtin_amdgcn_s_memtime();
-    ox = (double)(tm0 - ts0) + 1e-9 * ox;   // wait for the LDS constants
-    oy = (double)(tm1 - tm0) + 1e-9 * oy;   // rays, including the wait for the item's keypoints
-    oz = (double)(tm3 - tm1) + 1e-9 * oz;   // pair solves + fusion tail
-    os = (double)(ts0 & 0x7fffffffull);      // start stamp
-    bad = false;
-#endif
     return bad;
 }
 
@@ -366,9 +312,7 @@ __device__ __forceinline__ void dlt_add_observation(double (&A)[4][4], PPtr P, d
         for (int k = i; k < 4; k++) A[i][k] = fma(r1[i], r1[k], fma(r2[i], r2[k], A[i][k]));
 }
 
-#ifndef SNOWTRI_JACOBI_SWEEPS
-#define SNOWTRI_JACOBI_SWEEPS 6
-#endif
+constexpr int kJacobiSweeps = 6;
 // Eigenvector of the smallest eigenvalue of the symmetric 4x4 whose upper triangle is in A: cyclic Jacobi,
 // register resident, fixed sweep count (converged to 2e-14 m after 5 sweeps on the bench rig).
 // Rotation: t = sign(theta) / (|theta| + sqrt(theta^2 + 1)), c = 1/sqrt(t^2 + 1), s = t c, with
@@ -387,7 +331,7 @@ __device__ __forceinline__ void dlt_min_eigenvector(double (&A)[4][4], double (&
 #pragma unroll
         for (int k = 0; k < 4; k++) V[i][k] = (i == k) ? 1.0 : 0.0;
 #pragma unroll 1
-    for (int sweep = 0; sweep < SNOWTRI_JACOBI_SWEEPS; sweep++) {
+    for (int sweep = 0; sweep < kJacobiSweeps; sweep++) {
 #pragma unroll
         for (int p = 0; p < 3; p++) {
 #pragma unroll
@@ -431,16 +375,14 @@ __device__ __forceinline__ void dlt_min_eigenvector(double (&A)[4][4], double (&
     }
 }
 
-#ifndef SNOWTRI_DLT_INVIT
-#define SNOWTRI_DLT_INVIT 8
-#endif
+constexpr int kDltInvit = 8;
 // The same eigenvector by shifted inverse iteration: G = A^T A + mu I = L L^T (Cholesky, mu = 64 eps trace keeps
 // every pivot positive when the data are exact and A^T A is singular), x <- normalise(G^-1 x) from e_4.
 // The wanted eigenvalue is the squared reprojection residual (tiny), the next one is ~1e4..1e5 times larger at
 // one pixel of noise, so four steps reach 2e-14 m (same as the SVD oracle) -- ~15x fewer instructions than the
 // Jacobi sweeps.  Convergence is linear, so a lane is done when (step length)^2 / (previous step length), the
 // estimate of the error left, drops below 1e-14; the loop leaves when every lane of the wave is done; lanes that
-// are not by SNOWTRI_DLT_INVIT steps (gross outliers: eigenvalue ratio above ~0.02) report false and the caller
+// are not by kDltInvit steps (gross outliers: eigenvalue ratio above ~0.02) report false and the caller
 // re-solves them with Jacobi.  `live` = false lanes (fewer than two cameras) never block.
 __device__ __forceinline__ bool dlt_inverse_iteration(const double (&A)[4][4], bool live, double (&e)[4]) {
 #pragma clang fp contract(off)   // results must not depend on which inlined copy computes them (see pairwise_item)
@@ -464,7 +406,7 @@ __device__ __forceinline__ bool dlt_inverse_iteration(const double (&A)[4][4], b
     double prev = 1.0;  // previous step length
     bool conv = !live;
 #pragma unroll 1
-    for (int it = 0; it < SNOWTRI_DLT_INVIT; it++) {
+    for (int it = 0; it < kDltInvit; it++) {
         double y[4], z[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {  // L y = x
@@ -544,7 +486,7 @@ __device__ __forceinline__ void dlt_item(const double *__restrict__ Plds, const 
 }
 
 template <int C, int METHOD, typename TIn, typename TOut>
-__global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_single(int64_t F, int J, int T, Rig rig,
+__global__ __launch_bounds__(kBlock, kFastWaves) void k_fused_single(int64_t F, int J, int T, Rig rig,
                                                          const TIn *__restrict__ kpts,
                                                          const int32_t *__restrict__ n_persons, Params prm,
                                                          int Pout, TOut *__restrict__ out4,
@@ -553,9 +495,6 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_single(int
                                                          uint32_t *__restrict__ out_flags, char *scratch,
                                                          size_t scratch_per_block) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-#ifdef SNOWTRI_ITEM_TIMERS
-    const unsigned long long t_entry = __builtin_amdgcn_s_memtime();
-#endif
     constexpr int NP = C * (C - 1) / 2;
     const int kn = prm.kn, ci = prm.center;
     double *stash = reinterpret_cast<double *>(smem);                        // [T][kn] fused joint scores
@@ -576,11 +515,7 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_single(int
     const int dfl = kBlock / J, dj = kBlock - dfl * J;
     const int64_t ntiles = (F + T - 1) / T;
 
-#if SNOWTRI_RING == 3
     Kp3<TIn> bufA[C], bufB[C], bufC[C];
-#else
-    Kp3<TIn> bufA[C], bufB[C];
-#endif
     if (blockIdx.x < ntiles) prefetch_tile_head<C>(bufA, bufB, kp3, (int64_t)blockIdx.x, T, F, J, tid, dfl, dj);
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t f0 = tile * T;
@@ -631,7 +566,6 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_single(int
             int ff = fs, jf = js;                 // item being fetched: two ahead
             advance_item(ff, jf, dfl, dj, J);
             advance_item(ff, jf, dfl, dj, J);
-#if SNOWTRI_RING == 3
             for (int k = 0; k < n_my; k += 3) {
                 fetch_item<C>(bufC, tile_in, ff, jf, J, last_off);
                 solve_store(bufA, fs, js);
@@ -646,18 +580,6 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_single(int
                 advance_item(fs, js, dfl, dj, J);
                 advance_item(ff, jf, dfl, dj, J);
             }
-#else  // ring of two: bufA / bufB alternate, fetch distance 2 items (the solved buffer is refilled at once)
-            for (int k = 0; k < n_my; k += 2) {
-                solve_store(bufA, fs, js);
-                fetch_item<C>(bufA, tile_in, ff, jf, J, last_off);
-                advance_item(fs, js, dfl, dj, J);
-                advance_item(ff, jf, dfl, dj, J);
-                if (k + 1 < n_my) solve_store(bufB, fs, js);
-                fetch_item<C>(bufB, tile_in, ff, jf, J, last_off);
-                advance_item(fs, js, dfl, dj, J);
-                advance_item(ff, jf, dfl, dj, J);
-            }
-#endif
             // unused person slots are zero-filled here, NOT inside the item loop: a store loop with a
             // run-time trip count there makes the compiler's vmcnt bookkeeping give up and wait for
             // every outstanding load (vmcnt(0)) at each item, which defeats the prefetch ring
@@ -738,11 +660,6 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_single(int
                         fflag[w] |= kSlow;
                     } else {
                         out_count[f] = 1;
-#ifdef SNOWTRI_ITEM_TIMERS
-                        out_count[f] = (int32_t)(t_entry & 0x7fffffffull);
-                        if (out_ps) out_ps[f * Pout] = (TOut)(double)(__builtin_amdgcn_s_memtime() & 0x7fffffffull);
-                        if (false)
-#endif
                         if (out_ps) {
                             out_ps[f * Pout] = (TOut)avg;
                             for (int slot = 1; slot < Pout; slot++) out_ps[f * Pout + slot] = (TOut)0;

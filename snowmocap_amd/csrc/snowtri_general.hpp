@@ -247,9 +247,6 @@ __device__ __forceinline__ double candidate_chunk_sum_exact(const char *__restri
 // v_rsq_f64 (measured 2^-24.2 relative) only scales a score: the caller re-does candidates whose mean lies within 1e-6 of
 // average_score_threshold (:79-81).
 //   pa: record of the first ray's row, pb: record of the FIRST of the GS second rows (rows are kP1Rec bytes apart)
-#ifndef SNOWTRI_P1_PHASED
-#define SNOWTRI_P1_PHASED 0
-#endif
 template <int GS, typename TIn>
 __device__ __forceinline__ void p1_item_sums(const char *__restrict__ pa, const char *__restrict__ pb, int jstr, int nj,
                                              const Vec3 &d, const Params &prm, double (&acc)[GS]) {
@@ -265,24 +262,6 @@ __device__ __forceinline__ void p1_item_sums(const char *__restrict__ pa, const 
         }
         const double cx = fma(d.y, a.z, -(d.z * a.y)), cy = fma(d.z, a.x, -(d.x * a.z)), cz = fma(d.x, a.y, -(d.y * a.x));
         const bool okm = !below_kthr(sm, prm);
-#if SNOWTRI_P1_PHASED   // the GS solves in lock step: all arguments, all v_rsq_f64 back to back, all sums (the quarter-rate
-                        // transcendentals of one solve issue under the arithmetic of the next instead of stalling its own)
-        double det[GS], x[GS], w[GS];
-#pragma unroll
-        for (int u = 0; u < GS; u++) {
-            const double bq = fma(a.z, b[u].z, fma(a.y, b[u].y, a.x * b[u].x));
-            det[u] = fma(a.a, b[u].a, -(bq * bq));
-            const double dn = fma(cz, b[u].z, fma(cy, b[u].y, cx * b[u].x));
-            const double dn2 = dn * dn;
-            const bool kp_ = okm && !below_kthr(ss[u], prm) && !(dn2 > det[u] * prm.dthr2);   // :73-74
-            w[u] = gated_sum_sel(sm, ss[u], kp_);
-            x[u] = dn2 * det[u];
-        }
-#pragma unroll
-        for (int u = 0; u < GS; u++) x[u] = __builtin_amdgcn_rsq(x[u]);
-#pragma unroll
-        for (int u = 0; u < GS; u++) acc[u] = fma(w[u], det[u] * x[u], acc[u]);
-#else
 #pragma unroll
         for (int u = 0; u < GS; u++) {
             const double bq = fma(a.z, b[u].z, fma(a.y, b[u].y, a.x * b[u].x));
@@ -292,19 +271,13 @@ __device__ __forceinline__ void p1_item_sums(const char *__restrict__ pa, const 
             const bool kp_ = okm && !below_kthr(ss[u], prm) && !(dn2 > det * prm.dthr2);   // :73-74
             acc[u] = fma(gated_sum_sel(sm, ss[u], kp_), det * __builtin_amdgcn_rsq(dn2 * det), acc[u]);
         }
-#endif
     }
 }
 
 // Dynamic LDS = recompute_lds_bytes(R, J, kn, sizeof(TIn)); scratch = gridDim.x slabs of
 // recompute_scratch_bytes(Kc, R, kn).  R = C * Pmax ray rows.  Requires keypoint_num <= kRecomputeMaxKn.
-#ifndef SNOWTRI_RECOMPUTE_WAVES
-#define SNOWTRI_RECOMPUTE_WAVES 3
-#endif
-#ifndef SNOWTRI_RECOMPUTE_UNROLL
-#define SNOWTRI_RECOMPUTE_UNROLL 4
-#endif
-constexpr int kRecomputeUnroll = SNOWTRI_RECOMPUTE_UNROLL;
+constexpr int kRecomputeWaves = 3;
+constexpr int kRecomputeUnroll = 4;
 // Frames are handed out through an atomic counter (next_frame, zeroed by the host before the launch): the
 // time of a frame depends on how many candidates survive, so a static frame->workgroup map leaves CUs idle.
 //
@@ -314,7 +287,7 @@ constexpr int kRecomputeUnroll = SNOWTRI_RECOMPUTE_UNROLL;
 // whose confidence is not below keypoint_score_threshold (>= 2 needed, else the joint stays (0,0,0)/0);
 // joint score = their mean confidence.  One lane per (cluster, joint); no cross-lane reduction.
 template <int METHOD, typename TIn, typename TOut>
-__global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recompute(int64_t F, int Pmax, int J, int Kc, Rig rig,
+__global__ __launch_bounds__(kBlock, kRecomputeWaves) void k_frame_recompute(int64_t F, int Pmax, int J, int Kc, Rig rig,
                                                             const TIn *__restrict__ kpts,
                                                             const int32_t *__restrict__ n_persons, Params prm,
                                                             int Pout, TOut *__restrict__ out4,
@@ -461,11 +434,7 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
                 }
             } else {
                 // the waves of joint sub-range jsub walk joints [jlo, jhi) of the chunk; item = base + lane of the round
-#ifdef SNOWTRI_P1_NOSOLVE   // dev experiment (timing only, outputs are wrong): phase 1 without its solves
-                const int jlo = 0, jhi = 0;
-#else
                 const int jlo = jsub * nj / JS, jhi = (jsub + 1) * nj / JS;
-#endif
                 const unsigned long long magic_pq = (((unsigned long long)1 << 40) + (unsigned)per_q - 1) / (unsigned)per_q;
                 const unsigned long long magic_ng = (((unsigned long long)1 << 40) + (unsigned)NG - 1) / (unsigned)NG;
                 for (int base = iw * 64; base < nitems; base += wpg * 64) {
@@ -561,11 +530,6 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
         }
         __syncthreads();
 
-#ifdef SNOWTRI_REC_STOP_AFTER_P1  // dev experiment (timing only, outputs are wrong): phase 1 alone
-        if (tid == 0) out_count[f] = 0;
-        __syncthreads();
-        continue;
-#endif
         // ---------------- phase 2: kept list, centre joints, greedy clustering -------------------
         if (tid < 64) {
             int n = 0;
@@ -661,11 +625,6 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
         __syncthreads();
         const int ncl = misc[1];
 
-#ifdef SNOWTRI_REC_STOP_AFTER_P2  // dev experiment (timing only, outputs are wrong): phases 1 + 2
-        if (tid == 0) out_count[f] = 0;
-        __syncthreads();
-        continue;
-#endif
         // ---------------- phase 3: fusion per surviving cluster ------------------------------
         int nout = 0;
         if constexpr (METHOD == 1) {
@@ -951,11 +910,7 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_RECOMPUTE_WAVES) void k_frame_recom
                         const bool active = jj < nj && cb + ci < nsw;
                         const int slot = sbase + cb + ci;
                         const int cid = active ? cid_of_slot[slot] : 0;
-#ifdef SNOWTRI_P3_NOSOLVE   // dev experiment (timing only, outputs are wrong): phase 3 without its member solves
-                        const int size = 0, m0 = 0;
-#else
                         const int size = active ? csize[cid] : 0, m0 = active ? cstart[cid] : 0;
-#endif
                         double aS = 0.0, aX = 0.0, aY = 0.0, aZ = 0.0;
                         if constexpr (sizeof(TOut) == 4) {
                             // float32 outputs, TWO members per iteration: the member loop is a chain of dependent LDS reads

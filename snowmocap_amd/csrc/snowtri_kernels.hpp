@@ -94,7 +94,6 @@ struct Rig {
     const int32_t *pairs;
     const double *pairc;  // [npairs][6]: d = t_sc - t_mc, tsum = t_mc + t_sc (host-precomputed)
     const double *P;      // [C][12]: world->pixel matrices K [R^T | -R^T t] (DLT method)
-    const double *eg;     // [npairs][6]: M_mc^T d, M_sc^T d (the dot products h_m . d, h_s . d as linear forms of the pixel: SNOWTRI_LEAN_EG)
     int32_t C, npairs;
 };
 

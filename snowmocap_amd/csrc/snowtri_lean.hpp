@@ -27,19 +27,13 @@
 
 namespace snowtri {
 
-#ifndef SNOWTRI_LEAN_TW
-#define SNOWTRI_LEAN_TW 12
-#endif
-constexpr int kLeanTw = SNOWTRI_LEAN_TW;  // frames per wave tile (12 x 133 = 24.94 passes of 64 lanes; 10 would make the single-cluster check one pass of 60 lanes instead of two, measured: the same 348 instructions per item)
+constexpr int kLeanTw = 12;  // frames per wave tile (12 x 133 = 24.94 passes of 64 lanes; 10 would make the single-cluster check one pass of 60 lanes instead of two, measured: the same 348 instructions per item)
 constexpr int kLeanWaves = kBlock / 64;  // waves per workgroup
 constexpr int kLeanSlowShift = 4;        // slow-frame bit index = (tile ordinal of the workgroup << 4) | frame in tile
 
 __host__ __device__ constexpr int lean_items_pad(int JC) { return (kLeanTw * JC + 63) / 64 * 64; }   // item slots of a wave tile, whole passes
 __host__ __device__ constexpr int lean_table_entries(int JC) { return lean_items_pad(JC) + 256; }      // + the prefetch distance past the last pass
-#ifndef SNOWTRI_LEAN_EG
-#define SNOWTRI_LEAN_EG 0   // 1: e = h_m . d and g = h_s . d as linear forms of the pixel (two FMAs with Rig::eg from LDS instead of three with the ray)
-#endif
-__host__ __device__ constexpr int lean_const_doubles(int C) { return (12 * C + 4 * (C * (C - 1) / 2) + (SNOWTRI_LEAN_EG ? 6 * (C * (C - 1) / 2) : 0) + 1) & ~1; }  // M[C][9], t[C][3], d[NP][3], pairs[NP][2] (int32), eg[NP][6]
+__host__ __device__ constexpr int lean_const_doubles(int C) { return (12 * C + 4 * (C * (C - 1) / 2) + 1) & ~1; }  // M[C][9], t[C][3], d[NP][3], pairs[NP][2] (int32)
 
 __host__ __device__ constexpr size_t lean_lds_bytes(int C, int JC, int slow_words) {
     const size_t stash = (size_t)kLeanWaves * lean_items_pad(JC) * 4;        // fused joint scores (float32 as stored), per wave
@@ -52,14 +46,10 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t lean_rsrc(const void *base, un
     return __builtin_amdgcn_make_buffer_rsrc(const_cast<void *>(base), 0, (int)bytes, 0x00020000);
 }
 
-// cache-policy bits of the buffer instructions (gfx942 / gfx950: 1 = sc0, 2 = nt, 16 = sc1): development knobs
-#ifndef SNOWTRI_LEAN_STORE_AUX
-#define SNOWTRI_LEAN_STORE_AUX 2   // non-temporal output stores: the 21 MB a 10 000-frame launch writes leave the L2 while the launch
+// cache-policy bits of the buffer instructions (gfx942 / gfx950: 1 = sc0, 2 = nt, 16 = sc1)
+constexpr int kLeanStoreAux = 2;   // non-temporal output stores: the 21 MB a 10 000-frame launch writes leave the L2 while the launch
                                    // runs instead of as one write-back at its end (measured: 32.2 -> 31.3 us per launch)
-#endif
-#ifndef SNOWTRI_LEAN_LOAD_AUX
-#define SNOWTRI_LEAN_LOAD_AUX 0
-#endif
+constexpr int kLeanLoadAux = 0;
 
 typedef unsigned lean_u3 __attribute__((ext_vector_type(3)));
 typedef unsigned lean_u4 __attribute__((ext_vector_type(4)));
@@ -70,13 +60,13 @@ template <typename TIn>
 __device__ __forceinline__ Kp3<TIn> lean_load_kp3(__amdgpu_buffer_rsrc_t r, unsigned voff, unsigned soff) {
     Kp3<TIn> k;
     if constexpr (sizeof(TIn) == 4) {
-        const lean_u3 w = __builtin_amdgcn_raw_buffer_load_b96(r, (int)voff, (int)soff, SNOWTRI_LEAN_LOAD_AUX);
+        const lean_u3 w = __builtin_amdgcn_raw_buffer_load_b96(r, (int)voff, (int)soff, kLeanLoadAux);
         k.u = __uint_as_float(w.x);
         k.v = __uint_as_float(w.y);
         k.s = __uint_as_float(w.z);
     } else {
-        const lean_u4 w = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, SNOWTRI_LEAN_LOAD_AUX);
-        const lean_u2 z = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff + 16, (int)soff, SNOWTRI_LEAN_LOAD_AUX);
+        const lean_u4 w = __builtin_amdgcn_raw_buffer_load_b128(r, (int)voff, (int)soff, kLeanLoadAux);
+        const lean_u2 z = __builtin_amdgcn_raw_buffer_load_b64(r, (int)voff + 16, (int)soff, kLeanLoadAux);
         k.u = __hiloint2double((int)w.y, (int)w.x);
         k.v = __hiloint2double((int)w.w, (int)w.z);
         k.s = __hiloint2double((int)z.y, (int)z.x);
@@ -101,14 +91,8 @@ __device__ __forceinline__ float select_by_mask(float x, unsigned long long mask
 // One (frame, joint): C rays, all C(C,2) pair solves, score-weighted fusion (see pairwise_item for the
 // algebra of the fusion regrouped per ray; here the determinants cancel out of it: no reciprocal per pair).  Returns
 // true if the item needs the IEEE-exact routine.
-#ifndef SNOWTRI_LEAN_M_VGPR
-#define SNOWTRI_LEAN_M_VGPR 0
-#endif
-#ifndef SNOWTRI_LEAN_RING
-#define SNOWTRI_LEAN_RING 3
-#endif
 template <int C, typename TIn>
-__device__ __forceinline__ bool lean_item(const double *__restrict__ Mlds, const double (&Mres)[9 * C],
+__device__ __forceinline__ bool lean_item(const double *__restrict__ Mlds,
                                           const double (&dS)[3 * (C * (C - 1) / 2)],
                                           const Kp3<TIn> (&cur)[C], float kthr_f32, double kthr, double dthr2,
                                           float &ox, float &oy, float &oz, double &os) {
@@ -117,30 +101,18 @@ __device__ __forceinline__ bool lean_item(const double *__restrict__ Mlds, const
     // copy -- a frame's result would then depend (in the last bit) on which ring slot its position in the launch maps to.
 #pragma clang fp contract(off)
     constexpr int NPc = C * (C - 1) / 2;
-#if SNOWTRI_LEAN_M_VGPR  // dev experiment: ray matrices resident in VGPRs for the whole launch (passed in Mres)
-    const double (&Mp)[9 * C] = Mres;
-#else
     double Mp[9 * C];
 #pragma unroll
     for (int i = 0; i < 9 * C; i++) Mp[i] = Mlds[i];
     __builtin_amdgcn_sched_barrier(0);  // one burst of LDS reads, one wait (+2.5 % measured in round 1)
-#endif
     const double *tp = Mlds + 9 * C;
     Vec3 h[C];
     double a[C], alpha[C], beta[C];
     unsigned long long okm[C];
-#if SNOWTRI_LEAN_EG
-    double ud[C], vd[C];
-    const double *Eg = Mlds + 12 * C + 4 * NPc;
-#endif
 #pragma unroll
     for (int c = 0; c < C; c++) {
         // A1, camera.py:241-243 with M = R inv(K)
         const double u = (double)cur[c].u, v = (double)cur[c].v;
-#if SNOWTRI_LEAN_EG
-        ud[c] = u;
-        vd[c] = v;
-#endif
         h[c].x = fma(Mp[9 * c + 0], u, fma(Mp[9 * c + 1], v, Mp[9 * c + 2]));
         h[c].y = fma(Mp[9 * c + 3], u, fma(Mp[9 * c + 4], v, Mp[9 * c + 5]));
         h[c].z = fma(Mp[9 * c + 6], u, fma(Mp[9 * c + 7], v, Mp[9 * c + 8]));
@@ -171,13 +143,8 @@ __device__ __forceinline__ bool lean_item(const double *__restrict__ Mlds, const
             const double dx = dS[3 * q], dy = dS[3 * q + 1], dz = dS[3 * q + 2];
             const double b = dot3(hm, hs);
             const double det = fma(a[mc], a[sc], -(b * b));
-#if SNOWTRI_LEAN_EG
-            const double e = fma(Eg[6 * q], ud[mc], fma(Eg[6 * q + 1], vd[mc], Eg[6 * q + 2]));
-            const double g = fma(Eg[6 * q + 3], ud[sc], fma(Eg[6 * q + 4], vd[sc], Eg[6 * q + 5]));
-#else
             const double e = fma(hm.z, dz, fma(hm.y, dy, hm.x * dx));
             const double g = fma(hs.z, dz, fma(hs.y, dy, hs.x * dx));
-#endif
             const double N0 = fma(a[sc], e, -(b * g));
             const double N1 = fma(a[mc], g, -(b * e));
             // n = h_m . (h_s x d)
@@ -293,7 +260,7 @@ __device__ __forceinline__ void lean_tile_range(int64_t t, int base, int64_t rem
 // Grid: any number of workgroups; wave gw = 4 blockIdx.x + wave takes tiles gw, gw + 4 gridDim.x, ...
 // Dynamic LDS: lean_lds_bytes(C, JC, slow_words); slow_words >= ceil(tiles of one WORKGROUP * 16 / 32).
 template <int C, typename TIn, int JC>
-__global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean(
+__global__ __launch_bounds__(kBlock, kFastWaves) void k_fused_lean(
     int64_t F, int64_t ntiles, int tile_base, int64_t tile_rem, int slow_words, Rig rig, const TIn *__restrict__ kpts,
     const int32_t *__restrict__ n_persons, Params prm, float *__restrict__ out4, float *__restrict__ out_ps,
     int32_t *__restrict__ out_count, uint32_t *__restrict__ out_flags, char *scratch, size_t scratch_per_block) {
@@ -314,11 +281,7 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean(
     uint32_t *slowbits = reinterpret_cast<uint32_t *>(reinterpret_cast<float *>(table + kTable) + kLeanWaves * kItemsPad);
     const Kp3<TIn> *kp3 = reinterpret_cast<const Kp3<TIn> *>(kpts);
     const int64_t wstride = (int64_t)gridDim.x * kLeanWaves;
-#if SNOWTRI_LEAN_RING == 3
     Kp3<TIn> bufA[C], bufB[C], bufC[C];
-#else
-    Kp3<TIn> bufA[C], bufB[C];
-#endif
 
     // Item i = lane + 64 k of a tile is joint i % JC of the tile's frame i / JC; its camera-c record sits at byte
     // (i + (i / JC) (C-1) JC + c JC) kRec of the tile.  The part that does not depend on c is the same for every tile:
@@ -338,9 +301,6 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean(
     const double cM = rig.M[tid < 9 * C ? tid : 0], cT = rig.t[tid < 3 * C ? tid : 0];
     const double cD = rig.pairc[tid < 3 * NP ? 6 * (tid / 3) + tid % 3 : 0];
     const int32_t cP = rig.pairs[tid < 2 * NP ? tid : 0];
-#if SNOWTRI_LEAN_EG
-    const double cE = rig.eg[tid < 6 * NP ? tid : 0];
-#endif
     double dS[3 * NP];  // per-pair d = t_s - t_m, wave-uniform -> scalar registers
 #pragma unroll
     for (int i = 0; i < 3 * NP; i++) dS[i] = rig.pairc[6 * (i / 3) + i % 3];
@@ -362,20 +322,12 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean(
     if (tid < 3 * NP) Mlds[12 * C + tid] = cD;
     int32_t *pairs_lds = reinterpret_cast<int32_t *>(Mlds + 12 * C + 3 * NP);
     if (tid < 2 * NP) pairs_lds[tid] = cP;
-#if SNOWTRI_LEAN_EG
-    if (tid < 6 * NP) Mlds[12 * C + 4 * NP + tid] = cE;
-#endif
 #pragma unroll
     for (int i = 0; i < 3 * NP; i++) dS[i] = uniform_f64(dS[i]);
     const float kthr_f32 = prm.kthr_f32;
     const double kthr = prm.kthr, dthr2 = prm.dthr2;
     const double ctol2_lo = prm.ctol < 0.0 ? -1.0 : prm.ctol * prm.ctol * (1.0 - 1e-12);   // single-cluster check, see there
     __syncthreads();  // constants, table and the cleared slow-frame bits are visible to every wave
-    double Mres[9 * C];
-#if SNOWTRI_LEAN_M_VGPR
-#pragma unroll
-    for (int i = 0; i < 9 * C; i++) Mres[i] = Mlds[i];
-#endif
 
     for (int ord = 0; tile < ntiles; tile += wstride, ord++) {
         SNOWTRI_DEV_CHECK(f0 >= 0 && nf >= 1 && nf <= kLeanTw && f0 + nf <= F, 1);                 // the tile lies inside the batch
@@ -384,11 +336,7 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean(
         const __amdgpu_buffer_rsrc_t rout =
             lean_rsrc(reinterpret_cast<float4 *>(out4) + f0 * (int64_t)JC, (unsigned)(nf * JC) * 16u);
         const unsigned last = (unsigned)(nf * JC - 1);
-#ifdef SNOWTRI_LEAN_NOLOOP  // dev experiment (timing only, outputs are wrong): fixed cost of a launch without its items
-        const int npass = 0;
-#else
         const int npass = (nf * JC + 63) >> 6;
-#endif
         const unsigned slow_base = (unsigned)((ord * kLeanWaves + wave) << kLeanSlowShift);
         // centre-joint keypoints for the single-cluster check after the item loop (lane = frame x pair)
         constexpr int kCheckFrames = 64 / NP;
@@ -407,14 +355,14 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean(
         auto solve_store = [&](const Kp3<TIn>(&buf)[C], unsigned out_off, float *stash_slot) {
             float ox, oy, oz;
             double os;
-            const bool bad = lean_item<C>(Mlds, Mres, dS, buf, kthr_f32, kthr, dthr2, ox, oy, oz, os);
+            const bool bad = lean_item<C>(Mlds, dS, buf, kthr_f32, kthr, dthr2, ox, oy, oz, os);
             const float osf = (float)os;
             lean_u4 rec;
             rec.x = __float_as_uint(ox);
             rec.y = __float_as_uint(oy);
             rec.z = __float_as_uint(oz);
             rec.w = __float_as_uint(osf);
-            __builtin_amdgcn_raw_buffer_store_b128(rec, rout, (int)out_off, 0, SNOWTRI_LEAN_STORE_AUX);
+            __builtin_amdgcn_raw_buffer_store_b128(rec, rout, (int)out_off, 0, kLeanStoreAux);
             *stash_slot = osf;
             if (__ballot(bad)) {  // rare, wave-uniform branch
                 unsigned o = out_off;
@@ -428,7 +376,6 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean(
         unsigned out_off = (unsigned)lane * 16u;           // 16 x (item being solved); the one being fetched is two passes ahead
         float *sp = stash + lane;                          // its stash slot
         const uint32_t *tp = table + lane;                 // its table entry
-#if SNOWTRI_LEAN_RING == 3
         unsigned t0 = tp[128], t1 = tp[192], t2 = tp[256];  // (read one iteration ahead of their use)
         for (int k = 0; k < npass; k += 3) {
             fetch(bufC, rin, t0);
@@ -444,17 +391,6 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean(
             out_off += 3072u;
             sp += 192;
         }
-#else  // two buffers: the solved one is refilled at once (fetch distance still two passes)
-        for (int k = 0; k < npass; k += 2) {
-            solve_store(bufA, out_off, sp);
-            fetch(bufA, rin, tp[128]);
-            if (k + 1 < npass) solve_store(bufB, out_off + 1024u, sp + 64);
-            fetch(bufB, rin, tp[192]);
-            tp += 128;
-            out_off += 2048u;
-            sp += 128;
-        }
-#endif
         // this wave's next tile: its first two fetches fly during the epilogue
         const int64_t f0_cur = f0;
         const int nf_cur = nf;
@@ -471,9 +407,6 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean(
         //      the centre joint and takes candidate 0's point from the frame's first lane.  The keypoints of the
         //      first two passes were fetched before the item loop; rig constants come from LDS.
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-#ifdef SNOWTRI_LEAN_NOEPI  // dev experiment (timing only, outputs are wrong): no per-tile epilogue
-        if (nf_cur >= 0) continue;
-#endif
         for (int pass = 0; pass * kCheckFrames < nf_cur; pass++) {
             const int wl = lane / NP, qq = lane - wl * NP, w = pass * kCheckFrames + wl;
             const bool live = wl < kCheckFrames && w < nf_cur;
@@ -572,9 +505,6 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean(
 // Items, check and mean are the SAME functions as in k_fused_lean: a frame's bits do not depend on which kernel ran it.
 // Grid = number of tiles (tile t = frames lean_tile_range(t, tile_base, tile_rem), nf <= nf_max <= kCoopMaxFrames).
 // Dynamic LDS: lean_coop_lds_bytes(C, JC, nf_max).
-#ifndef SNOWTRI_COOP_PRIO
-#define SNOWTRI_COOP_PRIO 0
-#endif
 constexpr int kCoopMaxFrames = 32;   // frames per workgroup tile (one bit word of slow frames)
 __host__ __device__ constexpr int lean_coop_items_pad(int JC, int nf_max) { return (nf_max * JC + 63) / 64 * 64; }
 __host__ __device__ constexpr size_t lean_coop_lds_bytes(int C, int JC, int nf_max) {
@@ -584,7 +514,7 @@ __host__ __device__ constexpr size_t lean_coop_lds_bytes(int C, int JC, int nf_m
 }
 
 template <int C, typename TIn, int JC>
-__global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean_coop(
+__global__ __launch_bounds__(kBlock, kFastWaves) void k_fused_lean_coop(
     int64_t F, int tile_base, int64_t tile_rem, int nf_max, Rig rig, const TIn *__restrict__ kpts, const int32_t *__restrict__ n_persons,
     Params prm, float *__restrict__ out4, float *__restrict__ out_ps, int32_t *__restrict__ out_count, uint32_t *__restrict__ out_flags,
     char *scratch, size_t scratch_per_block) {
@@ -645,9 +575,6 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean_coop(
     const double cM = rig.M[tid < 9 * C ? tid : 0], cT = rig.t[tid < 3 * C ? tid : 0];
     const double cD = rig.pairc[tid < 3 * NP ? 6 * (tid / 3) + tid % 3 : 0];
     const int32_t cP = rig.pairs[tid < 2 * NP ? tid : 0];
-#if SNOWTRI_LEAN_EG
-    const double cE = rig.eg[tid < 6 * NP ? tid : 0];
-#endif
     double dS[3 * NP];
 #pragma unroll
     for (int i = 0; i < 3 * NP; i++) dS[i] = rig.pairc[6 * (i / 3) + i % 3];
@@ -667,9 +594,6 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean_coop(
     if (tid < 3 * C) Mlds[9 * C + tid] = cT;
     if (tid < 3 * NP) Mlds[12 * C + tid] = cD;
     if (tid < 2 * NP) pairs_lds[tid] = cP;
-#if SNOWTRI_LEAN_EG
-    if (tid < 6 * NP) Mlds[12 * C + 4 * NP + tid] = cE;
-#endif
 #pragma unroll
     for (int i = 0; i < 3 * NP; i++) dS[i] = uniform_f64(dS[i]);
     const float kthr_f32 = prm.kthr_f32;
@@ -685,23 +609,18 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean_coop(
         ckm = p[pairs_lds[2 * qq] * JC];
         cks = p[pairs_lds[2 * qq + 1] * JC];
     }
-    double Mres[9 * C];
-#if SNOWTRI_LEAN_M_VGPR
-#pragma unroll
-    for (int i = 0; i < 9 * C; i++) Mres[i] = Mlds[i];
-#endif
 
     auto solve_store = [&](const Kp3<TIn>(&buf)[C], unsigned out_off, float *stash_slot) {
         float ox, oy, oz;
         double os;
-        const bool bad = lean_item<C>(Mlds, Mres, dS, buf, kthr_f32, kthr, dthr2, ox, oy, oz, os);
+        const bool bad = lean_item<C>(Mlds, dS, buf, kthr_f32, kthr, dthr2, ox, oy, oz, os);
         const float osf = (float)os;
         lean_u4 rec;
         rec.x = __float_as_uint(ox);
         rec.y = __float_as_uint(oy);
         rec.z = __float_as_uint(oz);
         rec.w = __float_as_uint(osf);
-        __builtin_amdgcn_raw_buffer_store_b128(rec, rout, (int)out_off, 0, SNOWTRI_LEAN_STORE_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(rec, rout, (int)out_off, 0, kLeanStoreAux);
         *stash_slot = osf;
         if (__ballot(bad)) {  // rare, wave-uniform branch
             unsigned o = out_off;
@@ -717,22 +636,6 @@ __global__ __launch_bounds__(kBlock, SNOWTRI_FAST_WAVES) void k_fused_lean_coop(
         float *sp = stash + i0 + lane;
         const uint32_t *tp = table + i0 + lane;
         for (int k = 0; k < npass; k += 3) {
-#if SNOWTRI_COOP_PRIO
-            // issue priority by progress: a SIMD serves its waves oldest first, so the wave of the CU's older workgroup ran its
-            // passes at nearly full speed and left the younger one to finish alone, with nothing to hide its LDS and
-            // dependency stalls behind; a wave that is ahead steps down, the two stay within three passes of each other
-#if SNOWTRI_COOP_PRIO == 2   // the opposite: a wave near its end steps up (a launch finishes promptly when another one overlaps it)
-            if (k < 3) __builtin_amdgcn_s_setprio(0);
-            else if (k < 6) __builtin_amdgcn_s_setprio(1);
-            else if (k < 9) __builtin_amdgcn_s_setprio(2);
-            else __builtin_amdgcn_s_setprio(3);
-#else
-            if (k < 3) __builtin_amdgcn_s_setprio(3);
-            else if (k < 6) __builtin_amdgcn_s_setprio(2);
-            else if (k < 9) __builtin_amdgcn_s_setprio(1);
-            else __builtin_amdgcn_s_setprio(0);
-#endif
-#endif
             fetch(bufC, k + 2 < npass ? tp[128] : kNoItem);
             solve_store(bufA, out_off, sp);
             fetch(bufA, k + 3 < npass ? tp[192] : kNoItem);

@@ -13,6 +13,16 @@ namespace snowtri {
 // snowmocap_amd/libsnowtri_dbg.so with -DSNOWTRI_DEBUG_BOUNDS).  A violated check counts itself in g_dev_fault[0] and
 // the first one leaves (code << 32 | source line) in g_dev_fault[1]; snowtri_debug_faults() reads and clears them.
 // The production build compiles the checks out.
+// Build variants.  The production library is compiled with NONE of these (snowtri_build_info() lists the ones a binary
+// carries, tests/test_abi_and_host.py asserts the shipped one reports none):
+//   SNOWTRI_DEBUG_BOUNDS     device-side index checks (libsnowtri_dbg.so, tests only)
+//   SNOWTRI_DEV_MIN          4-camera float32 instantiations only (fast A/B builds, the ASan build)
+//   SNOWTRI_DEV_EXPERIMENTS  gate of everything that is a measurement aid: the wall-clock stamps of SNOWTRI_LEAN_TRACE /
+//                            _SUMS_TRACE / _ASSOC_TRACE.  Round 3's timing-only switches that produced WRONG outputs
+//                            (..._NOSOLVE, _NOFILL, _REPEAT, _NOLOOP, _NOEPI, _STOP_AFTER_*, _MEMTEST, _COMPUTETEST) are gone.
+#if (defined(SNOWTRI_LEAN_TRACE) || defined(SNOWTRI_SUMS_TRACE) || defined(SNOWTRI_ASSOC_TRACE)) && !defined(SNOWTRI_DEV_EXPERIMENTS)
+#error "trace stamps are development experiments: add -DSNOWTRI_DEV_EXPERIMENTS"
+#endif
 #ifdef SNOWTRI_DEBUG_BOUNDS
 __device__ unsigned long long g_dev_fault[2];
 #define SNOWTRI_DEV_CHECK(cond, code)                                                                             \

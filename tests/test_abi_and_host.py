@@ -231,3 +231,24 @@ def test_compat_snowvision_package_serves_main_py_imports():
     env = dict(os.environ, PYTHONPATH=os.pathsep.join([os.path.join(ROOT, "compat"), ROOT]))
     p = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
     assert p.returncode == 0 and "ok" in p.stdout, p.stdout + p.stderr
+
+
+def test_shipped_library_carries_no_development_switch():
+    """nothing told a user that the loaded .so was built without the development macros.  snowtri_build_info()
+    names every build variant a binary carries: the production library none, the debug-bounds library exactly its one."""
+    import ctypes as ct
+    info = _lib.build_info()
+    assert info["arch"] == "gfx950" and info["version"] >= 100
+    if not os.environ.get("SNOWTRI_LIB"):
+        assert info["variants"] == [], info
+    dbg = os.path.join(ROOT, "snowmocap_amd", "libsnowtri_dbg.so")
+    if os.path.exists(dbg):
+        h = ct.CDLL(dbg)
+        h.snowtri_build_info.restype = ct.c_char_p
+        assert h.snowtri_build_info().decode().endswith("variants=SNOWTRI_DEBUG_BOUNDS")
+    # no wrong-output switch is left in the kernel sources, and trace stamps need the experiments gate
+    src = "".join(open(os.path.join(ROOT, "snowmocap_amd", "csrc", f)).read() for f in os.listdir(os.path.join(ROOT, "snowmocap_amd", "csrc"))
+                  if f.endswith((".hpp", ".hip")))
+    for gone in ("_NOSOLVE", "_NOFILL", "K1_REPEAT", "LEAN_NOLOOP", "LEAN_NOEPI", "STOP_AFTER_P", "SNOWTRI_MEMTEST", "SNOWTRI_COMPUTETEST"):
+        assert ("#ifdef SNOWTRI" + gone not in src) and ("defined(SNOWTRI_" + gone.lstrip("_") not in src) and (gone + "  //" not in src), gone
+    assert "!defined(SNOWTRI_DEV_EXPERIMENTS)" in src and "#error" in src

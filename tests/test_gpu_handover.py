@@ -469,7 +469,7 @@ def test_frames_whose_member_lists_do_not_fit_the_staging_stay_in_phase3(api, mo
     (8, 4, 133, {"SNOWTRI_SUMS_LDS_KB": "24"}),                                      # one wave of tiles, four joint sub-ranges, 8-joint chunks
     (8, 4, 40, {"SNOWTRI_SUMS_THREADS": "1024", "SNOWTRI_SUMS_LDS_KB": "160"}),      # the whole frame in one chunk: no second buffer used
     (6, 3, 33, {"SNOWTRI_SUMS_THREADS": "512"}),                                     # odd person count: one candidate per lane
-    (8, 4, 133, {"SNOWTRI_CLUSTER_SPLIT": "0", "SNOWTRI_CLUSTER_PASSES_PER_WAVE": "3"}),   # member lists inside k_cluster_fuse, short-lived workgroups
+    (8, 4, 133, {"SNOWTRI_SPLIT_SEGMENTS": "1"}),                                    # the whole call on the caller's stream
 ])
 def test_candidate_sums_launch_shapes_against_oracle(api, C, P, J, knobs, monkeypatch):
     """k_candidate_sums picks its workgroup shape from the rig (256 threads x 3 per CU ... 1024 x 1), keeps a tile's sums in
@@ -499,3 +499,51 @@ def test_candidate_sums_launch_shapes_against_oracle(api, C, P, J, knobs, monkey
     _check(out, ref, pout, J, msg)
     _same(out, base, msg)
     assert sum(out["handed"]) == sum(base["handed"]) == int(np.minimum(ref["count"], pout).sum()), (out["handed"], base["handed"])
+
+
+@pytest.mark.parametrize("C,P,segments", [(8, 4, 2), (8, 4, 5), (16, 8, 3), (5, 3, 2)])
+def test_one_call_split_over_two_stream_sets_is_bit_identical(api, C, P, segments, monkeypatch):
+    """Round 4: a multi-person call is cut into segments that alternate between the caller's stream and an internal one (two
+    scratch sets, event fork / join inside the call).  SNOWTRI_SPLIT_SEGMENTS=n forces the cut on a small batch (odd n is
+    rounded up to an even count): outputs equal the uncut call bit for bit, and the oracle."""
+    from snowmocap_amd import synth
+    from oracle import oracle as orc
+    rng = np.random.default_rng(77 + C + segments)
+    F, J = (9 if C == 16 else 41), 133
+    K, R, t = synth.ring_rig(C, radius=5.0)
+    X = synth.make_people(rng, F, P, J=J)
+    kp, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=0.7, score_range=(3.5, 9.0), permute_persons=True, dtype=np.float32)
+    npers = npers.copy()
+    npers[2, 1] = P - 1
+    prm = dict(PRM, keypoint_num=J, condense_person_num_tol=10 if C == 16 else 2)
+    pout = P + 2
+    ref = orc.triangulate_condense_batch(K, R, t, kp, npers, orc.make_params(**prm), 64)
+    monkeypatch.setenv("SNOWTRI_SPLIT_SEGMENTS", "1")
+    whole = _run(api, K, R, t, prm, kp, npers, pout, monkeypatch)
+    monkeypatch.setenv("SNOWTRI_SPLIT_SEGMENTS", str(segments))
+    cut = _run(api, K, R, t, prm, kp, npers, pout, monkeypatch)
+    again = _run(api, K, R, t, prm, kp, npers, pout, monkeypatch)
+    monkeypatch.delenv("SNOWTRI_SPLIT_SEGMENTS")
+    _check(cut, ref, pout, J, f"split {segments}")
+    for k in ("xyzs", "pscore", "count", "flags"):
+        assert np.array_equal(whole[k], cut[k], equal_nan=True), k
+        assert np.array_equal(again[k], cut[k], equal_nan=True), k
+    assert sum(whole["handed"]) == int(np.minimum(ref["count"], pout).sum())
+    assert 0 < sum(cut["handed"]) < sum(whole["handed"])          # (the last segment alone)
+
+
+def test_reference_workloads_take_no_fall_back_of_the_streaming_route(api):
+    """parity alone cannot see a regression that sends every frame of the streaming route down one of its
+    fall-backs (second association launch, exact candidate sums, k_frame_recompute).  On the BASELINE multi-person shapes
+    all three counters are 0, the context reports no override, and the route is the streaming one."""
+    from snowmocap_amd import synth
+    for cfg, F, pout in ((3, 200, 16), (5, 24, 32)):
+        wl = synth.config_workload(cfg, F)
+        K, R, t = wl["rig"]
+        bt = api.BatchTriangulator(K, R, t, wl["params"], pout_max=pout, out_dtype=np.float32)
+        out = bt.run_host(wl["kpts"], wl["n_persons"])
+        assert out["status"] == 0
+        assert bt.ctx.overrides() == ""
+        assert "k_candidate_sums" in bt.ctx.last_kernel_names() and "k_associate" in bt.ctx.last_kernel_names()
+        assert bt.ctx.last_stream_counts() == (0, 0, 0), (cfg, bt.ctx.last_stream_counts())
+        bt.close()

@@ -389,3 +389,44 @@ def test_event_timing_attached_and_bracketed(api, F):
     for k in outs["attached"]:
         assert np.array_equal(outs["attached"][k], outs["bracketed"][k], equal_nan=True), k
     bt.close()
+
+
+@pytest.mark.parametrize("streams", [2, 3])
+def test_overlap_mode_gives_a_plain_loop_of_calls_the_same_bits(api, streams):
+    """BatchTriangulator(streams=n) = snowtri_ctx_set_overlap: consecutive device calls rotate over n internal streams behind the
+    caller's stream; after join() every call's outputs equal the ones of the same calls issued one after the other -- also
+    for frames that take the in-launch fall-back (their slabs belong to the stream set, not to the context)."""
+    import torch
+    from snowmocap_amd import synth, _lib
+    rng = np.random.default_rng(900 + streams)
+    F = 3000
+    wl = synth.config_workload(2, F, seed=5)
+    K, R, t = wl["rig"]
+    dev = torch.device("cuda", 0)
+    batches = []
+    for b in range(7):
+        kp = wl["kpts"].copy()
+        kp[..., :2] += rng.normal(0, 0.3, size=kp.shape[:-1] + (2,)).astype(np.float32)
+        npers = wl["n_persons"].copy()
+        _break_some_frames(rng, kp, npers, F)
+        batches.append((torch.from_numpy(kp).to(dev), torch.from_numpy(npers).to(dev)))
+    prm = dict(wl["params"], condense_distance_tol=0.5)
+    seq = api.BatchTriangulator(K, R, t, prm, pout_max=1, out_dtype=np.float32)
+    want = [{k: v.clone() for k, v in seq.run_torch(kp, npers).items()} for kp, npers in batches]
+    torch.cuda.synchronize(dev)
+    seq.close()
+    ovl = api.BatchTriangulator(K, R, t, prm, pout_max=1, out_dtype=np.float32, streams=streams)
+    assert ovl.ctx.overrides() == ""
+    side = torch.cuda.Stream(device=dev)
+    with torch.cuda.stream(side):                       # the caller's stream is not the null stream
+        for rep in range(2):
+            got = [ovl.run_torch(kp, npers) for kp, npers in batches]
+            ovl.join()
+            flat = [{k: v.clone() for k, v in g.items()} for g in got]     # reads on the caller's stream, behind the join
+            side.synchronize()
+            for g, w in zip(flat, want):
+                for k in ("xyzs", "pscore", "count", "flags"):     # bit patterns: a NaN pixel gives NaN joints in both
+                    assert torch.equal(g[k].view(torch.int32), w[k].view(torch.int32)), (rep, k)
+    slow = sum(int(((w["flags"] & _lib.FLAG_FASTPATH) == 0).sum()) for w in want)
+    assert slow > 0
+    ovl.close()
