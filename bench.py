@@ -609,16 +609,19 @@ def extra_workloads(torch, dev, device_index):
     from snowmocap_amd import synth
     from snowmocap_amd.batch import BatchTriangulator
     res = []
-    for cfg, F, gen_frames, pout, label in (
-            (3, 10000, 1000, 16, "BASELINE configs[2]: 8 cameras x 4 persons x 133 joints x 10 000 frames"),
-            (5, 12500, 250, 32, "BASELINE configs[4] per-GPU share: 16 cameras x 8 persons x 133 joints x 12 500 frames")):
+    for cfg, F, gen_frames, pout, label, odt in (
+            (3, 10000, 1000, 16, "BASELINE configs[2]: 8 cameras x 4 persons x 133 joints x 10 000 frames", np.float32),
+            (5, 12500, 250, 32, "BASELINE configs[4] per-GPU share: 16 cameras x 8 persons x 133 joints x 12 500 frames", np.float32),
+            # the reference's own output type (triangulation.py:136-148 returns float64 arrays): same route, Newton-refined 1/dist,
+            # person scores from the fused joints
+            (3, 10000, 1000, 16, "BASELINE configs[2] with float64 outputs: 8 cameras x 4 persons x 133 joints x 10 000 frames", np.float64)):
         wl = synth.config_workload(cfg, gen_frames)
         K, R, t = wl["rig"]
         C, P = K.shape[0], wl["kpts"].shape[2]
         rep = F // gen_frames
         kp = torch.from_numpy(wl["kpts"]).to(dev).repeat(rep, 1, 1, 1, 1).contiguous()
         npers = torch.from_numpy(wl["n_persons"]).to(dev).repeat(rep, 1).contiguous()
-        bt = BatchTriangulator(K, R, t, wl["params"], pout_max=pout, out_dtype=np.float32, device=device_index)
+        bt = BatchTriangulator(K, R, t, wl["params"], pout_max=pout, out_dtype=odt, device=device_index)
         out = bt.run_torch(kp, npers)
         torch.cuda.synchronize(dev)
         # ONE call = one fused entry on one caller stream (inside it the library alternates the call's segments between
@@ -639,7 +642,7 @@ def extra_workloads(torch, dev, device_index):
         counts = bt.ctx.last_stream_counts()
         # throughput with two calls in flight (two contexts on two streams, as the headline `value` is issued): the
         # latency-bound kernels of one call (k_associate, the member lists) run beside the VALU-bound ones of the other
-        bt2 = BatchTriangulator(K, R, t, wl["params"], pout_max=pout, out_dtype=np.float32, device=device_index)
+        bt2 = BatchTriangulator(K, R, t, wl["params"], pout_max=pout, out_dtype=odt, device=device_index)
         out2 = bt2.alloc_outputs(F, dev)
         streams2 = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
         pairs2 = ((bt, out, streams2[0]), (bt2, out2, streams2[1]))
@@ -660,13 +663,13 @@ def extra_workloads(torch, dev, device_index):
         kc = C * (C - 1) // 2 * P * P
         solves = F * kc * J / (m * 1e-3)
         persons = float(cnt.mean())
-        bpf = 12 * C * P * J + 16 * persons * J
+        bpf = 12 * C * P * J + (16 if odt == np.float32 else 32) * persons * J
         tflops = solves * FLOP_PER_SOLVE / 1e12
         # one fused call = the launches of the streaming association (snowtri_last_kernel_names lists them);
         # kernel_ms = HIP events around the whole call
         kernels = bt.ctx.last_kernel_names()
         handed = bt.ctx.last_handover_persons()
-        res.append({"workload": label, "kernel": kernels, "frames": F, "kernel_ms": m,
+        res.append({"workload": label, "kernel": kernels, "frames": F, "kernel_ms": m, "io": "fp32 in / %s out, fp64 math" % ("fp32" if odt == np.float32 else "fp64"),
                     "persons_handed_to_cluster_kernels_last_segment": {"complete_graph": handed[0], "member_list": handed[1]},
                     "kernel_ms_all": ms, "frames_per_s": F / (m * 1e-3),
                     "how": f"{ncalls} calls queued back to back on one stream, HIP events around each call, median",

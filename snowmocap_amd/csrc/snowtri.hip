@@ -1595,23 +1595,24 @@ int launch_frame_general(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax, 
 // The streaming kernels for the descriptors a k_frame_recompute launch over Fs frames left behind (snowtri_cluster.hpp):
 // `cnt[0]` complete-graph clusters in desc[0, cap), `cnt[1]` clusters of any other shape in desc[cap, 2 cap) with their
 // member words in `words`.
-template <int C, typename TIn>
+template <int C, typename TIn, typename TOut>
 int launch_cluster_fuse(snowtri_ctx *ctx, hipStream_t st, int64_t Fs, int Pmax, int J, const TIn *d_kpts, const Params &prm,
-                        int Pout, float *d_xyzs, const ClusterDesc *desc, const uint32_t *words,
+                        int Pout, TOut *d_xyzs, const ClusterDesc *desc, const uint32_t *words,
                         const unsigned long long *cnt, uint32_t cap) {
-    const int64_t passes_max = (Fs * Pout * (int64_t)J + 63) / 64;
+    const int kn = prm.kn;
+    const int64_t passes_max = (Fs * Pout * (int64_t)kn + 63) / 64;
     // exactly the waves that are resident at once (kClusterWaves per SIMD at this kernel's registers), each striding over
     // the passes: with the member lists in a kernel of their own every pass costs the same, and short-lived workgroups only
     // added their start-up (8 x 4: 334 -> 312 us).  (k_cluster_members on a second stream beside this kernel: measured, no gain.)
     const int64_t W = std::min<int64_t>(passes_max, (int64_t)ctx->num_cus * 4 * kClusterWaves);
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((W + kBlock / 64 - 1) / (kBlock / 64), (int64_t)ctx->num_cus * 64));
-    const unsigned long long jmagic = (((unsigned long long)1 << 40) + (unsigned long long)J - 1) / (unsigned long long)J;
-    hipLaunchKernelGGL((k_cluster_fuse<C, TIn>), dim3(grid), dim3(kBlock), cluster_lds_bytes(C), st, desc, cnt, cap, ctx->rig(), d_kpts, prm,
-                       Pmax, J, jmagic, Pout, d_xyzs);
+    const unsigned long long kmagic = (((unsigned long long)1 << 40) + (unsigned long long)kn - 1) / (unsigned long long)kn;
+    hipLaunchKernelGGL((k_cluster_fuse<C, TIn, TOut>), dim3(grid), dim3(kBlock), cluster_lds_bytes(C), st, desc, cnt, cap, ctx->rig(), d_kpts, prm,
+                       Pmax, J, kn, kmagic, Pout, d_xyzs);
     HIP_TRY(hipGetLastError());
     const int gridm = (int)std::max<int64_t>(1, std::min<int64_t>((passes_max + 3) / 4, (int64_t)ctx->num_cus * 16));
-    hipLaunchKernelGGL((k_cluster_members<TIn>), dim3(gridm), dim3(kBlock), cluster_members_lds_bytes(C, ctx->npairs), st, desc, words, cnt,
-                       cap, ctx->rig(), d_kpts, prm, Pmax, J, jmagic, Pout, d_xyzs);
+    hipLaunchKernelGGL((k_cluster_members<TIn, TOut>), dim3(gridm), dim3(kBlock), cluster_members_lds_bytes(C, ctx->npairs), st, desc, words, cnt,
+                       cap, ctx->rig(), d_kpts, prm, Pmax, J, kn, kmagic, Pout, d_xyzs);
     HIP_TRY(hipGetLastError());
     return SNOWTRI_OK;
 }
@@ -1668,19 +1669,23 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st_call, int64_t F, int
         if (ctx->debug) fprintf(stderr, "k_frame_recompute: R %d Kc %lld lds %zu occupancy/CU %d\n", R, (long long)Kc, lds, q);
     }
     int per_cu = oc.per_cu;
-    // Hand-over of the output persons to the streaming fusion kernels (snowtri_cluster.hpp): float32 outputs, pairwise
-    // method, 4-bit person fields, a person's mean score derivable from the candidate means (keypoint_num == J,
-    // non-negative scores).  handover_mode 1: the streaming association (<= 16 cameras); 2: descriptors written by
-    // k_frame_recompute itself (<= 8 cameras: register-resident rays in k_cluster_fuse), staged in its arena.
-    const bool can_hand = METHOD == 0 && sizeof(TOut) == 4 && C >= 2 && Pmax <= kClusterMaxPersons && prm.kn == J && J <= 256 &&
-                          prm.kthr >= 0.0 && Pout >= 1 && (size_t)Pout * 24 + 80 <= (size_t)kRayChunkBytes;
+    // Hand-over of the output persons to the streaming fusion kernels (snowtri_cluster.hpp): pairwise method, 4-bit person
+    // fields, non-negative scores (kthr >= 0).  A person's mean score (:150) is derived from the candidate means when
+    // keypoint_num == J and the outputs are float32; otherwise k_person_scores takes it from the fused joints afterwards, and
+    // the filter of :151-152 -- which the association must decide BEFORE it assigns the slots -- is vacuous only for
+    // condense_score_tol <= 0 (the reference's default), so keypoint_num < J needs that.
+    // handover_mode 1: the streaming association (<= 16 cameras); 2: descriptors written by k_frame_recompute itself
+    // (<= 8 cameras, float32 outputs, keypoint_num == J: register-resident rays in k_cluster_fuse), staged in its arena.
+    const bool can_hand = METHOD == 0 && C >= 2 && Pmax <= kClusterMaxPersons && prm.kn >= 1 && J <= 256 && prm.kthr >= 0.0 && Pout >= 1 &&
+                          (size_t)Pout * 24 + 80 <= (size_t)kRayChunkBytes && (prm.kn == J || prm.score_tol <= 0.0);
+    const bool post_scores = sizeof(TOut) == 8 || prm.kn != J;   // the persons' mean scores by k_person_scores
     SumsLaunch SL{};
     bool stream = can_hand && ctx->handover_mode == 1 && C <= 16 && Kc < ((int64_t)1 << 24) && Pout <= 1024;
     if (stream) {
         SL = sums_launch_shape(ctx, Pmax, J);
         stream = SL.Jc >= 1;
     }
-    const bool handover = !stream && can_hand && ctx->handover_mode != 0 && C <= kClusterMaxCams;
+    const bool handover = !stream && can_hand && sizeof(TOut) == 4 && prm.kn == J && ctx->handover_mode != 0 && C <= kClusterMaxCams;
     // the two descriptor lists hold Pout persons for every frame of a segment (<= 2 M entries each, 64 MB together), the
     // member list Kc words per frame (<= 32 M words, 128 MB); row indices are 32-bit; the candidate sums of the
     // streaming association 8 Kc bytes per frame (<= 512 MB)
@@ -1737,7 +1742,7 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st_call, int64_t F, int
         }
         ctx->last_kernels = ctx->names_buf.c_str();
     }
-    const unsigned long long jmagic = (((unsigned long long)1 << 40) + (unsigned long long)J - 1) / (unsigned long long)J;
+    const unsigned long long kn1 = (unsigned long long)std::max(1, prm.kn), kmagic = (((unsigned long long)1 << 40) + kn1 - 1) / kn1;   // item / keypoint_num
     int seg_index = 0;
     for (int64_t s0 = 0; s0 < F; s0 += seg, seg_index++) {
         const int64_t Fs = std::min<int64_t>(seg, F - s0);
@@ -1769,7 +1774,7 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st_call, int64_t F, int
         TOut *xyz_seg = d_xyzs + s0 * (int64_t)Pout * prm.kn * 4;
         TOut *ps_seg = d_ps ? d_ps + s0 * Pout : nullptr;
         uint32_t *fl_seg = d_fl ? d_fl + s0 : nullptr;
-        if constexpr (METHOD == 0 && sizeof(TOut) == 4) {
+        if constexpr (METHOD == 0) {
             if (stream) {
                 // ---- k_candidate_sums -> k_associate -> k_cluster_fuse, then k_frame_recompute on the frames left behind
                 const size_t sum_bytes = ((size_t)Fs * Kc * 8 + 255) & ~(size_t)255;
@@ -1777,7 +1782,7 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st_call, int64_t F, int
                 if (rc) return rc;
                 double *csum = (double *)ctx->cur->sums.p;
                 uint32_t *slow_list = (uint32_t *)((char *)ctx->cur->sums.p + sum_bytes);
-                auto k2 = k_associate<TIn>;
+                auto k2 = k_associate<TIn, TOut>;
                 const size_t lds2 = associate_lds_bytes(C, ctx->npairs, Pout, Kc);
                 const int grid1 = (int)std::min<int64_t>(Fs, (int64_t)ctx->num_cus * SL.per_cu);
                 if (ctx->debug)
@@ -1801,8 +1806,8 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st_call, int64_t F, int
                 HIP_TRY(hipGetLastError());
                 const int grid2 = (int)std::min<int64_t>(Fs, (int64_t)ctx->num_cus * ctx->assoc_wg_per_cu);
                 hipLaunchKernelGGL(k2, dim3(grid2), dim3(64), lds2, st, Fs, Pmax, J, (int)Kc, ctx->rig(), kp_seg, np_seg, prm, Pout, csum,
-                                   (float *)xyz_seg, (float *)ps_seg, d_cnt + s0, fl_seg, desc, words, hand_counters, cap, word_cap, slow_list,
-                                   slow_count, (int)lds2, 1, (const uint32_t *)nullptr, (const unsigned long long *)nullptr);
+                                   xyz_seg, ps_seg, d_cnt + s0, fl_seg, desc, words, hand_counters, cap, word_cap, slow_list,
+                                   slow_count, (int)lds2, 1, (const uint32_t *)nullptr, (const unsigned long long *)nullptr, post_scores ? 0 : 1);
                 HIP_TRY(hipGetLastError());
                 // the frames whose kept candidates did not fit that LDS (slow_count of them, known on the device only; none on
                 // the reference's workloads): again with room for every slot, one wave per CU; what this launch lists is
@@ -1815,9 +1820,9 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st_call, int64_t F, int
                     uint32_t *slow_list2 = exact_list + Fs;
                     const int per_cu2 = (int)std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds2_full));
                     hipLaunchKernelGGL(k2, dim3((int)std::min<int64_t>(Fs, (int64_t)ctx->num_cus * per_cu2)), dim3(64), lds2_full, st, Fs, Pmax, J,
-                                       (int)Kc, ctx->rig(), kp_seg, np_seg, prm, Pout, csum, (float *)xyz_seg, (float *)ps_seg, d_cnt + s0, fl_seg,
+                                       (int)Kc, ctx->rig(), kp_seg, np_seg, prm, Pout, csum, xyz_seg, ps_seg, d_cnt + s0, fl_seg,
                                        desc, words, hand_counters, cap, word_cap, slow_list2, slow_count2, (int)lds2_full, 1,
-                                       (const uint32_t *)slow_list, (const unsigned long long *)slow_count);
+                                       (const uint32_t *)slow_list, (const unsigned long long *)slow_count, post_scores ? 0 : 1);
                     HIP_TRY(hipGetLastError());
                     final_slow_list = slow_list2;
                     final_slow_count = slow_count2;
@@ -1830,13 +1835,13 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st_call, int64_t F, int
                                hand_counters, cap, word_cap, (const uint32_t *)nullptr, (const unsigned long long *)nullptr);
             HIP_TRY(hipGetLastError());
         }
-        if constexpr (METHOD == 0 && sizeof(TOut) == 4) {
+        if constexpr (METHOD == 0) {
             if (stream || handover) {
                 switch (C) {
 #define SNOWTRI_CASE(CC)                                                                                                       \
     case CC:                                                                                                                   \
-        rc = launch_cluster_fuse<CC, TIn>(ctx, st, Fs, Pmax, J, kp_seg, prm, Pout, (float *)xyz_seg, desc, words,             \
-                                          hand_counters, cap);                                                                 \
+        rc = launch_cluster_fuse<CC, TIn, TOut>(ctx, st, Fs, Pmax, J, kp_seg, prm, Pout, xyz_seg, desc, words,               \
+                                                hand_counters, cap);                                                           \
         break;
 #ifndef SNOWTRI_DEV_MIN
                     SNOWTRI_CASE(2)
@@ -1849,26 +1854,33 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st_call, int64_t F, int
                     SNOWTRI_CASE(8)
 #undef SNOWTRI_CASE
                     default: {   // more than 8 cameras: complete graphs with their rays in LDS, then the member lists
-                        const int64_t passes_max = (Fs * Pout * (int64_t)J + 63) / 64;
+                        const int64_t passes_max = (Fs * Pout * (int64_t)prm.kn + 63) / 64;
                         const int gridm = (int)std::max<int64_t>(1, std::min<int64_t>((passes_max + 3) / 4, (int64_t)ctx->num_cus * 16));
                         if (stream) {
-                            auto kw = k_cluster_fuse_wide<TIn>;
+                            auto kw = k_cluster_fuse_wide<TIn, TOut>;
                             const size_t ldsw = cluster_wide_lds_bytes(C);
                             if (ldsw > 48 * 1024 && ctx->raise_lds((const void *)kw, (int)ldsw)) return SNOWTRI_ERR_HIP;
-                            const int64_t wpasses = (Fs * Pout * (int64_t)J + 15) / 16;   // 16 items per wave pass
+                            const int64_t wpasses = (Fs * Pout * (int64_t)prm.kn + 15) / 16;   // 16 items per wave pass
                             const int ppw_wide = 8;   // (many short-lived workgroups here: 6 -> 886, 24 -> 906, 400 -> 1042 us per 4 000 frames of 16 x 8)
                             const int gridw = (int)std::max<int64_t>(1, std::min<int64_t>((wpasses + 4 * ppw_wide - 1) / (4 * ppw_wide),
                                                                                          (int64_t)ctx->num_cus * 64));
                             hipLaunchKernelGGL(kw, dim3(gridw), dim3(kBlock), ldsw, st, desc, hand_counters, cap, ctx->rig(), kp_seg, prm, Pmax, J,
-                                               jmagic, Pout, (float *)xyz_seg);
+                                               prm.kn, kmagic, Pout, xyz_seg);
                             HIP_TRY(hipGetLastError());
                         }
-                        hipLaunchKernelGGL((k_cluster_members<TIn>), dim3(gridm), dim3(kBlock), cluster_members_lds_bytes(C, ctx->npairs), st,
-                                           desc, words, hand_counters, cap, ctx->rig(), kp_seg, prm, Pmax, J, jmagic, Pout, (float *)xyz_seg);
+                        hipLaunchKernelGGL((k_cluster_members<TIn, TOut>), dim3(gridm), dim3(kBlock), cluster_members_lds_bytes(C, ctx->npairs), st,
+                                           desc, words, hand_counters, cap, ctx->rig(), kp_seg, prm, Pmax, J, prm.kn, kmagic, Pout, xyz_seg);
                         rc = hipGetLastError() == hipSuccess ? SNOWTRI_OK : SNOWTRI_ERR_HIP;
                     }
                 }
                 if (rc) return rc;
+            }
+            if (stream && post_scores && ps_seg) {
+                // the persons' mean scores from the fused joints (keypoint_num < J, float64 outputs)
+                const int gridp = (int)std::max<int64_t>(1, std::min<int64_t>((Fs * Pout + 3) / 4, (int64_t)ctx->num_cus * 32));
+                hipLaunchKernelGGL((k_person_scores<TOut>), dim3(gridp), dim3(kBlock), 0, st, Fs, Pout, prm.kn, (const TOut *)xyz_seg, ps_seg,
+                                   (const int32_t *)(d_cnt + s0));
+                HIP_TRY(hipGetLastError());
             }
             if (stream) {
                 // the frames k_associate listed (slow_count of them, known on the device only): phase 3 inside the kernel

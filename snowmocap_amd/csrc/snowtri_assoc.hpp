@@ -466,16 +466,17 @@ __device__ unsigned long long g_assoc_trace[4096 * 16];
 #else
 #define ASSOC_STAMP(i) ((void)0)
 #endif
-template <typename TIn>
+template <typename TIn, typename TOut>
 __global__ __launch_bounds__(64, 4) void k_associate(int64_t F, int Pmax, int J, int Kc, Rig rig, const TIn *__restrict__ kpts,
                                                   const int32_t *__restrict__ n_persons, Params prm, int Pout,
-                                                  const double *__restrict__ csum, float *__restrict__ out4,
-                                                  float *__restrict__ out_ps, int32_t *__restrict__ out_count,
+                                                  const double *__restrict__ csum, TOut *__restrict__ out4,
+                                                  TOut *__restrict__ out_ps, int32_t *__restrict__ out_count,
                                                   uint32_t *__restrict__ out_flags, ClusterDesc *__restrict__ desc,
                                                   uint32_t *__restrict__ hand_words, unsigned long long *hand_counters,
                                                   uint32_t desc_cap, uint32_t word_cap, uint32_t *__restrict__ slow_list,
                                                   unsigned long long *slow_count, int lds_total, int allow_complete,
-                                                  const uint32_t *__restrict__ frame_list, const unsigned long long *frame_count) {
+                                                  const uint32_t *__restrict__ frame_list, const unsigned long long *frame_count,
+                                                  int write_person_scores) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
     const int C = rig.C, R = C * Pmax, pp = Pmax * Pmax, NPq = rig.npairs;
@@ -495,8 +496,11 @@ __global__ __launch_bounds__(64, 4) void k_associate(int64_t F, int Pmax, int J,
     const unsigned long long magic_pmax = (((unsigned long long)1 << 40) + (unsigned)Pmax - 1) / (unsigned)Pmax;
     const unsigned long long magic_pp = (((unsigned long long)1 << 40) + (unsigned)pp - 1) / (unsigned)pp;
     const Kp3<TIn> *kp3 = reinterpret_cast<const Kp3<TIn> *>(kpts);
-    const PackedWriter<float> wr{out4, out_ps};
-    const int kn = prm.kn;   // == J (host-checked)
+    const PackedWriter<TOut> wr{out4, out_ps};
+    // keypoint_num < J (host-checked: condense_score_tol <= 0, so the filter of :150-152 never drops a person of
+    // non-negative scores) and float64 outputs: the persons' mean scores are written by k_person_scores from the fused
+    // joints (write_person_scores == 0); the unused slots' zeros are written here either way
+    const int kn = prm.kn;
     for (int i = lane; i < 2 * NPq; i += 64) pairs[i] = rig.pairs[i];
 
     // frame_list: the frames a first launch with less LDS left behind (frame_count of them, known on the device only)
@@ -762,7 +766,7 @@ __global__ __launch_bounds__(64, 4) void k_associate(int64_t F, int Pmax, int J,
                             else
                                 desc[desc_cap + (uint32_t)bg + st_idx[sl]] =
                                     ClusterDesc{(uint32_t)f, (uint32_t)bw + st_word[sl], (uint32_t)sl, (uint32_t)st_size[sl]};
-                            wr.person(f, Pout, sl, st_avg[sl]);
+                            if (write_person_scores) wr.person(f, Pout, sl, st_avg[sl]);
                         }
                         for (int sl = 0; sl < nsl; sl++) {
                             const int size = st_size[sl], m0 = (int)st_a[sl];
@@ -777,6 +781,7 @@ __global__ __launch_bounds__(64, 4) void k_associate(int64_t F, int Pmax, int J,
                 const unsigned long long at = atomicAdd(slow_count, 1ull);
                 SNOWTRI_DEV_CHECK(at < (unsigned long long)F, 25);   // the list holds one entry per frame of the segment
                 slow_list[at] = (uint32_t)f;
+                out_count[f] = -1;   // (k_person_scores skips the frame; whoever re-does it writes the count)
             }
             continue;
         }
@@ -797,11 +802,11 @@ __global__ __launch_bounds__(64, 4) void k_associate(int64_t F, int Pmax, int J,
 // instantiation for: any camera count up to kPairTabMaxPairs pairs.  Dynamic LDS: cluster_members_lds_bytes(C, npairs).
 __host__ __device__ inline size_t cluster_members_lds_bytes(int C, int npairs) { return (size_t)72 * C + (size_t)56 * npairs + 16; }
 
-template <typename TIn>
+template <typename TIn, typename TOut>
 __global__ __launch_bounds__(kBlock) void k_cluster_members(const ClusterDesc *__restrict__ desc, const uint32_t *__restrict__ words,
                                                             const unsigned long long *__restrict__ cnt, uint32_t desc_cap, Rig rig,
-                                                            const TIn *__restrict__ kpts, Params prm, int Pmax, int J,
-                                                            unsigned long long jmagic, int Pout, float *__restrict__ out4) {
+                                                            const TIn *__restrict__ kpts, Params prm, int Pmax, int J, int kn,
+                                                            unsigned long long kmagic, int Pout, TOut *__restrict__ out4) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int C = rig.C, NP = rig.npairs, tid = threadIdx.x;
     double *Ml = reinterpret_cast<double *>(smem);
@@ -814,8 +819,31 @@ __global__ __launch_bounds__(kBlock) void k_cluster_members(const ClusterDesc *_
     const uint32_t ngen = ng64 < (unsigned long long)desc_cap ? (uint32_t)ng64 : desc_cap;
     __syncthreads();
     const uint32_t W = gridDim.x * (uint32_t)(kBlock / 64);
-    cluster_member_passes<TIn>(desc + desc_cap, ngen, words, Ml, pc, pairs_l, C * Pmax, reinterpret_cast<const Kp3<TIn> *>(kpts), prm, J,
-                               jmagic, Pout, out4, blockIdx.x * (uint32_t)(kBlock / 64) + (uint32_t)(tid >> 6), W);
+    cluster_member_passes<TIn, TOut>(desc + desc_cap, ngen, words, Ml, pc, pairs_l, C * Pmax, reinterpret_cast<const Kp3<TIn> *>(kpts), prm, J, kn,
+                                     kmagic, Pout, out4, blockIdx.x * (uint32_t)(kBlock / 64) + (uint32_t)(tid >> 6), W);
+}
+
+// ---------------------------------------------------------------------------------------------------- k_person_scores
+// out_ps[f][slot] = mean over the keypoint_num fused joint scores of the person (:150), for every used slot of every frame
+// the streaming route finished (out_count >= 0; the frames it left behind get theirs from k_frame_recompute).  Used when
+// the association kernel cannot derive the mean from the candidate sums: keypoint_num < J (the sums run over all J joints,
+// :79) and float64 outputs (the sums carry the raw v_rsq_f64).  One wave per (frame, slot), lanes = joints, fixed order.
+template <typename TOut>
+__global__ __launch_bounds__(kBlock) void k_person_scores(int64_t F, int Pout, int kn, const TOut *__restrict__ out4, TOut *__restrict__ out_ps,
+                                                          const int32_t *__restrict__ out_count) {
+    const int lane = threadIdx.x & 63;
+    const int64_t W = (int64_t)gridDim.x * (kBlock / 64), total = F * Pout;
+    for (int64_t i = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); i < total; i += W) {
+        const int64_t f = i / Pout;
+        const int slot = (int)(i - f * Pout);
+        const int n = out_count[f];
+        if (slot >= n) continue;   // (n < 0: a frame left to k_frame_recompute)
+        const TOut *row = out4 + (size_t)i * kn * 4;
+        double v = 0.0;
+        for (int b = lane; b < kn; b += 64) v += (double)row[4 * b + 3];
+        v = wave_sum(v);
+        if (lane == 0) out_ps[i] = (TOut)(v / (double)kn);
+    }
 }
 
 }  // namespace snowtri

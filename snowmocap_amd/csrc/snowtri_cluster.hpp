@@ -15,8 +15,9 @@
 //
 // The descriptor carries everything that depends on the association: frame, output slot, the person index of every
 // camera.  out_count / out_ps / flags / the zero-fill of unused slots are written by k_frame_recompute (the person's
-// mean score is the mean of its members' candidate means, which phase 1 already has).  float32 outputs only: 1/dist is
-// the raw v_rsq_f64 as in k_fused_lean (same numerics contract).
+// mean score is the mean of its members' candidate means, which phase 1 already has).  float32 outputs: 1/dist is the raw
+// v_rsq_f64 as in k_fused_lean (same numerics contract); float64 outputs: Newton-refined, and the person's mean
+// score is taken from the fused joints afterwards (k_person_scores), as it is for keypoint_num < J.
 #pragma once
 #include <type_traits>
 #include <utility>
@@ -79,9 +80,12 @@ __device__ __forceinline__ void cluster_static_for(F &&f) {
 // One (cluster, joint): the item of k_fused_lean with the pair offsets read from LDS (28 pairs x 3 doubles do not fit
 // the scalar registers), pairs in groups of four (register budget).  K = [M | t | d] in LDS at offset 0.
 // Returns true if the joint needs the sequential routine (exact intersection, singular pair, NaN).
-template <int C, typename TIn>
+// TOut = float: 1/dist is the raw v_rsq_f64 (2^-24.2 relative, below the rounding of the stored score -- the contract of
+// k_fused_lean); TOut = double: one Newton step on it (2e-14), as the float64 outputs of every other kernel.  The
+// results come back in double; the caller rounds them to TOut when it stores.
+template <int C, typename TIn, typename TOut>
 __device__ __forceinline__ bool cluster_item(const double *__restrict__ K, const Kp3<TIn> (&cur)[C], float kthr_f32, double kthr,
-                                             double dthr2, float &ox, float &oy, float &oz, float &os) {
+                                             double dthr2, double &ox, double &oy, double &oz, double &os) {
 #pragma clang fp contract(off)
     constexpr int NP = C * (C - 1) / 2;
     constexpr int kGroup = 4;
@@ -125,7 +129,11 @@ __device__ __forceinline__ bool cluster_item(const double *__restrict__ K, const
             const double cx = fma(hs.y, dz, -(hs.z * dy)), cy = fma(hs.z, dx, -(hs.x * dz)), cz = fma(hs.x, dy, -(hs.y * dx));
             const double nn = fma(hm.z, cz, fma(hm.y, cy, hm.x * cx));
             const double n2 = nn * nn;
-            const double rho = __builtin_amdgcn_rsq(n2 * det);
+            double rho;
+            if constexpr (sizeof(TOut) == 4)
+                rho = __builtin_amdgcn_rsq(n2 * det);
+            else
+                rho = rsq_nr1(n2 * det);   // (n2 det == 0: inf -> NaN here; either way the sum is not finite and the joint is re-done)
             // :72-74, w det = 2000 x the pair score; the gates select the score sum before the product (plain selects here: 28
             // lane masks held for an inline v_cndmask, as in k_fused_lean, overflow the scalar registers)
             const bool keep = okc[mc] && okc[sc] && !(n2 > dthr2 * det);
@@ -152,58 +160,99 @@ __device__ __forceinline__ bool cluster_item(const double *__restrict__ K, const
     });
     // sb = 2 x 2000 x sum_q s_q (:141); sum == 0 -> (0,0,0)/0 (:142-143): sx = sy = sz = 0 then
     const double r = rcp_nr1(fmax(sb, 1e-300));
-    ox = (float)(sx * r);   // :144-147 as (sum s (Wm+Ws)) / (2 sum s)
-    oy = (float)(sy * r);
-    oz = (float)(sz * r);
-    os = (float)(sb * (0.00025 / (double)NP));   // :148
+    ox = sx * r;   // :144-147 as (sum s (Wm+Ws)) / (2 sum s)
+    oy = sy * r;
+    oz = sz * r;
+    os = sb * (0.00025 / (double)NP);   // :148
     return !(sb < 1e300);
 }
 
-// The same joint member by member, in the order and with the select semantics of phase 3 of k_frame_recompute
-// (float32 outputs): for the rare joints cluster_item cannot finish (0 x inf at an exact intersection whose confidence
-// is gated, inf / NaN sums, a singular pair).
-template <typename TIn>
-__device__ __noinline__ void cluster_joint_sequential(const Rig &rig, const Kp3<TIn> *__restrict__ kp3, int64_t frame0, uint32_t persons,
-                                                      int Pmax, int J, int j, const Params &prm, float &ox, float &oy, float &oz,
-                                                      float &os) {
-    const int C = rig.C, NP = rig.npairs;
-    double aS = 0.0, aX = 0.0, aY = 0.0, aZ = 0.0;
-    for (int q = 0; q < NP; q++) {
-        const int mc = rig.pairs[2 * q], sc = rig.pairs[2 * q + 1];
-        const int64_t rm = (frame0 * C + mc) * Pmax + (int)((persons >> (4 * mc)) & 15u);
-        const int64_t rs = (frame0 * C + sc) * Pmax + (int)((persons >> (4 * sc)) & 15u);
-        const Kp3<TIn> km = kp3[rm * J + j], ks = kp3[rs * J + j];
-        const RayRec a = make_ray(rig.M + 9 * mc, km.u, km.v), b = make_ray(rig.M + 9 * sc, ks.u, ks.v);
-        const double *pc = rig.pairc + 6 * q;
+// One joint record [x, y, z, score] of an output person, rounded to the output type: one 16-byte store (two for doubles).
+template <typename TOut>
+__device__ __forceinline__ void cluster_store(TOut *__restrict__ out4, uint64_t rec, double x, double y, double z, double s) {
+    if constexpr (sizeof(TOut) == 4) {
+        reinterpret_cast<float4 *>(out4)[rec] = make_float4((float)x, (float)y, (float)z, (float)s);
+    } else {
+        double2 *o = reinterpret_cast<double2 *>(out4) + 2 * rec;
+        o[0] = make_double2(x, y);
+        o[1] = make_double2(z, s);
+    }
+}
+
+// One member of a cluster at one joint, with the select semantics of phase 3 of k_frame_recompute: sq = 2000 x the pair
+// score of :72 for float32 outputs, the score itself for float64 (the gates ASSIGN 0, :73-74: select after the product --
+// 0 * inf at an exact intersection), sw = Wm + Ws.
+// float32 outputs: raw v_rsq_f64 for 1/dist; float64 outputs: pair_solve_fast (Newton-refined, d2 == 0 -> inf).
+template <typename TIn, typename TOut>
+__device__ __forceinline__ void cluster_member_solve(const RayRec &a, const RayRec &b, const double *__restrict__ c6, TIn sm, TIn ss,
+                                                     const Params &prm, double &sq, Vec3 &sw) {
+    if constexpr (sizeof(TOut) == 4) {
         const double bq = fma(a.z, b.z, fma(a.y, b.y, a.x * b.x));
-        const double e = fma(a.z, pc[2], fma(a.y, pc[1], a.x * pc[0]));
-        const double g = fma(b.z, pc[2], fma(b.y, pc[1], b.x * pc[0]));
+        const double e = fma(a.z, c6[2], fma(a.y, c6[1], a.x * c6[0]));
+        const double g = fma(b.z, c6[2], fma(b.y, c6[1], b.x * c6[0]));
         const double inv = rcp_nr2(fma(a.a, b.a, -(bq * bq)));
         const double S0 = fma(b.a, e, -(bq * g)) * inv;
         const double S1 = fma(a.a, g, -(bq * e)) * inv;
-        const double fx = fma(b.x, S1, fma(a.x, S0, -pc[0])), fy = fma(b.y, S1, fma(a.y, S0, -pc[1])),
-                     fz = fma(b.z, S1, fma(a.z, S0, -pc[2]));
+        const double fx = fma(b.x, S1, fma(a.x, S0, -c6[0])), fy = fma(b.y, S1, fma(a.y, S0, -c6[1])),
+                     fz = fma(b.z, S1, fma(a.z, S0, -c6[2]));
         const double d2 = fma(fz, fz, fma(fy, fy, fx * fx));
-        const bool kp_ = !below_kthr(km.s, prm) && !below_kthr(ks.s, prm) && !(d2 > prm.dthr2);
-        // the gate ASSIGNS 0 (:73-74): select after the product (0 * inf at an exact intersection)
-        const double sq = kp_ ? sum_score(km.s, ks.s) * __builtin_amdgcn_rsq(d2) : 0.0;
-        aS += sq;                                                              // :141
-        aX = fma(sq, fma(-b.x, S1, fma(a.x, S0, pc[3])), aX);                  // :144-147
-        aY = fma(sq, fma(-b.y, S1, fma(a.y, S0, pc[4])), aY);
-        aZ = fma(sq, fma(-b.z, S1, fma(a.z, S0, pc[5])), aZ);
+        const bool kp_ = !below_kthr(sm, prm) && !below_kthr(ss, prm) && !(d2 > prm.dthr2);
+        sq = kp_ ? sum_score(sm, ss) * __builtin_amdgcn_rsq(d2) : 0.0;
+        sw = {fma(-b.x, S1, fma(a.x, S0, c6[3])), fma(-b.y, S1, fma(a.y, S0, c6[4])), fma(-b.z, S1, fma(a.z, S0, c6[5]))};
+    } else {
+        const PairSolve o = pair_solve_fast<true>(a, b, Vec3{c6[0], c6[1], c6[2]}, Vec3{c6[3], c6[4], c6[5]});
+        const bool kp_ = !below_kthr(sm, prm) && !below_kthr(ss, prm) && !(o.d2 > prm.dthr2);
+        sq = kp_ ? sum_score(sm, ss) * (0.5 * o.score_base) : 0.0;       // the score of :72 itself (k_frame_recompute's float64 branch)
+        sw = o.sw;
     }
-    double x = 0.0, y = 0.0, z = 0.0, s = 0.0;
+}
+
+// sums over the members -> the joint (:141-148); aS = the sum of the members' scores (float32 outputs: 2000 x that)
+template <typename TOut>
+__device__ __forceinline__ void cluster_finish(double aS, double aX, double aY, double aZ, int size, double &x, double &y, double &z, double &s) {
+    x = y = z = s = 0.0;
     if (!(aS == 0.0)) {                                                        // :142-143
-        const double r = 0.5 * rcp_nr2(aS);
-        x = aX * r;
-        y = aY * r;
-        z = aZ * r;
-        s = aS * (0.0005 * rcp_nr2((double)NP));                              // :148
+        if constexpr (sizeof(TOut) == 4) {
+            const double r = 0.5 * rcp_nr2(aS);
+            x = aX * r;
+            y = aY * r;
+            z = aZ * r;
+            s = aS * (0.0005 * rcp_nr2((double)size));                         // :148
+        } else {
+            const double r = 0.5 / aS;
+            x = aX * r;
+            y = aY * r;
+            z = aZ * r;
+            s = aS / (double)size;                                             // :148
+        }
     }
-    ox = (float)x;
-    oy = (float)y;
-    oz = (float)z;
-    os = (float)s;
+}
+
+// The same joint member by member, in the order and with the select semantics of phase 3 of k_frame_recompute: for the rare
+// joints the fast items cannot finish (0 x inf at an exact intersection whose confidence is gated, inf / NaN sums, a
+// singular pair).  plo / phi: the person of camera c in 4 bits (cameras 0-7 / 8-15).
+template <typename TIn, typename TOut>
+__device__ __noinline__ void cluster_joint_sequential(const Rig &rig, const Kp3<TIn> *__restrict__ kp3, int64_t frame0, uint32_t plo,
+                                                      uint32_t phi, int Pmax, int J, int j, const Params &prm, double &ox, double &oy,
+                                                      double &oz, double &os) {
+    const int C = rig.C, NP = rig.npairs;
+    auto person = [&](int c) { return (int)(((c < 8 ? plo : phi) >> (4 * (c & 7))) & 15u); };
+    double aS = 0.0, aX = 0.0, aY = 0.0, aZ = 0.0;
+    for (int q = 0; q < NP; q++) {
+        const int mc = rig.pairs[2 * q], sc = rig.pairs[2 * q + 1];
+        const int64_t rm = (frame0 * C + mc) * Pmax + person(mc);
+        const int64_t rs = (frame0 * C + sc) * Pmax + person(sc);
+        const Kp3<TIn> km = kp3[rm * J + j], ks = kp3[rs * J + j];
+        const RayRec a = make_ray(rig.M + 9 * mc, km.u, km.v), b = make_ray(rig.M + 9 * sc, ks.u, ks.v);
+        double sq;
+        Vec3 sw;
+        cluster_member_solve<TIn, TOut>(a, b, rig.pairc + 6 * q, km.s, ks.s, prm, sq, sw);
+        aS += sq;                                                              // :141
+        aX = fma(sq, sw.x, aX);                                                // :144-147
+        aY = fma(sq, sw.y, aY);
+        aZ = fma(sq, sw.z, aZ);
+    }
+    cluster_finish<TOut>(aS, aX, aY, aZ, NP, ox, oy, oz, os);
 }
 
 // Clusters of any shape: lane = (descriptor, joint), one loop over the cluster's member words (rm | rs << 10 | q << 20,
@@ -211,21 +260,21 @@ __device__ __noinline__ void cluster_joint_sequential(const Rig &rig, const Kp3<
 // Called by every wave of k_cluster_fuse after its own passes (these clusters are few: ghost candidates, partly seen
 // persons; a pass is a chain of dependent loads that hides behind the other waves' complete-graph items).
 //   Ml [C][9] ray matrices, pc [NP][6] pair constants (d, t_m + t_s), pairs [NP][2] camera indices: in LDS.
-template <typename TIn>
+template <typename TIn, typename TOut>
 __device__ __forceinline__ void cluster_member_passes(const ClusterDesc *__restrict__ desc, uint32_t ndesc,
                                                       const uint32_t *__restrict__ words, const double *__restrict__ Ml,
                                                       const double *__restrict__ pc, const int32_t *__restrict__ pairs, int R,
-                                                      const Kp3<TIn> *__restrict__ kp3, const Params &prm, int J,
-                                                      unsigned long long jmagic, int Pout, float *__restrict__ out4, uint32_t p0, uint32_t W) {
+                                                      const Kp3<TIn> *__restrict__ kp3, const Params &prm, int J, int kn,
+                                                      unsigned long long kmagic, int Pout, TOut *__restrict__ out4, uint32_t p0, uint32_t W) {
     const int lane = threadIdx.x & 63;
-    const uint32_t total = ndesc * (uint32_t)J;
+    const uint32_t total = ndesc * (uint32_t)kn;
     const uint32_t npass = (total + 63u) >> 6;
     for (uint32_t p = p0; p < npass; p += W) {
         const uint32_t i = (p << 6) + (uint32_t)lane;
         bool valid = i < total;
         const uint32_t ic = valid ? i : 0u;
-        const uint32_t di = (uint32_t)(((unsigned long long)ic * jmagic) >> 40);
-        const uint32_t j = ic - di * (uint32_t)J;
+        const uint32_t di = (uint32_t)(((unsigned long long)ic * kmagic) >> 40);
+        const uint32_t j = ic - di * (uint32_t)kn;
         uint4 d = make_uint4(0u, 0u, 0u, 0u);
         if (valid) d = *reinterpret_cast<const uint4 *>(desc + di);
         valid = valid && d.z < (uint32_t)Pout;
@@ -238,52 +287,35 @@ __device__ __forceinline__ void cluster_member_passes(const ClusterDesc *__restr
                 const int rm = (int)(w & 1023u), rs = (int)((w >> 10) & 1023u), q = (int)(w >> 20);
                 const Kp3<TIn> km = kp3[(row0 + (uint32_t)rm) * (uint32_t)J + j], ks = kp3[(row0 + (uint32_t)rs) * (uint32_t)J + j];
                 const RayRec a = make_ray(Ml + 9 * pairs[2 * q], km.u, km.v), b = make_ray(Ml + 9 * pairs[2 * q + 1], ks.u, ks.v);
-                const double *c6 = pc + 6 * q;
-                const double bq = fma(a.z, b.z, fma(a.y, b.y, a.x * b.x));
-                const double e = fma(a.z, c6[2], fma(a.y, c6[1], a.x * c6[0]));
-                const double g = fma(b.z, c6[2], fma(b.y, c6[1], b.x * c6[0]));
-                const double inv = rcp_nr2(fma(a.a, b.a, -(bq * bq)));
-                const double S0 = fma(b.a, e, -(bq * g)) * inv;
-                const double S1 = fma(a.a, g, -(bq * e)) * inv;
-                const double fx = fma(b.x, S1, fma(a.x, S0, -c6[0])), fy = fma(b.y, S1, fma(a.y, S0, -c6[1])),
-                             fz = fma(b.z, S1, fma(a.z, S0, -c6[2]));
-                const double d2 = fma(fz, fz, fma(fy, fy, fx * fx));
-                const bool kp_ = !below_kthr(km.s, prm) && !below_kthr(ks.s, prm) && !(d2 > prm.dthr2);
-                // the gate ASSIGNS 0 (:73-74): select after the product (0 * inf at an exact intersection)
-                const double sq = kp_ ? sum_score(km.s, ks.s) * __builtin_amdgcn_rsq(d2) : 0.0;
+                double sq;
+                Vec3 sw;
+                cluster_member_solve<TIn, TOut>(a, b, pc + 6 * q, km.s, ks.s, prm, sq, sw);
                 aS += sq;                                                              // :141
-                aX = fma(sq, fma(-b.x, S1, fma(a.x, S0, c6[3])), aX);                  // :144-147
-                aY = fma(sq, fma(-b.y, S1, fma(a.y, S0, c6[4])), aY);
-                aZ = fma(sq, fma(-b.z, S1, fma(a.z, S0, c6[5])), aZ);
+                aX = fma(sq, sw.x, aX);                                                // :144-147
+                aY = fma(sq, sw.y, aY);
+                aZ = fma(sq, sw.z, aZ);
             }
         }
         if (valid) {
-            double x = 0.0, y = 0.0, z = 0.0, sc = 0.0;
-            if (!(aS == 0.0)) {                                                        // :142-143
-                const double r = 0.5 * rcp_nr2(aS);
-                x = aX * r;
-                y = aY * r;
-                z = aZ * r;
-                sc = aS * (0.0005 * rcp_nr2((double)size));                           // :148
-            }
-            float4 *o = reinterpret_cast<float4 *>(out4) + ((uint64_t)d.x * (uint32_t)Pout + d.z) * (uint64_t)(uint32_t)J + j;
-            *o = make_float4((float)x, (float)y, (float)z, (float)sc);
+            double x, y, z, sc;
+            cluster_finish<TOut>(aS, aX, aY, aZ, size, x, y, z, sc);
+            cluster_store<TOut>(out4, ((uint64_t)d.x * (uint32_t)Pout + d.z) * (uint64_t)(uint32_t)kn + j, x, y, z, sc);
         }
     }
 }
 
-// Grid: any number of workgroups.  Wave gw takes 64-item passes gw, gw + W, ... of the ndesc x J items
-// (item = descriptor * J + joint); the descriptor of the pass after next and the keypoints of the next pass are in
-// flight while a pass is solved.  Then the same for the clusters of any other shape (cluster_member_passes).
-// cnt[kHandComplete], cnt[kHandMembers] >> 32: descriptors in desc[0, cap) (complete graphs) and desc[cap, 2 cap) (member lists).
-// Dynamic LDS: cluster_lds_bytes(C).
-//   jmagic = ceil(2^40 / J): item / J = (item * jmagic) >> 40 for item < 2^31, J <= 256.
+// Grid: any number of workgroups.  Wave gw takes 64-item passes gw, gw + W, ... of the ndesc x kn items
+// (item = descriptor * kn + joint; joints >= keypoint_num are never fused, :136-149).  Three waves per SIMD hide the
+// keypoint fetch of a pass behind the items of the other two (a register prefetch of the next pass cost the third wave:
+// 182 -> 150 registers without it, 8 x 4: 344 -> 295 us).  The clusters of any other shape: k_cluster_members.
+// cnt[kHandComplete]: descriptors in desc[0, cap).  Dynamic LDS: cluster_lds_bytes(C).
+//   kmagic = ceil(2^40 / kn): item / kn = (item * kmagic) >> 40 for item < 2^31, kn <= 256.
 constexpr int kClusterWaves = 3;
-template <int C, typename TIn>
+template <int C, typename TIn, typename TOut>
 __global__ __launch_bounds__(kBlock, kClusterWaves) void k_cluster_fuse(const ClusterDesc *__restrict__ desc,
                                                           const unsigned long long *__restrict__ cnt, uint32_t desc_cap,
-                                                          Rig rig, const TIn *__restrict__ kpts, Params prm, int Pmax, int J,
-                                                          unsigned long long jmagic, int Pout, float *__restrict__ out4) {
+                                                          Rig rig, const TIn *__restrict__ kpts, Params prm, int Pmax, int J, int kn,
+                                                          unsigned long long kmagic, int Pout, TOut *__restrict__ out4) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NP = C * (C - 1) / 2;
     double *K = reinterpret_cast<double *>(smem);   // [M | t | d] for cluster_item
@@ -294,7 +326,7 @@ __global__ __launch_bounds__(kBlock, kClusterWaves) void k_cluster_fuse(const Cl
     if (tid < 3 * NP) K[12 * C + tid] = rig.pairc[6 * (tid / 3) + tid % 3];
     const unsigned long long nd64 = cnt[kHandComplete];
     const uint32_t ndesc = nd64 < (unsigned long long)desc_cap ? (uint32_t)nd64 : desc_cap;
-    const uint32_t total = ndesc * (uint32_t)J;
+    const uint32_t total = ndesc * (uint32_t)kn;
     const uint32_t npass = (total + 63u) >> 6;
     const uint32_t W = gridDim.x * (uint32_t)(kBlock / 64);
     const Kp3<TIn> *kp3 = reinterpret_cast<const Kp3<TIn> *>(kpts);
@@ -302,66 +334,39 @@ __global__ __launch_bounds__(kBlock, kClusterWaves) void k_cluster_fuse(const Cl
     const double kthr = prm.kthr, dthr2 = prm.dthr2;
     __syncthreads();
 
-    struct Item {
-        uint32_t frame, persons, slot, j;
-        bool valid;
-    };
-    auto locate = [&](uint32_t pass) {
-        Item it;
-        const uint32_t i = (pass << 6) + (uint32_t)lane;
-        it.valid = pass < npass && i < total;
-        const uint32_t ic = it.valid ? i : 0u;
-        const uint32_t di = (uint32_t)(((unsigned long long)ic * jmagic) >> 40);
-        it.j = ic - di * (uint32_t)J;
-        it.frame = 0u;
-        it.persons = 0u;
-        it.slot = 0u;
-        if (it.valid) {
-            const uint4 d = *reinterpret_cast<const uint4 *>(desc + di);
-            it.frame = d.x;
-            it.persons = d.y;
-            it.slot = d.z;
-            it.valid = d.z < (uint32_t)Pout;   // (a voided entry, see the hand-over in k_frame_recompute)
-            SNOWTRI_DEV_CHECK(di < ndesc && it.j < (uint32_t)J && (d.z < (uint32_t)Pout || d.z == 0xffffffffu), 30);   // descriptor and joint inside their ranges
+    for (uint32_t p = blockIdx.x * (uint32_t)(kBlock / 64) + (uint32_t)wave; p < npass; p += W) {
+        const uint32_t i = (p << 6) + (uint32_t)lane;
+        bool valid = i < total;
+        const uint32_t ic = valid ? i : 0u;
+        const uint32_t di = (uint32_t)(((unsigned long long)ic * kmagic) >> 40);
+        const uint32_t j = ic - di * (uint32_t)kn;
+        uint4 d = make_uint4(0u, 0u, 0u, 0u);
+        if (valid) {
+            d = *reinterpret_cast<const uint4 *>(desc + di);
+            SNOWTRI_DEV_CHECK(di < ndesc && j < (uint32_t)kn && (d.z < (uint32_t)Pout || d.z == 0xffffffffu), 30);   // descriptor and joint inside their ranges
+            valid = d.z < (uint32_t)Pout;   // (a voided entry, see the hand-over in k_frame_recompute)
         }
-        return it;
-    };
-    auto fetch = [&](Kp3<TIn>(&dst)[C], const Item &it) {
-        if (it.valid) {
+        const uint32_t frame = d.x, persons = d.y, slot = d.z;
+        Kp3<TIn> cur[C];
+        if (valid) {
 #pragma unroll
             for (int c = 0; c < C; c++) {
-                SNOWTRI_DEV_CHECK(((it.persons >> (4 * c)) & 15u) < (uint32_t)Pmax, 31);   // person index of camera c
-                const uint32_t row = (it.frame * (uint32_t)C + (uint32_t)c) * (uint32_t)Pmax + ((it.persons >> (4 * c)) & 15u);
-                dst[c] = kp3[(uint64_t)row * (uint32_t)J + it.j];
+                SNOWTRI_DEV_CHECK(((persons >> (4 * c)) & 15u) < (uint32_t)Pmax, 31);   // person index of camera c
+                const uint32_t row = (frame * (uint32_t)C + (uint32_t)c) * (uint32_t)Pmax + ((persons >> (4 * c)) & 15u);
+                cur[c] = kp3[(uint64_t)row * (uint32_t)J + j];
             }
         } else {
 #pragma unroll
-            for (int c = 0; c < C; c++) dst[c] = Kp3<TIn>{(TIn)0, (TIn)0, (TIn)0};
+            for (int c = 0; c < C; c++) cur[c] = Kp3<TIn>{(TIn)0, (TIn)0, (TIn)0};
         }
-    };
-
-    const uint32_t p_first = blockIdx.x * (uint32_t)(kBlock / 64) + (uint32_t)wave;
-    uint32_t p = p_first;
-    if (p < npass) {
-        Kp3<TIn> cur[C];
-        for (; p < npass; p += W) {
-            const Item it0 = locate(p);
-            fetch(cur, it0);
-            float ox, oy, oz, os;
-            asm volatile("" ::: "memory");   // the rig constants are re-read from LDS in every pass (hoisted out of the loop they would take 360 registers)
-            const bool bad = cluster_item<C, TIn>(K, cur, kthr_f32, kthr, dthr2, ox, oy, oz, os);
-            if (__ballot(bad && it0.valid)) {   // rare, wave-uniform branch
-                if (bad && it0.valid)
-                    cluster_joint_sequential<TIn>(rig, kp3, (int64_t)it0.frame, it0.persons, Pmax, J, (int)it0.j, prm, ox, oy, oz, os);
-            }
-            if (it0.valid) {
-                float4 *o = reinterpret_cast<float4 *>(out4) + ((uint64_t)it0.frame * (uint32_t)Pout + it0.slot) * (uint64_t)(uint32_t)J + it0.j;
-                *o = make_float4(ox, oy, oz, os);
-            }
+        double ox, oy, oz, os;
+        asm volatile("" ::: "memory");   // the rig constants are re-read from LDS in every pass (hoisted out of the loop they would take 360 registers)
+        const bool bad = cluster_item<C, TIn, TOut>(K, cur, kthr_f32, kthr, dthr2, ox, oy, oz, os);
+        if (__ballot(bad && valid)) {   // rare, wave-uniform branch
+            if (bad && valid) cluster_joint_sequential<TIn, TOut>(rig, kp3, (int64_t)frame, persons, 0u, Pmax, J, (int)j, prm, ox, oy, oz, os);
         }
+        if (valid) cluster_store<TOut>(out4, ((uint64_t)frame * (uint32_t)Pout + slot) * (uint64_t)(uint32_t)kn + j, ox, oy, oz, os);
     }
-    // (the member-list clusters of the same launch: k_cluster_members -- a member pass is a chain of dependent loads per member,
-    // which this kernel's waves hid badly: 415 -> 336 + 70 us when they moved out)
 }
 
 
@@ -381,7 +386,8 @@ __global__ __launch_bounds__(kBlock, kClusterWaves) void k_cluster_fuse(const Cl
 //           Fusion accumulates sum s (d + a S0 - b S1) per pair and adds 2 t_m sum s once per first camera
 //           (t_m + t_s = 2 t_m + d), so the camera centres are read once per run, not per pair.
 //   reduce  the four lanes' partial sums meet through two quad shuffles; lane g = 0 stores the joint.
-// Arithmetic per pair as cluster_item (raw v_rsq_f64 for 1/dist, gates select the float32 score sum before the product);
+// Arithmetic per pair as cluster_item (raw v_rsq_f64 for 1/dist with float32 outputs, one Newton step on it with float64
+// outputs; gates select the score sum before the product);
 // one reciprocal per pair (rcp + one Newton step).  Joints whose sum is not finite take cluster_joint_sequential.
 // Member-list descriptors of the same launch are left to k_cluster_members.
 // Dynamic LDS: cluster_wide_lds_bytes(C).
@@ -391,59 +397,13 @@ __host__ __device__ constexpr size_t cluster_wide_lds_bytes(int C) {
     return (size_t)72 * C + (size_t)24 * C + (size_t)24 * C * C + (size_t)(kBlock / 64) * C * kWideRayStride + 16;
 }
 
-// the sequential routine for 64-bit person words (4 bits per camera, 16 cameras)
-template <typename TIn>
-__device__ __noinline__ void cluster_joint_sequential_wide(const Rig &rig, const Kp3<TIn> *__restrict__ kp3, int64_t frame0, uint32_t plo,
-                                                           uint32_t phi, int Pmax, int J, int j, const Params &prm, float &ox, float &oy,
-                                                           float &oz, float &os) {
-    const int C = rig.C, NP = rig.npairs;
-    auto person = [&](int c) { return (int)(((c < 8 ? plo : phi) >> (4 * (c & 7))) & 15u); };
-    double aS = 0.0, aX = 0.0, aY = 0.0, aZ = 0.0;
-    for (int q = 0; q < NP; q++) {
-        const int mc = rig.pairs[2 * q], sc = rig.pairs[2 * q + 1];
-        const int64_t rm = (frame0 * C + mc) * Pmax + person(mc);
-        const int64_t rs = (frame0 * C + sc) * Pmax + person(sc);
-        const Kp3<TIn> km = kp3[rm * J + j], ks = kp3[rs * J + j];
-        const RayRec a = make_ray(rig.M + 9 * mc, km.u, km.v), b = make_ray(rig.M + 9 * sc, ks.u, ks.v);
-        const double *pc = rig.pairc + 6 * q;
-        const double bq = fma(a.z, b.z, fma(a.y, b.y, a.x * b.x));
-        const double e = fma(a.z, pc[2], fma(a.y, pc[1], a.x * pc[0]));
-        const double g = fma(b.z, pc[2], fma(b.y, pc[1], b.x * pc[0]));
-        const double inv = rcp_nr2(fma(a.a, b.a, -(bq * bq)));
-        const double S0 = fma(b.a, e, -(bq * g)) * inv;
-        const double S1 = fma(a.a, g, -(bq * e)) * inv;
-        const double fx = fma(b.x, S1, fma(a.x, S0, -pc[0])), fy = fma(b.y, S1, fma(a.y, S0, -pc[1])),
-                     fz = fma(b.z, S1, fma(a.z, S0, -pc[2]));
-        const double d2 = fma(fz, fz, fma(fy, fy, fx * fx));
-        const bool kp_ = !below_kthr(km.s, prm) && !below_kthr(ks.s, prm) && !(d2 > prm.dthr2);
-        // the gate ASSIGNS 0 (:73-74): select after the product (0 * inf at an exact intersection)
-        const double sq = kp_ ? sum_score(km.s, ks.s) * __builtin_amdgcn_rsq(d2) : 0.0;
-        aS += sq;                                                              // :141
-        aX = fma(sq, fma(-b.x, S1, fma(a.x, S0, pc[3])), aX);                  // :144-147
-        aY = fma(sq, fma(-b.y, S1, fma(a.y, S0, pc[4])), aY);
-        aZ = fma(sq, fma(-b.z, S1, fma(a.z, S0, pc[5])), aZ);
-    }
-    double x = 0.0, y = 0.0, z = 0.0, s = 0.0;
-    if (!(aS == 0.0)) {                                                        // :142-143
-        const double r = 0.5 * rcp_nr2(aS);
-        x = aX * r;
-        y = aY * r;
-        z = aZ * r;
-        s = aS * (0.0005 * rcp_nr2((double)NP));                              // :148
-    }
-    ox = (float)x;
-    oy = (float)y;
-    oz = (float)z;
-    os = (float)s;
-}
-
 constexpr int kWideWaves = 3;
-template <typename TIn>
+template <typename TIn, typename TOut>
 __global__ __launch_bounds__(kBlock, kWideWaves) void k_cluster_fuse_wide(const ClusterDesc *__restrict__ desc,
                                                                                  const unsigned long long *__restrict__ cnt,
                                                                                  uint32_t desc_cap, Rig rig, const TIn *__restrict__ kpts,
-                                                                                 Params prm, int Pmax, int J, unsigned long long jmagic,
-                                                                                 int Pout, float *__restrict__ out4) {
+                                                                                 Params prm, int Pmax, int J, int kn, unsigned long long kmagic,
+                                                                                 int Pout, TOut *__restrict__ out4) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int kMaxOwn = 4;                        // first cameras per lane: C <= 16
     const int C = rig.C, NP = rig.npairs;
@@ -470,7 +430,7 @@ __global__ __launch_bounds__(kBlock, kWideWaves) void k_cluster_fuse_wide(const 
     }
     const unsigned long long nd64 = cnt[kHandComplete];
     const uint32_t ndesc = nd64 < (unsigned long long)desc_cap ? (uint32_t)nd64 : desc_cap;
-    const uint32_t total = ndesc * (uint32_t)J;
+    const uint32_t total = ndesc * (uint32_t)kn;
     const uint32_t npass = (total + 15u) >> 4;
     const uint32_t W = gridDim.x * (uint32_t)(kBlock / 64);
     const Kp3<TIn> *kp3 = reinterpret_cast<const Kp3<TIn> *>(kpts);
@@ -489,8 +449,8 @@ __global__ __launch_bounds__(kBlock, kWideWaves) void k_cluster_fuse_wide(const 
         const uint32_t i = (pass << 4) + (uint32_t)it;
         t.valid = pass < npass && i < total;
         const uint32_t ic = t.valid ? i : 0u;
-        const uint32_t di = (uint32_t)(((unsigned long long)ic * jmagic) >> 40);
-        t.j = ic - di * (uint32_t)J;
+        const uint32_t di = (uint32_t)(((unsigned long long)ic * kmagic) >> 40);
+        t.j = ic - di * (uint32_t)kn;
         t.frame = t.plo = t.phi = t.slot = 0u;
         if (t.valid) {
             const uint4 d = *reinterpret_cast<const uint4 *>(desc + di);
@@ -589,7 +549,12 @@ __global__ __launch_bounds__(kBlock, kWideWaves) void k_cluster_fuse_wide(const 
                     keep = okm && !((float)ss < kthr_f32) && !(d2 > dthr2);
                 else
                     keep = okm && !((double)ss < kthr) && !(d2 > dthr2);
-                const double sq = gated_sum_sel(sm, ss, keep) * __builtin_amdgcn_rsq(d2);
+                double idist;
+                if constexpr (sizeof(TOut) == 4)
+                    idist = __builtin_amdgcn_rsq(d2);
+                else
+                    idist = rsq_nr1(d2);   // (d2 == 0: NaN instead of inf; the sum is not finite either way and the joint is re-done)
+                const double sq = gated_sum_sel(sm, ss, keep) * idist;
                 rS += sq;
                 rX = fma(sq, fma(-bx, S1, fma(ax, S0, dx)), rX);   // d + a S0 - b S1
                 rY = fma(sq, fma(-by, S1, fma(ay, S0, dy)), rY);
@@ -612,17 +577,15 @@ __global__ __launch_bounds__(kBlock, kWideWaves) void k_cluster_fuse_wide(const 
         aZ += __shfl_xor(aZ, 2, 64);
         // aS = 2000 x sum_q s_q (:141); sum == 0 -> (0,0,0)/0 (:142-143): aX = aY = aZ = 0 then
         const double r = 0.5 * rcp_nr1(fmax(aS, 1e-300));
-        float ox = (float)(aX * r), oy = (float)(aY * r), oz = (float)(aZ * r);   // :144-147
-        float os = (float)(aS * (0.0005 / (double)NP));                            // :148
+        double ox = aX * r, oy = aY * r, oz = aZ * r;   // :144-147
+        double os = aS * (0.0005 / (double)NP);         // :148
         const bool bad = !(aS < 1e300) && it0.valid;
         if (__ballot(bad)) {   // rare, wave-uniform branch
             if (bad && g == 0)
-                cluster_joint_sequential_wide<TIn>(rig, kp3, (int64_t)it0.frame, it0.plo, it0.phi, Pmax, J, (int)it0.j, prm, ox, oy, oz, os);
+                cluster_joint_sequential<TIn, TOut>(rig, kp3, (int64_t)it0.frame, it0.plo, it0.phi, Pmax, J, (int)it0.j, prm, ox, oy, oz, os);
         }
-        if (it0.valid && g == 0) {
-            float4 *o = reinterpret_cast<float4 *>(out4) + ((uint64_t)it0.frame * (uint32_t)Pout + it0.slot) * (uint64_t)(uint32_t)J + it0.j;
-            *o = make_float4(ox, oy, oz, os);
-        }
+        if (it0.valid && g == 0)
+            cluster_store<TOut>(out4, ((uint64_t)it0.frame * (uint32_t)Pout + it0.slot) * (uint64_t)(uint32_t)kn + it0.j, ox, oy, oz, os);
         __builtin_amdgcn_wave_barrier();   // the tile is rewritten by the next pass
 #pragma unroll
         for (int i = 0; i < kMaxOwn; i++) cur[i] = nxt[i];

@@ -30,13 +30,15 @@ def api():
     return sm
 
 
-def _run(api, K, R, t, prm, kp, npers, pout, monkeypatch, handover=True, mode=None):
+def _run(api, K, R, t, prm, kp, npers, pout, monkeypatch, handover=True, mode=None, out_dtype=np.float32):
     """mode 1 (default): the streaming association (k_candidate_sums -> k_associate -> cluster kernels, <= 16 cameras);
     mode 2: descriptors written by k_frame_recompute itself (<= 8 cameras); mode 0: everything inside k_frame_recompute."""
     monkeypatch.setenv("SNOWTRI_HANDOVER_MODE", str(mode) if mode is not None else ("1" if handover else "0"))
-    bt = api.BatchTriangulator(K, R, t, prm, pout_max=pout, out_dtype=np.float32)
+    bt = api.BatchTriangulator(K, R, t, prm, pout_max=pout, out_dtype=out_dtype)
     out = bt.run_host(kp, npers)      # (overflow / singular come back as out["status"], not as exceptions)
     out["handed"] = bt.ctx.last_handover_persons()
+    out["kernels"] = bt.ctx.last_kernel_names()
+    out["stream_counts"] = bt.ctx.last_stream_counts()
     bt.close()
     monkeypatch.delenv("SNOWTRI_HANDOVER_MODE")
     return out
@@ -547,3 +549,67 @@ def test_reference_workloads_take_no_fall_back_of_the_streaming_route(api):
         assert "k_candidate_sums" in bt.ctx.last_kernel_names() and "k_associate" in bt.ctx.last_kernel_names()
         assert bt.ctx.last_stream_counts() == (0, 0, 0), (cfg, bt.ctx.last_stream_counts())
         bt.close()
+
+
+@pytest.mark.parametrize("out_dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("kn,center", [(133, 0), (30, 18), (1, 5)])
+@pytest.mark.parametrize("C,P", [(8, 4), (16, 4), (5, 3)])
+def test_streaming_route_for_float64_outputs_and_keypoint_num_below_J(api, C, P, kn, center, out_dtype, monkeypatch):
+    """the reference returns float64 arrays and its signature defaults are center_point_index = 18,
+    keypoint_num = 30 (triangulation.py:95-100,136-148).  Both used to drop a multi-person batch to k_frame_recompute; now the
+    streaming kernels are templated on the output type and fuse only the first keypoint_num joints, and the persons' mean
+    scores (:150) come from the fused joints (k_person_scores).  Against the oracle (float64: 1e-8 m, 1e-9 relative), against
+    the same batch inside k_frame_recompute (SNOWTRI_HANDOVER_MODE=0), with the persons that took each route read back."""
+    from snowmocap_amd import synth
+    from oracle import oracle as orc
+    J = 133
+    rng = np.random.default_rng(500 + 10 * C + kn)
+    F = 6 if C == 16 else 16
+    K, R, t = synth.ring_rig(C, radius=5.0)
+    X = synth.make_people(rng, F, P, J=J)
+    kp, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=0.7, score_range=(2.5, 9.0), permute_persons=True, dtype=np.float32)
+    npers = npers.copy()
+    npers[1, C - 1] = P - 1                 # a person one camera missed: a member-list cluster
+    npers[3, :] = 0                         # an empty frame
+    prm = dict(PRM, keypoint_num=kn, center_point_index=center, condense_person_num_tol=6 if C == 16 else 2)
+    pout = P + 2
+    ref = orc.triangulate_condense_batch(K, R, t, kp, npers, orc.make_params(**prm), 64)
+    out = _run(api, K, R, t, prm, kp, npers, pout, monkeypatch, out_dtype=out_dtype)
+    off = _run(api, K, R, t, prm, kp, npers, pout, monkeypatch, handover=False, out_dtype=out_dtype)
+    assert out["xyzs"].dtype == out_dtype and out["xyzs"].shape == (F, pout, kn, 4)
+    assert "k_associate" in out["kernels"] and "k_associate" not in off["kernels"]
+    assert sum(out["handed"]) == int(np.minimum(ref["count"], pout).sum()) and out["handed"][0] > 0 and out["handed"][1] > 0, out["handed"]
+    f64 = out_dtype == np.float64
+    xyz_tol, rtol = (1e-8, 1e-9) if f64 else (XYZ_F32, 3e-7)
+    for o, name in ((out, "streaming"), (off, "k_frame_recompute")):
+        np.testing.assert_array_equal(o["count"], ref["count"], err_msg=name)
+        for f in range(F):
+            m = min(int(ref["count"][f]), pout)
+            assert not o["xyzs"][f, m:].any() and not o["pscore"][f, m:].any(), f"{name} frame {f}: unused slots must be zero"
+            if m:
+                msg = f"{name} C={C} kn={kn} {np.dtype(out_dtype).name} frame {f}"
+                assert_scores_close(o["xyzs"][f, :m, :, 3], ref["kscore"][f, :m], rtol=rtol, what=msg + " kscore")
+                assert_xyz_close(o["xyzs"][f, :m, :, :3], ref["xyz"][f, :m], xyz_tol, score_ref=ref["kscore"][f, :m], what=msg + " xyz")
+                assert_scores_close(o["pscore"][f, :m], ref["pscore"][f, :m], rtol=rtol, nterms=kn, what=msg + " pscore")
+
+
+def test_keypoint_num_below_J_with_an_active_score_filter_stays_exact(api, monkeypatch):
+    """keypoint_num < J with condense_score_tol > 0: the filter of :150-152 needs the mean over the FIRST keypoint_num joints
+    before the slots are assigned, which the candidate sums (all J joints, :79) do not give -- that combination keeps the
+    whole path inside k_frame_recompute, and matches the oracle."""
+    from snowmocap_amd import synth
+    from oracle import oracle as orc
+    rng = np.random.default_rng(8)
+    C, P, J, F = 6, 3, 133, 10
+    K, R, t = synth.ring_rig(C, radius=5.0)
+    X = synth.make_people(rng, F, P, J=J)
+    kp, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=0.7, score_range=(2.5, 9.0), permute_persons=True, dtype=np.float32)
+    prm = dict(PRM, keypoint_num=30, center_point_index=18)
+    ref0 = orc.triangulate_condense_batch(K, R, t, kp, npers, orc.make_params(**prm), 64)
+    tol = float(np.median(ref0["pscore"][ref0["pscore"] > 0]))     # in the middle of the persons' mean scores
+    prm["condense_score_tol"] = tol
+    ref = orc.triangulate_condense_batch(K, R, t, kp, npers, orc.make_params(**prm), 64)
+    assert 0 < ref["count"].sum() < ref0["count"].sum()
+    out = _run(api, K, R, t, prm, kp, npers, P + 2, monkeypatch)
+    assert "k_associate" not in out["kernels"] and out["handed"] == (-1, -1)
+    _check(out, ref, P + 2, 30, "kn < J with score filter")
