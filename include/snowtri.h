@@ -175,6 +175,17 @@ int snowtri_condense(snowtri_ctx *ctx, int64_t F, int32_t N, int32_t J, const do
                      int32_t Pout_max, double *out_xyz, double *out_kscore, double *out_pscore,
                      int32_t *out_count, uint32_t *out_flags, int memspace, void *stream);
 
+/* The candidates of the last SNOWTRI_HOST snowtri_triangulate call on a context stay on the device.
+ * snowtri_candidates_token names them (0 = none; any later snowtri_triangulate call on the context replaces them);
+ * snowtri_condense_resident runs A4 on them -- the kept slots in slot order, i.e. exactly the list Human_Triangulation
+ * returned -- without uploading them again: the reference calls Human_Triangulation and Human_Triangulation_Condense
+ * back to back (main.py:62-71), and the second upload was a quarter of the per-frame latency.  Host outputs as
+ * snowtri_condense (out_flags may be NULL); SNOWTRI_ERR_BAD_ARG if `token` is not the resident one (the caller then uses
+ * snowtri_condense on its own arrays). */
+int64_t snowtri_candidates_token(const snowtri_ctx *ctx);
+int snowtri_condense_resident(snowtri_ctx *ctx, int64_t token, const snowtri_params *params, int32_t Pout_max, double *out_xyz,
+                              double *out_kscore, double *out_pscore, int32_t *out_count, uint32_t *out_flags);
+
 /* A1..A4 fused over a batch of frames -- the hot path.  Replaces the per-frame sequence
  * add_human_2D_points x (C*P) -> Human_Triangulation -> Human_Triangulation_Condense of
  * main.py:50-71,106.  No candidate list ever reaches HBM on the fast path.

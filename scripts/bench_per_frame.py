@@ -31,6 +31,8 @@ def per_frame_api(frames=300, warm=20):
               for f in range(frames + warm)]
     t_all, t_tri, t_con = [], [], []
     last = None
+    from snowmocap_amd.triangulation import _Resident
+    resident0 = _Resident.used
     for f in range(frames + warm):
         a = time.perf_counter()
         for c in range(C):
@@ -64,6 +66,7 @@ def per_frame_api(frames=300, warm=20):
             "api_sequence_us_median": us(t_all), "api_sequence_us_p90": float(np.percentile(t_all, 90) * 1e6),
             "human_triangulation_us": us(t_tri), "human_triangulation_condense_us": us(t_con),
             "fused_host_call_us_median": us(t_fused),
+            "condense_calls_on_device_resident_candidates": _Resident.used - resident0,
             "reference_ms_per_frame": 24.9,
             "what": "add_human_2D_points x %d -> Human_Triangulation -> Human_Triangulation_Condense -> clear_2D_points "
                     "(reference main.py:50-71,106), wall time per frame incl. Python, PCIe and synchronisation; fused = one "

@@ -6,7 +6,8 @@ import numpy as np, torch
 from snowmocap_amd import synth, _lib
 from snowmocap_amd.batch import BatchTriangulator
 cfg = int(sys.argv[1]) if len(sys.argv) > 1 else 3
-F, gen, pout = (10000, 1000, 16) if cfg == 3 else (4000, 250, 32)
+F, gen, pout = (10000, 1000, 16) if cfg == 3 else (12000, 250, 32)
+os.environ["SNOWTRI_SPLIT_SEGMENTS"] = "1"   # whole segments: workgroups run a second frame (the traced one)
 wl = synth.config_workload(cfg, gen)
 K, R, t = wl["rig"]
 dev = torch.device("cuda", 0)

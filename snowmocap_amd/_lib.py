@@ -80,6 +80,8 @@ _SIGNATURES = {
     "snowtri_condense": (ct.c_int, [_c_p, ct.c_int64, ct.c_int32, ct.c_int32, _c_p, _c_p, _c_p,
                                     ct.POINTER(Params), ct.c_int32, _c_p, _c_p, _c_p, _c_p, _c_p,
                                     ct.c_int, _c_p]),
+    "snowtri_candidates_token": (ct.c_int64, [_c_p]),
+    "snowtri_condense_resident": (ct.c_int, [_c_p, ct.c_int64, ct.POINTER(Params), ct.c_int32, _c_p, _c_p, _c_p, _c_p, _c_p]),
     "snowtri_triangulate_condense": (ct.c_int, [_c_p, ct.c_int64, ct.c_int32, ct.c_int32, _c_p, ct.c_int,
                                                 _c_p, ct.POINTER(Params), ct.c_int, ct.c_int32, _c_p,
                                                 _c_p, ct.c_int, _c_p, _c_p, ct.c_int, _c_p]),

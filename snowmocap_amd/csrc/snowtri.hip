@@ -8,6 +8,7 @@
 #include <hip/hip_ext.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -199,6 +200,8 @@ struct snowtri_ctx {
     Scratch &sums = sets[0].sums;             // candidate sums of k_candidate_sums [frames][Kc] + the frames k_associate left behind
     Scratch in, out, aux;
     PinnedScratch pin_in, pin_out;            // host staging of the per-frame calls
+    Scratch cand;                             // candidates of the last SNOWTRI_HOST snowtri_triangulate call (device-resident hand-over)
+    int64_t cand_token = 0, cand_F = 0, cand_Kc = 0, cand_J = 0;   // token 0: none
     int overlap = 1;                  // snowtri_ctx_set_overlap: device calls rotate over this many sets (1 = the caller's stream)
     int64_t call_index = 0;
     hipEvent_t ev_fork = nullptr;     // the caller's stream at the time of a call / a split: the internal streams wait for it
@@ -440,6 +443,7 @@ int snowtri_ctx_destroy(snowtri_ctx *ctx) {
     ctx->in.release();
     ctx->out.release();
     ctx->aux.release();
+    ctx->cand.release();
     ctx->pin_in.release();
     ctx->pin_out.release();
     for (auto &e : ctx->ev)
@@ -827,15 +831,16 @@ int snowtri_triangulate(snowtri_ctx *ctx, int64_t F, int32_t Pmax, int32_t J, co
     if (host) {
         rc = ctx->in.ensure(in_np_off + np_bytes + 16);
         if (rc) return rc;
-        rc = ctx->out.ensure(out_ns_off + 64);
+        rc = ctx->cand.ensure(out_ns_off + 64);   // (a scratch of its own: the candidates stay resident for snowtri_condense_resident)
         if (rc) return rc;
+        ctx->cand_token = 0;
         d_kpts = ctx->in.p;
         if (n_persons) d_np = (int32_t *)((char *)ctx->in.p + in_np_off);
-        d_xyz = (double *)ctx->out.p;
+        d_xyz = (double *)ctx->cand.p;
         d_ks = d_xyz + nx * 3;
         d_ps = d_ks + nx;
         d_keep = (uint8_t *)(d_ps + (size_t)F * Kc);
-        d_nsing = (unsigned long long *)((char *)ctx->out.p + out_ns_off);
+        d_nsing = (unsigned long long *)((char *)ctx->cand.p + out_ns_off);
         if (pinned) {   // one staged upload
             rc = ctx->pin_in.ensure(in_np_off + np_bytes);
             if (rc) return rc;
@@ -860,7 +865,7 @@ int snowtri_triangulate(snowtri_ctx *ctx, int64_t F, int32_t Pmax, int32_t J, co
     if (host) {
         unsigned long long ns = 0;
         if (pinned) {   // one staged download
-            HIP_TRY(hipMemcpyAsync(ctx->pin_out.p, ctx->out.p, out_ns_off + 8, hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipMemcpyAsync(ctx->pin_out.p, ctx->cand.p, out_ns_off + 8, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             const char *o = (const char *)ctx->pin_out.p;
             std::memcpy(cand_xyz, o, sizeof(double) * nx * 3);
@@ -876,10 +881,18 @@ int snowtri_triangulate(snowtri_ctx *ctx, int64_t F, int32_t Pmax, int32_t J, co
             HIP_TRY(hipMemcpyAsync(&ns, d_nsing, sizeof(ns), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
         }
+        // the candidates stay on the device under a fresh token (snowtri_condense_resident)
+        static std::atomic<int64_t> next_token{1};
+        ctx->cand_token = next_token.fetch_add(1);
+        ctx->cand_F = F;
+        ctx->cand_Kc = Kc;
+        ctx->cand_J = J;
         if (ns) return SNOWTRI_ERR_SINGULAR;
     }
     return SNOWTRI_OK;
 }
+
+int64_t snowtri_candidates_token(const snowtri_ctx *ctx) { return ctx ? ctx->cand_token : 0; }
 
 // ------------------------------------------------------------------------------------------ A4
 int snowtri_condense(snowtri_ctx *ctx, int64_t F, int32_t N, int32_t J, const double *cand_xyz,
@@ -972,6 +985,62 @@ int snowtri_condense(snowtri_ctx *ctx, int64_t F, int32_t N, int32_t J, const do
         for (int64_t f = 0; f < F; f++)
             if (out_count[f] > Pout_max) return SNOWTRI_ERR_OVERFLOW;
     }
+    return SNOWTRI_OK;
+}
+
+// A4 on the candidates the last SNOWTRI_HOST snowtri_triangulate call left on the device: what Human_Triangulation_Condense
+// does when it is handed the unmodified result of Human_Triangulation (main.py:62-71) -- no second trip over PCIe for the
+// candidates (25 KB per frame at 4 x 1 x 133: the upload was a quarter of the per-frame latency).
+int snowtri_condense_resident(snowtri_ctx *ctx, int64_t token, const snowtri_params *params, int32_t Pout_max, double *out_xyz,
+                              double *out_kscore, double *out_pscore, int32_t *out_count, uint32_t *out_flags) {
+    if (!ctx || !params || Pout_max < 1 || !out_xyz || !out_kscore || !out_pscore || !out_count) return SNOWTRI_ERR_BAD_ARG;
+    if (token == 0 || token != ctx->cand_token) return SNOWTRI_ERR_BAD_ARG;   // (another triangulate call replaced them)
+    const int64_t F = ctx->cand_F, N = ctx->cand_Kc;
+    const int J = (int)ctx->cand_J;
+    Params prm;
+    int rc = validate_params(params, J, &prm, true);
+    if (rc) return rc;
+    ENTER_DEVICE(ctx->device);
+    hipStream_t st = nullptr;
+    const int kn = prm.kn;
+    const size_t nx = (size_t)F * N * J, no = (size_t)F * Pout_max * kn;
+    const double *d_xyz = (const double *)ctx->cand.p, *d_ks = d_xyz + nx * 3;
+    const uint8_t *d_keep = (const uint8_t *)(d_ks + nx + (size_t)F * N);
+    const size_t out_total = sizeof(double) * (no * 4 + (size_t)F * Pout_max) + 8 * (size_t)F;
+    rc = ctx->out.ensure(out_total + 64);
+    if (rc) return rc;
+    double *o_xyz = (double *)ctx->out.p, *o_ks = o_xyz + no * 3, *o_ps = o_ks + no;
+    int32_t *o_cnt = (int32_t *)(o_ps + (size_t)F * Pout_max);
+    uint32_t *o_fl = (uint32_t *)(o_cnt + F);
+    HIP_TRY(hipMemsetAsync(o_fl, 0, sizeof(uint32_t) * F, st));
+    rc = launch_condense(ctx, st, F, (int)N, J, d_xyz, d_ks, d_keep, prm, Pout_max, SplitWriter{o_xyz, o_ks, o_ps}, o_cnt, o_fl);
+    if (rc) return rc;
+    const bool pinned = out_total <= kPinnedMaxBytes;
+    const char *o = (const char *)ctx->out.p;
+    if (pinned) {   // one staged download
+        rc = ctx->pin_out.ensure(out_total + 16);
+        if (rc) return rc;
+        HIP_TRY(hipMemcpyAsync(ctx->pin_out.p, ctx->out.p, out_total, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        o = (const char *)ctx->pin_out.p;
+    } else {
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    auto fetch = [&](void *dst, size_t off, size_t bytes) -> hipError_t {
+        if (!bytes) return hipSuccess;
+        if (pinned) {
+            std::memcpy(dst, o + off, bytes);
+            return hipSuccess;
+        }
+        return hipMemcpy(dst, o + off, bytes, hipMemcpyDeviceToHost);
+    };
+    HIP_TRY(fetch(out_xyz, 0, sizeof(double) * no * 3));
+    HIP_TRY(fetch(out_kscore, sizeof(double) * no * 3, sizeof(double) * no));
+    HIP_TRY(fetch(out_pscore, sizeof(double) * no * 4, sizeof(double) * F * Pout_max));
+    HIP_TRY(fetch(out_count, sizeof(double) * (no * 4 + (size_t)F * Pout_max), sizeof(int32_t) * F));
+    if (out_flags) HIP_TRY(fetch(out_flags, sizeof(double) * (no * 4 + (size_t)F * Pout_max) + sizeof(int32_t) * F, sizeof(uint32_t) * F));
+    for (int64_t f = 0; f < F; f++)
+        if (out_count[f] > Pout_max) return SNOWTRI_ERR_OVERFLOW;
     return SNOWTRI_OK;
 }
 
@@ -1782,12 +1851,16 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st_call, int64_t F, int
                 if (rc) return rc;
                 double *csum = (double *)ctx->cur->sums.p;
                 uint32_t *slow_list = (uint32_t *)((char *)ctx->cur->sums.p + sum_bytes);
-                auto k2 = k_associate<TIn, TOut>;
-                const size_t lds2 = associate_lds_bytes(C, ctx->npairs, Pout, Kc);
+                // first launch: centres in registers where the rig's true pairs fit 4 / 16 rounds of 64 (snowtri_assoc.hpp)
+                const AssocShape ash = associate_shape(C, ctx->npairs, Pout, Kc);
+                auto k2 = k_associate<TIn, TOut, 0>;   // the second launch (every slot in LDS)
+                auto k2a = ash.rc == 4 ? k_associate<TIn, TOut, 4> : (ash.rc == 16 ? k_associate<TIn, TOut, 16> : k2);
+                const size_t lds2 = ash.lds;
+                if (lds2 > 48 * 1024 && ctx->raise_lds((const void *)k2a, (int)lds2)) return SNOWTRI_ERR_HIP;
                 const int grid1 = (int)std::min<int64_t>(Fs, (int64_t)ctx->num_cus * SL.per_cu);
                 if (ctx->debug)
-                    fprintf(stderr, "k_candidate_sums: threads %d lds %d per_cu %d grid %d Jc %d | k_associate lds %zu\n", SL.threads, SL.lds,
-                            SL.per_cu, grid1, SL.Jc, lds2);
+                    fprintf(stderr, "k_candidate_sums: threads %d lds %d per_cu %d grid %d Jc %d | k_associate rounds in registers %d lds %zu\n",
+                            SL.threads, SL.lds, SL.per_cu, grid1, SL.Jc, ash.rc, lds2);
                 uint32_t *exact_list = slow_list + Fs;
 #define SNOWTRI_SUMS(TT)                                                                                                             \
     {                                                                                                                                \
@@ -1804,8 +1877,10 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st_call, int64_t F, int
                                    (int)Kc, ctx->rig(), kp_seg, np_seg, prm, csum, fl_seg, (const uint32_t *)exact_list,
                                    (const unsigned long long *)exact_count);
                 HIP_TRY(hipGetLastError());
-                const int grid2 = (int)std::min<int64_t>(Fs, (int64_t)ctx->num_cus * ctx->assoc_wg_per_cu);
-                hipLaunchKernelGGL(k2, dim3(grid2), dim3(64), lds2, st, Fs, Pmax, J, (int)Kc, ctx->rig(), kp_seg, np_seg, prm, Pout, csum,
+                // small rigs: 16 waves per CU, each striding over the frames; large rigs (a frame takes > 100 us and only a few
+                // fit a CU's LDS): one frame per workgroup, the dispatcher evens out the tail
+                const int grid2 = (int)std::min<int64_t>(Fs, lds2 > 10 * 1024 ? Fs : (int64_t)ctx->num_cus * ctx->assoc_wg_per_cu);
+                hipLaunchKernelGGL(k2a, dim3(grid2), dim3(64), lds2, st, Fs, Pmax, J, (int)Kc, ctx->rig(), kp_seg, np_seg, prm, Pout, csum,
                                    xyz_seg, ps_seg, d_cnt + s0, fl_seg, desc, words, hand_counters, cap, word_cap, slow_list,
                                    slow_count, (int)lds2, 1, (const uint32_t *)nullptr, (const unsigned long long *)nullptr, post_scores ? 0 : 1);
                 HIP_TRY(hipGetLastError());

@@ -436,21 +436,40 @@ __host__ __device__ inline size_t associate_arena_offset(int C, int npairs, int 
     const size_t pq = ((size_t)Pout * 4 + 15) & ~(size_t)15;   // four 4-byte arrays padded to 16 bytes + one of doubles
     return ((size_t)64 + 4 * pq + (size_t)8 * Pout + (size_t)4 * C + (size_t)8 * npairs + 15) & ~(size_t)15;
 }
-constexpr int kAssocKeptBytes = 44;
-__host__ inline size_t associate_lds_bytes(int C, int npairs, int Pout, int64_t Kc) {
-    // room for a quarter of the slots (>= 64) and for 1.375 x the true
-    // pairs of Pmax persons every camera sees (npairs x Pmax: a third of the slots at 3 detections per camera, half at 2):
-    // the reference's own workloads keep 25 % (8 x 4) and 13 % (16 x 8) of their candidates
+// bytes per kept candidate: kept index, member index, word (4 B each), score sum (8 B) -- and its centre (24 B) unless the
+// centres live in registers (RC > 0 rounds of 64 candidates: lane l holds the centres of candidates l, 64 + l, ...)
+constexpr int kAssocKeptBytes = 44, kAssocKeptBytesRegs = 20, kAssocClusterRoom = 12 * 48 + 16;
+struct AssocShape {
+    int rc;       // 0: centres in LDS; 4 / 16: in registers, at most 64 rc kept candidates
+    size_t lds;
+};
+__host__ inline AssocShape associate_shape(int C, int npairs, int Pout, int64_t Kc) {
     const int64_t Pmax = (int64_t)(0.5 + __builtin_sqrt((double)Kc / (double)(npairs > 0 ? npairs : 1)));
-    // (no generous minimum: the kernel is latency-bound at one wave per frame, and the frames in flight per CU are what
-    // its LDS allows -- 8 x 4: 8.5 KB instead of 13.5 KB = 16 instead of 12 waves per CU; a frame that keeps more goes
-    // through the second launch)
-    int64_t slots = Kc / 4 < 64 ? 64 : Kc / 4;
-    if (slots < (int64_t)npairs * Pmax * 11 / 8) slots = (int64_t)npairs * Pmax * 11 / 8;
-    if (slots > Kc) slots = Kc;
-    const size_t want = associate_arena_offset(C, npairs, Pout) + (size_t)(kAssocKeptBytes + 6) * (size_t)slots + 64;
-    const size_t cap = 48 * 1024;
-    return want > cap ? cap : (want < 4096 ? 4096 : want);
+    const int64_t true_pairs = (int64_t)npairs * Pmax;   // the candidates of Pmax persons every camera sees
+    // The kernel is latency-bound at one wave per frame: the frames in flight per CU are what its LDS allows, so the first
+    // launch is sized for what the reference's own workloads keep (25 % of the slots at 8 x 4, 13 % at 16 x 8: the true
+    // pairs plus a few ghosts) and a frame that keeps more goes through the second launch.  With the centres in registers a
+    // kept candidate costs 20 bytes: 8 x 4 holds 4.6 KB per frame, 16 x 8 22 KB (7 frames per CU instead of 3 at 48 KB).
+    AssocShape a;
+    if (true_pairs * 11 / 8 <= 256 && (Kc / 4 < 64 ? 64 : Kc / 4) <= 256) {
+        int64_t slots = Kc / 4 < 64 ? 64 : Kc / 4;
+        if (slots < true_pairs * 11 / 8) slots = true_pairs * 11 / 8;
+        if (slots > Kc) slots = Kc;
+        a.rc = 4;
+        a.lds = associate_arena_offset(C, npairs, Pout) + (size_t)kAssocKeptBytesRegs * (size_t)slots + kAssocClusterRoom + 64;
+    } else if (true_pairs + 64 <= 1024) {
+        a.rc = 16;
+        a.lds = associate_arena_offset(C, npairs, Pout) + (size_t)kAssocKeptBytesRegs * 1024 + kAssocClusterRoom + 64;
+    } else {
+        int64_t slots = Kc / 4 < 64 ? 64 : Kc / 4;
+        if (slots < true_pairs * 11 / 8) slots = true_pairs * 11 / 8;
+        if (slots > Kc) slots = Kc;
+        a.rc = 0;
+        a.lds = associate_arena_offset(C, npairs, Pout) + (size_t)(kAssocKeptBytes + 6) * (size_t)slots + 64;
+        if (a.lds > 48 * 1024) a.lds = 48 * 1024;
+    }
+    if (a.lds < 4096) a.lds = 4096;
+    return a;
 }
 
 // LDS that holds EVERY candidate slot of a frame (second launch, for the frames whose kept list did not fit the first)
@@ -466,8 +485,8 @@ __device__ unsigned long long g_assoc_trace[4096 * 16];
 #else
 #define ASSOC_STAMP(i) ((void)0)
 #endif
-template <typename TIn, typename TOut>
-__global__ __launch_bounds__(64, 4) void k_associate(int64_t F, int Pmax, int J, int Kc, Rig rig, const TIn *__restrict__ kpts,
+template <typename TIn, typename TOut, int RC>
+__global__ __launch_bounds__(64, RC > 4 ? 2 : 4) void k_associate(int64_t F, int Pmax, int J, int Kc, Rig rig, const TIn *__restrict__ kpts,
                                                   const int32_t *__restrict__ n_persons, Params prm, int Pout,
                                                   const double *__restrict__ csum, TOut *__restrict__ out4,
                                                   TOut *__restrict__ out_ps, int32_t *__restrict__ out_count,
@@ -492,7 +511,10 @@ __global__ __launch_bounds__(64, 4) void k_associate(int64_t F, int Pmax, int J,
     const int arena_off = (int)associate_arena_offset(C, NPq, Pout);
     char *arena = smem + arena_off;
     const int arena_bytes = lds_total - arena_off;
-    const int n_cap = arena_bytes > 64 ? (arena_bytes - 64) / kAssocKeptBytes : 0;
+    constexpr int kKept = RC > 0 ? kAssocKeptBytesRegs : kAssocKeptBytes;
+    int n_cap = arena_bytes > 64 ? (arena_bytes - 64 - (RC > 0 ? kAssocClusterRoom : 0)) / kKept : 0;
+    if (RC > 0 && n_cap > 64 * RC) n_cap = 64 * RC;
+    if (n_cap < 0) n_cap = 0;
     const unsigned long long magic_pmax = (((unsigned long long)1 << 40) + (unsigned)Pmax - 1) / (unsigned)Pmax;
     const unsigned long long magic_pp = (((unsigned long long)1 << 40) + (unsigned)pp - 1) / (unsigned)pp;
     const Kp3<TIn> *kp3 = reinterpret_cast<const Kp3<TIn> *>(kpts);
@@ -562,19 +584,19 @@ __global__ __launch_bounds__(64, 4) void k_associate(int64_t F, int Pmax, int J,
         }
         int nout = 0;
         if (!slow) {
-            int32_t *cof = kidx + n;
-            uint32_t *lword = reinterpret_cast<uint32_t *>(cof + n);
+            int32_t *members = kidx + n;   // [n] kept indices grouped by cluster, list order inside a cluster (written while clustering)
+            uint32_t *lword = reinterpret_cast<uint32_t *>(members + n);
             double *lsum = reinterpret_cast<double *>(arena + (((size_t)n * 12 + 15) & ~(size_t)15));
-            double *cen = lsum + n;
-            int32_t *csize = reinterpret_cast<int32_t *>(cen + 3 * (size_t)n);
+            double *cen = lsum + n;                                // [n][3] centre joints (RC == 0; in registers otherwise)
+            int32_t *csize = reinterpret_cast<int32_t *>(RC > 0 ? lsum + n : cen + 3 * (size_t)n);
             const int ncl_rem = arena_bytes - (int)(reinterpret_cast<char *>(csize) - arena);
             const int ncl_cap = ncl_rem >= 16 ? (ncl_rem - 4) / 12 : 0;   // csize, cseed [ncl_cap], cstart [ncl_cap + 1]
             ASSOC_STAMP(2);
             __syncthreads();
             // ---- per kept candidate: word, score sum, centre joint.  Two candidates per lane and step: their keypoint loads
             // are in flight together.
-            for (int i0 = 0; i0 < n; i0 += 128) {
-                const int ia = i0 + lane, ib = i0 + 64 + lane;
+            double cx[RC > 0 ? RC : 1], cy[RC > 0 ? RC : 1], cz[RC > 0 ? RC : 1];   // RC > 0: centre of candidate 64 r + lane
+            auto centre_pair = [&](int ia, int ib, Vec3 &ca, Vec3 &cb) {
                 const bool va = ia < n, vb = ib < n;
                 const int ka = va ? kidx[ia] : 0, kb = vb ? kidx[ib] : 0;
                 int rma, rsa, qa, rmb, rsb, qb;
@@ -588,76 +610,150 @@ __global__ __launch_bounds__(64, 4) void k_associate(int64_t F, int Pmax, int J,
                     const RayRec a = make_ray(rig.M + 9 * mc, km.u, km.v), b = make_ray(rig.M + 9 * sc, ks.u, ks.v);
                     const double *pc = rig.pairc + 6 * q;
                     const PairSolve o = pair_solve_fast<true>(a, b, Vec3{pc[0], pc[1], pc[2]}, Vec3{pc[3], pc[4], pc[5]});
-                    cen[3 * i] = 0.5 * o.sw.x;
-                    cen[3 * i + 1] = 0.5 * o.sw.y;
-                    cen[3 * i + 2] = 0.5 * o.sw.z;
-                    cof[i] = -1;
                     lword[i] = (uint32_t)rm | ((uint32_t)rs << 10) | ((uint32_t)q << 20);
                     lsum[i] = s_;
+                    return Vec3{0.5 * o.sw.x, 0.5 * o.sw.y, 0.5 * o.sw.z};
                 };
-                if (va) centre(ia, rma, rsa, qa, kma, ksa, sa);
-                if (vb) centre(ib, rmb, rsb, qb, kmb, ksb, sb);
+                ca = cb = Vec3{0.0, 0.0, 0.0};
+                if (va) ca = centre(ia, rma, rsa, qa, kma, ksa, sa);
+                if (vb) cb = centre(ib, rmb, rsb, qb, kmb, ksb, sb);
+            };
+            if constexpr (RC > 0) {
+#pragma unroll
+                for (int r = 0; r < RC; r += 2) {
+                    cx[r] = cy[r] = cz[r] = 0.0;
+                    if (r + 1 < RC) cx[r + 1] = cy[r + 1] = cz[r + 1] = 0.0;
+                    if (64 * r < n) {   // wave-uniform
+                        Vec3 ca, cb;
+                        centre_pair(64 * r + lane, 64 * (r + 1) + lane, ca, cb);
+                        cx[r] = ca.x;
+                        cy[r] = ca.y;
+                        cz[r] = ca.z;
+                        if (r + 1 < RC) {
+                            cx[r + 1] = cb.x;
+                            cy[r + 1] = cb.y;
+                            cz[r + 1] = cb.z;
+                        }
+                    }
+                }
+            } else {
+                for (int i0 = 0; i0 < n; i0 += 128) {
+                    Vec3 ca, cb;
+                    centre_pair(i0 + lane, i0 + 64 + lane, ca, cb);
+                    if (i0 + lane < n) {
+                        cen[3 * (i0 + lane)] = ca.x;
+                        cen[3 * (i0 + lane) + 1] = ca.y;
+                        cen[3 * (i0 + lane) + 2] = ca.z;
+                    }
+                    if (i0 + 64 + lane < n) {
+                        cen[3 * (i0 + 64 + lane)] = cb.x;
+                        cen[3 * (i0 + 64 + lane) + 1] = cb.y;
+                        cen[3 * (i0 + 64 + lane) + 2] = cb.z;
+                    }
+                }
             }
             ASSOC_STAMP(3);
             __syncthreads();
             // ---- triangulation.py:107-130 -- seeds in list order, the last candidate never seeds, distance to the SEED's
-            // centre, `dist > tol` skips (NaN absorbs)
+            // centre, `dist > tol` skips (NaN absorbs).  Which kept candidates are still free is a bit set in REGISTERS: lane c
+            // holds the 64 bits of candidates 64 c .. 64 c + 63 (n <= 4096).  Finding the next seed is one ballot + one
+            // readlane; a seed's pass over the later candidates skips every 64-block without a free one (after the first
+            // persons' seeds most blocks are empty) and writes the absorbed indices straight into `members` -- the clusters come
+            // out grouped, in list order, without a second sweep per cluster (16 x 8, 983 kept candidates in 29 clusters:
+            // clustering + grouping took 110 of a frame's 172 us, wall-clock stamps).  The comparison is on squared distances;
+            // only a value within 1e-14 of the squared tolerance takes the square root the reference takes.
             int ncl = 0;
             int32_t *cseed = csize + ncl_cap;
-            if (ncl_cap < 1) slow = true;
+            int32_t *cstart = cseed + ncl_cap;                    // [ncl + 1]
+            const int nblk = (n + 63) >> 6;
+            if (ncl_cap < 1 || nblk > 64 || (RC > 0 && nblk > RC)) slow = true;
+            unsigned long long free_bits = 0ull;                  // lane c: candidates 64 c + b, bit b
+            if (lane < nblk) free_bits = (lane == nblk - 1 && (n & 63)) ? ((1ull << (n & 63)) - 1ull) : ~0ull;
+            const double ctol2 = prm.ctol < 0.0 ? -1.0 : prm.ctol * prm.ctol;   // (dist >= 0 > tol: nothing is absorbed but NaN)
+            const double ctol2_lo = ctol2 * (1.0 - 1e-14), ctol2_hi = ctol2 * (1.0 + 1e-14);
+            auto bits_of = [&](int blk) {                         // lane blk's word, wave-uniform
+                const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(free_bits & 0xffffffffull), blk);
+                const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(free_bits >> 32), blk);
+                return ((unsigned long long)hi << 32) | lo;
+            };
+            int off = 0;
             for (int next = 0; !slow;) {
-                int mc = -1;
-                for (int base = next & ~63; base < n - 1 && mc < 0; base += 64) {
-                    const int i = base + lane;
-                    const unsigned long long m = __ballot(i >= next && i < n - 1 && cof[i] == -1);
-                    if (m) mc = base + __ffsll((long long)m) - 1;
-                }
-                if (mc < 0) break;
+                // the first free candidate at or behind `next` that may seed (index < n - 1)
+                unsigned long long mine = free_bits;
+                const int blk_l = lane;
+                if (blk_l == (next >> 6)) mine &= ~((1ull << (next & 63)) - 1ull);
+                if (blk_l < (next >> 6)) mine = 0ull;
+                if (blk_l == ((n - 1) >> 6)) mine &= ~(1ull << ((n - 1) & 63));
+                const unsigned long long have = __ballot(mine != 0ull);
+                if (!have) break;
+                const int sblk = __ffsll((long long)have) - 1;
+                const unsigned slo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mine & 0xffffffffull), sblk);
+                const unsigned shi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(mine >> 32), sblk);
+                const unsigned long long sw = ((unsigned long long)shi << 32) | slo;
+                const int mc = (sblk << 6) + __ffsll((long long)sw) - 1;
                 if (ncl >= ncl_cap) {
                     slow = true;
                     break;
                 }
                 SNOWTRI_DEV_CHECK(mc >= 0 && mc < n - 1, 22);   // the seed is a kept candidate, never the last one (:107)
-                const double mx = cen[3 * mc], my = cen[3 * mc + 1], mz = cen[3 * mc + 2];
-                int cnt = 0;
-                for (int base = mc + 1; base < n; base += 64) {
-                    const int sc = base + lane;
-                    bool ab = false;
-                    if (sc < n && cof[sc] == -1) {
-                        const double dx = mx - cen[3 * sc], dy = my - cen[3 * sc + 1], dz = mz - cen[3 * sc + 2];
-                        const double dist = sqrt(fma(dz, dz, fma(dy, dy, dx * dx)));
-                        if (!(dist > prm.ctol)) {
-                            cof[sc] = ncl;
-                            ab = true;
+                double mx, my, mz;
+                if constexpr (RC > 0) {
+                    mx = my = mz = 0.0;
+#pragma unroll
+                    for (int r = 0; r < RC; r++)
+                        if (r == sblk) {   // wave-uniform
+                            mx = uniform_lane_f64(cx[r], mc & 63);
+                            my = uniform_lane_f64(cy[r], mc & 63);
+                            mz = uniform_lane_f64(cz[r], mc & 63);
                         }
+                } else {
+                    mx = cen[3 * mc];
+                    my = cen[3 * mc + 1];
+                    mz = cen[3 * mc + 2];
+                }
+                if (lane == 0) members[off] = mc;
+                int cnt = 1;
+                // one 64-block of candidates against the seed; (px, py, pz) = the lane's candidate of that block
+                auto absorb_block = [&](int blk, double px, double py, double pz) {
+                    unsigned long long fb = bits_of(blk);
+                    if (blk == sblk) fb &= ~((2ull << (mc & 63)) - 1ull);   // later candidates only (:116)
+                    if (fb == 0ull) return;
+                    const int sc = (blk << 6) + lane;
+                    bool ab = false;
+                    if ((fb >> lane) & 1ull) {
+                        const double dx = mx - px, dy = my - py, dz = mz - pz;
+                        const double d2 = fma(dz, dz, fma(dy, dy, dx * dx));
+                        bool far = d2 > ctol2_hi;
+                        if (!far && !(d2 < ctol2_lo)) far = sqrt(d2) > prm.ctol;   // (on the tolerance, or NaN: as :124-125)
+                        ab = !far;
                     }
-                    cnt += __popcll(__ballot(ab));
+                    const unsigned long long m = __ballot(ab);
+                    SNOWTRI_DEV_CHECK(!ab || off + cnt + __popcll(m & ((1ull << lane) - 1ull)) < n, 26);   // member inside the list
+                    if (ab) members[off + cnt + __popcll(m & ((1ull << lane) - 1ull))] = sc;
+                    cnt += __popcll(m);
+                    if (lane == blk) free_bits &= ~m;
+                };
+                if constexpr (RC > 0) {
+#pragma unroll
+                    for (int r = 0; r < RC; r++)
+                        if (r >= sblk && r < nblk) absorb_block(r, cx[r], cy[r], cz[r]);   // wave-uniform
+                } else {
+                    for (int blk = sblk; blk < nblk; blk++) {
+                        const int sc = (blk << 6) + lane, scc = sc < n ? sc : 0;
+                        absorb_block(blk, cen[3 * scc], cen[3 * scc + 1], cen[3 * scc + 2]);
+                    }
                 }
+                if (lane == sblk) free_bits &= ~(1ull << (mc & 63));
                 if (lane == 0) {
-                    cof[mc] = ncl;
-                    csize[ncl] = cnt + 1;
+                    csize[ncl] = cnt;
                     cseed[ncl] = mc;
+                    cstart[ncl] = off;
                 }
+                off += cnt;
                 ncl++;
                 next = mc + 1;
-                __syncthreads();
             }
             if (!slow) {
-                int32_t *cstart = cseed + ncl_cap;                    // [ncl + 1]
-                int32_t *members = reinterpret_cast<int32_t *>(cen);  // [n] kept indices grouped by cluster (the centres are dead)
-                __syncthreads();
-                // members grouped by cluster, list order inside each cluster
-                int off = 0;
-                for (int c = 0; c < ncl; c++) {
-                    if (lane == 0) cstart[c] = off;
-                    for (int base = cseed[c]; base < n; base += 64) {
-                        const int i = base + lane;
-                        const bool in = i < n && cof[i] == c;
-                        const unsigned long long m = __ballot(in);
-                        if (in) members[off + __popcll(m & ((1ull << lane) - 1ull))] = i;
-                        off += __popcll(m);
-                    }
-                }
                 if (lane == 0) cstart[ncl] = off;
                 __syncthreads();
                 ASSOC_STAMP(4);

@@ -80,6 +80,12 @@ __device__ __forceinline__ double uniform_f64(double x) {  // wave-uniform value
     return __hiloint2double(hi, lo);
 }
 
+__device__ __forceinline__ double uniform_lane_f64(double x, int lane) {  // the value lane `lane` (wave-uniform) holds
+    const int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
+    return __hiloint2double(hi, lo);
+}
+
 // x if the lane's bit of `mask` is set, else 0: one v_cndmask_b32 on a scalar lane mask (the compiler turns
 // a bool that crosses basic blocks into a VGPR 0/1 and three more VALU instructions)
 __device__ __forceinline__ float select_by_mask(float x, unsigned long long mask) {

@@ -76,11 +76,46 @@ def Human_Triangulation(camera_group, keypoint_score_threshold=0.5, average_scor
     if rc == _lib.ERR_SINGULAR:
         raise np.linalg.LinAlgError("Singular matrix")      # np.linalg.inv at triangulation.py:26
     _lib.check(rc, "snowtri_triangulate")
-    for k in np.nonzero(keep)[0]:
-        result[_KEYS[0]].append(xyz[k].copy())
-        result[_KEYS[1]].append(ks[k].copy())
-        result[_KEYS[2]].append(np.float64(ps[k]))
+    kept = np.nonzero(keep)[0]
+    # the candidates are rows of the two blocks the library filled (no copy per candidate); the blocks and the device-side
+    # twin the call left behind are remembered so that Human_Triangulation_Condense can skip the upload (_Resident)
+    pts = [xyz[k] for k in kept]
+    scs = [ks[k] for k in kept]
+    result[_KEYS[0]] = pts
+    result[_KEYS[1]] = scs
+    result[_KEYS[2]] = [np.float64(ps[k]) for k in kept]
+    _Resident.remember(ctx, int(L.snowtri_candidates_token(ctx.handle)), pts, scs, xyz, ks, J)
     return result
+
+
+class _Resident:
+    """The device-resident twin of the last Human_Triangulation result (main.py:62-71 calls Condense right after it).
+
+    Human_Triangulation leaves its candidates in the context's device scratch (snowtri_candidates_token) and hands the caller
+    VIEWS of the two host blocks it downloaded.  Human_Triangulation_Condense may use the device twin instead of uploading
+    the candidates again only if the dict it receives still IS that result: the same view objects in the same order, and
+    the blocks' contents unchanged (a user may edit candidates in place -- then, or after any other change, the ordinary
+    upload path runs on the arrays as they are)."""
+    last = None
+    used = 0       # Condense calls that took the device twin (tests / bench)
+
+    @classmethod
+    def remember(cls, ctx, token, pts, scs, xyz, ks, J):
+        cls.last = (ctx, token, list(pts), list(scs), xyz, ks, xyz.copy(), ks.copy(), J) if token else None
+
+    @classmethod
+    def match(cls, points, scores):
+        r = cls.last
+        if r is None:
+            return None
+        ctx, token, pts, scs, xyz, ks, xyz0, ks0, J = r
+        if len(points) != len(pts) or len(scores) != len(scs) or not ctx.handle:
+            return None
+        if any(a is not b for a, b in zip(points, pts)) or any(a is not b for a, b in zip(scores, scs)):
+            return None
+        if not (np.array_equal(xyz, xyz0, equal_nan=True) and np.array_equal(ks, ks0, equal_nan=True)):
+            return None
+        return ctx, token, J
 
 
 def Human_Triangulation_Condense(result, condense_distance_tol=0.1, condense_person_num_tol=0,
@@ -93,10 +128,6 @@ def Human_Triangulation_Condense(result, condense_distance_tol=0.1, condense_per
     if n - 1 <= 0:                 # range(person_num - 1) is empty: nothing is ever emitted
         return out
     L = _lib.lib()
-    ctx = _lib.scratch_context()
-    cxyz = np.ascontiguousarray(np.stack([np.asarray(p, dtype=np.float64) for p in points]))
-    cks = np.ascontiguousarray(np.stack([np.asarray(s, dtype=np.float64) for s in scores]))
-    J = cxyz.shape[1]
     prm = _lib.make_params(condense_distance_tol=condense_distance_tol,
                            condense_person_num_tol=condense_person_num_tol,
                            condense_score_tol=condense_score_tol,
@@ -107,8 +138,20 @@ def Human_Triangulation_Condense(result, condense_distance_tol=0.1, condense_per
     oks = np.empty((pout, max(kn, 0)))
     ops = np.empty(pout)
     cnt = np.zeros(1, dtype=np.int32)
-    rc = L.snowtri_condense(ctx.handle, 1, n, J, _lib.ptr(cxyz), _lib.ptr(cks), None, prm, pout,
-                            _lib.ptr(oxyz), _lib.ptr(oks), _lib.ptr(ops), _lib.ptr(cnt), None, _lib.HOST, None)
+    rc = _lib.ERR_BAD_ARG
+    resident = _Resident.match(points, scores)
+    if resident is not None:        # the unmodified result of Human_Triangulation: its candidates are still on the device
+        ctx, token, J = resident
+        rc = L.snowtri_condense_resident(ctx.handle, token, prm, pout, _lib.ptr(oxyz), _lib.ptr(oks), _lib.ptr(ops),
+                                         _lib.ptr(cnt), None)
+        _Resident.used += rc != _lib.ERR_BAD_ARG
+    if resident is None or rc == _lib.ERR_BAD_ARG:
+        ctx = _lib.scratch_context()
+        cxyz = np.ascontiguousarray(np.stack([np.asarray(p, dtype=np.float64) for p in points]))
+        cks = np.ascontiguousarray(np.stack([np.asarray(s, dtype=np.float64) for s in scores]))
+        J = cxyz.shape[1]
+        rc = L.snowtri_condense(ctx.handle, 1, n, J, _lib.ptr(cxyz), _lib.ptr(cks), None, prm, pout,
+                                _lib.ptr(oxyz), _lib.ptr(oks), _lib.ptr(ops), _lib.ptr(cnt), None, _lib.HOST, None)
     if rc == _lib.ERR_BAD_INDEX:
         raise IndexError("index out of bounds (center_point_index / keypoint_num vs. joints per candidate)")
     _lib.check(rc, "snowtri_condense")

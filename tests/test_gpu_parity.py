@@ -1288,3 +1288,55 @@ def test_every_entry_rejects_bad_arguments_on_a_real_context(api, tmp_path):
                            "-Wl,-rpath," + lib_dir])
     out = subprocess.run([exe], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0 and "0 failure(s)" in out.stdout, out.stdout[-3000:] + out.stderr[-2000:]
+
+
+def test_condense_uses_the_device_resident_candidates_only_for_an_unmodified_result(api):
+    """main.py:62-71 calls Human_Triangulation_Condense on the dict Human_Triangulation just returned: its candidates are
+    still on the device (snowtri_condense_resident) and are not uploaded again.  Anything else -- a copied dict of copied
+    arrays, a candidate edited in place, a replaced or removed entry, another Human_Triangulation call in between -- takes the
+    ordinary path on the arrays as they are.  Both paths give the same bits on the same candidates."""
+    import copy
+    from snowmocap_amd import synth
+    from snowmocap_amd.triangulation import _Resident
+    rng = np.random.default_rng(77)
+    C, P, J = 4, 2, 33
+    K, R, t = synth.ring_rig(C, radius=4.5)
+    X = synth.make_people(rng, 2, P, J=J)
+    kp, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=0.5, score_range=(3.5, 8.0), permute_persons=True, dtype=np.float32)
+    sc = dict(K=K, R=R, t=t, kpts=kp, n_persons=npers)
+    cg = _group(api, sc)
+    tri_kw = dict(keypoint_score_threshold=3.0, average_score_threshold=0.3, distance_threshold=0.05)
+    con_kw = dict(condense_distance_tol=0.3, condense_person_num_tol=0, condense_score_tol=0.0, center_point_index=0, keypoint_num=J)
+
+    def same(a, b):
+        return len(a[KEYS[0]]) == len(b[KEYS[0]]) and all(np.array_equal(x, y, equal_nan=True) for k in KEYS[:2] for x, y in zip(a[k], b[k])) \
+            and list(a[KEYS[2]]) == list(b[KEYS[2]])
+
+    KEYS = ("hrnet_triangulate_points", "hrnet_triangulate_keypoint_scores", "hrnet_triangulate_person_scores")
+    _feed(cg, sc, 0)
+    tri = api.Human_Triangulation(cg, **tri_kw)
+    assert len(tri[KEYS[0]]) >= 4
+    u0 = _Resident.used
+    con = api.Human_Triangulation_Condense(tri, **con_kw)
+    assert _Resident.used == u0 + 1 and len(con[KEYS[0]]) == P
+    con_again = api.Human_Triangulation_Condense(tri, **con_kw)                    # twice on the same dict: still resident
+    assert _Resident.used == u0 + 2 and same(con, con_again)
+    con_copy = api.Human_Triangulation_Condense(copy.deepcopy(tri), **con_kw)      # copies: uploaded
+    assert _Resident.used == u0 + 2 and same(con, con_copy)
+    # a candidate edited in place: the edit must count (the device twin is stale)
+    tri[KEYS[1]][1][:] = 0.0
+    edited = api.Human_Triangulation_Condense(tri, **con_kw)
+    assert _Resident.used == u0 + 2
+    assert same(edited, api.Human_Triangulation_Condense(copy.deepcopy(tri), **con_kw)) and not same(edited, con)
+    # a fresh result, then one entry removed / another frame triangulated in between
+    tri = api.Human_Triangulation(cg, **tri_kw)
+    shorter = {k: list(v[:-1]) for k, v in tri.items()}
+    s1 = api.Human_Triangulation_Condense(shorter, **con_kw)
+    assert _Resident.used == u0 + 2 and same(s1, api.Human_Triangulation_Condense(copy.deepcopy(shorter), **con_kw))
+    cg.clear_2D_points()
+    _feed(cg, sc, 1)
+    tri2 = api.Human_Triangulation(cg, **tri_kw)                                    # replaces the resident candidates
+    old = api.Human_Triangulation_Condense(tri, **con_kw)
+    assert _Resident.used == u0 + 2 and same(old, con)
+    new = api.Human_Triangulation_Condense(tri2, **con_kw)
+    assert _Resident.used == u0 + 3 and same(new, api.Human_Triangulation_Condense(copy.deepcopy(tri2), **con_kw))
