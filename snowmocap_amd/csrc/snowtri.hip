@@ -95,26 +95,32 @@ struct Scratch {
 // (a pageable copy is staged and synchronised by the runtime, ~10-20 us each).
 struct PinnedScratch {
     void *p = nullptr;
+    void *dev = nullptr;   // the same memory as the device sees it (mapped: the small calls' kernels read / write it in place)
     size_t cap = 0;
     int ensure(size_t bytes) {
         if (bytes <= cap) return SNOWTRI_OK;
         if (p) {
             HIP_TRY(hipHostFree(p));
-            p = nullptr;
+            p = dev = nullptr;
             cap = 0;
         }
         size_t want = std::max(bytes, (size_t)64 << 10);
-        HIP_TRY(hipHostMalloc(&p, want, hipHostMallocDefault));
+        HIP_TRY(hipHostMalloc(&p, want, hipHostMallocMapped));
+        HIP_TRY(hipHostGetDevicePointer(&dev, p, 0));
         cap = want;
         return SNOWTRI_OK;
     }
     void release() {
         if (p) (void)hipHostFree(p);
-        p = nullptr;
+        p = dev = nullptr;
         cap = 0;
     }
 };
 constexpr size_t kPinnedMaxBytes = (size_t)4 << 20;   // larger host batches keep the direct copies
+// The per-frame calls (main.py hands over 6 KB of keypoints and takes back 30 KB of candidates): below this size the kernels
+// read their inputs from, and mirror their outputs into, the mapped page-locked buffers directly -- no copy engine in the chain
+// (H2D + D2H were ~20 of the 39 us of a snowtri_triangulate call).
+constexpr size_t kZeroCopyMaxBytes = (size_t)256 << 10;
 
 int inv3(const double *m, double *o) {
     const double c00 = m[4] * m[8] - m[5] * m[7];
@@ -139,7 +145,7 @@ constexpr int kTimingRing = 1024;
 // ctx->d_counters: [0] singular pairs, [1] slow frames, [2] frame queue of k_frame_recompute, [6..9] slow / exact / slow
 // (second pass) frame counts and the frame tickets of k_candidate_sums, [16 .. 32] the two hand-over list counters
 // (snowtri_cluster.hpp: kHandComplete, kHandMembers -- 128 bytes apart)
-constexpr int kHandCountersAt = 16, kCounterWords = 48;
+constexpr int kHandCountersAt = 16, kCounterWords = 48, kTriangulateSingularAt = 40;   // [40]: singular pairs of the zero-copy snowtri_triangulate (self-resetting)
 
 // Everything a fused call writes besides its outputs: the slabs of the fall-back routines, the hand-over lists and
 // candidate sums of the multi-person path, the frame queue / list counters, the flags of a call that did not ask for
@@ -763,14 +769,24 @@ size_t dtype_size(int dt) { return dt == SNOWTRI_F32 ? 4 : 8; }
 template <typename TIn>
 void launch_triangulate(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax, int J, int Kc,
                         const void *kpts, const int32_t *n_persons, const Params &prm, double *cxyz,
-                        double *cks, double *cps, uint8_t *ckeep, unsigned long long *n_singular) {
+                        double *cks, double *cps, uint8_t *ckeep, unsigned long long *n_singular, char *mirror = nullptr) {
+    // mirror: host-mapped block [xyz | kscore | pscore | keep | (16-byte aligned) singular count] the kernels fill as well
     const int64_t total = F * (int64_t)Kc * J;
+    double *mx = (double *)mirror, *mk = mirror ? mx + 3 * total : nullptr, *mp = mirror ? mk + total : nullptr;
+    uint8_t *mkeep = mirror ? (uint8_t *)(mp + F * (int64_t)Kc) : nullptr;
+    const size_t ns_off = ((sizeof(double) * ((size_t)total * 4 + (size_t)F * Kc) + (size_t)F * Kc) + 15) & ~(size_t)15;
+    if (mirror && F * (int64_t)Kc <= 4096 && J <= 4096) {   // the per-frame call: one launch, a workgroup per candidate slot
+        hipLaunchKernelGGL((k_triangulate_slots<TIn>), dim3((unsigned)(F * Kc)), dim3(kBlock), sizeof(double) * J, st, F, Pmax, J, Kc, ctx->rig(),
+                           (const TIn *)kpts, n_persons, prm, cxyz, cks, cps, ckeep, n_singular, mx, mk, mp, mkeep,
+                           (unsigned long long *)(mirror + ns_off), (unsigned int *)(n_singular + 1));
+        return;
+    }
     hipLaunchKernelGGL((k_triangulate<TIn>), dim3(grid_for(total, kBlock, ctx->num_cus * 16)), dim3(kBlock), 0,
                        st, F, Pmax, J, Kc, ctx->rig(), (const TIn *)kpts, n_persons, prm, cxyz, cks,
-                       n_singular);
+                       n_singular, mx, mk);
     hipLaunchKernelGGL(k_cand_mean, dim3(grid_for(F * (int64_t)Kc, kBlock / 64, ctx->num_cus * 16)),
                        dim3(kBlock), 0, st, F, Pmax, J, Kc, ctx->rig(), n_persons, prm, (const double *)cks,
-                       cps, ckeep);
+                       cps, ckeep, mp, mkeep, n_singular, mirror ? (unsigned long long *)(mirror + ns_off) : nullptr);
 }
 
 constexpr int kCondenseMaxN = 9000;  // condense_lds_bytes(N) <= 160 KiB
@@ -828,6 +844,9 @@ int snowtri_triangulate(snowtri_ctx *ctx, int64_t F, int32_t Pmax, int32_t J, co
     const size_t out_ns_off = (out_bytes + 15) & ~(size_t)15;          // the singular-pair counter rides behind the outputs
     const bool host = memspace == SNOWTRI_HOST;
     const bool pinned = host && in_np_off + np_bytes <= kPinnedMaxBytes && out_ns_off + 8 <= kPinnedMaxBytes;
+    // the per-frame call: kernels read the staged inputs and mirror their outputs in mapped page-locked memory, no copy engine
+    const bool zero_copy = pinned && in_np_off + np_bytes + out_ns_off + 8 <= kZeroCopyMaxBytes;
+    char *mirror = nullptr;
     if (host) {
         rc = ctx->in.ensure(in_np_off + np_bytes + 16);
         if (rc) return rc;
@@ -848,24 +867,31 @@ int snowtri_triangulate(snowtri_ctx *ctx, int64_t F, int32_t Pmax, int32_t J, co
             if (rc) return rc;
             std::memcpy(ctx->pin_in.p, kpts, in_bytes);
             if (n_persons) std::memcpy((char *)ctx->pin_in.p + in_np_off, n_persons, np_bytes);
-            HIP_TRY(hipMemcpyAsync(ctx->in.p, ctx->pin_in.p, in_np_off + np_bytes, hipMemcpyHostToDevice, st));
+            if (zero_copy) {
+                d_kpts = ctx->pin_in.dev;
+                if (n_persons) d_np = (int32_t *)((char *)ctx->pin_in.dev + in_np_off);
+                mirror = (char *)ctx->pin_out.dev;
+                d_nsing = ctx->d_counters + kTriangulateSingularAt;   // (left at 0 by every call: k_cand_mean hands it over)
+            } else {
+                HIP_TRY(hipMemcpyAsync(ctx->in.p, ctx->pin_in.p, in_np_off + np_bytes, hipMemcpyHostToDevice, st));
+            }
         } else {
             HIP_TRY(hipMemcpyAsync(ctx->in.p, kpts, in_bytes, hipMemcpyHostToDevice, st));
             if (n_persons) HIP_TRY(hipMemcpyAsync((void *)d_np, n_persons, np_bytes, hipMemcpyHostToDevice, st));
         }
-        HIP_TRY(hipMemsetAsync(d_xyz, 0, out_ns_off + 8, st));  // invalid slots read back as zeros; counter = 0
+        if (!zero_copy) HIP_TRY(hipMemsetAsync(d_xyz, 0, out_ns_off + 8, st));  // invalid slots read back as zeros; counter = 0
     } else {
         HIP_TRY(hipMemsetAsync(d_nsing, 0, sizeof(unsigned long long), st));
     }
     if (in_dtype == SNOWTRI_F32)
-        launch_triangulate<float>(ctx, st, F, Pmax, J, (int)Kc, d_kpts, d_np, prm, d_xyz, d_ks, d_ps, d_keep, d_nsing);
+        launch_triangulate<float>(ctx, st, F, Pmax, J, (int)Kc, d_kpts, d_np, prm, d_xyz, d_ks, d_ps, d_keep, d_nsing, mirror);
     else
-        launch_triangulate<double>(ctx, st, F, Pmax, J, (int)Kc, d_kpts, d_np, prm, d_xyz, d_ks, d_ps, d_keep, d_nsing);
+        launch_triangulate<double>(ctx, st, F, Pmax, J, (int)Kc, d_kpts, d_np, prm, d_xyz, d_ks, d_ps, d_keep, d_nsing, mirror);
     HIP_TRY(hipGetLastError());
     if (host) {
         unsigned long long ns = 0;
-        if (pinned) {   // one staged download
-            HIP_TRY(hipMemcpyAsync(ctx->pin_out.p, ctx->cand.p, out_ns_off + 8, hipMemcpyDeviceToHost, st));
+        if (pinned) {   // one staged download (zero_copy: the kernels have written the staging buffer themselves)
+            if (!zero_copy) HIP_TRY(hipMemcpyAsync(ctx->pin_out.p, ctx->cand.p, out_ns_off + 8, hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
             const char *o = (const char *)ctx->pin_out.p;
             std::memcpy(cand_xyz, o, sizeof(double) * nx * 3);
@@ -1006,42 +1032,43 @@ int snowtri_condense_resident(snowtri_ctx *ctx, int64_t token, const snowtri_par
     const size_t nx = (size_t)F * N * J, no = (size_t)F * Pout_max * kn;
     const double *d_xyz = (const double *)ctx->cand.p, *d_ks = d_xyz + nx * 3;
     const uint8_t *d_keep = (const uint8_t *)(d_ks + nx + (size_t)F * N);
-    const size_t out_total = sizeof(double) * (no * 4 + (size_t)F * Pout_max) + 8 * (size_t)F;
-    rc = ctx->out.ensure(out_total + 64);
-    if (rc) return rc;
-    double *o_xyz = (double *)ctx->out.p, *o_ks = o_xyz + no * 3, *o_ps = o_ks + no;
-    int32_t *o_cnt = (int32_t *)(o_ps + (size_t)F * Pout_max);
-    uint32_t *o_fl = (uint32_t *)(o_cnt + F);
-    HIP_TRY(hipMemsetAsync(o_fl, 0, sizeof(uint32_t) * F, st));
-    rc = launch_condense(ctx, st, F, (int)N, J, d_xyz, d_ks, d_keep, prm, Pout_max, SplitWriter{o_xyz, o_ks, o_ps}, o_cnt, o_fl);
-    if (rc) return rc;
-    const bool pinned = out_total <= kPinnedMaxBytes;
-    const char *o = (const char *)ctx->out.p;
-    if (pinned) {   // one staged download
+    const size_t out_total = sizeof(double) * (no * 4 + (size_t)F * Pout_max) + 4 * (size_t)F;   // xyz | kscore | pscore | count
+    const bool zero_copy = out_total <= kZeroCopyMaxBytes;   // the kernel writes the page-locked staging buffer itself
+    char *base;
+    if (zero_copy) {
         rc = ctx->pin_out.ensure(out_total + 16);
         if (rc) return rc;
-        HIP_TRY(hipMemcpyAsync(ctx->pin_out.p, ctx->out.p, out_total, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
-        o = (const char *)ctx->pin_out.p;
+        base = (char *)ctx->pin_out.dev;
     } else {
-        HIP_TRY(hipStreamSynchronize(st));
+        rc = ctx->out.ensure(out_total + 64);
+        if (rc) return rc;
+        base = (char *)ctx->out.p;
     }
+    double *o_xyz = (double *)base, *o_ks = o_xyz + no * 3, *o_ps = o_ks + no;
+    int32_t *o_cnt = (int32_t *)(o_ps + (size_t)F * Pout_max);
+    // (the only flag of this entry is the overflow bit: derived from the counts below, no atomics on mapped memory)
+    rc = launch_condense(ctx, st, F, (int)N, J, d_xyz, d_ks, d_keep, prm, Pout_max, SplitWriter{o_xyz, o_ks, o_ps}, o_cnt, (uint32_t *)nullptr);
+    if (rc) return rc;
+    HIP_TRY(hipStreamSynchronize(st));
     auto fetch = [&](void *dst, size_t off, size_t bytes) -> hipError_t {
         if (!bytes) return hipSuccess;
-        if (pinned) {
-            std::memcpy(dst, o + off, bytes);
+        if (zero_copy) {
+            std::memcpy(dst, (const char *)ctx->pin_out.p + off, bytes);
             return hipSuccess;
         }
-        return hipMemcpy(dst, o + off, bytes, hipMemcpyDeviceToHost);
+        return hipMemcpy(dst, base + off, bytes, hipMemcpyDeviceToHost);
     };
     HIP_TRY(fetch(out_xyz, 0, sizeof(double) * no * 3));
     HIP_TRY(fetch(out_kscore, sizeof(double) * no * 3, sizeof(double) * no));
     HIP_TRY(fetch(out_pscore, sizeof(double) * no * 4, sizeof(double) * F * Pout_max));
     HIP_TRY(fetch(out_count, sizeof(double) * (no * 4 + (size_t)F * Pout_max), sizeof(int32_t) * F));
-    if (out_flags) HIP_TRY(fetch(out_flags, sizeof(double) * (no * 4 + (size_t)F * Pout_max) + sizeof(int32_t) * F, sizeof(uint32_t) * F));
-    for (int64_t f = 0; f < F; f++)
-        if (out_count[f] > Pout_max) return SNOWTRI_ERR_OVERFLOW;
-    return SNOWTRI_OK;
+    int status = SNOWTRI_OK;
+    for (int64_t f = 0; f < F; f++) {
+        const bool over = out_count[f] > Pout_max;
+        if (out_flags) out_flags[f] = over ? SNOWTRI_FLAG_OVERFLOW : 0u;
+        if (over) status = SNOWTRI_ERR_OVERFLOW;
+    }
+    return status;
 }
 
 }  // extern "C"

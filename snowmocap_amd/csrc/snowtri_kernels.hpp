@@ -103,7 +103,11 @@ __global__ __launch_bounds__(kBlock) void k_triangulate(int64_t F, int Pmax, int
                                                         const int32_t *__restrict__ n_persons, Params prm,
                                                         double *__restrict__ cand_xyz,
                                                         double *__restrict__ cand_kscore,
-                                                        unsigned long long *n_singular) {
+                                                        unsigned long long *n_singular, double *__restrict__ mirror_xyz,
+                                                        double *__restrict__ mirror_kscore) {
+    // mirror_*: the small per-frame host calls -- a second copy of every output straight into page-locked HOST memory mapped
+    // into the device (no D2H copy behind the kernels: an SDMA copy of 30 KB costs ~10 us of latency, these stores ~2);
+    // slots that are not real pairs are then written as zeros here (no memset in front of the kernel)
     const int64_t total = F * (int64_t)Kc * J;
     const int pp = Pmax * Pmax;
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -115,7 +119,13 @@ __global__ __launch_bounds__(kBlock) void k_triangulate(int64_t F, int Pmax, int
         const int mc = rig.pairs[2 * q], sc = rig.pairs[2 * q + 1];
         const int nm = n_persons ? n_persons[f * rig.C + mc] : Pmax;
         const int ns = n_persons ? n_persons[f * rig.C + sc] : Pmax;
-        if (pm >= nm || ps >= ns) continue;  // not a real pair: slot stays untouched, keep = 0
+        if (pm >= nm || ps >= ns) {  // not a real pair: slot stays untouched (zeroed when mirrored), keep = 0
+            if (mirror_xyz) {
+                cand_xyz[3 * i] = cand_xyz[3 * i + 1] = cand_xyz[3 * i + 2] = cand_kscore[i] = 0.0;
+                mirror_xyz[3 * i] = mirror_xyz[3 * i + 1] = mirror_xyz[3 * i + 2] = mirror_kscore[i] = 0.0;
+            }
+            continue;
+        }
         const TIn *km = kpts + ((((f * rig.C + mc) * Pmax + pm) * (int64_t)J) + j) * 3;
         const TIn *ks = kpts + ((((f * rig.C + sc) * Pmax + ps) * (int64_t)J) + j) * 3;
         const TIn um = km[0], vm = km[1], sm = km[2];
@@ -131,6 +141,12 @@ __global__ __launch_bounds__(kBlock) void k_triangulate(int64_t F, int Pmax, int
         cand_xyz[3 * i + 1] = o.W.y;
         cand_xyz[3 * i + 2] = o.W.z;
         cand_kscore[i] = s;
+        if (mirror_xyz) {
+            mirror_xyz[3 * i] = o.W.x;
+            mirror_xyz[3 * i + 1] = o.W.y;
+            mirror_xyz[3 * i + 2] = o.W.z;
+            mirror_kscore[i] = s;
+        }
     }
 }
 
@@ -139,7 +155,14 @@ __global__ __launch_bounds__(kBlock) void k_cand_mean(int64_t F, int Pmax, int J
                                                       const int32_t *__restrict__ n_persons, Params prm,
                                                       const double *__restrict__ cand_kscore,
                                                       double *__restrict__ cand_pscore,
-                                                      uint8_t *__restrict__ cand_keep) {
+                                                      uint8_t *__restrict__ cand_keep, double *__restrict__ mirror_pscore,
+                                                      uint8_t *__restrict__ mirror_keep, unsigned long long *n_singular,
+                                                      unsigned long long *mirror_singular) {
+    // mirror_*: see k_triangulate; the singular-pair counter of that kernel is handed over here and left at 0 for the next call
+    if (mirror_singular && blockIdx.x == 0 && threadIdx.x == 0) {
+        *mirror_singular = *n_singular;
+        *n_singular = 0ull;
+    }
     const int lane = threadIdx.x & 63;
     const int64_t wave = (blockIdx.x * (int64_t)blockDim.x + threadIdx.x) >> 6;
     const int64_t nwaves = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -160,6 +183,81 @@ __global__ __launch_bounds__(kBlock) void k_cand_mean(int64_t F, int Pmax, int J
         if (lane == 0) {
             cand_pscore[fk] = valid ? mean : 0.0;
             cand_keep[fk] = (valid && !(mean < prm.avg_thr)) ? 1 : 0;  // :80-81 (NaN mean is kept)
+            if (mirror_pscore) {
+                mirror_pscore[fk] = valid ? mean : 0.0;
+                mirror_keep[fk] = (valid && !(mean < prm.avg_thr)) ? 1 : 0;
+            }
+        }
+    }
+}
+
+// k_triangulate + k_cand_mean in ONE launch for the per-frame calls (a handful of candidate slots: the second launch was ~6 of
+// the call's 30 us): one workgroup per (frame, slot); the joints' scores meet in LDS and wave 0 takes their mean in the order
+// k_cand_mean takes it (lane-strided partial sums, then the wave tree), so a slot's bits do not depend on which route ran.
+// Dynamic LDS: 8 J bytes.  mirror_* as in k_triangulate (always given: this kernel serves the host calls only).
+template <typename TIn>
+__global__ __launch_bounds__(kBlock) void k_triangulate_slots(int64_t F, int Pmax, int J, int Kc, Rig rig, const TIn *__restrict__ kpts,
+                                                              const int32_t *__restrict__ n_persons, Params prm,
+                                                              double *__restrict__ cand_xyz, double *__restrict__ cand_kscore,
+                                                              double *__restrict__ cand_pscore, uint8_t *__restrict__ cand_keep,
+                                                              unsigned long long *n_singular, double *__restrict__ mirror_xyz,
+                                                              double *__restrict__ mirror_kscore, double *__restrict__ mirror_pscore,
+                                                              uint8_t *__restrict__ mirror_keep, unsigned long long *mirror_singular,
+                                                              unsigned int *done_count) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *sc_l = reinterpret_cast<double *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int pp = Pmax * Pmax;
+    const int64_t fk = blockIdx.x;
+    const int k = (int)(fk % Kc);
+    const int64_t f = fk / Kc;
+    const int q = k / pp, r = k - q * pp, pm = r / Pmax, ps = r - pm * Pmax;
+    const int mc = rig.pairs[2 * q], sc = rig.pairs[2 * q + 1];
+    const int nm = n_persons ? n_persons[f * rig.C + mc] : Pmax;
+    const int ns = n_persons ? n_persons[f * rig.C + sc] : Pmax;
+    const bool valid = pm < nm && ps < ns;
+    const Vec3 tm = {rig.t[3 * mc], rig.t[3 * mc + 1], rig.t[3 * mc + 2]};
+    const Vec3 ts = {rig.t[3 * sc], rig.t[3 * sc + 1], rig.t[3 * sc + 2]};
+    for (int j = tid; j < J; j += kBlock) {
+        const int64_t i = fk * J + j;
+        double x = 0.0, y = 0.0, z = 0.0, s = 0.0;
+        if (valid) {
+            const TIn *km = kpts + ((((f * rig.C + mc) * Pmax + pm) * (int64_t)J) + j) * 3;
+            const TIn *ks = kpts + ((((f * rig.C + sc) * Pmax + ps) * (int64_t)J) + j) * 3;
+            const TIn um = km[0], vm = km[1], sm = km[2];
+            const TIn us = ks[0], vs = ks[1], ss = ks[2];
+            const Vec3 hm = ray_from_pixel(rig.M + 9 * mc, (double)um, (double)vm);
+            const Vec3 hs = ray_from_pixel(rig.M + 9 * sc, (double)us, (double)vs);
+            const SkewOut o = skew_ray_solve(hm, hs, tm, ts);
+            if (o.singular) atomicAdd(n_singular, 1ull);
+            s = pair_score(sm, ss, o.dist, prm);
+            x = o.W.x;
+            y = o.W.y;
+            z = o.W.z;
+        }
+        cand_xyz[3 * i] = mirror_xyz[3 * i] = x;
+        cand_xyz[3 * i + 1] = mirror_xyz[3 * i + 1] = y;
+        cand_xyz[3 * i + 2] = mirror_xyz[3 * i + 2] = z;
+        cand_kscore[i] = mirror_kscore[i] = s;
+        sc_l[j] = s;
+    }
+    __syncthreads();
+    if (tid < 64) {
+        double s = 0.0;
+        if (valid)
+            for (int j = lane; j < J; j += 64) s += sc_l[j];
+        s = wave_sum(s);
+        const double mean = s / (double)J;  // triangulation.py:79
+        if (lane == 0) {
+            cand_pscore[fk] = mirror_pscore[fk] = valid ? mean : 0.0;
+            cand_keep[fk] = mirror_keep[fk] = (valid && !(mean < prm.avg_thr)) ? 1 : 0;  // :80-81 (NaN mean is kept)
+            // the last workgroup to finish hands the singular-pair count over and leaves both counters at 0 for the next call
+            __threadfence();
+            if (atomicAdd(done_count, 1u) == gridDim.x - 1u) {
+                *mirror_singular = atomicAdd(n_singular, 0ull);
+                *n_singular = 0ull;
+                *done_count = 0u;
+            }
         }
     }
 }

@@ -11,6 +11,7 @@ Every ★ function runs on the GPU through the C ABI; there is no NumPy fallback
 """
 from __future__ import annotations
 
+import ctypes as ct
 import math
 
 import numpy as np
@@ -66,25 +67,28 @@ def Human_Triangulation(camera_group, keypoint_score_threshold=0.5, average_scor
     prm = _lib.make_params(keypoint_score_threshold=keypoint_score_threshold,
                            average_score_threshold=average_score_threshold,
                            distance_threshold=distance_threshold)
-    xyz = np.empty((Kc, J, 3))
-    ks = np.empty((Kc, J))
-    ps = np.empty(Kc)
-    keep = np.empty(Kc, dtype=np.uint8)
+    # the four outputs in ONE block (a pointer costs more than the arrays: ~1.3 us per ndarray.ctypes.data)
+    n3, n4 = Kc * J * 3, Kc * J * 4
+    blk = np.empty(n4 + Kc + (Kc + 7) // 8)
+    xyz, ks, ps = blk[:n3].reshape(Kc, J, 3), blk[n3:n4].reshape(Kc, J), blk[n4:n4 + Kc]
+    keep = blk[n4 + Kc:].view(np.uint8)[:Kc]
+    base = blk.ctypes.data
+    vp = ct.c_void_p
     rc = L.snowtri_triangulate(ctx.handle, 1, Pmax, J, _lib.ptr(kpts), _lib.dtype_code(kpts.dtype),
-                               _lib.ptr(n_persons), prm, _lib.ptr(xyz), _lib.ptr(ks), _lib.ptr(ps),
-                               _lib.ptr(keep), _lib.HOST, None)
+                               _lib.ptr(n_persons), prm, vp(base), vp(base + 8 * n3), vp(base + 8 * n4),
+                               vp(base + 8 * (n4 + Kc)), _lib.HOST, None)
     if rc == _lib.ERR_SINGULAR:
         raise np.linalg.LinAlgError("Singular matrix")      # np.linalg.inv at triangulation.py:26
     _lib.check(rc, "snowtri_triangulate")
     kept = np.nonzero(keep)[0]
-    # the candidates are rows of the two blocks the library filled (no copy per candidate); the blocks and the device-side
-    # twin the call left behind are remembered so that Human_Triangulation_Condense can skip the upload (_Resident)
+    # the candidates are rows of the block the library filled (no copy per candidate); the block and the device-side twin
+    # the call left behind are remembered so that Human_Triangulation_Condense can skip the upload (_Resident)
     pts = [xyz[k] for k in kept]
     scs = [ks[k] for k in kept]
     result[_KEYS[0]] = pts
     result[_KEYS[1]] = scs
     result[_KEYS[2]] = [np.float64(ps[k]) for k in kept]
-    _Resident.remember(ctx, int(L.snowtri_candidates_token(ctx.handle)), pts, scs, xyz, ks, J)
+    _Resident.remember(ctx, int(L.snowtri_candidates_token(ctx.handle)), pts, scs, blk, n4, J)
     return result
 
 
@@ -100,20 +104,25 @@ class _Resident:
     used = 0       # Condense calls that took the device twin (tests / bench)
 
     @classmethod
-    def remember(cls, ctx, token, pts, scs, xyz, ks, J):
-        cls.last = (ctx, token, list(pts), list(scs), xyz, ks, xyz.copy(), ks.copy(), J) if token else None
+    def remember(cls, ctx, token, pts, scs, blk, n4, J):
+        # (the bytes of the candidate block as downloaded: an in-place edit of any candidate shows as a difference)
+        cls.last = (ctx, token, pts, scs, blk, n4, blk[:n4].tobytes(), J) if token else None
 
     @classmethod
     def match(cls, points, scores):
         r = cls.last
         if r is None:
             return None
-        ctx, token, pts, scs, xyz, ks, xyz0, ks0, J = r
+        ctx, token, pts, scs, blk, n4, pristine, J = r
         if len(points) != len(pts) or len(scores) != len(scs) or not ctx.handle:
             return None
-        if any(a is not b for a, b in zip(points, pts)) or any(a is not b for a, b in zip(scores, scs)):
-            return None
-        if not (np.array_equal(xyz, xyz0, equal_nan=True) and np.array_equal(ks, ks0, equal_nan=True)):
+        for a, b in zip(points, pts):
+            if a is not b:
+                return None
+        for a, b in zip(scores, scs):
+            if a is not b:
+                return None
+        if blk[:n4].tobytes() != pristine:
             return None
         return ctx, token, J
 
@@ -134,16 +143,17 @@ def Human_Triangulation_Condense(result, condense_distance_tol=0.1, condense_per
                            center_point_index=center_point_index, keypoint_num=keypoint_num)
     kn = int(keypoint_num)
     pout = n                        # at most n - 1 clusters
-    oxyz = np.empty((pout, max(kn, 0), 3))
-    oks = np.empty((pout, max(kn, 0)))
-    ops = np.empty(pout)
+    knn = max(kn, 0)
+    oblk = np.empty(pout * knn * 4 + pout)       # the three float64 outputs in one block (one pointer)
+    oxyz, oks, ops = oblk[:pout * knn * 3].reshape(pout, knn, 3), oblk[pout * knn * 3:pout * knn * 4].reshape(pout, knn), oblk[pout * knn * 4:]
     cnt = np.zeros(1, dtype=np.int32)
+    obase = oblk.ctypes.data
+    p_xyz, p_ks, p_ps, p_cnt = ct.c_void_p(obase), ct.c_void_p(obase + 8 * pout * knn * 3), ct.c_void_p(obase + 8 * pout * knn * 4), _lib.ptr(cnt)
     rc = _lib.ERR_BAD_ARG
     resident = _Resident.match(points, scores)
     if resident is not None:        # the unmodified result of Human_Triangulation: its candidates are still on the device
         ctx, token, J = resident
-        rc = L.snowtri_condense_resident(ctx.handle, token, prm, pout, _lib.ptr(oxyz), _lib.ptr(oks), _lib.ptr(ops),
-                                         _lib.ptr(cnt), None)
+        rc = L.snowtri_condense_resident(ctx.handle, token, prm, pout, p_xyz, p_ks, p_ps, p_cnt, None)
         _Resident.used += rc != _lib.ERR_BAD_ARG
     if resident is None or rc == _lib.ERR_BAD_ARG:
         ctx = _lib.scratch_context()
@@ -151,7 +161,7 @@ def Human_Triangulation_Condense(result, condense_distance_tol=0.1, condense_per
         cks = np.ascontiguousarray(np.stack([np.asarray(s, dtype=np.float64) for s in scores]))
         J = cxyz.shape[1]
         rc = L.snowtri_condense(ctx.handle, 1, n, J, _lib.ptr(cxyz), _lib.ptr(cks), None, prm, pout,
-                                _lib.ptr(oxyz), _lib.ptr(oks), _lib.ptr(ops), _lib.ptr(cnt), None, _lib.HOST, None)
+                                p_xyz, p_ks, p_ps, p_cnt, None, _lib.HOST, None)
     if rc == _lib.ERR_BAD_INDEX:
         raise IndexError("index out of bounds (center_point_index / keypoint_num vs. joints per candidate)")
     _lib.check(rc, "snowtri_condense")
