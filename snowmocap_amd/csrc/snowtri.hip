@@ -246,7 +246,7 @@ struct snowtri_ctx {
     int lean_tiles_per_wave = 0; // SNOWTRI_LEAN_TILES_PER_WAVE
     int debug = 0;               // SNOWTRI_DEBUG: launch shapes on stderr
     std::string overrides;
-    static constexpr int assoc_wg_per_cu = 16, lean_wg_per_cu = 2, lean_scratch_mb = 256;   // (settled by measurement: EXPERIMENTS.md)
+    static constexpr int assoc_wg_per_cu = 4 * kAssocWaves, lean_wg_per_cu = 2, lean_scratch_mb = 256;   // (settled by measurement: EXPERIMENTS.md)
     struct OccCache {
         size_t lds = 0;
         int per_cu = -1;
@@ -1799,7 +1799,9 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st_call, int64_t F, int
     // flight on two contexts, now inside the call).  Outputs do not depend on the cut (tests/test_gpu_handover.py).  Not
     // in overlap mode (whole calls already alternate over the sets) and not for batches too small to fill the chip twice.
     StreamSet *const set_call = ctx->cur;
-    bool split = stream && ctx->split_segments >= 2 && ctx->overlap <= 1 && set_call == &ctx->sets[0];
+    // (rigs whose candidate pass holds a whole CU per workgroup -- 16 x 8: 1024 threads, 160 KB -- gain nothing: nothing of the
+    // other segment fits beside it, measured 17.0 against 17.3 ms per 12 500 frames; they split only when a test asks for it)
+    bool split = stream && ctx->split_segments >= 2 && ctx->overlap <= 1 && set_call == &ctx->sets[0] && (SL.per_cu >= 2 || ctx->split_forced);
     if (split) {
         int64_t nseg = std::max<int64_t>((F + seg - 1) / seg, ctx->split_segments);
         nseg += nseg & 1;

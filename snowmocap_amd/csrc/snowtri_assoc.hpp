@@ -485,8 +485,11 @@ __device__ unsigned long long g_assoc_trace[4096 * 16];
 #else
 #define ASSOC_STAMP(i) ((void)0)
 #endif
+// waves per SIMD of the small-rig variants: the kernel is latency-bound, so frames in flight count for more than registers
+// (96 VGPRs, 28 of them spilled: 8 x 4 1.18 -> 1.14 ms per 10 000 frames against 4 waves without spills; 6 waves: the same)
+constexpr int kAssocWaves = 5;
 template <typename TIn, typename TOut, int RC>
-__global__ __launch_bounds__(64, RC > 4 ? 2 : 4) void k_associate(int64_t F, int Pmax, int J, int Kc, Rig rig, const TIn *__restrict__ kpts,
+__global__ __launch_bounds__(64, RC > 4 ? 2 : kAssocWaves) void k_associate(int64_t F, int Pmax, int J, int Kc, Rig rig, const TIn *__restrict__ kpts,
                                                   const int32_t *__restrict__ n_persons, Params prm, int Pout,
                                                   const double *__restrict__ csum, TOut *__restrict__ out4,
                                                   TOut *__restrict__ out_ps, int32_t *__restrict__ out_count,
