@@ -82,6 +82,7 @@ def bench_digest(line):
     if d.get("extra_workloads"):
         out["extra"] = [{"workload": e["workload"], "kernel": e["kernel"], "frames": e["frames"], "kernel_ms": e["kernel_ms"],
                          "frames_per_s": e["frames_per_s"], "pair_solves_per_s": e["pair_solves_per_s"], "frac": e["roofline"]["frac"],
+                         "fall_backs": e.get("fall_back_frames_last_segment"),
                          "two_streams_frames_per_s": (e.get("two_streams") or {}).get("frames_per_s"),
                          "two_streams_frac": (e.get("two_streams") or {}).get("frac")}
                         for e in d["extra_workloads"]]
@@ -135,11 +136,25 @@ def build(tag):
         s["multi"].setdefault(cfg, {})["counters"] = mc[cfg]
     s["bench_default"] = bench_digest(open(os.path.join(d, "bench_default.json")).read())
     s["bench_steps20"] = bench_digest(open(os.path.join(d, "bench_steps20.json")).read())
+    # the driver's own record of bench.py (copied beside the evidence by collect_profiles.sh: the newest BENCH_r*.json then)
+    drv = os.path.join(d, "driver_bench.json")
+    if os.path.exists(drv):
+        j = json.load(open(drv))
+        if j.get("parsed"):
+            s["driver"] = dict(bench_digest(json.dumps(j["parsed"])), file=j["file"], head=j.get("head"))
+    pw = os.path.join(d, "power_trace.json")
+    if os.path.exists(pw):
+        j = json.load(open(pw))
+        cap = j.get("power_cap") or {}
+        s["power"] = {"cap_W": (cap.get("power_cap") or 0) / 1e6 if isinstance(cap, dict) else None,
+                      "workloads": {w["workload"]: {"gfxclk_MHz": (w.get("gfxclk_MHz") or {}).get("median"),
+                                                    "socket_power_W": (w.get("socket_power_W") or {}).get("median"),
+                                                    "achieved": w.get("achieved")} for w in j["workloads"]}}
     return s
 
 
 if __name__ == "__main__":
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r03"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
     out = build(tag)
     json.dump(out, open(os.path.join(ROOT, "profiles", tag, "summary.json"), "w"), indent=1, sort_keys=True)
     print("profiles/%s/summary.json written" % tag)

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Copy the summaries of scripts/profile.sh <tag> + scripts/pmc_multi.sh (under gpurun_out/) into profiles/<tag>/.
-TAG=${1:-r03}; SRC=gpurun_out/prof_$TAG; DST=profiles/$TAG; mkdir -p $DST
+TAG=${1:-r04}; SRC=gpurun_out/prof_$TAG; DST=profiles/$TAG; mkdir -p $DST
 cp $SRC/summary.txt $SRC/bench_lines.jsonl $SRC/next_rows.jsonl $SRC/pmc_traffic.json $DST/
 cp $SRC/kernel_stats_stats.csv $DST/kernel_stats_cfg2_10k.csv
 cp $SRC/kernel_stats_stats_large.csv $DST/kernel_stats_large_2M.csv
@@ -30,6 +30,23 @@ for t in ("a3", "b3", "a5", "b5"):
 PY
 
 cp $SRC/summary.json $DST/counters.json
+# the clock / socket-power record of scripts/power_trace.py, and the newest record of the DRIVER's own bench run (an
+# independently run figure beside ours in the tables: it belongs to the previous round's sources until the round ends)
+[ -f gpurun_out/power/power_trace.json ] && cp gpurun_out/power/power_trace.json $DST/power_trace.json && cp gpurun_out/power/samples.csv $DST/power_samples.csv
+NEWEST=$(ls BENCH_r*.json 2>/dev/null | sort | tail -1)
+[ -n "$NEWEST" ] && python - <<PY
+import json
+d = json.load(open("$NEWEST"))
+line = d.get("parsed")
+run = d.get("run")
+if isinstance(run, dict):      # the whole JSON line bench.py printed (the driver's `parsed` keeps the contract keys only)
+    full = [l for l in (run.get("stdout_tail") or "").splitlines() if l.startswith('{"metric"')]
+    try:
+        line = json.loads(full[-1])
+    except Exception:
+        pass
+json.dump({"file": "$NEWEST", "head": d.get("head"), "cmd": d.get("cmd"), "parsed": line}, open("$DST/driver_bench.json", "w"))
+PY
 python scripts/build_summary.py $TAG
 python scripts/make_tables.py --write
 ls $DST | wc -l

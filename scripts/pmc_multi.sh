@@ -2,6 +2,9 @@
 # Dev aid (GPU box): SQ counters of k_frame_recompute on the cfg3 / cfg5 shapes.
 ROOT=$PWD; OUT=$ROOT/gpurun_out/pmc_multi; mkdir -p $OUT
 export TMPDIR=/tmp
+# one stream per call: with the call's segments on two streams (the default for the small rigs) the kernels of the two
+# segments overlap and a per-kernel duration would include the time a kernel waits for the other segment's workgroups
+export SNOWTRI_SPLIT_SEGMENTS=1
 cd /tmp
 for CFG in 3 5; do
 rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace -d $OUT/a$CFG -o a -- python $ROOT/scripts/bench_configs.py --full --only=$CFG > $OUT/a$CFG.log 2>&1

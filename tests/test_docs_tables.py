@@ -1,4 +1,4 @@
-"""The measured tables of README.md, DESIGN.md and profiles/README.md are generated from profiles/r03/summary.json
+"""The measured tables of README.md, DESIGN.md and profiles/README.md are generated from profiles/<tag>/summary.json
 (scripts/make_tables.py), and summary.json is derived from the CSVs / JSON lines committed beside it
 (scripts/build_summary.py).  These tests fail when a document quotes a number the committed evidence does not hold."""
 import json
