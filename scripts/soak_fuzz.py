@@ -34,7 +34,8 @@ sweeps = [("small_rigs auto", lambda e: T.test_random_small_rigs_against_oracle(
           ("lean thresholds", lambda e: TL.test_lean_random_thresholds_and_person_lists(api)),
           ("lean special", lambda e: TL.test_lean_special_values(api)),
           ("handover", lambda e: TH.test_random_rigs_with_handover_against_oracle_and_phase3(api, MP())),
-          ("handover wide rigs", lambda e: TH.test_random_wide_rigs_against_oracle_and_phase3(api, MP()))]
+          ("handover wide rigs", lambda e: TH.test_random_wide_rigs_against_oracle_and_phase3(api, MP())),
+          ("float64 outputs / keypoint_num on the streaming route", lambda e: TH.test_random_rigs_float64_outputs_and_keypoint_num(api, MP()))]
 fails = 0
 t0 = time.time()
 for r in range(rounds):

@@ -613,3 +613,57 @@ def test_keypoint_num_below_J_with_an_active_score_filter_stays_exact(api, monke
     out = _run(api, K, R, t, prm, kp, npers, P + 2, monkeypatch)
     assert "k_associate" not in out["kernels"] and out["handed"] == (-1, -1)
     _check(out, ref, P + 2, 30, "kn < J with score filter")
+
+
+def test_random_rigs_float64_outputs_and_keypoint_num(api, monkeypatch):
+    """The randomised sweep of test_random_rigs_with_handover_against_oracle_and_phase3 for the shapes round 4 brought to the
+    streaming route: float64 or float32 outputs, keypoint_num anywhere in 1..J, 2..16 cameras -- against the oracle, and against
+    k_frame_recompute on the same batch.  condense_score_tol > 0 with keypoint_num < J must stay off the route."""
+    from snowmocap_amd import synth
+    from oracle import oracle as orc
+    rng = np.random.default_rng(990)
+    streamed = kept_off = 0
+    for trial in range(36):
+        C = int(rng.choice([2, 3, 4, 5, 6, 7, 8, 9, 12, 16]))
+        P = int(rng.integers(2, 5))
+        J = int(rng.choice([5, 20, 33, 40]))
+        F = int(rng.integers(1, 5))
+        kn = J if trial % 4 == 0 else int(rng.integers(1, J + 1))
+        out_dtype = np.float64 if trial % 3 else np.float32
+        K, R, t = synth.ring_rig(C, radius=float(rng.uniform(3.5, 6)))
+        X = synth.make_people(rng, F, P, J=J)
+        kp, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=float(rng.choice([0.3, 1.0])), score_range=(2.0, 8.0),
+                                         permute_persons=True, dtype=np.float64 if trial % 5 == 0 else np.float32)
+        npers = npers.copy()
+        for _ in range(int(rng.integers(0, 3))):
+            npers[rng.integers(0, F), rng.integers(0, C)] = rng.integers(0, P + 1)
+        prm = dict(keypoint_score_threshold=float(rng.choice([0.0, 3.0, 5.0])), average_score_threshold=float(rng.choice([0.0, 0.3, 1.5])),
+                   distance_threshold=float(rng.choice([0.02, 0.05, 1.0])), condense_distance_tol=float(rng.choice([0.05, 0.3, 10.0])),
+                   condense_person_num_tol=int(rng.choice([0, 1, 2])), condense_score_tol=float(rng.choice([0.0, 0.0, 0.0, 0.5])),
+                   center_point_index=int(rng.integers(0, J)), keypoint_num=kn)
+        pout = int(rng.choice([1, 4, 16]))
+        ref = orc.triangulate_condense_batch(K, R, t, kp, npers, orc.make_params(**prm), 64)
+        out = _run(api, K, R, t, prm, kp, npers, pout, monkeypatch, out_dtype=out_dtype)
+        off = _run(api, K, R, t, prm, kp, npers, pout, monkeypatch, handover=False, out_dtype=out_dtype)
+        msg = f"trial {trial}: C={C} P={P} J={J} kn={kn} F={F} {np.dtype(out_dtype).name} {prm} pout={pout} n={npers.tolist()}"
+        on_route = "k_associate" in out["kernels"]
+        assert on_route == (kn == J or prm["condense_score_tol"] <= 0.0), msg
+        streamed += on_route
+        kept_off += not on_route
+        f64 = out_dtype == np.float64
+        xyz_tol, rtol = (1e-8, 1e-9) if f64 else (8e-6 if prm["distance_threshold"] >= 1.0 and C >= 9 else XYZ_F32, 3e-7)
+        # (the conditioning budget of assert_scores_close -- a rounding-level error of the distance, 5e-14 m -- is sized for rays of
+        # a 4-camera room; the rays of a 9-16 camera ring of up to 6 m radius are twice as long and meet under flatter angles)
+        derr = 2e-13 if C >= 9 else 5e-14
+        if C >= 9 and prm["condense_distance_tol"] >= 10.0:
+            derr = 5e-13    # (everything merges: a fused score is the mean of hundreds of member scores, 1/dist-tailed)
+        for o, name in ((out, "route"), (off, "k_frame_recompute")):
+            np.testing.assert_array_equal(o["count"], ref["count"], err_msg=msg + " " + name)
+            for f in range(F):
+                m = min(int(ref["count"][f]), pout)
+                assert not o["xyzs"][f, m:].any(), f"{msg} {name} frame {f}: unused slots must be zero"
+                if m:
+                    assert_scores_close(o["xyzs"][f, :m, :, 3], ref["kscore"][f, :m], rtol=rtol, dist_err=derr, what=f"{msg} {name} kscore frame {f}")
+                    assert_xyz_close(o["xyzs"][f, :m, :, :3], ref["xyz"][f, :m], xyz_tol, score_ref=ref["kscore"][f, :m], what=f"{msg} {name} xyz frame {f}")
+                    assert_scores_close(o["pscore"][f, :m], ref["pscore"][f, :m], rtol=rtol, dist_err=derr, nterms=kn, what=f"{msg} {name} pscore frame {f}")
+    assert streamed > 20 and kept_off > 1, (streamed, kept_off)
