@@ -105,6 +105,16 @@ int main(void) {
     EXPECT(snowtri_last_kernel_names(NULL)[0], 0);
     EXPECT(snowtri_debug_faults(NULL, NULL) < 0, 1);
     EXPECT(snowtri_debug_selftest(NULL) != SNOWTRI_OK, 1);
+    {   /* round 4's entries */
+        int64_t counts[3];
+        EXPECT(snowtri_build_info() != NULL && strstr(snowtri_build_info(), "arch=gfx950") != NULL, 1);
+        EXPECT(snowtri_ctx_overrides(NULL)[0], 0);
+        EXPECT(snowtri_ctx_set_overlap(NULL, 2), SNOWTRI_ERR_BAD_ARG);
+        EXPECT(snowtri_ctx_join(NULL, NULL), SNOWTRI_ERR_BAD_ARG);
+        EXPECT(snowtri_last_stream_counts(NULL, counts), SNOWTRI_ERR_BAD_ARG);
+        EXPECT(snowtri_candidates_token(NULL), 0);
+        EXPECT(snowtri_condense_resident(NULL, 1, &prm, 1, buf, buf, buf, ibuf, ubuf), SNOWTRI_ERR_BAD_ARG);
+    }
 
     /* ---- context creation with bad arguments -------------------------------------------------------------- */
     {
@@ -188,6 +198,20 @@ int main(void) {
         EXPECT(snowtri_ctx_set_distortion(ctx, NULL), SNOWTRI_ERR_BAD_ARG);
         EXPECT(snowtri_undistort_keypoints(ctx, 1, 1, J, fbuf, fbuf, SNOWTRI_F32, SNOWTRI_HOST, NULL), SNOWTRI_ERR_BAD_ARG); /* no D set */
         EXPECT(snowtri_last_kernel_ms(ctx, NULL), SNOWTRI_ERR_BAD_ARG);
+        {   /* round 4's entries on a real context */
+            int64_t counts[3] = {7, 7, 7};
+            EXPECT(snowtri_ctx_set_overlap(ctx, 0), SNOWTRI_ERR_BAD_ARG);
+            EXPECT(snowtri_ctx_set_overlap(ctx, 9), SNOWTRI_ERR_BAD_ARG);
+            EXPECT(snowtri_ctx_set_overlap(ctx, 2), SNOWTRI_OK);
+            EXPECT(snowtri_ctx_join(ctx, NULL), SNOWTRI_OK);             /* nothing in flight */
+            EXPECT(snowtri_ctx_set_overlap(ctx, 1), SNOWTRI_OK);
+            EXPECT(snowtri_last_stream_counts(ctx, NULL), SNOWTRI_ERR_BAD_ARG);
+            EXPECT(snowtri_last_stream_counts(ctx, counts), SNOWTRI_OK);
+            EXPECT(counts[0] == -1 && counts[1] == -1 && counts[2] == -1, 1);   /* no multi-person call yet */
+            EXPECT(snowtri_condense_resident(ctx, 0, &prm, 1, buf, buf, buf, ibuf, ubuf), SNOWTRI_ERR_BAD_ARG);       /* no candidates resident */
+            EXPECT(snowtri_condense_resident(ctx, 123456789, &prm, 1, buf, buf, buf, ibuf, ubuf), SNOWTRI_ERR_BAD_ARG); /* a stale token */
+            EXPECT(snowtri_ctx_overrides(ctx) != NULL, 1);
+        }
         EXPECT(snowtri_ctx_destroy(ctx), SNOWTRI_OK);
     }
     printf("abi_badargs: %d failure(s)\n", failures);

@@ -667,3 +667,38 @@ def test_random_rigs_float64_outputs_and_keypoint_num(api, monkeypatch):
                     assert_xyz_close(o["xyzs"][f, :m, :, :3], ref["xyz"][f, :m], xyz_tol, score_ref=ref["kscore"][f, :m], what=f"{msg} {name} xyz frame {f}")
                     assert_scores_close(o["pscore"][f, :m], ref["pscore"][f, :m], rtol=rtol, dist_err=derr, nterms=kn, what=f"{msg} {name} pscore frame {f}")
     assert streamed > 20 and kept_off > 1, (streamed, kept_off)
+
+
+def test_overlap_mode_with_multi_person_calls_is_bit_identical(api):
+    """Overlap mode (BatchTriangulator(streams=n)) on the streaming multi-person route: whole calls rotate over the stream sets
+    (each with its own hand-over lists, sums and counters; no split inside a call then); after join() every call's outputs
+    equal the ones of the same calls issued one after the other."""
+    import torch
+    from snowmocap_amd import synth
+    rng = np.random.default_rng(31)
+    C, P, J, F = 6, 3, 40, 300
+    K, R, t = synth.ring_rig(C, radius=5.0)
+    dev = torch.device("cuda", 0)
+    prm = dict(PRM, keypoint_num=J)
+    batches = []
+    for b in range(5):
+        X = synth.make_people(rng, F, P, J=J)
+        kp, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=0.7, score_range=(3.5, 9.0), permute_persons=True, dtype=np.float32)
+        npers = npers.copy()
+        npers[b, 1] = P - 1
+        batches.append((torch.from_numpy(kp).to(dev), torch.from_numpy(npers).to(dev)))
+    seq = api.BatchTriangulator(K, R, t, prm, pout_max=P + 2, out_dtype=np.float32)
+    want = [{k: v.clone() for k, v in seq.run_torch(kp, npers).items()} for kp, npers in batches]
+    torch.cuda.synchronize(dev)
+    assert "k_associate" in seq.ctx.last_kernel_names()
+    seq.close()
+    ovl = api.BatchTriangulator(K, R, t, prm, pout_max=P + 2, out_dtype=np.float32, streams=3)
+    for rep in range(2):
+        got = [ovl.run_torch(kp, npers) for kp, npers in batches]
+        ovl.join()
+        torch.cuda.synchronize(dev)
+        for g, w in zip(got, want):
+            for k in ("xyzs", "pscore", "count", "flags"):
+                assert torch.equal(g[k].view(torch.int32), w[k].view(torch.int32)), (rep, k)
+    assert int(want[0]["count"].sum()) >= F * P - 5
+    ovl.close()
