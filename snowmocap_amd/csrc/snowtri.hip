@@ -9,6 +9,7 @@
 
 #include <algorithm>
 #include <atomic>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -145,7 +146,7 @@ constexpr int kTimingRing = 1024;
 // ctx->d_counters: [0] singular pairs, [1] slow frames, [2] frame queue of k_frame_recompute, [6..9] slow / exact / slow
 // (second pass) frame counts and the frame tickets of k_candidate_sums, [16 .. 32] the two hand-over list counters
 // (snowtri_cluster.hpp: kHandComplete, kHandMembers -- 128 bytes apart)
-constexpr int kHandCountersAt = 16, kCounterWords = 48, kTriangulateSingularAt = 40;   // [40]: singular pairs of the zero-copy snowtri_triangulate (self-resetting)
+constexpr int kHandCountersAt = 16, kCounterWords = 48, kTriangulateSingularAt = 40, kHostDoneCountAt = 42;   // [40]: singular pairs of the zero-copy snowtri_triangulate (self-resetting)
 
 // Everything a fused call writes besides its outputs: the slabs of the fall-back routines, the hand-over lists and
 // candidate sums of the multi-person path, the frame queue / list counters, the flags of a call that did not ask for
@@ -206,6 +207,8 @@ struct snowtri_ctx {
     Scratch &sums = sets[0].sums;             // candidate sums of k_candidate_sums [frames][Kc] + the frames k_associate left behind
     Scratch in, out, aux;
     PinnedScratch pin_in, pin_out;            // host staging of the per-frame calls
+    PinnedScratch pin_done;                   // the completion word of the small host calls (HostDone, snowtri_kernels.hpp)
+    unsigned long long done_seq = 0;
     Scratch cand;                             // candidates of the last SNOWTRI_HOST snowtri_triangulate call (device-resident hand-over)
     int64_t cand_token = 0, cand_F = 0, cand_Kc = 0, cand_J = 0;   // token 0: none
     int overlap = 1;                  // snowtri_ctx_set_overlap: device calls rotate over this many sets (1 = the caller's stream)
@@ -450,6 +453,7 @@ int snowtri_ctx_destroy(snowtri_ctx *ctx) {
     ctx->out.release();
     ctx->aux.release();
     ctx->cand.release();
+    ctx->pin_done.release();
     ctx->pin_in.release();
     ctx->pin_out.release();
     for (auto &e : ctx->ev)
@@ -766,10 +770,39 @@ int validate_params(const snowtri_params *p, int J, Params *out, bool need_conde
 
 size_t dtype_size(int dt) { return dt == SNOWTRI_F32 ? 4 : 8; }
 
+// The completion word of a small host call: arm it before the launch, spin on it afterwards (the kernels' outputs are already
+// in mapped host memory then).  hipStreamSynchronize stays as the fall-back after 50 ms of spinning.
+int host_done_arm(snowtri_ctx *ctx, HostDone *hd) {
+    int rc = ctx->pin_done.ensure(64);
+    if (rc) return rc;
+    hd->count = (unsigned int *)(ctx->d_counters + kHostDoneCountAt);
+    hd->flag = (unsigned long long *)ctx->pin_done.dev;
+    hd->seq = ++ctx->done_seq;
+    return SNOWTRI_OK;
+}
+int host_done_wait(snowtri_ctx *ctx, hipStream_t st, const HostDone &hd) {
+    const volatile unsigned long long *w = (const volatile unsigned long long *)ctx->pin_done.p;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (unsigned spins = 0; *w != hd.seq; spins++) {
+        __builtin_ia32_pause();
+        if ((spins & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) {
+            HIP_TRY(hipStreamSynchronize(st));   // (a failed launch never writes the word: the runtime reports it here)
+            if (*w != hd.seq) {
+                g_last_error = "a per-frame kernel finished without its completion word";
+                return SNOWTRI_ERR_HIP;
+            }
+            break;
+        }
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    return SNOWTRI_OK;
+}
+
 template <typename TIn>
 void launch_triangulate(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax, int J, int Kc,
                         const void *kpts, const int32_t *n_persons, const Params &prm, double *cxyz,
-                        double *cks, double *cps, uint8_t *ckeep, unsigned long long *n_singular, char *mirror = nullptr) {
+                        double *cks, double *cps, uint8_t *ckeep, unsigned long long *n_singular, char *mirror = nullptr,
+                        HostDone done = HostDone{nullptr, nullptr, 0ull}, bool *one_launch = nullptr) {
     // mirror: host-mapped block [xyz | kscore | pscore | keep | (16-byte aligned) singular count] the kernels fill as well
     const int64_t total = F * (int64_t)Kc * J;
     double *mx = (double *)mirror, *mk = mirror ? mx + 3 * total : nullptr, *mp = mirror ? mk + total : nullptr;
@@ -778,7 +811,8 @@ void launch_triangulate(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax, i
     if (mirror && F * (int64_t)Kc <= 4096 && J <= 4096) {   // the per-frame call: one launch, a workgroup per candidate slot
         hipLaunchKernelGGL((k_triangulate_slots<TIn>), dim3((unsigned)(F * Kc)), dim3(kBlock), sizeof(double) * J, st, F, Pmax, J, Kc, ctx->rig(),
                            (const TIn *)kpts, n_persons, prm, cxyz, cks, cps, ckeep, n_singular, mx, mk, mp, mkeep,
-                           (unsigned long long *)(mirror + ns_off), (unsigned int *)(n_singular + 1));
+                           (unsigned long long *)(mirror + ns_off), (unsigned int *)(n_singular + 1), done);
+        if (one_launch) *one_launch = true;
         return;
     }
     hipLaunchKernelGGL((k_triangulate<TIn>), dim3(grid_for(total, kBlock, ctx->num_cus * 16)), dim3(kBlock), 0,
@@ -794,7 +828,7 @@ constexpr int kCondenseMaxN = 9000;  // condense_lds_bytes(N) <= 160 KiB
 template <typename Writer>
 int launch_condense(snowtri_ctx *ctx, hipStream_t st, int64_t nframes, int N, int J, const double *cxyz,
                     const double *cks, const uint8_t *ckeep, const Params &prm, int Pout, Writer wr,
-                    int32_t *out_count, uint32_t *out_flags) {
+                    int32_t *out_count, uint32_t *out_flags, HostDone done = HostDone{nullptr, nullptr, 0ull}) {
     if (N > kCondenseMaxN) return SNOWTRI_ERR_BAD_ARG;
     const size_t lds = condense_lds_bytes(N);
     auto kern = k_condense<Writer>;
@@ -806,7 +840,7 @@ int launch_condense(snowtri_ctx *ctx, hipStream_t st, int64_t nframes, int N, in
             }
         }
     hipLaunchKernelGGL(kern, dim3(grid_for(nframes, 1, ctx->num_cus * 8)), dim3(kBlock), lds, st, nframes, N, J,
-                       cxyz, cks, ckeep, prm, Pout, wr, out_count, out_flags);
+                       cxyz, cks, ckeep, prm, Pout, wr, out_count, out_flags, done);
     HIP_TRY(hipGetLastError());
     return SNOWTRI_OK;
 }
@@ -883,16 +917,27 @@ int snowtri_triangulate(snowtri_ctx *ctx, int64_t F, int32_t Pmax, int32_t J, co
     } else {
         HIP_TRY(hipMemsetAsync(d_nsing, 0, sizeof(unsigned long long), st));
     }
+    HostDone done{nullptr, nullptr, 0ull};
+    bool polled = false;
+    if (zero_copy) {
+        rc = host_done_arm(ctx, &done);
+        if (rc) return rc;
+    }
     if (in_dtype == SNOWTRI_F32)
-        launch_triangulate<float>(ctx, st, F, Pmax, J, (int)Kc, d_kpts, d_np, prm, d_xyz, d_ks, d_ps, d_keep, d_nsing, mirror);
+        launch_triangulate<float>(ctx, st, F, Pmax, J, (int)Kc, d_kpts, d_np, prm, d_xyz, d_ks, d_ps, d_keep, d_nsing, mirror, done, &polled);
     else
-        launch_triangulate<double>(ctx, st, F, Pmax, J, (int)Kc, d_kpts, d_np, prm, d_xyz, d_ks, d_ps, d_keep, d_nsing, mirror);
+        launch_triangulate<double>(ctx, st, F, Pmax, J, (int)Kc, d_kpts, d_np, prm, d_xyz, d_ks, d_ps, d_keep, d_nsing, mirror, done, &polled);
     HIP_TRY(hipGetLastError());
     if (host) {
         unsigned long long ns = 0;
         if (pinned) {   // one staged download (zero_copy: the kernels have written the staging buffer themselves)
             if (!zero_copy) HIP_TRY(hipMemcpyAsync(ctx->pin_out.p, ctx->cand.p, out_ns_off + 8, hipMemcpyDeviceToHost, st));
-            HIP_TRY(hipStreamSynchronize(st));
+            if (polled) {   // the one-launch kernel signals a mapped word: no sleep on the runtime's interrupt
+                rc = host_done_wait(ctx, st, done);
+                if (rc) return rc;
+            } else {
+                HIP_TRY(hipStreamSynchronize(st));
+            }
             const char *o = (const char *)ctx->pin_out.p;
             std::memcpy(cand_xyz, o, sizeof(double) * nx * 3);
             std::memcpy(cand_kscore, o + sizeof(double) * nx * 3, sizeof(double) * nx);
@@ -1047,9 +1092,19 @@ int snowtri_condense_resident(snowtri_ctx *ctx, int64_t token, const snowtri_par
     double *o_xyz = (double *)base, *o_ks = o_xyz + no * 3, *o_ps = o_ks + no;
     int32_t *o_cnt = (int32_t *)(o_ps + (size_t)F * Pout_max);
     // (the only flag of this entry is the overflow bit: derived from the counts below, no atomics on mapped memory)
-    rc = launch_condense(ctx, st, F, (int)N, J, d_xyz, d_ks, d_keep, prm, Pout_max, SplitWriter{o_xyz, o_ks, o_ps}, o_cnt, (uint32_t *)nullptr);
+    HostDone done{nullptr, nullptr, 0ull};
+    if (zero_copy) {
+        rc = host_done_arm(ctx, &done);
+        if (rc) return rc;
+    }
+    rc = launch_condense(ctx, st, F, (int)N, J, d_xyz, d_ks, d_keep, prm, Pout_max, SplitWriter{o_xyz, o_ks, o_ps}, o_cnt, (uint32_t *)nullptr, done);
     if (rc) return rc;
-    HIP_TRY(hipStreamSynchronize(st));
+    if (zero_copy) {
+        rc = host_done_wait(ctx, st, done);
+        if (rc) return rc;
+    } else {
+        HIP_TRY(hipStreamSynchronize(st));
+    }
     auto fetch = [&](void *dst, size_t off, size_t bytes) -> hipError_t {
         if (!bytes) return hipSuccess;
         if (zero_copy) {

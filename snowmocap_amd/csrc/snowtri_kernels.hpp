@@ -191,6 +191,28 @@ __global__ __launch_bounds__(kBlock) void k_cand_mean(int64_t F, int Pmax, int J
     }
 }
 
+// Completion word of the small host calls.  Their outputs land in mapped page-locked memory, so the host does not need the
+// runtime to tell it that the kernel is over (hipStreamSynchronize sleeps on an interrupt: ~10 us to wake up): every wave
+// makes its stores visible at system scope, the last workgroup to arrive writes `seq` into a mapped word behind them, and the
+// host spins on that word.  count: device counter, 0 between launches.  flag == nullptr: nothing to do.
+struct HostDone {
+    unsigned int *count;
+    unsigned long long *flag;   // mapped host memory
+    unsigned long long seq;
+};
+__device__ __forceinline__ void host_done_signal(const HostDone &d) {
+    if (!d.flag) return;
+    __threadfence_system();     // this wave's stores (device scratch and host mirror) are out
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        if (atomicAdd(d.count, 1u) == gridDim.x - 1u) {
+            *d.count = 0u;
+            __threadfence_system();
+            *reinterpret_cast<volatile unsigned long long *>(d.flag) = d.seq;
+        }
+    }
+}
+
 // k_triangulate + k_cand_mean in ONE launch for the per-frame calls (a handful of candidate slots: the second launch was ~6 of
 // the call's 30 us): one workgroup per (frame, slot); the joints' scores meet in LDS and wave 0 takes their mean in the order
 // k_cand_mean takes it (lane-strided partial sums, then the wave tree), so a slot's bits do not depend on which route ran.
@@ -203,7 +225,7 @@ __global__ __launch_bounds__(kBlock) void k_triangulate_slots(int64_t F, int Pma
                                                               unsigned long long *n_singular, double *__restrict__ mirror_xyz,
                                                               double *__restrict__ mirror_kscore, double *__restrict__ mirror_pscore,
                                                               uint8_t *__restrict__ mirror_keep, unsigned long long *mirror_singular,
-                                                              unsigned int *done_count) {
+                                                              unsigned int *slots_done, HostDone done) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     double *sc_l = reinterpret_cast<double *>(smem);
     const int tid = threadIdx.x, lane = tid & 63;
@@ -253,13 +275,14 @@ __global__ __launch_bounds__(kBlock) void k_triangulate_slots(int64_t F, int Pma
             cand_keep[fk] = mirror_keep[fk] = (valid && !(mean < prm.avg_thr)) ? 1 : 0;  // :80-81 (NaN mean is kept)
             // the last workgroup to finish hands the singular-pair count over and leaves both counters at 0 for the next call
             __threadfence();
-            if (atomicAdd(done_count, 1u) == gridDim.x - 1u) {
+            if (atomicAdd(slots_done, 1u) == gridDim.x - 1u) {
                 *mirror_singular = atomicAdd(n_singular, 0ull);
                 *n_singular = 0ull;
-                *done_count = 0u;
+                *slots_done = 0u;
             }
         }
     }
+    host_done_signal(done);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -462,12 +485,13 @@ __global__ __launch_bounds__(kBlock) void k_condense(int64_t F, int N, int J,
                                                      const double *__restrict__ cand_kscore,
                                                      const uint8_t *__restrict__ cand_keep, Params prm,
                                                      int Pout, Writer wr, int32_t *__restrict__ out_count,
-                                                     uint32_t *__restrict__ out_flags) {
+                                                     uint32_t *__restrict__ out_flags, HostDone done) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     for (int64_t f = blockIdx.x; f < F; f += gridDim.x)
         condense_frame(f, N, J, cand_xyz + f * (int64_t)N * J * 3, cand_kscore + f * (int64_t)N * J,
                        cand_keep ? cand_keep + f * (int64_t)N : nullptr, false, prm, Pout, wr, out_count,
                        out_flags, smem);
+    host_done_signal(done);
 }
 
 }  // namespace snowtri
