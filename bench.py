@@ -519,6 +519,12 @@ def main():
     if rank == 0:
         line = {
             "metric": "joint-triangulations/sec", "value": value, "unit": "joints/s", "n_gpus": world,
+            # what changed in the MEANING of a key, round by round (a figure is comparable only with records of the same schema
+            # for that key): 3 = roofline.kernel_ms_mean / .frac from events attached to the dispatch (rounds 1-2: bracketing
+            # records, still reported as kernel_ms_mean_bracketed / frac_bracketed); 4 = `value` issued as a plain loop of calls in
+            # the library's overlap mode (round 3: two contexts alternated by the bench), extra_workloads[*].kernel_ms from calls
+            # queued back to back (round 3: one synchronised call), N > 1 clock read before the barrier
+            "schema": 4,
             "steps": K_steps, "warmup": W_steps, "ms_per_step": ms_per_step, "ms_per_step_per_rank": step_ms_ranks, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "rccl_ranks": dist.get_world_size() if dist is not None else 1,
