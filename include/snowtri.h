@@ -311,8 +311,7 @@ int snowtri_debug_selftest(snowtri_ctx *ctx);
  * (its last segment) whose fusion (triangulation.py:136-152) was handed from the association kernel to the streaming
  * cluster kernels.  Returns the persons whose cluster is the complete graph over one detection per camera, and in
  * *n_other (may be NULL) those of any other shape; -1 / -1 if that call did not arm the hand-over (single-person
- * batches, float64 outputs, DLT, keypoint_num < J, more than 16 cameras or 16 persons per camera).  Synchronises
- * the device. */
+ * batches, DLT, more than 16 cameras or 16 persons per camera, a negative keypoint threshold).  Synchronises the device. */
 int64_t snowtri_last_handover_persons(snowtri_ctx *ctx, int64_t *n_other);
 /* Diagnostics of the streaming multi-person route, last call (its last segment): counts[0] = frames the association
  * kernel could not finish in its first launch (kept list larger than its LDS), counts[1] = frames with a candidate whose sum

@@ -1822,13 +1822,15 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st_call, int64_t F, int
     int per_cu = oc.per_cu;
     // Hand-over of the output persons to the streaming fusion kernels (snowtri_cluster.hpp): pairwise method, 4-bit person
     // fields, non-negative scores (kthr >= 0).  A person's mean score (:150) is derived from the candidate means when
-    // keypoint_num == J and the outputs are float32; otherwise k_person_scores takes it from the fused joints afterwards, and
-    // the filter of :151-152 -- which the association must decide BEFORE it assigns the slots -- is vacuous only for
-    // condense_score_tol <= 0 (the reference's default), so keypoint_num < J needs that.
+    // keypoint_num == J and the outputs are float32; otherwise k_person_scores takes it from the fused joints afterwards.  The
+    // filter of :151-152 -- which the association must decide BEFORE it assigns the slots -- is vacuous for condense_score_tol
+    // <= 0 (the reference's default); keypoint_num < J with an active filter costs a second launch of k_candidate_sums over
+    // the first keypoint_num joints (kn / J of the first).
     // handover_mode 1: the streaming association (<= 16 cameras); 2: descriptors written by k_frame_recompute itself
     // (<= 8 cameras, float32 outputs, keypoint_num == J: register-resident rays in k_cluster_fuse), staged in its arena.
     const bool can_hand = METHOD == 0 && C >= 2 && Pmax <= kClusterMaxPersons && prm.kn >= 1 && J <= 256 && prm.kthr >= 0.0 && Pout >= 1 &&
-                          (size_t)Pout * 24 + 80 <= (size_t)kRayChunkBytes && (prm.kn == J || prm.score_tol <= 0.0);
+                          (size_t)Pout * 24 + 80 <= (size_t)kRayChunkBytes && !(prm.score_tol != prm.score_tol);
+    const bool sums_kn = prm.kn != J && !(prm.score_tol <= 0.0);   // second candidate-sum launch over the first keypoint_num joints
     const bool post_scores = sizeof(TOut) == 8 || prm.kn != J;   // the persons' mean scores by k_person_scores
     SumsLaunch SL{};
     bool stream = can_hand && ctx->handover_mode == 1 && C <= 16 && Kc < ((int64_t)1 << 24) && Pout <= 1024;
@@ -1931,10 +1933,11 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st_call, int64_t F, int
             if (stream) {
                 // ---- k_candidate_sums -> k_associate -> k_cluster_fuse, then k_frame_recompute on the frames left behind
                 const size_t sum_bytes = ((size_t)Fs * Kc * 8 + 255) & ~(size_t)255;
-                rc = ctx->cur->sums.ensure(sum_bytes + (size_t)Fs * 12 + 256);   // + the frames left behind (two passes) + the frames to re-do exactly
+                rc = ctx->cur->sums.ensure((sums_kn ? 2 : 1) * sum_bytes + (size_t)Fs * 12 + 256);   // + the frames left behind (two passes) + the frames to re-do exactly
                 if (rc) return rc;
                 double *csum = (double *)ctx->cur->sums.p;
-                uint32_t *slow_list = (uint32_t *)((char *)ctx->cur->sums.p + sum_bytes);
+                double *csum_kn = sums_kn ? (double *)((char *)ctx->cur->sums.p + sum_bytes) : nullptr;
+                uint32_t *slow_list = (uint32_t *)((char *)ctx->cur->sums.p + (sums_kn ? 2 : 1) * sum_bytes);
                 // first launch: centres in registers where the rig's true pairs fit 4 / 16 rounds of 64 (snowtri_assoc.hpp)
                 const AssocShape ash = associate_shape(C, ctx->npairs, Pout, Kc);
                 auto k2 = k_associate<TIn, TOut, 0>;   // the second launch (every slot in LDS)
@@ -1950,8 +1953,12 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st_call, int64_t F, int
     {                                                                                                                                \
         auto k1 = k_candidate_sums<TIn, TT>;                                                                                         \
         if (SL.lds > 48 * 1024 && ctx->raise_lds((const void *)k1, SL.lds)) return SNOWTRI_ERR_HIP;                                 \
-        hipLaunchKernelGGL(k1, dim3(grid1), dim3(TT), SL.lds, st, Fs, Pmax, J, (int)Kc, ctx->rig(), kp_seg, np_seg, prm, csum, fl_seg, \
+        hipLaunchKernelGGL(k1, dim3(grid1), dim3(TT), SL.lds, st, Fs, Pmax, J, J, (int)Kc, ctx->rig(), kp_seg, np_seg, prm, csum, fl_seg, \
                            exact_list, exact_count, sums_ticket, SL.lds);                                                            \
+        if (sums_kn) {   /* the sums over the first keypoint_num joints, on a ticket counter of their own */                        \
+            hipLaunchKernelGGL(k1, dim3(grid1), dim3(TT), SL.lds, st, Fs, Pmax, prm.kn, J, (int)Kc, ctx->rig(), kp_seg, np_seg, prm,  \
+                               csum_kn, (uint32_t *)nullptr, (uint32_t *)nullptr, exact_count, sums_ticket + 1, SL.lds);            \
+        }                                                                                                                            \
     }
                 if (SL.threads == 256) SNOWTRI_SUMS(256) else if (SL.threads == 512) SNOWTRI_SUMS(512) else SNOWTRI_SUMS(1024)
 #undef SNOWTRI_SUMS
@@ -1966,7 +1973,8 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st_call, int64_t F, int
                 const int grid2 = (int)std::min<int64_t>(Fs, lds2 > 10 * 1024 ? Fs : (int64_t)ctx->num_cus * ctx->assoc_wg_per_cu);
                 hipLaunchKernelGGL(k2a, dim3(grid2), dim3(64), lds2, st, Fs, Pmax, J, (int)Kc, ctx->rig(), kp_seg, np_seg, prm, Pout, csum,
                                    xyz_seg, ps_seg, d_cnt + s0, fl_seg, desc, words, hand_counters, cap, word_cap, slow_list,
-                                   slow_count, (int)lds2, 1, (const uint32_t *)nullptr, (const unsigned long long *)nullptr, post_scores ? 0 : 1);
+                                   slow_count, (int)lds2, 1, (const uint32_t *)nullptr, (const unsigned long long *)nullptr, post_scores ? 0 : 1,
+                                   (const double *)csum_kn);
                 HIP_TRY(hipGetLastError());
                 // the frames whose kept candidates did not fit that LDS (slow_count of them, known on the device only; none on
                 // the reference's workloads): again with room for every slot, one wave per CU; what this launch lists is
@@ -1981,7 +1989,8 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st_call, int64_t F, int
                     hipLaunchKernelGGL(k2, dim3((int)std::min<int64_t>(Fs, (int64_t)ctx->num_cus * per_cu2)), dim3(64), lds2_full, st, Fs, Pmax, J,
                                        (int)Kc, ctx->rig(), kp_seg, np_seg, prm, Pout, csum, xyz_seg, ps_seg, d_cnt + s0, fl_seg,
                                        desc, words, hand_counters, cap, word_cap, slow_list2, slow_count2, (int)lds2_full, 1,
-                                       (const uint32_t *)slow_list, (const unsigned long long *)slow_count, post_scores ? 0 : 1);
+                                       (const uint32_t *)slow_list, (const unsigned long long *)slow_count, post_scores ? 0 : 1,
+                                       (const double *)csum_kn);
                     HIP_TRY(hipGetLastError());
                     final_slow_list = slow_list2;
                     final_slow_count = slow_count2;

@@ -142,9 +142,13 @@ __device__ unsigned long long g_sums_trace[4096 * 4 * 16];
 // add a chunk's sums to csum (loaded at the start of the round, stored at its end: in flight during the solves).
 template <typename TIn, int THREADS>
 __global__ __launch_bounds__(THREADS, SumsShape<THREADS>::kWavesPerSimd) void k_candidate_sums(
-    int64_t F, int Pmax, int J, int Kc, Rig rig, const TIn *__restrict__ kpts, const int32_t *__restrict__ n_persons, Params prm,
+    int64_t F, int Pmax, int J, int Jrow, int Kc, Rig rig, const TIn *__restrict__ kpts, const int32_t *__restrict__ n_persons, Params prm,
     double *__restrict__ csum, uint32_t *__restrict__ out_flags, uint32_t *__restrict__ exact_list, unsigned long long *exact_count,
     unsigned long long *next_frame, int lds_total) {
+    // J: the joints summed (the first J of a row); Jrow: the joints a keypoint row holds.  The second launch of a batch with
+    // keypoint_num < J and an active condense_score_tol sums the first keypoint_num joints only (:150 needs that mean before the
+    // slots are assigned); it is given no exact list and no flags (a sum that is not finite sends the frame to k_frame_recompute
+    // through k_associate, and average_score_threshold is not its business).
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int B = THREADS, NW = THREADS / 64, NPF = SumsShape<THREADS>::kPrefetch;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -193,12 +197,12 @@ __global__ __launch_bounds__(THREADS, SumsShape<THREADS>::kWavesPerSimd) void k_
             const int r = (int)(((unsigned long long)(unsigned)ic * magic_nj) >> 40), jj = ic - r * nj;
             const int c = (int)(((unsigned long long)(unsigned)r * magic_pmax) >> 40);
             SNOWTRI_DEV_CHECK(r >= 0 && r < R && j0 + jj >= 0 && j0 + jj < J, 10);   // keypoint (row, joint) inside the frame
-            pre[n] = kpf[(size_t)r * J + j0 + jj];
+            pre[n] = kpf[(size_t)r * Jrow + j0 + jj];
             pre_off[n] = i < R * nj ? ((jj * jstr + kP1Rec * r) | (c << 20)) : -1;
         }
     };
     auto fetch_frame = [&](int64_t fr) {   // first chunk and person counts of frame fr
-        fetch(kp3 + fr * (int64_t)R * J, 0, J < Jc ? J : Jc);
+        fetch(kp3 + fr * (int64_t)R * Jrow, 0, J < Jc ? J : Jc);
         if (n_persons && tid < C) npv = n_persons[fr * C + tid];
     };
     auto commit = [&](char *buf) {
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(THREADS, SumsShape<THREADS>::kWavesPerSimd) void k_
     __syncthreads();   // constants and the cleared head
     for (int it = 0; f < F; it++) {
         int32_t *hd = head + 4 * (it & 1);
-        const Kp3<TIn> *kpf = kp3 + f * (int64_t)R * J;
+        const Kp3<TIn> *kpf = kp3 + f * (int64_t)R * Jrow;
         double *cs_f = csum + f * (int64_t)Kc;
         SUMS_STAMP(0);
         if (tid == 0) hd[2] = (int32_t)atomicAdd(next_frame, 1ull);
@@ -318,7 +322,7 @@ __global__ __launch_bounds__(THREADS, SumsShape<THREADS>::kWavesPerSimd) void k_
             auto finish = [&](int k, double v) {
                 const double s_ = v * 0.0005, mean = s_ / (double)J;
                 cs_f[k] = s_;
-                redo |= !(fabs(mean) < 1e300) || (s_ != 0.0 && fabs(mean - prm.avg_thr) <= 1e-6 * fabs(mean));
+                redo |= exact_list != nullptr && (!(fabs(mean) < 1e300) || (s_ != 0.0 && fabs(mean - prm.avg_thr) <= 1e-6 * fabs(mean)));
             };
             if constexpr (SINGLE) {
                 if (JS == 1) {   // a lane owns its candidates' whole sums
@@ -362,7 +366,7 @@ __global__ __launch_bounds__(THREADS, SumsShape<THREADS>::kWavesPerSimd) void k_
         __syncthreads();
         if (tid == 0) {
             if (out_flags) out_flags[f] = 0u;
-            if (hd[0]) exact_list[atomicAdd(exact_count, 1ull)] = (uint32_t)f;
+            if (hd[0] && exact_list) exact_list[atomicAdd(exact_count, 1ull)] = (uint32_t)f;
             hd[0] = hd[1] = 0;   // (for the frame after the next one)
         }
         SUMS_STAMP(11);
@@ -498,7 +502,7 @@ __global__ __launch_bounds__(64, RC > 4 ? 2 : kAssocWaves) void k_associate(int6
                                                   uint32_t desc_cap, uint32_t word_cap, uint32_t *__restrict__ slow_list,
                                                   unsigned long long *slow_count, int lds_total, int allow_complete,
                                                   const uint32_t *__restrict__ frame_list, const unsigned long long *frame_count,
-                                                  int write_person_scores) {
+                                                  int write_person_scores, const double *__restrict__ csum_kn) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int lane = threadIdx.x;
     const int C = rig.C, R = C * Pmax, pp = Pmax * Pmax, NPq = rig.npairs;
@@ -522,9 +526,11 @@ __global__ __launch_bounds__(64, RC > 4 ? 2 : kAssocWaves) void k_associate(int6
     const unsigned long long magic_pp = (((unsigned long long)1 << 40) + (unsigned)pp - 1) / (unsigned)pp;
     const Kp3<TIn> *kp3 = reinterpret_cast<const Kp3<TIn> *>(kpts);
     const PackedWriter<TOut> wr{out4, out_ps};
-    // keypoint_num < J (host-checked: condense_score_tol <= 0, so the filter of :150-152 never drops a person of
-    // non-negative scores) and float64 outputs: the persons' mean scores are written by k_person_scores from the fused
-    // joints (write_person_scores == 0); the unused slots' zeros are written here either way
+    // keypoint_num < J: the mean of :150 runs over the first keypoint_num joints.  With condense_score_tol <= 0 the filter of
+    // :151-152 never drops a person of non-negative scores and the candidate sums over all J joints will do; otherwise csum_kn
+    // holds the sums over the first keypoint_num joints (a second launch of k_candidate_sums) and the filter is decided on them.
+    // There and with float64 outputs the persons' mean scores are written by k_person_scores from the fused joints
+    // (write_person_scores == 0); the unused slots' zeros are written here either way
     const int kn = prm.kn;
     for (int i = lane; i < 2 * NPq; i += 64) pairs[i] = rig.pairs[i];
 
@@ -540,6 +546,7 @@ __global__ __launch_bounds__(64, RC > 4 ? 2 : kAssocWaves) void k_associate(int6
         const int32_t *np_f = n_persons ? n_persons + f * C : nullptr;
         const Kp3<TIn> *kpf = kp3 + f * (int64_t)R * J;
         const double *cs_f = csum + f * (int64_t)Kc;
+        const double *cs_a = csum_kn ? csum_kn + f * (int64_t)Kc : cs_f;   // what a person's mean score is made of
         // candidate slot k -> ray rows, camera pair; false if a camera lists fewer persons than the slot's
         auto slot_rows = [&](int k, int &rm, int &rs, int &q) -> bool {
             q = (int)(((unsigned long long)(unsigned)k * magic_pp) >> 40);
@@ -607,7 +614,7 @@ __global__ __launch_bounds__(64, RC > 4 ? 2 : kAssocWaves) void k_associate(int6
                 slot_rows(kb, rmb, rsb, qb);
                 const Kp3<TIn> kma = kpf[(size_t)rma * J + ci], ksa = kpf[(size_t)rsa * J + ci];
                 const Kp3<TIn> kmb = kpf[(size_t)rmb * J + ci], ksb = kpf[(size_t)rsb * J + ci];
-                const double sa = cs_f[ka], sb = cs_f[kb];
+                const double sa = cs_a[ka], sb = cs_a[kb];
                 auto centre = [&](int i, int rm, int rs, int q, const Kp3<TIn> &km, const Kp3<TIn> &ks, double s_) {
                     const int mc = pairs[2 * q], sc = pairs[2 * q + 1];
                     const RayRec a = make_ray(rig.M + 9 * mc, km.u, km.v), b = make_ray(rig.M + 9 * sc, ks.u, ks.v);
@@ -769,7 +776,7 @@ __global__ __launch_bounds__(64, RC > 4 ? 2 : kAssocWaves) void k_associate(int6
                     double ssum = 0.0;
                     for (int base = 0; base < size; base += 64) ssum += base + lane < size ? lsum[members[m0 + base + lane]] : 0.0;
                     ssum = wave_sum(ssum);
-                    const double avg = ssum / ((double)size * (double)J);                       // :150 from :79
+                    const double avg = ssum / ((double)size * (double)(csum_kn ? kn : J));     // :150 from :79
                     // (a sum that is not finite, or a mean within 1e-6 of the tolerance -- the fast sums are within 6e-8 --
                     // is left to k_frame_recompute; a sum of exactly 0 is exact)
                     if (!(fabs(avg) < 1e300) || (ssum != 0.0 && fabs(avg - prm.score_tol) <= 1e-6 * fabs(avg))) {
