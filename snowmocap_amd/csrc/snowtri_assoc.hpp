@@ -556,7 +556,7 @@ __global__ __launch_bounds__(64, RC > 4 ? 2 : kAssocWaves) void k_associate(int6
             rs = sc * Pmax + ps;
             return !np_f || (pm < np_f[mc] && ps < np_f[sc]);
         };
-        bool slow = false;   // wave-uniform
+        bool slow = false, zero_filled = false;   // wave-uniform
         __syncthreads();     // (the previous frame's LDS is dead; the pair table is there)
         bool ragged = false;
         if (np_f) {
@@ -849,6 +849,11 @@ __global__ __launch_bounds__(64, RC > 4 ? 2 : kAssocWaves) void k_associate(int6
                                                               : (lane == 1 ? ((unsigned long long)ngen << 32) | (unsigned long long)nwords : 0ull);
                     unsigned long long got = 0ull;
                     if (want) got = atomicAdd(hand_counters + (lane == 0 ? kHandComplete : kHandMembers), want);
+                    // the round trip of that device-scope atomic is ~16 us under thousands of waves (wall-clock stamps): the
+                    // zero-fill of the unused slots, which needs nothing of it, goes out in its shadow
+                    for (int i = lane; i < (Pout - nout) * kn; i += 64) wr.zero_joint(f, Pout, kn, nout + i / kn, i % kn);
+                    for (int slot = nout + lane; slot < Pout; slot += 64) wr.person(f, Pout, slot, 0.0);
+                    zero_filled = true;
                     const unsigned long long bc = (unsigned long long)__shfl((long long)got, 0, 64), gm = (unsigned long long)__shfl((long long)got, 1, 64),
                                              bg = hand_member_descs(gm), bw = hand_member_words(gm);
                     // (cannot happen: the host sizes the lists for Pout persons and Kc members of every frame)
@@ -892,9 +897,11 @@ __global__ __launch_bounds__(64, RC > 4 ? 2 : kAssocWaves) void k_associate(int6
             continue;
         }
         ASSOC_STAMP(7);
-        // unused slots: one flat sweep of 16-byte stores
-        for (int i = lane; i < (Pout - nout) * kn; i += 64) wr.zero_joint(f, Pout, kn, nout + i / kn, i % kn);
-        for (int slot = nout + lane; slot < Pout; slot += 64) wr.person(f, Pout, slot, 0.0);
+        // unused slots: one flat sweep of 16-byte stores (already out for a frame that reserved list room)
+        if (!zero_filled) {
+            for (int i = lane; i < (Pout - nout) * kn; i += 64) wr.zero_joint(f, Pout, kn, nout + i / kn, i % kn);
+            for (int slot = nout + lane; slot < Pout; slot += 64) wr.person(f, Pout, slot, 0.0);
+        }
         if (lane == 0) {
             out_count[f] = nout;
             if (out_flags && nout > Pout) atomicOr(&out_flags[f], 2u /*SNOWTRI_FLAG_OVERFLOW*/);
