@@ -319,6 +319,13 @@ int64_t snowtri_last_handover_persons(snowtri_ctx *ctx, int64_t *n_other);
  * workloads (tests assert it: a regression that sends every frame down a fall-back still passes parity, but not this);
  * -1 each if that call did not take the route.  Synchronises the device. */
 int snowtri_last_stream_counts(snowtri_ctx *ctx, int64_t counts[3]);
+/* The context's internal streams (the second stream of the multi-person split, the streams of the overlap mode) are
+ * checked when they are created: the HIP runtime multiplexes a process's streams over a few hardware queues, and an
+ * internal stream that shares the caller's queue runs one after the other with it.  A pair of one-thread kernels tells
+ * (<= 300 us, once per stream; the first call that needs the stream synchronises it and the caller's); a stream that fails
+ * is replaced, up to six candidates.  out[0] = probes run, out[1] = streams discarded, out[2] = verdict on the stream kept
+ * last (1 side by side, 0 none of the candidates was, -1 no stream created yet).  No device work. */
+int snowtri_ctx_stream_probes(const snowtri_ctx *ctx, int64_t out[3]);
 
 #ifdef __cplusplus
 }

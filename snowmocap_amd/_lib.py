@@ -63,6 +63,7 @@ _SIGNATURES = {
     "snowtri_ctx_set_overlap": (ct.c_int, [_c_p, ct.c_int]),
     "snowtri_ctx_join": (ct.c_int, [_c_p, _c_p]),
     "snowtri_last_stream_counts": (ct.c_int, [_c_p, ct.POINTER(ct.c_int64 * 3)]),
+    "snowtri_ctx_stream_probes": (ct.c_int, [_c_p, ct.POINTER(ct.c_int64 * 3)]),
     "snowtri_ctx_create": (ct.c_int, [ct.c_int32, _c_p, _c_p, _c_p, ct.c_int, ct.POINTER(_c_p)]),
     "snowtri_ctx_destroy": (ct.c_int, [_c_p]),
     "snowtri_ctx_num_cameras": (ct.c_int, [_c_p]),
@@ -273,6 +274,13 @@ class Context:
         k_frame_recompute) of the last multi-person call's last segment; (-1, -1, -1) if it did not take the streaming route."""
         arr = (ct.c_int64 * 3)()
         check(lib().snowtri_last_stream_counts(self.handle, ct.byref(arr)), "snowtri_last_stream_counts")
+        return int(arr[0]), int(arr[1]), int(arr[2])
+
+    def stream_probes(self):
+        """(probes run, internal streams discarded, verdict on the stream kept last: 1 = runs beside the others, 0 = no
+        candidate did, -1 = no internal stream yet) -- see snowtri_ctx_stream_probes."""
+        arr = (ct.c_int64 * 3)()
+        check(lib().snowtri_ctx_stream_probes(self.handle, ct.byref(arr)), "snowtri_ctx_stream_probes")
         return int(arr[0]), int(arr[1]), int(arr[2])
 
     def last_slow_frames(self):

@@ -216,13 +216,78 @@ struct snowtri_ctx {
     hipEvent_t ev_fork = nullptr;     // the caller's stream at the time of a call / a split: the internal streams wait for it
     int split_segments = 2;           // one multi-person call is cut into >= this many segments on two sets (1: no split)
     bool split_forced = false;        // SNOWTRI_SPLIT_SEGMENTS given: also batches that would not fill the chip twice
-    int ensure_set(int k) {           // counters, stream and event of set k (set 0: counters at creation, stream on demand)
+    // Internal streams are only worth having on hardware queues of their own (k_probe_wait, snowtri_kernels.hpp):
+    PinnedScratch pin_probe;
+    int64_t probes = 0, probe_replaced = 0;   // snowtri_ctx_stream_probes
+    int probe_verdict = -1;                   // of the stream kept last: 1 side by side, 0 none of the candidates was, -1 no probe yet
+    hipStream_t split_beside[4];              // the caller streams sets[1].stream has been probed against (a ring of the last four)
+    int n_split_beside = 0;
+    bool split_knows(hipStream_t caller) const {
+        for (int i = 0; i < std::min(n_split_beside, 4); ++i)
+            if (split_beside[i] == caller) return true;
+        return false;
+    }
+    int probe_side_by_side(hipStream_t a, hipStream_t b) {   // 1 / 0, -1: HIP error
+        if (pin_probe.ensure(64)) return -1;
+        volatile unsigned int *w = (volatile unsigned int *)pin_probe.p;
+        w[0] = 0u;
+        w[1] = 2u;
+        ++probes;
+        hipLaunchKernelGGL(k_probe_wait, dim3(1), dim3(1), 0, a, (volatile unsigned int *)pin_probe.dev, 30000ull);   // <= 300 us
+        hipLaunchKernelGGL(k_probe_set, dim3(1), dim3(1), 0, b, (volatile unsigned int *)pin_probe.dev);
+        if (hipStreamSynchronize(a) != hipSuccess || hipStreamSynchronize(b) != hipSuccess) return -1;
+        return w[1] == 1u ? 1 : 0;
+    }
+    // a new non-blocking stream that runs beside `caller` (when `with_caller`) and beside the internal streams of the other
+    // sets; up to 6 candidates (each rejected one stays alive until the end, so that the next lands on another queue)
+    int fresh_stream(hipStream_t *out, int k, bool with_caller, hipStream_t caller) {
+        hipStream_t rejected[6];
+        int nrej = 0, rc = 0;
+        for (int attempt = 0; attempt < 6 && !rc; ++attempt) {
+            hipStream_t s = nullptr;
+            if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) {
+                rc = 1;
+                break;
+            }
+            int ok = with_caller ? probe_side_by_side(caller, s) : 1;
+            for (int j = 0; j < kMaxSets && ok == 1; ++j)
+                if (j != k && sets[j].stream) ok = probe_side_by_side(sets[j].stream, s);
+            if (ok < 0) rc = 1;
+            probe_verdict = ok == 1 ? 1 : 0;
+            if (ok == 1 || attempt == 5 || rc) {
+                *out = s;
+                break;
+            }
+            rejected[nrej++] = s;
+            ++probe_replaced;
+        }
+        for (int i = 0; i < nrej; ++i) (void)hipStreamDestroy(rejected[i]);
+        return rc;
+    }
+    int ensure_set(int k, bool with_caller = false, hipStream_t caller = nullptr) {   // counters, stream and event of set k
         StreamSet &S = sets[k];
         if (!S.d_counters) {
             if (hipMalloc(&S.d_counters, sizeof(unsigned long long) * kCounterWords) != hipSuccess) return 1;
             if (hipMemset(S.d_counters, 0, sizeof(unsigned long long) * kCounterWords) != hipSuccess) return 1;
         }
-        if (!S.stream && hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking) != hipSuccess) return 1;
+        if (S.stream && with_caller && !split_knows(caller)) {
+            // the split of a call that arrives on another stream than the last one did: still side by side?
+            const int ok = probe_side_by_side(caller, S.stream);
+            if (ok < 0) return 1;
+            if (ok == 0) {
+                if (hipStreamSynchronize(S.stream) != hipSuccess) return 1;
+                hipStream_t old = S.stream;
+                S.stream = nullptr;
+                const int rc = fresh_stream(&S.stream, k, true, caller);
+                (void)hipStreamDestroy(old);
+                ++probe_replaced;
+                n_split_beside = 0;
+                if (rc) return 1;
+            } else
+                probe_verdict = 1;
+        } else if (!S.stream && fresh_stream(&S.stream, k, with_caller, caller))
+            return 1;
+        if (with_caller && !split_knows(caller)) split_beside[n_split_beside++ & 3] = caller;
         if (!S.done && hipEventCreateWithFlags(&S.done, hipEventDisableTiming) != hipSuccess) return 1;
         if (!ev_fork && hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming) != hipSuccess) return 1;
         return 0;
@@ -454,6 +519,7 @@ int snowtri_ctx_destroy(snowtri_ctx *ctx) {
     ctx->aux.release();
     ctx->cand.release();
     ctx->pin_done.release();
+    ctx->pin_probe.release();
     ctx->pin_in.release();
     ctx->pin_out.release();
     for (auto &e : ctx->ev)
@@ -568,6 +634,14 @@ int snowtri_last_stream_counts(snowtri_ctx *ctx, int64_t counts[3]) {
     counts[0] = (int64_t)n[0];
     counts[1] = (int64_t)n[1];
     counts[2] = (int64_t)n[2];
+    return SNOWTRI_OK;
+}
+
+int snowtri_ctx_stream_probes(const snowtri_ctx *ctx, int64_t out[3]) {
+    if (!ctx || !out) return SNOWTRI_ERR_BAD_ARG;
+    out[0] = ctx->probes;
+    out[1] = ctx->probe_replaced;
+    out[2] = ctx->probe_verdict;
     return SNOWTRI_OK;
 }
 
@@ -1869,7 +1943,7 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st_call, int64_t F, int
             split = false;
     }
     if (split) {
-        if (ctx->ensure_set(1)) {
+        if (ctx->ensure_set(1, true, st_call)) {
             g_last_error = "creating the internal stream of the multi-person split failed";
             return SNOWTRI_ERR_HIP;
         }

@@ -213,6 +213,27 @@ __device__ __forceinline__ void host_done_signal(const HostDone &d) {
     }
 }
 
+// Do two HIP streams run side by side?  The runtime multiplexes a process's streams over a few hardware queues
+// (GPU_MAX_HW_QUEUES, 4 by default; a new stream joins the least-used one) and packets of one queue run in order, whichever
+// stream they came from: an internal stream that lands on the caller's queue turns the two-segment split of a multi-person
+// call into a serial run (measured: 8 x 4 with float64 outputs 1.19 -> 1.36 ms per 10 000 frames in a process that had created
+// 40 streams before).  The probe: k_probe_wait on stream A spins (bounded) on a mapped word that k_probe_set on stream B
+// writes.  B behind A on one queue never gets to run in time.  w[0]: flag, w[1]: verdict.
+__global__ void k_probe_wait(volatile unsigned int *w, unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();   // 100 MHz
+    unsigned int seen = 0;
+    do {
+        seen = w[0];
+        if (!seen) __builtin_amdgcn_s_sleep(64);
+    } while (!seen && wall_clock64() - t0 < ticks);
+    w[1] = seen ? 1u : 0u;
+    __threadfence_system();
+}
+__global__ void k_probe_set(volatile unsigned int *w) {
+    w[0] = 1u;
+    __threadfence_system();
+}
+
 // k_triangulate + k_cand_mean in ONE launch for the per-frame calls (a handful of candidate slots: the second launch was ~6 of
 // the call's 30 us): one workgroup per (frame, slot); the joints' scores meet in LDS and wave 0 takes their mean in the order
 // k_cand_mean takes it (lane-strided partial sums, then the wave tree), so a slot's bits do not depend on which route ran.

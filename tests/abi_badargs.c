@@ -112,6 +112,7 @@ int main(void) {
         EXPECT(snowtri_ctx_set_overlap(NULL, 2), SNOWTRI_ERR_BAD_ARG);
         EXPECT(snowtri_ctx_join(NULL, NULL), SNOWTRI_ERR_BAD_ARG);
         EXPECT(snowtri_last_stream_counts(NULL, counts), SNOWTRI_ERR_BAD_ARG);
+        EXPECT(snowtri_ctx_stream_probes(NULL, counts), SNOWTRI_ERR_BAD_ARG);
         EXPECT(snowtri_candidates_token(NULL), 0);
         EXPECT(snowtri_condense_resident(NULL, 1, &prm, 1, buf, buf, buf, ibuf, ubuf), SNOWTRI_ERR_BAD_ARG);
     }
@@ -208,6 +209,8 @@ int main(void) {
             EXPECT(snowtri_last_stream_counts(ctx, NULL), SNOWTRI_ERR_BAD_ARG);
             EXPECT(snowtri_last_stream_counts(ctx, counts), SNOWTRI_OK);
             EXPECT(counts[0] == -1 && counts[1] == -1 && counts[2] == -1, 1);   /* no multi-person call yet */
+            EXPECT(snowtri_ctx_stream_probes(ctx, NULL), SNOWTRI_ERR_BAD_ARG);
+            EXPECT(snowtri_ctx_stream_probes(ctx, counts), SNOWTRI_OK);
             EXPECT(snowtri_condense_resident(ctx, 0, &prm, 1, buf, buf, buf, ibuf, ubuf), SNOWTRI_ERR_BAD_ARG);       /* no candidates resident */
             EXPECT(snowtri_condense_resident(ctx, 123456789, &prm, 1, buf, buf, buf, ibuf, ubuf), SNOWTRI_ERR_BAD_ARG); /* a stale token */
             EXPECT(snowtri_ctx_overrides(ctx) != NULL, 1);

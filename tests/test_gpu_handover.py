@@ -534,6 +534,52 @@ def test_one_call_split_over_two_stream_sets_is_bit_identical(api, C, P, segment
     assert 0 < sum(cut["handed"]) < sum(whole["handed"])          # (the last segment alone)
 
 
+def test_internal_streams_are_probed_to_run_beside_the_callers(api, monkeypatch):
+    """The HIP runtime multiplexes a process's streams over a few hardware queues (4 by default, least-used first); an
+    internal stream on the caller's queue serialises the split (8 x 4 float64: 1.19 -> 1.36 ms once the process had created
+    some 40 streams).  Every internal stream is therefore probed when it is created (k_probe_wait / k_probe_set) and replaced
+    if it does not run beside the caller's.  Here: a process with torch's stream pool alive, a dozen contexts one after the
+    other on the null stream and on pool streams -- each reports a probe, a verdict of 1, and the uncut call's bits."""
+    import torch
+    from snowmocap_amd import synth
+    dev = torch.device("cuda", 0)
+    wl = synth.config_workload(3, 48)
+    K, R, t = wl["rig"]
+    kp = torch.from_numpy(wl["kpts"]).to(dev)
+    npers = torch.from_numpy(wl["n_persons"]).to(dev)
+    monkeypatch.setenv("SNOWTRI_SPLIT_SEGMENTS", "1")
+    bt = api.BatchTriangulator(K, R, t, wl["params"], pout_max=8, out_dtype=np.float64)
+    whole = {k: v.clone() for k, v in bt.run_torch(kp, npers).items()}
+    torch.cuda.synchronize(dev)
+    assert bt.ctx.stream_probes() == (0, 0, -1)          # no internal stream without the split
+    bt.close()
+    monkeypatch.setenv("SNOWTRI_SPLIT_SEGMENTS", "2")
+    pool = [torch.cuda.Stream(device=dev) for _ in range(5)]
+    discarded = 0
+    for i in range(12):
+        st = pool[i % 5] if i % 3 else torch.cuda.current_stream(dev)
+        bt = api.BatchTriangulator(K, R, t, wl["params"], pout_max=8, out_dtype=np.float64)
+        with torch.cuda.stream(st):
+            out = bt.run_torch(kp, npers)
+            out = bt.run_torch(kp, npers, out=out)       # (the same caller stream again: no second probe)
+        torch.cuda.synchronize(dev)
+        probes, replaced, verdict = bt.ctx.stream_probes()
+        assert probes >= 1 and verdict == 1, (i, probes, replaced, verdict)
+        assert probes == replaced + 1, (i, probes, replaced)
+        discarded += replaced
+        if i == 11:                                       # a call from another stream: one more probe, still side by side
+            with torch.cuda.stream(pool[(i + 1) % 5]):
+                out = bt.run_torch(kp, npers, out=out)
+            torch.cuda.synchronize(dev)
+            p2, r2, v2 = bt.ctx.stream_probes()
+            assert p2 > probes and v2 == 1, (p2, r2, v2)
+        for k in ("xyzs", "pscore", "count", "flags"):
+            assert torch.equal(out[k].view(torch.int32), whole[k].view(torch.int32)), (i, k)
+        bt.close()
+    monkeypatch.delenv("SNOWTRI_SPLIT_SEGMENTS")
+    print("internal streams discarded by the probe:", discarded)
+
+
 def test_reference_workloads_take_no_fall_back_of_the_streaming_route(api):
     """parity alone cannot see a regression that sends every frame of the streaming route down one of its
     fall-backs (second association launch, exact candidate sums, k_frame_recompute).  On the BASELINE multi-person shapes
