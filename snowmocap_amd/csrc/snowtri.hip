@@ -1930,9 +1930,11 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st_call, int64_t F, int
     // flight on two contexts, now inside the call).  Outputs do not depend on the cut (tests/test_gpu_handover.py).  Not
     // in overlap mode (whole calls already alternate over the sets) and not for batches too small to fill the chip twice.
     StreamSet *const set_call = ctx->cur;
-    // (rigs whose candidate pass holds a whole CU per workgroup -- 16 x 8: 1024 threads, 160 KB -- gain nothing: nothing of the
-    // other segment fits beside it, measured 17.0 against 17.3 ms per 12 500 frames; they split only when a test asks for it)
-    bool split = stream && ctx->split_segments >= 2 && ctx->overlap <= 1 && set_call == &ctx->sets[0] && (SL.per_cu >= 2 || ctx->split_forced);
+    // (rigs whose candidate pass holds a whole CU per workgroup -- 16 x 8: 1024 threads, 160 KB -- gain little, only the tails
+    // of the kernels fill one another: 17.20 -> 17.01 ms per 12 500 frames, six interleaved runs.  Staggering the segments --
+    // the second candidate pass waiting for the first so that it runs beside the first's latency-bound kernels -- LOSES:
+    // 8 x 4 1.10 -> 1.24 ms; two half-size candidate passes side by side fill each other's tails, one alone does not.)
+    bool split = stream && ctx->split_segments >= 2 && ctx->overlap <= 1 && set_call == &ctx->sets[0];
     if (split) {
         int64_t nseg = std::max<int64_t>((F + seg - 1) / seg, ctx->split_segments);
         nseg += nseg & 1;

@@ -534,6 +534,38 @@ def test_one_call_split_over_two_stream_sets_is_bit_identical(api, C, P, segment
     assert 0 < sum(cut["handed"]) < sum(whole["handed"])          # (the last segment alone)
 
 
+@pytest.mark.parametrize("cfg,gen,rep,pout", [(3, 220, 10, 16), (5, 70, 30, 32)])
+def test_batches_that_fill_the_chip_twice_are_split_by_default(api, cfg, gen, rep, pout, monkeypatch):
+    """No knob: a multi-person batch of >= 2 x 4 x 256 frames is cut in two by the library itself (8 x 4 and, since the
+    internal stream is probed, 16 x 8 as well: 17.20 -> 17.01 ms per 12 500 frames).  Bit-identical to the uncut call, and
+    the hand-over counters (last segment only) show that the cut happened."""
+    import torch
+    from snowmocap_amd import synth
+    dev = torch.device("cuda", 0)
+    wl = synth.config_workload(cfg, gen)
+    K, R, t = wl["rig"]
+    kp = torch.from_numpy(wl["kpts"]).to(dev).repeat(rep, 1, 1, 1, 1).contiguous()
+    npers = torch.from_numpy(wl["n_persons"]).to(dev).repeat(rep, 1).contiguous()
+    res = {}
+    for mode in ("uncut", "default"):
+        if mode == "uncut":
+            monkeypatch.setenv("SNOWTRI_SPLIT_SEGMENTS", "1")
+        bt = api.BatchTriangulator(K, R, t, wl["params"], pout_max=pout, out_dtype=np.float32)
+        if mode == "uncut":
+            monkeypatch.delenv("SNOWTRI_SPLIT_SEGMENTS")
+        out = bt.run_torch(kp, npers)
+        torch.cuda.synchronize(dev)
+        res[mode] = ({k: v.clone() for k, v in out.items()}, sum(bt.ctx.last_handover_persons()), bt.ctx.stream_probes(), bt.ctx.last_stream_counts())
+        bt.close()
+    for k in ("xyzs", "pscore", "count", "flags"):
+        assert torch.equal(res["uncut"][0][k].view(torch.int32), res["default"][0][k].view(torch.int32)), k
+    total = int(res["uncut"][0]["count"].clamp(max=pout).sum())
+    assert res["uncut"][1] == total and res["uncut"][2] == (0, 0, -1)
+    assert 0 < res["default"][1] < total                     # the last of two segments
+    assert res["default"][2][0] >= 1 and res["default"][2][2] == 1
+    assert res["default"][3] == (0, 0, 0)
+
+
 def test_internal_streams_are_probed_to_run_beside_the_callers(api, monkeypatch):
     """The HIP runtime multiplexes a process's streams over a few hardware queues (4 by default, least-used first); an
     internal stream on the caller's queue serialises the split (8 x 4 float64: 1.19 -> 1.36 ms once the process had created
