@@ -10,6 +10,7 @@ cp $SRC/event_check.json $DST/ 2>/dev/null
 if [ -d gpurun_out/pmc_multi ]; then   # (scripts/pmc_multi.sh was run too: the multi-person kernels)
 cp gpurun_out/pmc_multi/kernel_stats_cfg3.csv $DST/kernel_stats_multi_cfg3_8x4_10000.csv
 cp gpurun_out/pmc_multi/kernel_stats_cfg5.csv $DST/kernel_stats_multi_cfg5_16x8_12000.csv
+[ -f gpurun_out/pmc_multi/kernel_stats_cfg3_f64out.csv ] && cp gpurun_out/pmc_multi/kernel_stats_cfg3_f64out.csv $DST/kernel_stats_multi_cfg3_8x4_10000_f64out.csv
 grep "^a\|^b\|^{" gpurun_out/pmc_multi_stdout.txt > $DST/multi_person_counters.txt
 fi
 cp $SRC/bench_default.json $SRC/bench_steps20.json $SRC/large_launches.json $DST/

@@ -12,6 +12,10 @@ rocprofv3 --output-format csv --pmc GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_SALU S
 rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/s$CFG -o s -- python $ROOT/scripts/bench_configs.py --full --only=$CFG > $OUT/s$CFG.log 2>&1
 cp $(find $OUT/s$CFG -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_cfg$CFG.csv
 done
+# the same 8 x 4 batch with float64 outputs (the reference's own output type): per-kernel table, one stream
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/s3f64 -o s -- python $ROOT/scripts/bench_multi_hot.py --only=3 --no-two --out64 > $OUT/s3f64.log 2>&1
+cp $(find $OUT/s3f64 -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_cfg3_f64out.csv
+rm -rf $OUT/s3f64
 cd $ROOT
 python - <<PY
 import csv, glob, collections
