@@ -228,6 +228,8 @@ struct snowtri_ctx {
         return false;
     }
     int probe_side_by_side(hipStream_t a, hipStream_t b) {   // 1 / 0, -1: HIP error
+        hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;   // never put the probe into a graph under capture
+        if (hipStreamIsCapturing(a, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return -1;
         if (pin_probe.ensure(64)) return -1;
         volatile unsigned int *w = (volatile unsigned int *)pin_probe.p;
         w[0] = 0u;
@@ -252,9 +254,14 @@ struct snowtri_ctx {
             int ok = with_caller ? probe_side_by_side(caller, s) : 1;
             for (int j = 0; j < kMaxSets && ok == 1; ++j)
                 if (j != k && sets[j].stream) ok = probe_side_by_side(sets[j].stream, s);
-            if (ok < 0) rc = 1;
+            if (ok < 0) {   // the probe itself failed (a caller stream that cannot be synchronised now, e.g. under capture):
+                (void)hipGetLastError();   // keep the stream unprobed rather than fail the call
+                probe_verdict = -1;
+                *out = s;
+                break;
+            }
             probe_verdict = ok == 1 ? 1 : 0;
-            if (ok == 1 || attempt == 5 || rc) {
+            if (ok == 1 || attempt == 5) {
                 *out = s;
                 break;
             }
@@ -273,7 +280,7 @@ struct snowtri_ctx {
         if (S.stream && with_caller && !split_knows(caller)) {
             // the split of a call that arrives on another stream than the last one did: still side by side?
             const int ok = probe_side_by_side(caller, S.stream);
-            if (ok < 0) return 1;
+            if (ok < 0) (void)hipGetLastError();   // unprobed: keep the stream
             if (ok == 0) {
                 if (hipStreamSynchronize(S.stream) != hipSuccess) return 1;
                 hipStream_t old = S.stream;
@@ -284,7 +291,7 @@ struct snowtri_ctx {
                 n_split_beside = 0;
                 if (rc) return 1;
             } else
-                probe_verdict = 1;
+                probe_verdict = ok == 1 ? 1 : -1;
         } else if (!S.stream && fresh_stream(&S.stream, k, with_caller, caller))
             return 1;
         if (with_caller && !split_knows(caller)) split_beside[n_split_beside++ & 3] = caller;

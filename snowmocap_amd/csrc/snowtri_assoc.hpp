@@ -947,15 +947,24 @@ __global__ __launch_bounds__(kBlock) void k_person_scores(int64_t F, int Pout, i
     const int lane = threadIdx.x & 63;
     const int64_t W = (int64_t)gridDim.x * (kBlock / 64), total = F * Pout;
     for (int64_t i = (int64_t)blockIdx.x * (kBlock / 64) + (threadIdx.x >> 6); i < total; i += W) {
-        const int64_t f = i / Pout;
-        const int slot = (int)(i - f * Pout);
+        // slot-major items (slot = i / F): with frame-major items and a wave count that is a multiple of Pout a wave met the
+        // same slot in every round -- the waves of the unused slots idle, those of slot 0 do all the work
+        const int slot = (int)(i / F);
+        const int64_t f = i - (int64_t)slot * F;
         const int n = out_count[f];
         if (slot >= n) continue;   // (n < 0: a frame left to k_frame_recompute)
-        const TOut *row = out4 + (size_t)i * kn * 4;
-        double v = 0.0;
-        for (int b = lane; b < kn; b += 64) v += (double)row[4 * b + 3];
+        const int64_t rec = f * Pout + slot;
+        const TOut *row = out4 + (size_t)rec * kn * 4;
+        double v = 0.0;   // lane-strided partial sums in the order of the one-load loop; four loads in flight (+ 0.0 is exact)
+        for (int b0 = lane; b0 < kn; b0 += 256) {
+            TOut a[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) a[u] = b0 + 64 * u < kn ? row[4 * (b0 + 64 * u) + 3] : (TOut)0;
+#pragma unroll
+            for (int u = 0; u < 4; u++) v += (double)a[u];
+        }
         v = wave_sum(v);
-        if (lane == 0) out_ps[i] = (TOut)(v / (double)kn);
+        if (lane == 0) out_ps[rec] = (TOut)(v / (double)kn);
     }
 }
 
