@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Dev aid (GPU box): soak run of the randomised parity sweeps of tests/test_gpu_parity.py with many seeds.
-usage: python scripts/soak_fuzz.py <rounds>   -- every round re-seeds each sweep; the first failures are printed."""
+usage: python scripts/soak_fuzz.py <rounds> [first_round]   -- every round re-seeds each sweep (round r: seed * 100003 + r + 1);
+the first failures are printed.  first_round continues an earlier soak with fresh seeds."""
 import os, sys, time, traceback
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -24,6 +25,7 @@ class MP:                        # monkeypatch stand-in for the hand-over sweep
 
 
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
 sweeps = [("small_rigs auto", lambda e: T.test_random_small_rigs_against_oracle(api, "auto", e)),
           ("small_rigs spill", lambda e: T.test_random_small_rigs_against_oracle(api, "spill", e)),
           ("special auto", lambda e: T.test_random_special_values_against_oracle(api, "auto", e)),
@@ -38,7 +40,7 @@ sweeps = [("small_rigs auto", lambda e: T.test_random_small_rigs_against_oracle(
           ("float64 outputs / keypoint_num on the streaming route", lambda e: TH.test_random_rigs_float64_outputs_and_keypoint_num(api, MP()))]
 fails = 0
 t0 = time.time()
-for r in range(rounds):
+for r in range(first, first + rounds):
     np.random.default_rng = lambda seed=None, r=r: real_rng(None if seed is None else int(seed) * 100003 + r + 1)
     for name, fn in sweeps:
         env = Env()
@@ -59,6 +61,6 @@ for r in range(rounds):
             if fails >= 5: sys.exit(1)
         finally:
             env.undo()
-    if r % 5 == 4: print(f"round {r + 1}/{rounds} done, {fails} failures, {time.time() - t0:.0f} s", flush=True)
+    if r % 5 == 4: print(f"round {r + 1}/{first + rounds} done, {fails} failures, {time.time() - t0:.0f} s", flush=True)
 np.random.default_rng = real_rng
 print("soak finished:", rounds, "rounds,", fails, "failures")

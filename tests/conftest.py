@@ -66,7 +66,11 @@ def assert_scores_close(got, want, rtol=1e-9, what="score", dist_err=5e-14, nter
 
 def assert_xyz_close(got, want, atol, score_ref=None, what="xyz"):
     """3D joints in metres.  Where the reference itself is NaN (inf/inf in the fusion) ours must be
-    NaN or come from a rounding-noise score (see assert_scores_close)."""
+    NaN or come from a rounding-noise score (see assert_scores_close).  A float32 `got` is additionally allowed one unit in
+    the last place of the STORAGE type at the reference's magnitude: with a wide condense_distance_tol the ghost points of
+    near-parallel rays merge into clusters whose fused joints lie hundreds of metres out (soak rounds 39 / 43 / 48 / 57:
+    70-780 m, float32 spacing 8e-6 ... 6e-5 m there; float64 outputs of the same calls: < 1e-8 m)."""
+    ulp32 = 2.0 ** -23 if np.asarray(got).dtype == np.float32 else 0.0
     got = np.asarray(got, dtype=np.float64)
     want = np.asarray(want, dtype=np.float64)
     assert got.shape == want.shape, (what, got.shape, want.shape)
@@ -75,5 +79,6 @@ def assert_xyz_close(got, want, atol, score_ref=None, what="xyz"):
         fin &= (np.abs(np.asarray(score_ref)) < 1e11)[..., None] & np.isfinite(np.asarray(score_ref))[..., None]
     assert np.all(np.isfinite(got[fin])), what + ": non-finite where the reference is finite"
     err = np.max(np.abs(got[fin] - want[fin])) if fin.any() else 0.0
-    assert err <= atol, f"{what}: max |err| = {err:.3e} m > {atol:.1e}"
+    excess = np.max(np.abs(got[fin] - want[fin]) - ulp32 * np.abs(want[fin])) if fin.any() else 0.0
+    assert excess <= atol, f"{what}: max |err| = {err:.3e} m > {atol:.1e} (+ one float32 ulp of the value)" if ulp32 else f"{what}: max |err| = {err:.3e} m > {atol:.1e}"
     return err
