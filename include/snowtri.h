@@ -125,7 +125,11 @@ const char *snowtri_ctx_overrides(const snowtri_ctx *ctx);
  * 26 -> 20 us per call), without the caller creating streams or twin contexts.  The calls must be independent (distinct
  * output buffers; inputs ready on `stream` when the call is made).  Results become visible to the caller's stream at
  * snowtri_ctx_join(ctx, stream) -- `stream` then waits for every call issued since the last join -- or after
- * snowtri_ctx_synchronize.  SNOWTRI_HOST calls are synchronous and ignore the mode. */
+ * snowtri_ctx_synchronize.  SNOWTRI_HOST calls are synchronous and ignore the mode.
+ * Ordering rule: an overlapped call owns the scratch set of ITS internal stream (one set per stream, none of them the
+ * caller's); every other entry point -- host calls, snowtri_triangulate / snowtri_condense_resident, device calls made
+ * with the mode off -- works on the caller's own set, ordered by the stream it is given.  So entry points may be mixed
+ * freely with overlapped calls in flight; only the OUTPUTS of an overlapped call need the join before they are read. */
 int snowtri_ctx_set_overlap(snowtri_ctx *ctx, int n_streams);
 int snowtri_ctx_join(snowtri_ctx *ctx, void *stream);
 

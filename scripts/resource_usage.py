@@ -5,7 +5,7 @@ import re, subprocess, sys
 txt = open(sys.argv[1]).read()
 filters = sys.argv[2:]
 rows = []
-for b in re.split(r"remark: Function Name: ", txt)[1:]:
+for b in re.split(r"remark: [^\n]*?Function Name: ", txt)[1:]:
     name = b.split()[0]
     g = lambda k: (lambda m: int(m.group(1)) if m else -1)(re.search(k + r": (\d+)", b))
     rows.append((name, g("VGPRs"), g("VGPRs Spill"), g(r"ScratchSize \[bytes/lane\]"), g(r"Occupancy \[waves/SIMD\]"), g(r"LDS Size \[bytes/block\]")))

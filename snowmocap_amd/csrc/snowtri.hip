@@ -25,7 +25,7 @@
 #include "snowtri_lean.hpp"
 #include "snowtri_cluster.hpp"
 #include "snowtri_general.hpp"
-#include "snowtri_assoc.hpp"
+#include "snowtri_sums_rays.hpp"
 #include "snowtri_smooth.hpp"
 #include "snowtri_blender.hpp"
 #include "snowtri_undistort.hpp"
@@ -159,11 +159,12 @@ constexpr int kHandCountersAt = 16, kCounterWords = 48, kTriangulateSingularAt =
 struct StreamSet {
     Scratch work, desc, sums, misc;
     unsigned long long *d_counters = nullptr;   // kCounterWords
-    hipStream_t stream = nullptr;               // internal stream (nullptr for set 0 outside overlap mode: the caller's)
+    hipStream_t stream = nullptr;               // internal stream (set 0 never has one: it is ordered by the caller's stream)
     hipEvent_t done = nullptr;                  // recorded behind the last launch the set received
     bool pending = false;                       // `done` has been recorded and not yet joined
 };
-constexpr int kMaxSets = 4;
+constexpr int kMaxSets = 5;   // set 0 = the caller's stream; sets 1..4 carry an internal stream each
+constexpr int kMaxOverlap = kMaxSets - 1;
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a property of the FUNCTION (per device, process-wide) and the call SETS
 // it: two contexts with different rigs in one process must not lower each other's limit.  One monotone
@@ -314,6 +315,8 @@ struct snowtri_ctx {
     int general_mode = 0;        // SNOWTRI_GENERAL_MODE: 0 auto, 1 force the spill kernel, 2 force the recompute kernel
     int lean_mode = 1;           // SNOWTRI_LEAN_MODE: 0 keeps float32-output batches on k_fused_single
     int lean_coop = 1;           // SNOWTRI_LEAN_COOP: 0 keeps small launches on k_fused_lean
+    int sumless_mode = 1;        // SNOWTRI_SUMLESS_MODE: 0 keeps the candidate pass for single-detection batches on the streaming route
+    int sums_rays = 1;           // SNOWTRI_SUMS_RAYS: 0 keeps rigs of 32 rays per frame on the tile kernel (k_candidate_sums)
     int handover_mode = 1;       // SNOWTRI_HANDOVER_MODE: 1 streaming association (k_candidate_sums / k_associate / k_cluster_fuse), 2 hand-over
                                  // from inside k_frame_recompute, 0 the whole multi-person path inside k_frame_recompute
     int handover_seg_frames = 0; // SNOWTRI_HANDOVER_SEG_FRAMES: short segments of the streaming route
@@ -412,6 +415,8 @@ int snowtri_ctx_create(int32_t C, const double *K, const double *R, const double
     knob("SNOWTRI_GENERAL_MODE", &ctx->general_mode, 0);
     knob("SNOWTRI_LEAN_MODE", &ctx->lean_mode, 0);
     knob("SNOWTRI_LEAN_COOP", &ctx->lean_coop, 0);
+    knob("SNOWTRI_SUMLESS_MODE", &ctx->sumless_mode, 0);
+    knob("SNOWTRI_SUMS_RAYS", &ctx->sums_rays, 0);
     knob("SNOWTRI_HANDOVER_MODE", &ctx->handover_mode, 0);
     knob("SNOWTRI_HANDOVER_SEG_FRAMES", &ctx->handover_seg_frames, 1);
     knob("SNOWTRI_SPLIT_SEGMENTS", &ctx->split_segments, 1);
@@ -553,7 +558,7 @@ int snowtri_ctx_synchronize(snowtri_ctx *ctx) {
 }
 
 int snowtri_ctx_set_overlap(snowtri_ctx *ctx, int n_streams) {
-    if (!ctx || n_streams < 1 || n_streams > kMaxSets) return SNOWTRI_ERR_BAD_ARG;
+    if (!ctx || n_streams < 1 || n_streams > kMaxOverlap) return SNOWTRI_ERR_BAD_ARG;
     ENTER_DEVICE(ctx->device);
     for (auto &S : ctx->sets)   // calls still in flight on the internal streams finish under the old mode
         if (S.pending) {
@@ -1635,12 +1640,13 @@ const char *type_name() {
 // 256-wide passes) x (balance of the tiles over the CUs -- the kernel is fp64-VALU-bound, so a CU
 // with one more tile than its neighbours sets the launch time), under the LDS budget.  Prefer
 // >= 2 workgroups per CU (latency hiding) unless that costs more than 5 %.
-int choose_tile_frames(int64_t F, int J, int kn, int NP, int num_cus, int forced) {
-    if (forced >= 1 && forced <= 64 && fused_single_lds_bytes(forced, kn, NP) <= 64 * 1024) return forced;
+int choose_tile_frames(int64_t F, int J, int kn, int NP, int num_cus, int forced, int wg_per_cu) {
+    const size_t lds_cap = wg_per_cu >= 3 ? 52 * 1024 : 64 * 1024;   // (three workgroups share a CU's 160 KB; 53 KB admits two: kRecomputeLdsBytes)
+    if (forced >= 1 && forced <= 64 && fused_single_lds_bytes(forced, kn, NP) <= lds_cap) return forced;
     int best = 1;
     double best_score = -1.0;
     for (int T = 1; T <= 64; T++) {
-        if (fused_single_lds_bytes(T, kn, NP) > 64 * 1024) break;
+        if (T > 1 && fused_single_lds_bytes(T, kn, NP) > lds_cap) break;
         const int64_t items = (int64_t)T * J;
         const double eff_pass = (double)items / (double)(((items + kBlock - 1) / kBlock) * kBlock);
         const int64_t ntiles = (F + T - 1) / T;
@@ -1662,8 +1668,9 @@ int launch_fused_single(snowtri_ctx *ctx, hipStream_t st, int64_t F, int J, cons
                         const int32_t *d_np, const Params &prm, int Pout, TOut *d_xyzs, TOut *d_ps,
                         int32_t *d_cnt, uint32_t *d_fl) {
     constexpr int NP = C * (C - 1) / 2;
-    const int resident = ctx->num_cus * 4;  // 2 workgroups per CU are resident; 2 more queued ones even out the tail (measured)
-    const int T = choose_tile_frames(F, J, prm.kn, NP, ctx->num_cus, 0);
+    constexpr int kWgPerCu = FusedShape<C, METHOD, TIn>::kWaves;   // workgroups of four waves = waves per SIMD
+    const int resident = ctx->num_cus * 2 * kWgPerCu;  // as many again queued even out the tail (measured at 2 per CU)
+    const int T = choose_tile_frames(F, J, prm.kn, NP, ctx->num_cus, 0, kWgPerCu);
     const int64_t ntiles = (F + T - 1) / T;
     const int grid = (int)std::min<int64_t>(ntiles, resident);
     const size_t per_block = general_scratch_bytes(NP, J);
@@ -1694,6 +1701,7 @@ int launch_fused_single(snowtri_ctx *ctx, hipStream_t st, int64_t F, int J, cons
 //   the chip at once, so the hardware dispatcher evens out the tail (measured +3.5 % on a 2 000 000-frame launch
 //   against exactly-resident persistent workgroups).
 constexpr int kLeanJ = 133;
+constexpr int kFusedSingleMaxCams = 4;   // k_fused_single's pairwise item (everything in registers): up to six pairs
 constexpr int kLeanTilesPerWave = 4;
 
 template <int C, typename TIn>
@@ -1829,7 +1837,7 @@ int launch_frame_general(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax, 
 // member words in `words`.
 template <int C, typename TIn, typename TOut>
 int launch_cluster_fuse(snowtri_ctx *ctx, hipStream_t st, int64_t Fs, int Pmax, int J, const TIn *d_kpts, const Params &prm,
-                        int Pout, TOut *d_xyzs, const ClusterDesc *desc, const uint32_t *words,
+                        int Pout, TOut *d_xyzs, uint32_t *d_fl, const ClusterDesc *desc, const uint32_t *words,
                         const unsigned long long *cnt, uint32_t cap) {
     const int kn = prm.kn;
     const int64_t passes_max = (Fs * Pout * (int64_t)kn + 63) / 64;
@@ -1840,11 +1848,11 @@ int launch_cluster_fuse(snowtri_ctx *ctx, hipStream_t st, int64_t Fs, int Pmax, 
     const int grid = (int)std::max<int64_t>(1, std::min<int64_t>((W + kBlock / 64 - 1) / (kBlock / 64), (int64_t)ctx->num_cus * 64));
     const unsigned long long kmagic = (((unsigned long long)1 << 40) + (unsigned long long)kn - 1) / (unsigned long long)kn;
     hipLaunchKernelGGL((k_cluster_fuse<C, TIn, TOut>), dim3(grid), dim3(kBlock), cluster_lds_bytes(C), st, desc, cnt, cap, ctx->rig(), d_kpts, prm,
-                       Pmax, J, kn, kmagic, Pout, d_xyzs);
+                       Pmax, J, kn, kmagic, Pout, d_xyzs, d_fl);
     HIP_TRY(hipGetLastError());
     const int gridm = (int)std::max<int64_t>(1, std::min<int64_t>((passes_max + 3) / 4, (int64_t)ctx->num_cus * 16));
     hipLaunchKernelGGL((k_cluster_members<TIn, TOut>), dim3(gridm), dim3(kBlock), cluster_members_lds_bytes(C, ctx->npairs), st, desc, words, cnt,
-                       cap, ctx->rig(), d_kpts, prm, Pmax, J, kn, kmagic, Pout, d_xyzs);
+                       cap, ctx->rig(), d_kpts, prm, Pmax, J, kn, kmagic, Pout, d_xyzs, d_fl);
     HIP_TRY(hipGetLastError());
     return SNOWTRI_OK;
 }
@@ -1911,8 +1919,15 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st_call, int64_t F, int
     // (<= 8 cameras, float32 outputs, keypoint_num == J: register-resident rays in k_cluster_fuse), staged in its arena.
     const bool can_hand = METHOD == 0 && C >= 2 && Pmax <= kClusterMaxPersons && prm.kn >= 1 && J <= 256 && prm.kthr >= 0.0 && Pout >= 1 &&
                           (size_t)Pout * 24 + 80 <= (size_t)kRayChunkBytes && !(prm.score_tol != prm.score_tol);
-    const bool sums_kn = prm.kn != J && !(prm.score_tol <= 0.0);   // second candidate-sum launch over the first keypoint_num joints
-    const bool post_scores = sizeof(TOut) == 8 || prm.kn != J;   // the persons' mean scores by k_person_scores
+    // ONE detection per camera with average_score_threshold <= 0 <= keypoint_score_threshold and no mean-score filter: every
+    // listed candidate is kept whatever its mean (:80-81; scores that pass the keypoint gate are >= 0), so the candidate pass
+    // has nothing to decide.  It is skipped (`sumless`): k_associate reads a constant positive sum for every slot, the
+    // persons' mean scores come from the fused joints (k_person_scores), and a singular pair is flagged where its joint is
+    // fused (cluster_joint_sequential / cluster_member_passes).  This is the route of single-person rigs of five and more
+    // cameras on the shapes the lean kernels do not take (fused_dispatch).
+    const bool sumless = METHOD == 0 && Pmax == 1 && prm.avg_thr <= 0.0 && prm.kthr >= 0.0 && prm.score_tol <= 0.0 && ctx->sumless_mode != 0;
+    const bool sums_kn = !sumless && prm.kn != J && !(prm.score_tol <= 0.0);   // second candidate-sum launch over the first keypoint_num joints
+    const bool post_scores = sumless || sizeof(TOut) == 8 || prm.kn != J;   // the persons' mean scores by k_person_scores
     SumsLaunch SL{};
     bool stream = can_hand && ctx->handover_mode == 1 && C <= 16 && Kc < ((int64_t)1 << 24) && Pout <= 1024;
     if (stream) {
@@ -1959,17 +1974,29 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st_call, int64_t F, int
         HIP_TRY(hipEventRecord(ctx->ev_fork, st_call));
         HIP_TRY(hipStreamWaitEvent(ctx->sets[1].stream, ctx->ev_fork, 0));
     }
+    const bool sums_rays_shape = !sumless && ctx->sums_rays != 0 && ctx->sums_threads == 0 && ctx->sums_lds_kb == 0 &&
+                                 ((C == 8 && Pmax == 4)
+#ifndef SNOWTRI_DEV_MIN
+                                  || (C == 16 && Pmax == 2) || (C == 4 && Pmax == 8)
+#endif
+                                 );
     const uint32_t *final_slow_list = nullptr;                 // what the streaming association leaves to k_frame_recompute
     const unsigned long long *final_slow_count = nullptr;
     {   // the kernels of this route, in launch order (rebuilt only when the route changes)
         const long long key = ((long long)C << 8) | (METHOD << 7) | ((int)sizeof(TIn) << 3) | ((int)sizeof(TOut) >> 2 << 2) |
-                              (stream ? 2 : 0) | (handover ? 1 : 0) | ((long long)SL.threads << 16);
+                              (stream ? 2 : 0) | (handover ? 1 : 0) | ((long long)SL.threads << 16) | ((long long)(sumless ? 1 : 0) << 32) |
+                              ((long long)(sums_rays_shape ? 1 : 0) << 33) | ((long long)Pmax << 34);
         if (key != ctx->names_key) {
             const std::string tin = type_name<TIn>(), tout = type_name<TOut>();
             const std::string rec = "k_frame_recompute<" + std::to_string(METHOD) + "," + tin + "," + tout + ">";
             const std::string fuse = C <= kClusterMaxCams ? "k_cluster_fuse<" + std::to_string(C) + "," + tin + "> + k_cluster_members<" + tin + ">"
                                                            : "k_cluster_fuse_wide<" + tin + "> + k_cluster_members<" + tin + ">";
-            if (stream)
+            if (stream && sumless)
+                ctx->names_buf = "k_associate<" + tin + "> + " + fuse + " + k_person_scores<" + tout + "> + " + rec + " (frames left behind)";
+            else if (stream && sums_rays_shape)
+                ctx->names_buf = "k_candidate_sums_rays<" + tin + "," + std::to_string(C) + "," + std::to_string(Pmax) + "> + k_candidate_sums_exact<" + tin +
+                                 "> + k_associate<" + tin + "> + " + fuse + " + " + rec + " (frames left behind)";
+            else if (stream)
                 ctx->names_buf = "k_candidate_sums<" + tin + "," + std::to_string(SL.threads) + "> + k_candidate_sums_exact<" + tin +
                                  "> + k_associate<" + tin + "> + " + fuse + " + " + rec + " (frames left behind)";
             else if (handover)
@@ -2043,14 +2070,45 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st_call, int64_t F, int
                                csum_kn, (uint32_t *)nullptr, (uint32_t *)nullptr, exact_count, sums_ticket + 1, SL.lds);            \
         }                                                                                                                            \
     }
-                if (SL.threads == 256) SNOWTRI_SUMS(256) else if (SL.threads == 512) SNOWTRI_SUMS(512) else SNOWTRI_SUMS(1024)
+                if (sumless) {
+                    // every byte 0x3f: the double 4.7e-4 in every slot -- positive, finite, kept by :80-81 for any threshold <= 0
+                    HIP_TRY(hipMemsetAsync(csum, 0x3f, (size_t)Fs * Kc * 8, st));
+                    if (fl_seg) HIP_TRY(hipMemsetAsync(fl_seg, 0, (size_t)Fs * sizeof(uint32_t), st));   // (the candidate pass clears the flags otherwise)
+                } else {
+                    // rigs of exactly 32 rays per frame (8 x 4, 16 x 2, 4 x 8): one lane per ray and joint sub-range, every lane
+                    // of the workgroup at work (snowtri_sums_rays.hpp); everything else: tiles of a camera pair
+                    bool rays = false;
+#define SNOWTRI_RAYS(CC, PP)                                                                                                          \
+    if (C == CC && Pmax == PP) {                                                                                                      \
+        auto kr = k_candidate_sums_rays<TIn, CC, PP>;                                                                                 \
+        const int ldsr = (int)rays_lds_bytes(CC, CC * (CC - 1) / 2);                                                                  \
+        if (ldsr > 48 * 1024 && ctx->raise_lds((const void *)kr, ldsr)) return SNOWTRI_ERR_HIP;                                      \
+        const int gridr = (int)std::min<int64_t>(Fs, (int64_t)ctx->num_cus * kRaysWaves);                                             \
+        hipLaunchKernelGGL(kr, dim3(gridr), dim3(kRaysThreads), ldsr, st, Fs, J, J, ctx->rig(), kp_seg, np_seg, prm, csum, fl_seg,     \
+                           exact_list, exact_count, sums_ticket);                                                                     \
+        if (sums_kn)                                                                                                                  \
+            hipLaunchKernelGGL(kr, dim3(gridr), dim3(kRaysThreads), ldsr, st, Fs, prm.kn, J, ctx->rig(), kp_seg, np_seg, prm, csum_kn, \
+                               (uint32_t *)nullptr, (uint32_t *)nullptr, exact_count, sums_ticket + 1);                               \
+        rays = true;                                                                                                                  \
+    }
+                    if (ctx->sums_rays != 0 && ctx->sums_threads == 0 && ctx->sums_lds_kb == 0) {
+                        SNOWTRI_RAYS(8, 4)
+#ifndef SNOWTRI_DEV_MIN
+                        SNOWTRI_RAYS(16, 2)
+                        SNOWTRI_RAYS(4, 8)
+#endif
+                    }
+#undef SNOWTRI_RAYS
+                    if (rays) {
+                    } else if (SL.threads == 256) SNOWTRI_SUMS(256) else if (SL.threads == 512) SNOWTRI_SUMS(512) else SNOWTRI_SUMS(1024)
+                    HIP_TRY(hipGetLastError());
+                    // the frames it listed (exact_count of them, known on the device only; normally none)
+                    hipLaunchKernelGGL((k_candidate_sums_exact<TIn>), dim3((int)std::min<int64_t>(Fs, ctx->num_cus)), dim3(kBlock), 0, st, Pmax, J,
+                                       (int)Kc, ctx->rig(), kp_seg, np_seg, prm, csum, fl_seg, (const uint32_t *)exact_list,
+                                       (const unsigned long long *)exact_count);
+                    HIP_TRY(hipGetLastError());
+                }
 #undef SNOWTRI_SUMS
-                HIP_TRY(hipGetLastError());
-                // the frames it listed (exact_count of them, known on the device only; normally none)
-                hipLaunchKernelGGL((k_candidate_sums_exact<TIn>), dim3((int)std::min<int64_t>(Fs, ctx->num_cus)), dim3(kBlock), 0, st, Pmax, J,
-                                   (int)Kc, ctx->rig(), kp_seg, np_seg, prm, csum, fl_seg, (const uint32_t *)exact_list,
-                                   (const unsigned long long *)exact_count);
-                HIP_TRY(hipGetLastError());
                 // small rigs: 16 waves per CU, each striding over the frames; large rigs (a frame takes > 100 us and only a few
                 // fit a CU's LDS): one frame per workgroup, the dispatcher evens out the tail
                 const int grid2 = (int)std::min<int64_t>(Fs, lds2 > 10 * 1024 ? Fs : (int64_t)ctx->num_cus * ctx->assoc_wg_per_cu);
@@ -2091,7 +2149,7 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st_call, int64_t F, int
                 switch (C) {
 #define SNOWTRI_CASE(CC)                                                                                                       \
     case CC:                                                                                                                   \
-        rc = launch_cluster_fuse<CC, TIn, TOut>(ctx, st, Fs, Pmax, J, kp_seg, prm, Pout, xyz_seg, desc, words,               \
+        rc = launch_cluster_fuse<CC, TIn, TOut>(ctx, st, Fs, Pmax, J, kp_seg, prm, Pout, xyz_seg, fl_seg, desc, words,       \
                                                 hand_counters, cap);                                                           \
         break;
 #ifndef SNOWTRI_DEV_MIN
@@ -2116,11 +2174,11 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st_call, int64_t F, int
                             const int gridw = (int)std::max<int64_t>(1, std::min<int64_t>((wpasses + 4 * ppw_wide - 1) / (4 * ppw_wide),
                                                                                          (int64_t)ctx->num_cus * 64));
                             hipLaunchKernelGGL(kw, dim3(gridw), dim3(kBlock), ldsw, st, desc, hand_counters, cap, ctx->rig(), kp_seg, prm, Pmax, J,
-                                               prm.kn, kmagic, Pout, xyz_seg);
+                                               prm.kn, kmagic, Pout, xyz_seg, fl_seg);
                             HIP_TRY(hipGetLastError());
                         }
                         hipLaunchKernelGGL((k_cluster_members<TIn, TOut>), dim3(gridm), dim3(kBlock), cluster_members_lds_bytes(C, ctx->npairs), st,
-                                           desc, words, hand_counters, cap, ctx->rig(), kp_seg, prm, Pmax, J, prm.kn, kmagic, Pout, xyz_seg);
+                                           desc, words, hand_counters, cap, ctx->rig(), kp_seg, prm, Pmax, J, prm.kn, kmagic, Pout, xyz_seg, fl_seg);
                         rc = hipGetLastError() == hipSuccess ? SNOWTRI_OK : SNOWTRI_ERR_HIP;
                     }
                 }
@@ -2168,6 +2226,13 @@ int fused_dispatch(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax, int J,
     ctx->ev_attached = false;
     const bool lean = method != SNOWTRI_DLT && fast && std::is_same<TOut, float>::value && J == kLeanJ && prm.kn == kLeanJ && Pout == 1 &&
                       ctx->lean_mode != 0;
+    // Five cameras and more on any other shape (float64 outputs, keypoint_num < J, other skeletons, several slots): the
+    // unrolled pairwise_item of k_fused_single does not fit the register file there (10-28 pairs: 41-1 075 spilled VGPRs, round-4
+    // review).  Those calls take the streaming route WITHOUT its candidate pass (launch_frame_recompute: `sumless`): with one
+    // detection per camera and average_score_threshold <= 0 <= keypoint_score_threshold every candidate is kept whatever its
+    // mean, k_associate clusters the C(C,2) centre joints, k_cluster_fuse runs the complete-graph item (cluster_item, no
+    // scratch) and k_person_scores the mean of :150.
+    const bool single_small = fast && C <= kFusedSingleMaxCams;
     // attached timing of a fast-kernel call: NO event record around the dispatch (a record is a barrier packet: the launches of a
     // timing loop would no longer be back to back); launch_fused_lean attaches the ring's pair to the kernel, or brackets a
     // call of several segments itself
@@ -2221,7 +2286,7 @@ int fused_dispatch(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax, int J,
 #undef SNOWTRI_CASE
             default: rc = SNOWTRI_ERR_BAD_ARG;
         }
-    } else if (fast) {
+    } else if (single_small) {
         switch (C) {
 #define SNOWTRI_CASE(CC)                                                                                   \
     case CC:                                                                                               \
@@ -2229,10 +2294,6 @@ int fused_dispatch(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax, int J,
         break;
 #ifndef SNOWTRI_DEV_MIN
             SNOWTRI_CASE(3)
-            SNOWTRI_CASE(5)
-            SNOWTRI_CASE(6)
-            SNOWTRI_CASE(7)
-            SNOWTRI_CASE(8)
 #endif
             SNOWTRI_CASE(4)
 #undef SNOWTRI_CASE
@@ -2291,7 +2352,9 @@ extern "C" int snowtri_triangulate_condense(snowtri_ctx *ctx, int64_t F, int32_t
     if (memspace == SNOWTRI_DEVICE && ctx->overlap >= 2) {
         // overlap mode: this call runs on the next internal stream behind everything `stream` holds now; the caller's
         // stream sees its results after snowtri_ctx_join
-        const int k = (int)(ctx->call_index++ % ctx->overlap);
+        // (sets 1 .. n: set 0 -- scratch, lists, counters -- stays with the caller's stream, where the host calls, the per-frame
+        // entry points and the calls made outside overlap mode use it; ADVICE r4: an overlapped call on set 0 shared them unordered)
+        const int k = 1 + (int)(ctx->call_index++ % ctx->overlap);
         if (ctx->ensure_set(k)) {
             g_last_error = "creating an internal stream of the overlap mode failed";
             return SNOWTRI_ERR_HIP;

@@ -919,7 +919,8 @@ template <typename TIn, typename TOut>
 __global__ __launch_bounds__(kBlock) void k_cluster_members(const ClusterDesc *__restrict__ desc, const uint32_t *__restrict__ words,
                                                             const unsigned long long *__restrict__ cnt, uint32_t desc_cap, Rig rig,
                                                             const TIn *__restrict__ kpts, Params prm, int Pmax, int J, int kn,
-                                                            unsigned long long kmagic, int Pout, TOut *__restrict__ out4) {
+                                                            unsigned long long kmagic, int Pout, TOut *__restrict__ out4,
+                                                            uint32_t *__restrict__ out_flags) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int C = rig.C, NP = rig.npairs, tid = threadIdx.x;
     double *Ml = reinterpret_cast<double *>(smem);
@@ -933,7 +934,7 @@ __global__ __launch_bounds__(kBlock) void k_cluster_members(const ClusterDesc *_
     __syncthreads();
     const uint32_t W = gridDim.x * (uint32_t)(kBlock / 64);
     cluster_member_passes<TIn, TOut>(desc + desc_cap, ngen, words, Ml, pc, pairs_l, C * Pmax, reinterpret_cast<const Kp3<TIn> *>(kpts), prm, J, kn,
-                                     kmagic, Pout, out4, blockIdx.x * (uint32_t)(kBlock / 64) + (uint32_t)(tid >> 6), W);
+                                     kmagic, Pout, out4, blockIdx.x * (uint32_t)(kBlock / 64) + (uint32_t)(tid >> 6), W, out_flags);
 }
 
 // ---------------------------------------------------------------------------------------------------- k_person_scores

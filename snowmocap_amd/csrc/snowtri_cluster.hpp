@@ -22,7 +22,7 @@
 #include <type_traits>
 #include <utility>
 
-#include "snowtri_lean.hpp"
+#include "snowtri_lean.hpp"   // (snowtri_item.hpp: cluster_item, through snowtri_fused.hpp)
 
 namespace snowtri {
 
@@ -44,128 +44,8 @@ __host__ __device__ inline uint32_t hand_member_words(unsigned long long v) { re
 constexpr int kClusterMaxCams = 8;      // 4-bit person fields in one word, register-resident rays
 constexpr int kClusterMaxPersons = 16;
 
-// camera pair q = (m, s) in the candidate order of triangulation.py:56-57, as compile-time tables (indexed by the
-// unrolled pair counter: a loop that searches for q would leave the ray arrays dynamically indexed, i.e. in scratch)
-template <int C>
-struct ClusterPairs {
-    static constexpr int NP = C * (C - 1) / 2;
-    struct Tab {
-        int m[NP > 0 ? NP : 1], s[NP > 0 ? NP : 1];
-    };
-    static constexpr Tab make() {
-        Tab t{};
-        int k = 0;
-        for (int m = 0; m < C - 1; m++)
-            for (int s = m + 1; s < C; s++, k++) {
-                t.m[k] = m;
-                t.s[k] = s;
-            }
-        return t;
-    }
-    static constexpr Tab tab = make();
-};
 __host__ __device__ constexpr int cluster_const_doubles(int C) { return 12 * C + 3 * (C * (C - 1) / 2); }  // M[C][9], t[C][3], d[NP][3]
 __host__ __device__ constexpr size_t cluster_lds_bytes(int C) { return (size_t)8 * cluster_const_doubles(C) + 16; }
-
-// compile-time loop: f(std::integral_constant<int, 0>) ... f(std::integral_constant<int, N - 1>)
-template <typename F, int... I>
-__device__ __forceinline__ void cluster_static_for_impl(F &&f, std::integer_sequence<int, I...>) {
-    (f(std::integral_constant<int, I>{}), ...);
-}
-template <int N, typename F>
-__device__ __forceinline__ void cluster_static_for(F &&f) {
-    cluster_static_for_impl(f, std::make_integer_sequence<int, N>{});
-}
-
-// One (cluster, joint): the item of k_fused_lean with the pair offsets read from LDS (28 pairs x 3 doubles do not fit
-// the scalar registers), pairs in groups of four (register budget).  K = [M | t | d] in LDS at offset 0.
-// Returns true if the joint needs the sequential routine (exact intersection, singular pair, NaN).
-// TOut = float: 1/dist is the raw v_rsq_f64 (2^-24.2 relative, below the rounding of the stored score -- the contract of
-// k_fused_lean); TOut = double: one Newton step on it (2e-14), as the float64 outputs of every other kernel.  The
-// results come back in double; the caller rounds them to TOut when it stores.
-template <int C, typename TIn, typename TOut>
-__device__ __forceinline__ bool cluster_item(const double *__restrict__ K, const Kp3<TIn> (&cur)[C], float kthr_f32, double kthr,
-                                             double dthr2, double &ox, double &oy, double &oz, double &os) {
-#pragma clang fp contract(off)
-    constexpr int NP = C * (C - 1) / 2;
-    constexpr int kGroup = 4;
-    Vec3 h[C];
-    double a[C], alpha[C], beta[C];
-    bool okc[C];
-    cluster_static_for<C>([&](auto CC) {
-        constexpr int c = CC;
-        const double *M = K + 9 * c;
-        const double u = (double)cur[c].u, v = (double)cur[c].v;
-        h[c].x = fma(M[0], u, fma(M[1], v, M[2]));   // A1, camera.py:241-243 with M = R inv(K)
-        h[c].y = fma(M[3], u, fma(M[4], v, M[5]));
-        h[c].z = fma(M[6], u, fma(M[7], v, M[8]));
-        a[c] = dot3(h[c], h[c]);
-        if constexpr (sizeof(TIn) == 4)
-            okc[c] = !((float)cur[c].s < kthr_f32);   // triangulation.py:73, once per camera
-        else
-            okc[c] = !((double)cur[c].s < kthr);
-        alpha[c] = 0.0;
-        beta[c] = 0.0;
-    });
-    // per pair, without a reciprocal of the determinant (see lean_item): with n = h_m . (h_s x d) the distance of the two
-    // rays is |n| / sqrt(det), so 1 / dist = det rsq(n^2 det) and the pair's weight times S0, S1, 1 is w N0, w N1, w det with
-    // w = ssum rsq(n^2 det)
-    cluster_static_for<(NP + kGroup - 1) / kGroup>([&](auto GG) {
-        constexpr int q0 = kGroup * GG;
-        constexpr int n = NP - q0 < kGroup ? NP - q0 : kGroup;
-        __builtin_amdgcn_sched_barrier(0);   // a group's LDS reads and temporaries stay inside the group (register budget)
-        cluster_static_for<n>([&](auto UU) {
-            constexpr int u = UU, q = q0 + u, mc = ClusterPairs<C>::tab.m[q], sc = ClusterPairs<C>::tab.s[q];
-            const Vec3 &hm = h[mc], &hs = h[sc];
-            const double *dq = K + 12 * C + 3 * q;
-            const double dx = dq[0], dy = dq[1], dz = dq[2];
-            // A2 (triangulation.py:24-31)
-            const double b = dot3(hm, hs);
-            const double det = fma(a[mc], a[sc], -(b * b));
-            const double e = fma(hm.z, dz, fma(hm.y, dy, hm.x * dx));
-            const double g = fma(hs.z, dz, fma(hs.y, dy, hs.x * dx));
-            const double N0 = fma(a[sc], e, -(b * g));
-            const double N1 = fma(a[mc], g, -(b * e));
-            const double cx = fma(hs.y, dz, -(hs.z * dy)), cy = fma(hs.z, dx, -(hs.x * dz)), cz = fma(hs.x, dy, -(hs.y * dx));
-            const double nn = fma(hm.z, cz, fma(hm.y, cy, hm.x * cx));
-            const double n2 = nn * nn;
-            double rho;
-            if constexpr (sizeof(TOut) == 4)
-                rho = __builtin_amdgcn_rsq(n2 * det);
-            else
-                rho = rsq_nr1(n2 * det);   // (n2 det == 0: inf -> NaN here; either way the sum is not finite and the joint is re-done)
-            // :72-74, w det = 2000 x the pair score; the gates select the score sum before the product (plain selects here: 28
-            // lane masks held for an inline v_cndmask, as in k_fused_lean, overflow the scalar registers)
-            const bool keep = okc[mc] && okc[sc] && !(n2 > dthr2 * det);
-            double w;
-            if constexpr (sizeof(TIn) == 4)
-                w = (double)(keep ? (float)cur[mc].s + (float)cur[sc].s : 0.0f) * rho;   // float32 sum as NumPy
-            else
-                w = (keep ? (double)cur[mc].s + (double)cur[sc].s : 0.0) * rho;
-            alpha[mc] = fma(w, N0, alpha[mc]);
-            alpha[sc] = fma(-w, N1, alpha[sc]);
-            beta[mc] = fma(w, det, beta[mc]);
-            beta[sc] = fma(w, det, beta[sc]);
-        });
-    });
-    __builtin_amdgcn_sched_barrier(0);
-    const double *tp = K + 9 * C;
-    double sx = 0.0, sy = 0.0, sz = 0.0, sb = 0.0;
-    cluster_static_for<C>([&](auto CC) {
-        constexpr int c = CC;
-        sx = fma(alpha[c], h[c].x, fma(beta[c], tp[3 * c + 0], sx));
-        sy = fma(alpha[c], h[c].y, fma(beta[c], tp[3 * c + 1], sy));
-        sz = fma(alpha[c], h[c].z, fma(beta[c], tp[3 * c + 2], sz));
-        sb += beta[c];
-    });
-    // sb = 2 x 2000 x sum_q s_q (:141); sum == 0 -> (0,0,0)/0 (:142-143): sx = sy = sz = 0 then
-    const double r = rcp_nr1(fmax(sb, 1e-300));
-    ox = sx * r;   // :144-147 as (sum s (Wm+Ws)) / (2 sum s)
-    oy = sy * r;
-    oz = sz * r;
-    os = sb * (0.00025 / (double)NP);   // :148
-    return !(sb < 1e300);
-}
 
 // One joint record [x, y, z, score] of an output person, rounded to the output type: one 16-byte store (two for doubles).
 template <typename TOut>
@@ -183,14 +63,16 @@ __device__ __forceinline__ void cluster_store(TOut *__restrict__ out4, uint64_t 
 // score of :72 for float32 outputs, the score itself for float64 (the gates ASSIGN 0, :73-74: select after the product --
 // 0 * inf at an exact intersection), sw = Wm + Ws.
 // float32 outputs: raw v_rsq_f64 for 1/dist; float64 outputs: pair_solve_fast (Newton-refined, d2 == 0 -> inf).
+// Returns true for an exactly singular pair (det == 0: np.linalg.inv raises, triangulation.py:26 -> SNOWTRI_FLAG_SINGULAR).
 template <typename TIn, typename TOut>
-__device__ __forceinline__ void cluster_member_solve(const RayRec &a, const RayRec &b, const double *__restrict__ c6, TIn sm, TIn ss,
+__device__ __forceinline__ bool cluster_member_solve(const RayRec &a, const RayRec &b, const double *__restrict__ c6, TIn sm, TIn ss,
                                                      const Params &prm, double &sq, Vec3 &sw) {
     if constexpr (sizeof(TOut) == 4) {
         const double bq = fma(a.z, b.z, fma(a.y, b.y, a.x * b.x));
         const double e = fma(a.z, c6[2], fma(a.y, c6[1], a.x * c6[0]));
         const double g = fma(b.z, c6[2], fma(b.y, c6[1], b.x * c6[0]));
-        const double inv = rcp_nr2(fma(a.a, b.a, -(bq * bq)));
+        const double det = fma(a.a, b.a, -(bq * bq));
+        const double inv = rcp_nr2(det);
         const double S0 = fma(b.a, e, -(bq * g)) * inv;
         const double S1 = fma(a.a, g, -(bq * e)) * inv;
         const double fx = fma(b.x, S1, fma(a.x, S0, -c6[0])), fy = fma(b.y, S1, fma(a.y, S0, -c6[1])),
@@ -199,11 +81,13 @@ __device__ __forceinline__ void cluster_member_solve(const RayRec &a, const RayR
         const bool kp_ = !below_kthr(sm, prm) && !below_kthr(ss, prm) && !(d2 > prm.dthr2);
         sq = kp_ ? sum_score(sm, ss) * __builtin_amdgcn_rsq(d2) : 0.0;
         sw = {fma(-b.x, S1, fma(a.x, S0, c6[3])), fma(-b.y, S1, fma(a.y, S0, c6[4])), fma(-b.z, S1, fma(a.z, S0, c6[5]))};
+        return a.a * b.a == bq * bq;   // (see skew_ray_solve, snowtri_math.hpp)
     } else {
         const PairSolve o = pair_solve_fast<true>(a, b, Vec3{c6[0], c6[1], c6[2]}, Vec3{c6[3], c6[4], c6[5]});
         const bool kp_ = !below_kthr(sm, prm) && !below_kthr(ss, prm) && !(o.d2 > prm.dthr2);
         sq = kp_ ? sum_score(sm, ss) * (0.5 * o.score_base) : 0.0;       // the score of :72 itself (k_frame_recompute's float64 branch)
         sw = o.sw;
+        return o.singular;
     }
 }
 
@@ -234,10 +118,11 @@ __device__ __forceinline__ void cluster_finish(double aS, double aX, double aY, 
 template <typename TIn, typename TOut>
 __device__ __noinline__ void cluster_joint_sequential(const Rig &rig, const Kp3<TIn> *__restrict__ kp3, int64_t frame0, uint32_t plo,
                                                       uint32_t phi, int Pmax, int J, int j, const Params &prm, double &ox, double &oy,
-                                                      double &oz, double &os) {
+                                                      double &oz, double &os, uint32_t *__restrict__ out_flags) {
     const int C = rig.C, NP = rig.npairs;
     auto person = [&](int c) { return (int)(((c < 8 ? plo : phi) >> (4 * (c & 7))) & 15u); };
     double aS = 0.0, aX = 0.0, aY = 0.0, aZ = 0.0;
+    bool sing = false;
     for (int q = 0; q < NP; q++) {
         const int mc = rig.pairs[2 * q], sc = rig.pairs[2 * q + 1];
         const int64_t rm = (frame0 * C + mc) * Pmax + person(mc);
@@ -246,12 +131,13 @@ __device__ __noinline__ void cluster_joint_sequential(const Rig &rig, const Kp3<
         const RayRec a = make_ray(rig.M + 9 * mc, km.u, km.v), b = make_ray(rig.M + 9 * sc, ks.u, ks.v);
         double sq;
         Vec3 sw;
-        cluster_member_solve<TIn, TOut>(a, b, rig.pairc + 6 * q, km.s, ks.s, prm, sq, sw);
+        sing |= cluster_member_solve<TIn, TOut>(a, b, rig.pairc + 6 * q, km.s, ks.s, prm, sq, sw);
         aS += sq;                                                              // :141
         aX = fma(sq, sw.x, aX);                                                // :144-147
         aY = fma(sq, sw.y, aY);
         aZ = fma(sq, sw.z, aZ);
     }
+    if (sing && out_flags) atomicOr(&out_flags[frame0], 1u /*SNOWTRI_FLAG_SINGULAR*/);   // (idempotent beside the candidate pass's flag)
     cluster_finish<TOut>(aS, aX, aY, aZ, NP, ox, oy, oz, os);
 }
 
@@ -265,7 +151,8 @@ __device__ __forceinline__ void cluster_member_passes(const ClusterDesc *__restr
                                                       const uint32_t *__restrict__ words, const double *__restrict__ Ml,
                                                       const double *__restrict__ pc, const int32_t *__restrict__ pairs, int R,
                                                       const Kp3<TIn> *__restrict__ kp3, const Params &prm, int J, int kn,
-                                                      unsigned long long kmagic, int Pout, TOut *__restrict__ out4, uint32_t p0, uint32_t W) {
+                                                      unsigned long long kmagic, int Pout, TOut *__restrict__ out4, uint32_t p0, uint32_t W,
+                                                      uint32_t *__restrict__ out_flags) {
     const int lane = threadIdx.x & 63;
     const uint32_t total = ndesc * (uint32_t)kn;
     const uint32_t npass = (total + 63u) >> 6;
@@ -281,6 +168,7 @@ __device__ __forceinline__ void cluster_member_passes(const ClusterDesc *__restr
         const int size = valid ? (int)d.w : 0;
         const uint64_t row0 = (uint64_t)d.x * (uint32_t)R;
         double aS = 0.0, aX = 0.0, aY = 0.0, aZ = 0.0;
+        bool sing = false;
         for (int m = 0; __ballot(m < size) != 0ull; m++) {
             if (m < size) {
                 const uint32_t w = words[d.y + (uint32_t)m];
@@ -289,12 +177,15 @@ __device__ __forceinline__ void cluster_member_passes(const ClusterDesc *__restr
                 const RayRec a = make_ray(Ml + 9 * pairs[2 * q], km.u, km.v), b = make_ray(Ml + 9 * pairs[2 * q + 1], ks.u, ks.v);
                 double sq;
                 Vec3 sw;
-                cluster_member_solve<TIn, TOut>(a, b, pc + 6 * q, km.s, ks.s, prm, sq, sw);
+                sing |= cluster_member_solve<TIn, TOut>(a, b, pc + 6 * q, km.s, ks.s, prm, sq, sw);
                 aS += sq;                                                              // :141
                 aX = fma(sq, sw.x, aX);                                                // :144-147
                 aY = fma(sq, sw.y, aY);
                 aZ = fma(sq, sw.z, aZ);
             }
+        }
+        if (__ballot(sing)) {   // rare, wave-uniform branch: an exactly singular pair (the reference raises, :26)
+            if (sing && valid && out_flags) atomicOr(&out_flags[d.x], 1u /*SNOWTRI_FLAG_SINGULAR*/);
         }
         if (valid) {
             double x, y, z, sc;
@@ -315,7 +206,8 @@ template <int C, typename TIn, typename TOut>
 __global__ __launch_bounds__(kBlock, kClusterWaves) void k_cluster_fuse(const ClusterDesc *__restrict__ desc,
                                                           const unsigned long long *__restrict__ cnt, uint32_t desc_cap,
                                                           Rig rig, const TIn *__restrict__ kpts, Params prm, int Pmax, int J, int kn,
-                                                          unsigned long long kmagic, int Pout, TOut *__restrict__ out4) {
+                                                          unsigned long long kmagic, int Pout, TOut *__restrict__ out4,
+                                                          uint32_t *__restrict__ out_flags) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NP = C * (C - 1) / 2;
     double *K = reinterpret_cast<double *>(smem);   // [M | t | d] for cluster_item
@@ -363,7 +255,7 @@ __global__ __launch_bounds__(kBlock, kClusterWaves) void k_cluster_fuse(const Cl
         asm volatile("" ::: "memory");   // the rig constants are re-read from LDS in every pass (hoisted out of the loop they would take 360 registers)
         const bool bad = cluster_item<C, TIn, TOut>(K, cur, kthr_f32, kthr, dthr2, ox, oy, oz, os);
         if (__ballot(bad && valid)) {   // rare, wave-uniform branch
-            if (bad && valid) cluster_joint_sequential<TIn, TOut>(rig, kp3, (int64_t)frame, persons, 0u, Pmax, J, (int)j, prm, ox, oy, oz, os);
+            if (bad && valid) cluster_joint_sequential<TIn, TOut>(rig, kp3, (int64_t)frame, persons, 0u, Pmax, J, (int)j, prm, ox, oy, oz, os, out_flags);
         }
         if (valid) cluster_store<TOut>(out4, ((uint64_t)frame * (uint32_t)Pout + slot) * (uint64_t)(uint32_t)kn + j, ox, oy, oz, os);
     }
@@ -403,7 +295,7 @@ __global__ __launch_bounds__(kBlock, kWideWaves) void k_cluster_fuse_wide(const 
                                                                                  const unsigned long long *__restrict__ cnt,
                                                                                  uint32_t desc_cap, Rig rig, const TIn *__restrict__ kpts,
                                                                                  Params prm, int Pmax, int J, int kn, unsigned long long kmagic,
-                                                                                 int Pout, TOut *__restrict__ out4) {
+                                                                                 int Pout, TOut *__restrict__ out4, uint32_t *__restrict__ out_flags) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int kMaxOwn = 4;                        // first cameras per lane: C <= 16
     const int C = rig.C, NP = rig.npairs;
@@ -582,7 +474,7 @@ __global__ __launch_bounds__(kBlock, kWideWaves) void k_cluster_fuse_wide(const 
         const bool bad = !(aS < 1e300) && it0.valid;
         if (__ballot(bad)) {   // rare, wave-uniform branch
             if (bad && g == 0)
-                cluster_joint_sequential<TIn, TOut>(rig, kp3, (int64_t)it0.frame, it0.plo, it0.phi, Pmax, J, (int)it0.j, prm, ox, oy, oz, os);
+                cluster_joint_sequential<TIn, TOut>(rig, kp3, (int64_t)it0.frame, it0.plo, it0.phi, Pmax, J, (int)it0.j, prm, ox, oy, oz, os, out_flags);
         }
         if (it0.valid && g == 0)
             cluster_store<TOut>(out4, ((uint64_t)it0.frame * (uint32_t)Pout + it0.slot) * (uint64_t)(uint32_t)kn + it0.j, ox, oy, oz, os);

@@ -11,7 +11,7 @@
 //                     condense_distance_tol = 10 m, always produces), verifies that per frame, and
 //                     hands any frame that violates it to general_frame inside the same launch.
 #pragma once
-#include "snowtri_kernels.hpp"
+#include "snowtri_item.hpp"
 
 namespace snowtri {
 
@@ -108,6 +108,22 @@ __global__ __launch_bounds__(kBlock) void k_frame_general(int64_t F, int Pmax, i
 // Minimum waves per SIMD the fast kernel is compiled for (caps its VGPR allocation: 4 -> 128).
 // Depth of the register prefetch ring of k_fused_single (2 or 3 keypoint buffers per lane).
 constexpr int kFastWaves = 2;
+// Shape of k_fused_single per instantiation.  The pairwise method runs here for up to four cameras only (six pairs: every
+// constant and every pair's intermediate in registers); five and more take the lean kernels on cluster_item or the streaming
+// route (fused_dispatch).  The DLT item of five and more cameras reads a camera's world->pixel matrix where its observation
+// is added and keeps TWO keypoint buffers in flight instead of three, as do float64 keypoints (buffers of twice the size):
+// with three those shapes spilled 7-260 VGPRs (round-4 review).
+#ifndef SNOWTRI_DLT_RING1_FROM
+#define SNOWTRI_DLT_RING1_FROM 6
+#endif
+#ifndef SNOWTRI_DLT_WIDE_WAVES
+#define SNOWTRI_DLT_WIDE_WAVES 2
+#endif
+template <int C, int METHOD, typename TIn>
+struct FusedShape {
+    static constexpr int kRing = C >= SNOWTRI_DLT_RING1_FROM ? 1 : ((C >= 5 || sizeof(TIn) == 8) ? 2 : 3);
+    static constexpr int kWaves = C >= 5 ? SNOWTRI_DLT_WIDE_WAVES : kFastWaves;
+};
 
 template <typename T>
 struct Vec4T {
@@ -145,9 +161,9 @@ __device__ __forceinline__ void fetch_item(Kp3<TIn> (&dst)[C], const Kp3<TIn> *_
     for (int c = 0; c < C; c++) dst[c] = tile_in[off + (unsigned)(c * J)];
 }
 
-// first two items of this lane in tile `tile` -> bufA, bufB
-template <int C, typename TIn>
-__device__ __forceinline__ void prefetch_tile_head(Kp3<TIn> (&bufA)[C], Kp3<TIn> (&bufB)[C],
+// first two items of this lane in tile `tile` -> bufA, bufB (a ring of two: the first item -> bufA)
+template <int C, int RING, typename TIn>
+__device__ __forceinline__ void prefetch_tile_head(Kp3<TIn> (&bufA)[C], Kp3<TIn> (&bufB)[RING >= 2 ? C : 1],
                                                    const Kp3<TIn> *__restrict__ kp3, int64_t tile, int T,
                                                    int64_t F, int J, int tid, int dfl, int dj) {
     const int64_t f0 = tile * T;
@@ -156,8 +172,10 @@ __device__ __forceinline__ void prefetch_tile_head(Kp3<TIn> (&bufA)[C], Kp3<TIn>
     const Kp3<TIn> *tile_in = kp3 + f0 * C * (int64_t)J;
     int fl = tid / J, j = tid - fl * J;
     fetch_item<C>(bufA, tile_in, fl, j, J, last_off);
-    advance_item(fl, j, dfl, dj, J);
-    fetch_item<C>(bufB, tile_in, fl, j, J, last_off);
+    if constexpr (RING >= 3) {
+        advance_item(fl, j, dfl, dj, J);
+        fetch_item<C>(bufB, tile_in, fl, j, J, last_off);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -457,9 +475,13 @@ __device__ __forceinline__ void dlt_item(const double *__restrict__ Plds, const 
 #pragma clang fp contract(off)   // (same reason as in pairwise_item)
     // world->pixel matrices P[C][12] come from LDS (broadcast reads), like the ray matrices of the pairwise
     // item: 96 doubles in scalar registers overflow the SGPR file and come back as v_readlane traffic
-    double Pp[12 * C];
+    // (five cameras and more: 60+ doubles of P beside the ring spilled; there a camera's matrix is read where it is used)
+    constexpr bool kHoist = C <= 4;
+    double Pp[kHoist ? 12 * C : 1];
+    if constexpr (kHoist) {
 #pragma unroll
-    for (int i = 0; i < 12 * C; i++) Pp[i] = Plds[i];
+        for (int i = 0; i < 12 * C; i++) Pp[i] = Plds[i];
+    }
     double A[4][4];
 #pragma unroll
     for (int i = 0; i < 4; i++)
@@ -471,7 +493,12 @@ __device__ __forceinline__ void dlt_item(const double *__restrict__ Plds, const 
     for (int c = 0; c < C; c++) {
         bool use = !((double)cur[c].s < prm.kthr);
         if (np_f) use &= np_f[c] > 0;
-        dlt_add_observation(A, Pp + 12 * c, (double)cur[c].u, (double)cur[c].v, use ? 1.0 : 0.0);
+        if constexpr (kHoist)
+            dlt_add_observation(A, Pp + 12 * c, (double)cur[c].u, (double)cur[c].v, use ? 1.0 : 0.0);
+        else {
+            __builtin_amdgcn_sched_barrier(0);   // a camera's twelve LDS reads stay with its observation (register budget)
+            dlt_add_observation(A, Plds + 12 * c, (double)cur[c].u, (double)cur[c].v, use ? 1.0 : 0.0);
+        }
         ssum += use ? (double)cur[c].s : 0.0;
         cnt += use ? 1 : 0;
     }
@@ -486,7 +513,7 @@ __device__ __forceinline__ void dlt_item(const double *__restrict__ Plds, const 
 }
 
 template <int C, int METHOD, typename TIn, typename TOut>
-__global__ __launch_bounds__(kBlock, kFastWaves) void k_fused_single(int64_t F, int J, int T, Rig rig,
+__global__ __launch_bounds__(kBlock, (FusedShape<C, METHOD, TIn>::kWaves)) void k_fused_single(int64_t F, int J, int T, Rig rig,
                                                          const TIn *__restrict__ kpts,
                                                          const int32_t *__restrict__ n_persons, Params prm,
                                                          int Pout, TOut *__restrict__ out4,
@@ -514,9 +541,11 @@ __global__ __launch_bounds__(kBlock, kFastWaves) void k_fused_single(int64_t F, 
     }
     const int dfl = kBlock / J, dj = kBlock - dfl * J;
     const int64_t ntiles = (F + T - 1) / T;
+    using Shape = FusedShape<C, METHOD, TIn>;
+    constexpr int kRing = Shape::kRing;
 
-    Kp3<TIn> bufA[C], bufB[C], bufC[C];
-    if (blockIdx.x < ntiles) prefetch_tile_head<C>(bufA, bufB, kp3, (int64_t)blockIdx.x, T, F, J, tid, dfl, dj);
+    Kp3<TIn> bufA[C], bufB[kRing >= 2 ? C : 1], bufC[kRing >= 3 ? C : 1];
+    if (blockIdx.x < ntiles) prefetch_tile_head<C, kRing>(bufA, bufB, kp3, (int64_t)blockIdx.x, T, F, J, tid, dfl, dj);
     for (int64_t tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
         const int64_t f0 = tile * T;
         const int nf = (int)((F - f0) < T ? (F - f0) : T);
@@ -545,9 +574,11 @@ __global__ __launch_bounds__(kBlock, kFastWaves) void k_fused_single(int64_t F, 
                 double ox, oy, oz, os;
                 bool bad;
                 if constexpr (METHOD == 0) {
+                    static_assert(C <= 4, "the pairwise item of k_fused_single keeps everything in registers: up to six pairs");
                     bad = pairwise_item<C>(rig, Mlds, buf, prm, ox, oy, oz, os);
                 } else {
                     bad = false;
+                    if constexpr (C >= 5) asm volatile("" ::: "memory");   // (P is re-read from LDS by every item: hoisted out of the loop it takes 12 C doubles)
                     dlt_item<C>(Mlds, buf, n_persons ? n_persons + (f0 + fl_) * C : nullptr, prm, ox, oy, oz, os);
                 }
                 if (j_ < kn) {
@@ -563,22 +594,41 @@ __global__ __launch_bounds__(kBlock, kFastWaves) void k_fused_single(int64_t F, 
             // item k of this lane is tid + k*kBlock -> (fl, j); two cursors walk the ring
             const int n_my = tid < nitems ? (nitems - tid + kBlock - 1) / kBlock : 0;
             int fs = tid / J, js = tid - fs * J;  // item being solved
-            int ff = fs, jf = js;                 // item being fetched: two ahead
+            int ff = fs, jf = js;                 // item being fetched: kRing - 1 ahead
             advance_item(ff, jf, dfl, dj, J);
-            advance_item(ff, jf, dfl, dj, J);
-            for (int k = 0; k < n_my; k += 3) {
-                fetch_item<C>(bufC, tile_in, ff, jf, J, last_off);
-                solve_store(bufA, fs, js);
-                advance_item(fs, js, dfl, dj, J);
+            if constexpr (kRing >= 3) {
                 advance_item(ff, jf, dfl, dj, J);
-                fetch_item<C>(bufA, tile_in, ff, jf, J, last_off);
-                if (k + 1 < n_my) solve_store(bufB, fs, js);
-                advance_item(fs, js, dfl, dj, J);
-                advance_item(ff, jf, dfl, dj, J);
-                fetch_item<C>(bufB, tile_in, ff, jf, J, last_off);
-                if (k + 2 < n_my) solve_store(bufC, fs, js);
-                advance_item(fs, js, dfl, dj, J);
-                advance_item(ff, jf, dfl, dj, J);
+                for (int k = 0; k < n_my; k += 3) {
+                    fetch_item<C>(bufC, tile_in, ff, jf, J, last_off);
+                    solve_store(bufA, fs, js);
+                    advance_item(fs, js, dfl, dj, J);
+                    advance_item(ff, jf, dfl, dj, J);
+                    fetch_item<C>(bufA, tile_in, ff, jf, J, last_off);
+                    if (k + 1 < n_my) solve_store(bufB, fs, js);
+                    advance_item(fs, js, dfl, dj, J);
+                    advance_item(ff, jf, dfl, dj, J);
+                    fetch_item<C>(bufB, tile_in, ff, jf, J, last_off);
+                    if (k + 2 < n_my) solve_store(bufC, fs, js);
+                    advance_item(fs, js, dfl, dj, J);
+                    advance_item(ff, jf, dfl, dj, J);
+                }
+            } else if constexpr (kRing == 1) {   // one buffer: the other waves of the SIMD cover the fetch
+                for (int k = 0; k < n_my; k++) {
+                    solve_store(bufA, fs, js);
+                    advance_item(fs, js, dfl, dj, J);
+                    fetch_item<C>(bufA, tile_in, fs, js, J, last_off);
+                }
+            } else {   // two buffers: the next item's keypoints fly under the current item
+                for (int k = 0; k < n_my; k += 2) {
+                    fetch_item<C>(bufB, tile_in, ff, jf, J, last_off);
+                    solve_store(bufA, fs, js);
+                    advance_item(fs, js, dfl, dj, J);
+                    advance_item(ff, jf, dfl, dj, J);
+                    fetch_item<C>(bufA, tile_in, ff, jf, J, last_off);
+                    if (k + 1 < n_my) solve_store(bufB, fs, js);
+                    advance_item(fs, js, dfl, dj, J);
+                    advance_item(ff, jf, dfl, dj, J);
+                }
             }
             // unused person slots are zero-filled here, NOT inside the item loop: a store loop with a
             // run-time trip count there makes the compiler's vmcnt bookkeeping give up and wait for
@@ -593,7 +643,7 @@ __global__ __launch_bounds__(kBlock, kFastWaves) void k_fused_single(int64_t F, 
             }
             // next tile of this workgroup: start its first two fetches now, they fly during the epilogue
             const int64_t nt = tile + gridDim.x;
-            if (nt < ntiles) prefetch_tile_head<C>(bufA, bufB, kp3, nt, T, F, J, tid, dfl, dj);  // wave-uniform
+            if (nt < ntiles) prefetch_tile_head<C, kRing>(bufA, bufB, kp3, nt, T, F, J, tid, dfl, dj);  // wave-uniform
         }
 
         // ---- single-cluster check (:116-130): candidate q >= 1 must have its centre joint within

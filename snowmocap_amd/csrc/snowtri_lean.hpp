@@ -27,6 +27,30 @@
 
 namespace snowtri {
 
+// Six cameras and more (15 / 21 / 28 pairs): the unrolled lean_item with its three keypoint buffers, 9 C matrix entries and
+// the pair offsets in scalar registers needs far more than 256 VGPRs (round-4 review: k_fused_lean<8> spilled 431 of them,
+// the cooperative kernel 355).  Those rigs run the SAME kernels on cluster_item (snowtri_item.hpp: constants read from LDS
+// where they are used, pairs in groups of four) with kLeanRolledRing keypoint buffers at kLeanRolledWaves waves per SIMD;
+// such an item is 800-1 500 VALU instructions for 72-96 bytes of keypoints: compute-bound, the SIMD's other waves cover a
+// fetch.  Per-frame check, mean and fall-back are unchanged.
+#ifndef SNOWTRI_LEAN_ROLLED_WAVES
+#define SNOWTRI_LEAN_ROLLED_WAVES 2
+#endif
+#ifndef SNOWTRI_LEAN_ROLLED_RING
+#define SNOWTRI_LEAN_ROLLED_RING 2
+#endif
+#ifndef SNOWTRI_LEAN_ROLLED_GROUP
+#define SNOWTRI_LEAN_ROLLED_GROUP 4
+#endif
+constexpr int kLeanRolledWaves = SNOWTRI_LEAN_ROLLED_WAVES, kLeanRolledRing = SNOWTRI_LEAN_ROLLED_RING;   // (A/B builds override them)
+constexpr int kLeanRolledGroup = SNOWTRI_LEAN_ROLLED_GROUP;   // pairs between two scheduling barriers of the item
+template <int C>
+struct LeanShape {
+    static constexpr bool kRolled = C >= 6;
+    static constexpr int kWaves = kRolled ? kLeanRolledWaves : kFastWaves;
+    static constexpr int kRing = kRolled ? kLeanRolledRing : 3;
+};
+
 constexpr int kLeanTw = 12;  // frames per wave tile (12 x 133 = 24.94 passes of 64 lanes; 10 would make the single-cluster check one pass of 60 lanes instead of two, measured: the same 348 instructions per item)
 constexpr int kLeanWaves = kBlock / 64;  // waves per workgroup
 constexpr int kLeanSlowShift = 4;        // slow-frame bit index = (tile ordinal of the workgroup << 4) | frame in tile
@@ -210,6 +234,23 @@ __device__ __forceinline__ bool lean_item(const double *__restrict__ Mlds,
     return !(sb < 1e300);
 }
 
+// The item of a rig: lean_item up to five cameras, cluster_item (float32 outputs: raw v_rsq_f64, the same contract) beyond.
+template <int C, typename TIn, int ND>
+__device__ __forceinline__ bool lean_solve(const double *__restrict__ Mlds, const double (&dS)[ND], const Kp3<TIn> (&cur)[C], float kthr_f32,
+                                           double kthr, double dthr2, float &ox, float &oy, float &oz, double &os) {
+    if constexpr (LeanShape<C>::kRolled) {
+        double x, y, z;
+        asm volatile("" ::: "memory");   // the rig constants are re-read from LDS by every item (hoisted out of the item loop they take hundreds of registers)
+        const bool bad = cluster_item<C, TIn, float, kLeanRolledGroup>(Mlds, cur, kthr_f32, kthr, dthr2, x, y, z, os);
+        ox = (float)x;
+        oy = (float)y;
+        oz = (float)z;
+        return bad;
+    } else {
+        return lean_item<C>(Mlds, dS, cur, kthr_f32, kthr, dthr2, ox, oy, oz, os);
+    }
+}
+
 // ---- per-frame steps shared by k_fused_lean and k_fused_lean_coop (ONE definition: both kernels give the same bits) ----
 // Single-cluster check (:116-130) for lane = (frame wl of the pass, pair qq), lane = wl NP + qq: the lane solves its pair
 // at the centre joint (midpoint only) and takes candidate 0's point from the frame's first lane of the same pass.
@@ -266,7 +307,7 @@ __device__ __forceinline__ void lean_tile_range(int64_t t, int base, int64_t rem
 // Grid: any number of workgroups; wave gw = 4 blockIdx.x + wave takes tiles gw, gw + 4 gridDim.x, ...
 // Dynamic LDS: lean_lds_bytes(C, JC, slow_words); slow_words >= ceil(tiles of one WORKGROUP * 16 / 32).
 template <int C, typename TIn, int JC>
-__global__ __launch_bounds__(kBlock, kFastWaves) void k_fused_lean(
+__global__ __launch_bounds__(kBlock, LeanShape<C>::kWaves) void k_fused_lean(
     int64_t F, int64_t ntiles, int tile_base, int64_t tile_rem, int slow_words, Rig rig, const TIn *__restrict__ kpts,
     const int32_t *__restrict__ n_persons, Params prm, float *__restrict__ out4, float *__restrict__ out_ps,
     int32_t *__restrict__ out_count, uint32_t *__restrict__ out_flags, char *scratch, size_t scratch_per_block) {
@@ -287,7 +328,9 @@ __global__ __launch_bounds__(kBlock, kFastWaves) void k_fused_lean(
     uint32_t *slowbits = reinterpret_cast<uint32_t *>(reinterpret_cast<float *>(table + kTable) + kLeanWaves * kItemsPad);
     const Kp3<TIn> *kp3 = reinterpret_cast<const Kp3<TIn> *>(kpts);
     const int64_t wstride = (int64_t)gridDim.x * kLeanWaves;
-    Kp3<TIn> bufA[C], bufB[C], bufC[C];
+    constexpr bool kRolled = LeanShape<C>::kRolled;
+    constexpr int kRing = LeanShape<C>::kRing;
+    Kp3<TIn> bufA[C], bufB[kRing >= 2 ? C : 1], bufC[kRing >= 3 ? C : 1];
 
     // Item i = lane + 64 k of a tile is joint i % JC of the tile's frame i / JC; its camera-c record sits at byte
     // (i + (i / JC) (C-1) JC + c JC) kRec of the tile.  The part that does not depend on c is the same for every tile:
@@ -307,9 +350,11 @@ __global__ __launch_bounds__(kBlock, kFastWaves) void k_fused_lean(
     const double cM = rig.M[tid < 9 * C ? tid : 0], cT = rig.t[tid < 3 * C ? tid : 0];
     const double cD = rig.pairc[tid < 3 * NP ? 6 * (tid / 3) + tid % 3 : 0];
     const int32_t cP = rig.pairs[tid < 2 * NP ? tid : 0];
-    double dS[3 * NP];  // per-pair d = t_s - t_m, wave-uniform -> scalar registers
+    double dS[kRolled ? 1 : 3 * NP];  // per-pair d = t_s - t_m, wave-uniform -> scalar registers (cluster_item reads them from LDS)
+    if constexpr (!kRolled) {
 #pragma unroll
-    for (int i = 0; i < 3 * NP; i++) dS[i] = rig.pairc[6 * (i / 3) + i % 3];
+        for (int i = 0; i < 3 * NP; i++) dS[i] = rig.pairc[6 * (i / 3) + i % 3];
+    }
     int64_t tile = (int64_t)blockIdx.x * kLeanWaves + wave;
     int64_t f0 = 0;
     int nf = 0;
@@ -317,7 +362,7 @@ __global__ __launch_bounds__(kBlock, kFastWaves) void k_fused_lean(
         lean_tile_range(tile, tile_base, tile_rem, f0, nf);
         const __amdgpu_buffer_rsrc_t rin = lean_rsrc(kp3 + f0 * (int64_t)(C * JC), (unsigned)(nf * C * JC) * kRec);
         fetch(bufA, rin, voff0);
-        fetch(bufB, rin, voff1);
+        if constexpr (kRing >= 3) fetch(bufB, rin, voff1);
     }
     // (the first keypoints are in flight while the constants are set up)
     for (unsigned i = (unsigned)tid; i < (unsigned)kTable; i += kBlock)
@@ -328,8 +373,10 @@ __global__ __launch_bounds__(kBlock, kFastWaves) void k_fused_lean(
     if (tid < 3 * NP) Mlds[12 * C + tid] = cD;
     int32_t *pairs_lds = reinterpret_cast<int32_t *>(Mlds + 12 * C + 3 * NP);
     if (tid < 2 * NP) pairs_lds[tid] = cP;
+    if constexpr (!kRolled) {
 #pragma unroll
-    for (int i = 0; i < 3 * NP; i++) dS[i] = uniform_f64(dS[i]);
+        for (int i = 0; i < 3 * NP; i++) dS[i] = uniform_f64(dS[i]);
+    }
     const float kthr_f32 = prm.kthr_f32;
     const double kthr = prm.kthr, dthr2 = prm.dthr2;
     const double ctol2_lo = prm.ctol < 0.0 ? -1.0 : prm.ctol * prm.ctol * (1.0 - 1e-12);   // single-cluster check, see there
@@ -361,7 +408,7 @@ __global__ __launch_bounds__(kBlock, kFastWaves) void k_fused_lean(
         auto solve_store = [&](const Kp3<TIn>(&buf)[C], unsigned out_off, float *stash_slot) {
             float ox, oy, oz;
             double os;
-            const bool bad = lean_item<C>(Mlds, dS, buf, kthr_f32, kthr, dthr2, ox, oy, oz, os);
+            const bool bad = lean_solve<C>(Mlds, dS, buf, kthr_f32, kthr, dthr2, ox, oy, oz, os);
             const float osf = (float)os;
             lean_u4 rec;
             rec.x = __float_as_uint(ox);
@@ -382,20 +429,40 @@ __global__ __launch_bounds__(kBlock, kFastWaves) void k_fused_lean(
         unsigned out_off = (unsigned)lane * 16u;           // 16 x (item being solved); the one being fetched is two passes ahead
         float *sp = stash + lane;                          // its stash slot
         const uint32_t *tp = table + lane;                 // its table entry
-        unsigned t0 = tp[128], t1 = tp[192], t2 = tp[256];  // (read one iteration ahead of their use)
-        for (int k = 0; k < npass; k += 3) {
-            fetch(bufC, rin, t0);
-            solve_store(bufA, out_off, sp);
-            fetch(bufA, rin, t1);
-            if (k + 1 < npass) solve_store(bufB, out_off + 1024u, sp + 64);
-            fetch(bufB, rin, t2);
-            if (k + 2 < npass) solve_store(bufC, out_off + 2048u, sp + 128);
-            tp += 192;
-            t0 = tp[128];
-            t1 = tp[192];
-            t2 = tp[256];
-            out_off += 3072u;
-            sp += 192;
+        if constexpr (kRing >= 3) {
+            unsigned t0 = tp[128], t1 = tp[192], t2 = tp[256];  // (read one iteration ahead of their use)
+            for (int k = 0; k < npass; k += 3) {
+                fetch(bufC, rin, t0);
+                solve_store(bufA, out_off, sp);
+                fetch(bufA, rin, t1);
+                if (k + 1 < npass) solve_store(bufB, out_off + 1024u, sp + 64);
+                fetch(bufB, rin, t2);
+                if (k + 2 < npass) solve_store(bufC, out_off + 2048u, sp + 128);
+                tp += 192;
+                t0 = tp[128];
+                t1 = tp[192];
+                t2 = tp[256];
+                out_off += 3072u;
+                sp += 192;
+            }
+        } else if constexpr (kRing == 2) {   // the next item's keypoints fly under the current item
+            for (int k = 0; k < npass; k += 2) {
+                fetch(bufB, rin, tp[64]);
+                solve_store(bufA, out_off, sp);
+                fetch(bufA, rin, tp[128]);
+                if (k + 1 < npass) solve_store(bufB, out_off + 1024u, sp + 64);
+                tp += 128;
+                out_off += 2048u;
+                sp += 128;
+            }
+        } else {                             // one buffer: the SIMD's other waves cover the fetch
+            for (int k = 0; k < npass; k++) {
+                solve_store(bufA, out_off, sp);
+                fetch(bufA, rin, tp[64]);
+                tp += 64;
+                out_off += 1024u;
+                sp += 64;
+            }
         }
         // this wave's next tile: its first two fetches fly during the epilogue
         const int64_t f0_cur = f0;
@@ -405,7 +472,7 @@ __global__ __launch_bounds__(kBlock, kFastWaves) void k_fused_lean(
             lean_tile_range(nt, tile_base, tile_rem, f0, nf);
             const __amdgpu_buffer_rsrc_t rnext = lean_rsrc(kp3 + f0 * (int64_t)(C * JC), (unsigned)(nf * C * JC) * kRec);
             fetch(bufA, rnext, voff0);
-            fetch(bufB, rnext, voff1);
+            if constexpr (kRing >= 3) fetch(bufB, rnext, voff1);
         }
 
         // ---- single-cluster check (:116-130): every candidate's centre joint within condense_distance_tol of
@@ -520,7 +587,7 @@ __host__ __device__ constexpr size_t lean_coop_lds_bytes(int C, int JC, int nf_m
 }
 
 template <int C, typename TIn, int JC>
-__global__ __launch_bounds__(kBlock, kFastWaves) void k_fused_lean_coop(
+__global__ __launch_bounds__(kBlock, LeanShape<C>::kWaves) void k_fused_lean_coop(
     int64_t F, int tile_base, int64_t tile_rem, int nf_max, Rig rig, const TIn *__restrict__ kpts, const int32_t *__restrict__ n_persons,
     Params prm, float *__restrict__ out4, float *__restrict__ out_ps, int32_t *__restrict__ out_count, uint32_t *__restrict__ out_flags,
     char *scratch, size_t scratch_per_block) {
@@ -538,7 +605,9 @@ __global__ __launch_bounds__(kBlock, kFastWaves) void k_fused_lean_coop(
     double *favg = reinterpret_cast<double *>(stash + items_pad);          // [kCoopMaxFrames] mean fused score of a frame
     uint32_t *slowbits = reinterpret_cast<uint32_t *>(favg + kCoopMaxFrames);   // one word: bit = frame of the tile
     const Kp3<TIn> *kp3 = reinterpret_cast<const Kp3<TIn> *>(kpts);
-    Kp3<TIn> bufA[C], bufB[C], bufC[C];
+    constexpr bool kRolled = LeanShape<C>::kRolled;
+    constexpr int kRing = LeanShape<C>::kRing;
+    Kp3<TIn> bufA[C], bufB[kRing >= 2 ? C : 1], bufC[kRing >= 3 ? C : 1];
 
 #ifdef SNOWTRI_LEAN_TRACE   // dev build: wall-clock stamps (100 MHz) of every wave at the phase boundaries, in the workgroup's scratch slab
     unsigned long long *trace = reinterpret_cast<unsigned long long *>(scratch + (size_t)blockIdx.x * scratch_per_block) + 8 * (threadIdx.x >> 6);
@@ -581,13 +650,15 @@ __global__ __launch_bounds__(kBlock, kFastWaves) void k_fused_lean_coop(
     const double cM = rig.M[tid < 9 * C ? tid : 0], cT = rig.t[tid < 3 * C ? tid : 0];
     const double cD = rig.pairc[tid < 3 * NP ? 6 * (tid / 3) + tid % 3 : 0];
     const int32_t cP = rig.pairs[tid < 2 * NP ? tid : 0];
-    double dS[3 * NP];
+    double dS[kRolled ? 1 : 3 * NP];
+    if constexpr (!kRolled) {
 #pragma unroll
-    for (int i = 0; i < 3 * NP; i++) dS[i] = rig.pairc[6 * (i / 3) + i % 3];
+        for (int i = 0; i < 3 * NP; i++) dS[i] = rig.pairc[6 * (i / 3) + i % 3];
+    }
     // the wave's first two items (offsets computed: the table is not there yet); a pass the wave does not own reads nothing
     constexpr unsigned kNoItem = 0x40000000u;   // beyond every descriptor (and no wrap-around with the camera offsets): the load returns zeros without touching memory
     fetch(bufA, npass > 0 ? item_offset(i0 + (unsigned)lane) : kNoItem);
-    fetch(bufB, npass > 1 ? item_offset(i0 + 64u + (unsigned)lane) : kNoItem);
+    if constexpr (kRing >= 3) fetch(bufB, npass > 1 ? item_offset(i0 + 64u + (unsigned)lane) : kNoItem);
     // centre-joint keypoints of the check pass this wave will run after the barrier (pass `pos`: frames 10 pos ...)
     constexpr int kCheckFrames = 64 / NP;
     const int ncheck = (nf + kCheckFrames - 1) / kCheckFrames;
@@ -600,8 +671,10 @@ __global__ __launch_bounds__(kBlock, kFastWaves) void k_fused_lean_coop(
     if (tid < 3 * C) Mlds[9 * C + tid] = cT;
     if (tid < 3 * NP) Mlds[12 * C + tid] = cD;
     if (tid < 2 * NP) pairs_lds[tid] = cP;
+    if constexpr (!kRolled) {
 #pragma unroll
-    for (int i = 0; i < 3 * NP; i++) dS[i] = uniform_f64(dS[i]);
+        for (int i = 0; i < 3 * NP; i++) dS[i] = uniform_f64(dS[i]);
+    }
     const float kthr_f32 = prm.kthr_f32;
     const double kthr = prm.kthr, dthr2 = prm.dthr2;
     const double ctol2_lo = prm.ctol < 0.0 ? -1.0 : prm.ctol * prm.ctol * (1.0 - 1e-12);
@@ -619,7 +692,7 @@ __global__ __launch_bounds__(kBlock, kFastWaves) void k_fused_lean_coop(
     auto solve_store = [&](const Kp3<TIn>(&buf)[C], unsigned out_off, float *stash_slot) {
         float ox, oy, oz;
         double os;
-        const bool bad = lean_item<C>(Mlds, dS, buf, kthr_f32, kthr, dthr2, ox, oy, oz, os);
+        const bool bad = lean_solve<C>(Mlds, dS, buf, kthr_f32, kthr, dthr2, ox, oy, oz, os);
         const float osf = (float)os;
         lean_u4 rec;
         rec.x = __float_as_uint(ox);
@@ -641,16 +714,36 @@ __global__ __launch_bounds__(kBlock, kFastWaves) void k_fused_lean_coop(
         unsigned out_off = (i0 + (unsigned)lane) * 16u;
         float *sp = stash + i0 + lane;
         const uint32_t *tp = table + i0 + lane;
-        for (int k = 0; k < npass; k += 3) {
-            fetch(bufC, k + 2 < npass ? tp[128] : kNoItem);
-            solve_store(bufA, out_off, sp);
-            fetch(bufA, k + 3 < npass ? tp[192] : kNoItem);
-            if (k + 1 < npass) solve_store(bufB, out_off + 1024u, sp + 64);
-            fetch(bufB, k + 4 < npass ? tp[256] : kNoItem);
-            if (k + 2 < npass) solve_store(bufC, out_off + 2048u, sp + 128);
-            tp += 192;
-            out_off += 3072u;
-            sp += 192;
+        if constexpr (kRing >= 3) {
+            for (int k = 0; k < npass; k += 3) {
+                fetch(bufC, k + 2 < npass ? tp[128] : kNoItem);
+                solve_store(bufA, out_off, sp);
+                fetch(bufA, k + 3 < npass ? tp[192] : kNoItem);
+                if (k + 1 < npass) solve_store(bufB, out_off + 1024u, sp + 64);
+                fetch(bufB, k + 4 < npass ? tp[256] : kNoItem);
+                if (k + 2 < npass) solve_store(bufC, out_off + 2048u, sp + 128);
+                tp += 192;
+                out_off += 3072u;
+                sp += 192;
+            }
+        } else if constexpr (kRing == 2) {
+            for (int k = 0; k < npass; k += 2) {
+                fetch(bufB, k + 1 < npass ? tp[64] : kNoItem);
+                solve_store(bufA, out_off, sp);
+                fetch(bufA, k + 2 < npass ? tp[128] : kNoItem);
+                if (k + 1 < npass) solve_store(bufB, out_off + 1024u, sp + 64);
+                tp += 128;
+                out_off += 2048u;
+                sp += 128;
+            }
+        } else {
+            for (int k = 0; k < npass; k++) {
+                solve_store(bufA, out_off, sp);
+                fetch(bufA, k + 1 < npass ? tp[64] : kNoItem);
+                tp += 64;
+                out_off += 1024u;
+                sp += 64;
+            }
         }
     }
     SNOWTRI_STAMP(3);

@@ -114,7 +114,10 @@ __device__ __forceinline__ SkewOut skew_ray_solve(const Vec3 &hm, const Vec3 &hs
     SkewOut o;
     o.dist = sqrt(dot3(df, df));
     o.W = {0.5 * (Wm.x + Ws.x), 0.5 * (Wm.y + Ws.y), 0.5 * (Wm.z + Ws.z)};
-    o.singular = (det == 0.0);
+    // exactly singular as the reference's LU sees it for equal rays (H^T H = [[a, a], [a, a]]: u22 = a - a) and as the
+    // oracle defines it (a c - b b == 0 in separately rounded products).  The FUSED determinant above is the rounding
+    // error of b b when a c == b b mathematically, i.e. usually not zero: it serves the accuracy of S0 / S1, not this test.
+    o.singular = (a * c == b * b);
     return o;
 }
 
@@ -195,7 +198,7 @@ __device__ __forceinline__ PairSolve pair_solve_fast(const RayRec &rm, const Ray
     PairSolve o;
     o.d2 = d2;
     o.score_base = idist * 0.001;
-    o.singular = (det == 0.0);
+    o.singular = (rm.a * rs.a == b * b);   // (see skew_ray_solve)
     if (kNeedW)
         o.sw = {fma(-rs.x, S1, fma(rm.x, S0, tsum.x)), fma(-rs.y, S1, fma(rm.y, S0, tsum.y)),
                 fma(-rs.z, S1, fma(rm.z, S0, tsum.z))};

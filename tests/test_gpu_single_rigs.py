@@ -1,0 +1,194 @@
+"""ONE detection per camera on rigs of five and more cameras (round 5): the lean kernels on cluster_item (6-8 cameras,
+float32 outputs, J = keypoint_num = 133) and, for every other shape, the streaming route WITHOUT its candidate pass
+(`sumless`: k_associate -> k_cluster_fuse / _wide / k_cluster_members -> k_person_scores).  All against the CPU oracle
+through the C ABI; the route is read back from snowtri_last_kernel_names.
+
+Tolerances as tests/test_gpu_parity.py: float32 outputs <= 2e-6 m (+ one float32 ulp of the value), scores <= 3e-7
+relative; float64 outputs <= 1e-8 m, scores <= 1e-9 relative (+ the conditioning term of assert_scores_close).
+"""
+import numpy as np
+import pytest
+
+from conftest import assert_scores_close, assert_xyz_close
+
+pytestmark = pytest.mark.gpu
+J = 133
+
+
+@pytest.fixture(scope="module")
+def api():
+    import snowmocap_amd as sm
+    from snowmocap_amd import _lib
+    assert _lib.lib().snowtri_device_count() > 0, "these tests need the HIP device"
+    return sm
+
+
+def _run(api, K, R, t, prm, kp, npers, out_dtype, pout=1, env=None, monkeypatch=None):
+    for k, v in (env or {}).items():
+        monkeypatch.setenv(k, v)
+    bt = api.BatchTriangulator(K, R, t, prm, pout_max=pout, out_dtype=out_dtype)
+    out = bt.run_host(kp, npers)
+    out["names"] = bt.ctx.last_kernel_names()
+    bt.close()
+    for k in (env or {}):
+        monkeypatch.delenv(k)
+    return out
+
+
+def _compare(out, ref, F, out_dtype, kn, msg):
+    f32 = np.dtype(out_dtype) == np.float32
+    assert np.array_equal(out["count"], ref["count"]), msg      # (the count is the frame's persons, also beyond the slots: SNOWTRI_FLAG_OVERFLOW)
+    for f in range(F):
+        m = min(int(ref["count"][f]), out["xyzs"].shape[1])
+        assert not out["xyzs"][f, m:].any(), f"{msg} frame {f}: slots beyond the count must be zero-filled"
+        if not m:
+            continue
+        assert_scores_close(out["xyzs"][f, :m, :, 3], ref["kscore"][f, :m], rtol=3e-7 if f32 else 1e-9, what=f"{msg} kscore frame {f}")
+        assert_xyz_close(out["xyzs"][f, :m, :, :3], ref["xyz"][f, :m], 2e-6 if f32 else 1e-8, score_ref=ref["kscore"][f, :m],
+                         what=f"{msg} xyz frame {f}")
+        assert_scores_close(out["pscore"][f, :m], ref["pscore"][f, :m], rtol=3e-7 if f32 else 1e-9, nterms=kn, what=f"{msg} pscore frame {f}")
+
+
+@pytest.mark.parametrize("C", [6, 7, 8])
+@pytest.mark.parametrize("F", [3, 700, 20000])
+def test_rolled_lean_kernels(api, C, F):
+    """6-8 cameras on the production shape: k_fused_lean_coop (small launches) / k_fused_lean (large) on cluster_item; frames
+    that break the speculation (a camera without detection, a camera far off, everything gated) take the in-launch fall-back."""
+    from snowmocap_amd import synth, _lib
+    from oracle import oracle as orc
+    rng = np.random.default_rng(900 + 10 * C + F % 7)
+    K, R, t = synth.ring_rig(C)
+    gen = min(F, 160)
+    X = synth.make_people(rng, gen, 1)
+    kp, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=1.0, score_range=(2.0, 8.0))
+    kp, npers = kp.copy(), npers.copy()
+    if gen >= 40:
+        npers[5, 1] = 0
+        kp[11, 2, 0, :, :2] += 400.0
+        kp[17, :, 0, :, 2] = 0.0
+        kp[23, 3, 0, 20:40, :2] += 250.0
+    reps = (F + gen - 1) // gen
+    kpf, npf = np.tile(kp, (reps, 1, 1, 1, 1))[:F], np.tile(npers, (reps, 1))[:F]
+    prm = dict(synth.default_thresholds(), condense_distance_tol=2.0)
+    out = _run(api, K, R, t, prm, kpf, npf, np.float32)
+    assert out["names"].startswith(f"k_fused_lean_coop<{C},float,133>" if F <= 16384 else f"k_fused_lean<{C},float,133>"), out["names"]
+    ref = orc.triangulate_condense_batch(K, R, t, kp, npers, orc.make_params(**prm), 4)
+    sel = np.arange(min(F, gen))
+    sub = {k: (v[sel] if isinstance(v, np.ndarray) else v) for k, v in out.items()}
+    fast = (sub["flags"] & _lib.FLAG_FASTPATH) != 0
+    if gen >= 40:
+        assert not fast[5] and not fast[11] and fast[23]
+        assert fast.mean() > 0.9      # (opposite cameras of a ring see nearly parallel rays: a few frames take the fall-back)
+    # the one output slot holds the oracle's first person (a broken frame may resolve to several)
+    _compare(sub, ref, len(sel), np.float32, J, f"C={C} F={F}")
+    # the tail of a tiled batch equals its head (bit for bit: the same frames)
+    if F > gen:
+        tail = slice((reps - 1) * gen, F)
+        n = F - (reps - 1) * gen
+        assert np.array_equal(out["xyzs"][tail], out["xyzs"][:n], equal_nan=True)
+        assert np.array_equal(out["pscore"][tail], out["pscore"][:n], equal_nan=True)
+
+
+@pytest.mark.parametrize("C", [5, 6, 8, 12, 16])
+@pytest.mark.parametrize("out_dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("kn", [133, 30])
+def test_sumless_route_against_oracle(api, C, out_dtype, kn):
+    """Shapes the lean kernels do not take (float64 outputs, keypoint_num < J, two slots): no candidate pass, the mean scores
+    from the fused joints; frames with a missing detection (member-list clusters), a far-off camera (two clusters) and
+    gated confidences included."""
+    from snowmocap_amd import synth
+    from oracle import oracle as orc
+    if np.dtype(out_dtype) == np.float32 and kn == 133 and C <= 8:
+        pout = 2          # (one slot would be the lean shape)
+    else:
+        pout = 1 + (C % 2)
+    rng = np.random.default_rng(77 * C + kn)
+    K, R, t = synth.ring_rig(C)
+    F = 60
+    X = synth.make_people(rng, F, 1)
+    kp, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=1.0, score_range=(2.0, 8.0))
+    kp, npers = kp.copy(), npers.copy()
+    npers[3, 1] = 0
+    npers[9, C - 1] = 0
+    kp[14, 2, 0, :, :2] += 400.0
+    kp[20, :, 0, :, 2] = 0.0
+    kp[26, 0, 0, 7, 0] = np.nan
+    prm = dict(synth.default_thresholds(), condense_distance_tol=0.5, keypoint_num=kn, center_point_index=min(18, kn - 1))
+    ref = orc.triangulate_condense_batch(K, R, t, kp, npers, orc.make_params(**prm), pout)
+    out = _run(api, K, R, t, prm, kp, npers, out_dtype, pout=pout)
+    assert "k_candidate_sums" not in out["names"] and out["names"].startswith("k_associate<"), out["names"]
+    assert ("k_cluster_fuse<%d," % C if C <= 8 else "k_cluster_fuse_wide<") in out["names"], out["names"]
+    _compare(out, ref, F, out_dtype, kn, f"C={C} {np.dtype(out_dtype).name} kn={kn}")
+
+
+@pytest.mark.parametrize("C", [5, 8, 12])
+def test_sumless_equals_candidate_pass(api, C, monkeypatch):
+    """SNOWTRI_SUMLESS_MODE=0 keeps the candidate pass: the same counts, the same joints bit for bit (the same fusion
+    kernels on the same descriptors), the persons' mean scores within the float32 contract (candidate sums vs fused joints)."""
+    from snowmocap_amd import synth
+    rng = np.random.default_rng(5 + C)
+    K, R, t = synth.ring_rig(C)
+    F = 300
+    X = synth.make_people(rng, F, 1)
+    kp, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=1.0, score_range=(2.0, 8.0))
+    npers = npers.copy()
+    npers[7, 0] = 0
+    prm = dict(synth.default_thresholds(), condense_distance_tol=0.5)
+    a = _run(api, K, R, t, prm, kp, npers, np.float32, pout=2)
+    b = _run(api, K, R, t, prm, kp, npers, np.float32, pout=2, env={"SNOWTRI_SUMLESS_MODE": "0"}, monkeypatch=monkeypatch)
+    assert "k_candidate_sums" in b["names"] and "k_candidate_sums" not in a["names"]
+    assert np.array_equal(a["count"], b["count"])
+    assert np.array_equal(a["xyzs"], b["xyzs"], equal_nan=True)
+    np.testing.assert_allclose(a["pscore"], b["pscore"], rtol=3e-7)
+
+
+def test_sumless_flags_a_singular_pair(api):
+    """Two cameras with parallel rays at one joint: the reference's np.linalg.inv raises (triangulation.py:26); the fused
+    entry reports SNOWTRI_FLAG_SINGULAR for that frame on the route without a candidate pass as well."""
+    from snowmocap_amd import synth, _lib
+    C = 6
+    rng = np.random.default_rng(1)
+    K = np.tile(np.eye(3), (C, 1, 1))                      # normalised image coordinates: pixel (0, 0) is the ray (0, 0, 1) exactly
+    R = np.tile(np.eye(3), (C, 1, 1))                      # identical orientation: equal pixels = parallel rays
+    t = rng.uniform(-2, 2, size=(C, 3))
+    t[:, 2] = 0.0
+    F = 8
+    X = rng.uniform(-0.5, 0.5, size=(F, 1, J, 3)) + np.array([0, 0, 5.0])
+    kp, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=1e-3, score_range=(3.5, 8.0))
+    kp = kp.copy()
+    kp[4, :2, 0, 40, :2] = 0.0                              # frame 4, joint 40: cameras 0 and 1 both look straight down +z
+                                                            # (H^T H = [[1, 1], [1, 1]]: exactly singular, as tests/golden g4 "parallel_rays")
+    prm = dict(synth.default_thresholds())
+    bt = api.BatchTriangulator(K, R, t, prm, pout_max=1, out_dtype=np.float64)
+    out = bt.run_host(kp, npers)
+    names = bt.ctx.last_kernel_names()
+    bt.close()
+    assert names.startswith("k_associate<"), names
+    sing = (out["flags"] & _lib.FLAG_SINGULAR) != 0
+    assert sing[4] and sing.sum() == 1
+    assert out["status"] == _lib.ERR_SINGULAR
+
+
+@pytest.mark.parametrize("C", [5, 6, 8])
+@pytest.mark.parametrize("in_dtype", [np.float32, np.float64])
+def test_dlt_wide_rigs(api, C, in_dtype):
+    """DLT on 5-8 cameras (k_fused_single<C,1>: the world->pixel matrices read per camera, one or two keypoint buffers) vs oracle/dlt.py."""
+    from snowmocap_amd import synth, _lib
+    from oracle import dlt as odlt
+    rng = np.random.default_rng(60 + C)
+    K, R, t = synth.ring_rig(C)
+    F = 50
+    X = synth.make_people(rng, F, 1)
+    kp, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=0.5, score_range=(2.0, 8.0), dtype=in_dtype)
+    prm = dict(synth.default_thresholds())
+    bt = api.BatchTriangulator(K, R, t, prm, pout_max=1, out_dtype=np.float64, method=_lib.DLT)
+    out = bt.run_host(kp, npers)
+    names = bt.ctx.last_kernel_names()
+    bt.close()
+    assert names.startswith(f"k_fused_single<{C},1,"), names
+    want, wps, wcnt = odlt.dlt_batch(K, R, t, kp, prm["keypoint_score_threshold"], prm["keypoint_num"])
+    assert (out["count"] == 1).all()
+    err = np.abs(out["xyzs"][..., :3] - want[..., :3]).max()
+    assert err < 1e-9, err
+    np.testing.assert_allclose(out["xyzs"][..., 3], want[..., 3], rtol=1e-6)
+    np.testing.assert_allclose(out["pscore"], wps, rtol=1e-6)
