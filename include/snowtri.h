@@ -109,6 +109,8 @@ int snowtri_ctx_synchronize(snowtri_ctx *ctx);
  *   SNOWTRI_GENERAL_MODE=1|2        multi-person batches on the spill kernel / on k_frame_recompute
  *   SNOWTRI_LEAN_MODE=0             float32-output single-detection batches stay on k_fused_single
  *   SNOWTRI_LEAN_COOP=0             small launches stay on k_fused_lean
+ *   SNOWTRI_SUMLESS_MODE=0          single-detection batches on the streaming route keep its candidate pass
+ *   SNOWTRI_SUMS_RAYS=1             rigs of 32 rays per frame (8 x 4, 16 x 2, 4 x 8): candidate pass with one lane per ray
  *   SNOWTRI_HANDOVER_MODE=0|2       0: the whole multi-person path inside k_frame_recompute; 2: its descriptors to k_cluster_fuse
  *   SNOWTRI_HANDOVER_SEG_FRAMES=n   frames per segment of the streaming multi-person route
  *   SNOWTRI_SPLIT_SEGMENTS=1|n      1: one multi-person call stays on the caller's stream; n >= 2: at least n segments alternating

@@ -316,7 +316,7 @@ struct snowtri_ctx {
     int lean_mode = 1;           // SNOWTRI_LEAN_MODE: 0 keeps float32-output batches on k_fused_single
     int lean_coop = 1;           // SNOWTRI_LEAN_COOP: 0 keeps small launches on k_fused_lean
     int sumless_mode = 1;        // SNOWTRI_SUMLESS_MODE: 0 keeps the candidate pass for single-detection batches on the streaming route
-    int sums_rays = 1;           // SNOWTRI_SUMS_RAYS: 0 keeps rigs of 32 rays per frame on the tile kernel (k_candidate_sums)
+    int sums_rays = 0;           // SNOWTRI_SUMS_RAYS: 1 sends rigs of 32 rays per frame to k_candidate_sums_rays (measured slower: snowtri_sums_rays.hpp)
     int handover_mode = 1;       // SNOWTRI_HANDOVER_MODE: 1 streaming association (k_candidate_sums / k_associate / k_cluster_fuse), 2 hand-over
                                  // from inside k_frame_recompute, 0 the whole multi-person path inside k_frame_recompute
     int handover_seg_frames = 0; // SNOWTRI_HANDOVER_SEG_FRAMES: short segments of the streaming route

@@ -16,6 +16,12 @@
 // do not see).  A frame in which a camera lists fewer than P persons takes a plain loop over the candidate slots instead.
 // Same outputs, hand-shake (ticket counter, exact list, flags) and LDS record layout as k_candidate_sums.
 //
+// MEASURED (round 5, EXPERIMENTS.md) and NOT the default: 8 x 4 x 10 000 frames 831 us against the tile kernel's 710 us.  The
+// kernel issues 14 % fewer VALU instructions per frame (74 472 against 86 671 per wave) but keeps the SIMDs busy 54 % of the
+// time against 77 %: a lane solves two joints between two barriers, each behind 75 LDS reads, and at three waves per SIMD
+// (168 registers: 28 of sums, 24 of pair offsets, one set of partner records) nothing hides them; a second register set
+// for the next tile's records spills inside the loop.  SNOWTRI_SUMS_RAYS=1 selects it (tests/test_gpu_handover.py).
+//
 // Fill: thread t owns joint t % 16 of rows t / 16 and t / 16 + 16 of every chunk of 16 joints: no index arithmetic per
 // record, and the 16 lanes of an LDS write group stay inside one row (consecutive joints = consecutive banks): the write
 // groups of k_candidate_sums straddled a row every 20 joints, the source of its bank-conflict cycles (0.30 of the active LDS
@@ -174,25 +180,28 @@ __global__ __launch_bounds__(kRaysThreads, kRaysWaves) void k_candidate_sums_ray
                     const bool okm = !below_kthr(sm, prm);
 #pragma unroll
                     for (int ti = 0; ti < NT; ti++) {
-                        __builtin_amdgcn_sched_barrier(0);   // a tile's LDS reads and temporaries stay inside the tile (register budget: three waves per SIMD)
                         const Vec3 d = t_d[ti];
                         const double cx = fma(d.y, a.z, -(d.z * a.y)), cy = fma(d.z, a.x, -(d.x * a.z)), cz = fma(d.x, a.y, -(d.y * a.x));
-                        constexpr int kStep = 1;
-                        const int nu = (kHalf && ti == H) ? PH : P;
+                        RayRec b[P];
+                        TIn ss[P];
+#pragma unroll
+                        for (int u = 0; u < P; u++)
+                            if (u < ((kHalf && ti == H) ? PH : P)) {   // (compile-time after unrolling)
+                                const char *pb = pj + t_ob[ti] + kP1Rec * ((kHalf && ti == H) ? 2 * u : u);
+                                b[u] = p1_load_ray(pb);
+                                ss[u] = p1_load_score<TIn>(pb);
+                            }
 #pragma unroll
                         for (int u = 0; u < P; u++) {
-                            if (u < nu) {   // (compile-time after unrolling)
-                                const char *pb = pj + t_ob[ti] + kP1Rec * ((kHalf && ti == H) ? 2 * u : kStep * u);
-                                const RayRec b = p1_load_ray(pb);
-                                const TIn ss = p1_load_score<TIn>(pb);
-                                const double bq = fma(a.z, b.z, fma(a.y, b.y, a.x * b.x));
-                                const double det = fma(a.a, b.a, -(bq * bq));
-                                const double dn = fma(cz, b.z, fma(cy, b.y, cx * b.x));
+                            if (u < ((kHalf && ti == H) ? PH : P)) {
+                                const double bq = fma(a.z, b[u].z, fma(a.y, b[u].y, a.x * b[u].x));
+                                const double det = fma(a.a, b[u].a, -(bq * bq));
+                                const double dn = fma(cz, b[u].z, fma(cy, b[u].y, cx * b[u].x));
                                 const double dn2 = dn * dn;
-                                const bool kp_ = okm && !below_kthr(ss, prm) && !(dn2 > det * prm.dthr2);   // :73-74
+                                const bool kp_ = okm && !below_kthr(ss[u], prm) && !(dn2 > det * prm.dthr2);   // :73-74
                                 // (float32 confidences add in float32, first camera's + second camera's: the sum commutes)
                                 const int ai = (ti < H ? ti * P : H * P) + u;
-                                tot[ai] = fma(gated_sum_sel(sm, ss, kp_), det * __builtin_amdgcn_rsq(dn2 * det), tot[ai]);
+                                tot[ai] = fma(gated_sum_sel(sm, ss[u], kp_), det * __builtin_amdgcn_rsq(dn2 * det), tot[ai]);
                             }
                         }
                     }

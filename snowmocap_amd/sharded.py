@@ -39,6 +39,40 @@ def gather_track(local, F_total, group=None):
     return full[:F_total]
 
 
+_HOST_STAGE = {}   # (world, nbytes, dtype) -> pinned (send, recv) pair of the host-staged collective
+
+
+def all_gather_flat(recv, send, group=None):
+    """recv[world * n] <- send[n] of every rank, in rank order: ONE all_gather_into_tensor.
+
+    CUDA tensors on a group whose backend has no device path (gloo: several ranks sharing ONE GPU -- RCCL refuses two ranks
+    on a device -- or a debugging run) are STAGED through page-locked host buffers on the current stream: copy out,
+    synchronise that stream, the host collective, copy back.  The host blocks for the exchange, the stream order around it
+    is the one of the device path, so the side-stream / event / slot-reuse logic of gather_track_chunked and the device-side
+    combine of smooth_track_sharded run unchanged under genuine multi-process interleaving (tests/test_gpu_multiproc.py)."""
+    import torch
+    import torch.distributed as dist
+    if send.is_cuda and dist.get_backend(group) == "gloo":
+        world = dist.get_world_size(group)
+        key = (world, send.numel(), send.dtype)
+        if key not in _HOST_STAGE:
+            _HOST_STAGE[key] = (torch.empty(send.numel(), dtype=send.dtype).pin_memory(),
+                                torch.empty(world * send.numel(), dtype=send.dtype).pin_memory())
+        hs, hr = _HOST_STAGE[key][:2]
+        if len(_HOST_STAGE[key]) > 2:
+            _HOST_STAGE[key][2].synchronize()  # the previous copy back out of `hr` (possibly on another stream) has finished
+        st = torch.cuda.current_stream(send.device)
+        hs.copy_(send.reshape(-1), non_blocking=True)
+        st.synchronize()
+        dist.all_gather_into_tensor(hr, hs, group=group)
+        recv.reshape(-1).copy_(hr, non_blocking=True)
+        back = torch.cuda.Event()
+        back.record(st)
+        _HOST_STAGE[key] = (hs, hr, back)
+        return
+    dist.all_gather_into_tensor(recv.view(-1), send.contiguous().view(-1), group=group)   # (flat on both sides: every backend takes that)
+
+
 def auto_chunks(frames_per_rank, min_piece_frames=32768, max_chunks=8):
     """Pieces a rank's shard is cut into for the overlapped gather: as many as give pieces of >= min_piece_frames frames
     (a piece costs a handful of launches and one collective, ~100 us of host time: measured 0.15 ms per 10 000-frame
@@ -73,7 +107,9 @@ def gather_track_chunked(compute_block, n_local, F_total, regions, chunks=4, gro
     per = (F_total + world - 1) // world
     dev = torch.device(device) if device is not None else torch.device("cpu")
     if F_total <= 0:                                       # an empty track: nothing to compute, nothing to gather
-        return {name: torch.empty((0,) + tuple(tail), dtype=dt, device=dev) for name, (tail, dt) in regions.items()}
+        out = {name: torch.empty((0,) + tuple(tail), dtype=dt, device=dev) for name, (tail, dt) in regions.items()}
+        out["rank_status"] = torch.zeros(world, dtype=torch.int32, device=dev)
+        return out
     # A rank whose block does not fit (n_local > per) must not simply raise: the other ranks would enter the collectives
     # below and wait for it forever.  It takes part with an EMPTY block and a status word of 1 in every piece it sends
     # (the last 16 bytes of a piece's buffer), and raises after the last collective; the other ranks see the word in
@@ -132,7 +168,7 @@ def gather_track_chunked(compute_block, n_local, F_total, regions, chunks=4, gro
         width = min(cs, per - i * cs)                    # frame slots of this piece that exist in the block
 
         def gather_and_unpack():
-            dist.all_gather_into_tensor(recv[slot], send[slot], group=group)
+            all_gather_flat(recv[slot], send[slot], group=group)
             got = recv[slot].view(world, total)
             torch.maximum(status, got[:, status_off:status_off + 4].view(torch.int32).view(world), out=status)
             for name, (o, nb) in offs.items():
@@ -168,21 +204,175 @@ def gather_track_chunked(compute_block, n_local, F_total, regions, chunks=4, gro
     return out
 
 
+def gather_track_compact(compute_block, n_local, F_total, kn, pout_max, chunks=4, group=None, device=None):
+    """Frame-sharded results -> the whole track on every rank as PACKED persons ("or gather compacted persons +
+    counts"): per piece ONE all-gather of (count, flags) -- 8 bytes per frame -- then ONE of the persons the frames hold,
+    packed by prefix sum into a buffer sized by the largest per-rank total of the piece.  The padded gather moves
+    Pout_max slots per frame whatever they hold (BASELINE configs[4] at Pout_max 32 for 8 persons: 851 MB per rank for
+    213 MB of persons).
+
+    compute_block(lo, hi, views) as in gather_track_chunked, views = xyzs [n, Pout_max, kn, 4] float32, pscore [n, Pout_max]
+    float32, count [n] int32, flags [n] int32 (the kernels' padded outputs of the piece; they never leave the rank).
+    The host reads the piece's per-rank totals (one small copy, after the piece's kernels): piece i + 1 is therefore queued
+    BEFORE the gather of piece i, so the device computes it under that exchange.
+
+    Returns persons [N, kn, 4] float32 and pscore [N] float32 (rows in gathered order: piece-major, then rank, then frame,
+    then slot), offsets [F_total] int64 (row of a frame's first person), stored [F_total] int32 = min(count, Pout_max),
+    count [F_total] int32 (the frames' true person counts), flags [F_total] int32, rank_status [world] int32, and
+    gather_bytes (int: what this rank received).  compact_to_padded() rebuilds the padded track."""
+    import contextlib
+    import torch
+    import torch.distributed as dist
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    per = (F_total + world - 1) // world
+    dev = torch.device(device) if device is not None else torch.device("cpu")
+    P, kn = int(pout_max), int(kn)
+    i32, f32 = torch.int32, torch.float32
+    if F_total <= 0:
+        return dict(persons=torch.empty((0, kn, 4), dtype=f32, device=dev), pscore=torch.empty(0, dtype=f32, device=dev),
+                    offsets=torch.empty(0, dtype=torch.int64, device=dev), stored=torch.empty(0, dtype=i32, device=dev),
+                    count=torch.empty(0, dtype=i32, device=dev), flags=torch.empty(0, dtype=i32, device=dev),
+                    rank_status=torch.zeros(world, dtype=i32, device=dev), gather_bytes=0)
+    bad_local = not 0 <= n_local <= per
+    n_claimed = n_local
+    if bad_local:
+        n_local = 0
+    chunks = max(1, min(int(chunks), max(1, per)))
+    cs = (per + chunks - 1) // chunks
+    npieces = (per + cs - 1) // cs
+    on_gpu = dev.type == "cuda"
+    slots = [dict(xyzs=torch.zeros((cs, P, kn, 4), dtype=f32, device=dev), pscore=torch.zeros((cs, P), dtype=f32, device=dev),
+                  count=torch.zeros(cs, dtype=i32, device=dev), flags=torch.zeros(cs, dtype=i32, device=dev)) for _ in range(2)]
+    count_full = torch.zeros(world * per, dtype=i32, device=dev)
+    flags_full = torch.zeros(world * per, dtype=i32, device=dev)
+    stored_full = torch.zeros(world * per, dtype=i32, device=dev)
+    offsets_full = torch.zeros(world * per, dtype=torch.int64, device=dev)
+    status = torch.zeros(world, dtype=i32, device=dev)
+    pieces_x, pieces_s = [], []
+    rows_so_far = 0
+    gather_bytes = 0
+    if on_gpu:
+        main = torch.cuda.current_stream(dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(main)
+        ready, packed = [None, None], [None, None]
+    arangeP = torch.arange(P, device=dev, dtype=i32)
+
+    def compute(i):
+        slot = i & 1
+        lo, hi = min(n_local, i * cs), min(n_local, (i + 1) * cs)
+        if on_gpu and packed[slot] is not None:
+            main.wait_event(packed[slot])                 # the pack that last read this slot is done
+        if hi - lo < cs:
+            for t in slots[slot].values():
+                t.zero_()                                 # short or empty piece: counts of 0 behind the block
+        if hi > lo:
+            compute_block(lo, hi, {k: v[: hi - lo] for k, v in slots[slot].items()})
+        if on_gpu:
+            ready[slot] = torch.cuda.Event()
+            ready[slot].record(main)
+
+    compute(0)
+    for i in range(npieces):
+        slot = i & 1
+        if i + 1 < npieces:
+            compute(i + 1)                                # queued before the host waits for piece i's totals
+        width = min(cs, per - i * cs)
+        if on_gpu:
+            side.wait_event(ready[slot])
+        with (torch.cuda.stream(side) if on_gpu else contextlib.nullcontext()):
+            S = slots[slot]
+            meta = torch.empty(2 * cs + 4, dtype=i32, device=dev)
+            meta[:cs] = S["count"]
+            meta[cs:2 * cs] = S["flags"]
+            meta[2 * cs:] = 1 if bad_local else 0
+            meta_all = torch.empty(world * (2 * cs + 4), dtype=i32, device=dev)
+            all_gather_flat(meta_all, meta, group=group)
+            meta_all = meta_all.view(world, 2 * cs + 4)
+            cnt_all = meta_all[:, :cs]
+            sto_all = cnt_all.clamp(0, P)
+            torch.maximum(status, meta_all[:, 2 * cs], out=status)
+            totals = sto_all.sum(dim=1).cpu()             # the one host read of the piece (synchronises the side stream)
+            maxtot = int(totals.max())
+            gather_bytes += world * (2 * cs + 4) * 4
+            # pack this rank's persons: row = exclusive prefix sum of the stored counts + slot
+            mask = arangeP[None, :] < sto_all[rank][:, None]            # [cs, P]
+            send = torch.zeros((maxtot, kn * 4 + 1), dtype=f32, device=dev)
+            tot_r = int(totals[rank])
+            if tot_r:
+                send[:tot_r, : kn * 4] = S["xyzs"][mask].reshape(tot_r, kn * 4)
+                send[:tot_r, kn * 4] = S["pscore"][mask]
+            if on_gpu:
+                packed[slot] = torch.cuda.Event()
+                packed[slot].record(side)
+            if maxtot:
+                recv = torch.empty((world, maxtot, kn * 4 + 1), dtype=f32, device=dev)
+                all_gather_flat(recv, send, group=group)
+                gather_bytes += world * maxtot * (kn * 4 + 1) * 4
+                rowmask = torch.arange(maxtot, device=dev)[None, :] < totals.to(dev)[:, None]   # [world, maxtot]
+                rows = recv[rowmask]                                     # rank-major, then frame, then slot
+                pieces_x.append(rows[:, : kn * 4].reshape(-1, kn, 4))
+                pieces_s.append(rows[:, kn * 4].clone())
+            # per-frame bookkeeping of the piece: frame (r, j) of the piece is frame r * per + i * cs + j of the track
+            flat_sto = sto_all[:, :width].reshape(-1).to(torch.int64)    # rank-major like the rows ...
+            full_sto = sto_all.reshape(-1).to(torch.int64)               # ... but the rows also count the slots behind `width`
+            excl = torch.cumsum(full_sto, 0) - full_sto                  # (those hold no persons: count 0)
+            idx = (torch.arange(world, device=dev)[:, None] * per + i * cs + torch.arange(width, device=dev)[None, :]).reshape(-1)
+            offsets_full[idx] = rows_so_far + excl.view(world, cs)[:, :width].reshape(-1)
+            stored_full[idx] = flat_sto.to(i32)
+            count_full[idx] = cnt_all[:, :width].reshape(-1)
+            flags_full[idx] = meta_all[:, cs:cs + width].reshape(-1)
+            rows_so_far += int(totals.sum())
+    if on_gpu:
+        main.wait_stream(side)
+    if bad_local:
+        raise ValueError(f"gather_track_compact: a rank holds {n_claimed} frames but contiguous blocks of "
+                         f"ceil({F_total} / {world}) = {per} frames are what is gathered (use shard_bounds)")
+    if not on_gpu and bool(status.any()):
+        bad = [q for q in range(world) if int(status[q])]
+        raise ValueError(f"gather_track_compact: rank(s) {bad} hold more frames than their contiguous block of "
+                         f"ceil({F_total} / {world}) = {per} (use shard_bounds); their blocks were gathered as empty")
+    persons = torch.cat(pieces_x) if pieces_x else torch.empty((0, kn, 4), dtype=f32, device=dev)
+    pscore = torch.cat(pieces_s) if pieces_s else torch.empty(0, dtype=f32, device=dev)
+    return dict(persons=persons, pscore=pscore, offsets=offsets_full[:F_total], stored=stored_full[:F_total],
+                count=count_full[:F_total], flags=flags_full[:F_total], rank_status=status, gather_bytes=gather_bytes)
+
+
+def compact_to_padded(out, pout_max):
+    """The padded track {xyzs [F, Pout_max, kn, 4], pscore [F, Pout_max]} of a gather_track_compact result (zeros in the unused
+    slots, as the kernels write them)."""
+    import torch
+    persons, F = out["persons"], int(out["offsets"].shape[0])
+    kn, dev = int(persons.shape[1]), persons.device
+    xyzs = torch.zeros((F, pout_max, kn, 4), dtype=persons.dtype, device=dev)
+    ps = torch.zeros((F, pout_max), dtype=persons.dtype, device=dev)
+    slot = torch.arange(pout_max, device=dev)[None, :]
+    mask = slot < out["stored"][:, None]
+    rows = (out["offsets"][:, None] + slot)[mask]
+    xyzs[mask] = persons[rows]
+    ps[mask] = out["pscore"][rows]
+    return dict(xyzs=xyzs, pscore=ps)
+
+
 class ShardedTriangulator:
     """One instance per rank (one process per GPU).  `run(kpts_local, F_total)` triangulates this rank's frame block
     on its GPU, piece by piece, and returns the gathered track: the all-gather of piece i (joints, person scores,
     counts and flags in one buffer, one collective) overlaps the kernel of piece i + 1."""
 
-    def __init__(self, K, R, t, params, pout_max=1, device=0, group=None, chunks="auto", reuse_buffers=False):
+    def __init__(self, K, R, t, params, pout_max=1, device=0, group=None, chunks="auto", reuse_buffers=False, compact=False):
         """chunks: pieces per shard, or "auto" (auto_chunks: pieces of >= 32 768 frames, at most 8).
         reuse_buffers: keep the gathered tensors, the send / receive slots and the side stream between calls (no
-        allocation in steady state); the track returned by one run() is then overwritten by the next."""
+        allocation in steady state); the track returned by one run() is then overwritten by the next.
+        compact: gather the PERSONS, not the padded slots (gather_track_compact): per piece one all-gather of the counts
+        (4 B per frame), then one of the persons packed by prefix sum -- the padded [Pout_max, kn, 4] block of a frame with
+        8 persons in 32 slots is four times what its persons take ("or gather compacted persons + counts")."""
         import numpy as np
         from .batch import BatchTriangulator
         self.bt = BatchTriangulator(K, R, t, params, pout_max=pout_max, out_dtype=np.float32, device=device)
         self.group = group
         self.chunks = chunks
         self.device = device
+        self.compact = bool(compact)
         self._ws = {} if reuse_buffers else None
 
     def regions(self):
@@ -191,9 +381,22 @@ class ShardedTriangulator:
         return {"xyzs": ((P, kn, 4), torch.float32), "pscore": ((P,), torch.float32),
                 "count": ((), torch.int32), "flags": ((), torch.int32)}
 
-    def run(self, kpts_local, F_total, n_persons_local=None, gather=True, chunks=None):
+    def verify(self):
+        """Reads the status words of the last gathered run (one small device-to-host copy: synchronises) and raises if a
+        rank's block was refused -- its frames were gathered as zeros (gather_track_chunked).  run(strict=True) calls it."""
+        st = getattr(self, "last_status", None)
+        if st is not None and bool(st.any().item()):
+            bad = [q for q in range(int(st.numel())) if int(st[q])]
+            raise ValueError(f"ShardedTriangulator: rank(s) {bad} held more frames than their contiguous block (use shard_bounds); "
+                             f"their frames were gathered as zeros")
+
+    def run(self, kpts_local, F_total, n_persons_local=None, gather=True, chunks=None, strict=False):
+        """strict: check the ranks' status words before returning (a host synchronisation; the default leaves them in
+        out["rank_status"] / self.last_status for verify() at the caller's next synchronisation point)."""
         if not gather:
             return self.bt.run_torch(kpts_local, n_persons_local)
+        if self.compact:
+            return self._run_compact(kpts_local, F_total, n_persons_local, chunks, strict)
 
         def compute_block(lo, hi, views):
             out = {k: v[: hi - lo] for k, v in views.items()}
@@ -205,9 +408,40 @@ class ShardedTriangulator:
             world = dist.get_world_size(self.group)
             chunks = auto_chunks((F_total + world - 1) // world)
         self.last_chunks = int(chunks)
-        return gather_track_chunked(compute_block, int(kpts_local.shape[0]), F_total, self.regions(),
-                                    chunks=int(chunks), group=self.group,
-                                    device=kpts_local.device, workspace=self._ws)
+        out = gather_track_chunked(compute_block, int(kpts_local.shape[0]), F_total, self.regions(),
+                                   chunks=int(chunks), group=self.group,
+                                   device=kpts_local.device, workspace=self._ws)
+        self.last_status = out["rank_status"]
+        self.last_gather_bytes = self._gather_bytes_padded(F_total)
+        if strict:
+            self.verify()
+        return out
+
+    def _run_compact(self, kpts_local, F_total, n_persons_local, chunks, strict):
+        def compute_block(lo, hi, views):
+            self.bt.run_torch(kpts_local[lo:hi], None if n_persons_local is None else n_persons_local[lo:hi], out=views)
+
+        import torch.distributed as dist
+        chunks = self.chunks if chunks is None else chunks
+        if chunks == "auto":
+            world = dist.get_world_size(self.group)
+            chunks = auto_chunks((F_total + world - 1) // world)
+        self.last_chunks = int(chunks)
+        out = gather_track_compact(compute_block, int(kpts_local.shape[0]), F_total, self.bt.params.keypoint_num, self.bt.pout_max,
+                                   chunks=int(chunks), group=self.group, device=kpts_local.device)
+        self.last_status = out["rank_status"]
+        self.last_gather_bytes = out["gather_bytes"]
+        if strict:
+            self.verify()
+        return out
+
+    def _gather_bytes_padded(self, F_total):
+        """bytes ONE rank receives in the padded gather of a whole track (what xGMI moves per rank)"""
+        import torch.distributed as dist
+        world = dist.get_world_size(self.group)
+        per = (F_total + world - 1) // world
+        kn, P = self.bt.params.keypoint_num, self.bt.pout_max
+        return world * per * (P * kn * 16 + P * 4 + 8)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -286,7 +520,7 @@ def smooth_exchange(x_local, local_fn, combine_fn, fix_fn, group=None, first=Non
         payload[2 * n:3 * n] = x_local[0].reshape(-1)
         payload[3 * n:4 * n] = x_local[-1].reshape(-1)
     flat = torch.empty(world * (4 * n + 1), dtype=torch.float64, device=x_local.device)
-    dist.all_gather_into_tensor(flat, payload, group=group)             # the one exchange: 4n+1 doubles per rank
+    all_gather_flat(flat, payload, group=group)                         # the one exchange: 4n+1 doubles per rank
     allp = flat.view(world, 4 * n + 1)
     if T == 0:
         return y

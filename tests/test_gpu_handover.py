@@ -473,6 +473,10 @@ def test_frames_whose_member_lists_do_not_fit_the_staging_stay_in_phase3(api, mo
     (8, 4, 40, {"SNOWTRI_SUMS_THREADS": "1024", "SNOWTRI_SUMS_LDS_KB": "160"}),      # the whole frame in one chunk: no second buffer used
     (6, 3, 33, {"SNOWTRI_SUMS_THREADS": "512"}),                                     # odd person count: one candidate per lane
     (8, 4, 133, {"SNOWTRI_SPLIT_SEGMENTS": "1"}),                                    # the whole call on the caller's stream
+    (8, 4, 133, {"SNOWTRI_SUMS_RAYS": "1"}),                                         # k_candidate_sums_rays: one lane per ray and joint sub-range
+    (8, 4, 21, {"SNOWTRI_SUMS_RAYS": "1"}),                                          # ... two chunks, the second of five joints
+    (16, 2, 133, {"SNOWTRI_SUMS_RAYS": "1"}),                                        # ... 15 candidates per lane, seven full partners + a half
+    (4, 8, 57, {"SNOWTRI_SUMS_RAYS": "1"}),                                          # ... one full partner + a half of four persons
 ])
 def test_candidate_sums_launch_shapes_against_oracle(api, C, P, J, knobs, monkeypatch):
     """k_candidate_sums picks its workgroup shape from the rig (256 threads x 3 per CU ... 1024 x 1), keeps a tile's sums in
@@ -499,6 +503,7 @@ def test_candidate_sums_launch_shapes_against_oracle(api, C, P, J, knobs, monkey
     for k in knobs:
         monkeypatch.delenv(k)
     msg = f"C={C} P={P} J={J} {knobs}"
+    assert ("k_candidate_sums_rays<" in out["kernels"]) == ("SNOWTRI_SUMS_RAYS" in knobs), out["kernels"]
     _check(out, ref, pout, J, msg)
     _same(out, base, msg)
     assert sum(out["handed"]) == sum(base["handed"]) == int(np.minimum(ref["count"], pout).sum()), (out["handed"], base["handed"])

@@ -1,0 +1,112 @@
+"""The sharded path with the REAL kernels and more than one rank, on the one GPU a build box has (round-4 review, item 3).
+
+RCCL refuses two ranks on one device, so the ranks share cuda:0 and the collectives of the group go through gloo, staged
+through page-locked host buffers on the stream they were queued on (sharded.all_gather_flat).  Everything else is the
+product path: every rank computes its frame block with ShardedTriangulator on the GPU, the gather of a piece runs on the
+side stream under the kernels of the next piece (events, two slots, slot reuse), smooth_track_sharded filters a block
+with the device-side combine between its all-gather and its fix -- now under genuine multi-process interleaving on the
+device.  Each rank compares the gathered track with ITS OWN unsharded launch of the whole batch: bit for bit.
+
+world_size 2 and 4; BASELINE configs[1]-shaped (4 x 1) and configs[2]-shaped (8 x 4, the streaming multi-person route)
+batches; uneven blocks and empty trailing blocks; padded and compact gathers.  (e) of SURVEY 8 stays "unmeasured on
+hardware" for more than one GPU: this covers the logic, not xGMI.
+"""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def _worker(rank, world, port, case, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import torch
+    import torch.distributed as dist
+    from snowmocap_amd import synth
+    from snowmocap_amd.batch import BatchTriangulator
+    from snowmocap_amd.sharded import ShardedTriangulator, shard_bounds, smooth_track_sharded, compact_to_padded
+    import snowmocap_amd as sm
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    ok, notes = True, []
+
+    def expect(cond, what):
+        nonlocal ok
+        if not cond:
+            ok = False
+            notes.append(what)
+
+    cfg, F, pout, chunks = case
+    gen = min(F, 400)
+    wl = synth.config_workload(cfg, gen, seed=17)
+    K, R, t = wl["rig"]
+    reps = (F + gen - 1) // gen
+    kp = torch.from_numpy(wl["kpts"]).to(dev).repeat(reps, 1, 1, 1, 1)[:F].contiguous()
+    npers = torch.from_numpy(wl["n_persons"]).to(dev).repeat(reps, 1)[:F].contiguous()
+    # the unsharded launch of the whole batch on this rank's context
+    bt = BatchTriangulator(K, R, t, wl["params"], pout_max=pout, out_dtype=np.float32)
+    full = bt.run_torch(kp, npers)
+    torch.cuda.synchronize(dev)
+    full = {k: v.clone() for k, v in full.items()}
+    bt.close()
+    lo, hi, per = shard_bounds(F, world, rank)
+    for compact in (False, True):
+        st = ShardedTriangulator(K, R, t, wl["params"], pout_max=pout, device=0, chunks=chunks, reuse_buffers=not compact, compact=compact)
+        for rep in range(2):       # twice: the second run reuses the workspace (slots, side stream) of the first
+            out = st.run(kp[lo:hi], F, npers[lo:hi], strict=True)
+            torch.cuda.synchronize(dev)
+            if compact:
+                pad = compact_to_padded(out, pout)
+                expect(torch.equal(pad["xyzs"].view(torch.int32), full["xyzs"].view(torch.int32)), f"compact xyzs rep {rep}")
+                expect(torch.equal(pad["pscore"].view(torch.int32), full["pscore"].view(torch.int32)), f"compact pscore rep {rep}")
+                expect(int(out["persons"].shape[0]) == int(full["count"].clamp(0, pout).sum()), "compact person rows")
+            else:
+                expect(torch.equal(out["xyzs"].view(torch.int32), full["xyzs"].view(torch.int32)), f"xyzs rep {rep}")
+                expect(torch.equal(out["pscore"].view(torch.int32), full["pscore"].view(torch.int32)), f"pscore rep {rep}")
+            expect(torch.equal(out["count"], full["count"]), f"count compact={compact} rep {rep}")
+            expect(torch.equal(out["flags"], full["flags"]), f"flags compact={compact} rep {rep}")
+            expect(not bool(out["rank_status"].any()), "rank_status")
+        if not compact:
+            padded_bytes = st.last_gather_bytes
+        else:
+            if pout >= 6:      # (slots the frames do not fill: 8 x 4 resolves to ~5 persons)
+                expect(st.last_gather_bytes < padded_bytes, f"compact gather {st.last_gather_bytes} B vs padded {padded_bytes} B")
+        st.bt.close()
+    # row N1 on the sharded track: the block of this rank filtered with the carry exchange == the whole track filtered at once
+    count1 = bool((full["count"] >= 1).all())
+    track = full["xyzs"][:, 0, :, :3].to(torch.float64).contiguous()          # first person of every frame [F, kn, 3]
+    want = torch.from_numpy(sm.smooth_track(track.cpu().numpy()[:, None], f=2.5, z=0.75, r=0.5, delta_time=1 / 30))[:, 0].to(dev)
+    got = smooth_track_sharded(track[lo:hi].contiguous(), f=2.5, z=0.75, r=0.5, delta_time=1 / 30, F_total=F)
+    torch.cuda.synchronize(dev)
+    if hi > lo:
+        err = float((got - want[lo:hi]).abs().max())
+        expect(err < 1e-10 or not count1, f"sharded smoothing differs by {err}")
+    np.save(os.path.join(tmp, f"ok{rank}.npy"), np.array([ok]))
+    if notes:
+        with open(os.path.join(tmp, f"notes{rank}.txt"), "w") as fh:
+            fh.write("\n".join(notes))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+@pytest.mark.parametrize("case", [
+    (2, 1003, 1, 3),      # 4 x 1: blocks of 502 / 251 frames, the last one short; three pieces per block
+    (2, 5, 1, 2),         # five frames: with four ranks the blocks are 2 / 2 / 1 / 0 -- an EMPTY trailing block
+    (3, 601, 6, 2),       # 8 x 4 through the streaming route, ragged person counts, six slots
+    (3, 3, 16, 1),        # three frames of 8 x 4 over four ranks: one frame each, one rank empty
+], ids=["cfg2-1003", "cfg2-5", "cfg3-601", "cfg3-3"])
+def test_sharded_path_with_real_kernels_on_several_ranks(tmp_path, world, case):
+    import torch.multiprocessing as mp
+    port = 24000 + (os.getpid() * 13 + world * 101 + case[1]) % 4000
+    mp.spawn(_worker, args=(world, port, case, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        note = tmp_path / f"notes{r}.txt"
+        assert np.load(tmp_path / f"ok{r}.npy").all(), f"rank {r}: " + (note.read_text() if note.exists() else "?")

@@ -131,6 +131,58 @@ def test_one_rank_with_an_oversized_block_fails_everywhere_without_a_hang(tmp_pa
     assert all(np.load(tmp_path / f"ok{r}.npy").all() for r in range(WORLD))
 
 
+def _compact_worker(rank, port, F, chunks, P, tmp):
+    _init(rank, port)
+    from snowmocap_amd.sharded import gather_track_compact, compact_to_padded
+    kn = 3
+    lo0, hi0, per = shard_bounds(F, WORLD, rank)
+
+    def persons_of(g):                     # ragged person counts per GLOBAL frame, some beyond the slots (overflow frames)
+        return (g * 7 + g // 3) % (P + 2)
+
+    def compute_block(lo, hi, views):      # stand-in for the kernels: padded outputs, zeros in the unused slots
+        g = torch.arange(lo0 + lo, lo0 + hi)
+        cnt = persons_of(g)
+        views["count"][: hi - lo] = cnt.to(torch.int32)
+        views["flags"][: hi - lo] = (g % 3).to(torch.int32)
+        x = g.to(torch.float32).view(-1, 1, 1, 1) * 100 + torch.arange(P, dtype=torch.float32).view(1, P, 1, 1) * 10 \
+            + torch.arange(kn, dtype=torch.float32).view(1, 1, kn, 1) + torch.tensor([0.0, 0.25, 0.5, 0.75]).view(1, 1, 1, 4)
+        used = torch.arange(P).view(1, P) < cnt.view(-1, 1)
+        views["xyzs"][: hi - lo] = x * used.view(-1, P, 1, 1)
+        views["pscore"][: hi - lo] = (g.view(-1, 1) + 0.5 * torch.arange(P).view(1, P)).to(torch.float32) * used
+
+    out = gather_track_compact(compute_block, hi0 - lo0, F, kn, P, chunks=chunks)
+    g = torch.arange(F)
+    cnt = persons_of(g)
+    sto = cnt.clamp(max=P)
+    ok = torch.equal(out["count"], cnt.to(torch.int32)) and torch.equal(out["stored"], sto.to(torch.int32))
+    ok = ok and torch.equal(out["flags"], (g % 3).to(torch.int32)) and not bool(out["rank_status"].any())
+    ok = ok and int(out["persons"].shape[0]) == int(sto.sum()) and tuple(out["persons"].shape[1:]) == (kn, 4)
+    pad = compact_to_padded(out, P)
+    used = torch.arange(P).view(1, P) < cnt.view(-1, 1)
+    want = (g.to(torch.float32).view(-1, 1, 1, 1) * 100 + torch.arange(P, dtype=torch.float32).view(1, P, 1, 1) * 10
+            + torch.arange(kn, dtype=torch.float32).view(1, 1, kn, 1) + torch.tensor([0.0, 0.25, 0.5, 0.75]).view(1, 1, 1, 4)) * used.view(-1, P, 1, 1)
+    ok = ok and torch.equal(pad["xyzs"], want)
+    ok = ok and torch.equal(pad["pscore"], (g.view(-1, 1) + 0.5 * torch.arange(P).view(1, P)).to(torch.float32) * used)
+    # what this rank received: the persons + 8 bytes per frame slot, not Pout_max slots per frame
+    padded_bytes = WORLD * per * (P * kn * 16 + P * 4 + 8)
+    np.save(os.path.join(tmp, f"ok{rank}.npy"), np.array([ok, out["gather_bytes"], padded_bytes, int(sto.sum())]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("F,chunks,P", [(61, 3, 4), (9, 2, 2), (1, 4, 3), (1000, 2, 32), (40, 1, 8)])
+def test_eight_rank_compact_gather_of_ragged_person_counts(tmp_path, F, chunks, P):
+    """gather_track_compact ("or gather compacted persons + counts"): per piece the counts, then the persons packed
+    by prefix sum; ragged counts incl. frames without persons and frames beyond the slots, uneven and empty trailing blocks.
+    The padded track rebuilt from it equals the padded gather; the bytes received follow the persons, not the slots."""
+    mp.spawn(_compact_worker, args=(_port(F + P), F, chunks, P, str(tmp_path)), nprocs=WORLD, join=True)
+    res = [np.load(tmp_path / f"ok{r}.npy") for r in range(WORLD)]
+    assert all(r[0] for r in res), res
+    if F == 1000:      # 32 slots for ~15 persons per frame (uniform 0..33 clipped): well under half the padded bytes
+        assert all(r[1] < 0.75 * r[2] for r in res), res
+
+
 # ---------------------------------------------------------------------------------- sharded smoothing, 8 shards
 def _coeffs(f, z, r, dt):
     pi = np.pi
