@@ -4,10 +4,10 @@
     -> Blender control points (N2) -> per-bone smoothing (N2) -> the reference's JSON track
 
 One call per recording instead of one Python iteration per frame.  The per-frame protocol of the reference
-identifies persons by list index and lets the list length vary from frame to frame; a track needs a fixed set of
-persons, so `run` requires every frame to resolve to exactly `n_persons_out` persons (the shipped configuration,
-condense_distance_tol = 10 m, always yields one) and raises otherwise.  PyTorch is used for device memory and the
-stream only.
+identifies persons by list index and lets the list length vary from frame to frame: its filter banks are those of
+frame 0, later frames are zip-truncated against them (triangulation.py:169-171, blender.py:152-166).  `run` follows
+that: n_persons_out is the number of SLOTS, frame f carries min(count[f], count[0]) persons (fixture G9).  PyTorch is
+used for device memory and the stream only.
 """
 from __future__ import annotations
 
@@ -38,10 +38,19 @@ class TrackPipeline:
     def close(self):
         self.bt.close()
 
-    def run(self, kpts, n_persons=None, check=True):
+    def run(self, kpts, n_persons=None, check=True, ragged="reference"):
         """kpts [F, C, Pmax, J, 3] (NumPy or CUDA tensor; raw-frame pixels if D was given) ->
         dict of CUDA tensors: xyzs [F, P, kn, 4] (triangulated), smoothed [F, P, kn, 4], points [F, P, 24, 4],
-        valid [F, P, 24], points_smoothed [F, P, 24, 4], count [F], flags [F]."""
+        valid [F, P, 24], points_smoothed [F, P, 24, 4], count [F], flags [F], tracked [F] (P = n_persons_out slots).
+
+        Person counts that vary from frame to frame follow the reference (ragged="reference"): its filter banks are those of
+        frame 0 and `zip` matches a frame's persons to them BY LIST INDEX (triangulation.py:169-171, blender.py:152-166), so
+        frame f carries tracked[f] = min(count[f], count[0]) persons, the persons behind that are dropped, and a bank whose
+        person is missing in a frame is not stepped in that frame (its time stands still).  Per slot i this is the plain
+        filter over the frames with tracked > i: those are gathered, filtered by the same kernels and scattered back;
+        slots at or behind tracked[f] hold zeros.  Frame 0 must fit the slots (count[0] <= n_persons_out).
+        ragged="refuse": raise unless every frame resolves to exactly n_persons_out persons (round 4's behaviour).
+        check=False skips the host read of counts and flags and treats every slot of every frame as tracked."""
         import torch
         dev = torch.device("cuda", self.device)
         if not torch.is_tensor(kpts):
@@ -52,47 +61,89 @@ class TrackPipeline:
         L, h = _lib.lib(), self.bt.ctx.handle
         st = ct.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         tri = self.bt.run_torch(kpts, n_persons)
+        tracked = None                                   # None: every slot of every frame
         if check:
             cnt = tri["count"].cpu().numpy()
             flg = tri["flags"].cpu().numpy()
             if (flg & _lib.FLAG_SINGULAR).any():    # the reference's np.linalg.inv raises (triangulation.py:26)
                 raise np.linalg.LinAlgError(f"Singular matrix (frame {int(np.argmax((flg & _lib.FLAG_SINGULAR) != 0))})")
             if not (cnt == self.P).all():
-                bad = int(np.argmax(cnt != self.P))
-                raise ValueError(f"frame {bad} resolved to {int(cnt[bad])} persons, the track is built for {self.P}")
+                if ragged == "refuse":
+                    bad = int(np.argmax(cnt != self.P))
+                    raise ValueError(f"frame {bad} resolved to {int(cnt[bad])} persons, the track is built for {self.P}")
+                if F and int(cnt[0]) > self.P:
+                    raise ValueError(f"frame 0 resolved to {int(cnt[0])} persons, the track has {self.P} slots (n_persons_out)")
+                tracked = np.minimum(cnt, int(cnt[0]) if F else 0).astype(np.int32)
         xyzs = tri["xyzs"]
-        n = self.P * self.kn * 4
-        sm = torch.empty_like(xyzs)
         th = self.th
-        _lib.check(L.snowtri_smooth_track(h, F, n, ct.c_void_p(xyzs.data_ptr()), float(th["smooth_f"]),
-                                          float(th["smooth_z"]), float(th["smooth_r"]), float(th["smooth_delta_time"]),
-                                          ct.c_void_p(sm.data_ptr()), _lib.DEVICE, st), "snowtri_smooth_track")
-        sm[..., 3] = xyzs[..., 3]                      # only the points are filtered (triangulation.py:169-184)
+        fzrd = (float(th["smooth_f"]), float(th["smooth_z"]), float(th["smooth_r"]), float(th["smooth_delta_time"]))
         pts = torch.empty((F, self.P, 24, 4), dtype=torch.float64, device=dev)
         val = torch.empty((F, self.P, 24), dtype=torch.uint8, device=dev)
-        _lib.check(L.snowtri_blender_points(h, F * self.P, self.kn, ct.c_void_p(sm.data_ptr()), _lib.F64,
-                                            ct.c_void_p(pts.data_ptr()), ct.c_void_p(val.data_ptr()), _lib.DEVICE, st),
-                   "snowtri_blender_points")
-        pts_s = torch.empty_like(pts)
-        _lib.check(L.snowtri_blender_smooth(h, F, self.P, ct.c_void_p(pts.data_ptr()), ct.c_void_p(val.data_ptr()),
-                                            _lib.ptr(self.fzr), float(th["smooth_delta_time"]),
-                                            ct.c_void_p(pts_s.data_ptr()), _lib.DEVICE, st), "snowtri_blender_smooth")
+
+        def blender_points(x, n, p_out, v_out):
+            _lib.check(L.snowtri_blender_points(h, n, self.kn, ct.c_void_p(x.data_ptr()), _lib.F64, ct.c_void_p(p_out.data_ptr()),
+                                                ct.c_void_p(v_out.data_ptr()), _lib.DEVICE, st), "snowtri_blender_points")
+
+        if tracked is None:
+            n = self.P * self.kn * 4
+            sm = torch.empty_like(xyzs)
+            _lib.check(L.snowtri_smooth_track(h, F, n, ct.c_void_p(xyzs.data_ptr()), *fzrd, ct.c_void_p(sm.data_ptr()), _lib.DEVICE, st),
+                       "snowtri_smooth_track")
+            sm[..., 3] = xyzs[..., 3]                      # only the points are filtered (triangulation.py:169-184)
+            blender_points(sm, F * self.P, pts, val)
+            pts_s = torch.empty_like(pts)
+            _lib.check(L.snowtri_blender_smooth(h, F, self.P, ct.c_void_p(pts.data_ptr()), ct.c_void_p(val.data_ptr()),
+                                                _lib.ptr(self.fzr), fzrd[3], ct.c_void_p(pts_s.data_ptr()), _lib.DEVICE, st),
+                       "snowtri_blender_smooth")
+            trk = torch.full((F,), self.P, dtype=torch.int32, device=dev)
+        else:
+            # slot by slot over the frames that carry it (frame 0 among them: it seeds the slot's filters)
+            trk = torch.from_numpy(tracked).to(dev)
+            sm = torch.zeros_like(xyzs)
+            pts.zero_()
+            val.zero_()
+            pts_s = torch.zeros_like(pts)
+            for i in range(int(tracked[0]) if F else 0):
+                idx = torch.nonzero(trk > i).view(-1)
+                T = int(idx.numel())
+                xi = xyzs[idx, i].contiguous()                                  # [T, kn, 4]
+                si = torch.empty_like(xi)
+                _lib.check(L.snowtri_smooth_track(h, T, self.kn * 4, ct.c_void_p(xi.data_ptr()), *fzrd, ct.c_void_p(si.data_ptr()),
+                                                  _lib.DEVICE, st), "snowtri_smooth_track")
+                si[..., 3] = xi[..., 3]
+                pi = torch.empty((T, 1, 24, 4), dtype=torch.float64, device=dev)
+                vi = torch.empty((T, 1, 24), dtype=torch.uint8, device=dev)
+                blender_points(si, T, pi, vi)
+                qi = torch.empty_like(pi)
+                _lib.check(L.snowtri_blender_smooth(h, T, 1, ct.c_void_p(pi.data_ptr()), ct.c_void_p(vi.data_ptr()),
+                                                    _lib.ptr(self.fzr), fzrd[3], ct.c_void_p(qi.data_ptr()), _lib.DEVICE, st),
+                           "snowtri_blender_smooth")
+                sm[idx, i] = si
+                pts[idx, i] = pi[:, 0]
+                val[idx, i] = vi[:, 0]
+                pts_s[idx, i] = qi[:, 0]
         return dict(xyzs=xyzs, smoothed=sm, points=pts, valid=val, points_smoothed=pts_s, count=tri["count"],
-                    flags=tri["flags"])
+                    flags=tri["flags"], tracked=trk)
 
     @staticmethod
-    def to_blender_result(points_smoothed, valid, armature_profile=None):
+    def to_blender_result(points_smoothed, valid, armature_profile=None, tracked=None):
         """Device (or NumPy) track -> the list the reference dumps with save_blender_result (blender.py:180-187):
-        one {'armature': [per person {name: list}], 'score': [per person {name: 0/1}]} per frame."""
+        one {'armature': [per person {name: list}], 'score': [per person {name: 0/1}]} per frame.  tracked [F]: persons
+        frame f carries (run()'s "tracked"; default: every slot)."""
         pts = points_smoothed.cpu().numpy() if hasattr(points_smoothed, "cpu") else np.asarray(points_smoothed)
         val = valid.cpu().numpy() if hasattr(valid, "cpu") else np.asarray(valid)
-        if not val[..., 1].all():
+        if tracked is None:
+            trk = np.full(pts.shape[0], pts.shape[1], dtype=np.int64)
+        else:
+            trk = (tracked.cpu().numpy() if hasattr(tracked, "cpu") else np.asarray(tracked)).astype(np.int64)
+        live = np.arange(pts.shape[1])[None, :] < trk[:, None]
+        if not val[..., 1][live].all():
             raise np.linalg.LinAlgError("SVD did not converge")     # the reference raises on a NaN pelvis matrix
         names = list(armature_profile.keys()) if armature_profile is not None else list(CONTROL_POINT_NAMES)
         slot = {n: i for i, n in enumerate(CONTROL_POINT_NAMES)}
         frames = []
         for f in range(pts.shape[0]):
             frames.append({
-                "armature": [{n: pts[f, p, slot[n], :_WIDTH[n]].tolist() for n in names} for p in range(pts.shape[1])],
-                "score": [{n: int(val[f, p, slot[n]]) for n in names} for p in range(pts.shape[1])]})
+                "armature": [{n: pts[f, p, slot[n], :_WIDTH[n]].tolist() for n in names} for p in range(int(trk[f]))],
+                "score": [{n: int(val[f, p, slot[n]]) for n in names} for p in range(int(trk[f]))]})
         return frames

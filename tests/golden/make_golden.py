@@ -426,9 +426,65 @@ def g8_blender_track():
     print("g8_blender_track.npz", os.path.getsize(path) / 1e6, "MB")
 
 
+def g9_pipeline_multi_person():
+    """main.py:47-106 on a BASELINE configs[2]-shaped sequence (ring rig of 8 cameras, 4 persons walking, the configs[2]
+    thresholds) whose person count VARIES: a person leaves for two frames (nobody lists it), a frame is empty, opposing
+    cameras produce ghost persons in some frames.  The reference matches persons by list index against the filter banks of
+    frame 0 (zip, triangulation.py:169-171, blender.py:152-166): pins the batched N1 / N2 with ragged counts."""
+    rng = np.random.default_rng(9)
+    K, R, t = synth.ring_rig(8)
+    th = dict(synth.default_thresholds(), average_score_threshold=1.0, condense_distance_tol=0.3)
+    with open(os.path.join(REF, "configs/blender_armature_profile.json")) as fh:
+        arm = json.load(fh)
+    with open(os.path.join(REF, "configs/blender_smooth_profile.json")) as fh:
+        smo = json.load(fh)
+    F, P = 14, 4
+    base = synth.make_people(rng, 1, P)[0]
+    X = base[None] + np.cumsum(rng.normal(0, 0.004, size=(F, P, 133, 3)), axis=0)
+    kpts, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=1.0, score_range=(3.5, 8.0))
+    npers = npers.copy()
+    npers[4:6] = 3              # the last person is listed by nobody in frames 4-5
+    npers[8] = 0                # an empty frame
+    npers[10, :3] = 3           # three cameras miss the last person: a partly seen person
+    kpts[11, :, 1] = kpts[11, :, 3]   # frame 11: person 1 is a second detection of person 3 (a merged / duplicate person)
+    cg = ref_camera_group(K, R, t)
+    prev_tri = prev_bl = None
+    frames, counts, tracked = [], [], []
+    for f in range(F):
+        for c in range(8):
+            for p in range(int(npers[f, c])):
+                cg.add_human_2D_points(kpts[f, c, p, :, :2], kpts[f, c, p, :, 2], c)
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            tri = sv.Human_Triangulation(cg, keypoint_score_threshold=th["keypoint_score_threshold"],
+                                         average_score_threshold=th["average_score_threshold"],
+                                         distance_threshold=th["distance_threshold"])
+            tri = sv.Human_Triangulation_Condense(tri, condense_distance_tol=th["condense_distance_tol"],
+                                                  condense_person_num_tol=th["condense_person_num_tol"],
+                                                  condense_score_tol=th["condense_score_tol"],
+                                                  center_point_index=th["center_point_index"],
+                                                  keypoint_num=th["keypoint_num"])
+            counts.append(len(tri["hrnet_triangulate_points"]))
+            tri = sv.Human_Triangulation_Smooth(tri, prev_tri, f=th["smooth_f"], z=th["smooth_z"], r=th["smooth_r"],
+                                                delta_time=th["smooth_delta_time"])
+            prev_tri = tri
+            tracked.append(len(tri["hrnet_triangulate_points"]))
+            bl = sv.Human_Triangulation_Blender(tri, arm)
+            bl = sv.Human_Triangulation_Blender_Smooth(bl, arm, smo, prev_bl, delta_time=th["smooth_delta_time"])
+            prev_bl = bl
+        frames.append(sv.Human_Triangulation_To_Blender_Result(bl))
+        cg.clear_2D_points()
+    print("g9 persons per frame after condense:", counts, "tracked:", tracked)
+    assert len(set(counts)) >= 3 and max(counts) > counts[0] and min(counts) == 0
+    path = os.path.join(HERE, "g9_pipeline_multi.npz")
+    np.savez_compressed(path, K=K, R=R, t=t, kpts=kpts, n_persons=npers, thresholds=json.dumps(th), armature=json.dumps(arm),
+                        smooth=json.dumps(smo), result=json.dumps(frames), counts=np.array(counts), tracked=np.array(tracked))
+    print("g9_pipeline_multi.npz", os.path.getsize(path) / 1e6, "MB")
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
     fns = dict(g1=g1_plumbing, g2=g2_near_exact, g3=g3_multi_person, g4=g4_edge_cases,
-               g5=g5_skew_ray, g6=g6_smooth_blender, g7=g7_pipeline, g8=g8_blender_track)
+               g5=g5_skew_ray, g6=g6_smooth_blender, g7=g7_pipeline, g8=g8_blender_track, g9=g9_pipeline_multi_person)
     for w in which:
         fns[w]()

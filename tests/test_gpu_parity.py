@@ -1007,10 +1007,69 @@ def test_track_pipeline_reproduces_reference_json(api):
     out = pipe.run(raw)
     compare(pipe.to_blender_result(out["points_smoothed"], out["valid"], arm), 2e-6)   # kpts were float32 in G7
     pipe.close()
-    # a frame that resolves to a different person count is refused, not silently padded
+    # more slots than persons: the reference's semantics (banks of frame 0) -- one tracked person, the same track;
+    # ragged="refuse" insists on n_persons_out persons in every frame
     pipe = api.TrackPipeline(K, R, t, th, smo, n_persons_out=2)
+    out = pipe.run(kpts)
+    assert bool((out["tracked"] == 1).all()) and not bool(out["points_smoothed"][:, 1].any())
+    compare(pipe.to_blender_result(out["points_smoothed"], out["valid"], arm, out["tracked"]), 1e-8)
     with pytest.raises(ValueError):
-        pipe.run(kpts)
+        pipe.run(kpts, ragged="refuse")
+    pipe.close()
+
+
+def test_track_pipeline_with_varying_person_counts_reproduces_reference_json(api):
+    """Fixture G9: main.py's loop on a BASELINE configs[2]-shaped sequence (8 cameras, 4 persons) whose person count varies
+    between 0 and 7 (a person leaves, an empty frame, ghost persons): the reference matches persons by list index against
+    the filter banks of frame 0 and zip-truncates (triangulation.py:169-171, blender.py:152-166).  TrackPipeline.run
+    (batched N1 / N2, slot by slot over the frames that carry the slot) writes the same JSON track."""
+    import json
+    z = np.load(f"{GOLDEN}/g9_pipeline_multi.npz")
+    th, arm, smo = json.loads(str(z["thresholds"])), json.loads(str(z["armature"])), json.loads(str(z["smooth"]))
+    want = json.loads(str(z["result"]))
+    pipe = api.TrackPipeline(z["K"], z["R"], z["t"], th, smo, n_persons_out=8)
+    out = pipe.run(z["kpts"], z["n_persons"])
+    assert np.array_equal(out["count"].cpu().numpy(), z["counts"])
+    assert np.array_equal(out["tracked"].cpu().numpy(), z["tracked"])
+    got = pipe.to_blender_result(out["points_smoothed"], out["valid"], arm, out["tracked"])
+    pipe.close()
+    assert len(got) == len(want)
+    for f, (g, w) in enumerate(zip(got, want)):
+        assert len(g["armature"]) == len(w["armature"]) == int(z["tracked"][f]) and g["score"] == w["score"], f
+        for p, (ga, wa) in enumerate(zip(g["armature"], w["armature"])):
+            assert list(ga) == list(wa)
+            for name, vec in wa.items():
+                np.testing.assert_allclose(ga[name], vec, rtol=0, atol=1e-8, err_msg=f"frame {f} person {p} {name}")
+    # frame 0 must fit the slots
+    pipe = api.TrackPipeline(z["K"], z["R"], z["t"], th, smo, n_persons_out=3)
+    with pytest.raises(ValueError):
+        pipe.run(z["kpts"], z["n_persons"])
+    pipe.close()
+
+
+def test_track_pipeline_runs_the_configs2_workload(api):
+    """BASELINE configs[2] (8 cameras x 4 persons, ~5 persons per frame with ghosts, 10 000 frames): the device-resident
+    pipeline past A4 -- round 4 raised on the varying count.  The slots beyond a frame's tracked persons stay zero and the
+    first tracked person equals the plain filter over the whole track where every frame carries it."""
+    import torch
+    from snowmocap_amd import synth
+    wl = synth.config_workload(3, 500, seed=3)
+    K, R, t = wl["rig"]
+    th = dict(synth.default_thresholds(), **wl["params"])
+    from snowmocap_amd.blender import CONTROL_POINT_NAMES
+    smo = {n: [2.0, 0.75, 0.0] for n in CONTROL_POINT_NAMES}
+    kp = torch.from_numpy(wl["kpts"]).cuda().repeat(20, 1, 1, 1, 1).contiguous()      # 10 000 frames
+    npers = torch.from_numpy(wl["n_persons"]).cuda().repeat(20, 1).contiguous()
+    pipe = api.TrackPipeline(K, R, t, th, smo, n_persons_out=16)
+    out = pipe.run(kp, npers)
+    trk = out["tracked"].cpu().numpy()
+    cnt = out["count"].cpu().numpy()
+    assert np.array_equal(trk, np.minimum(cnt, cnt[0])) and trk.min() >= 1 and len(set(cnt.tolist())) > 1
+    live = torch.arange(16, device="cuda")[None, :] < out["tracked"][:, None]
+    assert not bool(out["smoothed"][~live].any()) and not bool(out["points_smoothed"][~live].any())
+    x0 = out["xyzs"][:, :1].contiguous().cpu().numpy()[..., :3]
+    want = api.smooth_track(x0, f=th["smooth_f"], z=th["smooth_z"], r=th["smooth_r"], delta_time=th["smooth_delta_time"])
+    np.testing.assert_allclose(out["smoothed"][:, 0, :, :3].cpu().numpy(), want[:, 0], rtol=0, atol=1e-10)
     pipe.close()
 
 
