@@ -347,7 +347,7 @@ def main():
             e2 = float(np.median(e2s))
             ok = tuple(full["xyzs"].shape) == (world * F, Pout, J, 4) and bool((full["count"] == 1).all())
             sweep.append({"chunks": chunks, "pieces": sht.last_chunks, "value": joints_per_step * K_steps / e2, "ms_per_step": e2 / K_steps * 1e3,
-                          "gathered_track_ok": ok})
+                          "gathered_track_ok": ok, "gathered_bytes_per_rank_per_step": int(sht.last_gather_bytes)})
         sht.bt.close()
         with_gather = dict(sweep[0], sweep=sweep,
                            what="same steps through ShardedTriangulator.run: the shard in `chunks` pieces, each piece's outputs "
@@ -377,6 +377,19 @@ def main():
         return k
     kms_bracketed = timed_launches(False)
     kms = timed_launches(True)
+    # (1b) the same attached pairs while the launches are issued as the timed region issues them: a plain loop of calls in
+    # the library's overlap mode.  Two consecutive launches then share the chip, each takes longer from its begin to its end,
+    # and a step -- the time per launch of the loop -- is SHORTER than one launch alone: `ms_per_step` < `kernel_ms_mean` is
+    # that overlap, and this figure shows it inside the line (round-4 review).
+    kms_overlapped = None
+    if bto is not bt:
+        bto.ctx.set_timing(True, attach=True)
+        for i in range(n_timed):
+            bto.run_torch(pool[i % len(pool)], None, out=outs[i % len(pool)])
+        bto.join()
+        kms_overlapped = bto.ctx.timing_collect()
+        bto.ctx.set_timing(False)
+        torch.cuda.synchronize(dev)
     trace_index["step"] = [_batch.FUSED_CALLS, _batch.FUSED_CALLS + n_timed]
     # (3) the same launches with NO event in between, one pair around the whole loop: the time from one launch's end to the
     # next one's end on one stream (kernel + the command processor's hand-over to the next dispatch), `kernel_ms_step_one_stream`
@@ -557,6 +570,10 @@ def main():
                                 "kernel_ms_step_one_stream = the same launches with no event in between, one pair around the loop / launches "
                                 "(kernel + hand-over to the next dispatch: what a rocprofv3 --stats average of a one-stream run lands on)",
                          "kernel_ms_mean": kernel_ms, "kernel_ms_median": float(np.median(kms)), "kernel_ms_min": kernel_ms_min, "launches": len(kms),
+                         "kernel_ms_mean_overlapped": None if kms_overlapped is None or not len(kms_overlapped) else float(np.mean(kms_overlapped)),
+                         "overlapped_note": f"the same kernel's begin-to-end time while launches are issued as `value` issues them (overlap mode, "
+                                            f"{nstreams} internal streams): two launches share the chip, each lasts longer, and ms_per_step "
+                                            "(time per launch of that loop) is shorter than kernel_ms_mean (one launch alone on the chip)",
                          "kernel_ms_mean_bracketed": kernel_ms_bracketed,
                          "frac_bracketed": bpf * F / (kernel_ms_bracketed * 1e-3) / 1e9 / HBM_PEAK_GBS,
                          "measured_device_copy_GBs": copy_GBs,
@@ -699,6 +716,31 @@ def extra_workloads(torch, dev, device_index):
                                  "hbm_GBs": bpf * F / (m * 1e-3) / 1e9, "hbm_frac": bpf * F / (m * 1e-3) / 1e9 / HBM_PEAK_GBS}})
         bt.close()
         del kp, npers, out
+    # measured VALU utilisation of the kernels of these calls (rocprofv3 SQ counters of scripts/pmc_multi.sh, profiles/pmc_multi.json),
+    # quoted beside the NOMINAL roofline fraction only while the file carries the hash of these kernel sources
+    try:
+        pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_multi.json")))
+        if pm.get("source_sha256") == kernel_source_hash():
+            for e, cfg in zip(res, ("cfg3", "cfg5", "cfg3")):
+                if "float64" in e["workload"]:
+                    continue
+                e["roofline"]["valu_busy"] = pm["workloads"].get(cfg)
+                e["roofline"]["valu_busy_note"] = ("SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs) per kernel of the call, one stream, "
+                                                   "rocprofv3 (profiles/pmc_multi.json: source_sha256 matches); `frac` above prices the REFERENCE's "
+                                                   "90 flop per candidate joint, the kernels execute about a third of them")
+    except Exception:
+        pass
+    # ONE detection per camera on other shapes than the headline's: the reference's own output type on the headline rig
+    # (k_fused_single<4,0,float,double>), and rigs of 6 and 8 cameras (the lean kernels on the complete-graph item, float32;
+    # the streaming route without a candidate pass, float64) -- 15 / 28 pair solves per joint: fp64-VALU-bound
+    sys.path.insert(0, os.path.join(ROOT, "scripts"))
+    from bench_single_rigs import measure
+    for C_, rig_, odt in ((4, "floor", np.float64), (6, "ring", np.float32), (8, "ring", np.float32), (6, "ring", np.float64), (8, "ring", np.float64)):
+        e = measure(C_, 10000, odt, rig=rig_, device_index=device_index)
+        e["kernel"] = e.pop("kernels")
+        e["kernel_ms"] = e["ms_per_call"]
+        e["io"] = "fp32 in / %s out, fp64 math" % ("fp32" if odt == np.float32 else "fp64")
+        res.append(e)
     return res
 
 

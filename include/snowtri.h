@@ -331,7 +331,9 @@ int snowtri_last_stream_counts(snowtri_ctx *ctx, int64_t counts[3]);
  * (<= 300 us, once per stream; the first call that needs the stream synchronises it and the caller's); a stream that fails
  * is replaced, up to six candidates.  out[0] = probes run, out[1] = streams discarded, out[2] = verdict on the stream kept
  * last (1 side by side, 0 none of the candidates was, -1 no stream created yet or the probe could not run: a caller
- * stream under graph capture is never probed).  No device work. */
+ * stream under graph capture is never probed).  That synchronisation happens ONCE per context, in the call that creates
+ * the internal stream; a caller stream the context meets later is probed only while it is idle (never waited for), and a
+ * context runs at most 16 probes in its life.  No device work. */
 int snowtri_ctx_stream_probes(const snowtri_ctx *ctx, int64_t out[3]);
 
 #ifdef __cplusplus

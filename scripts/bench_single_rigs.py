@@ -12,6 +12,7 @@ Roofline of a line: fp64 vector peak 78.6 TFLOP/s against the REFERENCE's work p
 import json
 import os
 import sys
+import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
@@ -38,19 +39,25 @@ def flop_per_joint(C):
     return 90.0 * (C * (C - 1) // 2) + 15.0 * C
 
 
-def measure(C, F, out_dtype, calls=0, kn=0, gen=500, seed=7):
-    dev = torch.device("cuda", 0)
+def measure(C, F, out_dtype, calls=0, kn=0, gen=500, seed=7, rig="ring", device_index=0):
+    """rig = "ring": C cameras on the synthetic ring; "floor": the reference's 4-camera rig (BASELINE configs[1]'s frames)."""
+    dev = torch.device("cuda", device_index)
     rng = np.random.default_rng(seed + C)
-    K, R, t = synth.ring_rig(C)
-    X = synth.make_people(rng, gen, 1)
-    kp, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=1.0, score_range=(3.5, 8.0))
+    if rig == "floor":
+        wl = synth.config_workload(2, gen, seed=seed)
+        (K, R, t), kp, npers = wl["rig"], wl["kpts"], wl["n_persons"]
+        C = K.shape[0]
+    else:
+        K, R, t = synth.ring_rig(C)
+        X = synth.make_people(rng, gen, 1)
+        kp, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=1.0, score_range=(3.5, 8.0))
     prm = dict(synth.default_thresholds())
     if kn:
         prm["keypoint_num"] = kn
     reps = (F + gen - 1) // gen
     kpd = torch.from_numpy(kp).to(dev).repeat(reps, 1, 1, 1, 1)[:F].contiguous()
     npd = torch.from_numpy(npers).to(dev).repeat(reps, 1)[:F].contiguous()
-    bt = BatchTriangulator(K, R, t, prm, pout_max=1, out_dtype=out_dtype)
+    bt = BatchTriangulator(K, R, t, prm, pout_max=1, out_dtype=out_dtype, device=device_index)
     out = bt.alloc_outputs(F, dev)
     bt.run_torch(kpd, npd, out=out)
     torch.cuda.synchronize(dev)
@@ -61,8 +68,11 @@ def measure(C, F, out_dtype, calls=0, kn=0, gen=500, seed=7):
     knn = prm["keypoint_num"]
     if not calls:
         calls = max(10, min(200, int(2e8 / (F * C * C))))
-    for _ in range(3):
-        bt.run_torch(kpd, npd, out=out)
+    t_w = time.perf_counter()
+    while time.perf_counter() - t_w < 0.1:      # device warm-up as in bench.py: the set-up above left the chip idle
+        for _ in range(8):
+            bt.run_torch(kpd, npd, out=out)
+        torch.cuda.synchronize(dev)
     bt.ctx.set_timing(True)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
@@ -78,9 +88,11 @@ def measure(C, F, out_dtype, calls=0, kn=0, gen=500, seed=7):
     joints = F * knn
     # the whole item runs for every joint < keypoint_num; rays of all J joints are never built for the others
     flops = joints * flop_per_joint(C)
-    line = dict(workload=f"{C} cameras x 1 person x {J} joints x {F} frames, ring rig, default thresholds",
+    line = dict(workload=f"{C} cameras x 1 person x {J} joints x {F} frames, {'the floor rig of the reference' if rig == 'floor' else 'ring rig'}, default thresholds",
+                frames=F,
                 out_dtype=np.dtype(out_dtype).name, keypoint_num=knn, kernels=names, calls=calls,
                 ms_per_call=ms, ms_per_call_loop=loop_ms, frames_per_s=F / (ms * 1e-3), joints_per_s=joints / (ms * 1e-3),
+                pair_solves_per_s=joints * (C * (C - 1) // 2) / (ms * 1e-3),
                 roofline=dict(bound="fp64 VALU (reference flops per joint: %d)" % flop_per_joint(C), achieved=flops / (ms * 1e-3) / 1e12,
                               peak=FP64_PEAK / 1e12, unit="TFLOP/s", frac=flops / (ms * 1e-3) / FP64_PEAK),
                 hbm=dict(bytes_per_joint=12 * C + (16 if out_dtype == np.float32 else 32),

@@ -10,6 +10,7 @@
 #include <algorithm>
 #include <atomic>
 #include <chrono>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -108,6 +109,7 @@ struct PinnedScratch {
         size_t want = std::max(bytes, (size_t)64 << 10);
         HIP_TRY(hipHostMalloc(&p, want, hipHostMallocMapped));
         HIP_TRY(hipHostGetDevicePointer(&dev, p, 0));
+        std::memset(p, 0, want);   // (completion words are compared with a sequence number: never start from stale memory)
         cap = want;
         return SNOWTRI_OK;
     }
@@ -228,9 +230,21 @@ struct snowtri_ctx {
             if (split_beside[i] == caller) return true;
         return false;
     }
-    int probe_side_by_side(hipStream_t a, hipStream_t b) {   // 1 / 0, -1: HIP error
+    // The probe SYNCHRONISES both streams (<= 300 us).  Policy: when a context CREATES its internal stream -- its
+    // first split call -- the caller's stream is waited for once (documented in include/snowtri.h); a caller stream the
+    // context meets LATER is probed only while it is idle (`only_if_idle`: a stream with work in flight is never waited for
+    // -- the internal stream is kept, and the question is asked again at a later call); and a context probes at most
+    // kMaxProbes times in its life: a caller that rotates many streams, or a box whose queues never come out side by side,
+    // keeps what it has instead of paying a synchronisation per call.
+    static constexpr int64_t kMaxProbes = 16;
+    int probe_side_by_side(hipStream_t a, hipStream_t b, bool only_if_idle = false) {   // 1 / 0, -1: not probed
         hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;   // never put the probe into a graph under capture
         if (hipStreamIsCapturing(a, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) return -1;
+        if (probes >= kMaxProbes) return -1;
+        if (only_if_idle && hipStreamQuery(a) != hipSuccess) {
+            (void)hipGetLastError();
+            return -2;   // busy: ask again later
+        }
         if (pin_probe.ensure(64)) return -1;
         volatile unsigned int *w = (volatile unsigned int *)pin_probe.p;
         w[0] = 0u;
@@ -280,7 +294,8 @@ struct snowtri_ctx {
         }
         if (S.stream && with_caller && !split_knows(caller)) {
             // the split of a call that arrives on another stream than the last one did: still side by side?
-            const int ok = probe_side_by_side(caller, S.stream);
+            const int ok = probe_side_by_side(caller, S.stream, true);
+            if (ok == -2) with_caller = false;     // the caller's stream is busy: keep the stream, probe at a later call
             if (ok < 0) (void)hipGetLastError();   // unprobed: keep the stream
             if (ok == 0) {
                 if (hipStreamSynchronize(S.stream) != hipSuccess) return 1;
@@ -291,7 +306,7 @@ struct snowtri_ctx {
                 ++probe_replaced;
                 n_split_beside = 0;
                 if (rc) return 1;
-            } else
+            } else if (ok != -2)
                 probe_verdict = ok == 1 ? 1 : -1;
         } else if (!S.stream && fresh_stream(&S.stream, k, with_caller, caller))
             return 1;
@@ -866,11 +881,20 @@ int host_done_arm(snowtri_ctx *ctx, HostDone *hd) {
     hd->seq = ++ctx->done_seq;
     return SNOWTRI_OK;
 }
+static inline void cpu_relax() {   // spin-wait hint of the host CPU
+#if defined(__x86_64__) || defined(__i386__)
+    __builtin_ia32_pause();
+#elif defined(__aarch64__)
+    asm volatile("yield" ::: "memory");
+#else
+    std::this_thread::yield();
+#endif
+}
 int host_done_wait(snowtri_ctx *ctx, hipStream_t st, const HostDone &hd) {
     const volatile unsigned long long *w = (const volatile unsigned long long *)ctx->pin_done.p;
     const auto t0 = std::chrono::steady_clock::now();
     for (unsigned spins = 0; *w != hd.seq; spins++) {
-        __builtin_ia32_pause();
+        cpu_relax();
         if ((spins & 0xfff) == 0xfff && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(50)) {
             HIP_TRY(hipStreamSynchronize(st));   // (a failed launch never writes the word: the runtime reports it here)
             if (*w != hd.seq) {
@@ -1704,24 +1728,25 @@ constexpr int kLeanJ = 133;
 constexpr int kFusedSingleMaxCams = 4;   // k_fused_single's pairwise item (everything in registers): up to six pairs
 constexpr int kLeanTilesPerWave = 4;
 
-template <int C, typename TIn>
+template <int C, typename TIn, typename TOut = float>
 int launch_fused_lean(snowtri_ctx *ctx, hipStream_t st, int64_t F, const TIn *d_kpts, const int32_t *d_np,
-                      const Params &prm, float *d_xyzs, float *d_ps, int32_t *d_cnt, uint32_t *d_fl) {
+                      const Params &prm, TOut *d_xyzs, TOut *d_ps, int32_t *d_cnt, uint32_t *d_fl) {
+    constexpr int kScoreBytes = (int)sizeof(TOut);
     constexpr int NP = C * (C - 1) / 2;
     const int wg_small = ctx->lean_wg_per_cu, tpw = ctx->lean_tiles_per_wave > 0 ? ctx->lean_tiles_per_wave : kLeanTilesPerWave;
     const size_t per_block = general_scratch_bytes(NP, kLeanJ);
-    auto kern = k_fused_lean<C, TIn, kLeanJ>;
+    auto kern = k_fused_lean<C, TIn, kLeanJ, TOut>;
     const int64_t W_small = (int64_t)ctx->num_cus * wg_small * kLeanWaves;
     const int64_t seg_max = (int64_t)kLeanTw * kLeanWaves * 512 * ((int64_t)ctx->num_cus * 6);  // <= 512 tiles per wave
     // small launch (at most kCoopMaxFrames frames per resident workgroup): workgroup tiles, passes dealt to the waves,
     // cooperative epilogue (k_fused_lean_coop)
     if (ctx->lean_coop != 0 && F <= (int64_t)ctx->num_cus * wg_small * kCoopMaxFrames) {
-        auto kc = k_fused_lean_coop<C, TIn, kLeanJ>;
+        auto kc = k_fused_lean_coop<C, TIn, kLeanJ, TOut>;
         const int grid = (int)std::min<int64_t>(F, (int64_t)ctx->num_cus * wg_small);
         const int base = (int)(F / grid);
         const int64_t rem = F % grid;
         const int nf_max = base + (rem ? 1 : 0);
-        const size_t lds = lean_coop_lds_bytes(C, kLeanJ, nf_max);
+        const size_t lds = lean_coop_lds_bytes(C, kLeanJ, nf_max, kScoreBytes);
         int rc = ctx->cur->work.ensure(per_block * (size_t)grid);
         if (rc) return rc;
         if (lds > 48 * 1024 && ctx->raise_lds((const void *)kc, (int)lds)) return SNOWTRI_ERR_HIP;
@@ -1739,7 +1764,7 @@ int launch_fused_lean(snowtri_ctx *ctx, hipStream_t st, int64_t F, const TIn *d_
         }
         HIP_TRY(hipGetLastError());
         static const std::string cname = std::string("k_fused_lean_coop<") + std::to_string(C) + "," + type_name<TIn>() + "," +
-                                         std::to_string(kLeanJ) + ">";
+                                         std::to_string(kLeanJ) + (kScoreBytes == 8 ? ",double>" : ">");
         ctx->last_kernels = cname.c_str();
         return SNOWTRI_OK;
     }
@@ -1766,7 +1791,7 @@ int launch_fused_lean(snowtri_ctx *ctx, hipStream_t st, int64_t F, const TIn *d_
         const int base = (int)(Fs / ntiles);
         const int64_t rem = Fs % ntiles;
         const int slow_words = (int)((tiles_per_wave * kLeanWaves * (1 << kLeanSlowShift) + 31) / 32);
-        const size_t lds = lean_lds_bytes(C, kLeanJ, slow_words);
+        const size_t lds = lean_lds_bytes(C, kLeanJ, slow_words, kScoreBytes);
         int rc = ctx->cur->work.ensure(per_block * (size_t)grid);
         if (rc) return rc;
         if (lds > 48 * 1024)
@@ -1797,7 +1822,7 @@ int launch_fused_lean(snowtri_ctx *ctx, hipStream_t st, int64_t F, const TIn *d_
         HIP_TRY(hipGetLastError());
     }
     static const std::string name = std::string("k_fused_lean<") + std::to_string(C) + "," + type_name<TIn>() + "," +
-                                    std::to_string(kLeanJ) + ">";
+                                    std::to_string(kLeanJ) + (kScoreBytes == 8 ? ",double>" : ">");
     ctx->last_kernels = name.c_str();
     return SNOWTRI_OK;
 }
@@ -1974,6 +1999,20 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st_call, int64_t F, int
         HIP_TRY(hipEventRecord(ctx->ev_fork, st_call));
         HIP_TRY(hipStreamWaitEvent(ctx->sets[1].stream, ctx->ev_fork, 0));
     }
+    // Whatever way this function is left, the caller's stream continues BEHIND the internal one: a segment already queued
+    // there writes the caller's outputs, and an error return in the middle of the loop must not leave it unordered with the
+    // caller's stream.  The regular exit joins explicitly and disarms the guard.
+    struct SplitJoin {
+        snowtri_ctx *ctx;
+        hipStream_t caller;
+        StreamSet *set_call;
+        bool armed;
+        ~SplitJoin() {
+            ctx->cur = set_call;
+            if (armed && hipEventRecord(ctx->sets[1].done, ctx->sets[1].stream) == hipSuccess)
+                (void)hipStreamWaitEvent(caller, ctx->sets[1].done, 0);
+        }
+    } split_join{ctx, st_call, set_call, split};
     const bool sums_rays_shape = !sumless && ctx->sums_rays != 0 && ctx->sums_threads == 0 && ctx->sums_lds_kb == 0 &&
                                  ((C == 8 && Pmax == 4)
 #ifndef SNOWTRI_DEV_MIN
@@ -2204,6 +2243,7 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st_call, int64_t F, int
     }
     ctx->cur = set_call;
     if (split) {   // the caller's stream continues behind the internal one
+        split_join.armed = false;
         HIP_TRY(hipEventRecord(ctx->sets[1].done, ctx->sets[1].stream));
         HIP_TRY(hipStreamWaitEvent(st_call, ctx->sets[1].done, 0));
     }
@@ -2224,8 +2264,10 @@ int fused_dispatch(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax, int J,
                       !((double)ctx->npairs < prm.num_tol) && ctx->general_mode == 0;
     const int64_t ring_slot = ctx->ev_count % kTimingRing;
     ctx->ev_attached = false;
-    const bool lean = method != SNOWTRI_DLT && fast && std::is_same<TOut, float>::value && J == kLeanJ && prm.kn == kLeanJ && Pout == 1 &&
-                      ctx->lean_mode != 0;
+    // (float64 outputs -- the reference's own output type -- on the lean kernels from five cameras on: the rolled item's
+    // Newton-refined branch; up to four cameras they stay on k_fused_single<C,0,TIn,double>)
+    const bool lean = method != SNOWTRI_DLT && fast && (std::is_same<TOut, float>::value || C >= 5) && J == kLeanJ && prm.kn == kLeanJ &&
+                      Pout == 1 && ctx->lean_mode != 0;
     // Five cameras and more on any other shape (float64 outputs, keypoint_num < J, other skeletons, several slots): the
     // unrolled pairwise_item of k_fused_single does not fit the register file there (10-28 pairs: 41-1 075 spilled VGPRs, round-4
     // review).  Those calls take the streaming route WITHOUT its candidate pass (launch_frame_recompute: `sumless`): with one
@@ -2270,21 +2312,38 @@ int fused_dispatch(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax, int J,
             default: rc = SNOWTRI_ERR_BAD_ARG;
         }
     } else if (lean) {
-        switch (C) {
+        if constexpr (std::is_same<TOut, float>::value) {
+            switch (C) {
 #define SNOWTRI_CASE(CC)                                                                                          \
     case CC:                                                                                                      \
         rc = launch_fused_lean<CC, TIn>(ctx, st, F, d_kpts, d_np, prm, (float *)xyzs, (float *)ps, d_cnt, d_fl); \
         break;
 #ifndef SNOWTRI_DEV_MIN
-            SNOWTRI_CASE(3)
-            SNOWTRI_CASE(5)
-            SNOWTRI_CASE(6)
-            SNOWTRI_CASE(7)
-            SNOWTRI_CASE(8)
+                SNOWTRI_CASE(3)
+                SNOWTRI_CASE(5)
+                SNOWTRI_CASE(6)
+                SNOWTRI_CASE(7)
+                SNOWTRI_CASE(8)
 #endif
-            SNOWTRI_CASE(4)
+                SNOWTRI_CASE(4)
 #undef SNOWTRI_CASE
-            default: rc = SNOWTRI_ERR_BAD_ARG;
+                default: rc = SNOWTRI_ERR_BAD_ARG;
+            }
+        } else {
+            switch (C) {
+#define SNOWTRI_CASE(CC)                                                                                          \
+    case CC:                                                                                                      \
+        rc = launch_fused_lean<CC, TIn, double>(ctx, st, F, d_kpts, d_np, prm, d_xyzs, d_ps, d_cnt, d_fl);       \
+        break;
+#ifndef SNOWTRI_DEV_MIN
+                SNOWTRI_CASE(5)
+                SNOWTRI_CASE(6)
+                SNOWTRI_CASE(7)
+                SNOWTRI_CASE(8)
+#endif
+#undef SNOWTRI_CASE
+                default: rc = SNOWTRI_ERR_BAD_ARG;
+            }
         }
     } else if (single_small) {
         switch (C) {

@@ -723,6 +723,7 @@ __global__ __launch_bounds__(kBlock, (FusedShape<C, METHOD, TIn>::kWaves)) void 
         // ---- rare: frames the speculation could not resolve -> the reference's full algorithm
         unsigned long long slow_mask = __ballot(lane < nf && (fflag[lane] & kSlow) != 0u);  // T <= 64
         __syncthreads();
+        if constexpr (METHOD != 0) slow_mask = 0ull;   // (DLT never speculates: the general routine is not compiled into those kernels)
         if (slow_mask) {
             double *slab = reinterpret_cast<double *>(scratch + (size_t)blockIdx.x * scratch_per_block);
             while (slow_mask) {

@@ -284,6 +284,7 @@ __global__ __launch_bounds__(kBlock) void k_triangulate_slots(int64_t F, int Pma
         cand_kscore[i] = mirror_kscore[i] = s;
         sc_l[j] = s;
     }
+    __threadfence();   // every thread's n_singular atomics are visible device-wide before this workgroup counts itself done below
     __syncthreads();
     if (tid < 64) {
         double s = 0.0;

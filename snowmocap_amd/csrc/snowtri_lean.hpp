@@ -44,9 +44,11 @@ namespace snowtri {
 #endif
 constexpr int kLeanRolledWaves = SNOWTRI_LEAN_ROLLED_WAVES, kLeanRolledRing = SNOWTRI_LEAN_ROLLED_RING;   // (A/B builds override them)
 constexpr int kLeanRolledGroup = SNOWTRI_LEAN_ROLLED_GROUP;   // pairs between two scheduling barriers of the item
-template <int C>
+// float64 outputs (the reference's own output type) exist on the rolled item only -- cluster_item<..., double> refines 1/dist by a
+// Newton step, lean_item carries the raw v_rsq_f64 of the float32 contract -- so five cameras roll too when they are asked for.
+template <int C, typename TOut = float>
 struct LeanShape {
-    static constexpr bool kRolled = C >= 6;
+    static constexpr bool kRolled = C >= 6 || (C == 5 && sizeof(TOut) == 8);
     static constexpr int kWaves = kRolled ? kLeanRolledWaves : kFastWaves;
     static constexpr int kRing = kRolled ? kLeanRolledRing : 3;
 };
@@ -59,8 +61,8 @@ __host__ __device__ constexpr int lean_items_pad(int JC) { return (kLeanTw * JC 
 __host__ __device__ constexpr int lean_table_entries(int JC) { return lean_items_pad(JC) + 256; }      // + the prefetch distance past the last pass
 __host__ __device__ constexpr int lean_const_doubles(int C) { return (12 * C + 4 * (C * (C - 1) / 2) + 1) & ~1; }  // M[C][9], t[C][3], d[NP][3], pairs[NP][2] (int32)
 
-__host__ __device__ constexpr size_t lean_lds_bytes(int C, int JC, int slow_words) {
-    const size_t stash = (size_t)kLeanWaves * lean_items_pad(JC) * 4;        // fused joint scores (float32 as stored), per wave
+__host__ __device__ constexpr size_t lean_lds_bytes(int C, int JC, int slow_words, int score_bytes = 4) {
+    const size_t stash = (size_t)kLeanWaves * lean_items_pad(JC) * score_bytes;   // fused joint scores as stored (float32 / float64), per wave
     const size_t table = (size_t)4 * lean_table_entries(JC);                 // item -> byte offset of its camera-0 keypoint in the tile
     return (((size_t)8 * lean_const_doubles(C) + table + stash + (size_t)4 * slow_words) + 15) & ~(size_t)15;
 }
@@ -251,6 +253,44 @@ __device__ __forceinline__ bool lean_solve(const double *__restrict__ Mlds, cons
     }
 }
 
+// One item solved, its joint record stored (non-temporal, range-checked by the descriptor) and its score stashed for the frame's
+// mean: float32 records through lean_solve, float64 records (two 16-byte stores) through cluster_item's Newton-refined branch.
+template <int C, typename TIn, typename TOut, int ND>
+__device__ __forceinline__ bool lean_solve_store(const double *__restrict__ Mlds, const double (&dS)[ND], const Kp3<TIn> (&cur)[C], float kthr_f32,
+                                                 double kthr, double dthr2, __amdgpu_buffer_rsrc_t rout, unsigned out_off, TOut *stash_slot) {
+    if constexpr (sizeof(TOut) == 4) {
+        float ox, oy, oz;
+        double os;
+        const bool bad = lean_solve<C>(Mlds, dS, cur, kthr_f32, kthr, dthr2, ox, oy, oz, os);
+        const float osf = (float)os;
+        lean_u4 rec;
+        rec.x = __float_as_uint(ox);
+        rec.y = __float_as_uint(oy);
+        rec.z = __float_as_uint(oz);
+        rec.w = __float_as_uint(osf);
+        __builtin_amdgcn_raw_buffer_store_b128(rec, rout, (int)out_off, 0, kLeanStoreAux);
+        *stash_slot = osf;
+        return bad;
+    } else {
+        double x, y, z, os;
+        asm volatile("" ::: "memory");   // (as lean_solve: the rig constants are re-read from LDS by every item)
+        const bool bad = cluster_item<C, TIn, double, kLeanRolledGroup>(Mlds, cur, kthr_f32, kthr, dthr2, x, y, z, os);
+        lean_u4 lo, hi;
+        lo.x = (unsigned)__double2loint(x);
+        lo.y = (unsigned)__double2hiint(x);
+        lo.z = (unsigned)__double2loint(y);
+        lo.w = (unsigned)__double2hiint(y);
+        hi.x = (unsigned)__double2loint(z);
+        hi.y = (unsigned)__double2hiint(z);
+        hi.z = (unsigned)__double2loint(os);
+        hi.w = (unsigned)__double2hiint(os);
+        __builtin_amdgcn_raw_buffer_store_b128(lo, rout, (int)out_off, 0, kLeanStoreAux);
+        __builtin_amdgcn_raw_buffer_store_b128(hi, rout, (int)out_off + 16, 0, kLeanStoreAux);
+        *stash_slot = os;
+        return bad;
+    }
+}
+
 // ---- per-frame steps shared by k_fused_lean and k_fused_lean_coop (ONE definition: both kernels give the same bits) ----
 // Single-cluster check (:116-130) for lane = (frame wl of the pass, pair qq), lane = wl NP + qq: the lane solves its pair
 // at the centre joint (midpoint only) and takes candidate 0's point from the frame's first lane of the same pass.
@@ -281,8 +321,8 @@ __device__ __forceinline__ bool lean_centre_far(const double *__restrict__ Mlds,
 
 // Sum of a frame's JC fused joint scores (float32 as stored) by four lanes (sub = 0..3 takes joints sub, sub + 4, ...),
 // in double: the partial of lane `sub`; the caller adds the four partials with two xor-shuffles.
-template <int JC>
-__device__ __forceinline__ double lean_row_partial(const float *__restrict__ row, int sub) {
+template <int JC, typename TS>
+__device__ __forceinline__ double lean_row_partial(const TS *__restrict__ row, int sub) {
     constexpr int G = 4;
     double sum = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
     int b = sub;
@@ -306,10 +346,10 @@ __device__ __forceinline__ void lean_tile_range(int64_t t, int base, int64_t rem
 
 // Grid: any number of workgroups; wave gw = 4 blockIdx.x + wave takes tiles gw, gw + 4 gridDim.x, ...
 // Dynamic LDS: lean_lds_bytes(C, JC, slow_words); slow_words >= ceil(tiles of one WORKGROUP * 16 / 32).
-template <int C, typename TIn, int JC>
-__global__ __launch_bounds__(kBlock, LeanShape<C>::kWaves) void k_fused_lean(
+template <int C, typename TIn, int JC, typename TOut = float>
+__global__ __launch_bounds__(kBlock, (LeanShape<C, TOut>::kWaves)) void k_fused_lean(
     int64_t F, int64_t ntiles, int tile_base, int64_t tile_rem, int slow_words, Rig rig, const TIn *__restrict__ kpts,
-    const int32_t *__restrict__ n_persons, Params prm, float *__restrict__ out4, float *__restrict__ out_ps,
+    const int32_t *__restrict__ n_persons, Params prm, TOut *__restrict__ out4, TOut *__restrict__ out_ps,
     int32_t *__restrict__ out_count, uint32_t *__restrict__ out_flags, char *scratch, size_t scratch_per_block) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NP = C * (C - 1) / 2;
@@ -324,12 +364,14 @@ __global__ __launch_bounds__(kBlock, LeanShape<C>::kWaves) void k_fused_lean(
     // the constants sit at offset 0 so that every ds_read of them is base + immediate
     double *Mlds = reinterpret_cast<double *>(smem);
     uint32_t *table = reinterpret_cast<uint32_t *>(Mlds + kConstDoubles);
-    float *stash = reinterpret_cast<float *>(table + kTable) + wave * kItemsPad;
-    uint32_t *slowbits = reinterpret_cast<uint32_t *>(reinterpret_cast<float *>(table + kTable) + kLeanWaves * kItemsPad);
+    TOut *stash = reinterpret_cast<TOut *>(table + kTable) + wave * kItemsPad;
+    uint32_t *slowbits = reinterpret_cast<uint32_t *>(reinterpret_cast<TOut *>(table + kTable) + kLeanWaves * kItemsPad);
     const Kp3<TIn> *kp3 = reinterpret_cast<const Kp3<TIn> *>(kpts);
     const int64_t wstride = (int64_t)gridDim.x * kLeanWaves;
-    constexpr bool kRolled = LeanShape<C>::kRolled;
-    constexpr int kRing = LeanShape<C>::kRing;
+    constexpr bool kRolled = LeanShape<C, TOut>::kRolled;
+    constexpr unsigned kOutRec = 4u * (unsigned)sizeof(TOut);   // bytes of one joint record [x, y, z, score]
+    static_assert(sizeof(TOut) == 4 || kRolled, "float64 outputs: the rolled item only");
+    constexpr int kRing = (kRolled && sizeof(TIn) == 8 && C >= 8) ? 1 : LeanShape<C, TOut>::kRing;   // (float64 keypoints: buffers of twice the size)
     Kp3<TIn> bufA[C], bufB[kRing >= 2 ? C : 1], bufC[kRing >= 3 ? C : 1];
 
     // Item i = lane + 64 k of a tile is joint i % JC of the tile's frame i / JC; its camera-c record sits at byte
@@ -387,15 +429,17 @@ __global__ __launch_bounds__(kBlock, LeanShape<C>::kWaves) void k_fused_lean(
         SNOWTRI_DEV_CHECK((ord * kLeanWaves + wave + 1) << kLeanSlowShift <= slow_words * 32, 2);  // its slow-frame bits exist
         const __amdgpu_buffer_rsrc_t rin = lean_rsrc(kp3 + f0 * (int64_t)(C * JC), (unsigned)(nf * C * JC) * kRec);
         const __amdgpu_buffer_rsrc_t rout =
-            lean_rsrc(reinterpret_cast<float4 *>(out4) + f0 * (int64_t)JC, (unsigned)(nf * JC) * 16u);
+            lean_rsrc(reinterpret_cast<char *>(out4) + f0 * (int64_t)JC * kOutRec, (unsigned)(nf * JC) * kOutRec);
         const unsigned last = (unsigned)(nf * JC - 1);
         const int npass = (nf * JC + 63) >> 6;
         const unsigned slow_base = (unsigned)((ord * kLeanWaves + wave) << kLeanSlowShift);
         // centre-joint keypoints for the single-cluster check after the item loop (lane = frame x pair)
         constexpr int kCheckFrames = 64 / NP;
-        Kp3<TIn> ckm[2], cks[2];
+        // (not for the rolled item: its registers are spoken for, and an item of 15+ pair solves hides the check's loads anyway)
+        constexpr int kCheckPre = kRolled ? 0 : 2;
+        Kp3<TIn> ckm[kCheckPre ? kCheckPre : 1], cks[kCheckPre ? kCheckPre : 1];
 #pragma unroll
-        for (int pass = 0; pass < 2; pass++) {
+        for (int pass = 0; pass < kCheckPre; pass++) {
             const int wl = lane / NP, qq = lane - wl * NP, w = pass * kCheckFrames + wl;
             const bool live = wl < kCheckFrames && w < nf;
             const Kp3<TIn> *p = kp3 + (f0 + (live ? w : 0)) * (int64_t)(C * JC) + prm.center;
@@ -405,29 +449,19 @@ __global__ __launch_bounds__(kBlock, LeanShape<C>::kWaves) void k_fused_lean(
 
         // item `is` + 64 k of the lane: output record at byte 16 (is + 64 k), stash slot is + 64 k.  Lanes past the
         // tile's last item work on zeros; their store is out of the descriptor's range and their stash slot is padding.
-        auto solve_store = [&](const Kp3<TIn>(&buf)[C], unsigned out_off, float *stash_slot) {
-            float ox, oy, oz;
-            double os;
-            const bool bad = lean_solve<C>(Mlds, dS, buf, kthr_f32, kthr, dthr2, ox, oy, oz, os);
-            const float osf = (float)os;
-            lean_u4 rec;
-            rec.x = __float_as_uint(ox);
-            rec.y = __float_as_uint(oy);
-            rec.z = __float_as_uint(oz);
-            rec.w = __float_as_uint(osf);
-            __builtin_amdgcn_raw_buffer_store_b128(rec, rout, (int)out_off, 0, kLeanStoreAux);
-            *stash_slot = osf;
+        auto solve_store = [&](const Kp3<TIn>(&buf)[C], unsigned out_off, TOut *stash_slot) {
+            const bool bad = lean_solve_store<C, TIn, TOut>(Mlds, dS, buf, kthr_f32, kthr, dthr2, rout, out_off, stash_slot);
             if (__ballot(bad)) {  // rare, wave-uniform branch
                 unsigned o = out_off;
                 asm volatile("" : "+v"(o));  // (keeps the bit arithmetic below inside the branch)
-                const unsigned i = o >> 4;
+                const unsigned i = o / kOutRec;
                 const unsigned bit = slow_base + i / (unsigned)JC;
                 if (bad && i <= last) atomicOr(&slowbits[bit >> 5], 1u << (bit & 31u));
             }
         };
         // ---- item loop: a ring of three register buffers keeps the keypoints of the next two items in flight
-        unsigned out_off = (unsigned)lane * 16u;           // 16 x (item being solved); the one being fetched is two passes ahead
-        float *sp = stash + lane;                          // its stash slot
+        unsigned out_off = (unsigned)lane * kOutRec;       // record of the item being solved; the one being fetched is two passes ahead
+        TOut *sp = stash + lane;                           // its stash slot
         const uint32_t *tp = table + lane;                 // its table entry
         if constexpr (kRing >= 3) {
             unsigned t0 = tp[128], t1 = tp[192], t2 = tp[256];  // (read one iteration ahead of their use)
@@ -435,14 +469,14 @@ __global__ __launch_bounds__(kBlock, LeanShape<C>::kWaves) void k_fused_lean(
                 fetch(bufC, rin, t0);
                 solve_store(bufA, out_off, sp);
                 fetch(bufA, rin, t1);
-                if (k + 1 < npass) solve_store(bufB, out_off + 1024u, sp + 64);
+                if (k + 1 < npass) solve_store(bufB, out_off + 64u * kOutRec, sp + 64);
                 fetch(bufB, rin, t2);
-                if (k + 2 < npass) solve_store(bufC, out_off + 2048u, sp + 128);
+                if (k + 2 < npass) solve_store(bufC, out_off + 128u * kOutRec, sp + 128);
                 tp += 192;
                 t0 = tp[128];
                 t1 = tp[192];
                 t2 = tp[256];
-                out_off += 3072u;
+                out_off += 192u * kOutRec;
                 sp += 192;
             }
         } else if constexpr (kRing == 2) {   // the next item's keypoints fly under the current item
@@ -450,9 +484,9 @@ __global__ __launch_bounds__(kBlock, LeanShape<C>::kWaves) void k_fused_lean(
                 fetch(bufB, rin, tp[64]);
                 solve_store(bufA, out_off, sp);
                 fetch(bufA, rin, tp[128]);
-                if (k + 1 < npass) solve_store(bufB, out_off + 1024u, sp + 64);
+                if (k + 1 < npass) solve_store(bufB, out_off + 64u * kOutRec, sp + 64);
                 tp += 128;
-                out_off += 2048u;
+                out_off += 128u * kOutRec;
                 sp += 128;
             }
         } else {                             // one buffer: the SIMD's other waves cover the fetch
@@ -460,7 +494,7 @@ __global__ __launch_bounds__(kBlock, LeanShape<C>::kWaves) void k_fused_lean(
                 solve_store(bufA, out_off, sp);
                 fetch(bufA, rin, tp[64]);
                 tp += 64;
-                out_off += 1024u;
+                out_off += 64u * kOutRec;
                 sp += 64;
             }
         }
@@ -485,7 +519,7 @@ __global__ __launch_bounds__(kBlock, LeanShape<C>::kWaves) void k_fused_lean(
             const bool live = wl < kCheckFrames && w < nf_cur;
             const int mc = pairs_lds[2 * qq], sc = pairs_lds[2 * qq + 1];
             Kp3<TIn> km, ks;
-            if (pass < 2) {
+            if (pass < kCheckPre) {
                 km = ckm[pass];
                 ks = cks[pass];
             } else {
@@ -507,7 +541,7 @@ __global__ __launch_bounds__(kBlock, LeanShape<C>::kWaves) void k_fused_lean(
             const bool live = w < nf_cur;
             const int64_t f = f0_cur + (live ? w : 0);
             double sum = 0.0;
-            if (live) sum = lean_row_partial<JC>(stash + w * JC, sub);
+            if (live) sum = lean_row_partial<JC, TOut>(stash + w * JC, sub);
             int not_one = 0;
             if (n_persons && live)
                 for (int c = sub; c < C; c += G) not_one |= n_persons[f * C + c] != 1;
@@ -527,7 +561,7 @@ __global__ __launch_bounds__(kBlock, LeanShape<C>::kWaves) void k_fused_lean(
                     atomicOr(&slowbits[bit >> 5], 1u << (bit & 31u));
                 } else {
                     out_count[f] = 1;
-                    if (out_ps) out_ps[f] = (float)avg;
+                    if (out_ps) out_ps[f] = (TOut)avg;
                     if (out_flags) out_flags[f] = kFlagFast;
                 }
             }
@@ -541,7 +575,7 @@ __global__ __launch_bounds__(kBlock, LeanShape<C>::kWaves) void k_fused_lean(
     for (int i = lane; i < slow_words; i += 64) any |= slowbits[i];
     if (__ballot(any != 0u) == 0ull) return;  // every wave reads the same words: uniform exit
     {
-        const PackedWriter<float> wr{out4, out_ps};
+        const PackedWriter<TOut> wr{out4, out_ps};
         double *slab = reinterpret_cast<double *>(scratch + (size_t)blockIdx.x * scratch_per_block);
         for (int wd = 0; wd < slow_words; wd++) {
             uint32_t m = slowbits[wd];
@@ -580,16 +614,16 @@ __global__ __launch_bounds__(kBlock, LeanShape<C>::kWaves) void k_fused_lean(
 // Dynamic LDS: lean_coop_lds_bytes(C, JC, nf_max).
 constexpr int kCoopMaxFrames = 32;   // frames per workgroup tile (one bit word of slow frames)
 __host__ __device__ constexpr int lean_coop_items_pad(int JC, int nf_max) { return (nf_max * JC + 63) / 64 * 64; }
-__host__ __device__ constexpr size_t lean_coop_lds_bytes(int C, int JC, int nf_max) {
+__host__ __device__ constexpr size_t lean_coop_lds_bytes(int C, int JC, int nf_max, int score_bytes = 4) {
     // [rig constants | item -> input offset table (+ 256 entries of prefetch distance) | stash | mean per frame | slow bits]
-    return (((size_t)8 * lean_const_doubles(C) + (size_t)4 * (lean_coop_items_pad(JC, nf_max) + 256) + (size_t)4 * lean_coop_items_pad(JC, nf_max) +
+    return (((size_t)8 * lean_const_doubles(C) + (size_t)4 * (lean_coop_items_pad(JC, nf_max) + 256) + (size_t)score_bytes * lean_coop_items_pad(JC, nf_max) +
              (size_t)8 * kCoopMaxFrames + 16) + 15) & ~(size_t)15;
 }
 
-template <int C, typename TIn, int JC>
-__global__ __launch_bounds__(kBlock, LeanShape<C>::kWaves) void k_fused_lean_coop(
+template <int C, typename TIn, int JC, typename TOut = float>
+__global__ __launch_bounds__(kBlock, (LeanShape<C, TOut>::kWaves)) void k_fused_lean_coop(
     int64_t F, int tile_base, int64_t tile_rem, int nf_max, Rig rig, const TIn *__restrict__ kpts, const int32_t *__restrict__ n_persons,
-    Params prm, float *__restrict__ out4, float *__restrict__ out_ps, int32_t *__restrict__ out_count, uint32_t *__restrict__ out_flags,
+    Params prm, TOut *__restrict__ out4, TOut *__restrict__ out_ps, int32_t *__restrict__ out_count, uint32_t *__restrict__ out_flags,
     char *scratch, size_t scratch_per_block) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int NP = C * (C - 1) / 2;
@@ -601,12 +635,14 @@ __global__ __launch_bounds__(kBlock, LeanShape<C>::kWaves) void k_fused_lean_coo
     const int items_pad = lean_coop_items_pad(JC, nf_max), ntable = items_pad + 256;
     double *Mlds = reinterpret_cast<double *>(smem);
     uint32_t *table = reinterpret_cast<uint32_t *>(Mlds + kConstDoubles);
-    float *stash = reinterpret_cast<float *>(table + ntable);
+    TOut *stash = reinterpret_cast<TOut *>(table + ntable);
     double *favg = reinterpret_cast<double *>(stash + items_pad);          // [kCoopMaxFrames] mean fused score of a frame
     uint32_t *slowbits = reinterpret_cast<uint32_t *>(favg + kCoopMaxFrames);   // one word: bit = frame of the tile
     const Kp3<TIn> *kp3 = reinterpret_cast<const Kp3<TIn> *>(kpts);
-    constexpr bool kRolled = LeanShape<C>::kRolled;
-    constexpr int kRing = LeanShape<C>::kRing;
+    constexpr bool kRolled = LeanShape<C, TOut>::kRolled;
+    constexpr unsigned kOutRec = 4u * (unsigned)sizeof(TOut);   // bytes of one joint record [x, y, z, score]
+    static_assert(sizeof(TOut) == 4 || kRolled, "float64 outputs: the rolled item only");
+    constexpr int kRing = (kRolled && sizeof(TIn) == 8 && C >= 8) ? 1 : LeanShape<C, TOut>::kRing;   // (float64 keypoints: buffers of twice the size)
     Kp3<TIn> bufA[C], bufB[kRing >= 2 ? C : 1], bufC[kRing >= 3 ? C : 1];
 
 #ifdef SNOWTRI_LEAN_TRACE   // dev build: wall-clock stamps (100 MHz) of every wave at the phase boundaries, in the workgroup's scratch slab
@@ -635,7 +671,7 @@ __global__ __launch_bounds__(kBlock, LeanShape<C>::kWaves) void k_fused_lean_coo
     const int p0 = pos * pq + (pos < pr ? pos : pr), npass = pq + (pos < pr ? 1 : 0);
     const unsigned i0 = (unsigned)p0 * 64u;   // first item of the wave
     const __amdgpu_buffer_rsrc_t rin = lean_rsrc(kp3 + f0 * (int64_t)(C * JC), (unsigned)(nf * C * JC) * kRec);
-    const __amdgpu_buffer_rsrc_t rout = lean_rsrc(reinterpret_cast<float4 *>(out4) + f0 * (int64_t)JC, (unsigned)(nf * JC) * 16u);
+    const __amdgpu_buffer_rsrc_t rout = lean_rsrc(reinterpret_cast<char *>(out4) + f0 * (int64_t)JC * kOutRec, (unsigned)(nf * JC) * kOutRec);
     const unsigned last = (unsigned)(nf * JC - 1);
     auto fetch = [&](Kp3<TIn>(&dst)[C], unsigned voff) {
 #pragma unroll
@@ -689,41 +725,31 @@ __global__ __launch_bounds__(kBlock, LeanShape<C>::kWaves) void k_fused_lean_coo
         cks = p[pairs_lds[2 * qq + 1] * JC];
     }
 
-    auto solve_store = [&](const Kp3<TIn>(&buf)[C], unsigned out_off, float *stash_slot) {
-        float ox, oy, oz;
-        double os;
-        const bool bad = lean_solve<C>(Mlds, dS, buf, kthr_f32, kthr, dthr2, ox, oy, oz, os);
-        const float osf = (float)os;
-        lean_u4 rec;
-        rec.x = __float_as_uint(ox);
-        rec.y = __float_as_uint(oy);
-        rec.z = __float_as_uint(oz);
-        rec.w = __float_as_uint(osf);
-        __builtin_amdgcn_raw_buffer_store_b128(rec, rout, (int)out_off, 0, kLeanStoreAux);
-        *stash_slot = osf;
+    auto solve_store = [&](const Kp3<TIn>(&buf)[C], unsigned out_off, TOut *stash_slot) {
+        const bool bad = lean_solve_store<C, TIn, TOut>(Mlds, dS, buf, kthr_f32, kthr, dthr2, rout, out_off, stash_slot);
         if (__ballot(bad)) {  // rare, wave-uniform branch
             unsigned o = out_off;
             asm volatile("" : "+v"(o));
-            const unsigned i = o >> 4;
+            const unsigned i = o / kOutRec;
             if (bad && i <= last) atomicOr(&slowbits[0], 1u << (i / (unsigned)JC));
         }
     };
     // ---- item loop over the wave's passes: the ring of three register buffers as in k_fused_lean; the fetch two passes
     //      ahead stops at the wave's last pass (the passes behind it belong to the next wave)
     {
-        unsigned out_off = (i0 + (unsigned)lane) * 16u;
-        float *sp = stash + i0 + lane;
+        unsigned out_off = (i0 + (unsigned)lane) * kOutRec;
+        TOut *sp = stash + i0 + lane;
         const uint32_t *tp = table + i0 + lane;
         if constexpr (kRing >= 3) {
             for (int k = 0; k < npass; k += 3) {
                 fetch(bufC, k + 2 < npass ? tp[128] : kNoItem);
                 solve_store(bufA, out_off, sp);
                 fetch(bufA, k + 3 < npass ? tp[192] : kNoItem);
-                if (k + 1 < npass) solve_store(bufB, out_off + 1024u, sp + 64);
+                if (k + 1 < npass) solve_store(bufB, out_off + 64u * kOutRec, sp + 64);
                 fetch(bufB, k + 4 < npass ? tp[256] : kNoItem);
-                if (k + 2 < npass) solve_store(bufC, out_off + 2048u, sp + 128);
+                if (k + 2 < npass) solve_store(bufC, out_off + 128u * kOutRec, sp + 128);
                 tp += 192;
-                out_off += 3072u;
+                out_off += 192u * kOutRec;
                 sp += 192;
             }
         } else if constexpr (kRing == 2) {
@@ -731,9 +757,9 @@ __global__ __launch_bounds__(kBlock, LeanShape<C>::kWaves) void k_fused_lean_coo
                 fetch(bufB, k + 1 < npass ? tp[64] : kNoItem);
                 solve_store(bufA, out_off, sp);
                 fetch(bufA, k + 2 < npass ? tp[128] : kNoItem);
-                if (k + 1 < npass) solve_store(bufB, out_off + 1024u, sp + 64);
+                if (k + 1 < npass) solve_store(bufB, out_off + 64u * kOutRec, sp + 64);
                 tp += 128;
-                out_off += 2048u;
+                out_off += 128u * kOutRec;
                 sp += 128;
             }
         } else {
@@ -741,7 +767,7 @@ __global__ __launch_bounds__(kBlock, LeanShape<C>::kWaves) void k_fused_lean_coo
                 solve_store(bufA, out_off, sp);
                 fetch(bufA, k + 1 < npass ? tp[64] : kNoItem);
                 tp += 64;
-                out_off += 1024u;
+                out_off += 64u * kOutRec;
                 sp += 64;
             }
         }
@@ -773,7 +799,7 @@ __global__ __launch_bounds__(kBlock, LeanShape<C>::kWaves) void k_fused_lean_coo
             const bool live = w < nf;
             const int64_t f = f0 + (live ? w : 0);
             double sum = 0.0;
-            if (live) sum = lean_row_partial<JC>(stash + w * JC, sub);
+            if (live) sum = lean_row_partial<JC, TOut>(stash + w * JC, sub);
             int not_one = 0;
             if (n_persons && live)
                 for (int c = sub; c < C; c += G) not_one |= n_persons[f * C + c] != 1;
@@ -797,14 +823,14 @@ __global__ __launch_bounds__(kBlock, LeanShape<C>::kWaves) void k_fused_lean_coo
     if (wave == 0 && lane < nf && !((slow >> lane) & 1u)) {
         const int64_t f = f0 + lane;
         out_count[f] = 1;
-        if (out_ps) out_ps[f] = (float)favg[lane];
+        if (out_ps) out_ps[f] = (TOut)favg[lane];
         if (out_flags) out_flags[f] = kFlagFast;
     }
     SNOWTRI_STAMP(6);
     if (slow == 0u) return;   // (uniform: every thread reads the same word)
     // ---- rare: frames the speculation could not resolve -> the reference's full algorithm, by the whole workgroup
     {
-        const PackedWriter<float> wr{out4, out_ps};
+        const PackedWriter<TOut> wr{out4, out_ps};
         double *slab = reinterpret_cast<double *>(scratch + (size_t)blockIdx.x * scratch_per_block);
         uint32_t m = slow;
         __syncthreads();  // general_frame reuses the front of the LDS (the finalising reads of favg are done)
