@@ -264,6 +264,31 @@ int snowtri_blender_smooth(snowtri_ctx *ctx, int64_t T, int64_t n_persons, const
                            const uint8_t *valid, const double *fzr, double dt, double *out, int memspace,
                            void *stream);
 
+/* N2 on a FRAME-SHARDED track (one contiguous frame block per rank; DEVICE pointers, asynchronous on `stream`).  An invalid
+ * point feeds a filter its previous input (blender.py:157-160), i.e. the filters run on the HELD sequence
+ * x_eff[t] = valid[t] ? x[t] : x_eff[t-1] (x_eff[-1] = 0: a filter whose first point is invalid is seeded with zeros,
+ * :172-173) -- and on x_eff they are plain linear filters, so a shard takes TWO small exchanges:
+ *   1. snowtri_blender_hold_shard_last   payload[2n] = last valid input of the shard per lane | found (1.0 / 0.0) per lane,
+ *                                        n = n_persons * 24 * 4 (an empty shard: all zeros);  all-gather the payloads;
+ *      snowtri_blender_hold_shard_apply  held[T][n] = x_eff of the shard, entering with the last valid input of the nearest
+ *                                        shard before `rank` that has one (gathered[world][2n], frame order);
+ *   2. the carry exchange of row N1 on `held` with the per-point coefficients fzr[24][3]:
+ *      snowtri_blender_smooth_shard_local / _combine / _fix = snowtri_smooth_shard_local / _combine / _fix (same payload
+ *      gathered[world][4n + 1]: end state | first row of held | last row of held | T; same contract on `first`).
+ * The shard that starts the track returns its frame 0 as the filter saw it (x_eff[0]); the reference returns the RAW points
+ * of frame 0 (NaNs included, blender.py:176): the caller copies that row over (snowmocap_amd/sharded.py does).
+ * snowmocap_amd/sharded.py::blender_smooth_sharded drives the protocol; tests compare it with snowtri_blender_smooth. */
+int snowtri_blender_hold_shard_last(snowtri_ctx *ctx, int64_t T, int64_t n_persons, const double *points, const uint8_t *valid,
+                                    double *payload, void *stream);
+int snowtri_blender_hold_shard_apply(snowtri_ctx *ctx, int32_t world, int32_t rank, int64_t T, int64_t n_persons, const double *points,
+                                     const uint8_t *valid, const double *gathered, double *held, void *stream);
+int snowtri_blender_smooth_shard_local(snowtri_ctx *ctx, int64_t T, int64_t n_persons, const double *held, int first, const double *fzr,
+                                       double dt, double *y, double *end_state, void *stream);
+int snowtri_blender_smooth_shard_combine(snowtri_ctx *ctx, int32_t world, int32_t rank, int64_t n_persons, const double *gathered,
+                                         const double *fzr, double dt, double *start_state, void *stream);
+int snowtri_blender_smooth_shard_fix(snowtri_ctx *ctx, int64_t T, int64_t n_persons, int first, const double *start_state, const double *fzr,
+                                     double dt, double *y, void *stream);
+
 /* N4  Keypoint-level lens undistortion, for detections made on RAW frames (the reference undistorts whole
  * images before detection: main.py:52 cv2.undistort(frame, K, D)).  OpenCV's 5-coefficient Brown-Conrady model,
  * D[C][5] = (k1, k2, p1, p2, k3) per camera (camera_group_floor.json:53-61; Camera.D, camera.py:24,44); K as

@@ -98,6 +98,11 @@ _SIGNATURES = {
     "snowtri_blender_points": (ct.c_int, [_c_p, ct.c_int64, ct.c_int32, _c_p, ct.c_int, _c_p, _c_p, ct.c_int, _c_p]),
     "snowtri_blender_smooth": (ct.c_int, [_c_p, ct.c_int64, ct.c_int64, _c_p, _c_p, _c_p, ct.c_double, _c_p,
                                           ct.c_int, _c_p]),
+    "snowtri_blender_hold_shard_last": (ct.c_int, [_c_p, ct.c_int64, ct.c_int64, _c_p, _c_p, _c_p, _c_p]),
+    "snowtri_blender_hold_shard_apply": (ct.c_int, [_c_p, ct.c_int32, ct.c_int32, ct.c_int64, ct.c_int64, _c_p, _c_p, _c_p, _c_p, _c_p]),
+    "snowtri_blender_smooth_shard_local": (ct.c_int, [_c_p, ct.c_int64, ct.c_int64, _c_p, ct.c_int, _c_p, ct.c_double, _c_p, _c_p, _c_p]),
+    "snowtri_blender_smooth_shard_combine": (ct.c_int, [_c_p, ct.c_int32, ct.c_int32, ct.c_int64, _c_p, _c_p, ct.c_double, _c_p, _c_p]),
+    "snowtri_blender_smooth_shard_fix": (ct.c_int, [_c_p, ct.c_int64, ct.c_int64, ct.c_int, _c_p, _c_p, ct.c_double, _c_p, _c_p]),
     "snowtri_ctx_set_distortion": (ct.c_int, [_c_p, _c_p]),
     "snowtri_undistort_keypoints": (ct.c_int, [_c_p, ct.c_int64, ct.c_int32, ct.c_int32, _c_p, _c_p, ct.c_int,
                                                ct.c_int, _c_p]),

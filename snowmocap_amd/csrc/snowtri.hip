@@ -1443,8 +1443,8 @@ int snowtri_smooth_shard_combine(snowtri_ctx *ctx, int32_t world, int32_t rank, 
         dg = (const double *)ctx->in.p;
         ds = (double *)ctx->misc.p;
     }
-    hipLaunchKernelGGL(k_smooth_combine, dim3((unsigned)((n + kSmoothBlock - 1) / kSmoothBlock)), dim3(kSmoothBlock), 0, st, (int)world,
-                       (int)rank, n, dg, k, ds);
+    hipLaunchKernelGGL(k_smooth_combine<UniformCoef>, dim3((unsigned)((n + kSmoothBlock - 1) / kSmoothBlock)), dim3(kSmoothBlock), 0, st, (int)world,
+                       (int)rank, n, dg, UniformCoef{k}, ds);
     HIP_TRY(hipGetLastError());
     if (memspace == SNOWTRI_HOST) {
         HIP_TRY(hipMemcpyAsync(start_state, ds, sbytes, hipMemcpyDeviceToHost, st));
@@ -1579,6 +1579,122 @@ int snowtri_blender_points(snowtri_ctx *ctx, int64_t n, int32_t keypoint_num, co
     return SNOWTRI_OK;
 }
 
+// per-bone coefficient table of the context: rebuilt and uploaded only when (fzr, dt) change -- the common caller passes the
+// same smooth profile every time, and an upload has to drain the stream first
+static int blender_table(snowtri_ctx *ctx, hipStream_t st, const double *fzr, double dt) {
+    std::vector<double> key(fzr, fzr + 3 * kBlenderPoints);
+    key.push_back(dt);
+    if (!ctx->dBlenderTab) HIP_TRY(hipMalloc(&ctx->dBlenderTab, sizeof(SmoothCoef) * kBlenderPoints));
+    if (key != ctx->blender_key) {
+        SmoothCoef tab[kBlenderPoints];
+        for (int i = 0; i < kBlenderPoints; i++) tab[i] = smooth_coef(fzr[3 * i], fzr[3 * i + 1], fzr[3 * i + 2], dt);
+        HIP_TRY(hipStreamSynchronize(st));   // kernels of an earlier call may still read the old table
+        HIP_TRY(hipMemcpy(ctx->dBlenderTab, tab, sizeof(tab), hipMemcpyHostToDevice));
+        ctx->blender_key = key;
+    }
+    return SNOWTRI_OK;
+}
+static bool blender_shard_args_ok(snowtri_ctx *ctx, int64_t T, int64_t n_persons, const double *fzr, double dt) {
+    if (!ctx || T < 0 || n_persons < 0 || (fzr && !(dt > 0.0))) return false;
+    if (fzr)
+        for (int i = 0; i < kBlenderPoints; i++)
+            if (!(fzr[3 * i] > 0.0)) return false;
+    return true;
+}
+
+// ---- N2 on a FRAME-SHARDED track (device pointers only; include/snowtri.h describes the protocol)
+int snowtri_blender_hold_shard_last(snowtri_ctx *ctx, int64_t T, int64_t n_persons, const double *points, const uint8_t *valid,
+                                    double *payload, void *stream) {
+    if (!blender_shard_args_ok(ctx, T, n_persons, nullptr, 0.0) || !payload) return SNOWTRI_ERR_BAD_ARG;
+    const int64_t n = n_persons * kBlenderPoints * 4;
+    if (n == 0) return SNOWTRI_OK;
+    ENTER_DEVICE(ctx->device);
+    hipStream_t st = (hipStream_t)stream;
+    if (T == 0) {   // an empty shard: nothing found
+        HIP_TRY(hipMemsetAsync(payload, 0, sizeof(double) * 2 * (size_t)n, st));
+        return SNOWTRI_OK;
+    }
+    if (!points || !valid) return SNOWTRI_ERR_BAD_ARG;
+    hipLaunchKernelGGL(k_hold_block_last, smooth_grid(n, 1), dim3(256), 0, st, T, n, 4, points, valid, payload);
+    HIP_TRY(hipGetLastError());
+    return SNOWTRI_OK;
+}
+
+int snowtri_blender_hold_shard_apply(snowtri_ctx *ctx, int32_t world, int32_t rank, int64_t T, int64_t n_persons, const double *points,
+                                     const uint8_t *valid, const double *gathered, double *held, void *stream) {
+    if (!blender_shard_args_ok(ctx, T, n_persons, nullptr, 0.0) || world < 1 || rank < 0 || rank >= world) return SNOWTRI_ERR_BAD_ARG;
+    const int64_t n = n_persons * kBlenderPoints * 4;
+    if (T == 0 || n == 0) return SNOWTRI_OK;
+    if (!points || !valid || !gathered || !held) return SNOWTRI_ERR_BAD_ARG;
+    ENTER_DEVICE(ctx->device);
+    hipStream_t st = (hipStream_t)stream;
+    const int64_t nchunks = (T - 1 + kSmoothChunk - 1) / kSmoothChunk;   // the filter's chunks: frames 1 .. T-1
+    if (nchunks > 65535) return SNOWTRI_ERR_BAD_ARG;
+    const size_t cn = (size_t)std::max<int64_t>(1, nchunks) * n;
+    const size_t off_H = 4096, off_start = off_H + sizeof(double) * cn, off_Hf = off_start + sizeof(double) * cn,
+                 off_ent = (off_Hf + cn + 255) & ~(size_t)255;
+    int rc = ctx->aux.ensure(off_ent + sizeof(double) * (size_t)n);
+    if (rc) return rc;
+    char *aux = (char *)ctx->aux.p;
+    double *H = (double *)(aux + off_H), *start = (double *)(aux + off_start), *entering = (double *)(aux + off_ent);
+    uint8_t *Hf = (uint8_t *)(aux + off_Hf);
+    const dim3 g1 = smooth_grid(n, 1);
+    hipLaunchKernelGGL(k_hold_entering, g1, dim3(256), 0, st, (int)world, (int)rank, n, gathered, entering);
+    if (nchunks > 0)
+        hipLaunchKernelGGL(k_hold_last, smooth_grid(n, nchunks), dim3(256), 0, st, T, n, kSmoothChunk, 4, points, valid, H, Hf);
+    hipLaunchKernelGGL(k_hold_carry, g1, dim3(256), 0, st, n, nchunks, 4, points, valid, (const double *)H, (const uint8_t *)Hf, start,
+                       (const double *)entering);
+    hipLaunchKernelGGL(k_hold_fill, smooth_grid(n, nchunks + 1), dim3(256), 0, st, T, n, kSmoothChunk, 4, points, valid,
+                       (const double *)start, (const double *)entering, held);
+    HIP_TRY(hipGetLastError());
+    return SNOWTRI_OK;
+}
+
+int snowtri_blender_smooth_shard_local(snowtri_ctx *ctx, int64_t T, int64_t n_persons, const double *held, int first, const double *fzr,
+                                       double dt, double *y, double *end_state, void *stream) {
+    if (!fzr || !blender_shard_args_ok(ctx, T, n_persons, fzr, dt)) return SNOWTRI_ERR_BAD_ARG;
+    const int64_t n = n_persons * kBlenderPoints * 4;
+    if (T == 0 || n == 0) return SNOWTRI_OK;
+    if (!held || !y) return SNOWTRI_ERR_BAD_ARG;
+    ENTER_DEVICE(ctx->device);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = blender_table(ctx, st, fzr, dt);
+    if (rc) return rc;
+    const TableCoef k{(const SmoothCoef *)ctx->dBlenderTab, 4, kBlenderPoints};
+    return smooth_local_dev(ctx, st, T, n, held, y, first != 0, k, end_state);
+}
+
+int snowtri_blender_smooth_shard_combine(snowtri_ctx *ctx, int32_t world, int32_t rank, int64_t n_persons, const double *gathered,
+                                         const double *fzr, double dt, double *start_state, void *stream) {
+    if (!fzr || !blender_shard_args_ok(ctx, 0, n_persons, fzr, dt) || world < 1 || rank < 0 || rank >= world) return SNOWTRI_ERR_BAD_ARG;
+    const int64_t n = n_persons * kBlenderPoints * 4;
+    if (n == 0) return SNOWTRI_OK;
+    if (!gathered || !start_state) return SNOWTRI_ERR_BAD_ARG;
+    ENTER_DEVICE(ctx->device);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = blender_table(ctx, st, fzr, dt);
+    if (rc) return rc;
+    const TableCoef k{(const SmoothCoef *)ctx->dBlenderTab, 4, kBlenderPoints};
+    hipLaunchKernelGGL(k_smooth_combine<TableCoef>, dim3((unsigned)((n + kSmoothBlock - 1) / kSmoothBlock)), dim3(kSmoothBlock), 0, st, (int)world,
+                       (int)rank, n, gathered, k, start_state);
+    HIP_TRY(hipGetLastError());
+    return SNOWTRI_OK;
+}
+
+int snowtri_blender_smooth_shard_fix(snowtri_ctx *ctx, int64_t T, int64_t n_persons, int first, const double *start_state, const double *fzr,
+                                     double dt, double *y, void *stream) {
+    if (!fzr || !blender_shard_args_ok(ctx, T, n_persons, fzr, dt)) return SNOWTRI_ERR_BAD_ARG;
+    const int64_t n = n_persons * kBlenderPoints * 4;
+    if (T == 0 || n == 0) return SNOWTRI_OK;
+    if (!start_state || !y) return SNOWTRI_ERR_BAD_ARG;
+    ENTER_DEVICE(ctx->device);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = blender_table(ctx, st, fzr, dt);
+    if (rc) return rc;
+    const TableCoef k{(const SmoothCoef *)ctx->dBlenderTab, 4, kBlenderPoints};
+    return smooth_fix_dev(ctx, st, T, n, y, first != 0, start_state, k);
+}
+
 int snowtri_blender_smooth(snowtri_ctx *ctx, int64_t T, int64_t n_persons, const double *points,
                            const uint8_t *valid, const double *fzr, double dt, double *out, int memspace,
                            void *stream) {
@@ -1604,16 +1720,8 @@ int snowtri_blender_smooth(snowtri_ctx *ctx, int64_t T, int64_t n_persons, const
     char *aux = (char *)ctx->aux.p;
     // per-bone coefficient table: rebuilt and uploaded only when (fzr, dt) change -- the common caller passes the
     // same smooth profile every time, and an upload has to drain the stream first
-    std::vector<double> key(fzr, fzr + 3 * kBlenderPoints);
-    key.push_back(dt);
-    if (!ctx->dBlenderTab) HIP_TRY(hipMalloc(&ctx->dBlenderTab, sizeof(SmoothCoef) * kBlenderPoints));
-    if (key != ctx->blender_key) {
-        SmoothCoef tab[kBlenderPoints];
-        for (int i = 0; i < kBlenderPoints; i++) tab[i] = smooth_coef(fzr[3 * i], fzr[3 * i + 1], fzr[3 * i + 2], dt);
-        HIP_TRY(hipStreamSynchronize(st));   // kernels of an earlier call may still read the old table
-        HIP_TRY(hipMemcpy(ctx->dBlenderTab, tab, sizeof(tab), hipMemcpyHostToDevice));
-        ctx->blender_key = key;
-    }
+    rc = blender_table(ctx, st, fzr, dt);
+    if (rc) return rc;
     const double *dx = points;
     const uint8_t *dv = valid;
     double *dy = out;

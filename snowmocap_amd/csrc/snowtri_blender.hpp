@@ -169,10 +169,12 @@ __global__ __launch_bounds__(256) void k_hold_last(int64_t T, int64_t n, int L, 
 __global__ __launch_bounds__(256) void k_hold_carry(int64_t n, int64_t nchunks, int comps,
                                                      const double *__restrict__ x, const uint8_t *__restrict__ valid,
                                                      const double *__restrict__ H, const uint8_t *__restrict__ Hf,
-                                                     double *__restrict__ start) {
+                                                     double *__restrict__ start, const double *__restrict__ entering = nullptr) {
+    // entering (optional, [n]): the held input in front of frame 0 -- a later shard of a frame-sharded track; absent = the
+    // zeros an invalid first point of a TRACK is seeded with
     const int64_t lane = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
     if (lane >= n) return;
-    double v = valid[lane / comps] ? x[lane] : 0.0;
+    double v = valid[lane / comps] ? x[lane] : (entering ? entering[lane] : 0.0);
     constexpr int U = 8;   // chunk summaries in flight ahead of the carried value
     int64_t c = 0;
     for (; c + U <= nchunks; c += U) {
@@ -193,6 +195,59 @@ __global__ __launch_bounds__(256) void k_hold_carry(int64_t n, int64_t nchunks, 
         start[c * n + lane] = v;
         const double h = H[c * n + lane];
         v = Hf[c * n + lane] ? h : v;
+    }
+}
+
+// ---- the hold on a FRAME-SHARDED track (snowtri_blender_hold_shard_*): a shard's payload = [last valid input per lane | found
+// (1.0 / 0.0) per lane], the held input entering shard `rank` = the last valid input of the nearest shard before it that has
+// one (zeros if none: the seed of a filter whose points have all been invalid so far), and x_eff of the shard written out --
+// on x_eff the per-bone filters are PLAIN filters, i.e. the linear carry exchange of row N1 applies to them.
+__global__ __launch_bounds__(256) void k_hold_block_last(int64_t T, int64_t n, int comps, const double *__restrict__ x,
+                                                          const uint8_t *__restrict__ valid, double *__restrict__ payload) {
+    const int64_t lane = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (lane >= n) return;
+    const int64_t nv = n / comps, g = lane / comps;
+    double v = 0.0, found = 0.0;
+    for (int64_t t = T - 1; t >= 0; t--)
+        if (valid[t * nv + g]) {
+            v = x[t * n + lane];
+            found = 1.0;
+            break;
+        }
+    payload[lane] = v;
+    payload[n + lane] = found;
+}
+
+__global__ __launch_bounds__(256) void k_hold_entering(int world, int rank, int64_t n, const double *__restrict__ gathered,
+                                                        double *__restrict__ entering) {
+    const int64_t lane = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    if (lane >= n) return;
+    double v = 0.0;
+    for (int q = 0; q < rank && q < world; q++) {
+        const double *g = gathered + (int64_t)q * 2 * n;
+        if (g[n + lane] != 0.0) v = g[lane];
+    }
+    entering[lane] = v;
+}
+
+// x_eff of a shard: frame 0 from `entering`, chunk c = frames [1 + c L, ...) from start[c] (k_hold_carry); grid.y = chunks + 1
+// (the last row of blocks writes frame 0)
+__global__ __launch_bounds__(256) void k_hold_fill(int64_t T, int64_t n, int L, int comps, const double *__restrict__ x,
+                                                    const uint8_t *__restrict__ valid, const double *__restrict__ start,
+                                                    const double *__restrict__ entering, double *__restrict__ out) {
+    const int64_t lane = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+    const int64_t c = blockIdx.y, nchunks = (int64_t)gridDim.y - 1;
+    if (lane >= n) return;
+    const int64_t nv = n / comps, g = lane / comps;
+    if (c == nchunks) {
+        out[lane] = valid[g] ? x[lane] : entering[lane];
+        return;
+    }
+    const int64_t t0 = 1 + c * L, t1 = (t0 + L < T) ? t0 + L : T;
+    double v = start[c * n + lane];
+    for (int64_t t = t0; t < t1; t++) {
+        v = valid[t * nv + g] ? x[t * n + lane] : v;
+        out[t * n + lane] = v;
     }
 }
 

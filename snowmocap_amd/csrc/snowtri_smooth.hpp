@@ -225,10 +225,12 @@ __global__ __launch_bounds__(kSmoothBlock) void k_smooth_shard_end(int64_t T, in
 //     S_{q+1} = A^m start_q + E_q,   m = T_q  (T_q - 1 for the shard that starts the track: its frame 0 passes through)
 // A^m by squaring (<= 63 steps, the same for every lane).  Empty shards (T_q = 0) are skipped; no shard before `rank`
 // holds a frame -> rank starts the track and start = (x_first, 0).  (Host twin: snowmocap_amd/sharded.py::combine_carries.)
+template <typename KS>
 __global__ __launch_bounds__(kSmoothBlock) void k_smooth_combine(int world, int rank, int64_t n, const double *__restrict__ gathered,
-                                                                 SmoothCoef k, double *__restrict__ start_state) {
+                                                                 KS ks, double *__restrict__ start_state) {
     const int64_t i = (int64_t)blockIdx.x * kSmoothBlock + threadIdx.x;
     if (i >= n) return;
+    const SmoothCoef k = ks.at(i);
     const int64_t stride = 4 * n + 1;
     const double det = k.a00 * k.a11 - k.a01 * k.a10;
     const double iv0 = -k.a01 / det, iv1 = k.a00 / det;   // second column of A^-1

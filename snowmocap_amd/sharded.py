@@ -571,3 +571,86 @@ def smooth_track_sharded(x_local, f=2, z=0.75, r=0, delta_time=1 / 30, group=Non
                                               ct.c_void_p(y.data_ptr()), _lib.DEVICE, stream), "snowtri_smooth_shard_fix")
 
     return smooth_exchange(x_local, local_fn, combine_fn, fix_fn, group=group, first=first)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Row N2 on the sharded track: the per-bone filters of Human_Triangulation_Blender_Smooth (blender.py:145-178) WITHOUT
+# reassembling the control-point track.  An invalid point feeds its filter the previous input, i.e. the filters see the held
+# sequence x_eff[t] = valid[t] ? x[t] : x_eff[t-1]; on x_eff they are the plain linear filters of row N1.  So: one small
+# exchange for the hold (last valid input of every block), then the carry exchange of smooth_exchange on x_eff.
+
+def hold_exchange(pts_local, val_local, last_fn, apply_fn, group=None):
+    """x_eff of this rank's block.  pts_local [T, P, 24, 4] float64, val_local [T, P, 24] uint8.
+        last_fn(pts, val, payload)               payload[2n] = last valid input per lane | found per lane (n = P * 96)
+        apply_fn(allp, rank, pts, val, held)     held = x_eff of the block given the gathered payloads [world, 2n]
+    (the product binds them to snowtri_blender_hold_shard_last / _apply; the gloo tests bind NumPy stand-ins).  ONE all-gather."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    n = int(pts_local.shape[1]) * 24 * 4
+    payload = torch.zeros(2 * n, dtype=torch.float64, device=pts_local.device)
+    if int(pts_local.shape[0]) > 0:
+        last_fn(pts_local, val_local, payload)
+    flat = torch.empty(world * 2 * n, dtype=torch.float64, device=pts_local.device)
+    all_gather_flat(flat, payload, group=group)
+    held = torch.empty_like(pts_local)
+    if int(pts_local.shape[0]) > 0:
+        apply_fn(flat.view(world, 2 * n), rank, pts_local, val_local, held)
+    return held
+
+
+def blender_smooth_sharded(pts_local, val_local, fzr, delta_time=1 / 30, group=None, ctx=None, F_total=None):
+    """pts_local [T_r, P, 24, 4] (CUDA float64), val_local [T_r, P, 24] (CUDA uint8): this rank's frame block of a control-point
+    track sharded in frame order.  Returns the smoothed block [T_r, P, 24, 4] = the rows snowtri_blender_smooth returns for
+    these frames on the whole track (to rounding: the carries are propagated in closed form).  Two small all-gathers
+    (2n and 4n + 1 doubles per rank, n = P * 96); the track itself never moves."""
+    import ctypes as ct
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from . import _lib
+    assert pts_local.is_cuda and pts_local.dtype == torch.float64 and pts_local.is_contiguous()
+    assert val_local.is_cuda and val_local.dtype == torch.uint8 and val_local.is_contiguous()
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    T, P = int(pts_local.shape[0]), int(pts_local.shape[1])
+    first = None
+    if F_total is not None:
+        lo, hi, _ = shard_bounds(int(F_total), world, rank)
+        if hi - lo != T:
+            raise ValueError(f"blender_smooth_sharded: rank {rank} holds {T} frames, shard_bounds gives it [{lo}, {hi})")
+        first = lo == 0 and hi > lo
+    ctx = ctx or _lib.scratch_context(pts_local.device.index)
+    stream = ct.c_void_p(torch.cuda.current_stream(pts_local.device).cuda_stream)
+    L = _lib.lib()
+    fzr = np.ascontiguousarray(fzr, dtype=np.float64).reshape(24, 3)
+    dt = float(delta_time)
+
+    def last_fn(p, v, payload):
+        _lib.check(L.snowtri_blender_hold_shard_last(ctx.handle, int(p.shape[0]), P, ct.c_void_p(p.data_ptr()), ct.c_void_p(v.data_ptr()),
+                                                     ct.c_void_p(payload.data_ptr()), stream), "snowtri_blender_hold_shard_last")
+
+    def apply_fn(allp, rk, p, v, held):
+        _lib.check(L.snowtri_blender_hold_shard_apply(ctx.handle, world, rk, int(p.shape[0]), P, ct.c_void_p(p.data_ptr()),
+                                                      ct.c_void_p(v.data_ptr()), ct.c_void_p(allp.data_ptr()), ct.c_void_p(held.data_ptr()),
+                                                      stream), "snowtri_blender_hold_shard_apply")
+
+    held = hold_exchange(pts_local, val_local, last_fn, apply_fn, group=group)
+
+    def local_fn(x, is_first, y, payload):
+        _lib.check(L.snowtri_blender_smooth_shard_local(ctx.handle, int(x.shape[0]), P, ct.c_void_p(x.data_ptr()), 1 if is_first else 0,
+                                                        _lib.ptr(fzr), dt, ct.c_void_p(y.data_ptr()), ct.c_void_p(payload.data_ptr()), stream),
+                   "snowtri_blender_smooth_shard_local")
+
+    def combine_fn(allp, rk, start):
+        _lib.check(L.snowtri_blender_smooth_shard_combine(ctx.handle, world, rk, P, ct.c_void_p(allp.data_ptr()), _lib.ptr(fzr), dt,
+                                                          ct.c_void_p(start.data_ptr()), stream), "snowtri_blender_smooth_shard_combine")
+
+    def fix_fn(y, is_first, start):
+        _lib.check(L.snowtri_blender_smooth_shard_fix(ctx.handle, int(y.shape[0]), P, 1 if is_first else 0, ct.c_void_p(start.data_ptr()),
+                                                      _lib.ptr(fzr), dt, ct.c_void_p(y.data_ptr()), stream), "snowtri_blender_smooth_shard_fix")
+
+    y = smooth_exchange(held, local_fn, combine_fn, fix_fn, group=group, first=first)
+    is_first = (rank == 0) if first is None else first
+    if is_first and T > 0:
+        y[0].copy_(pts_local[0])       # frame 0 of the track is returned as given, NaNs included (blender.py:176)
+    return y

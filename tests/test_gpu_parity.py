@@ -1103,6 +1103,76 @@ def test_fast_path_other_camera_counts(api, C):
             assert_xyz_close(out["xyzs"][f, :m, :, :3], ref["xyz"][f, :m], XYZ_FUSED, score_ref=ref["kscore"][f, :m])
 
 
+def test_sharded_blender_smoothing_kernels_with_hold_and_carry_exchange(api):
+    """snowtri_blender_hold_shard_last / _apply and snowtri_blender_smooth_shard_local / _combine / _fix on three uneven frame
+    blocks (what blender_smooth_sharded does around its two all-gathers) == snowtri_blender_smooth on the whole track, on
+    the reference's own control-point track with knocked-out points (fixture G8, invalid FIRST frame included) and on a
+    long random track (several 256-frame chunks per block, a gap longer than a block)."""
+    import ctypes as ct
+    import torch
+    from snowmocap_amd import _lib, blender as bl
+    z = np.load(f"{GOLDEN}/g8_blender_track.npz")
+    rng = np.random.default_rng(12)
+    T2, P2 = 1500, 2
+    pts2 = np.cumsum(rng.normal(0, 0.01, size=(T2, P2, 24, 4)), axis=0) + rng.uniform(-1, 1, size=(1, P2, 24, 4))
+    val2 = (rng.uniform(size=(T2, P2, 24)) > 0.2).astype(np.uint8)
+    val2[0, 1, :6] = 0
+    val2[300:1100, 0, 3] = 0
+    val2[:, 1, 11] = 0
+    fzr2 = np.stack([rng.uniform(1.0, 4.0, 24), rng.uniform(0.4, 1.2, 24), rng.uniform(-0.5, 1.0, 24)], axis=1)
+    ctx = _lib.scratch_context()
+    L = _lib.lib()
+    dev = torch.device("cuda", 0)
+    st = ct.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    for pts, val, fzr, dt, cuts, want, tol in (
+            (z["raw"], z["valid"], z["fzr"], float(z["dt"]), (0, 31, 32, 80), z["smoothed"], 1e-11),
+            (pts2, val2, fzr2, 1 / 30, (0, 520, 1190, 1500), None, 1e-10)):
+        T, P = pts.shape[0], pts.shape[1]
+        n = P * 96
+        if want is None:
+            want = bl.blender_smooth_track(pts, val, {nm: list(fzr[i]) for i, nm in enumerate(bl.CONTROL_POINT_NAMES)}, dt) \
+                if hasattr(bl, "blender_smooth_track") else None
+        fz = np.ascontiguousarray(fzr, dtype=np.float64)
+        blocks = [(cuts[i], cuts[i + 1]) for i in range(len(cuts) - 1)]
+        world = len(blocks)
+        dp = [torch.from_numpy(np.ascontiguousarray(pts[a:b])).to(dev) for a, b in blocks]
+        dv = [torch.from_numpy(np.ascontiguousarray(val[a:b])).to(dev) for a, b in blocks]
+        hold = torch.zeros((world, 2 * n), dtype=torch.float64, device=dev)
+        for q in range(world):
+            _lib.check(L.snowtri_blender_hold_shard_last(ctx.handle, dp[q].shape[0], P, ct.c_void_p(dp[q].data_ptr()), ct.c_void_p(dv[q].data_ptr()),
+                                                         ct.c_void_p(hold[q].data_ptr()), st), "hold_last")
+        held = [torch.empty_like(x) for x in dp]
+        for q in range(world):
+            _lib.check(L.snowtri_blender_hold_shard_apply(ctx.handle, world, q, dp[q].shape[0], P, ct.c_void_p(dp[q].data_ptr()),
+                                                          ct.c_void_p(dv[q].data_ptr()), ct.c_void_p(hold.data_ptr()), ct.c_void_p(held[q].data_ptr()), st), "hold_apply")
+        ys = [torch.empty_like(x) for x in dp]
+        gathered = torch.zeros((world, 4 * n + 1), dtype=torch.float64, device=dev)
+        for q in range(world):
+            Tq = dp[q].shape[0]
+            _lib.check(L.snowtri_blender_smooth_shard_local(ctx.handle, Tq, P, ct.c_void_p(held[q].data_ptr()), 1 if q == 0 else 0, _lib.ptr(fz), dt,
+                                                            ct.c_void_p(ys[q].data_ptr()), ct.c_void_p(gathered[q].data_ptr()), st), "local")
+            gathered[q, 2 * n:3 * n] = held[q][0].reshape(-1)
+            gathered[q, 3 * n:4 * n] = held[q][-1].reshape(-1)
+            gathered[q, 4 * n] = Tq
+        for q in range(world):
+            start = torch.empty((n, 2), dtype=torch.float64, device=dev)
+            _lib.check(L.snowtri_blender_smooth_shard_combine(ctx.handle, world, q, P, ct.c_void_p(gathered.data_ptr()), _lib.ptr(fz), dt,
+                                                              ct.c_void_p(start.data_ptr()), st), "combine")
+            _lib.check(L.snowtri_blender_smooth_shard_fix(ctx.handle, dp[q].shape[0], P, 1 if q == 0 else 0, ct.c_void_p(start.data_ptr()),
+                                                          _lib.ptr(fz), dt, ct.c_void_p(ys[q].data_ptr()), st), "fix")
+        ys[0][0] = dp[0][0]
+        got = torch.cat(ys).cpu().numpy()
+        # the whole track through the unsharded entry on the device
+        full_p, full_v = torch.from_numpy(np.ascontiguousarray(pts)).to(dev), torch.from_numpy(np.ascontiguousarray(val)).to(dev)
+        whole = torch.empty_like(full_p)
+        _lib.check(L.snowtri_blender_smooth(ctx.handle, T, P, ct.c_void_p(full_p.data_ptr()), ct.c_void_p(full_v.data_ptr()), _lib.ptr(fz), dt,
+                                            ct.c_void_p(whole.data_ptr()), _lib.DEVICE, st), "snowtri_blender_smooth")
+        torch.cuda.synchronize(dev)
+        np.testing.assert_allclose(got, whole.cpu().numpy(), rtol=0, atol=tol, equal_nan=True)
+        if want is not None and want.shape == got.shape:
+            np.testing.assert_allclose(got, want, rtol=0, atol=tol * 10, equal_nan=True)
+
+
 def test_sharded_smoothing_kernels_with_carry_exchange(api):
     """snowtri_smooth_shard_local / _fix on three uneven frame blocks + combine_carries (what
     smooth_track_sharded does around its one all-gather) == the sequential oracle on the whole track."""

@@ -249,6 +249,112 @@ def test_eight_rank_sharded_smoothing_exchange_matches_the_sequential_filter(tmp
     np.testing.assert_allclose(got, want, rtol=0, atol=1e-11)
 
 
+def _blender_worker(rank, port, T, P, tmp):
+    """hold_exchange + smooth_exchange (what blender_smooth_sharded runs around the C ABI) with NumPy twins of the kernels and
+    PER-LANE coefficients: lane = (person, control point, component), coefficients per control point."""
+    _init(rank, port)
+    from snowmocap_amd.sharded import combine_carries, hold_exchange, smooth_exchange
+    rng = np.random.default_rng(21)
+    pts = np.cumsum(rng.normal(0, 0.01, size=(T, P, 24, 4)), axis=0) + rng.uniform(-1, 1, size=(1, P, 24, 4))
+    val = (rng.uniform(size=(T, P, 24)) > 0.25).astype(np.uint8)
+    val[0, 0, :5] = 0                         # invalid points in the very first frame: seeded with zeros
+    val[:, P - 1, 7] = 0                      # a point that is never valid
+    val[T // 3: 2 * T // 3, 0, 9] = 0         # a gap longer than a block
+    fzr = np.stack([rng.uniform(1.0, 4.0, 24), rng.uniform(0.4, 1.2, 24), rng.uniform(-0.5, 1.0, 24)], axis=1)
+    dt = 1 / 30
+    n = P * 96
+    coef = [_coeffs(*fzr[b], dt) for b in range(24)]
+    lane_b = (np.arange(n) // 4) % 24
+    A = np.stack([coef[b][0] for b in lane_b])            # [n, 2, 2]
+    cx = np.array([coef[b][1] for b in lane_b])
+    cxd = np.array([coef[b][2] for b in lane_b])
+    lo, hi, per = shard_bounds(T, WORLD, rank)
+    grp = np.arange(n) // 4                               # validity group of a lane
+
+    def last_fn(p, v, payload):
+        pv, vv = p.numpy().reshape(-1, n), v.numpy().reshape(-1, n // 4)
+        out = np.zeros(2 * n)
+        for ln in range(n):
+            ok = np.nonzero(vv[:, grp[ln]])[0]
+            if ok.size:
+                out[ln], out[n + ln] = pv[ok[-1], ln], 1.0
+        payload.copy_(torch.from_numpy(out))
+
+    def apply_fn(allp, rk, p, v, held):
+        a = allp.numpy()
+        ent = np.zeros(n)
+        for q in range(rk):
+            f = a[q, n:] != 0
+            ent[f] = a[q, :n][f]
+        pv, vv = p.numpy().reshape(-1, n), v.numpy().reshape(-1, n // 4)
+        h = np.empty_like(pv)
+        cur = ent
+        for t_ in range(pv.shape[0]):
+            cur = np.where(vv[t_, grp] != 0, pv[t_], cur)
+            h[t_] = cur
+        held.copy_(torch.from_numpy(h.reshape(held.shape)))
+
+    held = hold_exchange(torch.from_numpy(pts[lo:hi].copy()), torch.from_numpy(val[lo:hi].copy()), last_fn, apply_fn)
+
+    def local_fn(xl, first, y, payload):
+        xv = xl.numpy().reshape(-1, n)
+        s_ = np.zeros((n, 2))
+        yv = np.zeros_like(xv)
+        if first:
+            yv[0] = xv[0]
+        xp = xv[0].copy()
+        for t_ in range(1 if first else 0, xv.shape[0]):
+            c = cx * xv[t_] + cxd * (xv[t_] - xp)
+            xp = xv[t_]
+            s_ = np.einsum("nij,nj->ni", A, s_) + np.stack([np.zeros(n), c], axis=1)
+            yv[t_] = s_[:, 0]
+        y.copy_(torch.from_numpy(yv.reshape(y.shape)))
+        payload[: 2 * n] = torch.from_numpy(s_.reshape(-1))
+
+    def combine_fn(allp, rk, start):
+        a = allp.numpy()
+        out = np.zeros((n, 2))
+        for ln in range(n):                   # lane by lane with the lane's own A (combine_carries is the one-coefficient twin)
+            pay = [(a[q, 2 * ln:2 * ln + 2].reshape(1, 2), a[q, 2 * n + ln:2 * n + ln + 1], a[q, 3 * n + ln:3 * n + ln + 1], a[q, 4 * n])
+                   for q in range(WORLD)]
+            out[ln] = combine_carries(pay, rk, A[ln], cxd[ln])[0]
+        start.copy_(torch.from_numpy(out))
+
+    def fix_fn(y, first, start):
+        v = start.numpy().copy()
+        yv = y.numpy().reshape(-1, n)
+        for t_ in range(1 if first else 0, yv.shape[0]):
+            v = np.einsum("nij,nj->ni", A, v)
+            yv[t_] += v[:, 0]
+
+    y = smooth_exchange(held, local_fn, combine_fn, fix_fn)
+    if rank == 0 and hi > lo:
+        y[0] = torch.from_numpy(pts[0])
+    np.save(os.path.join(tmp, f"y{rank}.npy"), y.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("T,P", [(41, 2), (100, 1), (5, 1)])
+def test_eight_rank_sharded_blender_smoothing_matches_the_sequential_filters(tmp_path, T, P):
+    """Row N2 sharded (round-4 review, item 4b): hold exchange (last valid input of every block) + carry exchange with per-bone
+    coefficients, over 8 gloo ranks with empty trailing blocks, invalid first points, a never-valid point and a gap longer
+    than a block -- against oracle/blender.py::smooth_track (the reference's frame-by-frame filters, pinned on G6 / G8)."""
+    from oracle import blender as ob
+    mp.spawn(_blender_worker, args=(_port(T + 31 * P), T, P, str(tmp_path)), nprocs=WORLD, join=True)
+    got = np.concatenate([np.load(tmp_path / f"y{r}.npy") for r in range(WORLD)])
+    rng = np.random.default_rng(21)
+    pts = np.cumsum(rng.normal(0, 0.01, size=(T, P, 24, 4)), axis=0) + rng.uniform(-1, 1, size=(1, P, 24, 4))
+    val = (rng.uniform(size=(T, P, 24)) > 0.25).astype(np.uint8)
+    val[0, 0, :5] = 0
+    val[:, P - 1, 7] = 0
+    val[T // 3: 2 * T // 3, 0, 9] = 0
+    fzr = np.stack([rng.uniform(1.0, 4.0, 24), rng.uniform(0.4, 1.2, 24), rng.uniform(-0.5, 1.0, 24)], axis=1)
+    want = ob.smooth_track(pts, val, fzr, 1 / 30)
+    assert got.shape == want.shape
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-10)
+
+
 def test_bench_dry_run_with_eight_ranks():
     """`python bench.py --gpus 8 --dry-run`: the launcher logic and bench's gather leg (gather_track_chunked) with the rank
     count the driver's SCALE run uses."""
