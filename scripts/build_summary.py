@@ -154,7 +154,7 @@ def build(tag):
 
 
 if __name__ == "__main__":
-    tag = sys.argv[1] if len(sys.argv) > 1 else "r04"
+    tag = sys.argv[1] if len(sys.argv) > 1 else "r05"
     out = build(tag)
     json.dump(out, open(os.path.join(ROOT, "profiles", tag, "summary.json"), "w"), indent=1, sort_keys=True)
     print("profiles/%s/summary.json written" % tag)

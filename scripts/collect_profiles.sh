@@ -1,6 +1,6 @@
 #!/bin/bash
 # Copy the summaries of scripts/profile.sh <tag> + scripts/pmc_multi.sh (under gpurun_out/) into profiles/<tag>/.
-TAG=${1:-r04}; SRC=gpurun_out/prof_$TAG; DST=profiles/$TAG; mkdir -p $DST
+TAG=${1:-r05}; SRC=gpurun_out/prof_$TAG; DST=profiles/$TAG; mkdir -p $DST
 cp $SRC/summary.txt $SRC/bench_lines.jsonl $SRC/next_rows.jsonl $SRC/pmc_traffic.json $DST/
 cp $SRC/kernel_stats_stats.csv $DST/kernel_stats_cfg2_10k.csv
 cp $SRC/kernel_stats_stats_large.csv $DST/kernel_stats_large_2M.csv
@@ -12,6 +12,9 @@ cp gpurun_out/pmc_multi/kernel_stats_cfg3.csv $DST/kernel_stats_multi_cfg3_8x4_1
 cp gpurun_out/pmc_multi/kernel_stats_cfg5.csv $DST/kernel_stats_multi_cfg5_16x8_12000.csv
 [ -f gpurun_out/pmc_multi/kernel_stats_cfg3_f64out.csv ] && cp gpurun_out/pmc_multi/kernel_stats_cfg3_f64out.csv $DST/kernel_stats_multi_cfg3_8x4_10000_f64out.csv
 grep "^a\|^b\|^{" gpurun_out/pmc_multi_stdout.txt > $DST/multi_person_counters.txt
+[ -f gpurun_out/pmc_multi/single_rigs.txt ] && grep "k_fused\|raw:" gpurun_out/pmc_multi/single_rigs.txt > $DST/single_rigs_counters.txt
+[ -f gpurun_out/pmc_multi/kernel_stats_single_rigs.csv ] && cp gpurun_out/pmc_multi/kernel_stats_single_rigs.csv $DST/kernel_stats_single_rigs.csv
+[ -f profiles/pmc_multi.json ] && cp profiles/pmc_multi.json $DST/pmc_multi.json
 fi
 cp $SRC/bench_default.json $SRC/bench_steps20.json $SRC/large_launches.json $DST/
 python - <<PY

@@ -12,7 +12,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = "r04"
+TAG = "r05"
 DOCS = {"README.md": ["headline"], "DESIGN.md": ["headline", "detail"], os.path.join("profiles", "README.md"): ["detail"]}
 
 
@@ -90,6 +90,9 @@ def headline(s):
         ("8 x 4 x 10 000 frames with float64 outputs (the reference's output type), ONE call",
          ("%s frames/s (%.3f ms; float32: %.3f ms), same route" % (e(b["extra"][2]["frames_per_s"]), b["extra"][2]["kernel_ms"], b["extra"][0]["kernel_ms"]))
          if len(b["extra"]) > 2 else "-", "- (k_frame_recompute then)"),
+        ("one detection per camera, other shapes, 10 000 frames per call (`extra_workloads[3..]`; fp64-vector roof against the reference's 90 flop per pair solve + 15 per ray)",
+         "; ".join("%s: %.1f us = %s joints/s, **%.3f**" % (x["workload"].split(" x 133")[0].replace(" cameras x 1 person", " x 1") + (" float64 out" if "double" in x["kernel"] or "k_associate" in x["kernel"] else ""),
+                                                        x["kernel_ms"] * 1e3, e(x["frames_per_s"] * 133), x["frac"]) for x in b["extra"][3:]) or "-", "-"),
         ("per-frame API (`main.py:50-71,106`, floor rig, 300 frames one by one)",
          "%.0f us per frame through the reference-named calls, %.0f us as one F = 1 fused host call (reference: %.1f ms per frame)"
          % (b["per_frame"]["api_sequence_us"], b["per_frame"]["fused_host_call_us"], b["per_frame"]["reference_ms"]),
@@ -98,7 +101,7 @@ def headline(s):
          "%s joints/s; GPU batch vs oracle %.1e m" % (e(b["cpu"]["value"]), b["cpu"]["gpu_vs_oracle_max_abs_m"]),
          drv(lambda d: "%s joints/s" % e(d["cpu"]["value"]))),
     ]
-    out = ["| Quantity | Round 4 (`profiles/%s/`, our boxes) | Driver's record `%s` (round-%s sources) |"
+    out = ["| Quantity | Round 5 (`profiles/%s/`, our boxes) | Driver's record `%s` (round-%s sources) |"
            % (s["tag"], (d or {}).get("file", "-"), ((d or {}).get("file", "BENCH_r??")[7:9])), "|---|---|---|"]
     out += ["| %s | %s | %s |" % r for r in rows]
     return "\n".join(out)

@@ -30,5 +30,10 @@ for tag in ("a3", "b3", "a5", "b5"):
             print(tag, g, {k: "%.4g" % (sum(v) / len(v)) for k, v in c.items()}, "n=%d" % len(next(iter(c.values()))))
 PY
 grep -h "^{" $OUT/a3.log $OUT/a5.log | head -8
+# ONE detection per camera on 6 and 8 cameras (the lean kernels on the complete-graph item) and the headline rig with float64
+# outputs: counters + stats of scripts/bench_single_rigs.py (10 000 and 200 000 frames)
+bash scripts/pmc_any.sh single "k_fused_lean|k_fused_single" -- python scripts/bench_single_rigs.py --cams=6,8 --frames=10000,200000 --calls=20 > $OUT/single_rigs.txt 2>&1
+grep -v "^    raw" $OUT/single_rigs.txt | grep "k_fused"
+cp $ROOT/gpurun_out/pmc_single/kernel_stats.csv $OUT/kernel_stats_single_rigs.csv 2>/dev/null
 for t in a3 b3 a5 b5; do mkdir -p $OUT/csv; cp $(find $OUT/$t -name "*counter_collection.csv" | head -1) $OUT/csv/pmc_$t.csv 2>/dev/null; done
 rm -rf $OUT/a3 $OUT/b3 $OUT/a5 $OUT/b5 $OUT/s3 $OUT/s5

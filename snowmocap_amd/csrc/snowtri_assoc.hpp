@@ -26,13 +26,19 @@ namespace snowtri {
 constexpr int kSumsHeadBytes = 64;
 // workgroup shapes (threads, waves per SIMD the registers must allow, records of the coming chunk a thread holds in
 // registers): 256 threads x 3 workgroups per CU for the small rigs, 512 x 2 or 1024 x 1 for the large ones
-constexpr int kSumsWaves256 = 3;   // (4 waves per SIMD = 128 registers: the 2 x 4 tile spills, 8 x 4 measured 1027 us against 729)
+#ifndef SNOWTRI_SUMS_WAVES256
+#define SNOWTRI_SUMS_WAVES256 3
+#endif
+#ifndef SNOWTRI_SUMS_GA
+#define SNOWTRI_SUMS_GA 2
+#endif
+constexpr int kSumsWaves256 = SNOWTRI_SUMS_WAVES256;   // (4 waves per SIMD = 128 registers: the 2 x 4 tile spills, 8 x 4 measured 1027 us against 729)
 template <int THREADS>
 struct SumsShape {
     static constexpr int kWavesPerSimd = THREADS == 256 ? kSumsWaves256 : 4;
     static constexpr int kPrefetch = THREADS == 256 ? 3 : 2;
 };
-constexpr int kSumsGA = 2;   // persons of the FIRST camera per tile (when the person count is even)
+constexpr int kSumsGA = SNOWTRI_SUMS_GA;   // persons of the FIRST camera per tile (when the person count is even)
 
 __host__ __device__ inline size_t sums_arena_offset(int C, int npairs) {
     return ((size_t)kSumsHeadBytes + (size_t)4 * C + (size_t)32 * npairs + (size_t)72 * C + 15) & ~(size_t)15;
