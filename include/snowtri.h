@@ -199,7 +199,14 @@ int snowtri_condense_resident(snowtri_ctx *ctx, int64_t token, const snowtri_par
  *   (SNOWTRI_DEVICE: kpts aligned to its element size, out_xyzs to 16 bytes -- else SNOWTRI_ERR_BAD_ARG)
  *   out_pscore [F][Pout_max] of out_dtype (may be NULL), out_count[F] int32, out_flags[F] (may be NULL)
  * Entries of persons >= out_count[f] are zero-filled.  Returns OK / ERR_SINGULAR / ERR_OVERFLOW only
- * for SNOWTRI_HOST calls (device calls are asynchronous: inspect out_flags). */
+ * for SNOWTRI_HOST calls (device calls are asynchronous: inspect out_flags).
+ * Accuracy: all arithmetic is fp64; SNOWTRI_F64 outputs are within 1e-8 m of the reference's.  SNOWTRI_F32 outputs are the
+ * fp64 results rounded to float32, i.e. exact to ONE UNIT IN THE LAST PLACE OF THE VALUE: 6e-8 relative -- below the 1e-4 m
+ * of the project's parity bar only for coordinates under ~840 m.  Real joints are metres from the origin (error < 1e-6 m);
+ * the ghost clusters near-parallel rays produce under a wide condense_distance_tol can lie hundreds of metres out, where
+ * a float32 cannot hold 1e-4 m: ask for SNOWTRI_F64 outputs if such points matter.
+ * SNOWTRI_FLAG_SINGULAR: a pair is exactly singular when a c == b b in separately rounded products (a = hm.hm, b = hm.hs,
+ * c = hs.hs: what the reference's LU of [[a, b], [b, c]] sees for equal rays, np.linalg.inv raises, triangulation.py:26). */
 int snowtri_triangulate_condense(snowtri_ctx *ctx, int64_t F, int32_t Pmax, int32_t J,
                                  const void *kpts, int in_dtype, const int32_t *n_persons,
                                  const snowtri_params *params, int method, int32_t Pout_max,

@@ -27,7 +27,10 @@ BYTES_PER_FRAME = 8512            # 4 cameras x 1 person: 12 C P J in + 16 Pout 
 def short(name):
     """snowtri kernel name without its argument list."""
     m = re.search(r"snowtri::(\w+(?:<[^(]*>)?)\(", name)
-    return m.group(1).replace(" ", "") if m else name[:60]
+    n = m.group(1).replace(" ", "") if m else name[:60]
+    # the lean kernels carry the output type as a defaulted fourth template argument since round 5: the float32 instances keep
+    # the name snowtri_last_kernel_names (and every earlier record) gives them
+    return re.sub(r"^(k_fused_lean(?:_coop)?<\d+,\w+,\d+),float>$", r"\1>", n)
 
 
 def kernel_stats(path):
@@ -66,15 +69,17 @@ def multi_counters(path):
 
 def bench_digest(line):
     d = json.loads(line)
+    r, rep = d.get("roofline") or {}, d.get("repeats") or {}     # (the driver's record keeps the contract keys only: the rest may be absent)
     out = {"value": d["value"], "ms_per_step": d["ms_per_step"], "steps": d["steps"], "warmup": d["warmup"],
-           "ms_per_step_min": d["repeats"]["ms_per_step_min"], "ms_per_step_max": d["repeats"]["ms_per_step_max"],
-           "roofline_frac": d["roofline"]["frac"], "roofline_kernel": d["roofline"]["kernel"],
-           "kernel_us_mean": d["roofline"]["kernel_ms_mean"] * 1e3, "kernel_us_min": d["roofline"]["kernel_ms_min"] * 1e3,
-           "kernel_us_bracketed": d["roofline"].get("kernel_ms_mean_bracketed", 0.0) * 1e3,
-           "kernel_us_step_one_stream": d["roofline"].get("kernel_ms_step_one_stream", 0.0) * 1e3,
-           "copy_GBs": d["roofline"].get("measured_device_copy_GBs"), "frac_of_copy": d["roofline"].get("frac_of_measured_copy"),
-           "frac_bracketed": d["roofline"].get("frac_bracketed"), "frac_step_one_stream": d["roofline"].get("frac_step_one_stream"),
-           "roofline_traffic": d["roofline"]["traffic"], "roofline_region_frac": d["roofline_region"]["frac"],
+           "ms_per_step_min": rep.get("ms_per_step_min", d["ms_per_step"]), "ms_per_step_max": rep.get("ms_per_step_max", d["ms_per_step"]),
+           "roofline_frac": r.get("frac"), "roofline_kernel": r.get("kernel"),
+           "kernel_us_mean": (r.get("kernel_ms_mean") or 0.0) * 1e3, "kernel_us_min": (r.get("kernel_ms_min") or 0.0) * 1e3,
+           "kernel_us_overlapped": (r.get("kernel_ms_mean_overlapped") or 0.0) * 1e3,
+           "kernel_us_bracketed": (r.get("kernel_ms_mean_bracketed") or 0.0) * 1e3,
+           "kernel_us_step_one_stream": (r.get("kernel_ms_step_one_stream") or 0.0) * 1e3,
+           "copy_GBs": r.get("measured_device_copy_GBs"), "frac_of_copy": r.get("frac_of_measured_copy"),
+           "frac_bracketed": r.get("frac_bracketed"), "frac_step_one_stream": r.get("frac_step_one_stream"),
+           "roofline_traffic": r.get("traffic"), "roofline_region_frac": (d.get("roofline_region") or {}).get("frac"),
            "valu_per_64": (d.get("fp64_valu_issue") or {}).get("valu_insts_per_64_joints")}
     if d.get("large_batch"):
         out["large"] = {"frames": d["large_batch"]["frames"], "kernel_ms": d["large_batch"]["kernel_ms"], "frac": d["large_batch"]["frac"],

@@ -231,6 +231,30 @@ def main():
         b.close()
         del kp, npers, out
 
+    # ---- one detection per camera on 8 cameras (the lean kernel on the complete-graph item: 28 pair solves per joint)
+    rng = np.random.default_rng(8)
+    K, R, t = synth.ring_rig(8)
+    X = synth.make_people(rng, 500, 1)
+    kp8, np8 = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=1.0, score_range=(3.5, 8.0))
+    F8 = 200000
+    kp8 = torch.from_numpy(kp8).to(dev).repeat(F8 // 500, 1, 1, 1, 1).contiguous()
+    np8 = torch.from_numpy(np8).to(dev).repeat(F8 // 500, 1).contiguous()
+    b8 = BatchTriangulator(K, R, t, synth.default_thresholds(), pout_max=1, out_dtype=np.float32)
+    out8 = b8.run_torch(kp8, np8)
+    torch.cuda.synchronize(dev)
+
+    def bench_single8(s):
+        n, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < s:
+            for _ in range(8):
+                b8.run_torch(kp8, np8, out=out8)
+            torch.cuda.synchronize(dev)
+            n += 8
+        dt = time.perf_counter() - t0
+        return {"joints_per_s": n * F8 * J / dt, "ms_per_call": dt / n * 1e3, "frac_of_fp64_peak": n * F8 * J * (28 * 90 + 8 * 15) / dt / 78.6e12}
+    run("single_8x1_200k", bench_single8, "k_fused_lean<8,float,133>: 200 000-frame launches back to back on one stream")
+    b8.close()
+
     sampler.stop = True
     sampler.join(timeout=2.0)
     with open(os.path.join(OUT, "samples.csv"), "w") as fh:

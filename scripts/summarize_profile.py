@@ -59,7 +59,8 @@ try:
         scale_r, scale_w = known[0] / (fr_cal * 1024.0), known[1] / (wr_cal * 1024.0)
         import re
         kfull = next(k for k in summary["pmc_fetch"] if "k_fused_lean" in k)
-        kshort = re.search(r"(k_fused_lean\w*<[^(]*>)", kfull).group(1).replace(" ", "")      # what snowtri_last_kernel_names() reports
+        kshort = re.search(r"(k_fused_lean\w*<[^(]*>)", kfull).group(1).replace(" ", "")      # what snowtri_last_kernel_names() reports ...
+        kshort = re.sub(r"^(k_fused_lean(?:_coop)?<\d+,\w+,\d+),float>$", r"\1>", kshort)   # ... which omits the defaulted output type of the float32 instances
         traffic = {"kernel": kshort, "frames_per_launch": known[2],
                    "workload": "BASELINE configs[1]: %d frames per launch" % known[2],
                    "FETCH_SIZE_KB_raw": fr_k, "WRITE_SIZE_KB_raw": wr_k,
