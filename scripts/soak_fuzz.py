@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Dev aid (GPU box): soak run of the randomised parity sweeps of tests/test_gpu_parity.py with many seeds.
-usage: python scripts/soak_fuzz.py <rounds> [first_round]   -- every round re-seeds each sweep (round r: seed * 100003 + r + 1);
+usage: python scripts/soak_fuzz.py <rounds> [first_round] [--only=<part of a sweep's name>]   -- every round re-seeds each sweep (round r: seed * 100003 + r + 1);
 the first failures are printed.  first_round continues an earlier soak with fresh seeds."""
 import os, sys, time, traceback
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -10,6 +10,7 @@ import snowmocap_amd as api
 import test_gpu_parity as T
 import test_gpu_lean as TL
 import test_gpu_handover as TH
+import test_gpu_single_rigs as TS
 
 real_rng = np.random.default_rng
 
@@ -24,8 +25,9 @@ class MP:                        # monkeypatch stand-in for the hand-over sweep
     def delenv(self, k): os.environ.pop(k, None)
 
 
-rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 20
-first = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+_pos = [a for a in sys.argv[1:] if not a.startswith("--")]
+rounds = int(_pos[0]) if len(_pos) > 0 else 20
+first = int(_pos[1]) if len(_pos) > 1 else 0
 sweeps = [("small_rigs auto", lambda e: T.test_random_small_rigs_against_oracle(api, "auto", e)),
           ("small_rigs spill", lambda e: T.test_random_small_rigs_against_oracle(api, "spill", e)),
           ("special auto", lambda e: T.test_random_special_values_against_oracle(api, "auto", e)),
@@ -37,7 +39,11 @@ sweeps = [("small_rigs auto", lambda e: T.test_random_small_rigs_against_oracle(
           ("lean special", lambda e: TL.test_lean_special_values(api)),
           ("handover", lambda e: TH.test_random_rigs_with_handover_against_oracle_and_phase3(api, MP())),
           ("handover wide rigs", lambda e: TH.test_random_wide_rigs_against_oracle_and_phase3(api, MP())),
-          ("float64 outputs / keypoint_num on the streaming route", lambda e: TH.test_random_rigs_float64_outputs_and_keypoint_num(api, MP()))]
+          ("float64 outputs / keypoint_num on the streaming route", lambda e: TH.test_random_rigs_float64_outputs_and_keypoint_num(api, MP())),
+          ("single-person rigs of 5-16 cameras, every route", lambda e: TS.test_random_single_person_rigs_on_every_route(api))]
+only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only=")]
+if only:
+    sweeps = [sw for sw in sweeps if any(o in sw[0] for o in only)]
 fails = 0
 t0 = time.time()
 for r in range(first, first + rounds):

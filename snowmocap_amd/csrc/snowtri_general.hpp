@@ -963,9 +963,22 @@ __global__ __launch_bounds__(kBlock, kRecomputeWaves) void k_frame_recompute(int
                                 const uint32_t n0 = (mi + 2 * G < size) ? member_word(m0 + mi + 2 * G) : 0u;   // in flight during the solves
                                 const uint32_t n1 = (mi + 3 * G < size) ? member_word(m0 + mi + 3 * G) : n0;
                                 const Half h0 = front(w0), h1 = front(w1);   // (w1 repeats w0 when the cluster has no second member left)
-                                const double run = rcp_nr2(h0.det * h1.det);
-                                back(h0, run * h1.det, true);
-                                back(h1, run * h0.det, two);
+                                // one reciprocal for the two members -- unless their determinants' product is not a normal number
+                                // (a NaN ray, a singular or wildly conditioned pair): the shared reciprocal would hand the one
+                                // member's NaN to the OTHER, healthy member (found by the round-5 sweep: a NaN pixel whose
+                                // confidence is gated poisoned its partner's score); then each member takes its own
+                                const double prod = h0.det * h1.det;
+                                double i0, i1;
+                                if (fabs(prod) > 1e-250 && fabs(prod) < 1e250) {
+                                    const double run = rcp_nr2(prod);
+                                    i0 = run * h1.det;
+                                    i1 = run * h0.det;
+                                } else {
+                                    i0 = rcp_nr2(h0.det);
+                                    i1 = rcp_nr2(h1.det);
+                                }
+                                back(h0, i0, true);
+                                back(h1, i1, two);
                                 w0 = n0;
                                 w1 = n1;
                             }
