@@ -46,8 +46,10 @@ def run(K, R, t, prm, kp, npers, pout, out_dtype=np.float32, method=_lib.PAIRWIS
             m = min(int(ref["count"][f]), pout)
             fin = np.isfinite(ref["xyz"][f, :m]) & (np.abs(ref["kscore"][f, :m]) < 1e9)[..., None]
             assert np.abs(out["xyzs"][f, :m, :, :3].astype(np.float64) - ref["xyz"][f, :m])[fin].max(initial=0.0) < 1e-5
+    names = bt.ctx.last_kernel_names()
     bt.close()
     ran += 1
+    return names
 # the fast kernel: one frame ... many tiles per wave
 for F in (1, 7, 300, 5000, 30000):
     wl = synth.config_workload(2, F, seed=5)
@@ -76,6 +78,42 @@ for C, P, J, F in ((8, 4, 133, 40), (4, 3, 40, 9), (2, 2, 133, 5), (16, 8, 133, 
 wl = synth.config_workload(5, 3)
 K, R, t = wl["rig"]
 run(K, R, t, wl["params"], wl["kpts"], wl["n_persons"], 32)
+# round 5: one detection per camera on 6-8 cameras (the lean kernels on the rolled item, float32 and float64 records, small and
+# large launches), the streaming route without its candidate pass (keypoint_num < J, two slots, 12 cameras), and the candidate
+# pass with one lane per ray (SNOWTRI_SUMS_RAYS=1: 8 x 4, 16 x 2, 4 x 8, ragged frames included)
+import os
+for C in (6, 8):
+    K, R, t = synth.ring_rig(C)
+    for F in (5, 700, 20000):
+        X = synth.make_people(rng, min(F, 200), 1)
+        kp, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=1.0, score_range=(2.0, 8.0))
+        reps = (F + len(kp) - 1) // len(kp)
+        kp, npers = np.tile(kp, (reps, 1, 1, 1, 1))[:F].copy(), np.tile(npers, (reps, 1))[:F].copy()
+        npers[F // 2, 1] = 0
+        prm = dict(synth.default_thresholds(), condense_distance_tol=2.0)
+        names = run(K, R, t, prm, kp, npers, 1, check=F <= 700)
+        assert "k_fused_lean" in names, names
+        names = run(K, R, t, prm, kp, npers, 1, out_dtype=np.float64, check=False)
+        assert "k_fused_lean" in names, names
+for C, kn, pout in ((7, 30, 1), (8, 133, 2), (12, 133, 1)):
+    K, R, t = synth.ring_rig(C)
+    X = synth.make_people(rng, 30, 1)
+    kp, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=1.0, score_range=(2.0, 8.0))
+    npers = npers.copy()
+    npers[3, 0] = 0
+    prm = dict(synth.default_thresholds(), condense_distance_tol=0.5, keypoint_num=kn, center_point_index=0)
+    run(K, R, t, prm, kp, npers, pout)
+    run(K, R, t, prm, kp, npers, pout, out_dtype=np.float64, check=False)
+os.environ["SNOWTRI_SUMS_RAYS"] = "1"
+for C, P, J, F in ((8, 4, 133, 30), (16, 2, 40, 6), (4, 8, 57, 6)):
+    K, R, t = synth.ring_rig(C, radius=5.0)
+    X = synth.make_people(rng, F, P, J=J)
+    kp, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=0.7, score_range=(2.0, 9.0), permute_persons=True, dtype=np.float32)
+    npers = npers.copy()
+    npers[1, C - 1] = P - 1
+    names = run(K, R, t, dict(PRM, keypoint_num=J), kp, npers, P + 2)
+    assert "k_candidate_sums_rays" in names, names
+os.environ.pop("SNOWTRI_SUMS_RAYS")
 print("debug-bounds ok:", ran, "calls")
 '''
 
