@@ -45,3 +45,25 @@ for i, nme in enumerate(names):
     v = us[:, i]
     print("%-58s at median %7.2f us  (+%6.2f, p95 +%6.2f)" % (nme, np.median(v), np.median(v - prev), np.percentile(v - prev, 95)))
     prev = v
+
+# the third joint chunk of that frame, wave by wave (its keypoint requests are in front of stamp 2): solve | write the next chunk's records | barrier
+idx = [2, 3, 4, 6]
+ch = st[(st[:, idx] > 0).all(axis=1)]
+if len(ch):
+    d = np.diff(ch[:, idx], axis=1) / 100.0
+    for i, nme in enumerate(["solve", "commit (records of the next chunk)", "barrier wait"]):
+        print("chunk 2: %-40s median %6.2f us  p5 %6.2f  p95 %6.2f" % (nme, np.median(d[:, i]), np.percentile(d[:, i], 5), np.percentile(d[:, i], 95)))
+    tot = (ch[:, 6] - ch[:, 2]) / 100.0
+    print("chunk 2: whole                                    median %6.2f us" % np.median(tot))
+    wv = np.arange(len(st))[(st[:, idx] > 0).all(axis=1)] % 4
+    for w in range(4):
+        print("  wave %d of its workgroup: solve median %6.2f us, barrier wait %6.2f us" % (w, np.median(d[wv == w, 0]), np.median(d[wv == w, 2])))
+
+if os.environ.get("TRACE_MODE") == "2":   # a -DSNOWTRI_SUMS_TRACE=2 build: slots 2 .. 9 = the end of chunk 0 .. 7 of that frame
+    idx = [1] + list(range(2, 10))
+    ok = st[(st[:, [0, 1, 2]] > 0).all(axis=1)]
+    d = np.diff(ok[:, idx], axis=1) / 100.0
+    for c in range(8):
+        v = d[:, c][ok[:, 2 + c] > 0]
+        if len(v):
+            print("chunk %d: median %6.2f us  p5 %6.2f  p95 %6.2f" % (c, np.median(v), np.percentile(v, 5), np.percentile(v, 95)))

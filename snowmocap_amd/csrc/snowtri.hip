@@ -1998,14 +1998,18 @@ SumsLaunch sums_launch_shape(const snowtri_ctx *ctx, int Pmax, int J) {
     const int C = ctx->C, gs = p1_group_size(Pmax);
     const int64_t nitems = (int64_t)ctx->npairs * (Pmax / (gs >= 2 ? kSumsGA : 1)) * (Pmax / gs);   // (k_candidate_sums: GA x GS tiles)
     SumsLaunch L;
-    // one pass over the items should keep every wave busy: 256 threads for the small rigs, the whole CU for the large
+    // one pass over the items should keep every wave busy: 256 threads for the small rigs, the whole CU for the large.
+    // (SNOWTRI_SUMS_THREADS=64: one wave per workgroup, for rigs whose tiles fit a wave -- measured slower, SumsShape)
     L.threads = ctx->sums_threads > 0 ? ctx->sums_threads : (nitems <= 256 ? 256 : (nitems <= 768 ? 512 : 1024));
     L.threads = std::max(64, std::min(1024, (L.threads / 64) * 64));
-    L.lds = ctx->sums_lds_kb > 0 ? ctx->sums_lds_kb * 1024 : (L.threads <= 256 ? 52 * 1024 : (L.threads <= 512 ? 80 * 1024 : 160 * 1024));
-    L.threads = L.threads <= 256 ? 256 : (L.threads <= 512 ? 512 : 1024);   // the instantiated shapes
+    L.threads = L.threads <= 64 ? 64 : (L.threads <= 256 ? 256 : (L.threads <= 512 ? 512 : 1024));   // the instantiated shapes
+    L.lds = ctx->sums_lds_kb > 0 ? ctx->sums_lds_kb * 1024
+                                 : (L.threads <= 64 ? 13 * 1024 : (L.threads <= 256 ? 52 * 1024 : (L.threads <= 512 ? 80 * 1024 : 160 * 1024)));
     L.lds = std::min(L.lds, 160 * 1024);
-    L.per_cu = std::max(1, std::min((160 * 1024) / L.lds, 2048 / L.threads));
-    const int pf = L.threads == 256 ? SumsShape<256>::kPrefetch : (L.threads == 512 ? SumsShape<512>::kPrefetch : SumsShape<1024>::kPrefetch);
+    // (a one-wave workgroup: 12 per CU, three waves per SIMD at 168 registers)
+    L.per_cu = std::max(1, std::min((160 * 1024) / L.lds, L.threads == 64 ? 12 : 2048 / L.threads));
+    const int pf = L.threads == 64 ? SumsShape<64>::kPrefetch
+                                   : (L.threads == 256 ? SumsShape<256>::kPrefetch : (L.threads == 512 ? SumsShape<512>::kPrefetch : SumsShape<1024>::kPrefetch));
     L.Jc = sums_chunk_joints(C, Pmax, J, ctx->npairs, L.threads, pf, L.lds);
     return L;
 }
@@ -2062,7 +2066,8 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st_call, int64_t F, int
     const bool sums_kn = !sumless && prm.kn != J && !(prm.score_tol <= 0.0);   // second candidate-sum launch over the first keypoint_num joints
     const bool post_scores = sumless || sizeof(TOut) == 8 || prm.kn != J;   // the persons' mean scores by k_person_scores
     SumsLaunch SL{};
-    bool stream = can_hand && ctx->handover_mode == 1 && C <= 16 && Kc < ((int64_t)1 << 24) && Pout <= 1024;
+    // (distance_threshold >= 0: k_candidate_sums reads its distance gate off a sign bit, p1_tile_sums)
+    bool stream = can_hand && ctx->handover_mode == 1 && C <= 16 && Kc < ((int64_t)1 << 24) && Pout <= 1024 && (sumless || prm.dthr >= 0.0);
     if (stream) {
         SL = sums_launch_shape(ctx, Pmax, J);
         stream = SL.Jc >= 1;
@@ -2247,7 +2252,7 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st_call, int64_t F, int
                     }
 #undef SNOWTRI_RAYS
                     if (rays) {
-                    } else if (SL.threads == 256) SNOWTRI_SUMS(256) else if (SL.threads == 512) SNOWTRI_SUMS(512) else SNOWTRI_SUMS(1024)
+                    } else if (SL.threads == 64) SNOWTRI_SUMS(64) else if (SL.threads == 256) SNOWTRI_SUMS(256) else if (SL.threads == 512) SNOWTRI_SUMS(512) else SNOWTRI_SUMS(1024)
                     HIP_TRY(hipGetLastError());
                     // the frames it listed (exact_count of them, known on the device only; normally none)
                     hipLaunchKernelGGL((k_candidate_sums_exact<TIn>), dim3((int)std::min<int64_t>(Fs, ctx->num_cus)), dim3(kBlock), 0, st, Pmax, J,

@@ -23,7 +23,9 @@ namespace snowtri {
 // indices (32 B) | ray matrices | arena = TWO buffers of one joint chunk of ray records each (layout and bank map:
 // snowtri_general.hpp, p1_joint_stride): the waves solve the chunk in one buffer while the records of the next chunk are
 // written to the other; at the end of a frame the buffer of its last chunk holds the partial sums of the joint sub-ranges.
-constexpr int kSumsHeadBytes = 64;
+// flags and tickets | [2][8] per frame parity and PAIR of cameras (16 bits each): persons whose records are not finite.  (Every
+// byte in front of the arena counts: 8 cameras x 4 persons hold chunks of 20 joints in 52 KB with 1 728 bytes to spare.)
+constexpr int kSumsHeadBytes = 64 + 2 * 8 * 4;
 // workgroup shapes (threads, waves per SIMD the registers must allow, records of the coming chunk a thread holds in
 // registers): 256 threads x 3 workgroups per CU for the small rigs, 512 x 2 or 1024 x 1 for the large ones
 #ifndef SNOWTRI_SUMS_WAVES256
@@ -32,20 +34,30 @@ constexpr int kSumsHeadBytes = 64;
 #ifndef SNOWTRI_SUMS_GA
 #define SNOWTRI_SUMS_GA 2
 #endif
+#ifndef SNOWTRI_SUMS_PREFETCH64
+#define SNOWTRI_SUMS_PREFETCH64 4
+#endif
 constexpr int kSumsWaves256 = SNOWTRI_SUMS_WAVES256;   // (4 waves per SIMD = 128 registers: the 2 x 4 tile spills, 8 x 4 measured 1027 us against 729)
+// 64 threads (SNOWTRI_SUMS_THREADS=64 only): ONE wave per workgroup for rigs whose tiles fit one wave (8 cameras x 4 persons:
+// 56) -- no barrier (a workgroup of one wave), ONE chunk buffer (a wave's fill follows its own solves in program order), sums
+// in registers for the whole frame.  The experiment behind it: the four waves of a 256-thread workgroup meet at a barrier every
+// joint chunk, the fastest 5 % of the chunks take 4.5 us and the median 8 (-DSNOWTRI_SUMS_TRACE=2), so a wave that waits for
+// nobody should do better.  It does not: 8 x 4 x 10 000 frames 720-736 us against 696-700 us (17 chunks of 8 joints per frame
+// instead of 7 of 20, VALU busy 0.68 against 0.75 -- at 2.16 against 2.08 GHz: the kernel runs on the socket's power limit).
 template <int THREADS>
 struct SumsShape {
-    static constexpr int kWavesPerSimd = THREADS == 256 ? kSumsWaves256 : 4;
-    static constexpr int kPrefetch = THREADS == 256 ? 3 : 2;
+    static constexpr int kWavesPerSimd = THREADS == 64 ? 3 : (THREADS == 256 ? kSumsWaves256 : 4);
+    static constexpr int kPrefetch = THREADS == 64 ? SNOWTRI_SUMS_PREFETCH64 : (THREADS == 256 ? 3 : 2);
+    static constexpr int kBuffers = THREADS == 64 ? 1 : 2;
 };
 constexpr int kSumsGA = SNOWTRI_SUMS_GA;   // persons of the FIRST camera per tile (when the person count is even)
 
 __host__ __device__ inline size_t sums_arena_offset(int C, int npairs) {
-    return ((size_t)kSumsHeadBytes + (size_t)4 * C + (size_t)32 * npairs + (size_t)72 * C + 15) & ~(size_t)15;
+    return ((size_t)kSumsHeadBytes + (size_t)8 * (C + (C & 1)) + (size_t)32 * npairs + (size_t)72 * C + 15) & ~(size_t)15;   // head | n_persons [2][C] | pairs | ray matrices
 }
-// bytes of ONE of the two chunk buffers
-__host__ __device__ inline int sums_buffer_bytes(int C, int npairs, int lds_total) {
-    return ((lds_total - (int)sums_arena_offset(C, npairs)) / 2) & ~15;
+// bytes of ONE of the chunk buffers (two; a one-wave workgroup has one)
+__host__ __device__ inline int sums_buffer_bytes(int C, int npairs, int lds_total, int threads) {
+    return ((lds_total - (int)sums_arena_offset(C, npairs)) / (threads == 64 ? 1 : 2)) & ~15;
 }
 // item = tile of GA persons of a pair's first camera x GS persons of its second; JS = how many ways a chunk's joints are
 // split over the workgroup's NW waves when one pass over the items leaves waves idle (whole waves take a joint sub-range:
@@ -61,7 +73,7 @@ __host__ __device__ inline int sums_joint_split(int nitems, int NW) {
 // four waves would cost every chunk the time of 5)
 __host__ __device__ inline int sums_chunk_joints(int C, int Pmax, int J, int npairs, int threads, int prefetch, int lds_total) {
     const int R = C * Pmax;
-    int cap = sums_buffer_bytes(C, npairs, lds_total) / p1_joint_stride(R);
+    int cap = sums_buffer_bytes(C, npairs, lds_total, threads) / p1_joint_stride(R);
     const int pf = prefetch * threads / R;   // every record of a chunk prefetched
     if (cap > pf) cap = pf;
     if (cap > 64) cap = 64;
@@ -82,35 +94,89 @@ __host__ __device__ inline int sums_chunk_joints(int C, int Pmax, int J, int npa
 
 // The fast phase-1 arithmetic of p1_item_sums (snowtri_general.hpp) on a GA x GS TILE of candidates: GA consecutive persons
 // of camera m against GS consecutive persons of camera s, acc[i * GS + u] += 2000 x score of candidate (pm0 + i, ps0 + u).
-// A 2 x 4 tile reads 6 records per 8 solves where the 1 x 4 item read 5 per 4 (3.75 instead of 6.25 ds_read_b64 per solve: all
-// waves of a CU queue on one LDS pipe, and a wave waits for its reads at the top of every joint), and the keypoint gate
-// of a second ray is evaluated once per tile.  Same operations per candidate in the same order: the sums are the bits of
-// p1_item_sums.
+// A 2 x 4 tile reads 6 records per 8 solves where the 1 x 4 item read 5 per 4 (3.75 instead of 6.25 ds_read_b64 per solve).
+//
+// The gates of :73-74 WITHOUT compares.  The loop is bound by VALU issue, and measured in isolation (registers only,
+// scripts/ubench/sums_mix.hip) the three gates of p1_item_sums -- two keypoint-threshold compares and `dn2 > det * dthr2`
+// into scalar masks, s_or, v_cndmask -- cost 42 of its 110 SIMD cycles per candidate against 68 for the arithmetic.  Here:
+//   * the keypoint gate is applied when the RECORD is written: a score below the threshold is stored as -infinity (GatedScore),
+//     so that the sum of a pair's scores is negative -- or NaN -- exactly when one of them is gated (scores that pass are
+//     >= keypoint_score_threshold >= 0, host-checked);
+//   * the distance gate is the SIGN of r = fma(det, dthr2, -dn2) (r < 0 <=> dn2 > det * dthr2, rounded once instead of twice),
+//     OR-ed into the sign of the score sum (v_and_or_b32);
+//   * one v_max with 0 then zeroes the weight of a gated candidate: 5 full-rate instructions (v_add, v_fma, v_and_or, v_max,
+//     v_cvt) in place of 9 with three of them on the scalar path: 110 -> 87 cycles per candidate in the same harness.
+// The weight of a kept candidate is the float (double: the double) sum of the two scores as before and the geometry is
+// untouched: a kept candidate adds the bits it added before.  What the sign trick cannot carry is a NaN (v_max returns
+// its other operand, the sign of a NaN r is arbitrary): records that are not finite are caught where they are written
+// (k_candidate_sums, `commit`) and send the frame to the exact pass.  r = -0 needs det = dn2 = 0 and dthr2 < 0: the host
+// keeps batches with a negative distance_threshold off this kernel.
+template <typename TIn>
+struct GatedScore;
+template <>
+struct GatedScore<float> {
+    static constexpr float value = -__builtin_huge_valf();
+};
+template <>
+struct GatedScore<double> {
+    static constexpr double value = -__builtin_huge_val();
+};
+__device__ __forceinline__ double tile_weight(float sm, float ss, double r) {
+    const uint32_t t = ((uint32_t)__double2hiint(r) & 0x80000000u) | __float_as_uint(sm + ss);
+    float v;
+    asm("v_max_f32 %0, %1, 0" : "=v"(v) : "v"(t));   // (fmaxf would canonicalize t first: one more instruction)
+    return (double)v;
+}
+__device__ __forceinline__ double tile_weight(double sm, double ss, double r) {
+    const double sd = sm + ss;
+    const uint32_t hi = ((uint32_t)__double2hiint(r) & 0x80000000u) | (uint32_t)__double2hiint(sd);
+    const double t = __hiloint2double((int)hi, __double2loint(sd));
+    double v;
+    asm("v_max_f64 %0, %1, 0" : "=v"(v) : "v"(t));
+    return v;
+}
 template <int GA, int GS, typename TIn>
 __device__ __forceinline__ void p1_tile_sums(const char *__restrict__ pa, const char *__restrict__ pb, int jstr, int nj, const Vec3 &d,
                                              const Params &prm, double (&acc)[GA * GS]) {
+#ifdef SNOWTRI_K1_NOLDS   // TIMING-ONLY build (wrong sums): the records of the chunk's first joint, read once -- what the solve loop costs without its LDS reads
+    RayRec b0[GS], a0[GA];
+    TIn ss0[GS], sm0[GA];
+    for (int u = 0; u < GS; u++) { b0[u] = p1_load_ray(pb + kP1Rec * u); ss0[u] = p1_load_score<TIn>(pb + kP1Rec * u); }
+    for (int i = 0; i < GA; i++) { a0[i] = p1_load_ray(pa + kP1Rec * i); sm0[i] = p1_load_score<TIn>(pa + kP1Rec * i); }
+#endif
     for (int t = 0; t < nj; t++, pa += jstr, pb += jstr) {
         RayRec b[GS];
         TIn ss[GS];
 #pragma unroll
         for (int u = 0; u < GS; u++) {
+#ifdef SNOWTRI_K1_NOLDS
+            asm volatile("" : "+v"(b0[u].x), "+v"(b0[u].y), "+v"(b0[u].z), "+v"(b0[u].a), "+v"(ss0[u]));
+            b[u] = b0[u];
+            ss[u] = ss0[u];
+#else
             b[u] = p1_load_ray(pb + kP1Rec * u);
             ss[u] = p1_load_score<TIn>(pb + kP1Rec * u);
+#endif
         }
 #pragma unroll
         for (int i = 0; i < GA; i++) {
+#ifdef SNOWTRI_K1_NOLDS
+            asm volatile("" : "+v"(a0[i].x), "+v"(a0[i].y), "+v"(a0[i].z), "+v"(a0[i].a), "+v"(sm0[i]));
+            const RayRec a = a0[i];
+            const TIn sm = sm0[i];
+#else
             const RayRec a = p1_load_ray(pa + kP1Rec * i);
             const TIn sm = p1_load_score<TIn>(pa + kP1Rec * i);
+#endif
             const double cx = fma(d.y, a.z, -(d.z * a.y)), cy = fma(d.z, a.x, -(d.x * a.z)), cz = fma(d.x, a.y, -(d.y * a.x));
-            const bool okm = !below_kthr(sm, prm);
 #pragma unroll
             for (int u = 0; u < GS; u++) {
                 const double bq = fma(a.z, b[u].z, fma(a.y, b[u].y, a.x * b[u].x));
                 const double det = fma(a.a, b[u].a, -(bq * bq));
                 const double dn = fma(cz, b[u].z, fma(cy, b[u].y, cx * b[u].x));
                 const double dn2 = dn * dn;
-                const bool kp_ = okm && !below_kthr(ss[u], prm) && !(dn2 > det * prm.dthr2);   // :73-74
-                acc[i * GS + u] = fma(gated_sum_sel(sm, ss[u], kp_), det * __builtin_amdgcn_rsq(dn2 * det), acc[i * GS + u]);
+                const double r = fma(det, prm.dthr2, -dn2);                                         // :73-74: r < 0 <=> dist > distance_threshold
+                acc[i * GS + u] = fma(tile_weight(sm, ss[u], r), det * __builtin_amdgcn_rsq(dn2 * det), acc[i * GS + u]);
             }
         }
     }
@@ -120,9 +186,15 @@ __device__ __forceinline__ void p1_tile_sums(const char *__restrict__ pa, const 
 __device__ unsigned long long g_sums_trace[4096 * 4 * 16];
 #define SUMS_STAMP_ALWAYS(i) do { if ((threadIdx.x & 63) == 0 && blockIdx.x < 4096 && threadIdx.x < 256) g_sums_trace[(blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #define SUMS_STAMP(i) do { if (it == 1) SUMS_STAMP_ALWAYS(i); } while (0)
+#if SNOWTRI_SUMS_TRACE == 2
+#define SUMS_STAMP_C2(i) ((void)0)
+#else
+#define SUMS_STAMP_C2(i) do { if (c == 2) SUMS_STAMP(i); } while (0)   // the phases of the frame's third chunk
+#endif
 #else
 #define SUMS_STAMP_ALWAYS(i) ((void)0)
 #define SUMS_STAMP(i) ((void)0)
+#define SUMS_STAMP_C2(i) ((void)0)
 #endif
 // csum[f][k] = sum over the joints of the score of candidate slot k (J x the mean of :79; 0 for a slot whose cameras
 // list fewer persons), with the fast arithmetic of p1_tile_sums; a frame with a candidate whose fast sum cannot decide
@@ -135,13 +207,15 @@ __device__ unsigned long long g_sums_trace[4096 * 4 * 16];
 // per wave, -DSNOWTRI_SUMS_TRACE), the youngest finished alone on its CU with nothing to hide its latencies behind.
 //
 // Per frame, a software pipeline over the joint chunks with ONE barrier per chunk:
-//     solve chunk c (buffer c & 1)  ->  write the records of chunk c + 1 (other buffer; their keypoints were requested a
-//     chunk ago)  ->  request the keypoints of chunk c + 2 -- behind the frame's last chunk: of the NEXT frame's first
-//     chunk, with its n_persons (the ticket is drawn at the frame's start)  ->  barrier.
+//     request the keypoints of chunk c + 1 -- in the frame's last chunk: of the NEXT frame's first chunk, with its n_persons
+//     (the ticket is drawn at the frame's start)  ->  solve chunk c (buffer c & 1) with the requests in flight  ->  write
+//     the records of chunk c + 1 (other buffer)  ->  barrier.
 // A wave that is done with its solves fills LDS for the next chunk instead of waiting for the others, a frame starts on
-// records that are already in registers, and what used to be two barriers and an exposed fill per chunk plus an HBM round
-// trip per frame (26 % of the kernel on 8 x 4, 19 % on 16 x 8: its time against the solve phase run N times,
-// -DSNOWTRI_K1_REPEAT) overlaps the solves.
+// records that are already in LDS (its top is the ticket and one barrier), and what used to be two barriers and an exposed
+// fill per chunk plus an HBM round trip per frame overlaps the solves.  The requests are made and used inside ONE pass of the
+// chunk loop: round 4 requested chunk c + 2 behind chunk c + 1's fill and carried the registers around the loop, and the
+// compiler put a copy of one loaded register -- with s_waitcnt vmcnt(0) in front of it -- right behind the loads: every
+// request waited for its own data (1.0-1.4 us of the 9 us of a chunk of 8 x 4, wall-clock stamps of the chunk's phases).
 // The items (tiles) are dealt to the lanes once per frame.  If one pass of the workgroup covers them (SINGLE: items x JS
 // <= threads -- 8 cameras x 4 persons: 56 tiles, four joint sub-ranges, 224 of 256 lanes; 16 x 8: 960 tiles on 15 of 16
 // waves) a lane keeps the sums of its tile in registers over all joint chunks; larger rigs walk the items in rounds and
@@ -172,8 +246,10 @@ __global__ __launch_bounds__(THREADS, SumsShape<THREADS>::kWavesPerSimd) void k_
     // head: per frame parity p = it & 1: [4p] a candidate needs the exact sum, [4p + 1] ragged frame, [4p + 2] ticket of the
     // frame after it (a slot is rewritten two frames later, behind that frame's barriers)
     int32_t *head = reinterpret_cast<int32_t *>(smem);
-    int32_t *np_l = reinterpret_cast<int32_t *>(smem + kSumsHeadBytes);    // [C] persons listed by the cameras in this frame
-    double *paird = reinterpret_cast<double *>(np_l + C + (C & 1));        // [npairs][3]
+    uint32_t *badrows = reinterpret_cast<uint32_t *>(smem + 64);           // [2][8]: bit p + 16 (c & 1) of [frame parity][c >> 1]: a record of person p of camera c is not finite
+    const int Cp = C + (C & 1);
+    int32_t *np_both = reinterpret_cast<int32_t *>(smem + kSumsHeadBytes); // [2][Cp]: persons listed by the cameras, by frame parity
+    double *paird = reinterpret_cast<double *>(np_both + 2 * Cp);          // [npairs][3]
     int32_t *pairs = reinterpret_cast<int32_t *>(paird + 3 * rig.npairs);  // [npairs][2]
     double *Ml = reinterpret_cast<double *>(pairs + 2 * rig.npairs);
     if (tid < kSumsHeadBytes / 4) head[tid] = 0;
@@ -181,7 +257,8 @@ __global__ __launch_bounds__(THREADS, SumsShape<THREADS>::kWavesPerSimd) void k_
     for (int i = tid; i < 2 * rig.npairs; i += B) pairs[i] = rig.pairs[i];
     for (int i = tid; i < 9 * C; i += B) Ml[i] = rig.M[i];
     char *const rec0 = smem + sums_arena_offset(C, rig.npairs);
-    const int half = sums_buffer_bytes(C, rig.npairs, lds_total);   // bytes of one chunk buffer
+    const int half = sums_buffer_bytes(C, rig.npairs, lds_total, B);   // bytes of one chunk buffer
+    const int bufstep = SumsShape<THREADS>::kBuffers == 2 ? half : 0;  // (one buffer: a wave's fill of chunk c + 1 follows its solves of chunk c in program order)
     const int jstr = p1_joint_stride(R), Jc = sums_chunk_joints(C, Pmax, J, rig.npairs, B, NPF, lds_total);
     const int nch = (J + Jc - 1) / Jc;
     const unsigned long long magic_pmax = (((unsigned long long)1 << 40) + (unsigned)Pmax - 1) / (unsigned)Pmax;
@@ -190,56 +267,97 @@ __global__ __launch_bounds__(THREADS, SumsShape<THREADS>::kWavesPerSimd) void k_
     // ---- the records of a joint chunk: keypoints fetched into registers (a chunk ahead), then ray + |h|^2 + score into
     // LDS.  Lanes = consecutive joints of a row: coalesced 12-byte reads.  Rows a camera does not list are filled with
     // whatever the buffer holds: no valid candidate reads them.
+    // The keypoints of a chunk are requested in FRONT of the solves of the chunk before it and turned into records BEHIND them,
+    // in the same pass of the chunk loop: no register carries a load across a loop edge.  (Carried around the loops -- requested
+    // behind chunk c, used behind chunk c + 1 -- the compiler placed its copies between the six loop variants right behind the
+    // loads, with s_waitcnt vmcnt(0) in front of them: every request waited for its own data, ~1 us per chunk of 8 x 4.)
     Kp3<TIn> pre[NPF];
-    int pre_off[NPF];   // byte offset of the record in its buffer | camera << 20, or -1
-    int npv = Pmax;     // threads < C: n_persons of the coming frame
-    auto fetch = [&](const Kp3<TIn> *kpf, int j0, int nj) {
-        const unsigned long long magic_nj = (((unsigned long long)1 << 40) + (unsigned)nj - 1) / (unsigned)nj;
+    int npv = Pmax;     // threads < C: n_persons of the frame whose first chunk is in `pre`
+    // Slot n of a thread holds record i = tid + n B of a chunk of Jc joints: row r = i / Jc, joint jj = i % Jc of the chunk --
+    // the same for every chunk of every frame, worked out once (a last chunk of fewer joints leaves the slots of its missing
+    // joints idle; 133 joints are 7 x 19).  A chunk's fetch is then an add and a load per slot.
+    int pre_map[NPF];   // row r | camera << 8 | jj << 12; -1: no record
+    {
+        const unsigned long long magic_jc = (((unsigned long long)1 << 40) + (unsigned)Jc - 1) / (unsigned)Jc;
 #pragma unroll
         for (int n = 0; n < NPF; n++) {
-            // (every slot loads, past the chunk's end the last record again: a load inside a branch would have to be
-            // waited for where the branch joins)
-            const int i = tid + n * B, ic = i < R * nj ? i : R * nj - 1;
-            const int r = (int)(((unsigned long long)(unsigned)ic * magic_nj) >> 40), jj = ic - r * nj;
+            const int i = tid + n * B, ic = i < R * Jc ? i : 0;
+            const int r = (int)(((unsigned long long)(unsigned)ic * magic_jc) >> 40), jj = ic - r * Jc;
             const int c = (int)(((unsigned long long)(unsigned)r * magic_pmax) >> 40);
-            SNOWTRI_DEV_CHECK(r >= 0 && r < R && j0 + jj >= 0 && j0 + jj < J, 10);   // keypoint (row, joint) inside the frame
-            pre[n] = kpf[(size_t)r * Jrow + j0 + jj];
-            pre_off[n] = i < R * nj ? ((jj * jstr + kP1Rec * r) | (c << 20)) : -1;
+            pre_map[n] = i < R * Jc ? (r | (c << 8) | (jj << 12)) : -1;
+        }
+    }
+    auto fetch = [&](const Kp3<TIn> *kpf, int j0, int nj) {
+        // (range-checked on the byte offset: an idle slot reads zeros from past the frame's end)
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<Kp3<TIn> *>(kpf), 0, R * Jrow * (int)sizeof(Kp3<TIn>), 0x00020000);
+#pragma unroll
+        for (int n = 0; n < NPF; n++) {
+            const int r = pre_map[n] & 255, jj = (pre_map[n] >> 12) & 63;
+            const bool live = ((unsigned)pre_map[n] >> 12) < (unsigned)nj;
+            SNOWTRI_DEV_CHECK(!live || (r < R && j0 + jj < J), 10);   // keypoint (row, joint) inside the frame
+            // three loads of one component each, at offsets the compiler cannot relate (or it merges them again): one load of
+            // three registers ties them to a register triple, and the compiler, wanting one of the three elsewhere during
+            // the solves, copied it right behind the load -- s_waitcnt vmcnt(0) in front of the copy
+            int o0 = live ? (r * Jrow + jj + j0) * (int)sizeof(Kp3<TIn>) : 0x7ffffff0, o1 = o0, o2 = o0;
+            asm volatile("" : "+v"(o1));
+            asm volatile("" : "+v"(o2));
+            if constexpr (sizeof(TIn) == 4) {
+                pre[n].u = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, o0, 0, 0));
+                pre[n].v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, o1 + 4, 0, 0));
+                pre[n].s = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, o2 + 8, 0, 0));
+            } else {
+                typedef unsigned u2v __attribute__((ext_vector_type(2)));
+                const u2v a = __builtin_amdgcn_raw_buffer_load_b64(rs, o0, 0, 0), b = __builtin_amdgcn_raw_buffer_load_b64(rs, o1 + 8, 0, 0),
+                          d = __builtin_amdgcn_raw_buffer_load_b64(rs, o2 + 16, 0, 0);
+                pre[n].u = __hiloint2double((int)a.y, (int)a.x);
+                pre[n].v = __hiloint2double((int)b.y, (int)b.x);
+                pre[n].s = __hiloint2double((int)d.y, (int)d.x);
+            }
         }
     };
     auto fetch_frame = [&](int64_t fr) {   // first chunk and person counts of frame fr
         fetch(kp3 + fr * (int64_t)R * Jrow, 0, J < Jc ? J : Jc);
         if (n_persons && tid < C) npv = n_persons[fr * C + tid];
     };
-    auto commit = [&](char *buf) {
+    // (the score of a record is stored GATED, see p1_tile_sums; a record that is not finite -- a NaN or infinite pixel, a NaN
+    // score -- sets the bit of its person in `bad`: the frame's end looks at the bits of the persons its cameras list)
+    auto commit = [&](char *buf, uint32_t *bad, int nj) {
+#ifdef SNOWTRI_K1_NOFILL   // TIMING-ONLY build (wrong sums): no ray records written
+        if (F >= 0) return;
+#endif
 #pragma unroll
         for (int n = 0; n < NPF; n++)
-            if (pre_off[n] >= 0) {
-                SNOWTRI_DEV_CHECK((pre_off[n] & 0xfffff) + kP1Rec <= half && (pre_off[n] >> 20) < C, 11);   // record inside the buffer
-                p1_store_record<TIn>(buf + (pre_off[n] & 0xfffff), make_ray(Ml + 9 * (pre_off[n] >> 20), pre[n].u, pre[n].v), pre[n].s);
+            if (((unsigned)pre_map[n] >> 12) < (unsigned)nj) {
+                const int r = pre_map[n] & 255, c = (pre_map[n] >> 8) & 15, off = ((pre_map[n] >> 12) & 63) * jstr + kP1Rec * r;
+                SNOWTRI_DEV_CHECK(off + kP1Rec <= half && c < C, 11);   // record inside the buffer
+                const RayRec h = make_ray(Ml + 9 * c, pre[n].u, pre[n].v);
+                const TIn sc = pre[n].s;
+                if (!(fma((double)sc, 0.0, h.a) < 1e300)) atomicOr(&bad[c >> 1], 1u << (r - c * Pmax + 16 * (c & 1)));   // (NaN or infinite |h|^2, NaN or infinite score)
+                p1_store_record<TIn>(buf + off, h, below_kthr(sc, prm) ? GatedScore<TIn>::value : sc);
             }
     };
 
     int64_t f = blockIdx.x;
-    if (f < F) fetch_frame(f);
     int par = 0;   // buffer of the frame's first chunk
     __syncthreads();   // constants and the cleared head
+    if (f < F) {   // the first chunk of the workgroup's first frame (every later one is written during the frame before it)
+        fetch_frame(f);
+        commit(rec0, badrows, J < Jc ? J : Jc);
+        if (tid < C) np_both[tid] = npv;
+    }
     for (int it = 0; f < F; it++) {
         int32_t *hd = head + 4 * (it & 1);
+        const int32_t *np_l = np_both + Cp * (it & 1);   // [C] persons listed by the cameras in this frame
         const Kp3<TIn> *kpf = kp3 + f * (int64_t)R * Jrow;
         double *cs_f = csum + f * (int64_t)Kc;
         SUMS_STAMP(0);
         if (tid == 0) hd[2] = (int32_t)atomicAdd(next_frame, 1ull);
-        if (tid < C) {   // (the previous frame's readers of np_l are behind its barriers)
-            np_l[tid] = npv;
-            if (npv != Pmax) hd[1] = 1;
-        }
-        commit(rec0 + par * half);
-        if (nch >= 2) fetch(kpf, Jc, (J - Jc) < Jc ? (J - Jc) : Jc);
-        __syncthreads();   // first chunk, np_l, ragged flag and ticket are there
+        if (tid < C && np_l[tid] != Pmax) hd[1] = 1;   // (np_l[tid] was written by this thread)
+        uint32_t *bad = badrows + 8 * (it & 1);
+        __syncthreads();   // first chunk (written during the frame before), np_l, ragged flag and ticket are there
         SUMS_STAMP(1);
+        if (tid == 0) head[4 * ((it & 1) ^ 1)] = head[4 * ((it & 1) ^ 1) + 1] = 0;   // the flags of the frame before: read for the last time in front of this barrier, set again behind this frame's last one
         const int64_t fnext = (int64_t)gridDim.x + (int64_t)(uint32_t)hd[2];
-        if (nch == 1 && fnext < F) fetch_frame(fnext);
         const int GS = hd[1] ? 1 : p1_group_size(Pmax);   // a ragged frame keeps one candidate per lane
         const int GA = GS >= 2 ? kSumsGA : 1;      // (GS >= 2: Pmax is even)
         const int NG = Pmax / GS, per_q = (Pmax / GA) * NG, nitems = rig.npairs * per_q;
@@ -290,13 +408,25 @@ __global__ __launch_bounds__(THREADS, SumsShape<THREADS>::kWavesPerSimd) void k_
             }
             for (int c = 0, j0 = 0; c < nch; c++, j0 += Jc) {
                 const int nj = (J - j0) < Jc ? (J - j0) : Jc;
-                const char *cur = rec0 + ((par ^ c) & 1) * half;
+                const char *cur = rec0 + ((par ^ c) & 1) * bufstep;
                 // the waves of joint sub-range jsub walk joints [jlo, jhi) of the chunk (the sub-ranges rotate from chunk to
                 // chunk: where the joints of a chunk do not divide by JS every wave gets the long sub-range in turn)
                 const int jrot = (jsub + c) & (JS - 1);
                 const int jlo = jrot * nj / JS, jhi = (jrot + 1) * nj / JS;
+                // requested here, in flight during the solves: the chunk after this one -- behind the frame's last chunk the
+                // first chunk of the NEXT frame (its ticket was drawn at the frame's start) with its n_persons
+                // (one request site: a frame without a successor requests a chunk of no joints)
+                const bool last = c + 1 >= nch, succ = fnext < F;
+                const int j0_next = last ? 0 : j0 + Jc;
+                const int nj_next = last ? (succ ? (J < Jc ? J : Jc) : 0) : ((J - j0 - Jc) < Jc ? (J - j0 - Jc) : Jc);
+                const char *pa = cur + jlo * jstr + mine.oa, *pb = cur + jlo * jstr + mine.ob;
+                const int njs = mine.cand ? jhi - jlo : 0;
+                fetch(last && succ ? kp3 + fnext * (int64_t)R * Jrow : kpf, j0_next, nj_next);
+                if (last && succ && n_persons && tid < C) npv = n_persons[fnext * C + tid];
+                __builtin_amdgcn_sched_barrier(0);   // (nothing of the solves' set-up behind the requests: a reload from scratch there waits for them)
+                SUMS_STAMP_C2(2);
                 if constexpr (SINGLE) {
-                    p1_tile_sums<GAC, GSC, TIn>(cur + jlo * jstr + mine.oa, cur + jlo * jstr + mine.ob, jstr, mine.cand ? jhi - jlo : 0, mine.d, prm, tot);
+                    p1_tile_sums<GAC, GSC, TIn>(pa, pb, jstr, njs, mine.d, prm, tot);
                 } else {
                     for (int base = iw * 64; base < nitems; base += wpg * 64) {
                         const Item t = locate(base);
@@ -314,14 +444,16 @@ __global__ __launch_bounds__(THREADS, SumsShape<THREADS>::kWavesPerSimd) void k_
                         }
                     }
                 }
-                if (c + 1 < nch) {
-                    commit(rec0 + ((par ^ (c + 1)) & 1) * half);
-                    if (c + 2 < nch)
-                        fetch(kpf, j0 + 2 * Jc, (J - j0 - 2 * Jc) < Jc ? (J - j0 - 2 * Jc) : Jc);
-                    else if (fnext < F)
-                        fetch_frame(fnext);
-                }
+                SUMS_STAMP_C2(3);
+                // (the buffer chunk c - 1 was solved in; the next frame's first chunk lands where this frame's last chunk is not)
+                commit(rec0 + ((par ^ (c + 1)) & 1) * bufstep, last ? badrows + 8 * ((it & 1) ^ 1) : bad, nj_next);
+                if (last && succ && tid < C) np_both[Cp * ((it & 1) ^ 1) + tid] = npv;
+                SUMS_STAMP_C2(4);
                 __syncthreads();   // chunk c is solved (its buffer is free), chunk c + 1 is in LDS, csum is up to date
+                SUMS_STAMP_C2(6);
+#if defined(SNOWTRI_SUMS_TRACE) && SNOWTRI_SUMS_TRACE == 2   // (instead of the stamps of chunk 2: the end of every chunk, slots 2 .. 9)
+                if (c < 8) SUMS_STAMP(2 + c);
+#endif
             }
             SUMS_STAMP(10);
             // the 1 / (2 * 1000) of :72, and whether a mean can decide :80-81
@@ -337,7 +469,7 @@ __global__ __launch_bounds__(THREADS, SumsShape<THREADS>::kWavesPerSimd) void k_
                         for (int u = 0; u < NT; u++) finish(slot(mine, u), mine.cand ? tot[u] : 0.0);
                     }
                 } else {         // the partial sums of the joint sub-ranges meet in the buffer of the last chunk
-                    double *lsum = reinterpret_cast<double *>(rec0 + ((par ^ (nch - 1)) & 1) * half);
+                    double *lsum = reinterpret_cast<double *>(rec0 + ((par ^ (nch - 1)) & 1) * bufstep);
                     if (mine.live) {
 #pragma unroll
                         for (int u = 0; u < NT; u++) lsum[jsub * Kc + slot(mine, u)] = mine.cand ? tot[u] : 0.0;
@@ -369,12 +501,21 @@ __global__ __launch_bounds__(THREADS, SumsShape<THREADS>::kWavesPerSimd) void k_
                 frame_body(std::integral_constant<int, 1>{}, std::false_type{});
         }
         if (redo) hd[0] = 1;
+        // a listed row with a record that is not finite (every commit of the frame is behind a barrier by now): the exact pass
+        // takes the frame; a launch without an exact list makes the frame's sums NaN -- which is what they would be -- so that
+        // k_associate leaves it to k_frame_recompute
+        if (tid < C) {
+            const uint32_t listed = np_l[tid] >= 16 ? 0xffffu : ((1u << np_l[tid]) - 1u);
+            if ((bad[tid >> 1] >> (16 * (tid & 1))) & listed) hd[0] = exact_list ? 1 : 2;
+        }
         __syncthreads();
+        if (tid < 8) bad[tid] = 0u;   // (read above by two threads each; set again during the frame after the next)
+        if (hd[0] == 2)
+            for (int k = tid; k < Kc; k += B) cs_f[k] = __longlong_as_double(0x7ff8000000000000ll);
         if (tid == 0) {
             if (out_flags) out_flags[f] = 0u;
             if (hd[0] && exact_list) exact_list[atomicAdd(exact_count, 1ull)] = (uint32_t)f;
-            hd[0] = hd[1] = 0;   // (for the frame after the next one)
-        }
+        }   // (hd[0] and hd[1] are cleared behind the next frame's first barrier: every thread reads hd[0] here)
         SUMS_STAMP(11);
         par ^= nch & 1;   // the next frame's first chunk goes where this frame's last chunk was not (its partial sums may still be read)
         f = fnext;

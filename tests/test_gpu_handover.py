@@ -472,6 +472,9 @@ def test_frames_whose_member_lists_do_not_fit_the_staging_stay_in_phase3(api, mo
     (8, 4, 133, {"SNOWTRI_SUMS_LDS_KB": "24"}),                                      # one wave of tiles, four joint sub-ranges, 8-joint chunks
     (8, 4, 40, {"SNOWTRI_SUMS_THREADS": "1024", "SNOWTRI_SUMS_LDS_KB": "160"}),      # the whole frame in one chunk: no second buffer used
     (6, 3, 33, {"SNOWTRI_SUMS_THREADS": "512"}),                                     # odd person count: one candidate per lane
+    (8, 4, 133, {"SNOWTRI_SUMS_THREADS": "64"}),                                     # one wave per workgroup: no barrier, one chunk buffer, 8-joint chunks
+    (4, 8, 57, {"SNOWTRI_SUMS_THREADS": "64"}),                                      # ... 48 tiles of 2 x 4
+    (16, 8, 133, {"SNOWTRI_SUMS_THREADS": "64", "SNOWTRI_SUMS_LDS_KB": "24"}),       # ... 960 tiles in 15 rounds of one wave
     (8, 4, 133, {"SNOWTRI_SPLIT_SEGMENTS": "1"}),                                    # the whole call on the caller's stream
     (8, 4, 133, {"SNOWTRI_SUMS_RAYS": "1"}),                                         # k_candidate_sums_rays: one lane per ray and joint sub-range
     (8, 4, 21, {"SNOWTRI_SUMS_RAYS": "1"}),                                          # ... two chunks, the second of five joints
@@ -801,3 +804,59 @@ def test_overlap_mode_with_multi_person_calls_is_bit_identical(api):
                 assert torch.equal(g[k].view(torch.int32), w[k].view(torch.int32)), (rep, k)
     assert int(want[0]["count"].sum()) >= F * P - 5
     ovl.close()
+
+
+@pytest.mark.parametrize("in_dtype", [np.float32, np.float64])
+def test_records_that_are_not_finite_send_their_frame_to_the_exact_pass(api, in_dtype, monkeypatch):
+    """k_candidate_sums gates without compares (a sign trick, p1_tile_sums): a NaN cannot pass through it, so a NaN or infinite
+    pixel or a NaN confidence in a LISTED row sends the frame to k_candidate_sums_exact where the record is written -- the
+    result must be the reference's -- and the same values in rows a camera does not list must change nothing at all.  A negative
+    distance_threshold (every pair gated; the sign of a zero would decide) keeps the batch off the streaming kernels."""
+    from snowmocap_amd import synth
+    from oracle import oracle as orc
+    rng = np.random.default_rng(77)
+    C, P, J, F = 8, 4, 133, 12
+    K, R, t = synth.ring_rig(C, radius=4.5)
+    X = synth.make_people(rng, F, P, J=J)
+    kp, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=0.7, score_range=(3.5, 9.0), permute_persons=True, dtype=in_dtype)
+    npers = npers.copy()
+    npers[5, 2] = 2                       # a ragged frame: rows 2 and 3 of camera 2 are not listed
+    npers[9, 7] = 3
+    prm = dict(PRM, keypoint_num=J)
+    clean = _run(api, K, R, t, prm, kp, npers, P + 2, monkeypatch)
+    assert "k_candidate_sums<" in clean["kernels"], clean["kernels"]
+    # unlisted rows full of NaN / inf: bit-identical outputs
+    junk = kp.copy()
+    junk[5, 2, 2:] = np.nan
+    junk[9, 7, 3, :, 0] = np.inf
+    junk[9, 7, 3, :, 2] = np.nan
+    out = _run(api, K, R, t, prm, junk, npers, P + 2, monkeypatch)
+    for k in ("xyzs", "pscore", "count", "flags"):
+        assert np.array_equal(out[k], clean[k], equal_nan=True), k
+    # listed rows: one NaN pixel, one infinite pixel, one NaN confidence, one -inf confidence (simply gated), in four frames
+    bad = kp.copy()
+    bad[1, 3, 1, 17, 0] = np.nan
+    bad[2, 0, 2, 130, 1] = np.inf
+    bad[3, 6, 0, 60, 2] = np.nan
+    bad[4, 5, 3, 5, 2] = -np.inf
+    ref = orc.triangulate_condense_batch(K, R, t, bad, npers, orc.make_params(**prm), 64)
+    out = _run(api, K, R, t, prm, bad, npers, P + 2, monkeypatch)
+    off = _run(api, K, R, t, prm, bad, npers, P + 2, monkeypatch, handover=False)
+    np.testing.assert_array_equal(out["count"], ref["count"])
+    np.testing.assert_array_equal(off["count"], ref["count"])
+    for f in range(F):
+        m = min(int(ref["count"][f]), P + 2)
+        g, o = out["xyzs"][f, :m].astype(np.float64), np.concatenate([ref["xyz"][f, :m], ref["kscore"][f, :m][..., None]], axis=-1)
+        np.testing.assert_array_equal(np.isnan(g), np.isnan(o), err_msg=f"frame {f}")
+        fin = np.isfinite(o[..., 3]) & (np.abs(o[..., 3]) < 1e9)
+        assert np.abs(g[..., :3] - o[..., :3])[fin].max(initial=0.0) < XYZ_F32 * 4, f
+        np.testing.assert_array_equal(np.isnan(out["pscore"][f, :m]), np.isnan(ref["pscore"][f, :m]), err_msg=f"pscore frame {f}")
+    # the frames without a bad record are untouched
+    for f in (0, 5, 6, 7, 8, 9, 10, 11):
+        assert np.array_equal(out["xyzs"][f], clean["xyzs"][f]), f
+    # negative distance_threshold: not a streaming batch, and the reference's result (nothing survives the pair gate)
+    neg = dict(prm, distance_threshold=-0.05)
+    refn = orc.triangulate_condense_batch(K, R, t, kp, npers, orc.make_params(**neg), 64)
+    outn = _run(api, K, R, t, neg, kp, npers, P + 2, monkeypatch)
+    assert "k_candidate_sums<" not in outn["kernels"], outn["kernels"]
+    np.testing.assert_array_equal(outn["count"], refn["count"])
