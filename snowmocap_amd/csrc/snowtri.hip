@@ -2074,13 +2074,15 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st_call, int64_t F, int
     }
     const bool handover = !stream && can_hand && sizeof(TOut) == 4 && prm.kn == J && ctx->handover_mode != 0 && C <= kClusterMaxCams;
     // the two descriptor lists hold Pout persons for every frame of a segment (<= 2 M entries each, 64 MB together), the
-    // member list Kc words per frame (<= 32 M words, 128 MB); row indices are 32-bit; the candidate sums of the
-    // streaming association 8 Kc bytes per frame (<= 512 MB)
+    // member list Kc words per frame (<= 64 M words, 256 MB); row indices are 32-bit; the candidate sums of the
+    // streaming association 8 Kc bytes per frame (<= 1 GB).  Sized for the LARGE rigs: a frame of 16 x 8 holds a CU for
+    // ~225 us of its candidate pass, a launch ends with up to one such frame per CU in its tail, and 12 500 frames in
+    // four segments of 3 125 (12 frames per CU) paid that tail four times -- now two segments of 6 250.
     int64_t seg_frames = F;
     if (stream || handover)
-        seg_frames = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(((int64_t)2 << 20) / Pout, ((int64_t)32 << 20) / Kc),
+        seg_frames = std::max<int64_t>(1, std::min<int64_t>(std::min<int64_t>(((int64_t)2 << 20) / Pout, ((int64_t)64 << 20) / Kc),
                                                           ((int64_t)1 << 31) / R));
-    if (stream) seg_frames = std::max<int64_t>(1, std::min<int64_t>(seg_frames, ((int64_t)64 << 20) / Kc));
+    if (stream) seg_frames = std::max<int64_t>(1, std::min<int64_t>(seg_frames, ((int64_t)128 << 20) / Kc));
     const int64_t seg_cap = ctx->handover_seg_frames > 0 ? ctx->handover_seg_frames : seg_frames;
     int64_t seg = (stream || handover) ? std::min(seg_frames, seg_cap) : F;
     // ONE call in (at least) two segments on two stream sets: every kernel of the streaming route holds the whole chip

@@ -109,7 +109,7 @@ __host__ __device__ inline int sums_chunk_joints(int C, int Pmax, int J, int npa
 // The weight of a kept candidate is the float (double: the double) sum of the two scores as before and the geometry is
 // untouched: a kept candidate adds the bits it added before.  What the sign trick cannot carry is a NaN (v_max returns
 // its other operand, the sign of a NaN r is arbitrary): records that are not finite are caught where they are written
-// (k_candidate_sums, `commit`) and send the frame to the exact pass.  r = -0 needs det = dn2 = 0 and dthr2 < 0: the host
+// (k_candidate_sums, `commit`; the arithmetic: gated_weight, snowtri_math.hpp) and send the frame to the exact pass.  r = -0 needs det = dn2 = 0 and dthr2 < 0: the host
 // keeps batches with a negative distance_threshold off this kernel.
 template <typename TIn>
 struct GatedScore;
@@ -121,20 +121,6 @@ template <>
 struct GatedScore<double> {
     static constexpr double value = -__builtin_huge_val();
 };
-__device__ __forceinline__ double tile_weight(float sm, float ss, double r) {
-    const uint32_t t = ((uint32_t)__double2hiint(r) & 0x80000000u) | __float_as_uint(sm + ss);
-    float v;
-    asm("v_max_f32 %0, %1, 0" : "=v"(v) : "v"(t));   // (fmaxf would canonicalize t first: one more instruction)
-    return (double)v;
-}
-__device__ __forceinline__ double tile_weight(double sm, double ss, double r) {
-    const double sd = sm + ss;
-    const uint32_t hi = ((uint32_t)__double2hiint(r) & 0x80000000u) | (uint32_t)__double2hiint(sd);
-    const double t = __hiloint2double((int)hi, __double2loint(sd));
-    double v;
-    asm("v_max_f64 %0, %1, 0" : "=v"(v) : "v"(t));
-    return v;
-}
 template <int GA, int GS, typename TIn>
 __device__ __forceinline__ void p1_tile_sums(const char *__restrict__ pa, const char *__restrict__ pb, int jstr, int nj, const Vec3 &d,
                                              const Params &prm, double (&acc)[GA * GS]) {
@@ -176,7 +162,7 @@ __device__ __forceinline__ void p1_tile_sums(const char *__restrict__ pa, const 
                 const double dn = fma(cz, b[u].z, fma(cy, b[u].y, cx * b[u].x));
                 const double dn2 = dn * dn;
                 const double r = fma(det, prm.dthr2, -dn2);                                         // :73-74: r < 0 <=> dist > distance_threshold
-                acc[i * GS + u] = fma(tile_weight(sm, ss[u], r), det * __builtin_amdgcn_rsq(dn2 * det), acc[i * GS + u]);
+                acc[i * GS + u] = fma(gated_weight(sm, ss[u], r), det * __builtin_amdgcn_rsq(dn2 * det), acc[i * GS + u]);
             }
         }
     }
@@ -325,16 +311,29 @@ __global__ __launch_bounds__(THREADS, SumsShape<THREADS>::kWavesPerSimd) void k_
 #ifdef SNOWTRI_K1_NOFILL   // TIMING-ONLY build (wrong sums): no ray records written
         if (F >= 0) return;
 #endif
+        // the ray matrices of ALL the thread's records first, then the rays, then the stores under their predicates: record by
+        // record inside `if (live)` the compiler read a matrix in three dependent LDS round trips per record -- nine in a row,
+        // ~1 us per chunk of 8 x 4 (wall-clock stamps) -- with nothing of the other records to put between them
+        double Mr[NPF][9];
 #pragma unroll
-        for (int n = 0; n < NPF; n++)
+        for (int n = 0; n < NPF; n++) {
+            const double *M = Ml + 9 * (pre_map[n] >= 0 ? (pre_map[n] >> 8) & 15 : 0);
+#pragma unroll
+            for (int k = 0; k < 9; k++) Mr[n][k] = M[k];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < NPF; n++) {
+            const int r = pre_map[n] & 255, c = (pre_map[n] >> 8) & 15, off = ((pre_map[n] >> 12) & 63) * jstr + kP1Rec * r;
+            const RayRec h = make_ray(Mr[n], pre[n].u, pre[n].v);
+            const TIn sc = pre[n].s;
+            const bool notfinite = !(fma((double)sc, 0.0, h.a) < 1e300);   // NaN or infinite |h|^2, NaN or infinite score
             if (((unsigned)pre_map[n] >> 12) < (unsigned)nj) {
-                const int r = pre_map[n] & 255, c = (pre_map[n] >> 8) & 15, off = ((pre_map[n] >> 12) & 63) * jstr + kP1Rec * r;
                 SNOWTRI_DEV_CHECK(off + kP1Rec <= half && c < C, 11);   // record inside the buffer
-                const RayRec h = make_ray(Ml + 9 * c, pre[n].u, pre[n].v);
-                const TIn sc = pre[n].s;
-                if (!(fma((double)sc, 0.0, h.a) < 1e300)) atomicOr(&bad[c >> 1], 1u << (r - c * Pmax + 16 * (c & 1)));   // (NaN or infinite |h|^2, NaN or infinite score)
+                if (notfinite) atomicOr(&bad[c >> 1], 1u << (r - c * Pmax + 16 * (c & 1)));
                 p1_store_record<TIn>(buf + off, h, below_kthr(sc, prm) ? GatedScore<TIn>::value : sc);
             }
+        }
     };
 
     int64_t f = blockIdx.x;
@@ -351,13 +350,19 @@ __global__ __launch_bounds__(THREADS, SumsShape<THREADS>::kWavesPerSimd) void k_
         const Kp3<TIn> *kpf = kp3 + f * (int64_t)R * Jrow;
         double *cs_f = csum + f * (int64_t)Kc;
         SUMS_STAMP(0);
-        if (tid == 0) hd[2] = (int32_t)atomicAdd(next_frame, 1ull);
+        // (the ticket is needed in the frame's LAST chunk: with two and more chunks it is handed to the workgroup behind the
+        // solves of the first one, so that the barrier below does not wait for the atomic's round trip)
+        unsigned long long ticket = 0;
+        if (tid == 0) {
+            ticket = atomicAdd(next_frame, 1ull);
+            if (nch == 1) hd[2] = (int32_t)ticket;
+        }
         if (tid < C && np_l[tid] != Pmax) hd[1] = 1;   // (np_l[tid] was written by this thread)
         uint32_t *bad = badrows + 8 * (it & 1);
         __syncthreads();   // first chunk (written during the frame before), np_l, ragged flag and ticket are there
         SUMS_STAMP(1);
         if (tid == 0) head[4 * ((it & 1) ^ 1)] = head[4 * ((it & 1) ^ 1) + 1] = 0;   // the flags of the frame before: read for the last time in front of this barrier, set again behind this frame's last one
-        const int64_t fnext = (int64_t)gridDim.x + (int64_t)(uint32_t)hd[2];
+        int64_t fnext = nch == 1 ? (int64_t)gridDim.x + (int64_t)(uint32_t)hd[2] : 0;
         const int GS = hd[1] ? 1 : p1_group_size(Pmax);   // a ragged frame keeps one candidate per lane
         const int GA = GS >= 2 ? kSumsGA : 1;      // (GS >= 2: Pmax is even)
         const int NG = Pmax / GS, per_q = (Pmax / GA) * NG, nitems = rig.npairs * per_q;
@@ -449,7 +454,9 @@ __global__ __launch_bounds__(THREADS, SumsShape<THREADS>::kWavesPerSimd) void k_
                 commit(rec0 + ((par ^ (c + 1)) & 1) * bufstep, last ? badrows + 8 * ((it & 1) ^ 1) : bad, nj_next);
                 if (last && succ && tid < C) np_both[Cp * ((it & 1) ^ 1) + tid] = npv;
                 SUMS_STAMP_C2(4);
+                if (nch > 1 && c == 0 && tid == 0) hd[2] = (int32_t)ticket;
                 __syncthreads();   // chunk c is solved (its buffer is free), chunk c + 1 is in LDS, csum is up to date
+                if (nch > 1 && c == 0) fnext = (int64_t)gridDim.x + (int64_t)(uint32_t)hd[2];
                 SUMS_STAMP_C2(6);
 #if defined(SNOWTRI_SUMS_TRACE) && SNOWTRI_SUMS_TRACE == 2   // (instead of the stamps of chunk 2: the end of every chunk, slots 2 .. 9)
                 if (c < 8) SUMS_STAMP(2 + c);

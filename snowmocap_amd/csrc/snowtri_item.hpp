@@ -62,7 +62,8 @@ __device__ __forceinline__ bool cluster_item(const double *__restrict__ K, const
     constexpr int kGroup = GROUP;
     Vec3 h[C];
     double a[C], alpha[C], beta[C];
-    bool okc[C];
+    TIn sg[C];          // the camera's confidence, -infinity where it is below the threshold (:73, once per camera)
+    bool nanscore = false;
     cluster_static_for<C>([&](auto CC) {
         constexpr int c = CC;
         const double *M = K + 9 * c;
@@ -72,9 +73,10 @@ __device__ __forceinline__ bool cluster_item(const double *__restrict__ K, const
         h[c].z = fma(M[6], u, fma(M[7], v, M[8]));
         a[c] = dot3(h[c], h[c]);
         if constexpr (sizeof(TIn) == 4)
-            okc[c] = !((float)cur[c].s < kthr_f32);   // triangulation.py:73, once per camera
+            sg[c] = (float)cur[c].s < kthr_f32 ? -__builtin_huge_valf() : (float)cur[c].s;
         else
-            okc[c] = !((double)cur[c].s < kthr);
+            sg[c] = (double)cur[c].s < kthr ? -__builtin_huge_val() : (double)cur[c].s;
+        nanscore |= cur[c].s != cur[c].s;
         alpha[c] = 0.0;
         beta[c] = 0.0;
     });
@@ -105,14 +107,10 @@ __device__ __forceinline__ bool cluster_item(const double *__restrict__ K, const
                 rho = __builtin_amdgcn_rsq(n2 * det);
             else
                 rho = rsq_nr1(n2 * det);   // (n2 det == 0: inf -> NaN here; either way the sum is not finite and the joint is re-done)
-            // :72-74, w det = 2000 x the pair score; the gates select the score sum before the product (plain selects here: 28
-            // lane masks held for an inline v_cndmask, as in k_fused_lean, overflow the scalar registers)
-            const bool keep = okc[mc] && okc[sc] && !(n2 > dthr2 * det);
-            double w;
-            if constexpr (sizeof(TIn) == 4)
-                w = (double)(keep ? (float)cur[mc].s + (float)cur[sc].s : 0.0f) * rho;   // float32 sum as NumPy
-            else
-                w = (keep ? (double)cur[mc].s + (double)cur[sc].s : 0.0) * rho;
+            // :72-74, w det = 2000 x the pair score.  The gates without compares (gated_weight, snowtri_math.hpp): a gated
+            // confidence is -infinity, the distance gate the sign of fma(det, dthr2, -n2), one v_max with 0 -- the sum of a
+            // kept pair is the float32 (float64) sum NumPy takes, a gated pair weighs exactly +0 as the select it replaces
+            const double w = gated_weight(sg[mc], sg[sc], fma(det, dthr2, -n2)) * rho;
             alpha[mc] = fma(w, N0, alpha[mc]);
             alpha[sc] = fma(-w, N1, alpha[sc]);
             beta[mc] = fma(w, det, beta[mc]);
@@ -135,7 +133,7 @@ __device__ __forceinline__ bool cluster_item(const double *__restrict__ K, const
     oy = sy * r;
     oz = sz * r;
     os = sb * (0.00025 / (double)NP);   // :148
-    return !(sb < 1e300);
+    return !(sb < 1e300) || nanscore;   // (a NaN confidence does not survive the v_max: the sequential routine takes the joint)
 }
 
 }  // namespace snowtri

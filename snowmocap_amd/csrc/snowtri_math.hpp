@@ -89,6 +89,27 @@ __device__ __forceinline__ double gated_sum_sel(float sm, float ss, bool keep) {
 }
 __device__ __forceinline__ double gated_sum_sel(double sm, double ss, bool keep) { return keep ? sm + ss : 0.0; }
 
+// The pair gates of triangulation.py:73-74 WITHOUT compares: the weight (sm + ss) of a pair whose confidences were gated when
+// they were read (a confidence below the threshold replaced by -infinity: the sum is negative or NaN exactly when one of them
+// is gated; confidences that pass are >= keypoint_score_threshold >= 0) and whose distance gate is the SIGN of r =
+// fma(det, dthr2, -n2) (r < 0 <=> dist > distance_threshold): the sign of r is OR-ed into the sign of the sum, one v_max with 0
+// zeroes a gated weight.  Four full-rate instructions where two compares into scalar masks, s_and and v_cndmask cost three
+// times their issue slots (scripts/ubench/sums_mix.hip).  A kept pair weighs the float32 (float64) sum NumPy takes, a gated
+// one exactly +0.  A NaN confidence does not survive the v_max: callers catch it where they read it.
+__device__ __forceinline__ double gated_weight(float sm, float ss, double r) {
+    const uint32_t t = ((uint32_t)__double2hiint(r) & 0x80000000u) | __float_as_uint(sm + ss);
+    float v;
+    asm("v_max_f32 %0, %1, 0" : "=v"(v) : "v"(t));   // (fmaxf would canonicalize t first: one more instruction)
+    return (double)v;
+}
+__device__ __forceinline__ double gated_weight(double sm, double ss, double r) {
+    const double sd = sm + ss;
+    const uint32_t hi = ((uint32_t)__double2hiint(r) & 0x80000000u) | (uint32_t)__double2hiint(sd);
+    const double t = __hiloint2double((int)hi, __double2loint(sd));
+    double v;
+    asm("v_max_f64 %0, %1, 0" : "=v"(v) : "v"(t));
+    return v;
+}
 struct SkewOut {
     Vec3 W;       // midpoint (Wm + Ws) / 2
     double dist;  // ||Wm - Ws||

@@ -757,8 +757,10 @@ def test_random_rigs_float64_outputs_and_keypoint_num(api, monkeypatch):
         # (the conditioning budget of assert_scores_close -- a rounding-level error of the distance, 5e-14 m -- is sized for rays of
         # a 4-camera room; the rays of a 9-16 camera ring of up to 6 m radius are twice as long and meet under flatter angles)
         derr = 2e-13 if C >= 9 else 5e-14
-        if C >= 9 and prm["condense_distance_tol"] >= 10.0:
-            derr = 5e-13    # (everything merges: a fused score is the mean of hundreds of member scores, 1/dist-tailed)
+        if prm["condense_distance_tol"] >= 10.0:
+            # (everything merges: a fused score is the mean of hundreds of member scores, 1/dist-tailed.  8 cameras x 4 persons
+            # too -- 448 members: soak round 404 of round 5, 1.32 x the 4-camera budget, with the library of round 4 as well)
+            derr = 5e-13 if C >= 9 else 2e-13
         for o, name in ((out, "route"), (off, "k_frame_recompute")):
             np.testing.assert_array_equal(o["count"], ref["count"], err_msg=msg + " " + name)
             for f in range(F):
