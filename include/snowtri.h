@@ -116,7 +116,8 @@ int snowtri_ctx_synchronize(snowtri_ctx *ctx);
  *   SNOWTRI_SPLIT_SEGMENTS=1|n      1: one multi-person call stays on the caller's stream; n >= 2: at least n segments alternating
  *                                   between the caller's stream and an internal one, also for small batches (default: 2
  *                                   segments once a segment holds >= 4 frames per CU)
- *   SNOWTRI_SUMS_THREADS, SNOWTRI_SUMS_LDS_KB, SNOWTRI_LEAN_TILES_PER_WAVE   launch shapes (tests force the rare ones)
+ *   SNOWTRI_SUMS_THREADS, SNOWTRI_SUMS_LDS_KB, SNOWTRI_LEAN_TILES_PER_WAVE   launch shapes (tests force the rare ones;
+ *                                   SNOWTRI_SUMS_THREADS=64: the candidate pass with one wave per workgroup, measured slower)
  *   SNOWTRI_DEBUG=1                 launch shapes on stderr
  * Results never depend on a knob (that is what the tests that set them check); only the route does. */
 const char *snowtri_ctx_overrides(const snowtri_ctx *ctx);

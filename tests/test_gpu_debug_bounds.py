@@ -114,6 +114,20 @@ for C, P, J, F in ((8, 4, 133, 30), (16, 2, 40, 6), (4, 8, 57, 6)):
     names = run(K, R, t, dict(PRM, keypoint_num=J), kp, npers, P + 2)
     assert "k_candidate_sums_rays" in names, names
 os.environ.pop("SNOWTRI_SUMS_RAYS")
+# the candidate pass with one wave per workgroup (one chunk buffer), and its 1 024-thread shape on a small rig (one chunk, no second buffer)
+for knobs in ({"SNOWTRI_SUMS_THREADS": "64"}, {"SNOWTRI_SUMS_THREADS": "1024", "SNOWTRI_SUMS_LDS_KB": "160"}):
+    os.environ.update(knobs)
+    for C, P, J, F in ((8, 4, 133, 20), (4, 8, 57, 6), (6, 3, 33, 6)):
+        K, R, t = synth.ring_rig(C, radius=5.0)
+        X = synth.make_people(rng, F, P, J=J)
+        kp, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=0.7, score_range=(2.0, 9.0), permute_persons=True, dtype=np.float32)
+        npers = npers.copy()
+        npers[1, C - 1] = P - 1
+        kp[2, 0, 0, 3, 0] = np.nan            # a record that is not finite: the bad-row mask and the exact pass
+        names = run(K, R, t, dict(PRM, keypoint_num=J), kp, npers, P + 2, check=False)
+        assert "k_candidate_sums<" in names, names
+    for k in knobs:
+        os.environ.pop(k)
 print("debug-bounds ok:", ran, "calls")
 '''
 
