@@ -16,11 +16,15 @@
 // do not see).  A frame in which a camera lists fewer than P persons takes a plain loop over the candidate slots instead.
 // Same outputs, hand-shake (ticket counter, exact list, flags) and LDS record layout as k_candidate_sums.
 //
-// MEASURED (round 5, EXPERIMENTS.md) and NOT the default: 8 x 4 x 10 000 frames 831 us against the tile kernel's 710 us.  The
-// kernel issues 14 % fewer VALU instructions per frame (74 472 against 86 671 per wave) but keeps the SIMDs busy 54 % of the
-// time against 77 %: a lane solves two joints between two barriers, each behind 75 LDS reads, and at three waves per SIMD
-// (168 registers: 28 of sums, 24 of pair offsets, one set of partner records) nothing hides them; a second register set
-// for the next tile's records spills inside the loop.  SNOWTRI_SUMS_RAYS=1 selects it (tests/test_gpu_handover.py).
+// MEASURED (round 5, EXPERIMENTS.md) and NOT the default.  First version: 8 x 4 x 10 000 frames 831 us against the tile kernel's
+// 710 us, VALU busy 0.54 against 0.77 -- blamed on its 75 LDS reads per joint.  The real causes were the tile kernel's too (found
+// there with wall-clock stamps): every keypoint request waited for its own data, the record fill read its matrices in dependent
+// LDS round trips, the pair gates went through scalar masks.  With the same fixes (requests inside one pass of the chunk loop,
+// gated_weight, bad-record masks): 635-655 us against the reworked tile kernel's 674-680 us on one stream -- 10 % fewer VALU
+// instructions per wave (71 566 against 79 269), conflict ratio 0.05, VALU busy 0.72 against 0.75 (nine chunks of 16 joints per
+// frame against seven of 20: more barriers per solve) -- and END TO END NOTHING: 1.071-1.085 against 1.086-1.091 ms per call on
+// one stream, 1.040-1.050 against 1.036-1.043 ms in the default two-segment mode.  SNOWTRI_SUMS_RAYS=1 selects it
+// (tests/test_gpu_handover.py, tests/test_gpu_debug_bounds.py).
 //
 // Fill: thread t owns joint t % 16 of rows t / 16 and t / 16 + 16 of every chunk of 16 joints: no index arithmetic per
 // record, and the 16 lanes of an LDS write group stay inside one row (consecutive joints = consecutive banks): the write
@@ -39,7 +43,7 @@ constexpr int kRaysJc = kRaysJS * kRaysJPS;       // joints per chunk (16)
 constexpr int kRaysWaves = 3;                     // waves per SIMD the registers must allow
 
 __host__ __device__ constexpr size_t rays_arena_offset(int C, int npairs) {
-    return ((size_t)kSumsHeadBytes + (size_t)4 * (C + (C & 1)) + (size_t)8 * npairs + (size_t)72 * C + 15) & ~(size_t)15;
+    return ((size_t)kSumsHeadBytes + (size_t)8 * (C + (C & 1)) + (size_t)8 * npairs + (size_t)72 * C + 15) & ~(size_t)15;   // head | n_persons [2][C] | pairs | ray matrices
 }
 __host__ __device__ constexpr int rays_buffer_bytes() { return kRaysJc * (kP1Rec * kRaysRows + 8); }
 __host__ __device__ constexpr size_t rays_lds_bytes(int C, int npairs) { return rays_arena_offset(C, npairs) + 2 * (size_t)rays_buffer_bytes(); }
@@ -68,8 +72,10 @@ __global__ __launch_bounds__(kRaysThreads, kRaysWaves) void k_candidate_sums_ray
     (void)lane;
 
     int32_t *head = reinterpret_cast<int32_t *>(smem);
-    int32_t *np_l = reinterpret_cast<int32_t *>(smem + kSumsHeadBytes);           // [C]
-    int32_t *pairs = np_l + C + (C & 1);                                          // [NP][2]
+    uint32_t *badrows = reinterpret_cast<uint32_t *>(smem + 64);                  // [2][8]: records that are not finite, as in k_candidate_sums
+    constexpr int Cp = C + (C & 1);
+    int32_t *np_both = reinterpret_cast<int32_t *>(smem + kSumsHeadBytes);        // [2][Cp]: persons listed by the cameras, by frame parity
+    int32_t *pairs = np_both + 2 * Cp;                                            // [NP][2]
     double *Ml = reinterpret_cast<double *>(pairs + 2 * NP);                      // [C][9]
     char *const rec0 = smem + rays_arena_offset(C, NP);
     if (tid < kSumsHeadBytes / 4) head[tid] = 0;
@@ -102,49 +108,79 @@ __global__ __launch_bounds__(kRaysThreads, kRaysWaves) void k_candidate_sums_ray
 
     // ---- fill: thread t holds joint t % Jc of rows t / Jc + (B / Jc) n of a chunk
     const int fj = tid % Jc, frow0 = tid / Jc;
+    // (requested in front of a chunk's solves, written behind them, inside one pass of the chunk loop; one-component loads at
+    // offsets the compiler cannot relate; the ray matrices of both records before the rays: k_candidate_sums has the reasons)
     Kp3<TIn> pre[NPF];
-    int pre_nj = 0;    // joints of the chunk in `pre`
-    int npv = P;       // threads < C: n_persons of the coming frame
+    int npv = P;       // threads < C: n_persons of the frame whose first chunk is in `pre`
     auto fetch = [&](const Kp3<TIn> *kpf, int j0, int nj) {
-        const int j = j0 + (fj < nj ? fj : nj - 1);   // (every thread loads: a load inside a branch is waited for where the branch joins)
-        SNOWTRI_DEV_CHECK(j >= 0 && j < J, 41);
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<Kp3<TIn> *>(kpf), 0, R * Jrow * (int)sizeof(Kp3<TIn>), 0x00020000);
+        SNOWTRI_DEV_CHECK(fj >= nj || (j0 + fj >= 0 && j0 + fj < J), 41);
 #pragma unroll
-        for (int n = 0; n < NPF; n++) pre[n] = kpf[(size_t)(frow0 + (B / Jc) * n) * Jrow + j];
-        pre_nj = nj;
+        for (int n = 0; n < NPF; n++) {
+            int o0 = fj < nj ? ((frow0 + (B / Jc) * n) * Jrow + j0 + fj) * (int)sizeof(Kp3<TIn>) : 0x7ffffff0, o1 = o0, o2 = o0;   // (past the range: zeros)
+            asm volatile("" : "+v"(o1));
+            asm volatile("" : "+v"(o2));
+            if constexpr (sizeof(TIn) == 4) {
+                pre[n].u = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, o0, 0, 0));
+                pre[n].v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, o1 + 4, 0, 0));
+                pre[n].s = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, o2 + 8, 0, 0));
+            } else {
+                typedef unsigned u2v __attribute__((ext_vector_type(2)));
+                const u2v a = __builtin_amdgcn_raw_buffer_load_b64(rs, o0, 0, 0), b = __builtin_amdgcn_raw_buffer_load_b64(rs, o1 + 8, 0, 0),
+                          d = __builtin_amdgcn_raw_buffer_load_b64(rs, o2 + 16, 0, 0);
+                pre[n].u = __hiloint2double((int)a.y, (int)a.x);
+                pre[n].v = __hiloint2double((int)b.y, (int)b.x);
+                pre[n].s = __hiloint2double((int)d.y, (int)d.x);
+            }
+        }
     };
-    auto fetch_frame = [&](int64_t fr) {
-        fetch(kp3 + fr * (int64_t)R * Jrow, 0, J < Jc ? J : Jc);
-        if (n_persons && tid < C) npv = n_persons[fr * C + tid];
-    };
-    auto commit = [&](char *buf) {
-        if (fj < pre_nj) {
+    auto commit = [&](char *buf, uint32_t *bad, int nj) {
+        double Mr[NPF][9];
 #pragma unroll
-            for (int n = 0; n < NPF; n++) {
-                const int row = frow0 + (B / Jc) * n;
-                p1_store_record<TIn>(buf + fj * jstr + kP1Rec * row, make_ray(Ml + 9 * (row / P), pre[n].u, pre[n].v), pre[n].s);
+        for (int n = 0; n < NPF; n++) {
+            const double *M = Ml + 9 * ((frow0 + (B / Jc) * n) / P);
+#pragma unroll
+            for (int k = 0; k < 9; k++) Mr[n][k] = M[k];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < NPF; n++) {
+            const int row = frow0 + (B / Jc) * n, c = row / P;
+            const RayRec h = make_ray(Mr[n], pre[n].u, pre[n].v);
+            const TIn sc = pre[n].s;
+            const bool notfinite = !(fma((double)sc, 0.0, h.a) < 1e300);   // NaN or infinite |h|^2, NaN or infinite score
+            if (fj < nj) {
+                if (notfinite) atomicOr(&bad[c >> 1], 1u << (row - c * P + 16 * (c & 1)));
+                p1_store_record<TIn>(buf + fj * jstr + kP1Rec * row, h, below_kthr(sc, prm) ? GatedScore<TIn>::value : sc);
             }
         }
     };
 
     const int nch = (J + Jc - 1) / Jc;
     int64_t f = blockIdx.x;
-    if (f < F) fetch_frame(f);
     int par = 0;
     __syncthreads();   // constants and the cleared head
+    if (f < F) {       // the first chunk of the workgroup's first frame (every later one is written during the frame before it)
+        fetch(kp3 + f * (int64_t)R * Jrow, 0, J < Jc ? J : Jc);
+        if (n_persons && tid < C) npv = n_persons[f * C + tid];
+        commit(rec0, badrows, J < Jc ? J : Jc);
+        if (tid < C) np_both[tid] = npv;
+    }
     for (int it = 0; f < F; it++) {
         int32_t *hd = head + 4 * (it & 1);
+        const int32_t *np_l = np_both + Cp * (it & 1);
+        uint32_t *bad = badrows + 8 * (it & 1);
         const Kp3<TIn> *kpf = kp3 + f * (int64_t)R * Jrow;
         double *cs_f = csum + f * (int64_t)Kc;
-        if (tid == 0) hd[2] = (int32_t)atomicAdd(next_frame, 1ull);
-        if (tid < C) {
-            np_l[tid] = npv;
-            if (npv != P) hd[1] = 1;
+        unsigned long long ticket = 0;   // (handed to the workgroup behind the first chunk's solves: the barrier below does not wait for the atomic)
+        if (tid == 0) {
+            ticket = atomicAdd(next_frame, 1ull);
+            if (nch == 1) hd[2] = (int32_t)ticket;
         }
-        commit(rec0 + par * half);
-        if (nch >= 2) fetch(kpf, Jc, (J - Jc) < Jc ? (J - Jc) : Jc);
-        __syncthreads();   // first chunk, np_l, ragged flag and ticket are there
-        const int64_t fnext = (int64_t)gridDim.x + (int64_t)(uint32_t)hd[2];
-        if (nch == 1 && fnext < F) fetch_frame(fnext);
+        if (tid < C && np_l[tid] != P) hd[1] = 1;   // (np_l[tid] was written by this thread)
+        __syncthreads();   // first chunk (written during the frame before), np_l, ragged flag and ticket are there
+        if (tid == 0) head[4 * ((it & 1) ^ 1)] = head[4 * ((it & 1) ^ 1) + 1] = 0;   // the flags of the frame before
+        int64_t fnext = nch == 1 ? (int64_t)gridDim.x + (int64_t)(uint32_t)hd[2] : 0;
         const bool ragged = hd[1] != 0;   // workgroup-uniform
         bool redo = false;
         auto finish = [&](int k, double v) {   // the 1 / (2 * 1000) of :72, and whether a mean can decide :80-81
@@ -152,14 +188,25 @@ __global__ __launch_bounds__(kRaysThreads, kRaysWaves) void k_candidate_sums_ray
             cs_f[k] = s_;
             redo |= exact_list != nullptr && (!(fabs(mean) < 1e300) || (s_ != 0.0 && fabs(mean - prm.avg_thr) <= 1e-6 * fabs(mean)));
         };
-        auto advance = [&](int c, int j0) {    // behind the solves of chunk c: the next chunk's records, the one after's keypoints
-            if (c + 1 < nch) {
-                commit(rec0 + ((par ^ (c + 1)) & 1) * half);
-                if (c + 2 < nch)
-                    fetch(kpf, j0 + 2 * Jc, (J - j0 - 2 * Jc) < Jc ? (J - j0 - 2 * Jc) : Jc);
-                else if (fnext < F)
-                    fetch_frame(fnext);
-            }
+        // in front of the solves of chunk c: the keypoints of chunk c + 1 -- in the frame's last chunk those of the NEXT frame's
+        // first chunk, with its n_persons; behind them: its records, into the buffer chunk c - 1 was solved in
+        int nj_next = 0;
+        bool last = false, succ = false;
+        auto request = [&](int c, int j0) {
+            last = c + 1 >= nch;
+            succ = fnext < F;
+            nj_next = last ? (succ ? (J < Jc ? J : Jc) : 0) : ((J - j0 - Jc) < Jc ? (J - j0 - Jc) : Jc);
+            fetch(last && succ ? kp3 + fnext * (int64_t)R * Jrow : kpf, last ? 0 : j0 + Jc, nj_next);
+            if (last && succ && n_persons && tid < C) npv = n_persons[fnext * C + tid];
+            __builtin_amdgcn_sched_barrier(0);
+        };
+        auto written = [&](int c) {
+            commit(rec0 + ((par ^ (c + 1)) & 1) * half, last ? badrows + 8 * ((it & 1) ^ 1) : bad, nj_next);
+            if (last && succ && tid < C) np_both[Cp * ((it & 1) ^ 1) + tid] = npv;
+            if (nch > 1 && c == 0 && tid == 0) hd[2] = (int32_t)ticket;
+        };
+        auto handed = [&](int c) {   // behind the barrier of chunk c
+            if (nch > 1 && c == 0) fnext = (int64_t)gridDim.x + (int64_t)(uint32_t)hd[2];
         };
 
         if (!ragged) {
@@ -174,10 +221,10 @@ __global__ __launch_bounds__(kRaysThreads, kRaysWaves) void k_candidate_sums_ray
                 const int jlo = jrot * kRaysJPS;
                 const int cnt = nj - jlo < kRaysJPS ? (nj - jlo < 0 ? 0 : nj - jlo) : kRaysJPS;
                 const char *pj = cur + jlo * jstr;
+                request(c, j0);
                 for (int t = 0; t < cnt; t++, pj += jstr) {
                     const RayRec a = p1_load_ray(pj + oa);
                     const TIn sm = p1_load_score<TIn>(pj + oa);
-                    const bool okm = !below_kthr(sm, prm);
 #pragma unroll
                     for (int ti = 0; ti < NT; ti++) {
                         const Vec3 d = t_d[ti];
@@ -198,16 +245,16 @@ __global__ __launch_bounds__(kRaysThreads, kRaysWaves) void k_candidate_sums_ray
                                 const double det = fma(a.a, b[u].a, -(bq * bq));
                                 const double dn = fma(cz, b[u].z, fma(cy, b[u].y, cx * b[u].x));
                                 const double dn2 = dn * dn;
-                                const bool kp_ = okm && !below_kthr(ss[u], prm) && !(dn2 > det * prm.dthr2);   // :73-74
-                                // (float32 confidences add in float32, first camera's + second camera's: the sum commutes)
+                                // :73-74 without compares (gated_weight; float32 confidences add in float32, the sum commutes)
                                 const int ai = (ti < H ? ti * P : H * P) + u;
-                                tot[ai] = fma(gated_sum_sel(sm, ss[u], kp_), det * __builtin_amdgcn_rsq(dn2 * det), tot[ai]);
+                                tot[ai] = fma(gated_weight(sm, ss[u], fma(det, prm.dthr2, -dn2)), det * __builtin_amdgcn_rsq(dn2 * det), tot[ai]);
                             }
                         }
                     }
                 }
-                advance(c, j0);
+                written(c);
                 __syncthreads();   // chunk c is solved (its buffer is free), chunk c + 1 is in LDS
+                handed(c);
             }
             // the two joint sub-ranges of a wave meet in its lower half, the four waves in the buffer of the last chunk
             double *lsum = reinterpret_cast<double *>(rec0 + ((par ^ (nch - 1)) & 1) * half);
@@ -248,6 +295,7 @@ __global__ __launch_bounds__(kRaysThreads, kRaysWaves) void k_candidate_sums_ray
             for (int c = 0, j0 = 0; c < nch; c++, j0 += Jc) {
                 const int nj = (J - j0) < Jc ? (J - j0) : Jc;
                 const char *cur = rec0 + ((par ^ c) & 1) * half;
+                request(c, j0);
 #pragma unroll
                 for (int rd = 0; rd < 2; rd++) {
                     const char *pj = cur;
@@ -264,20 +312,27 @@ __global__ __launch_bounds__(kRaysThreads, kRaysWaves) void k_candidate_sums_ray
                         acc[rd] = fma(gated_sum_sel(sm, ss, kp_), det * __builtin_amdgcn_rsq(dn2 * det), acc[rd]);
                     }
                 }
-                advance(c, j0);
+                written(c);
                 __syncthreads();
+                handed(c);
             }
 #pragma unroll
             for (int rd = 0; rd < 2; rd++)
                 if (tid + rd * B < Kc) finish(tid + rd * B, live[rd] ? acc[rd] : 0.0);
         }
         if (redo) hd[0] = 1;
+        if (tid < C) {   // a listed row with a record that is not finite: the exact pass, or NaN sums where the launch has no exact list
+            const uint32_t listed = np_l[tid] >= 16 ? 0xffffu : ((1u << np_l[tid]) - 1u);
+            if ((bad[tid >> 1] >> (16 * (tid & 1))) & listed) hd[0] = exact_list ? 1 : 2;
+        }
         __syncthreads();
+        if (tid < 8) bad[tid] = 0u;
+        if (hd[0] == 2)
+            for (int k = tid; k < Kc; k += B) cs_f[k] = __longlong_as_double(0x7ff8000000000000ll);
         if (tid == 0) {
             if (out_flags) out_flags[f] = 0u;
             if (hd[0] && exact_list) exact_list[atomicAdd(exact_count, 1ull)] = (uint32_t)f;
-            hd[0] = hd[1] = 0;   // (for the frame after the next one)
-        }
+        }   // (hd[0] and hd[1] are cleared behind the next frame's first barrier)
         par ^= nch & 1;   // the next frame's first chunk goes where this frame's last chunk was not (its partial sums may still be read)
         f = fnext;
     }
