@@ -12,7 +12,7 @@ for path in glob.glob("$OUT/t/**/*kernel_trace.csv", recursive=True):
         rows.append((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"][:60]))
 rows.sort()
 # last 20 kernels
-last = rows[-16:]
+last = rows[-22:]
 t0 = last[0][0]
 prev_end = None
 for s, e, n in last:
