@@ -862,3 +862,33 @@ def test_records_that_are_not_finite_send_their_frame_to_the_exact_pass(api, in_
     outn = _run(api, K, R, t, neg, kp, npers, P + 2, monkeypatch)
     assert "k_candidate_sums<" not in outn["kernels"], outn["kernels"]
     np.testing.assert_array_equal(outn["count"], refn["count"])
+
+
+def test_a_record_that_is_not_finite_in_the_second_candidate_sum_launch(api, monkeypatch):
+    """keypoint_num < J with an active condense_score_tol: k_candidate_sums runs a second time over the first keypoint_num joints,
+    without an exact list -- a frame with a NaN record there gets NaN sums (which is what they are) and k_associate leaves it to
+    k_frame_recompute.  Against the oracle, NaN patterns included."""
+    from snowmocap_amd import synth
+    from oracle import oracle as orc
+    rng = np.random.default_rng(78)
+    C, P, J, F, kn = 8, 4, 133, 8, 30
+    K, R, t = synth.ring_rig(C, radius=4.5)
+    X = synth.make_people(rng, F, P, J=J)
+    kp, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=0.7, score_range=(3.5, 9.0), permute_persons=True, dtype=np.float32)
+    prm = dict(PRM, keypoint_num=kn, condense_score_tol=0.5)
+    kp = kp.copy()
+    kp[2, 1, 0, 7, 0] = np.nan        # inside the first keypoint_num joints: both launches see it
+    kp[5, 4, 2, 100, 2] = np.nan      # behind them: only the launch over all J joints does
+    ref = orc.triangulate_condense_batch(K, R, t, kp, npers, orc.make_params(**prm), 64)
+    out = _run(api, K, R, t, prm, kp, npers, P + 2, monkeypatch)
+    assert "k_candidate_sums<" in out["kernels"], out["kernels"]
+    np.testing.assert_array_equal(out["count"], ref["count"])
+    for f in range(F):
+        m = min(int(ref["count"][f]), P + 2)
+        g, o = out["xyzs"][f, :m].astype(np.float64), np.concatenate([ref["xyz"][f, :m], ref["kscore"][f, :m][..., None]], axis=-1)
+        np.testing.assert_array_equal(np.isnan(g), np.isnan(o), err_msg=f"frame {f}")
+        fin = np.isfinite(o[..., 3]) & (np.abs(o[..., 3]) < 1e9)
+        assert np.abs(g[..., :3] - o[..., :3])[fin].max(initial=0.0) < XYZ_F32 * 4, f
+        np.testing.assert_array_equal(np.isnan(out["pscore"][f, :m]), np.isnan(ref["pscore"][f, :m]), err_msg=f"pscore frame {f}")
+        ok = np.isfinite(ref["pscore"][f, :m])
+        assert_scores_close(out["pscore"][f, :m][ok], ref["pscore"][f, :m][ok], rtol=3e-7, nterms=kn, what=f"pscore frame {f}")
