@@ -19,12 +19,12 @@
 namespace snowtri {
 
 // ---------------------------------------------------------------------------------------------- k_candidate_sums
-// LDS: [0, 64) flags and tickets | n_persons of the frame (4 B x C) | per camera pair d = t_s - t_m and the two camera
+// LDS: [0, 64) flags and tickets | [64, 128) per frame parity and PAIR of cameras (16 bits each): the persons whose records are
+// not finite | n_persons of the frame, per frame parity (2 x 4 B x C) | per camera pair d = t_s - t_m and the two camera
 // indices (32 B) | ray matrices | arena = TWO buffers of one joint chunk of ray records each (layout and bank map:
 // snowtri_general.hpp, p1_joint_stride): the waves solve the chunk in one buffer while the records of the next chunk are
 // written to the other; at the end of a frame the buffer of its last chunk holds the partial sums of the joint sub-ranges.
-// flags and tickets | [2][8] per frame parity and PAIR of cameras (16 bits each): persons whose records are not finite.  (Every
-// byte in front of the arena counts: 8 cameras x 4 persons hold chunks of 20 joints in 52 KB with 1 728 bytes to spare.)
+// (Every byte in front of the arena counts: 8 cameras x 4 persons hold chunks of 20 joints in 52 KB with 1 728 bytes to spare.)
 constexpr int kSumsHeadBytes = 64 + 2 * 8 * 4;
 // workgroup shapes (threads, waves per SIMD the registers must allow, records of the coming chunk a thread holds in
 // registers): 256 threads x 3 workgroups per CU for the small rigs, 512 x 2 or 1024 x 1 for the large ones
@@ -185,7 +185,8 @@ __device__ unsigned long long g_sums_trace[4096 * 4 * 16];
 // csum[f][k] = sum over the joints of the score of candidate slot k (J x the mean of :79; 0 for a slot whose cameras
 // list fewer persons), with the fast arithmetic of p1_tile_sums; a frame with a candidate whose fast sum cannot decide
 // :80-81 -- not finite, or within 1e-6 relative of average_score_threshold -- is appended to exact_list and re-done by
-// k_candidate_sums_exact.  out_flags[f] = 0.  Host-checked: keypoint_score_threshold >= 0, C <= 16.  Dynamic LDS = lds_total.
+// k_candidate_sums_exact; so is a frame with a record that is not finite in a listed row (`commit`).  out_flags[f] = 0.
+// Host-checked: keypoint_score_threshold >= 0, distance_threshold >= 0, C <= 16, <= 16 persons per camera.  Dynamic LDS = lds_total.
 //
 // Frames: the first one by workgroup index, the following ones through a ticket counter (next_frame, zeroed by the host).
 // Every frame costs the same instructions, but the SIMDs serve their waves oldest first: with a static deal the oldest
