@@ -277,25 +277,33 @@ __global__ __launch_bounds__(THREADS, SumsShape<THREADS>::kWavesPerSimd) void k_
     auto fetch = [&](const Kp3<TIn> *kpf, int j0, int nj) {
         // (range-checked on the byte offset: an idle slot reads zeros from past the frame's end)
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<Kp3<TIn> *>(kpf), 0, R * Jrow * (int)sizeof(Kp3<TIn>), 0x00020000);
+        // every offset first, then the loads back to back: whatever the offsets need from scratch (the 1 024-thread shape spills)
+        // is reloaded in FRONT of the requests -- a reload between or behind them waits for them (vmcnt counts in order).
+        // Three loads of one component each, at offsets the compiler cannot relate (or it merges them again): one load of three
+        // registers ties them to a register triple, and the compiler, wanting one of the three elsewhere during the solves,
+        // copied it right behind the load -- s_waitcnt vmcnt(0) in front of the copy
+        int o0[NPF], o1[NPF], o2[NPF];
 #pragma unroll
         for (int n = 0; n < NPF; n++) {
             const int r = pre_map[n] & 255, jj = (pre_map[n] >> 12) & 63;
             const bool live = ((unsigned)pre_map[n] >> 12) < (unsigned)nj;
             SNOWTRI_DEV_CHECK(!live || (r < R && j0 + jj < J), 10);   // keypoint (row, joint) inside the frame
-            // three loads of one component each, at offsets the compiler cannot relate (or it merges them again): one load of
-            // three registers ties them to a register triple, and the compiler, wanting one of the three elsewhere during
-            // the solves, copied it right behind the load -- s_waitcnt vmcnt(0) in front of the copy
-            int o0 = live ? (r * Jrow + jj + j0) * (int)sizeof(Kp3<TIn>) : 0x7ffffff0, o1 = o0, o2 = o0;
-            asm volatile("" : "+v"(o1));
-            asm volatile("" : "+v"(o2));
+            o0[n] = live ? (r * Jrow + jj + j0) * (int)sizeof(Kp3<TIn>) : 0x7ffffff0;
+            o1[n] = o0[n];
+            o2[n] = o0[n];
+            asm volatile("" : "+v"(o0[n]), "+v"(o1[n]), "+v"(o2[n]));
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int n = 0; n < NPF; n++) {
             if constexpr (sizeof(TIn) == 4) {
-                pre[n].u = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, o0, 0, 0));
-                pre[n].v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, o1 + 4, 0, 0));
-                pre[n].s = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, o2 + 8, 0, 0));
+                pre[n].u = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, o0[n], 0, 0));
+                pre[n].v = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, o1[n] + 4, 0, 0));
+                pre[n].s = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rs, o2[n] + 8, 0, 0));
             } else {
                 typedef unsigned u2v __attribute__((ext_vector_type(2)));
-                const u2v a = __builtin_amdgcn_raw_buffer_load_b64(rs, o0, 0, 0), b = __builtin_amdgcn_raw_buffer_load_b64(rs, o1 + 8, 0, 0),
-                          d = __builtin_amdgcn_raw_buffer_load_b64(rs, o2 + 16, 0, 0);
+                const u2v a = __builtin_amdgcn_raw_buffer_load_b64(rs, o0[n], 0, 0), b = __builtin_amdgcn_raw_buffer_load_b64(rs, o1[n] + 8, 0, 0),
+                          d = __builtin_amdgcn_raw_buffer_load_b64(rs, o2[n] + 16, 0, 0);
                 pre[n].u = __hiloint2double((int)a.y, (int)a.x);
                 pre[n].v = __hiloint2double((int)b.y, (int)b.x);
                 pre[n].s = __hiloint2double((int)d.y, (int)d.x);
@@ -382,8 +390,7 @@ __global__ __launch_bounds__(THREADS, SumsShape<THREADS>::kWavesPerSimd) void k_
             constexpr bool SINGLE = decltype(single_c)::value;
             // item of (round base, lane) -> first candidate slot, record offsets of its rows, pair offset; live?
             struct Item {
-                int k0, oa, ob;
-                Vec3 d;
+                int k0, oa, ob, dq;   // dq: the pair's d = t_s - t_m in `paird` (read where a chunk's solves start: six registers less over the frame)
                 bool live, cand;
             };
             auto locate = [&](int base) {
@@ -394,11 +401,10 @@ __global__ __launch_bounds__(THREADS, SumsShape<THREADS>::kWavesPerSimd) void k_
                 const int q = (int)(((unsigned long long)(unsigned)ii * magic_pq) >> 40), r2 = ii - q * per_q;
                 const int pmg = (int)(((unsigned long long)(unsigned)r2 * magic_ng) >> 40), pm = pmg * GAC, ps0 = (r2 - pmg * NG) * GSC;
                 const int mc = pairs[2 * q], sc = pairs[2 * q + 1];
-                const double *pc = paird + 3 * q;
+                t.dq = 3 * q;
                 t.k0 = q * pp + pm * Pmax + ps0;   // candidate (i, u) of the tile: slot k0 + i Pmax + u
                 t.oa = kP1Rec * (mc * Pmax + pm);
                 t.ob = kP1Rec * (sc * Pmax + ps0);
-                t.d = {pc[0], pc[1], pc[2]};
                 t.live = t.cand = live;
                 SNOWTRI_DEV_CHECK(!live || (t.k0 >= 0 && t.k0 + (GAC - 1) * Pmax + GSC <= Kc && t.oa + GAC * kP1Rec <= jstr && t.ob + GSC * kP1Rec <= jstr), 12);   // slots and rows of the item
                 if constexpr (GSC == 1) t.cand = live && pm < np_l[mc] && ps0 < np_l[sc];   // empty slots stay at 0
@@ -427,12 +433,13 @@ __global__ __launch_bounds__(THREADS, SumsShape<THREADS>::kWavesPerSimd) void k_
                 const int nj_next = last ? (succ ? (J < Jc ? J : Jc) : 0) : ((J - j0 - Jc) < Jc ? (J - j0 - Jc) : Jc);
                 const char *pa = cur + jlo * jstr + mine.oa, *pb = cur + jlo * jstr + mine.ob;
                 const int njs = mine.cand ? jhi - jlo : 0;
+                if (last && succ && n_persons && tid < C) npv = n_persons[fnext * C + tid];   // (in front of the keypoint requests, as everything that may touch scratch)
                 fetch(last && succ ? kp3 + fnext * (int64_t)R * Jrow : kpf, j0_next, nj_next);
-                if (last && succ && n_persons && tid < C) npv = n_persons[fnext * C + tid];
                 __builtin_amdgcn_sched_barrier(0);   // (nothing of the solves' set-up behind the requests: a reload from scratch there waits for them)
                 SUMS_STAMP_C2(2);
                 if constexpr (SINGLE) {
-                    p1_tile_sums<GAC, GSC, TIn>(pa, pb, jstr, njs, mine.d, prm, tot);
+                    const Vec3 d = {paird[mine.dq], paird[mine.dq + 1], paird[mine.dq + 2]};
+                    p1_tile_sums<GAC, GSC, TIn>(pa, pb, jstr, njs, d, prm, tot);
                 } else {
                     for (int base = iw * 64; base < nitems; base += wpg * 64) {
                         const Item t = locate(base);
@@ -442,7 +449,8 @@ __global__ __launch_bounds__(THREADS, SumsShape<THREADS>::kWavesPerSimd) void k_
                             acc[u] = 0.0;
                             old[u] = (c > 0 && t.cand) ? cs_f[slot(t, u)] : 0.0;   // (in flight during the solves)
                         }
-                        p1_tile_sums<GAC, GSC, TIn>(cur + jlo * jstr + t.oa, cur + jlo * jstr + t.ob, jstr, t.cand ? jhi - jlo : 0, t.d, prm, acc);
+                        const Vec3 d = {paird[t.dq], paird[t.dq + 1], paird[t.dq + 2]};
+                        p1_tile_sums<GAC, GSC, TIn>(cur + jlo * jstr + t.oa, cur + jlo * jstr + t.ob, jstr, t.cand ? jhi - jlo : 0, d, prm, acc);
                         // (the first chunk defines every slot of the frame, the empty ones as 0)
                         if (t.cand || (c == 0 && t.live)) {
 #pragma unroll
