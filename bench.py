@@ -603,6 +603,10 @@ def main():
             "extra_workloads": extra,
             "ray_pair_solves_per_s": value * (C * (C - 1) // 2),
         }
+        # LAST key of the line: the driver keeps `parsed` (the contract keys) and the last 8 KB of stdout, so what survives of
+        # a 40 KB line used to be an accident of ordering (round 5: the float32 8 x 4 line fell out).  Every BASELINE config
+        # and north_star's DLT, one short entry each, in the tail.
+        line["summary"] = summary_of(line)
     for b_ in {id(bt): bt, id(bto): bto}.values():
         b_.close()
     if dist is not None:
@@ -621,6 +625,51 @@ def main():
         print(json.dumps(line), flush=True)
 
 
+def summary_of(line):
+    """Compact digest of the line (every BASELINE configuration that fits one GPU, the DLT method, the per-frame API, the CPU
+    baseline): numbers only, < 3 KB."""
+    def r3(x):
+        return None if x is None else float("%.4g" % x)
+    ex = line.get("extra_workloads") or []
+
+    def find(*needles, method="pairwise", zero_fill=True):
+        for e in ex:
+            if all(n in e["workload"] for n in needles) and e.get("method", "pairwise") == method and e.get("zero_fill", True) == zero_fill:
+                return e
+        return None
+
+    def multi(e):
+        return None if e is None else {"frames_per_s": r3(e["frames_per_s"]), "ms_per_call": r3(e["kernel_ms"]),
+                                       "frac_fp64_nominal": r3(e["roofline"]["frac"]), "persons_per_frame": r3(e.get("mean_persons_per_frame")),
+                                       "two_calls_in_flight_frames_per_s": r3(e.get("two_streams", {}).get("frames_per_s"))}
+
+    def single(e):
+        return None if e is None else {"joints_per_s": r3(e["joints_per_s"]), "us_per_call": r3(e["kernel_ms"] * 1e3), "frac_fp64": r3(e["roofline"]["frac"]),
+                                       "frac_hbm": r3(e.get("hbm", {}).get("frac_of_8TBs")), "kernel": e["kernel"][:48]}
+    rf, lb, cpu, pf = line["roofline"], line.get("large_batch"), line.get("cpu_baseline"), line.get("per_frame_api")
+    nzf = find("NO_ZERO_FILL", zero_fill=False)
+    s = {
+        "configs1_4x1_10000_frames": {"joints_per_s": r3(line["value"]), "ms_per_step": r3(line["ms_per_step"]), "kernel_us_one_stream": r3(rf["kernel_ms_mean"] * 1e3),
+                                      "frac_hbm": r3(rf["frac"]), "frac_of_measured_copy": r3(rf.get("frac_of_measured_copy")), "hbm_traffic_over_algorithmic": None if not rf.get("traffic") else r3(rf["traffic"] / rf["algorithmic_bytes_per_launch"]),
+                                      "frac_hbm_2M_frame_launch": None if lb is None else r3(lb["frac"])},
+        "configs2_8x4_10000_frames_f32": multi(find("configs[2]: 8 cameras")),
+        "configs2_8x4_f64_out": multi(find("configs[2] with float64")),
+        "configs2_8x4_no_zero_fill": None if nzf is None else dict(multi(nzf), output_MB_written_per_call=r3(nzf["output_bytes_written_per_frame"] * nzf["frames"] / 1e6),
+                                                                   output_MB_written_per_call_default=r3(nzf["pout_max"] * (J * 16 + 4) * nzf["frames"] / 1e6)),
+        "configs4_share_16x8_12500_frames": multi(find("configs[4]")),
+        "dlt_4x1": single(find("DLT", "4 cameras x 1", method="dlt")),
+        "dlt_8x1": single(find("DLT", "8 cameras x 1", method="dlt")),
+        "dlt_8x4_with_association": multi(find("DLT", "configs[2]", method="dlt")),
+        "single_4x1_f64_out": single(next((e for e in ex if e.get("out_dtype") == "float64" and "4 cameras x 1" in e["workload"] and e.get("method") == "pairwise"), None)),
+        "single_6x1": single(next((e for e in ex if e.get("out_dtype") == "float32" and "6 cameras x 1" in e["workload"] and e.get("method") == "pairwise"), None)),
+        "single_8x1": single(next((e for e in ex if e.get("out_dtype") == "float32" and "8 cameras x 1" in e["workload"] and e.get("method") == "pairwise"), None)),
+        "per_frame_api_us": None if not pf else {k: r3(v) for k, v in pf.items() if isinstance(v, (int, float)) and "us" in k},
+        "cpu_baseline": None if not cpu else {"joints_per_s": r3(cpu["value"]), "cores": cpu["cores"], "gpu_vs_oracle_max_abs_m": r3(cpu["gpu_vs_oracle_max_abs_m"])},
+        "n_gpus": line["n_gpus"], "dtype": line["dtype"],
+    }
+    return s
+
+
 def extra_workloads(torch, dev, device_index):
     """The multi-person configurations of BASELINE.json on this GPU (the streaming association): configs[2] = 8 cameras x
     4 persons x 10 000 frames, and one GPU's share of configs[4] = 16 cameras x 8 persons x 12 500 frames.  A few
@@ -631,20 +680,26 @@ def extra_workloads(torch, dev, device_index):
     distance-only solve the candidate sums really use -- the figure prices the reference's work, not the kernel's)."""
     from snowmocap_amd import synth
     from snowmocap_amd.batch import BatchTriangulator
+    from snowmocap_amd import _lib
     res = []
-    for cfg, F, gen_frames, pout, label, odt in (
-            (3, 10000, 1000, 16, "BASELINE configs[2]: 8 cameras x 4 persons x 133 joints x 10 000 frames", np.float32),
-            (5, 12500, 250, 32, "BASELINE configs[4] per-GPU share: 16 cameras x 8 persons x 133 joints x 12 500 frames", np.float32),
+    for cfg, F, gen_frames, pout, label, odt, meth, zero_fill in (
+            (3, 10000, 1000, 16, "BASELINE configs[2]: 8 cameras x 4 persons x 133 joints x 10 000 frames", np.float32, _lib.PAIRWISE, True),
+            (5, 12500, 250, 32, "BASELINE configs[4] per-GPU share: 16 cameras x 8 persons x 133 joints x 12 500 frames", np.float32, _lib.PAIRWISE, True),
             # the reference's own output type (triangulation.py:136-148 returns float64 arrays): same route, Newton-refined 1/dist,
             # person scores from the fused joints
-            (3, 10000, 1000, 16, "BASELINE configs[2] with float64 outputs: 8 cameras x 4 persons x 133 joints x 10 000 frames", np.float64)):
+            (3, 10000, 1000, 16, "BASELINE configs[2] with float64 outputs: 8 cameras x 4 persons x 133 joints x 10 000 frames", np.float64, _lib.PAIRWISE, True),
+            # the same call with SNOWTRI_CALL_NO_ZERO_FILL: the 16 - ~5 unused slots of every frame are not written
+            (3, 10000, 1000, 16, "BASELINE configs[2] with SNOWTRI_CALL_NO_ZERO_FILL: 8 cameras x 4 persons x 133 joints x 10 000 frames", np.float32, _lib.PAIRWISE, False),
+            # north_star's DLT (row N3; NOT the reference's algorithm) behind the reference's association: candidates + clustering as
+            # above, then one N-view DLT per cluster and joint over its distinct observations (k_frame_recompute<1>)
+            (3, 10000, 1000, 16, "DLT (method = SNOWTRI_DLT) on BASELINE configs[2]: 8 cameras x 4 persons x 133 joints x 10 000 frames, the reference's association, then DLT per cluster", np.float32, _lib.DLT, True)):
         wl = synth.config_workload(cfg, gen_frames)
         K, R, t = wl["rig"]
         C, P = K.shape[0], wl["kpts"].shape[2]
         rep = F // gen_frames
         kp = torch.from_numpy(wl["kpts"]).to(dev).repeat(rep, 1, 1, 1, 1).contiguous()
         npers = torch.from_numpy(wl["n_persons"]).to(dev).repeat(rep, 1).contiguous()
-        bt = BatchTriangulator(K, R, t, wl["params"], pout_max=pout, out_dtype=odt, device=device_index)
+        bt = BatchTriangulator(K, R, t, wl["params"], pout_max=pout, out_dtype=odt, device=device_index, method=meth, zero_fill=zero_fill)
         out = bt.run_torch(kp, npers)
         torch.cuda.synchronize(dev)
         # ONE call = one fused entry on one caller stream (inside it the library alternates the call's segments between
@@ -672,8 +727,10 @@ def extra_workloads(torch, dev, device_index):
         counts = bt.ctx.last_stream_counts()
         # throughput with two calls in flight (two contexts on two streams, as the headline `value` is issued): the
         # latency-bound kernels of one call (k_associate, the member lists) run beside the VALU-bound ones of the other
-        bt2 = BatchTriangulator(K, R, t, wl["params"], pout_max=pout, out_dtype=odt, device=device_index)
+        bt2 = BatchTriangulator(K, R, t, wl["params"], pout_max=pout, out_dtype=odt, device=device_index, method=meth, zero_fill=zero_fill)
         out2 = bt2.alloc_outputs(F, dev)
+        if not zero_fill:          # (unspecified slots: compare like with like)
+            out2["xyzs"].copy_(out["xyzs"])
         streams2 = [torch.cuda.Stream(device=dev), torch.cuda.Stream(device=dev)]
         pairs2 = ((bt, out, streams2[0]), (bt2, out2, streams2[1]))
         def two_stream_round(calls):
@@ -699,7 +756,12 @@ def extra_workloads(torch, dev, device_index):
         # kernel_ms = HIP events around the whole call
         kernels = bt.ctx.last_kernel_names()
         handed = bt.ctx.last_handover_persons()
+        osz = 4 if odt == np.float32 else 8
         res.append({"workload": label, "kernel": kernels, "frames": F, "kernel_ms": m, "io": "fp32 in / %s out, fp64 math" % ("fp32" if odt == np.float32 else "fp64"),
+                    "method": "dlt" if meth == _lib.DLT else "pairwise", "pout_max": pout, "zero_fill": zero_fill,
+                    # what the call WRITES to out_xyzs + out_pscore per frame: every slot (the default) / the persons only
+                    "output_bytes_written_per_frame": (pout if zero_fill else persons) * (J * 4 * osz + osz),
+                    "output_bytes_of_persons_per_frame": persons * (J * 4 * osz + osz),
                     "persons_handed_to_cluster_kernels_last_segment": {"complete_graph": handed[0], "member_list": handed[1]},
                     "kernel_ms_all": ms, "frames_per_s": F / (m * 1e-3),
                     "how": f"100 ms of untimed calls (device warm-up), then {ncalls} calls queued back to back on one stream, HIP events around each call, median",
@@ -721,8 +783,8 @@ def extra_workloads(torch, dev, device_index):
     try:
         pm = json.load(open(os.path.join(ROOT, "profiles", "pmc_multi.json")))
         if pm.get("source_sha256") == kernel_source_hash():
-            for e, cfg in zip(res, ("cfg3", "cfg5", "cfg3")):
-                if "float64" in e["workload"]:
+            for e, cfg in zip(res, ("cfg3", "cfg5", "cfg3", "cfg3", "cfg3")):
+                if "float64" in e["workload"] or e["method"] != "pairwise" or not e["zero_fill"]:
                     continue
                 e["roofline"]["valu_busy"] = pm["workloads"].get(cfg)
                 e["roofline"]["valu_busy_note"] = ("SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs) per kernel of the call, one stream, "
@@ -740,6 +802,16 @@ def extra_workloads(torch, dev, device_index):
         e["kernel"] = e.pop("kernels")
         e["kernel_ms"] = e["ms_per_call"]
         e["io"] = "fp32 in / %s out, fp64 math" % ("fp32" if odt == np.float32 else "fp64")
+        res.append(e)
+    # north_star's kernel (row N3): N-view DLT, one detection per camera, on the headline rig and on eight cameras --
+    # k_fused_single<C,1,...>: A^T A accumulated per joint (64 flop per observation), Cholesky + shifted inverse iteration
+    # (~60 + 60 per step, four steps typical), dehomogenise: 64 C + 310 flop per joint (stated model; the kernel's own count).
+    # Four cameras: 64 B per joint -- against HBM like the headline; eight: 112 B, fp64 VALU.
+    for C_, rig_ in ((4, "floor"), (8, "ring")):
+        e = measure(C_, 10000, np.float32, rig=rig_, device_index=device_index, method=_lib.DLT)
+        e["kernel"] = e.pop("kernels")
+        e["kernel_ms"] = e["ms_per_call"]
+        e["io"] = "fp32 in / fp32 out, fp64 math"
         res.append(e)
     return res
 

@@ -89,8 +89,8 @@ const char *snowtri_last_error(void);
 int snowtri_device_count(void);
 
 /* What this binary is: "version=<n>;arch=gfx950;variants=<comma-separated build variants>".  The production library
- * reports an empty variant list; libsnowtri_dbg.so reports SNOWTRI_DEBUG_BOUNDS; development builds name their
- * switches (snowmocap_amd/csrc/snowtri_math.hpp lists them).  Never fails; the string lives as long as the library. */
+ * reports an empty variant list; the test build libsnowtri_dbg.so reports SNOWTRI_DEBUG_BOUNDS,SNOWTRI_TEST_KNOBS; development
+ * builds name their switches (snowmocap_amd/csrc/snowtri_math.hpp lists them).  Never fails; the string lives as long as the library. */
 const char *snowtri_build_info(void);
 
 /* Rig constants.  Replaces Camera.__init__/CameraGroup.__init__ state used by the path
@@ -104,20 +104,20 @@ int snowtri_ctx_num_cameras(const snowtri_ctx *ctx);
 int snowtri_ctx_ray_matrices(const snowtri_ctx *ctx, double *M_out);
 /* Block until everything queued by this context has finished. */
 int snowtri_ctx_synchronize(snowtri_ctx *ctx);
-/* Test knobs.  A context reads these environment variables ONCE, at creation, and names the ones that were set as
- * "NAME=value,..." ("" = the context runs the defaults; bench.py prints it, tests assert on it):
+/* Test knobs.  The PRODUCTION library reads no environment and snowtri_ctx_overrides() returns "" for every context of it.
+ * The TEST build (-DSNOWTRI_TEST_KNOBS: snowmocap_amd/libsnowtri_dbg.so, which also carries the device-side bounds checks;
+ * snowtri_build_info() names both variants) reads these environment variables ONCE, when a context is created, and names the
+ * ones that were set as "NAME=value,..." (tests assert on it):
  *   SNOWTRI_GENERAL_MODE=1|2        multi-person batches on the spill kernel / on k_frame_recompute
  *   SNOWTRI_LEAN_MODE=0             float32-output single-detection batches stay on k_fused_single
  *   SNOWTRI_LEAN_COOP=0             small launches stay on k_fused_lean
  *   SNOWTRI_SUMLESS_MODE=0          single-detection batches on the streaming route keep its candidate pass
- *   SNOWTRI_SUMS_RAYS=1             rigs of 32 rays per frame (8 x 4, 16 x 2, 4 x 8): candidate pass with one lane per ray
  *   SNOWTRI_HANDOVER_MODE=0|2       0: the whole multi-person path inside k_frame_recompute; 2: its descriptors to k_cluster_fuse
  *   SNOWTRI_HANDOVER_SEG_FRAMES=n   frames per segment of the streaming multi-person route
  *   SNOWTRI_SPLIT_SEGMENTS=1|n      1: one multi-person call stays on the caller's stream; n >= 2: at least n segments alternating
  *                                   between the caller's stream and an internal one, also for small batches (default: 2
  *                                   segments once a segment holds >= 4 frames per CU)
- *   SNOWTRI_SUMS_THREADS, SNOWTRI_SUMS_LDS_KB, SNOWTRI_LEAN_TILES_PER_WAVE   launch shapes (tests force the rare ones;
- *                                   SNOWTRI_SUMS_THREADS=64: the candidate pass with one wave per workgroup, measured slower)
+ *   SNOWTRI_SUMS_THREADS, SNOWTRI_SUMS_LDS_KB, SNOWTRI_LEAN_TILES_PER_WAVE   launch shapes (tests force the rare ones)
  *   SNOWTRI_DEBUG=1                 launch shapes on stderr
  * Results never depend on a knob (that is what the tests that set them check); only the route does. */
 const char *snowtri_ctx_overrides(const snowtri_ctx *ctx);
@@ -135,6 +135,15 @@ const char *snowtri_ctx_overrides(const snowtri_ctx *ctx);
  * freely with overlapped calls in flight; only the OUTPUTS of an overlapped call need the join before they are read. */
 int snowtri_ctx_set_overlap(snowtri_ctx *ctx, int n_streams);
 int snowtri_ctx_join(snowtri_ctx *ctx, void *stream);
+/* THE SPLIT of one multi-person call (several detections per camera, the streaming route).  By default a call whose batch fills
+ * the chip at least twice (a segment holds >= 4 frames per CU) runs as two segments that alternate between the caller's stream
+ * and ONE internal stream (fork / join events inside the call, results ordered behind `stream` as always): the latency-bound
+ * kernels of one segment run beside the VALU-bound ones of the other (8 cameras x 4 persons: +8 %).  Outputs do not depend on
+ * the cut (tested bit for bit).  segments = 1: the whole call stays on the caller's stream -- for a caller that captures the call
+ * into a hipGraph on one stream, or profiles its kernels one at a time (scripts/pmc_multi.sh); segments = 2 .. 64: at least that
+ * many segments (rounded up to an even count), small batches included; 0: the default policy again.  Not used in overlap mode
+ * (whole calls alternate there). */
+int snowtri_ctx_set_split(snowtri_ctx *ctx, int segments);
 
 /* Test hook (no reference counterpart): evaluates the fast reciprocal / reciprocal-square-root helpers
  * the throughput kernels use (v_rcp_f64 / v_rsq_f64 + Newton steps) on x[n]; host pointers. */
@@ -213,6 +222,22 @@ int snowtri_triangulate_condense(snowtri_ctx *ctx, int64_t F, int32_t Pmax, int3
                                  const snowtri_params *params, int method, int32_t Pout_max,
                                  void *out_xyzs, void *out_pscore, int out_dtype, int32_t *out_count,
                                  uint32_t *out_flags, int memspace, void *stream);
+
+/* The same call with flags (0 = exactly snowtri_triangulate_condense; an unknown bit is SNOWTRI_ERR_BAD_ARG).
+ * SNOWTRI_CALL_NO_ZERO_FILL: the slots of persons >= out_count[f] -- out_xyzs[f][p >= count][.][.] and out_pscore[f][p >= count] --
+ * are UNSPECIFIED after the call: the library does not spend HBM writes on them (whatever the caller's buffer held may still be
+ * there, or zeros where a kernel writes them anyway).  The reference returns LISTS of out_count[f] persons
+ * (triangulation.py:154-160); the [F][Pout_max] padding is this ABI's artefact, and on a multi-person batch with a generous
+ * Pout_max the zeros are most of what the call writes (BASELINE configs[2], 8 cameras x 4 persons resolving to ~5 persons per
+ * frame, Pout_max 16: 234 MB of zeros beside 106 MB of results per 10 000 frames).  A caller that reads out_count[f] first --
+ * snowmocap_amd/sharded.py's compact gather, BatchTriangulator(zero_fill=False) -- loses nothing.  SNOWTRI_HOST calls copy the
+ * whole padded block back either way (their device staging is not cleared: the unused slots then hold earlier results). */
+#define SNOWTRI_CALL_NO_ZERO_FILL 1u
+int snowtri_triangulate_condense_ex(snowtri_ctx *ctx, int64_t F, int32_t Pmax, int32_t J,
+                                    const void *kpts, int in_dtype, const int32_t *n_persons,
+                                    const snowtri_params *params, int method, int32_t Pout_max,
+                                    void *out_xyzs, void *out_pscore, int out_dtype, int32_t *out_count,
+                                    uint32_t *out_flags, int memspace, void *stream, uint32_t call_flags);
 
 /* N1  Human_Triangulation_Smooth / SecondOrderDynamic (triangulation.py:4-22,164-186) over a whole track.
  * x[T][n] fp64, frame-major, n = persons * joints * 3 lanes (persons matched by index, as the reference does)

@@ -12,7 +12,7 @@ from oracle import oracle as orc
 J = 133
 SIZES = ((3, 2000, 16), (5, 256, 32)) if "--small" in sys.argv else ((3, 10000, 16), (5, 2000, 32))
 REPEAT = {5: 6} if "--full" in sys.argv else {}   # cfg5: 2 000 generated frames tiled to 12 000 = its per-GPU share
-MODES = ("2", "1") if "--spill" in sys.argv else ("2",)
+ONE_STREAM = "--one-stream" in sys.argv     # snowtri_ctx_set_split(1): every kernel of a call on the caller's stream (per-kernel profiles)
 METHOD = _lib.DLT if "--dlt" in sys.argv else _lib.PAIRWISE
 ONLY = [int(a.split("=")[1]) for a in sys.argv if a.startswith("--only=")]
 for cfg, F, pout in SIZES:
@@ -28,9 +28,10 @@ for cfg, F, pout in SIZES:
         kp = kp.repeat(REPEAT[cfg], 1, 1, 1, 1).contiguous()
         npers = npers.repeat(REPEAT[cfg], 1).contiguous()
         F = F * REPEAT[cfg]
-    for mode in MODES:
-        os.environ["SNOWTRI_GENERAL_MODE"] = mode
+    for mode in ("2",):
         bt = BatchTriangulator(K, R, t, wl["params"], pout_max=pout, out_dtype=np.float32, method=METHOD)
+        if ONE_STREAM:
+            bt.ctx.set_split(1)
         out = bt.run_torch(kp, npers)
         torch.cuda.synchronize()
         bt.ctx.set_timing(True)
@@ -47,7 +48,6 @@ for cfg, F, pout in SIZES:
                           "frames_per_s": F / (m * 1e-3), "output_joints_per_s": joints / (m * 1e-3),
                           "pair_solves_per_s": F * kc * J / (m * 1e-3), "mean_persons": float(cnt.mean()), "handed_last_segment": handed}))
         bt.close()
-    os.environ.pop("SNOWTRI_GENERAL_MODE", None)
     if "--no-oracle" in sys.argv:
         continue
     nf = 8 if cfg == 3 else 2

@@ -4,8 +4,8 @@
 event pairs read afterwards (a synchronize between calls lets the chip idle and clock down: round 3's `kernel_ms` of a
 single synchronised call was 10 % above the same call in a loop).  Also: two calls in flight on two contexts / streams.
 
-    python scripts/bench_multi_hot.py [--only=3|5] [--calls=N] [--out64] [--kn=K] [--center=I] [--no-two]
-    python scripts/bench_multi_hot.py --sweep=SNOWTRI_SPLIT_SEGMENTS=1,2,4      (a test knob, each value twice, interleaved)
+    python scripts/bench_multi_hot.py [--only=3|5] [--calls=N] [--out64] [--kn=K] [--center=I] [--no-two] [--pout=N] [--no-zero-fill]
+    python scripts/bench_multi_hot.py --sweep-split=1,2,4      (snowtri_ctx_set_split, each value twice, interleaved)
 A/B of development builds: SNOWTRI_LIB=.../ab/libsnowtri_<tag>.so python scripts/bench_multi_hot.py
 """
 import json
@@ -26,9 +26,11 @@ KN = ([int(a.split("=")[1]) for a in sys.argv if a.startswith("--kn=")] or [0])[
 CENTER = ([int(a.split("=")[1]) for a in sys.argv if a.startswith("--center=")] or [-1])[0]
 OUT64 = "--out64" in sys.argv
 NO_TWO = "--no-two" in sys.argv
+POUT = ([int(a.split("=")[1]) for a in sys.argv if a.startswith("--pout=")] or [0])[0]
+ZERO_FILL = "--no-zero-fill" not in sys.argv
 
 
-def measure(cfg, F, gen, pout, calls):
+def measure(cfg, F, gen, pout, calls, split=None):
     dev = torch.device("cuda", 0)
     wl = synth.config_workload(cfg, gen)
     K, R, t = wl["rig"]
@@ -40,7 +42,10 @@ def measure(cfg, F, gen, pout, calls):
     kp = torch.from_numpy(wl["kpts"]).to(dev).repeat(F // gen, 1, 1, 1, 1).contiguous()
     npers = torch.from_numpy(wl["n_persons"]).to(dev).repeat(F // gen, 1).contiguous()
     odt = np.float64 if OUT64 else np.float32
-    bts = [BatchTriangulator(K, R, t, params, pout_max=pout, out_dtype=odt) for _ in range(2)]
+    bts = [BatchTriangulator(K, R, t, params, pout_max=pout, out_dtype=odt, zero_fill=ZERO_FILL) for _ in range(2)]
+    if split is not None:
+        for b in bts:
+            b.ctx.set_split(split)
     outs = [b.alloc_outputs(F, dev) for b in bts]
     streams = [torch.cuda.Stream(device=dev) for _ in range(2)]
     bts[0].run_torch(kp, npers, out=outs[0])
@@ -81,6 +86,7 @@ def measure(cfg, F, gen, pout, calls):
     same = bool(torch.equal(outs[0]["xyzs"], outs[1]["xyzs"])) and bool(torch.equal(outs[0]["count"], outs[1]["count"]))
     cnt = outs[0]["count"].cpu().numpy()
     res = {"cfg": cfg, "frames": F, "out": "f64" if OUT64 else "f32", "kn": params["keypoint_num"], "lib": os.environ.get("SNOWTRI_LIB", "production"),
+           "pout_max": pout, "zero_fill": ZERO_FILL,
            "kernels": bts[0].ctx.last_kernel_names(),
            "ms_per_call_loop": loop_ms, "ms_per_call_events_median": float(np.median(per_call)), "ms_per_call_events_min": float(np.min(per_call)),
            "frames_per_s_loop": F / (loop_ms * 1e-3), "ms_single_synchronised_call": float(np.median(alone[1:])),
@@ -91,21 +97,16 @@ def measure(cfg, F, gen, pout, calls):
     return res
 
 
-# --sweep=NAME=v1,v2,...: the whole measurement once per value of that test knob (contexts read the environment at creation),
-# interleaved twice so that a drifting box shows
-SWEEP = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--sweep=")]
+# --sweep-split=v1,v2,...: the whole measurement once per value of snowtri_ctx_set_split, interleaved twice so that a drifting box shows
+SWEEP = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--sweep-split=")]
 settings = [None]
 if SWEEP:
-    name, vals = SWEEP[0].split("=", 1)
-    settings = [(name, v) for v in vals.split(",")] * 2
+    settings = [int(v) for v in SWEEP[0].split(",")] * 2
 for cfg, F, gen, pout in ((3, 10000, 1000, 16), (5, 12500, 250, 32)):
     if ONLY and cfg not in ONLY:
         continue
     for st in settings:
-        if st:
-            os.environ[st[0]] = st[1]
-        r = measure(cfg, F, gen, pout, CALLS or (40 if cfg == 3 else 8))
-        if st:
-            r["knob"] = "%s=%s" % st
-            os.environ.pop(st[0])
+        r = measure(cfg, F, gen, POUT or pout, CALLS or (40 if cfg == 3 else 8), split=st)
+        if st is not None:
+            r["split"] = st
         print(json.dumps(r), flush=True)

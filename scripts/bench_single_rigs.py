@@ -39,7 +39,14 @@ def flop_per_joint(C):
     return 90.0 * (C * (C - 1) // 2) + 15.0 * C
 
 
-def measure(C, F, out_dtype, calls=0, kn=0, gen=500, seed=7, rig="ring", device_index=0):
+def dlt_flop_per_joint(C):
+    """Stated flop model of the DLT item (snowtri_fused.hpp: dlt_add_observation, dlt_inverse_iteration): two rows per camera into
+    the upper triangle of A^T A (64 flop per observation), Cholesky of the shifted 4 x 4 (~60), four steps of inverse iteration
+    (two triangular solves + normalisation, ~60 each; the loop leaves when the wave has settled: 3-5 on noisy data), dehomogenise (~10)."""
+    return 64.0 * C + 60.0 + 4 * 60.0 + 10.0
+
+
+def measure(C, F, out_dtype, calls=0, kn=0, gen=500, seed=7, rig="ring", device_index=0, method=0):
     """rig = "ring": C cameras on the synthetic ring; "floor": the reference's 4-camera rig (BASELINE configs[1]'s frames)."""
     dev = torch.device("cuda", device_index)
     rng = np.random.default_rng(seed + C)
@@ -57,7 +64,7 @@ def measure(C, F, out_dtype, calls=0, kn=0, gen=500, seed=7, rig="ring", device_
     reps = (F + gen - 1) // gen
     kpd = torch.from_numpy(kp).to(dev).repeat(reps, 1, 1, 1, 1)[:F].contiguous()
     npd = torch.from_numpy(npers).to(dev).repeat(reps, 1)[:F].contiguous()
-    bt = BatchTriangulator(K, R, t, prm, pout_max=1, out_dtype=out_dtype, device=device_index)
+    bt = BatchTriangulator(K, R, t, prm, pout_max=1, out_dtype=out_dtype, device=device_index, method=method)
     out = bt.alloc_outputs(F, dev)
     bt.run_torch(kpd, npd, out=out)
     torch.cuda.synchronize(dev)
@@ -87,16 +94,19 @@ def measure(C, F, out_dtype, calls=0, kn=0, gen=500, seed=7, rig="ring", device_
     ms = min(ms, loop_ms) if per_call.size else ms
     joints = F * knn
     # the whole item runs for every joint < keypoint_num; rays of all J joints are never built for the others
-    flops = joints * flop_per_joint(C)
-    line = dict(workload=f"{C} cameras x 1 person x {J} joints x {F} frames, {'the floor rig of the reference' if rig == 'floor' else 'ring rig'}, default thresholds",
-                frames=F,
+    flops = joints * (dlt_flop_per_joint(C) if method else flop_per_joint(C))
+    line = dict(workload=("DLT (method = SNOWTRI_DLT, NOT the reference's algorithm): " if method else "") +
+                         f"{C} cameras x 1 person x {J} joints x {F} frames, {'the floor rig of the reference' if rig == 'floor' else 'ring rig'}, default thresholds",
+                frames=F, method="dlt" if method else "pairwise",
                 out_dtype=np.dtype(out_dtype).name, keypoint_num=knn, kernels=names, calls=calls,
                 ms_per_call=ms, ms_per_call_loop=loop_ms, frames_per_s=F / (ms * 1e-3), joints_per_s=joints / (ms * 1e-3),
                 pair_solves_per_s=joints * (C * (C - 1) // 2) / (ms * 1e-3),
-                roofline=dict(bound="fp64 VALU (reference flops per joint: %d)" % flop_per_joint(C), achieved=flops / (ms * 1e-3) / 1e12,
+                roofline=dict(bound=("fp64 VALU (stated DLT flops per joint: %d)" % dlt_flop_per_joint(C)) if method else ("fp64 VALU (reference flops per joint: %d)" % flop_per_joint(C)),
+                              achieved=flops / (ms * 1e-3) / 1e12,
                               peak=FP64_PEAK / 1e12, unit="TFLOP/s", frac=flops / (ms * 1e-3) / FP64_PEAK),
                 hbm=dict(bytes_per_joint=12 * C + (16 if out_dtype == np.float32 else 32),
-                         achieved_GBps=joints * (12 * C + (16 if out_dtype == np.float32 else 32)) / (ms * 1e-3) / 1e9),
+                         achieved_GBps=joints * (12 * C + (16 if out_dtype == np.float32 else 32)) / (ms * 1e-3) / 1e9,
+                         frac_of_8TBs=joints * (12 * C + (16 if out_dtype == np.float32 else 32)) / (ms * 1e-3) / 8e12),
                 fast_frames=fast, one_person_frames=cnt1, overrides=bt.ctx.overrides())
     bt.close()
     return line

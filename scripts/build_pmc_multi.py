@@ -19,7 +19,7 @@ from bench import kernel_source_hash          # noqa: E402
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "gpurun_out", "pmc_multi_stdout.txt")
 mc = multi_counters(src)
 out = {"source_sha256": kernel_source_hash(),
-       "what": "per kernel of ONE fused call (one stream, SNOWTRI_SPLIT_SEGMENTS=1): valu_busy = SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), "
+       "what": "per kernel of ONE fused call (one stream: snowtri_ctx_set_split(1)): valu_busy = SQ_ACTIVE_INST_VALU x 4 / (GRBM_GUI_ACTIVE / 8 x 1024 SIMDs), "
                "lds_conflict_ratio = SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS; rocprofv3 --pmc, scripts/pmc_multi.sh",
        "workloads": {cfg: {k: {"valu_busy": v.get("valu_busy"), "lds_conflict_ratio": v.get("lds_conflict_ratio"), "grid": v.get("grid")}
                            for k, v in ks.items() if v.get("valu_busy") is not None} for cfg, ks in mc.items()}}

@@ -4,16 +4,16 @@ ROOT=$PWD; OUT=$ROOT/gpurun_out/pmc_multi; mkdir -p $OUT
 export TMPDIR=/tmp
 # one stream per call: with the call's segments on two streams (the default for the small rigs) the kernels of the two
 # segments overlap and a per-kernel duration would include the time a kernel waits for the other segment's workgroups
-export SNOWTRI_SPLIT_SEGMENTS=1
+# (bench_configs.py --one-stream / bench_multi_hot.py --sweep-split=1: snowtri_ctx_set_split(1) -- the production library reads no environment)
 cd /tmp
 for CFG in 3 5; do
-rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace -d $OUT/a$CFG -o a -- python $ROOT/scripts/bench_configs.py --full --only=$CFG > $OUT/a$CFG.log 2>&1
-rocprofv3 --output-format csv --pmc GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_SMEM --kernel-trace -d $OUT/b$CFG -o b -- python $ROOT/scripts/bench_configs.py --full --only=$CFG > $OUT/b$CFG.log 2>&1
-rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/s$CFG -o s -- python $ROOT/scripts/bench_configs.py --full --only=$CFG > $OUT/s$CFG.log 2>&1
+rocprofv3 --output-format csv --pmc SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace -d $OUT/a$CFG -o a -- python $ROOT/scripts/bench_configs.py --full --one-stream --only=$CFG > $OUT/a$CFG.log 2>&1
+rocprofv3 --output-format csv --pmc GRBM_GUI_ACTIVE SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_INSTS_VMEM_RD SQ_INSTS_SMEM --kernel-trace -d $OUT/b$CFG -o b -- python $ROOT/scripts/bench_configs.py --full --one-stream --only=$CFG > $OUT/b$CFG.log 2>&1
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/s$CFG -o s -- python $ROOT/scripts/bench_configs.py --full --one-stream --only=$CFG > $OUT/s$CFG.log 2>&1
 cp $(find $OUT/s$CFG -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_cfg$CFG.csv
 done
 # the same 8 x 4 batch with float64 outputs (the reference's own output type): per-kernel table, one stream
-rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/s3f64 -o s -- python $ROOT/scripts/bench_multi_hot.py --only=3 --no-two --out64 > $OUT/s3f64.log 2>&1
+rocprofv3 --output-format csv --kernel-trace --stats -d $OUT/s3f64 -o s -- python $ROOT/scripts/bench_multi_hot.py --only=3 --no-two --out64 --sweep-split=1 > $OUT/s3f64.log 2>&1
 cp $(find $OUT/s3f64 -name "*kernel_stats.csv" | head -1) $OUT/kernel_stats_cfg3_f64out.csv
 rm -rf $OUT/s3f64
 cd $ROOT

@@ -15,14 +15,18 @@ import test_gpu_single_rigs as TS
 real_rng = np.random.default_rng
 
 
-class Env:                       # minimal stand-in for pytest's monkeypatch
-    def setenv(self, k, v): os.environ[k] = v
-    def undo(self): os.environ.pop("SNOWTRI_GENERAL_MODE", None)
+import conftest
 
 
-class MP:                        # monkeypatch stand-in for the hand-over sweep
+class MP:                        # what conftest.Knobs needs of pytest's monkeypatch
     def setenv(self, k, v): os.environ[k] = v
-    def delenv(self, k): os.environ.pop(k, None)
+    def delenv(self, k, raising=True): os.environ.pop(k, None)
+
+
+def Env():                       # the `knobs` fixture of the tests: a forced route binds the test build of the library (conftest.Knobs)
+    k = conftest.Knobs(MP())
+    k.undo = lambda: (k.clear(), k.restore())
+    return k
 
 
 _pos = [a for a in sys.argv[1:] if not a.startswith("--")]
@@ -37,9 +41,9 @@ sweeps = [("small_rigs auto", lambda e: T.test_random_small_rigs_against_oracle(
           ("per-frame api", lambda e: T.test_random_small_rigs_per_frame_api(api)),
           ("lean thresholds", lambda e: TL.test_lean_random_thresholds_and_person_lists(api)),
           ("lean special", lambda e: TL.test_lean_special_values(api)),
-          ("handover", lambda e: TH.test_random_rigs_with_handover_against_oracle_and_phase3(api, MP())),
-          ("handover wide rigs", lambda e: TH.test_random_wide_rigs_against_oracle_and_phase3(api, MP())),
-          ("float64 outputs / keypoint_num on the streaming route", lambda e: TH.test_random_rigs_float64_outputs_and_keypoint_num(api, MP())),
+          ("handover", lambda e: TH.test_random_rigs_with_handover_against_oracle_and_phase3(api, e)),
+          ("handover wide rigs", lambda e: TH.test_random_wide_rigs_against_oracle_and_phase3(api, e)),
+          ("float64 outputs / keypoint_num on the streaming route", lambda e: TH.test_random_rigs_float64_outputs_and_keypoint_num(api, e)),
           ("single-person rigs of 5-16 cameras, every route", lambda e: TS.test_random_single_person_rigs_on_every_route(api))]
 only = [a.split("=", 1)[1] for a in sys.argv if a.startswith("--only=")]
 if only:

@@ -19,6 +19,8 @@ F32, F64 = 0, 1
 HOST, DEVICE = 0, 1
 PAIRWISE, DLT = 0, 1
 FLAG_SINGULAR, FLAG_OVERFLOW, FLAG_FASTPATH = 1, 2, 4
+CALL_NO_ZERO_FILL = 1          # snowtri_triangulate_condense_ex: the slots behind out_count[f] are left unwritten
+TEST_LIB_PATH = os.path.join(_HERE, "libsnowtri_dbg.so")   # -DSNOWTRI_DEBUG_BOUNDS -DSNOWTRI_TEST_KNOBS (tests only: use_library)
 
 
 class SnowtriError(RuntimeError):
@@ -62,6 +64,7 @@ _SIGNATURES = {
     "snowtri_ctx_overrides": (ct.c_char_p, [_c_p]),
     "snowtri_ctx_set_overlap": (ct.c_int, [_c_p, ct.c_int]),
     "snowtri_ctx_join": (ct.c_int, [_c_p, _c_p]),
+    "snowtri_ctx_set_split": (ct.c_int, [_c_p, ct.c_int]),
     "snowtri_last_stream_counts": (ct.c_int, [_c_p, ct.POINTER(ct.c_int64 * 3)]),
     "snowtri_ctx_stream_probes": (ct.c_int, [_c_p, ct.POINTER(ct.c_int64 * 3)]),
     "snowtri_ctx_create": (ct.c_int, [ct.c_int32, _c_p, _c_p, _c_p, ct.c_int, ct.POINTER(_c_p)]),
@@ -86,6 +89,9 @@ _SIGNATURES = {
     "snowtri_triangulate_condense": (ct.c_int, [_c_p, ct.c_int64, ct.c_int32, ct.c_int32, _c_p, ct.c_int,
                                                 _c_p, ct.POINTER(Params), ct.c_int, ct.c_int32, _c_p,
                                                 _c_p, ct.c_int, _c_p, _c_p, ct.c_int, _c_p]),
+    "snowtri_triangulate_condense_ex": (ct.c_int, [_c_p, ct.c_int64, ct.c_int32, ct.c_int32, _c_p, ct.c_int,
+                                                   _c_p, ct.POINTER(Params), ct.c_int, ct.c_int32, _c_p,
+                                                   _c_p, ct.c_int, _c_p, _c_p, ct.c_int, _c_p, ct.c_uint32]),
     "snowtri_smooth_track": (ct.c_int, [_c_p, ct.c_int64, ct.c_int64, _c_p, ct.c_double, ct.c_double, ct.c_double,
                                         ct.c_double, _c_p, ct.c_int, _c_p]),
     "snowtri_smooth_coeffs": (ct.c_int, [ct.c_double, ct.c_double, ct.c_double, ct.c_double, _c_p]),
@@ -117,19 +123,19 @@ _SIGNATURES = {
 }
 
 _lib = None
+_loaded = {}      # path -> bound CDLL handle (a process may hold the production library and the test build side by side)
 
 
 def exported_symbols():
     return sorted(_SIGNATURES)
 
 
-def lib():
-    """Load libsnowtri.so (built by __graft_entry__.build() / `make -C snowmocap_amd/csrc`)."""
-    global _lib
-    if _lib is None:
-        if not os.path.exists(LIB_PATH):
+def _load(path):
+    handle = _loaded.get(path)
+    if handle is None:
+        if not os.path.exists(path):
             raise ImportError(
-                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                f"{path} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  snowmocap_amd has no CPU fallback.")
         # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (same SONAME as
         # /opt/rocm's).  Loading it FIRST makes the dynamic linker bind libsnowtri.so to that copy,
@@ -140,13 +146,34 @@ def lib():
                 import torch  # noqa: F401
             except Exception:
                 pass
-        handle = ct.CDLL(LIB_PATH)
+        handle = ct.CDLL(path)              # (RTLD_LOCAL: two builds of the library do not see each other's symbols)
         for name, (res, args) in _SIGNATURES.items():
             fn = getattr(handle, name)      # AttributeError if the ABI lost a symbol
             fn.restype = res
             fn.argtypes = args
-        _lib = handle
+        _loaded[path] = handle
+    return handle
+
+
+def lib():
+    """Load libsnowtri.so (built by __graft_entry__.build() / `make -C snowmocap_amd/csrc`)."""
+    global _lib
+    if _lib is None:
+        _lib = _load(LIB_PATH)
     return _lib
+
+
+def use_library(path=None):
+    """Bind the package to another build of the library -- the TEST build libsnowtri_dbg.so (device-side bounds checks + the
+    route-forcing knobs, which the production library does not contain) -- or back to the production one (path=None).
+    Returns the path that was bound before.  Contexts keep the library they were created with (Context.L), so objects made
+    under one binding stay valid under the next; everything created afterwards uses the new one.  Tests only
+    (tests/conftest.py::knob_lib)."""
+    global _lib, LIB_PATH
+    prev = LIB_PATH
+    LIB_PATH = path or os.environ.get("SNOWTRI_LIB") or os.path.join(_HERE, "libsnowtri.so")
+    _lib = _load(LIB_PATH)
+    return prev
 
 
 def build_info():
@@ -181,7 +208,7 @@ class Context:
     """Owner of a snowtri_ctx (rig constants + device scratch).  Not thread-safe."""
 
     def __init__(self, K=None, R=None, t=None, device=0):
-        L = lib()
+        L = self.L = lib()                  # the library this context belongs to (use_library may rebind the package later)
         if L.snowtri_device_count() <= 0:
             raise SnowtriError(ERR_NO_DEVICE, "snowtri_ctx_create")
         if K is None:
@@ -203,7 +230,7 @@ class Context:
 
     def close(self):
         if getattr(self, "handle", None):
-            lib().snowtri_ctx_destroy(self.handle)
+            self.L.snowtri_ctx_destroy(self.handle)
             self.handle = None
 
     def __del__(self):
@@ -213,11 +240,11 @@ class Context:
             pass
 
     def synchronize(self):
-        check(lib().snowtri_ctx_synchronize(self.handle), "snowtri_ctx_synchronize")
+        check(self.L.snowtri_ctx_synchronize(self.handle), "snowtri_ctx_synchronize")
 
     def ray_matrices(self):
         M = np.empty((self.C, 9))
-        check(lib().snowtri_ctx_ray_matrices(self.handle, ptr(M)), "snowtri_ctx_ray_matrices")
+        check(self.L.snowtri_ctx_ray_matrices(self.handle, ptr(M)), "snowtri_ctx_ray_matrices")
         return M.reshape(self.C, 3, 3)
 
     def set_distortion(self, D):
@@ -229,7 +256,7 @@ class Context:
             D2 = D2[:, :5]
         Dc = np.zeros((self.C, 5), dtype=np.float64)          # OpenCV's shorter forms (4 coefficients) mean k3 = 0
         Dc[:, :D2.shape[1]] = D2
-        check(lib().snowtri_ctx_set_distortion(self.handle, ptr(Dc)), "snowtri_ctx_set_distortion")
+        check(self.L.snowtri_ctx_set_distortion(self.handle, ptr(Dc)), "snowtri_ctx_set_distortion")
 
     def undistort_keypoints(self, kpts):
         """Raw-image keypoints kpts[F, C, Pmax, J, 3] -> the same array with (u, v) moved to the undistorted
@@ -241,72 +268,76 @@ class Context:
         F, C, Pmax, J, three = a.shape
         assert C == self.C and three == 3
         out = np.empty_like(a)
-        check(lib().snowtri_undistort_keypoints(self.handle, F, Pmax, J, ptr(a), ptr(out), dtype_code(a.dtype), HOST,
+        check(self.L.snowtri_undistort_keypoints(self.handle, F, Pmax, J, ptr(a), ptr(out), dtype_code(a.dtype), HOST,
                                                 None), "snowtri_undistort_keypoints")
         return out
 
     def set_timing(self, enabled=True, attach=False):
         """attach: single-kernel calls carry the event pair on their dispatch (the kernel's own begin / end) instead of being bracketed."""
-        check(lib().snowtri_set_timing(self.handle, (2 if attach else 1) if enabled else 0), "snowtri_set_timing")
+        check(self.L.snowtri_set_timing(self.handle, (2 if attach else 1) if enabled else 0), "snowtri_set_timing")
 
     def last_kernel_ms(self):
         arr = (ct.c_float * 2)()
-        check(lib().snowtri_last_kernel_ms(self.handle, ct.byref(arr)), "snowtri_last_kernel_ms")
+        check(self.L.snowtri_last_kernel_ms(self.handle, ct.byref(arr)), "snowtri_last_kernel_ms")
         return float(arr[0]), float(arr[1])
 
     def timing_collect(self, cap=1024):
         """Durations (ms) of the fused calls recorded since the last collect (timing must be enabled)."""
         arr = (ct.c_float * cap)()
-        n = lib().snowtri_timing_collect(self.handle, arr, cap)
+        n = self.L.snowtri_timing_collect(self.handle, arr, cap)
         if n < 0:
             raise SnowtriError(ERR_HIP, "snowtri_timing_collect")
         return [float(arr[i]) for i in range(n)]
 
     def overrides(self):
         """Test knobs (environment) this context was created under: "" when it runs the defaults."""
-        return (lib().snowtri_ctx_overrides(self.handle) or b"").decode()
+        return (self.L.snowtri_ctx_overrides(self.handle) or b"").decode()
 
     def set_overlap(self, n_streams):
         """Overlap mode: device calls of the fused entry rotate over n internal streams (1 = off); join() before reading results."""
-        check(lib().snowtri_ctx_set_overlap(self.handle, int(n_streams)), "snowtri_ctx_set_overlap")
+        check(self.L.snowtri_ctx_set_overlap(self.handle, int(n_streams)), "snowtri_ctx_set_overlap")
+
+    def set_split(self, segments):
+        """Segments of one multi-person call (snowtri_ctx_set_split): 1 = the caller's stream only, >= 2 forced, 0 = the default policy."""
+        check(self.L.snowtri_ctx_set_split(self.handle, int(segments)), "snowtri_ctx_set_split")
 
     def join(self, stream=None):
         """`stream` (a HIP stream handle, default the null stream) waits for every overlapped call issued since the last join."""
-        check(lib().snowtri_ctx_join(self.handle, ct.c_void_p(stream) if stream else None), "snowtri_ctx_join")
+        check(self.L.snowtri_ctx_join(self.handle, ct.c_void_p(stream) if stream else None), "snowtri_ctx_join")
 
     def last_stream_counts(self):
         """(frames past the association's first launch, frames with an exactly re-done candidate sum, frames left to
         k_frame_recompute) of the last multi-person call's last segment; (-1, -1, -1) if it did not take the streaming route."""
         arr = (ct.c_int64 * 3)()
-        check(lib().snowtri_last_stream_counts(self.handle, ct.byref(arr)), "snowtri_last_stream_counts")
+        check(self.L.snowtri_last_stream_counts(self.handle, ct.byref(arr)), "snowtri_last_stream_counts")
         return int(arr[0]), int(arr[1]), int(arr[2])
 
     def stream_probes(self):
         """(probes run, internal streams discarded, verdict on the stream kept last: 1 = runs beside the others, 0 = no
         candidate did, -1 = no internal stream yet) -- see snowtri_ctx_stream_probes."""
         arr = (ct.c_int64 * 3)()
-        check(lib().snowtri_ctx_stream_probes(self.handle, ct.byref(arr)), "snowtri_ctx_stream_probes")
+        check(self.L.snowtri_ctx_stream_probes(self.handle, ct.byref(arr)), "snowtri_ctx_stream_probes")
         return int(arr[0]), int(arr[1]), int(arr[2])
 
     def last_slow_frames(self):
-        return int(lib().snowtri_last_slow_frames(self.handle))
+        return int(self.L.snowtri_last_slow_frames(self.handle))
 
     def last_kernel_names(self):
         """Template names of the kernels the last fused call launched, in launch order."""
-        return (lib().snowtri_last_kernel_names(self.handle) or b"").decode()
+        return (self.L.snowtri_last_kernel_names(self.handle) or b"").decode()
 
     def debug_faults(self):
         """(violated device-side bounds checks since the last call, code << 32 | line of the first); (-1, 0) unless the
         library is the -DSNOWTRI_DEBUG_BOUNDS build (libsnowtri_dbg.so)."""
         first = ct.c_uint64(0)
-        n = int(lib().snowtri_debug_faults(self.handle, ct.byref(first)))
+        n = int(self.L.snowtri_debug_faults(self.handle, ct.byref(first)))
         return n, int(first.value)
 
     def last_handover_persons(self):
         """(persons fused as complete-graph clusters, persons fused from member lists) of the last multi-person call,
         (-1, -1) if it did not arm the hand-over."""
         other = ct.c_int64(-1)
-        n = int(lib().snowtri_last_handover_persons(self.handle, ct.byref(other)))
+        n = int(self.L.snowtri_last_handover_persons(self.handle, ct.byref(other)))
         return n, int(other.value)
 
 
@@ -331,7 +362,8 @@ def scratch_context(device=None):
     """Rig-less context for entry points that need only device scratch (condense, skew rays, smoothing).
     One per device: a context's scratch and kernels live on the GPU it was created for."""
     dev = current_device() if device is None else int(device)
-    ctx = _scratch_ctx.get(dev)
+    key = (LIB_PATH, dev)                   # (a context belongs to the library that made it)
+    ctx = _scratch_ctx.get(key)
     if ctx is None:
-        ctx = _scratch_ctx[dev] = Context(device=dev)
+        ctx = _scratch_ctx[key] = Context(device=dev)
     return ctx

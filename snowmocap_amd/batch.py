@@ -14,14 +14,19 @@ FUSED_CALLS = 0   # fused device calls issued through run_torch by this process 
 
 
 class BatchTriangulator:
-    def __init__(self, K, R, t, params, pout_max=1, out_dtype=np.float32, device=0, method=_lib.PAIRWISE, D=None, streams=1):
+    def __init__(self, K, R, t, params, pout_max=1, out_dtype=np.float32, device=0, method=_lib.PAIRWISE, D=None, streams=1,
+                 zero_fill=True):
         """D (optional, [C, 5] lens coefficients): the keypoints handed to run_* were detected on RAW frames and
         are undistorted on the GPU first (row N4, snowtri_undistort_keypoints).
         streams (1..4): OVERLAP MODE of the library (snowtri_ctx_set_overlap) -- consecutive run_torch calls are issued
         round-robin on that many internal streams, so a plain loop of independent calls (distinct `out` buffers) overlaps the
         tail of one launch with the ramp-up of the next; call join() before reading the results (or queueing work that
-        reads them) on the caller's stream."""
+        reads them) on the caller's stream.
+        zero_fill=False: run_torch leaves the slots behind count[f] as the output buffers hold them (SNOWTRI_CALL_NO_ZERO_FILL:
+        the reference returns lists of count[f] persons, the padding is this ABI's; on a multi-person batch with a generous
+        pout_max the zeros are most of what a call writes).  Read count[f] before a slot."""
         self.ctx = _lib.Context(K, R, t, device=device)
+        self.call_flags = 0 if zero_fill else _lib.CALL_NO_ZERO_FILL
         self.streams = int(streams)
         if self.streams > 1:
             self.ctx.set_overlap(self.streams)
@@ -50,7 +55,7 @@ class BatchTriangulator:
         pscore = np.empty((F, self.pout_max), dtype=self.out_dtype)
         count = np.zeros(F, dtype=np.int32)
         flags = np.zeros(F, dtype=np.uint32)
-        rc = _lib.lib().snowtri_triangulate_condense(
+        rc = self.ctx.L.snowtri_triangulate_condense(
             self.ctx.handle, F, Pmax, J, _lib.ptr(kpts), _lib.dtype_code(kpts.dtype), _lib.ptr(n_persons),
             self.params, self.method, self.pout_max, _lib.ptr(xyzs), _lib.ptr(pscore),
             _lib.dtype_code(self.out_dtype), _lib.ptr(count), _lib.ptr(flags), _lib.HOST, None)
@@ -95,18 +100,18 @@ class BatchTriangulator:
             if self._ukpts is None or self._ukpts.shape != kpts.shape or self._ukpts.dtype != kpts.dtype \
                     or self._ukpts.device != kpts.device:
                 self._ukpts = torch.empty_like(kpts)
-            _lib.check(_lib.lib().snowtri_undistort_keypoints(
+            _lib.check(self.ctx.L.snowtri_undistort_keypoints(
                 self.ctx.handle, F, Pmax, J, ct.c_void_p(kpts.data_ptr()), ct.c_void_p(self._ukpts.data_ptr()),
                 in_code, _lib.DEVICE, ct.c_void_p(stream)), "snowtri_undistort_keypoints")
             kpts = self._ukpts
         global FUSED_CALLS
         FUSED_CALLS += 1
-        rc = _lib.lib().snowtri_triangulate_condense(
+        rc = self.ctx.L.snowtri_triangulate_condense_ex(
             self.ctx.handle, F, Pmax, J, ct.c_void_p(kpts.data_ptr()), in_code,
             ct.c_void_p(n_persons.data_ptr()) if n_persons is not None else None, self.params, self.method,
             self.pout_max, ct.c_void_p(out["xyzs"].data_ptr()), ct.c_void_p(out["pscore"].data_ptr()),
             _lib.dtype_code(self.out_dtype), ct.c_void_p(out["count"].data_ptr()),
-            ct.c_void_p(out["flags"].data_ptr()), _lib.DEVICE, ct.c_void_p(stream))
+            ct.c_void_p(out["flags"].data_ptr()), _lib.DEVICE, ct.c_void_p(stream), self.call_flags)
         if rc == _lib.ERR_BAD_INDEX:
             raise IndexError("center_point_index / keypoint_num out of range")
         _lib.check(rc, "snowtri_triangulate_condense")

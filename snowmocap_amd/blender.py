@@ -43,7 +43,7 @@ def blender_points_track(xyzs):
     pts = np.empty((n, 24, 4), np.float64)
     val = np.empty((n, 24), np.uint8)
     ctx = _lib.scratch_context()
-    st = _lib.lib().snowtri_blender_points(ctx.handle, n, kn, _lib.ptr(a), _lib.dtype_code(a.dtype), _lib.ptr(pts),
+    st = ctx.L.snowtri_blender_points(ctx.handle, n, kn, _lib.ptr(a), _lib.dtype_code(a.dtype), _lib.ptr(pts),
                                            _lib.ptr(val), _lib.HOST, None)
     if st == _lib.ERR_BAD_INDEX:
         raise IndexError(f"index 129 is out of bounds for axis 0 with size {kn}")      # blender.py:117
@@ -60,7 +60,7 @@ def blender_smooth_track(points, valid, blender_smooth_profile, delta_time=1 / 3
     fzr = np.ascontiguousarray([blender_smooth_profile[n] for n in CONTROL_POINT_NAMES], dtype=np.float64)
     y = np.empty_like(x)
     ctx = _lib.scratch_context()
-    _lib.check(_lib.lib().snowtri_blender_smooth(ctx.handle, T, P, _lib.ptr(x), _lib.ptr(v), _lib.ptr(fzr),
+    _lib.check(ctx.L.snowtri_blender_smooth(ctx.handle, T, P, _lib.ptr(x), _lib.ptr(v), _lib.ptr(fzr),
                                                  float(delta_time), _lib.ptr(y), _lib.HOST, None),
                "snowtri_blender_smooth")
     return y

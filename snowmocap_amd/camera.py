@@ -53,7 +53,7 @@ class Camera:
             for person in self.hrnet_points:
                 uv = np.ascontiguousarray(np.asarray(person, dtype=np.float64)[:, :2])
                 rays = np.empty((uv.shape[0], 3))
-                _lib.check(_lib.lib().snowtri_rays_from_pixels(ctx.handle, self._index, uv.shape[0],
+                _lib.check(ctx.L.snowtri_rays_from_pixels(ctx.handle, self._index, uv.shape[0],
                                                                _lib.ptr(uv), _lib.ptr(rays)),
                            "snowtri_rays_from_pixels")
                 out.append([rays[j].reshape(3, 1) for j in range(rays.shape[0])])

@@ -26,7 +26,7 @@
 #include "snowtri_lean.hpp"
 #include "snowtri_cluster.hpp"
 #include "snowtri_general.hpp"
-#include "snowtri_sums_rays.hpp"
+#include "snowtri_assoc.hpp"
 #include "snowtri_smooth.hpp"
 #include "snowtri_blender.hpp"
 #include "snowtri_undistort.hpp"
@@ -331,7 +331,6 @@ struct snowtri_ctx {
     int lean_mode = 1;           // SNOWTRI_LEAN_MODE: 0 keeps float32-output batches on k_fused_single
     int lean_coop = 1;           // SNOWTRI_LEAN_COOP: 0 keeps small launches on k_fused_lean
     int sumless_mode = 1;        // SNOWTRI_SUMLESS_MODE: 0 keeps the candidate pass for single-detection batches on the streaming route
-    int sums_rays = 0;           // SNOWTRI_SUMS_RAYS: 1 sends rigs of 32 rays per frame to k_candidate_sums_rays (measured slower: snowtri_sums_rays.hpp)
     int handover_mode = 1;       // SNOWTRI_HANDOVER_MODE: 1 streaming association (k_candidate_sums / k_associate / k_cluster_fuse), 2 hand-over
                                  // from inside k_frame_recompute, 0 the whole multi-person path inside k_frame_recompute
     int handover_seg_frames = 0; // SNOWTRI_HANDOVER_SEG_FRAMES: short segments of the streaming route
@@ -382,6 +381,9 @@ const char *snowtri_build_info(void) {
 #ifdef SNOWTRI_DEBUG_BOUNDS
         add("SNOWTRI_DEBUG_BOUNDS");
 #endif
+#ifdef SNOWTRI_TEST_KNOBS
+        add("SNOWTRI_TEST_KNOBS");
+#endif
 #ifdef SNOWTRI_DEV_MIN
         add("SNOWTRI_DEV_MIN");
 #endif
@@ -419,8 +421,10 @@ int snowtri_ctx_create(int32_t C, const double *K, const double *R, const double
     if (!ctx) return SNOWTRI_ERR_BAD_ARG;
     ctx->device = device;
     ctx->C = C;
-    // Test knobs (include/snowtri.h lists them): read HERE, once -- nothing on the launch path calls getenv -- and every one
-    // that is set is named by snowtri_ctx_overrides(), so a test or a bench can see that a context does not run the defaults.
+    // Test knobs (include/snowtri.h lists them) exist ONLY in a -DSNOWTRI_TEST_KNOBS build (libsnowtri_dbg.so, which the tests that
+    // force a route load): the production library reads no environment.  There they are read HERE, once -- nothing on the launch
+    // path calls getenv -- and every one that is set is named by snowtri_ctx_overrides().
+#ifdef SNOWTRI_TEST_KNOBS
     auto knob = [&](const char *name, int *field, int lo) {
         if (const char *e = getenv(name)) {
             *field = std::max(lo, atoi(e));
@@ -431,7 +435,6 @@ int snowtri_ctx_create(int32_t C, const double *K, const double *R, const double
     knob("SNOWTRI_LEAN_MODE", &ctx->lean_mode, 0);
     knob("SNOWTRI_LEAN_COOP", &ctx->lean_coop, 0);
     knob("SNOWTRI_SUMLESS_MODE", &ctx->sumless_mode, 0);
-    knob("SNOWTRI_SUMS_RAYS", &ctx->sums_rays, 0);
     knob("SNOWTRI_HANDOVER_MODE", &ctx->handover_mode, 0);
     knob("SNOWTRI_HANDOVER_SEG_FRAMES", &ctx->handover_seg_frames, 1);
     knob("SNOWTRI_SPLIT_SEGMENTS", &ctx->split_segments, 1);
@@ -440,6 +443,7 @@ int snowtri_ctx_create(int32_t C, const double *K, const double *R, const double
     knob("SNOWTRI_SUMS_LDS_KB", &ctx->sums_lds_kb, 0);
     knob("SNOWTRI_LEAN_TILES_PER_WAVE", &ctx->lean_tiles_per_wave, 1);
     knob("SNOWTRI_DEBUG", &ctx->debug, 0);
+#endif
     ctx->hM.resize((size_t)C * 9);
     ctx->ht.assign(t, t + (size_t)C * 3);
     ctx->hK.assign(K, K + (size_t)C * 9);
@@ -582,6 +586,13 @@ int snowtri_ctx_set_overlap(snowtri_ctx *ctx, int n_streams) {
         }
     ctx->overlap = n_streams;
     ctx->call_index = 0;
+    return SNOWTRI_OK;
+}
+
+int snowtri_ctx_set_split(snowtri_ctx *ctx, int segments) {
+    if (!ctx || segments < 0 || segments > 64) return SNOWTRI_ERR_BAD_ARG;
+    ctx->split_segments = segments == 0 ? 2 : segments;
+    ctx->split_forced = segments >= 2;
     return SNOWTRI_OK;
 }
 
@@ -865,6 +876,7 @@ int validate_params(const snowtri_params *p, int J, Params *out, bool need_conde
         if ((double)kf < q.kthr) kf = std::nextafter(kf, std::numeric_limits<float>::infinity());
         q.kthr_f32 = kf;            // NaN stays NaN: every comparison false, as in NumPy
     }
+    q.no_zero_fill = 0;             // (snowtri_triangulate_condense_ex sets it from its call flags)
     *out = q;
     return SNOWTRI_OK;
 }
@@ -1629,7 +1641,7 @@ int snowtri_blender_hold_shard_apply(snowtri_ctx *ctx, int32_t world, int32_t ra
     ENTER_DEVICE(ctx->device);
     hipStream_t st = (hipStream_t)stream;
     const int64_t nchunks = (T - 1 + kSmoothChunk - 1) / kSmoothChunk;   // the filter's chunks: frames 1 .. T-1
-    if (nchunks > 65535) return SNOWTRI_ERR_BAD_ARG;
+    if (nchunks + 1 > 65535) return SNOWTRI_ERR_BAD_ARG;   // (k_hold_fill runs nchunks + 1 block rows: checked BEFORE anything is queued)
     const size_t cn = (size_t)std::max<int64_t>(1, nchunks) * n;
     const size_t off_H = 4096, off_start = off_H + sizeof(double) * cn, off_Hf = off_start + sizeof(double) * cn,
                  off_ent = (off_Hf + cn + 255) & ~(size_t)255;
@@ -1999,17 +2011,12 @@ SumsLaunch sums_launch_shape(const snowtri_ctx *ctx, int Pmax, int J) {
     const int64_t nitems = (int64_t)ctx->npairs * (Pmax / (gs >= 2 ? kSumsGA : 1)) * (Pmax / gs);   // (k_candidate_sums: GA x GS tiles)
     SumsLaunch L;
     // one pass over the items should keep every wave busy: 256 threads for the small rigs, the whole CU for the large.
-    // (SNOWTRI_SUMS_THREADS=64: one wave per workgroup, for rigs whose tiles fit a wave -- measured slower, SumsShape)
     L.threads = ctx->sums_threads > 0 ? ctx->sums_threads : (nitems <= 256 ? 256 : (nitems <= 768 ? 512 : 1024));
-    L.threads = std::max(64, std::min(1024, (L.threads / 64) * 64));
-    L.threads = L.threads <= 64 ? 64 : (L.threads <= 256 ? 256 : (L.threads <= 512 ? 512 : 1024));   // the instantiated shapes
-    L.lds = ctx->sums_lds_kb > 0 ? ctx->sums_lds_kb * 1024
-                                 : (L.threads <= 64 ? 13 * 1024 : (L.threads <= 256 ? 52 * 1024 : (L.threads <= 512 ? 80 * 1024 : 160 * 1024)));
+    L.threads = L.threads <= 256 ? 256 : (L.threads <= 512 ? 512 : 1024);   // the instantiated shapes
+    L.lds = ctx->sums_lds_kb > 0 ? ctx->sums_lds_kb * 1024 : (L.threads <= 256 ? 52 * 1024 : (L.threads <= 512 ? 80 * 1024 : 160 * 1024));
     L.lds = std::min(L.lds, 160 * 1024);
-    // (a one-wave workgroup: 12 per CU, three waves per SIMD at 168 registers)
-    L.per_cu = std::max(1, std::min((160 * 1024) / L.lds, L.threads == 64 ? 12 : 2048 / L.threads));
-    const int pf = L.threads == 64 ? SumsShape<64>::kPrefetch
-                                   : (L.threads == 256 ? SumsShape<256>::kPrefetch : (L.threads == 512 ? SumsShape<512>::kPrefetch : SumsShape<1024>::kPrefetch));
+    L.per_cu = std::max(1, std::min((160 * 1024) / L.lds, 2048 / L.threads));
+    const int pf = L.threads == 256 ? SumsShape<256>::kPrefetch : (L.threads == 512 ? SumsShape<512>::kPrefetch : SumsShape<1024>::kPrefetch);
     L.Jc = sums_chunk_joints(C, Pmax, J, ctx->npairs, L.threads, pf, L.lds);
     return L;
 }
@@ -2128,28 +2135,19 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st_call, int64_t F, int
                 (void)hipStreamWaitEvent(caller, ctx->sets[1].done, 0);
         }
     } split_join{ctx, st_call, set_call, split};
-    const bool sums_rays_shape = !sumless && ctx->sums_rays != 0 && ctx->sums_threads == 0 && ctx->sums_lds_kb == 0 &&
-                                 ((C == 8 && Pmax == 4)
-#ifndef SNOWTRI_DEV_MIN
-                                  || (C == 16 && Pmax == 2) || (C == 4 && Pmax == 8)
-#endif
-                                 );
     const uint32_t *final_slow_list = nullptr;                 // what the streaming association leaves to k_frame_recompute
     const unsigned long long *final_slow_count = nullptr;
     {   // the kernels of this route, in launch order (rebuilt only when the route changes)
         const long long key = ((long long)C << 8) | (METHOD << 7) | ((int)sizeof(TIn) << 3) | ((int)sizeof(TOut) >> 2 << 2) |
                               (stream ? 2 : 0) | (handover ? 1 : 0) | ((long long)SL.threads << 16) | ((long long)(sumless ? 1 : 0) << 32) |
-                              ((long long)(sums_rays_shape ? 1 : 0) << 33) | ((long long)Pmax << 34);
+                              ((long long)Pmax << 34);
         if (key != ctx->names_key) {
             const std::string tin = type_name<TIn>(), tout = type_name<TOut>();
             const std::string rec = "k_frame_recompute<" + std::to_string(METHOD) + "," + tin + "," + tout + ">";
             const std::string fuse = C <= kClusterMaxCams ? "k_cluster_fuse<" + std::to_string(C) + "," + tin + "> + k_cluster_members<" + tin + ">"
                                                            : "k_cluster_fuse_wide<" + tin + "> + k_cluster_members<" + tin + ">";
             if (stream && sumless)
-                ctx->names_buf = "k_associate<" + tin + "> + " + fuse + " + k_person_scores<" + tout + "> + " + rec + " (frames left behind)";
-            else if (stream && sums_rays_shape)
-                ctx->names_buf = "k_candidate_sums_rays<" + tin + "," + std::to_string(C) + "," + std::to_string(Pmax) + "> + k_candidate_sums_exact<" + tin +
-                                 "> + k_associate<" + tin + "> + " + fuse + " + " + rec + " (frames left behind)";
+                ctx->names_buf = "k_singular_scan<" + tin + "> + k_associate<" + tin + "> + " + fuse + " + k_person_scores<" + tout + "> + " + rec + " (frames left behind)";
             else if (stream)
                 ctx->names_buf = "k_candidate_sums<" + tin + "," + std::to_string(SL.threads) + "> + k_candidate_sums_exact<" + tin +
                                  "> + k_associate<" + tin + "> + " + fuse + " + " + rec + " (frames left behind)";
@@ -2227,34 +2225,16 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st_call, int64_t F, int
                 if (sumless) {
                     // every byte 0x3f: the double 4.7e-4 in every slot -- positive, finite, kept by :80-81 for any threshold <= 0
                     HIP_TRY(hipMemsetAsync(csum, 0x3f, (size_t)Fs * Kc * 8, st));
-                    if (fl_seg) HIP_TRY(hipMemsetAsync(fl_seg, 0, (size_t)Fs * sizeof(uint32_t), st));   // (the candidate pass clears the flags otherwise)
-                } else {
-                    // rigs of exactly 32 rays per frame (8 x 4, 16 x 2, 4 x 8): one lane per ray and joint sub-range, every lane
-                    // of the workgroup at work (snowtri_sums_rays.hpp); everything else: tiles of a camera pair
-                    bool rays = false;
-#define SNOWTRI_RAYS(CC, PP)                                                                                                          \
-    if (C == CC && Pmax == PP) {                                                                                                      \
-        auto kr = k_candidate_sums_rays<TIn, CC, PP>;                                                                                 \
-        const int ldsr = (int)rays_lds_bytes(CC, CC * (CC - 1) / 2);                                                                  \
-        if (ldsr > 48 * 1024 && ctx->raise_lds((const void *)kr, ldsr)) return SNOWTRI_ERR_HIP;                                      \
-        const int gridr = (int)std::min<int64_t>(Fs, (int64_t)ctx->num_cus * kRaysWaves);                                             \
-        hipLaunchKernelGGL(kr, dim3(gridr), dim3(kRaysThreads), ldsr, st, Fs, J, J, ctx->rig(), kp_seg, np_seg, prm, csum, fl_seg,     \
-                           exact_list, exact_count, sums_ticket);                                                                     \
-        if (sums_kn)                                                                                                                  \
-            hipLaunchKernelGGL(kr, dim3(gridr), dim3(kRaysThreads), ldsr, st, Fs, prm.kn, J, ctx->rig(), kp_seg, np_seg, prm, csum_kn, \
-                               (uint32_t *)nullptr, (uint32_t *)nullptr, exact_count, sums_ticket + 1);                               \
-        rays = true;                                                                                                                  \
-    }
-                    if (ctx->sums_rays != 0 && ctx->sums_threads == 0 && ctx->sums_lds_kb == 0) {
-                        SNOWTRI_RAYS(8, 4)
-#ifndef SNOWTRI_DEV_MIN
-                        SNOWTRI_RAYS(16, 2)
-                        SNOWTRI_RAYS(4, 8)
-#endif
+                    if (fl_seg) {
+                        HIP_TRY(hipMemsetAsync(fl_seg, 0, (size_t)Fs * sizeof(uint32_t), st));   // (the candidate pass clears the flags otherwise)
+                        // ... and finds every singular pair of every listed candidate and joint; here a scan asks that one question
+                        // (the flag must not depend on the route: k_singular_scan, snowtri_assoc.hpp)
+                        hipLaunchKernelGGL((k_singular_scan<TIn>), dim3(grid_for(Fs * (int64_t)J, kBlock, ctx->num_cus * 16)), dim3(kBlock), 0, st, Fs, J,
+                                           ctx->rig(), kp_seg, np_seg, fl_seg);
+                        HIP_TRY(hipGetLastError());
                     }
-#undef SNOWTRI_RAYS
-                    if (rays) {
-                    } else if (SL.threads == 64) SNOWTRI_SUMS(64) else if (SL.threads == 256) SNOWTRI_SUMS(256) else if (SL.threads == 512) SNOWTRI_SUMS(512) else SNOWTRI_SUMS(1024)
+                } else {
+                    if (SL.threads == 256) SNOWTRI_SUMS(256) else if (SL.threads == 512) SNOWTRI_SUMS(512) else SNOWTRI_SUMS(1024)
                     HIP_TRY(hipGetLastError());
                     // the frames it listed (exact_count of them, known on the device only; normally none)
                     hipLaunchKernelGGL((k_candidate_sums_exact<TIn>), dim3((int)std::min<int64_t>(Fs, ctx->num_cus)), dim3(kBlock), 0, st, Pmax, J,
@@ -2503,7 +2483,18 @@ extern "C" int snowtri_triangulate_condense(snowtri_ctx *ctx, int64_t F, int32_t
                                             void *out_xyzs, void *out_pscore, int out_dtype,
                                             int32_t *out_count, uint32_t *out_flags, int memspace,
                                             void *stream) {
+    return snowtri_triangulate_condense_ex(ctx, F, Pmax, J, kpts, in_dtype, n_persons, params, method, Pout_max, out_xyzs, out_pscore,
+                                           out_dtype, out_count, out_flags, memspace, stream, 0u);
+}
+
+extern "C" int snowtri_triangulate_condense_ex(snowtri_ctx *ctx, int64_t F, int32_t Pmax, int32_t J,
+                                               const void *kpts, int in_dtype, const int32_t *n_persons,
+                                               const snowtri_params *params, int method, int32_t Pout_max,
+                                               void *out_xyzs, void *out_pscore, int out_dtype,
+                                               int32_t *out_count, uint32_t *out_flags, int memspace,
+                                               void *stream, uint32_t call_flags) {
     if (!ctx || ctx->C < 1 || F < 0 || Pmax < 1 || J < 1 || Pout_max < 1 || !params) return SNOWTRI_ERR_BAD_ARG;
+    if (call_flags & ~(uint32_t)SNOWTRI_CALL_NO_ZERO_FILL) return SNOWTRI_ERR_BAD_ARG;   // (an unknown flag is refused, not ignored)
     if ((in_dtype != SNOWTRI_F32 && in_dtype != SNOWTRI_F64) || (out_dtype != SNOWTRI_F32 && out_dtype != SNOWTRI_F64))
         return SNOWTRI_ERR_BAD_ARG;
     if (memspace != SNOWTRI_HOST && memspace != SNOWTRI_DEVICE) return SNOWTRI_ERR_BAD_ARG;
@@ -2517,6 +2508,7 @@ extern "C" int snowtri_triangulate_condense(snowtri_ctx *ctx, int64_t F, int32_t
     Params prm;
     int rc = validate_params(params, J, &prm, true);
     if (rc) return rc;
+    prm.no_zero_fill = (call_flags & SNOWTRI_CALL_NO_ZERO_FILL) ? 1 : 0;
     ENTER_DEVICE(ctx->device);
     hipStream_t st = (hipStream_t)stream;
     ctx->cur = &ctx->sets[0];

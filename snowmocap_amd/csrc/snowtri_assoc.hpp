@@ -34,30 +34,22 @@ constexpr int kSumsHeadBytes = 64 + 2 * 8 * 4;
 #ifndef SNOWTRI_SUMS_GA
 #define SNOWTRI_SUMS_GA 2
 #endif
-#ifndef SNOWTRI_SUMS_PREFETCH64
-#define SNOWTRI_SUMS_PREFETCH64 4
-#endif
 constexpr int kSumsWaves256 = SNOWTRI_SUMS_WAVES256;   // (4 waves per SIMD = 128 registers: the 2 x 4 tile spills, 8 x 4 measured 1027 us against 729)
-// 64 threads (SNOWTRI_SUMS_THREADS=64 only): ONE wave per workgroup for rigs whose tiles fit one wave (8 cameras x 4 persons:
-// 56) -- no barrier (a workgroup of one wave), ONE chunk buffer (a wave's fill follows its own solves in program order), sums
-// in registers for the whole frame.  The experiment behind it: the four waves of a 256-thread workgroup meet at a barrier every
-// joint chunk, the fastest 5 % of the chunks take 4.5 us and the median 8 (-DSNOWTRI_SUMS_TRACE=2), so a wave that waits for
-// nobody should do better.  It does not: 8 x 4 x 10 000 frames 720-736 us against 696-700 us (17 chunks of 8 joints per frame
-// instead of 7 of 20, VALU busy 0.68 against 0.75 -- at 2.16 against 2.08 GHz: the kernel runs on the socket's power limit).
+// (Round 5 also carried a 64-thread shape -- ONE wave per workgroup, no barrier, one chunk buffer -- and a kernel with one lane per
+// ray (snowtri_sums_rays.hpp of round 5); both measured no faster per call and were removed in round 6: EXPERIMENTS.md keeps their numbers.)
 template <int THREADS>
 struct SumsShape {
-    static constexpr int kWavesPerSimd = THREADS == 64 ? 3 : (THREADS == 256 ? kSumsWaves256 : 4);
-    static constexpr int kPrefetch = THREADS == 64 ? SNOWTRI_SUMS_PREFETCH64 : (THREADS == 256 ? 3 : 2);
-    static constexpr int kBuffers = THREADS == 64 ? 1 : 2;
+    static constexpr int kWavesPerSimd = THREADS == 256 ? kSumsWaves256 : 4;
+    static constexpr int kPrefetch = THREADS == 256 ? 3 : 2;
 };
 constexpr int kSumsGA = SNOWTRI_SUMS_GA;   // persons of the FIRST camera per tile (when the person count is even)
 
 __host__ __device__ inline size_t sums_arena_offset(int C, int npairs) {
     return ((size_t)kSumsHeadBytes + (size_t)8 * (C + (C & 1)) + (size_t)32 * npairs + (size_t)72 * C + 15) & ~(size_t)15;   // head | n_persons [2][C] | pairs | ray matrices
 }
-// bytes of ONE of the chunk buffers (two; a one-wave workgroup has one)
-__host__ __device__ inline int sums_buffer_bytes(int C, int npairs, int lds_total, int threads) {
-    return ((lds_total - (int)sums_arena_offset(C, npairs)) / (threads == 64 ? 1 : 2)) & ~15;
+// bytes of ONE of the two chunk buffers
+__host__ __device__ inline int sums_buffer_bytes(int C, int npairs, int lds_total, int) {
+    return ((lds_total - (int)sums_arena_offset(C, npairs)) / 2) & ~15;
 }
 // item = tile of GA persons of a pair's first camera x GS persons of its second; JS = how many ways a chunk's joints are
 // split over the workgroup's NW waves when one pass over the items leaves waves idle (whole waves take a joint sub-range:
@@ -124,41 +116,27 @@ struct GatedScore<double> {
 template <int GA, int GS, typename TIn>
 __device__ __forceinline__ void p1_tile_sums(const char *__restrict__ pa, const char *__restrict__ pb, int jstr, int nj, const Vec3 &d,
                                              const Params &prm, double (&acc)[GA * GS]) {
-#ifdef SNOWTRI_K1_NOLDS   // TIMING-ONLY build (wrong sums): the records of the chunk's first joint, read once -- what the solve loop costs without its LDS reads
-    RayRec b0[GS], a0[GA];
-    TIn ss0[GS], sm0[GA];
-    for (int u = 0; u < GS; u++) { b0[u] = p1_load_ray(pb + kP1Rec * u); ss0[u] = p1_load_score<TIn>(pb + kP1Rec * u); }
-    for (int i = 0; i < GA; i++) { a0[i] = p1_load_ray(pa + kP1Rec * i); sm0[i] = p1_load_score<TIn>(pa + kP1Rec * i); }
-#endif
+#pragma clang fp contract(off)   // (every fused product-sum below is an explicit fma(); the determinant must NOT be fused)
     for (int t = 0; t < nj; t++, pa += jstr, pb += jstr) {
         RayRec b[GS];
         TIn ss[GS];
 #pragma unroll
         for (int u = 0; u < GS; u++) {
-#ifdef SNOWTRI_K1_NOLDS
-            asm volatile("" : "+v"(b0[u].x), "+v"(b0[u].y), "+v"(b0[u].z), "+v"(b0[u].a), "+v"(ss0[u]));
-            b[u] = b0[u];
-            ss[u] = ss0[u];
-#else
             b[u] = p1_load_ray(pb + kP1Rec * u);
             ss[u] = p1_load_score<TIn>(pb + kP1Rec * u);
-#endif
         }
 #pragma unroll
         for (int i = 0; i < GA; i++) {
-#ifdef SNOWTRI_K1_NOLDS
-            asm volatile("" : "+v"(a0[i].x), "+v"(a0[i].y), "+v"(a0[i].z), "+v"(a0[i].a), "+v"(sm0[i]));
-            const RayRec a = a0[i];
-            const TIn sm = sm0[i];
-#else
             const RayRec a = p1_load_ray(pa + kP1Rec * i);
             const TIn sm = p1_load_score<TIn>(pa + kP1Rec * i);
-#endif
             const double cx = fma(d.y, a.z, -(d.z * a.y)), cy = fma(d.z, a.x, -(d.x * a.z)), cz = fma(d.x, a.y, -(d.y * a.x));
 #pragma unroll
             for (int u = 0; u < GS; u++) {
                 const double bq = fma(a.z, b[u].z, fma(a.y, b[u].y, a.x * b[u].x));
-                const double det = fma(a.a, b[u].a, -(bq * bq));
+                // separately rounded products: a pair that is singular as the reference sees it (a c == b b, skew_ray_solve)
+                // has det == 0 exactly -> det * rsq(0) = NaN reaches the sum whatever the gates select -> the frame goes to
+                // the exact pass, which flags it.  (The fused determinant is the rounding error of b b there.)
+                const double det = a.a * b[u].a - bq * bq;
                 const double dn = fma(cz, b[u].z, fma(cy, b[u].y, cx * b[u].x));
                 const double dn2 = dn * dn;
                 const double r = fma(det, prm.dthr2, -dn2);                                         // :73-74: r < 0 <=> dist > distance_threshold
@@ -245,7 +223,7 @@ __global__ __launch_bounds__(THREADS, SumsShape<THREADS>::kWavesPerSimd) void k_
     for (int i = tid; i < 9 * C; i += B) Ml[i] = rig.M[i];
     char *const rec0 = smem + sums_arena_offset(C, rig.npairs);
     const int half = sums_buffer_bytes(C, rig.npairs, lds_total, B);   // bytes of one chunk buffer
-    const int bufstep = SumsShape<THREADS>::kBuffers == 2 ? half : 0;  // (one buffer: a wave's fill of chunk c + 1 follows its solves of chunk c in program order)
+    const int bufstep = half;
     const int jstr = p1_joint_stride(R), Jc = sums_chunk_joints(C, Pmax, J, rig.npairs, B, NPF, lds_total);
     const int nch = (J + Jc - 1) / Jc;
     const unsigned long long magic_pmax = (((unsigned long long)1 << 40) + (unsigned)Pmax - 1) / (unsigned)Pmax;
@@ -1014,8 +992,10 @@ __global__ __launch_bounds__(64, RC > 4 ? 2 : kAssocWaves) void k_associate(int6
                     if (want) got = atomicAdd(hand_counters + (lane == 0 ? kHandComplete : kHandMembers), want);
                     // the round trip of that device-scope atomic is ~16 us under thousands of waves (wall-clock stamps): the
                     // zero-fill of the unused slots, which needs nothing of it, goes out in its shadow
-                    for (int i = lane; i < (Pout - nout) * kn; i += 64) wr.zero_joint(f, Pout, kn, nout + i / kn, i % kn);
-                    for (int slot = nout + lane; slot < Pout; slot += 64) wr.person(f, Pout, slot, 0.0);
+                    if (!prm.no_zero_fill) {
+                        for (int i = lane; i < (Pout - nout) * kn; i += 64) wr.zero_joint(f, Pout, kn, nout + i / kn, i % kn);
+                        for (int slot = nout + lane; slot < Pout; slot += 64) wr.person(f, Pout, slot, 0.0);
+                    }
                     zero_filled = true;
                     const unsigned long long bc = (unsigned long long)__shfl((long long)got, 0, 64), gm = (unsigned long long)__shfl((long long)got, 1, 64),
                                              bg = hand_member_descs(gm), bw = hand_member_words(gm);
@@ -1061,7 +1041,7 @@ __global__ __launch_bounds__(64, RC > 4 ? 2 : kAssocWaves) void k_associate(int6
         }
         ASSOC_STAMP(7);
         // unused slots: one flat sweep of 16-byte stores (already out for a frame that reserved list room)
-        if (!zero_filled) {
+        if (!zero_filled && !prm.no_zero_fill) {
             for (int i = lane; i < (Pout - nout) * kn; i += 64) wr.zero_joint(f, Pout, kn, nout + i / kn, i % kn);
             for (int slot = nout + lane; slot < Pout; slot += 64) wr.person(f, Pout, slot, 0.0);
         }
@@ -1129,6 +1109,40 @@ __global__ __launch_bounds__(kBlock) void k_person_scores(int64_t F, int Pout, i
         }
         v = wave_sum(v);
         if (lane == 0) out_ps[rec] = (TOut)(v / (double)kn);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------- k_singular_scan
+// The streaming route WITHOUT its candidate pass (one detection per camera, `sumless` in launch_frame_recompute) flags a
+// singular pair where its joint is FUSED -- which leaves out what the reference solves and this route never touches: the joints
+// behind keypoint_num, and the candidates outside every kept cluster (the lone last candidate of :107, clusters dropped by
+// condense_person_num_tol).  The reference's np.linalg.inv raises for those too (triangulation.py:26 runs for every listed
+// pair and every joint), and with the candidate pass the same frames ARE flagged: the flag must not depend on the route
+// (round-5 advice).  This scan is the candidate pass reduced to that one question -- lane = (frame, joint), every pair of
+// listed cameras, rays and products exactly as skew_ray_solve forms them: a c == b b in separately rounded products.
+template <typename TIn>
+__global__ __launch_bounds__(kBlock) void k_singular_scan(int64_t F, int J, Rig rig, const TIn *__restrict__ kpts,
+                                                          const int32_t *__restrict__ n_persons, uint32_t *__restrict__ out_flags) {
+    const int C = rig.C;
+    const Kp3<TIn> *kp3 = reinterpret_cast<const Kp3<TIn> *>(kpts);
+    const int64_t total = F * (int64_t)J;
+    for (int64_t i = blockIdx.x * (int64_t)kBlock + threadIdx.x; i < total; i += (int64_t)gridDim.x * kBlock) {
+        const int64_t f = i / J;
+        const int j = (int)(i - f * J);
+        bool sing = false;
+        for (int m = 0; m + 1 < C; m++) {
+            if (n_persons && n_persons[f * C + m] < 1) continue;
+            const Kp3<TIn> km = kp3[(f * C + m) * J + j];
+            const RayRec a = make_ray(rig.M + 9 * m, km.u, km.v);
+            for (int s = m + 1; s < C; s++) {
+                if (n_persons && n_persons[f * C + s] < 1) continue;
+                const Kp3<TIn> ks = kp3[(f * C + s) * J + j];
+                const RayRec b = make_ray(rig.M + 9 * s, ks.u, ks.v);
+                const double bq = fma(a.z, b.z, fma(a.y, b.y, a.x * b.x));
+                sing |= a.a * b.a == bq * bq;
+            }
+        }
+        if (sing) atomicOr(&out_flags[f], 1u /*SNOWTRI_FLAG_SINGULAR*/);
     }
 }
 

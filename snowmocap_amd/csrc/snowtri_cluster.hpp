@@ -404,6 +404,7 @@ __global__ __launch_bounds__(kBlock, kWideWaves) void k_cluster_fuse_wide(const 
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         // ---- solve: first cameras m = g, g + 4, ...; second camera cyclic
         double aS = 0.0, aX = 0.0, aY = 0.0, aZ = 0.0;
+        bool sing = false;   // a pair that is singular as the reference sees it (a c == b b, skew_ray_solve): the sequential routine flags the joint
         for (int m = g; m < C; m += 4) {
             const char *ra = tile + m * kWideRayStride + it * 8;
             lds_cv_f64 pa = (lds_cv_f64)ra;
@@ -428,6 +429,9 @@ __global__ __launch_bounds__(kBlock, kWideWaves) void k_cluster_fuse_wide(const 
                 // A2 (triangulation.py:24-31)
                 const double bq = fma(az, bz, fma(ay, by, ax * bx));
                 const double det = fma(aa, bb, -(bq * bq));
+                // (the fused determinant of equal rays is the rounding error of b b -- a finite, wrong member that `aS` below
+                // does not give away: S0 = S1 = inf -> d2 = inf -> 1/dist = 0.  Tested explicitly instead.)
+                sing |= aa * bb == bq * bq;
                 const double e = fma(az, dz, fma(ay, dy, ax * dx));
                 const double gg = fma(bz, dz, fma(by, dy, bx * dx));
                 const double inv = rcp_nr1(det);   // (2^-46: 1e-13 m on the point)
@@ -471,7 +475,8 @@ __global__ __launch_bounds__(kBlock, kWideWaves) void k_cluster_fuse_wide(const 
         const double r = 0.5 * rcp_nr1(fmax(aS, 1e-300));
         double ox = aX * r, oy = aY * r, oz = aZ * r;   // :144-147
         double os = aS * (0.0005 / (double)NP);         // :148
-        const bool bad = !(aS < 1e300) && it0.valid;
+        const unsigned long long sing_lanes = __ballot(sing);
+        const bool bad = (!(aS < 1e300) || ((sing_lanes >> (lane & ~3)) & 15ull) != 0ull) && it0.valid;   // (the item's four lanes sit side by side)
         if (__ballot(bad)) {   // rare, wave-uniform branch
             if (bad && g == 0)
                 cluster_joint_sequential<TIn, TOut>(rig, kp3, (int64_t)it0.frame, it0.plo, it0.phi, Pmax, J, (int)it0.j, prm, ox, oy, oz, os, out_flags);

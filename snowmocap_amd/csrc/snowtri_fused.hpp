@@ -231,7 +231,7 @@ __device__ __forceinline__ bool pairwise_item(const Rig &rig, const double *__re
 #pragma unroll
         for (int sc = mc + 1; sc < C; sc++, q++) {
             bq[q] = dot3(h[mc], h[sc]);
-            detq[q] = fma(a[mc], a[sc], -(bq[q] * bq[q]));
+            detq[q] = a[mc] * a[sc] - bq[q] * bq[q];   // separately rounded products (contraction off): singular as the reference sees it (a c == b b) <=> 0 exactly, which poisons the product below; the fused form is the rounding error of b b there
             pre[q] = q == 0 ? detq[0] : pre[q - 1] * detq[q];
         }
     {
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(kBlock, (FusedShape<C, METHOD, TIn>::kWaves)) void 
             // unused person slots are zero-filled here, NOT inside the item loop: a store loop with a
             // run-time trip count there makes the compiler's vmcnt bookkeeping give up and wait for
             // every outstanding load (vmcnt(0)) at each item, which defeats the prefetch ring
-            if (Pout > 1) {
+            if (Pout > 1 && !prm.no_zero_fill) {
                 Vec4T<TOut> *tile_out = reinterpret_cast<Vec4T<TOut> *>(out4) + f0 * Pout * (int64_t)kn;
                 const int per = (Pout - 1) * kn;
                 for (int i = tid; i < nf * per; i += kBlock) {

@@ -194,6 +194,9 @@ __device__ __forceinline__ double candidate_chunk_sum_exact(const char *__restri
             e[u] = fma(a[u].z, d.z, fma(a[u].y, d.y, a[u].x * d.x));
             g[u] = fma(b[u].z, d.z, fma(b[u].y, d.y, b[u].x * d.x));
             det[u] = fma(a[u].a, b[u].a, -(bq[u] * bq[u]));
+            // singular as the reference's LU sees equal rays and as the oracle defines it: a c == b b in separately rounded
+            // products (skew_ray_solve).  The fused determinant above is the rounding error of b b there -- not 0.
+            sing |= a[u].a * b[u].a == bq[u] * bq[u];
         }
         const double p01 = det[0] * det[1], p012 = p01 * det[2], p0123 = p012 * det[3];
         // a product outside the normal range (a singular or wildly conditioned pair in the group) falls back to
@@ -206,12 +209,9 @@ __device__ __forceinline__ double candidate_chunk_sum_exact(const char *__restri
             run *= det[2];
             inv[1] = run * det[0];
             inv[0] = run * det[1];
-        } else {   // includes every exactly singular pair (product 0): flagged here, off the common path
+        } else {
 #pragma unroll
-            for (int u = 0; u < 4; u++) {
-                inv[u] = rcp_nr2(det[u]);
-                sing |= det[u] == 0.0;
-            }
+            for (int u = 0; u < 4; u++) inv[u] = rcp_nr2(det[u]);
         }
 #pragma unroll
         for (int u = 0; u < 4; u++) finish(a[u], b[u], bq[u], e[u], g[u], inv[u], sm[u], ss[u]);
@@ -222,7 +222,7 @@ __device__ __forceinline__ double candidate_chunk_sum_exact(const char *__restri
         const double e = fma(a.z, d.z, fma(a.y, d.y, a.x * d.x));
         const double g = fma(b.z, d.z, fma(b.y, d.y, b.x * d.x));
         const double det = fma(a.a, b.a, -(bq * bq));
-        sing |= det == 0.0;
+        sing |= a.a * b.a == bq * bq;
         finish(a, b, bq, e, g, rcp_nr2(det), p1_load_score<TIn>(ra + jj * jstr), p1_load_score<TIn>(rb + jj * jstr));
     }
     return acc;
@@ -250,6 +250,7 @@ __device__ __forceinline__ double candidate_chunk_sum_exact(const char *__restri
 template <int GS, typename TIn>
 __device__ __forceinline__ void p1_item_sums(const char *__restrict__ pa, const char *__restrict__ pb, int jstr, int nj,
                                              const Vec3 &d, const Params &prm, double (&acc)[GS]) {
+#pragma clang fp contract(off)   // (the determinant must not be fused: see p1_tile_sums)
     for (int t = 0; t < nj; t++, pa += jstr, pb += jstr) {
         const RayRec a = p1_load_ray(pa);
         const TIn sm = p1_load_score<TIn>(pa);
@@ -265,7 +266,7 @@ __device__ __forceinline__ void p1_item_sums(const char *__restrict__ pa, const 
 #pragma unroll
         for (int u = 0; u < GS; u++) {
             const double bq = fma(a.z, b[u].z, fma(a.y, b[u].y, a.x * b[u].x));
-            const double det = fma(a.a, b[u].a, -(bq * bq));
+            const double det = a.a * b[u].a - bq * bq;   // separately rounded: singular (a c == b b) <=> det == 0 -> NaN -> exact pass
             const double dn = fma(cz, b[u].z, fma(cy, b[u].y, cx * b[u].x));
             const double dn2 = dn * dn;
             const bool kp_ = okm && !below_kthr(ss[u], prm) && !(dn2 > det * prm.dthr2);   // :73-74
@@ -1093,9 +1094,11 @@ __global__ __launch_bounds__(kBlock, kRecomputeWaves) void k_frame_recompute(int
             }
             }   // !handed
         }
-        // unused slots: one flat sweep of 16-byte stores
-        for (int i = tid; i < (Pout - nout) * kn; i += kBlock) wr.zero_joint(f, Pout, kn, nout + i / kn, i % kn);
-        for (int slot = nout + tid; slot < Pout; slot += kBlock) wr.person(f, Pout, slot, 0.0);
+        // unused slots: one flat sweep of 16-byte stores (unless the call opted out: SNOWTRI_CALL_NO_ZERO_FILL)
+        if (!prm.no_zero_fill) {
+            for (int i = tid; i < (Pout - nout) * kn; i += kBlock) wr.zero_joint(f, Pout, kn, nout + i / kn, i % kn);
+            for (int slot = nout + tid; slot < Pout; slot += kBlock) wr.person(f, Pout, slot, 0.0);
+        }
         if (tid == 0) {
             out_count[f] = nout;
             if (out_flags && nout > Pout) atomicOr(&out_flags[f], 2u /*SNOWTRI_FLAG_OVERFLOW*/);

@@ -94,7 +94,11 @@ __device__ __forceinline__ bool cluster_item(const double *__restrict__ K, const
             const double dx = dq[0], dy = dq[1], dz = dq[2];
             // A2 (triangulation.py:24-31)
             const double b = dot3(hm, hs);
-            const double det = fma(a[mc], a[sc], -(b * b));
+            // det with SEPARATELY rounded products (contraction is off): a pair that is singular as the reference sees it
+            // (a c == b b, skew_ray_solve) has det == 0 exactly -> rho = inf -> the sum is not finite -> the sequential
+            // routine takes the joint and flags it.  The fused form is the rounding error of b b there: usually not 0, and
+            // positive often enough (18 % of equal rays) for a finite, wrong joint to pass (round-5 advice).
+            const double det = a[mc] * a[sc] - b * b;
             const double e = fma(hm.z, dz, fma(hm.y, dy, hm.x * dx));
             const double g = fma(hs.z, dz, fma(hs.y, dy, hs.x * dx));
             const double N0 = fma(a[sc], e, -(b * g));

@@ -488,7 +488,7 @@ __device__ __forceinline__ void condense_frame(int64_t f, int N, int J, const do
         }
         nout++;
     }
-    for (int slot = nout; slot < Pout; slot++) {  // deterministic padding
+    for (int slot = nout; slot < Pout && !prm.no_zero_fill; slot++) {  // deterministic padding (unless the call opted out)
         for (int b = tid; b < kn; b += kBlock) wr.joint(f, Pout, kn, slot, b, 0.0, 0.0, 0.0, 0.0);
         if (tid == 0) wr.person(f, Pout, slot, 0.0);
     }

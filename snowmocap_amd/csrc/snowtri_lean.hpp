@@ -164,8 +164,9 @@ __device__ __forceinline__ bool lean_item(const double *__restrict__ Mlds,
     // reciprocal (no chain over the pairs, no range of a product to watch).  Conditioning: n cancels to dist |h_m x h_s|
     // from terms of size |d| |h_m| |h_s|, 1e-16 |d| / dist relative -- the same cancellation as ||Wm - Ws|| from
     // 5 m coordinates in the reference.  The gate dist > dthr (:74) is taken on n^2 > dthr^2 det (both sides x det > 0).
-    // A singular pair (det = 0 => n = 0) or an exact intersection (n = 0) give rho = inf, a negative (rounding of
-    // nearly parallel rays) or NaN determinant rho = NaN: they reach the score sum, whatever the gates select.
+    // A singular pair (a c == b b in separately rounded products: det = 0 exactly) or an exact intersection (n = 0) give
+    // rho = inf, a negative (rounding of nearly parallel rays) or NaN determinant rho = NaN: they reach the score sum,
+    // whatever the gates select (0 x inf = NaN).
     int q = 0;
 #pragma unroll
     for (int mc = 0; mc < C - 1; mc++) {
@@ -174,7 +175,7 @@ __device__ __forceinline__ bool lean_item(const double *__restrict__ Mlds,
             const Vec3 &hm = h[mc], &hs = h[sc];
             const double dx = dS[3 * q], dy = dS[3 * q + 1], dz = dS[3 * q + 2];
             const double b = dot3(hm, hs);
-            const double det = fma(a[mc], a[sc], -(b * b));
+            const double det = a[mc] * a[sc] - b * b;   // separately rounded products (contraction off): singular as the reference sees it <=> det == 0 exactly (cluster_item)
             const double e = fma(hm.z, dz, fma(hm.y, dy, hm.x * dx));
             const double g = fma(hs.z, dz, fma(hs.y, dy, hs.x * dx));
             const double N0 = fma(a[sc], e, -(b * g));

@@ -16,6 +16,8 @@ namespace snowtri {
 // Build variants.  The production library is compiled with NONE of these (snowtri_build_info() lists the ones a binary
 // carries, tests/test_abi_and_host.py asserts the shipped one reports none):
 //   SNOWTRI_DEBUG_BOUNDS     device-side index checks (libsnowtri_dbg.so, tests only)
+//   SNOWTRI_TEST_KNOBS       the route-forcing environment knobs of include/snowtri.h (libsnowtri_dbg.so, tests only: the
+//                            production library reads no environment)
 //   SNOWTRI_DEV_MIN          4-camera float32 instantiations only (fast A/B builds, the ASan build)
 //   SNOWTRI_DEV_EXPERIMENTS  gate of everything that is a measurement aid: the wall-clock stamps of SNOWTRI_LEAN_TRACE /
 //                            _SUMS_TRACE / _ASSOC_TRACE.  Round 3's timing-only switches that produced WRONG outputs
@@ -45,6 +47,7 @@ struct Params {
     // derived on the host for the throughput kernels
     double dthr2;    // dist > dthr  <=>  dist^2 > dthr2   (dthr < 0: -1, so every finite dist^2 exceeds it)
     float kthr_f32;  // smallest float >= kthr: for a float s,  s < kthr  <=>  s < kthr_f32  (exactly)
+    int32_t no_zero_fill;  // SNOWTRI_CALL_NO_ZERO_FILL: the slots behind out_count[f] are left as the caller's buffer holds them
 };
 
 // `s < kthr` of triangulation.py:73 on the stored element type, without widening float scores.

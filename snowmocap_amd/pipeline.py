@@ -58,7 +58,7 @@ class TrackPipeline:
         if n_persons is not None and not torch.is_tensor(n_persons):
             n_persons = torch.from_numpy(np.ascontiguousarray(n_persons, dtype=np.int32)).to(dev)
         F = kpts.shape[0]
-        L, h = _lib.lib(), self.bt.ctx.handle
+        L, h = self.bt.ctx.L, self.bt.ctx.handle
         st = ct.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         tri = self.bt.run_torch(kpts, n_persons)
         tracked = None                                   # None: every slot of every frame
@@ -183,7 +183,7 @@ class ShardedTrackPipeline:
         T = int(kpts_local.shape[0])
         if T != hi - lo:
             raise ValueError(f"ShardedTrackPipeline: rank {rank} holds {T} frames, shard_bounds gives it [{lo}, {hi})")
-        L, h = _lib.lib(), p.bt.ctx.handle
+        L, h = p.bt.ctx.L, p.bt.ctx.handle
         st = ct.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
         P, kn, th = p.P, p.kn, p.th
         if T:

@@ -39,7 +39,8 @@ def gather_track(local, F_total, group=None):
     return full[:F_total]
 
 
-_HOST_STAGE = {}   # (world, nbytes, dtype) -> pinned (send, recv) pair of the host-staged collective
+_HOST_STAGE = {}   # (device, world, numel, dtype) -> pinned (send, recv) pair of the host-staged collective
+_HOST_STAGE_MAX_BYTES = 1 << 30   # pairs larger than this are not kept (a one-off gather of a whole track would pin its size for good)
 
 
 def all_gather_flat(recv, send, group=None):
@@ -52,23 +53,34 @@ def all_gather_flat(recv, send, group=None):
     combine of smooth_track_sharded run unchanged under genuine multi-process interleaving (tests/test_gpu_multiproc.py)."""
     import torch
     import torch.distributed as dist
+    if not recv.is_contiguous():
+        # (both paths write THROUGH a flat view of recv: reshape(-1) of a non-contiguous tensor would be a temporary copy and the
+        # gathered data would be dropped silently -- round-5 advice)
+        raise ValueError("all_gather_flat: recv must be contiguous")
     if send.is_cuda and dist.get_backend(group) == "gloo":
         world = dist.get_world_size(group)
-        key = (world, send.numel(), send.dtype)
-        if key not in _HOST_STAGE:
-            _HOST_STAGE[key] = (torch.empty(send.numel(), dtype=send.dtype).pin_memory(),
-                                torch.empty(world * send.numel(), dtype=send.dtype).pin_memory())
-        hs, hr = _HOST_STAGE[key][:2]
-        if len(_HOST_STAGE[key]) > 2:
-            _HOST_STAGE[key][2].synchronize()  # the previous copy back out of `hr` (possibly on another stream) has finished
+        key = (send.device.index, world, send.numel(), send.dtype)
+        keep = world * send.numel() * send.element_size() <= _HOST_STAGE_MAX_BYTES
+        ent = _HOST_STAGE.get(key)
+        if ent is None:
+            ent = (torch.empty(send.numel(), dtype=send.dtype).pin_memory(),
+                   torch.empty(world * send.numel(), dtype=send.dtype).pin_memory())
+            if keep:
+                _HOST_STAGE[key] = ent
+        hs, hr = ent[:2]
+        if len(ent) > 2:
+            ent[2].synchronize()  # the previous copy back out of `hr` (possibly on another stream) has finished
         st = torch.cuda.current_stream(send.device)
         hs.copy_(send.reshape(-1), non_blocking=True)
         st.synchronize()
         dist.all_gather_into_tensor(hr, hs, group=group)
-        recv.reshape(-1).copy_(hr, non_blocking=True)
+        recv.view(-1).copy_(hr, non_blocking=True)
         back = torch.cuda.Event()
         back.record(st)
-        _HOST_STAGE[key] = (hs, hr, back)
+        if keep:
+            _HOST_STAGE[key] = (hs, hr, back)
+        else:
+            back.synchronize()   # (the one-off pinned pair is freed when this returns)
         return
     dist.all_gather_into_tensor(recv.view(-1), send.contiguous().view(-1), group=group)   # (flat on both sides: every backend takes that)
 
@@ -325,6 +337,11 @@ def gather_track_compact(compute_block, n_local, F_total, kn, pout_max, chunks=4
             rows_so_far += int(totals.sum())
     if on_gpu:
         main.wait_stream(side)
+        # the pieces were ALLOCATED under the side stream and are read on the main one from here on (the cat below, the
+        # caller): tell the allocator, or their blocks go back to the side stream's pool when they are freed and a later
+        # side-stream allocation may overwrite them under a main-stream reader (round-5 advice)
+        for t_ in pieces_x + pieces_s:
+            t_.record_stream(main)
     if bad_local:
         raise ValueError(f"gather_track_compact: a rank holds {n_claimed} frames but contiguous blocks of "
                          f"ceil({F_total} / {world}) = {per} frames are what is gathered (use shard_bounds)")
@@ -359,16 +376,24 @@ class ShardedTriangulator:
     on its GPU, piece by piece, and returns the gathered track: the all-gather of piece i (joints, person scores,
     counts and flags in one buffer, one collective) overlaps the kernel of piece i + 1."""
 
-    def __init__(self, K, R, t, params, pout_max=1, device=0, group=None, chunks="auto", reuse_buffers=False, compact=False):
+    def __init__(self, K, R, t, params, pout_max=1, device=0, group=None, chunks="auto", reuse_buffers=False, compact=False,
+                 zero_fill=None):
         """chunks: pieces per shard, or "auto" (auto_chunks: pieces of >= 32 768 frames, at most 8).
         reuse_buffers: keep the gathered tensors, the send / receive slots and the side stream between calls (no
         allocation in steady state); the track returned by one run() is then overwritten by the next.
         compact: gather the PERSONS, not the padded slots (gather_track_compact): per piece one all-gather of the counts
         (4 B per frame), then one of the persons packed by prefix sum -- the padded [Pout_max, kn, 4] block of a frame with
-        8 persons in 32 slots is four times what its persons take ("or gather compacted persons + counts")."""
+        8 persons in 32 slots is four times what its persons take ("or gather compacted persons + counts").
+        zero_fill: False = the kernels leave the slots behind count[f] unwritten (SNOWTRI_CALL_NO_ZERO_FILL).  Default: False for
+        the compact gather (it packs by the counts and never reads those slots), True for the padded one (the padding IS what
+        every rank receives: it must be the documented zeros)."""
         import numpy as np
         from .batch import BatchTriangulator
-        self.bt = BatchTriangulator(K, R, t, params, pout_max=pout_max, out_dtype=np.float32, device=device)
+        if zero_fill is None:
+            zero_fill = not compact
+        if not zero_fill and not compact:
+            raise ValueError("ShardedTriangulator: the padded gather hands every rank the unused slots: they must be zero-filled")
+        self.bt = BatchTriangulator(K, R, t, params, pout_max=pout_max, out_dtype=np.float32, device=device, zero_fill=zero_fill)
         self.group = group
         self.chunks = chunks
         self.device = device
@@ -552,7 +577,7 @@ def smooth_track_sharded(x_local, f=2, z=0.75, r=0, delta_time=1 / 30, group=Non
         n *= int(d)
     ctx = ctx or _lib.scratch_context(x_local.device.index)     # scratch and kernels on the GPU that holds the shard
     stream = ct.c_void_p(torch.cuda.current_stream(x_local.device).cuda_stream)
-    L = _lib.lib()
+    L = ctx.L
     fzrd = (float(f), float(z), float(r), float(delta_time))
 
     def local_fn(x, is_first, y, payload):
@@ -621,7 +646,7 @@ def blender_smooth_sharded(pts_local, val_local, fzr, delta_time=1 / 30, group=N
         first = lo == 0 and hi > lo
     ctx = ctx or _lib.scratch_context(pts_local.device.index)
     stream = ct.c_void_p(torch.cuda.current_stream(pts_local.device).cuda_stream)
-    L = _lib.lib()
+    L = ctx.L
     fzr = np.ascontiguousarray(fzr, dtype=np.float64).reshape(24, 3)
     dt = float(delta_time)
 

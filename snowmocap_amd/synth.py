@@ -154,3 +154,40 @@ def config_workload(cfg, F, seed=None, dtype=np.float32):
     kpts, n_persons = make_keypoints(rng, K, R, t, X, pixel_sigma=1.0,
                                      score_range=(3.5, 8.0), permute_persons=permute, dtype=dtype)
     return dict(rig=(K, R, t), kpts=kpts, n_persons=n_persons, params=params, X=X)
+
+
+def config_workload_device(cfg, F, seed, device, chunk=20000, dtype=None):
+    """The BASELINE.json workloads generated ON the device (torch: device memory and its Philox generator; the distributions of
+    config_workload / SURVEY.md 8d -- joints uniform in a 0.6 x 0.6 x 1.8 m box around each person's centre, exact projections +
+    N(0, 1 px), confidences U(3.5, 8), per-(frame, camera) person order permuted for the multi-person rigs).  For batches too
+    large to build on the host and upload: a frame block of the 1 000 000-frame configs[3] / the 100 000-frame configs[4] takes
+    milliseconds, and the SAME (cfg, F, seed, device type, chunk) gives the same bits in every process -- each rank of a sharded
+    run generates its own block from a per-block seed, a checker regenerates any block it wants to recompute.
+    Returns dict(rig=(K, R, t) NumPy, params, kpts [F, C, P, J, 3] float32 CUDA tensor, n_persons [F, C] int32 CUDA tensor)."""
+    import torch
+    base = config_workload(cfg, 1)
+    K, R, t = base["rig"]
+    C, P, J = K.shape[0], base["kpts"].shape[2], J_WHOLEBODY
+    dev = torch.device(device)
+    g = torch.Generator(device=dev)
+    g.manual_seed(int(seed))
+    f64 = torch.float64
+    Kt, Rt, tt = (torch.from_numpy(np.ascontiguousarray(a)).to(dev) for a in (K, R, t))
+    centres = torch.from_numpy(person_centres(P)).to(dev)
+    box = torch.tensor([0.6, 0.6, 1.8], dtype=f64, device=dev)
+    off = torch.tensor([0.5, 0.5, 0.0], dtype=f64, device=dev)
+    kpts = torch.empty((F, C, P, J, 3), dtype=dtype or torch.float32, device=dev)
+    for lo in range(0, F, chunk):
+        n = min(chunk, F - lo)
+        X = (torch.rand((n, P, J, 3), generator=g, dtype=f64, device=dev) - off) * box + centres[None, :, None, :]
+        for c in range(C):
+            pix = ((X - tt[c]) @ Rt[c]) @ Kt[c].T                   # K R^T (X - t)
+            uv = pix[..., :2] / pix[..., 2:3] + torch.randn((n, P, J, 2), generator=g, dtype=f64, device=dev)
+            sc = 3.5 + 4.5 * torch.rand((n, P, J, 1), generator=g, dtype=f64, device=dev)
+            rec = torch.cat([uv, sc], dim=-1)
+            if P > 1:                                               # a per-view detector lists its persons in its own order
+                perm = torch.argsort(torch.rand((n, P), generator=g, device=dev), dim=1)
+                rec = torch.gather(rec, 1, perm[:, :, None, None].expand(n, P, J, 3))
+            kpts[lo:lo + n, c] = rec.to(kpts.dtype)
+    n_persons = torch.full((F, C), P, dtype=torch.int32, device=dev)
+    return dict(rig=(K, R, t), params=base["params"], kpts=kpts, n_persons=n_persons)

@@ -23,8 +23,8 @@ _KEYS = ("hrnet_triangulate_points", "hrnet_triangulate_keypoint_scores", "hrnet
 
 def Skew_Ray_Solver(hm, hs, tm, ts):
     """Closest approach of rays tm + a*hm and ts + b*hs -> (skew distance, midpoint[3])."""
-    L = _lib.lib()
     ctx = _lib.scratch_context()
+    L = ctx.L
     arrs = [np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(1, 3)) for x in (hm, hs, tm, ts)]
     dist = np.empty(1)
     W = np.empty((1, 3))
@@ -37,8 +37,8 @@ def Skew_Ray_Solver(hm, hs, tm, ts):
 
 def skew_ray_solver_batch(hm, hs, tm, ts):
     """Additive batched form of Skew_Ray_Solver: [n,3] x4 -> dist[n], W[n,3], n_singular."""
-    L = _lib.lib()
     ctx = _lib.scratch_context()
+    L = ctx.L
     arrs = [np.ascontiguousarray(np.asarray(x, dtype=np.float64).reshape(-1, 3)) for x in (hm, hs, tm, ts)]
     n = arrs[0].shape[0]
     dist = np.empty(n)
@@ -56,8 +56,8 @@ def Human_Triangulation(camera_group, keypoint_score_threshold=0.5, average_scor
                         distance_threshold=0.05):
     """All camera-pair x person-pair candidate skeletons of the current frame, scored and filtered
     by their mean score; list order = the reference's loop order (triangulation.py:56-65)."""
-    L = _lib.lib()
     ctx = camera_group.native_context()
+    L = ctx.L
     kpts, n_persons = camera_group.pack_frame()
     C, Pmax, J, _ = kpts.shape
     Kc = int(L.snowtri_num_candidate_slots(C, Pmax))
@@ -136,7 +136,6 @@ def Human_Triangulation_Condense(result, condense_distance_tol=0.1, condense_per
     n = len(points)
     if n - 1 <= 0:                 # range(person_num - 1) is empty: nothing is ever emitted
         return out
-    L = _lib.lib()
     prm = _lib.make_params(condense_distance_tol=condense_distance_tol,
                            condense_person_num_tol=condense_person_num_tol,
                            condense_score_tol=condense_score_tol,
@@ -153,14 +152,14 @@ def Human_Triangulation_Condense(result, condense_distance_tol=0.1, condense_per
     resident = _Resident.match(points, scores)
     if resident is not None:        # the unmodified result of Human_Triangulation: its candidates are still on the device
         ctx, token, J = resident
-        rc = L.snowtri_condense_resident(ctx.handle, token, prm, pout, p_xyz, p_ks, p_ps, p_cnt, None)
+        rc = ctx.L.snowtri_condense_resident(ctx.handle, token, prm, pout, p_xyz, p_ks, p_ps, p_cnt, None)
         _Resident.used += rc != _lib.ERR_BAD_ARG
     if resident is None or rc == _lib.ERR_BAD_ARG:
         ctx = _lib.scratch_context()
         cxyz = np.ascontiguousarray(np.stack([np.asarray(p, dtype=np.float64) for p in points]))
         cks = np.ascontiguousarray(np.stack([np.asarray(s, dtype=np.float64) for s in scores]))
         J = cxyz.shape[1]
-        rc = L.snowtri_condense(ctx.handle, 1, n, J, _lib.ptr(cxyz), _lib.ptr(cks), None, prm, pout,
+        rc = ctx.L.snowtri_condense(ctx.handle, 1, n, J, _lib.ptr(cxyz), _lib.ptr(cks), None, prm, pout,
                                 p_xyz, p_ks, p_ps, p_cnt, None, _lib.HOST, None)
     if rc == _lib.ERR_BAD_INDEX:
         raise IndexError("index out of bounds (center_point_index / keypoint_num vs. joints per candidate)")
@@ -220,7 +219,7 @@ def smooth_track(track, f=2, z=0.75, r=0, delta_time=1 / 30):
     n = int(np.prod(x.shape[1:])) if x.ndim > 1 else 1
     y = np.empty_like(x)
     ctx = _lib.scratch_context()
-    _lib.check(_lib.lib().snowtri_smooth_track(ctx.handle, T, n, _lib.ptr(x), float(f), float(z), float(r),
+    _lib.check(ctx.L.snowtri_smooth_track(ctx.handle, T, n, _lib.ptr(x), float(f), float(z), float(r),
                                                float(delta_time), _lib.ptr(y), _lib.HOST, None),
                "snowtri_smooth_track")
     return y

@@ -78,6 +78,7 @@ int main(void) {
     EXPECT(snowtri_ctx_ray_matrices(NULL, buf), SNOWTRI_ERR_BAD_ARG);
     EXPECT(snowtri_ctx_synchronize(NULL), SNOWTRI_ERR_BAD_ARG);
     EXPECT(snowtri_fastmath_probe(NULL, 4, buf, buf, buf, buf), SNOWTRI_ERR_BAD_ARG);
+    EXPECT(snowtri_ctx_set_split(NULL, 1), SNOWTRI_ERR_BAD_ARG);
     EXPECT(snowtri_rays_from_pixels(NULL, 0, 4, buf, buf), SNOWTRI_ERR_BAD_ARG);
     EXPECT(snowtri_skew_ray_batch(NULL, 4, buf, buf, buf, buf, buf, buf, &nsing), SNOWTRI_ERR_BAD_ARG);
     EXPECT(snowtri_triangulate(NULL, 1, 1, 5, fbuf, SNOWTRI_F32, NULL, &prm, buf, buf, buf, bbuf, SNOWTRI_HOST, NULL),
@@ -86,6 +87,9 @@ int main(void) {
            SNOWTRI_ERR_BAD_ARG);
     EXPECT(snowtri_triangulate_condense(NULL, 1, 1, 5, fbuf, SNOWTRI_F32, NULL, &prm, SNOWTRI_PAIRWISE, 1, fbuf, fbuf,
                                         SNOWTRI_F32, ibuf, ubuf, SNOWTRI_HOST, NULL),
+           SNOWTRI_ERR_BAD_ARG);
+    EXPECT(snowtri_triangulate_condense_ex(NULL, 1, 1, 5, fbuf, SNOWTRI_F32, NULL, &prm, SNOWTRI_PAIRWISE, 1, fbuf, fbuf,
+                                           SNOWTRI_F32, ibuf, ubuf, SNOWTRI_HOST, NULL, SNOWTRI_CALL_NO_ZERO_FILL),
            SNOWTRI_ERR_BAD_ARG);
     EXPECT(snowtri_smooth_track(NULL, 4, 3, buf, 2.0, 0.75, 0.0, 1.0 / 30, buf, SNOWTRI_HOST, NULL), SNOWTRI_ERR_BAD_ARG);
     EXPECT(snowtri_smooth_shard_local(NULL, 4, 3, buf, 1, 2.0, 0.75, 0.0, 1.0 / 30, buf, buf, SNOWTRI_HOST, NULL),
@@ -180,6 +184,15 @@ int main(void) {
         /* device buffers: joint records must be 16-byte aligned, keypoints element-aligned (checked before any launch) */
         EXPECT(FUSED(1, 1, J, fbuf, SNOWTRI_F32, &prm, SNOWTRI_PAIRWISE, 1, (char *)fbuf + 4, SNOWTRI_F32, ibuf, SNOWTRI_DEVICE), SNOWTRI_ERR_BAD_ARG);
         EXPECT(FUSED(1, 1, J, (char *)fbuf + 2, SNOWTRI_F32, &prm, SNOWTRI_PAIRWISE, 1, fbuf, SNOWTRI_F32, ibuf, SNOWTRI_DEVICE), SNOWTRI_ERR_BAD_ARG);
+        EXPECT(snowtri_ctx_set_split(ctx, -1), SNOWTRI_ERR_BAD_ARG);
+        EXPECT(snowtri_ctx_set_split(ctx, 65), SNOWTRI_ERR_BAD_ARG);
+        EXPECT(snowtri_ctx_set_split(ctx, 1), SNOWTRI_OK);
+        EXPECT(snowtri_ctx_set_split(ctx, 0), SNOWTRI_OK);
+        /* call flags: an unknown bit is refused, not ignored */
+        EXPECT(snowtri_triangulate_condense_ex(ctx, 1, 1, J, fbuf, SNOWTRI_F32, NULL, &prm, SNOWTRI_PAIRWISE, 1, fbuf, fbuf, SNOWTRI_F32, ibuf, ubuf,
+                                               SNOWTRI_HOST, NULL, 2u), SNOWTRI_ERR_BAD_ARG);
+        EXPECT(snowtri_triangulate_condense_ex(ctx, 0, 1, J, NULL, SNOWTRI_F32, NULL, &prm, SNOWTRI_PAIRWISE, 1, NULL, NULL, SNOWTRI_F32, NULL, NULL,
+                                               SNOWTRI_HOST, NULL, SNOWTRI_CALL_NO_ZERO_FILL), SNOWTRI_OK);
         prm.center_point_index = J;   /* reference: IndexError */
         EXPECT(FUSED(1, 1, J, fbuf, SNOWTRI_F32, &prm, SNOWTRI_PAIRWISE, 1, fbuf, SNOWTRI_F32, ibuf, SNOWTRI_HOST), SNOWTRI_ERR_BAD_INDEX);
         prm = good_params(J);

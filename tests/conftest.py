@@ -21,6 +21,55 @@ def pytest_configure(config):
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "snowmocap_amd", "csrc"), "-s"])
 
 
+KNOB_NAMES = ("SNOWTRI_GENERAL_MODE", "SNOWTRI_LEAN_MODE", "SNOWTRI_LEAN_COOP", "SNOWTRI_SUMLESS_MODE", "SNOWTRI_HANDOVER_MODE",
+              "SNOWTRI_HANDOVER_SEG_FRAMES", "SNOWTRI_SPLIT_SEGMENTS", "SNOWTRI_SUMS_THREADS", "SNOWTRI_SUMS_LDS_KB",
+              "SNOWTRI_LEAN_TILES_PER_WAVE", "SNOWTRI_DEBUG")
+
+
+class Knobs:
+    """Route-forcing knobs exist only in the TEST build of the library (snowmocap_amd/libsnowtri_dbg.so: -DSNOWTRI_TEST_KNOBS,
+    and device-side bounds checks with it); the production libsnowtri.so reads no environment.  `knobs.set(name, value)` binds
+    the package to the test build (snowmocap_amd._lib.use_library) and sets the variable a context reads at creation; when the
+    last knob is cleared -- or the test ends -- the production library is bound again.  So a test's DEFAULT-route runs go
+    through the product, and only the runs that force a route go through the test build."""
+
+    def __init__(self, monkeypatch):
+        self.mp = monkeypatch
+        self.prev = None
+        self.active = set()
+
+    def set(self, name, value):
+        from snowmocap_amd import _lib
+        assert name in KNOB_NAMES, name
+        if self.prev is None:
+            assert os.path.exists(_lib.TEST_LIB_PATH), "build the test library: make -C snowmocap_amd/csrc debug"
+            self.prev = _lib.use_library(_lib.TEST_LIB_PATH)
+            assert "SNOWTRI_TEST_KNOBS" in _lib.build_info()["variants"]
+        self.mp.setenv(name, str(value))
+        self.active.add(name)
+
+    def clear(self, *names):
+        for n in (names or tuple(self.active)):
+            self.mp.delenv(n, raising=False)
+            self.active.discard(n)
+        if not self.active:
+            self.restore()
+
+    def restore(self):
+        from snowmocap_amd import _lib
+        if self.prev is not None:
+            _lib.use_library(self.prev)
+            self.prev = None
+
+
+@pytest.fixture
+def knobs(monkeypatch):
+    k = Knobs(monkeypatch)
+    yield k
+    k.clear()
+    k.restore()
+
+
 def load_scenarios(name):
     """tests/golden/<name>.npz -> {scenario: {field: array}} (schema: tests/golden/make_golden.py)."""
     z = np.load(os.path.join(GOLDEN, name), allow_pickle=False)

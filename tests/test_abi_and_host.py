@@ -245,10 +245,34 @@ def test_shipped_library_carries_no_development_switch():
     if os.path.exists(dbg):
         h = ct.CDLL(dbg)
         h.snowtri_build_info.restype = ct.c_char_p
-        assert h.snowtri_build_info().decode().endswith("variants=SNOWTRI_DEBUG_BOUNDS")
+        assert h.snowtri_build_info().decode().endswith("variants=SNOWTRI_DEBUG_BOUNDS,SNOWTRI_TEST_KNOBS")
     # no wrong-output switch is left in the kernel sources, and trace stamps need the experiments gate
     src = "".join(open(os.path.join(ROOT, "snowmocap_amd", "csrc", f)).read() for f in os.listdir(os.path.join(ROOT, "snowmocap_amd", "csrc"))
                   if f.endswith((".hpp", ".hip")))
     for gone in ("_NOSOLVE", "_NOFILL", "K1_REPEAT", "LEAN_NOLOOP", "LEAN_NOEPI", "STOP_AFTER_P", "SNOWTRI_MEMTEST", "SNOWTRI_COMPUTETEST"):
         assert ("#ifdef SNOWTRI" + gone not in src) and ("defined(SNOWTRI_" + gone.lstrip("_") not in src) and (gone + "  //" not in src), gone
     assert "!defined(SNOWTRI_DEV_EXPERIMENTS)" in src and "#error" in src
+
+
+def test_production_library_reads_no_environment():
+    """Round-5 review, item 7: eleven environment knobs selected routes in the production library.  They now exist only under
+    -DSNOWTRI_TEST_KNOBS (libsnowtri_dbg.so, which the tests that force a route bind through conftest.Knobs): libsnowtri.so does
+    not even import getenv, the test build does, and the experiments that were "measured no faster" are gone from the sources."""
+    import subprocess
+    def imports(path):
+        return subprocess.run(["nm", "-D", "--undefined-only", path], capture_output=True, text=True, check=True).stdout
+    prod = os.path.join(ROOT, "snowmocap_amd", "libsnowtri.so")
+    assert "getenv" not in imports(prod)
+    dbg = os.path.join(ROOT, "snowmocap_amd", "libsnowtri_dbg.so")
+    if os.path.exists(dbg):
+        assert "getenv" in imports(dbg)
+    csrc = os.path.join(ROOT, "snowmocap_amd", "csrc")
+    src = "".join(open(os.path.join(csrc, f)).read() for f in os.listdir(csrc) if f.endswith((".hpp", ".hip")))
+    assert src.count("getenv(") == 2 and "#ifdef SNOWTRI_TEST_KNOBS" in src       # the knob reader and the split switch, both fenced
+    assert "k_candidate_sums_rays" not in src and "SNOWTRI_SUMS_RAYS" not in src
+    assert not os.path.exists(os.path.join(csrc, "snowtri_sums_rays.hpp"))
+    # the knob names the header documents are the ones the test build reads, and conftest.Knobs knows them all
+    from conftest import KNOB_NAMES
+    hdr = open(os.path.join(ROOT, "include", "snowtri.h")).read()
+    for name in KNOB_NAMES:
+        assert name in hdr and f'"{name}"' in src, name

@@ -56,3 +56,39 @@ def test_bench_single_rank_dry_run_needs_no_launcher():
     assert p.returncode == 0, p.stderr[-2000:]
     d = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
     assert d["rccl_ranks"] == 1
+
+
+def test_summary_is_the_last_key_and_small():
+    """Round-5 review, item 3: the driver keeps the last 8 KB of bench.py's stdout; the `summary` object -- every BASELINE
+    config that fits a GPU, the DLT method, per-frame API, CPU baseline -- is the LAST key of the line and stays under 3 KB.
+    Driven here with a stand-in line of the real shapes (no GPU)."""
+    sys.path.insert(0, ROOT)
+    import bench
+    multi = lambda w, **kw: dict(dict(workload=w, frames=10000, kernel_ms=1.0, frames_per_s=1e7, roofline={"frac": 0.68}, mean_persons_per_frame=5.08,
+                                      two_streams={"frames_per_s": 1.05e7}, method="pairwise", zero_fill=True, pout_max=16,
+                                      output_bytes_written_per_frame=34112.0), **kw)
+    single = lambda w, **kw: dict(dict(workload=w, kernel="k_fused_single<4,1,float,float>", kernel_ms=0.03, joints_per_s=4e10, roofline={"frac": 0.3},
+                                       hbm={"frac_of_8TBs": 0.33}, out_dtype="float32", method="pairwise"), **kw)
+    line = {"metric": "joint-triangulations/sec", "value": 6.3e10, "ms_per_step": 0.0211, "n_gpus": 1, "dtype": "f64",
+            "roofline": {"kernel_ms_mean": 0.0252, "frac": 0.42, "frac_of_measured_copy": 0.61, "traffic": 8.8e7, "algorithmic_bytes_per_launch": 8.512e7},
+            "large_batch": {"frac": 0.52}, "cpu_baseline": {"value": 1.7e8, "cores": 16, "gpu_vs_oracle_max_abs_m": 6e-8},
+            "per_frame_api": {"api_sequence_us_median": 78.0, "fused_host_call_us_median": 31.0, "what": "..."},
+            "extra_workloads": [
+                multi("BASELINE configs[2]: 8 cameras x 4 persons x 133 joints x 10 000 frames"),
+                multi("BASELINE configs[4] per-GPU share: 16 cameras x 8 persons x 133 joints x 12 500 frames"),
+                multi("BASELINE configs[2] with float64 outputs: 8 cameras x 4 persons"),
+                multi("BASELINE configs[2] with SNOWTRI_CALL_NO_ZERO_FILL: 8 cameras", zero_fill=False, output_bytes_written_per_frame=10830.0),
+                multi("DLT (method = SNOWTRI_DLT) on BASELINE configs[2]: 8 cameras x 4 persons", method="dlt"),
+                single("4 cameras x 1 person x 133 joints x 10000 frames, the floor rig", out_dtype="float64"),
+                single("6 cameras x 1 person x 133 joints"), single("8 cameras x 1 person x 133 joints"),
+                single("DLT (method = SNOWTRI_DLT, NOT the reference's algorithm): 4 cameras x 1 person", method="dlt"),
+                single("DLT (method = SNOWTRI_DLT, NOT the reference's algorithm): 8 cameras x 1 person", method="dlt")]}
+    s = bench.summary_of(line)
+    assert len(json.dumps(s)) < 3000, len(json.dumps(s))
+    for key in ("configs1_4x1_10000_frames", "configs2_8x4_10000_frames_f32", "configs2_8x4_f64_out", "configs2_8x4_no_zero_fill",
+                "configs4_share_16x8_12500_frames", "dlt_4x1", "dlt_8x1", "dlt_8x4_with_association", "single_4x1_f64_out", "single_6x1",
+                "single_8x1", "per_frame_api_us", "cpu_baseline"):
+        assert s[key] is not None, key
+    assert s["configs2_8x4_no_zero_fill"]["output_MB_written_per_call"] < s["configs2_8x4_no_zero_fill"]["output_MB_written_per_call_default"]
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert src.index('line["summary"] = summary_of(line)') > src.index('"extra_workloads": extra,')      # appended behind everything else

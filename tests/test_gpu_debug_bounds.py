@@ -24,6 +24,7 @@ from snowmocap_amd import synth, _lib
 from snowmocap_amd.batch import BatchTriangulator
 from oracle import oracle as orc
 assert _lib.LIB_PATH.endswith("libsnowtri_dbg.so")
+assert set(_lib.build_info()["variants"]) == {"SNOWTRI_DEBUG_BOUNDS", "SNOWTRI_TEST_KNOBS"}
 # the mechanism itself: a kernel in which three lanes violate a check is reported as 3 faults with its code, and cleared
 c0 = _lib.Context(device=0)
 assert c0.debug_faults()[0] == 0
@@ -79,8 +80,7 @@ wl = synth.config_workload(5, 3)
 K, R, t = wl["rig"]
 run(K, R, t, wl["params"], wl["kpts"], wl["n_persons"], 32)
 # round 5: one detection per camera on 6-8 cameras (the lean kernels on the rolled item, float32 and float64 records, small and
-# large launches), the streaming route without its candidate pass (keypoint_num < J, two slots, 12 cameras), and the candidate
-# pass with one lane per ray (SNOWTRI_SUMS_RAYS=1: 8 x 4, 16 x 2, 4 x 8, ragged frames included)
+# large launches), the streaming route without its candidate pass (keypoint_num < J, two slots, 12 cameras)
 import os
 for C in (6, 8):
     K, R, t = synth.ring_rig(C)
@@ -104,18 +104,8 @@ for C, kn, pout in ((7, 30, 1), (8, 133, 2), (12, 133, 1)):
     prm = dict(synth.default_thresholds(), condense_distance_tol=0.5, keypoint_num=kn, center_point_index=0)
     run(K, R, t, prm, kp, npers, pout)
     run(K, R, t, prm, kp, npers, pout, out_dtype=np.float64, check=False)
-os.environ["SNOWTRI_SUMS_RAYS"] = "1"
-for C, P, J, F in ((8, 4, 133, 30), (16, 2, 40, 6), (4, 8, 57, 6)):
-    K, R, t = synth.ring_rig(C, radius=5.0)
-    X = synth.make_people(rng, F, P, J=J)
-    kp, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=0.7, score_range=(2.0, 9.0), permute_persons=True, dtype=np.float32)
-    npers = npers.copy()
-    npers[1, C - 1] = P - 1
-    names = run(K, R, t, dict(PRM, keypoint_num=J), kp, npers, P + 2)
-    assert "k_candidate_sums_rays" in names, names
-os.environ.pop("SNOWTRI_SUMS_RAYS")
-# the candidate pass with one wave per workgroup (one chunk buffer), and its 1 024-thread shape on a small rig (one chunk, no second buffer)
-for knobs in ({"SNOWTRI_SUMS_THREADS": "64"}, {"SNOWTRI_SUMS_THREADS": "1024", "SNOWTRI_SUMS_LDS_KB": "160"}):
+# the candidate pass in its 512-thread shape and in its 1 024-thread shape on a small rig (one chunk, no second buffer)
+for knobs in ({"SNOWTRI_SUMS_THREADS": "512"}, {"SNOWTRI_SUMS_THREADS": "1024", "SNOWTRI_SUMS_LDS_KB": "160"}):
     os.environ.update(knobs)
     for C, P, J, F in ((8, 4, 133, 20), (4, 8, 57, 6), (6, 3, 33, 6)):
         K, R, t = synth.ring_rig(C, radius=5.0)

@@ -30,17 +30,20 @@ def api():
     return sm
 
 
-def _run(api, K, R, t, prm, kp, npers, pout, monkeypatch, handover=True, mode=None, out_dtype=np.float32):
+def _run(api, K, R, t, prm, kp, npers, pout, knobs, handover=True, mode=None, out_dtype=np.float32):
     """mode 1 (default): the streaming association (k_candidate_sums -> k_associate -> cluster kernels, <= 16 cameras);
     mode 2: descriptors written by k_frame_recompute itself (<= 8 cameras); mode 0: everything inside k_frame_recompute."""
-    monkeypatch.setenv("SNOWTRI_HANDOVER_MODE", str(mode) if mode is not None else ("1" if handover else "0"))
+    m = int(mode) if mode is not None else (1 if handover else 0)
+    if m != 1:      # (a forced route: the test build of the library, conftest.Knobs; mode 1 is the product's default)
+        knobs.set("SNOWTRI_HANDOVER_MODE", m)
     bt = api.BatchTriangulator(K, R, t, prm, pout_max=pout, out_dtype=out_dtype)
     out = bt.run_host(kp, npers)      # (overflow / singular come back as out["status"], not as exceptions)
     out["handed"] = bt.ctx.last_handover_persons()
     out["kernels"] = bt.ctx.last_kernel_names()
     out["stream_counts"] = bt.ctx.last_stream_counts()
     bt.close()
-    monkeypatch.delenv("SNOWTRI_HANDOVER_MODE")
+    if m != 1:
+        knobs.clear("SNOWTRI_HANDOVER_MODE")
     return out
 
 
@@ -70,7 +73,7 @@ def _same(a, b, msg, xyz_tol=XYZ_F32):
 
 @pytest.mark.parametrize("C,P,in_dtype", [(8, 4, np.float32), (4, 3, np.float64), (2, 2, np.float32), (3, 4, np.float32),
                                           (5, 2, np.float32), (6, 3, np.float64), (7, 2, np.float32), (8, 2, np.float64)])
-def test_complete_clusters_are_handed_over_and_match_the_oracle(api, C, P, in_dtype, monkeypatch):
+def test_complete_clusters_are_handed_over_and_match_the_oracle(api, C, P, in_dtype, knobs):
     from snowmocap_amd import synth
     from oracle import oracle as orc
     rng = np.random.default_rng(100 * C + P)
@@ -81,15 +84,15 @@ def test_complete_clusters_are_handed_over_and_match_the_oracle(api, C, P, in_dt
     prm = dict(PRM, keypoint_num=J, condense_person_num_tol=1 if C == 2 else 2)
     ref = orc.triangulate_condense_batch(K, R, t, kp, npers, orc.make_params(**prm), 64)
     pout = P + 1
-    out = _run(api, K, R, t, prm, kp, npers, pout, monkeypatch)
-    off = _run(api, K, R, t, prm, kp, npers, pout, monkeypatch, handover=False)
+    out = _run(api, K, R, t, prm, kp, npers, pout, knobs)
+    off = _run(api, K, R, t, prm, kp, npers, pout, knobs, handover=False)
     msg = f"C={C} P={P}"
     _check(out, ref, pout, J, msg)
     _check(off, ref, pout, J, msg + " (hand-over off)")
     _same(out, off, msg)
     assert off["handed"] == (-1, -1)
     # the second hand-over route (descriptors written by k_frame_recompute): same persons handed over, same results
-    in_kernel = _run(api, K, R, t, prm, kp, npers, pout, monkeypatch, mode=2)
+    in_kernel = _run(api, K, R, t, prm, kp, npers, pout, knobs, mode=2)
     _check(in_kernel, ref, pout, J, msg + " (hand-over from k_frame_recompute)")
     _same(in_kernel, off, msg + " (hand-over from k_frame_recompute)")
     assert sum(in_kernel["handed"]) == sum(out["handed"]), (in_kernel["handed"], out["handed"])
@@ -101,7 +104,7 @@ def test_complete_clusters_are_handed_over_and_match_the_oracle(api, C, P, in_dt
 
 @pytest.mark.parametrize("C,P,J,in_dtype", [(9, 3, 133, np.float32), (12, 2, 133, np.float64), (16, 3, 133, np.float32),
                                             (16, 8, 133, np.float32), (13, 2, 40, np.float32), (10, 4, 20, np.float32)])
-def test_wide_rigs_hand_their_clusters_to_the_lds_resident_kernel(api, C, P, J, in_dtype, monkeypatch):
+def test_wide_rigs_hand_their_clusters_to_the_lds_resident_kernel(api, C, P, J, in_dtype, knobs):
     """9-16 cameras (BASELINE configs[4] is 16 x 8): the streaming association hands complete-graph clusters to
     k_cluster_fuse_wide (rays in LDS, four lanes per (person, joint)) and every other cluster to k_cluster_members.
     Against the oracle, against the same launch with phase 3 inside k_frame_recompute, with the routes read back.
@@ -119,8 +122,8 @@ def test_wide_rigs_hand_their_clusters_to_the_lds_resident_kernel(api, C, P, J, 
     prm = dict(PRM, keypoint_num=J, condense_person_num_tol=10)
     ref = orc.triangulate_condense_batch(K, R, t, kp, npers, orc.make_params(**prm), 64)
     pout = P + 2
-    out = _run(api, K, R, t, prm, kp, npers, pout, monkeypatch)
-    off = _run(api, K, R, t, prm, kp, npers, pout, monkeypatch, handover=False)
+    out = _run(api, K, R, t, prm, kp, npers, pout, knobs)
+    off = _run(api, K, R, t, prm, kp, npers, pout, knobs, handover=False)
     msg = f"C={C} P={P} J={J}"
     _check(out, ref, pout, J, msg)
     _check(off, ref, pout, J, msg + " (hand-over off)")
@@ -132,7 +135,7 @@ def test_wide_rigs_hand_their_clusters_to_the_lds_resident_kernel(api, C, P, J, 
     assert n_complete >= P and n_other >= 2, out["handed"]
 
 
-def test_random_wide_rigs_against_oracle_and_phase3(api, monkeypatch):
+def test_random_wide_rigs_against_oracle_and_phase3(api, knobs):
     """Randomised sweep over 9..16 cameras: 1..3 detections per camera with ragged lists, thresholds that switch the
     filters on and off, float32 / float64 keypoints, Pout_max below and above the person count."""
     from snowmocap_amd import synth
@@ -160,8 +163,8 @@ def test_random_wide_rigs_against_oracle_and_phase3(api, monkeypatch):
                    center_point_index=int(rng.integers(0, J)), keypoint_num=J)
         pout = int(rng.choice([1, 4, 16]))
         ref = orc.triangulate_condense_batch(K, R, t, kp, npers, orc.make_params(**prm), 64)
-        out = _run(api, K, R, t, prm, kp, npers, pout, monkeypatch)
-        off = _run(api, K, R, t, prm, kp, npers, pout, monkeypatch, handover=False)
+        out = _run(api, K, R, t, prm, kp, npers, pout, knobs)
+        off = _run(api, K, R, t, prm, kp, npers, pout, knobs, handover=False)
         msg = f"trial {trial}: C={C} P={P} J={J} F={F} {prm} pout={pout} n={npers.tolist()}"
         # float32 outputs take 1/dist from the raw v_rsq_f64 (5e-8 relative): the fused point sees it through the weights
         # s_q / sum s, i.e. times the SPREAD of the member points.  With the distance gate practically off (1 m) a ring of
@@ -176,7 +179,7 @@ def test_random_wide_rigs_against_oracle_and_phase3(api, monkeypatch):
     assert routes[0] > 0 and routes[1] > 5, routes
 
 
-def test_mixed_launch_incomplete_and_ragged_frames_stay_in_phase3(api, monkeypatch):
+def test_mixed_launch_incomplete_and_ragged_frames_stay_in_phase3(api, knobs):
     """One launch, three kinds of frames: complete clusters (k_cluster_fuse), a person whose detection in one camera is
     below the keypoint threshold everywhere or missing from the list (its cluster has fewer members: a member-list descriptor),
     empty frames."""
@@ -202,8 +205,8 @@ def test_mixed_launch_incomplete_and_ragged_frames_stay_in_phase3(api, monkeypat
             kinds[f] = "empty"
     prm = dict(PRM, keypoint_num=J)
     ref = orc.triangulate_condense_batch(K, R, t, kp, npers, orc.make_params(**prm), 64)
-    out = _run(api, K, R, t, prm, kp, npers, P, monkeypatch)
-    off = _run(api, K, R, t, prm, kp, npers, P, monkeypatch, handover=False)
+    out = _run(api, K, R, t, prm, kp, npers, P, knobs)
+    off = _run(api, K, R, t, prm, kp, npers, P, knobs, handover=False)
     _check(out, ref, P, J, "mixed launch")
     _same(out, off, "mixed launch")
     full = int(np.minimum(ref["count"], P).sum())
@@ -214,7 +217,7 @@ def test_mixed_launch_incomplete_and_ragged_frames_stay_in_phase3(api, monkeypat
 
 
 @pytest.mark.parametrize("score_tol,pout", [(0.0, 2), (1.2, 4), (1.2, 1), (50.0, 4)])
-def test_mean_score_filter_and_overflow_with_handover(api, score_tol, pout, monkeypatch):
+def test_mean_score_filter_and_overflow_with_handover(api, score_tol, pout, knobs):
     """condense_score_tol in the middle of the persons' mean scores: some clusters are dropped and the later ones move up
     (the slots are decided by the association kernel from the candidate means); pout < persons: overflow flag, only
     the first pout persons written."""
@@ -236,8 +239,8 @@ def test_mean_score_filter_and_overflow_with_handover(api, score_tol, pout, monk
     if score_tol == 1.2:    # the filter really fires, and not for the last persons only: later ones move up
         assert 0.3 * len(ps) < ref["count"].sum() < 0.7 * len(ps), (ref["count"], ref0["count"])
         assert any((ref0["pscore"][f, 0] < tol) and ref["count"][f] > 0 for f in range(F))
-    out = _run(api, K, R, t, prm, kp, npers, pout, monkeypatch)
-    off = _run(api, K, R, t, prm, kp, npers, pout, monkeypatch, handover=False)
+    out = _run(api, K, R, t, prm, kp, npers, pout, knobs)
+    off = _run(api, K, R, t, prm, kp, npers, pout, knobs, handover=False)
     msg = f"score_tol={score_tol} pout={pout}"
     _check(out, ref, pout, J, msg)
     _same(out, off, msg)
@@ -247,7 +250,7 @@ def test_mean_score_filter_and_overflow_with_handover(api, score_tol, pout, monk
     assert total - (P if score_tol == 1.2 else 0) <= sum(out["handed"]) <= total, (out["handed"], ref["count"])
 
 
-def test_exact_intersections_and_gated_confidences_in_handed_over_clusters(api, monkeypatch):
+def test_exact_intersections_and_gated_confidences_in_handed_over_clusters(api, knobs):
     """dist == 0 gives an inf pair score (triangulation.py:72); a confidence below the threshold ASSIGNS 0 to that pair
     (:73-74).  The fast item multiplies (0 * inf = NaN) and must re-do such joints member by member.  Exactly
     representable geometry (K = R = I) so that rays really intersect."""
@@ -274,8 +277,8 @@ def test_exact_intersections_and_gated_confidences_in_handed_over_clusters(api, 
     prm = dict(keypoint_score_threshold=3.0, average_score_threshold=0.0, distance_threshold=0.05, condense_distance_tol=0.5,
                condense_person_num_tol=0, condense_score_tol=0.0, center_point_index=4, keypoint_num=J)
     ref = orc.triangulate_condense_batch(K, R, t, kp, npers, orc.make_params(**prm), 64)
-    out = _run(api, K, R, t, prm, kp, npers, 4, monkeypatch)
-    off = _run(api, K, R, t, prm, kp, npers, 4, monkeypatch, handover=False)
+    out = _run(api, K, R, t, prm, kp, npers, 4, knobs)
+    off = _run(api, K, R, t, prm, kp, npers, 4, knobs, handover=False)
     np.testing.assert_array_equal(out["count"], ref["count"])
     np.testing.assert_array_equal(off["count"], ref["count"])
     for name, o in (("hand-over", out), ("phase 3", off)):
@@ -288,7 +291,7 @@ def test_exact_intersections_and_gated_confidences_in_handed_over_clusters(api, 
             assert np.abs(got[fin] - want[fin]).max() < 1e-5 * max(1.0, np.abs(want[fin]).max())
 
 
-def test_handover_is_deterministic_and_independent_of_the_batch_split(api, monkeypatch):
+def test_handover_is_deterministic_and_independent_of_the_batch_split(api, knobs):
     """The descriptor list is filled in whatever order the workgroups finish their frames; the outputs must not
     depend on it, nor on how the frames are split over launches."""
     from snowmocap_amd import synth
@@ -299,19 +302,19 @@ def test_handover_is_deterministic_and_independent_of_the_batch_split(api, monke
     kp, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=0.7, score_range=(3.5, 9.0), permute_persons=True, dtype=np.float32)
     kp = np.tile(kp, (F // 30, 1, 1, 1, 1)); npers = np.tile(npers, (F // 30, 1))
     prm = dict(PRM, keypoint_num=J)
-    a = _run(api, K, R, t, prm, kp, npers, P, monkeypatch)
-    b = _run(api, K, R, t, prm, kp, npers, P, monkeypatch)
+    a = _run(api, K, R, t, prm, kp, npers, P, knobs)
+    b = _run(api, K, R, t, prm, kp, npers, P, knobs)
     assert a["handed"] == b["handed"] and sum(a["handed"]) == int(np.minimum(a["count"], P).sum())
     for key in ("xyzs", "pscore", "count"):
         assert np.array_equal(a[key], b[key]), key
     # the frames repeat with period 30: so must the outputs, wherever a frame sits in the launch
     assert np.array_equal(a["xyzs"][:30], a["xyzs"][270:])
-    parts = [_run(api, K, R, t, prm, kp[s:e], npers[s:e], P, monkeypatch) for s, e in ((0, 7), (7, 130), (130, 300))]
+    parts = [_run(api, K, R, t, prm, kp[s:e], npers[s:e], P, knobs) for s, e in ((0, 7), (7, 130), (130, 300))]
     assert np.array_equal(np.concatenate([p["xyzs"] for p in parts]), a["xyzs"])
     assert np.array_equal(np.concatenate([p["pscore"] for p in parts]), a["pscore"])
 
 
-def test_random_rigs_with_handover_against_oracle_and_phase3(api, monkeypatch):
+def test_random_rigs_with_handover_against_oracle_and_phase3(api, knobs):
     """Randomised sweep of what the hand-over can meet: 2..8 cameras, 2..4 detections per camera with ragged (also empty)
     person lists, 5..40 joints, thresholds that switch every filter on and off, ghost candidates that form clusters of
     their own, persons merged by a wide condense_distance_tol, Pout_max below and above the person count -- float32
@@ -342,8 +345,8 @@ def test_random_rigs_with_handover_against_oracle_and_phase3(api, monkeypatch):
                    center_point_index=int(rng.integers(0, J)), keypoint_num=J)
         pout = int(rng.choice([1, 4, 16]))
         ref = orc.triangulate_condense_batch(K, R, t, kp, npers, orc.make_params(**prm), 64)
-        out = _run(api, K, R, t, prm, kp, npers, pout, monkeypatch)
-        off = _run(api, K, R, t, prm, kp, npers, pout, monkeypatch, handover=False)
+        out = _run(api, K, R, t, prm, kp, npers, pout, knobs)
+        off = _run(api, K, R, t, prm, kp, npers, pout, knobs, handover=False)
         msg = f"trial {trial}: C={C} P={P} J={J} F={F} {prm} pout={pout} n={npers.tolist()}"
         _check(out, ref, pout, J, msg)
         _same(out, off, msg)
@@ -354,7 +357,7 @@ def test_random_rigs_with_handover_against_oracle_and_phase3(api, monkeypatch):
     assert routes[0] > 20 and routes[1] > 20 and routes.sum() > 0.5 * checked, (routes, checked)
 
 
-def test_long_batches_are_cut_into_segments(api, monkeypatch):
+def test_long_batches_are_cut_into_segments(api, knobs):
     """The descriptor and member lists are sized per segment of a long batch (<= 2 M persons, 32 M member words); the
     test knob SNOWTRI_HANDOVER_SEG_FRAMES makes the segments 7 frames short: same outputs, bit for bit."""
     from snowmocap_amd import synth
@@ -366,10 +369,10 @@ def test_long_batches_are_cut_into_segments(api, monkeypatch):
     npers = npers.copy()
     npers[::6, 1] = P - 1
     prm = dict(PRM, keypoint_num=J)
-    whole = _run(api, K, R, t, prm, kp, npers, P, monkeypatch)
-    monkeypatch.setenv("SNOWTRI_HANDOVER_SEG_FRAMES", "7")
-    cut = _run(api, K, R, t, prm, kp, npers, P, monkeypatch)
-    monkeypatch.delenv("SNOWTRI_HANDOVER_SEG_FRAMES")
+    whole = _run(api, K, R, t, prm, kp, npers, P, knobs)
+    knobs.set("SNOWTRI_HANDOVER_SEG_FRAMES", "7")
+    cut = _run(api, K, R, t, prm, kp, npers, P, knobs)
+    knobs.clear("SNOWTRI_HANDOVER_SEG_FRAMES")
     for key in ("xyzs", "pscore", "count", "flags"):
         assert np.array_equal(whole[key], cut[key]), key
     assert sum(whole["handed"]) == int(np.minimum(whole["count"], P).sum())
@@ -422,7 +425,7 @@ def test_sharded_multi_person_batch_with_handover_single_rank_group(api, chunks)
 
 
 @pytest.mark.parametrize("C,P,armed", [(4, 16, True), (8, 16, True), (3, 17, False)])
-def test_person_index_limits_of_the_descriptor(api, C, P, armed, monkeypatch):
+def test_person_index_limits_of_the_descriptor(api, C, P, armed, knobs):
     """The descriptor packs one 4-bit person index per camera: 16 detections per camera is the last shape that is handed
     over (person 15 must survive the packing), 17 keeps phase 3 in the association kernel."""
     from snowmocap_amd import synth
@@ -435,8 +438,8 @@ def test_person_index_limits_of_the_descriptor(api, C, P, armed, monkeypatch):
     kp, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=0.3, score_range=(3.5, 9.0), permute_persons=True, dtype=np.float32)
     prm = dict(PRM, keypoint_num=J, condense_person_num_tol=1)
     ref = orc.triangulate_condense_batch(K, R, t, kp, npers, orc.make_params(**prm), 128)
-    out = _run(api, K, R, t, prm, kp, npers, 128, monkeypatch)
-    off = _run(api, K, R, t, prm, kp, npers, 128, monkeypatch, handover=False)
+    out = _run(api, K, R, t, prm, kp, npers, 128, knobs)
+    off = _run(api, K, R, t, prm, kp, npers, 128, knobs, handover=False)
     msg = f"C={C} P={P}"
     _check(out, ref, 128, J, msg)
     _same(out, off, msg)
@@ -446,7 +449,7 @@ def test_person_index_limits_of_the_descriptor(api, C, P, armed, monkeypatch):
         assert out["handed"] == (-1, -1)
 
 
-def test_frames_whose_member_lists_do_not_fit_the_staging_stay_in_phase3(api, monkeypatch):
+def test_frames_whose_member_lists_do_not_fit_the_staging_stay_in_phase3(api, knobs):
     """Every filter off and a huge condense_distance_tol: all 7 168 candidates of an 8 x 16 frame are kept and fall into
     one cluster.  Its member list does not fit the LDS staging of the hand-over: the frame keeps phase 3 (nothing handed
     over although the hand-over is armed), results as the oracle's."""
@@ -461,27 +464,20 @@ def test_frames_whose_member_lists_do_not_fit_the_staging_stay_in_phase3(api, mo
                condense_person_num_tol=0, condense_score_tol=0.0, center_point_index=0, keypoint_num=J)
     ref = orc.triangulate_condense_batch(K, R, t, kp, npers, orc.make_params(**prm), 4)
     assert (ref["count"] == 1).all()
-    out = _run(api, K, R, t, prm, kp, npers, 4, monkeypatch)
+    out = _run(api, K, R, t, prm, kp, npers, 4, knobs)
     _check(out, ref, 4, J, "one cluster of 7 168 members")
     assert out["handed"] == (0, 0), out["handed"]
 
 
-@pytest.mark.parametrize("C,P,J,knobs", [
+@pytest.mark.parametrize("C,P,J,forced", [
     (16, 8, 133, {"SNOWTRI_SUMS_THREADS": "512"}),                                   # 960 tiles on 8 waves: two rounds through csum per chunk
     (16, 8, 133, {"SNOWTRI_SUMS_THREADS": "256", "SNOWTRI_SUMS_LDS_KB": "64"}),      # four rounds, three joints per buffer
     (8, 4, 133, {"SNOWTRI_SUMS_LDS_KB": "24"}),                                      # one wave of tiles, four joint sub-ranges, 8-joint chunks
     (8, 4, 40, {"SNOWTRI_SUMS_THREADS": "1024", "SNOWTRI_SUMS_LDS_KB": "160"}),      # the whole frame in one chunk: no second buffer used
     (6, 3, 33, {"SNOWTRI_SUMS_THREADS": "512"}),                                     # odd person count: one candidate per lane
-    (8, 4, 133, {"SNOWTRI_SUMS_THREADS": "64"}),                                     # one wave per workgroup: no barrier, one chunk buffer, 8-joint chunks
-    (4, 8, 57, {"SNOWTRI_SUMS_THREADS": "64"}),                                      # ... 48 tiles of 2 x 4
-    (16, 8, 133, {"SNOWTRI_SUMS_THREADS": "64", "SNOWTRI_SUMS_LDS_KB": "24"}),       # ... 960 tiles in 15 rounds of one wave
     (8, 4, 133, {"SNOWTRI_SPLIT_SEGMENTS": "1"}),                                    # the whole call on the caller's stream
-    (8, 4, 133, {"SNOWTRI_SUMS_RAYS": "1"}),                                         # k_candidate_sums_rays: one lane per ray and joint sub-range
-    (8, 4, 21, {"SNOWTRI_SUMS_RAYS": "1"}),                                          # ... two chunks, the second of five joints
-    (16, 2, 133, {"SNOWTRI_SUMS_RAYS": "1"}),                                        # ... 15 candidates per lane, seven full partners + a half
-    (4, 8, 57, {"SNOWTRI_SUMS_RAYS": "1"}),                                          # ... one full partner + a half of four persons
 ])
-def test_candidate_sums_launch_shapes_against_oracle(api, C, P, J, knobs, monkeypatch):
+def test_candidate_sums_launch_shapes_against_oracle(api, C, P, J, forced, knobs):
     """k_candidate_sums picks its workgroup shape from the rig (256 threads x 3 per CU ... 1024 x 1), keeps a tile's sums in
     registers when one pass of the workgroup covers the tiles and walks them in rounds otherwise, and pipelines the joint
     chunks through two LDS buffers.  The development knobs force the shapes the BASELINE rigs do not take by themselves:
@@ -499,21 +495,19 @@ def test_candidate_sums_launch_shapes_against_oracle(api, C, P, J, knobs, monkey
     prm = dict(PRM, keypoint_num=J, condense_person_num_tol=10 if C == 16 else 2)
     ref = orc.triangulate_condense_batch(K, R, t, kp, npers, orc.make_params(**prm), 64)
     pout = P + 2
-    base = _run(api, K, R, t, prm, kp, npers, pout, monkeypatch)
-    for k, v in knobs.items():
-        monkeypatch.setenv(k, v)
-    out = _run(api, K, R, t, prm, kp, npers, pout, monkeypatch)
-    for k in knobs:
-        monkeypatch.delenv(k)
-    msg = f"C={C} P={P} J={J} {knobs}"
-    assert ("k_candidate_sums_rays<" in out["kernels"]) == ("SNOWTRI_SUMS_RAYS" in knobs), out["kernels"]
+    base = _run(api, K, R, t, prm, kp, npers, pout, knobs)
+    for k, v in forced.items():
+        knobs.set(k, v)
+    out = _run(api, K, R, t, prm, kp, npers, pout, knobs)
+    knobs.clear(*forced)
+    msg = f"C={C} P={P} J={J} {forced}"
     _check(out, ref, pout, J, msg)
     _same(out, base, msg)
     assert sum(out["handed"]) == sum(base["handed"]) == int(np.minimum(ref["count"], pout).sum()), (out["handed"], base["handed"])
 
 
 @pytest.mark.parametrize("C,P,segments", [(8, 4, 2), (8, 4, 5), (16, 8, 3), (5, 3, 2)])
-def test_one_call_split_over_two_stream_sets_is_bit_identical(api, C, P, segments, monkeypatch):
+def test_one_call_split_over_two_stream_sets_is_bit_identical(api, C, P, segments, knobs):
     """Round 4: a multi-person call is cut into segments that alternate between the caller's stream and an internal one (two
     scratch sets, event fork / join inside the call).  SNOWTRI_SPLIT_SEGMENTS=n forces the cut on a small batch (odd n is
     rounded up to an even count): outputs equal the uncut call bit for bit, and the oracle."""
@@ -529,12 +523,12 @@ def test_one_call_split_over_two_stream_sets_is_bit_identical(api, C, P, segment
     prm = dict(PRM, keypoint_num=J, condense_person_num_tol=10 if C == 16 else 2)
     pout = P + 2
     ref = orc.triangulate_condense_batch(K, R, t, kp, npers, orc.make_params(**prm), 64)
-    monkeypatch.setenv("SNOWTRI_SPLIT_SEGMENTS", "1")
-    whole = _run(api, K, R, t, prm, kp, npers, pout, monkeypatch)
-    monkeypatch.setenv("SNOWTRI_SPLIT_SEGMENTS", str(segments))
-    cut = _run(api, K, R, t, prm, kp, npers, pout, monkeypatch)
-    again = _run(api, K, R, t, prm, kp, npers, pout, monkeypatch)
-    monkeypatch.delenv("SNOWTRI_SPLIT_SEGMENTS")
+    knobs.set("SNOWTRI_SPLIT_SEGMENTS", "1")
+    whole = _run(api, K, R, t, prm, kp, npers, pout, knobs)
+    knobs.set("SNOWTRI_SPLIT_SEGMENTS", str(segments))
+    cut = _run(api, K, R, t, prm, kp, npers, pout, knobs)
+    again = _run(api, K, R, t, prm, kp, npers, pout, knobs)
+    knobs.clear("SNOWTRI_SPLIT_SEGMENTS")
     _check(cut, ref, pout, J, f"split {segments}")
     for k in ("xyzs", "pscore", "count", "flags"):
         assert np.array_equal(whole[k], cut[k], equal_nan=True), k
@@ -544,7 +538,7 @@ def test_one_call_split_over_two_stream_sets_is_bit_identical(api, C, P, segment
 
 
 @pytest.mark.parametrize("cfg,gen,rep,pout", [(3, 220, 10, 16), (5, 70, 30, 32)])
-def test_batches_that_fill_the_chip_twice_are_split_by_default(api, cfg, gen, rep, pout, monkeypatch):
+def test_batches_that_fill_the_chip_twice_are_split_by_default(api, cfg, gen, rep, pout, knobs):
     """No knob: a multi-person batch of >= 2 x 4 x 256 frames is cut in two by the library itself (8 x 4 and, since the
     internal stream is probed, 16 x 8 as well: 17.20 -> 17.01 ms per 12 500 frames).  Bit-identical to the uncut call, and
     the hand-over counters (last segment only) show that the cut happened."""
@@ -558,10 +552,10 @@ def test_batches_that_fill_the_chip_twice_are_split_by_default(api, cfg, gen, re
     res = {}
     for mode in ("uncut", "default"):
         if mode == "uncut":
-            monkeypatch.setenv("SNOWTRI_SPLIT_SEGMENTS", "1")
+            knobs.set("SNOWTRI_SPLIT_SEGMENTS", "1")
         bt = api.BatchTriangulator(K, R, t, wl["params"], pout_max=pout, out_dtype=np.float32)
         if mode == "uncut":
-            monkeypatch.delenv("SNOWTRI_SPLIT_SEGMENTS")
+            knobs.clear("SNOWTRI_SPLIT_SEGMENTS")
         out = bt.run_torch(kp, npers)
         torch.cuda.synchronize(dev)
         res[mode] = ({k: v.clone() for k, v in out.items()}, sum(bt.ctx.last_handover_persons()), bt.ctx.stream_probes(), bt.ctx.last_stream_counts())
@@ -575,7 +569,7 @@ def test_batches_that_fill_the_chip_twice_are_split_by_default(api, cfg, gen, re
     assert res["default"][3] == (0, 0, 0)
 
 
-def test_internal_streams_are_probed_to_run_beside_the_callers(api, monkeypatch):
+def test_internal_streams_are_probed_to_run_beside_the_callers(api, knobs):
     """The HIP runtime multiplexes a process's streams over a few hardware queues (4 by default, least-used first); an
     internal stream on the caller's queue serialises the split (8 x 4 float64: 1.19 -> 1.36 ms once the process had created
     some 40 streams).  Every internal stream is therefore probed when it is created (k_probe_wait / k_probe_set) and replaced
@@ -588,13 +582,13 @@ def test_internal_streams_are_probed_to_run_beside_the_callers(api, monkeypatch)
     K, R, t = wl["rig"]
     kp = torch.from_numpy(wl["kpts"]).to(dev)
     npers = torch.from_numpy(wl["n_persons"]).to(dev)
-    monkeypatch.setenv("SNOWTRI_SPLIT_SEGMENTS", "1")
+    knobs.set("SNOWTRI_SPLIT_SEGMENTS", "1")
     bt = api.BatchTriangulator(K, R, t, wl["params"], pout_max=8, out_dtype=np.float64)
     whole = {k: v.clone() for k, v in bt.run_torch(kp, npers).items()}
     torch.cuda.synchronize(dev)
     assert bt.ctx.stream_probes() == (0, 0, -1)          # no internal stream without the split
     bt.close()
-    monkeypatch.setenv("SNOWTRI_SPLIT_SEGMENTS", "2")
+    knobs.set("SNOWTRI_SPLIT_SEGMENTS", "2")
     pool = [torch.cuda.Stream(device=dev) for _ in range(5)]
     discarded = 0
     for i in range(12):
@@ -617,7 +611,7 @@ def test_internal_streams_are_probed_to_run_beside_the_callers(api, monkeypatch)
         for k in ("xyzs", "pscore", "count", "flags"):
             assert torch.equal(out[k].view(torch.int32), whole[k].view(torch.int32)), (i, k)
         bt.close()
-    monkeypatch.delenv("SNOWTRI_SPLIT_SEGMENTS")
+    knobs.clear("SNOWTRI_SPLIT_SEGMENTS")
     print("internal streams discarded by the probe:", discarded)
 
 
@@ -641,7 +635,7 @@ def test_reference_workloads_take_no_fall_back_of_the_streaming_route(api):
 @pytest.mark.parametrize("out_dtype", [np.float32, np.float64])
 @pytest.mark.parametrize("kn,center", [(133, 0), (30, 18), (1, 5)])
 @pytest.mark.parametrize("C,P", [(8, 4), (16, 4), (5, 3)])
-def test_streaming_route_for_float64_outputs_and_keypoint_num_below_J(api, C, P, kn, center, out_dtype, monkeypatch):
+def test_streaming_route_for_float64_outputs_and_keypoint_num_below_J(api, C, P, kn, center, out_dtype, knobs):
     """the reference returns float64 arrays and its signature defaults are center_point_index = 18,
     keypoint_num = 30 (triangulation.py:95-100,136-148).  Both used to drop a multi-person batch to k_frame_recompute; now the
     streaming kernels are templated on the output type and fuse only the first keypoint_num joints, and the persons' mean
@@ -661,8 +655,8 @@ def test_streaming_route_for_float64_outputs_and_keypoint_num_below_J(api, C, P,
     prm = dict(PRM, keypoint_num=kn, center_point_index=center, condense_person_num_tol=6 if C == 16 else 2)
     pout = P + 2
     ref = orc.triangulate_condense_batch(K, R, t, kp, npers, orc.make_params(**prm), 64)
-    out = _run(api, K, R, t, prm, kp, npers, pout, monkeypatch, out_dtype=out_dtype)
-    off = _run(api, K, R, t, prm, kp, npers, pout, monkeypatch, handover=False, out_dtype=out_dtype)
+    out = _run(api, K, R, t, prm, kp, npers, pout, knobs, out_dtype=out_dtype)
+    off = _run(api, K, R, t, prm, kp, npers, pout, knobs, handover=False, out_dtype=out_dtype)
     assert out["xyzs"].dtype == out_dtype and out["xyzs"].shape == (F, pout, kn, 4)
     assert "k_associate" in out["kernels"] and "k_associate" not in off["kernels"]
     assert sum(out["handed"]) == int(np.minimum(ref["count"], pout).sum()) and out["handed"][0] > 0 and out["handed"][1] > 0, out["handed"]
@@ -681,7 +675,7 @@ def test_streaming_route_for_float64_outputs_and_keypoint_num_below_J(api, C, P,
 
 
 @pytest.mark.parametrize("out_dtype", [np.float32, np.float64])
-def test_keypoint_num_below_J_with_an_active_score_filter(api, out_dtype, monkeypatch):
+def test_keypoint_num_below_J_with_an_active_score_filter(api, out_dtype, knobs):
     """keypoint_num < J with condense_score_tol > 0: the filter of :150-152 needs the mean over the FIRST keypoint_num joints
     before the slots are assigned, which the candidate sums over all J joints (:79) do not give -- a second launch of
     k_candidate_sums over the first keypoint_num joints feeds k_associate.  A tolerance in the middle of the persons' mean
@@ -700,8 +694,8 @@ def test_keypoint_num_below_J_with_an_active_score_filter(api, out_dtype, monkey
         prm["condense_score_tol"] = tol
         ref = orc.triangulate_condense_batch(K, R, t, kp, npers, orc.make_params(**prm), 64)
         assert 0 < ref["count"].sum() < ref0["count"].sum()
-        out = _run(api, K, R, t, prm, kp, npers, P + 2, monkeypatch, out_dtype=out_dtype)
-        off = _run(api, K, R, t, prm, kp, npers, P + 2, monkeypatch, handover=False, out_dtype=out_dtype)
+        out = _run(api, K, R, t, prm, kp, npers, P + 2, knobs, out_dtype=out_dtype)
+        off = _run(api, K, R, t, prm, kp, npers, P + 2, knobs, handover=False, out_dtype=out_dtype)
         assert "k_associate" in out["kernels"] and sum(out["handed"]) > 0
         for o, name in ((out, "route"), (off, "k_frame_recompute")):
             np.testing.assert_array_equal(o["count"], ref["count"], err_msg=name)
@@ -717,7 +711,7 @@ def test_keypoint_num_below_J_with_an_active_score_filter(api, out_dtype, monkey
     assert out["stream_counts"][2] >= 1, out["stream_counts"]
 
 
-def test_random_rigs_float64_outputs_and_keypoint_num(api, monkeypatch):
+def test_random_rigs_float64_outputs_and_keypoint_num(api, knobs):
     """The randomised sweep of test_random_rigs_with_handover_against_oracle_and_phase3 for the shapes round 4 brought to the
     streaming route: float64 or float32 outputs, keypoint_num anywhere in 1..J, 2..16 cameras -- against the oracle, and against
     k_frame_recompute on the same batch (condense_score_tol > 0 with keypoint_num < J: the second candidate-sum launch)."""
@@ -745,8 +739,8 @@ def test_random_rigs_float64_outputs_and_keypoint_num(api, monkeypatch):
                    center_point_index=int(rng.integers(0, J)), keypoint_num=kn)
         pout = int(rng.choice([1, 4, 16]))
         ref = orc.triangulate_condense_batch(K, R, t, kp, npers, orc.make_params(**prm), 64)
-        out = _run(api, K, R, t, prm, kp, npers, pout, monkeypatch, out_dtype=out_dtype)
-        off = _run(api, K, R, t, prm, kp, npers, pout, monkeypatch, handover=False, out_dtype=out_dtype)
+        out = _run(api, K, R, t, prm, kp, npers, pout, knobs, out_dtype=out_dtype)
+        off = _run(api, K, R, t, prm, kp, npers, pout, knobs, handover=False, out_dtype=out_dtype)
         msg = f"trial {trial}: C={C} P={P} J={J} kn={kn} F={F} {np.dtype(out_dtype).name} {prm} pout={pout} n={npers.tolist()}"
         on_route = "k_associate" in out["kernels"]
         assert on_route, msg
@@ -809,7 +803,7 @@ def test_overlap_mode_with_multi_person_calls_is_bit_identical(api):
 
 
 @pytest.mark.parametrize("in_dtype", [np.float32, np.float64])
-def test_records_that_are_not_finite_send_their_frame_to_the_exact_pass(api, in_dtype, monkeypatch):
+def test_records_that_are_not_finite_send_their_frame_to_the_exact_pass(api, in_dtype, knobs):
     """k_candidate_sums gates without compares (a sign trick, p1_tile_sums): a NaN cannot pass through it, so a NaN or infinite
     pixel or a NaN confidence in a LISTED row sends the frame to k_candidate_sums_exact where the record is written -- the
     result must be the reference's -- and the same values in rows a camera does not list must change nothing at all.  A negative
@@ -825,14 +819,14 @@ def test_records_that_are_not_finite_send_their_frame_to_the_exact_pass(api, in_
     npers[5, 2] = 2                       # a ragged frame: rows 2 and 3 of camera 2 are not listed
     npers[9, 7] = 3
     prm = dict(PRM, keypoint_num=J)
-    clean = _run(api, K, R, t, prm, kp, npers, P + 2, monkeypatch)
+    clean = _run(api, K, R, t, prm, kp, npers, P + 2, knobs)
     assert "k_candidate_sums<" in clean["kernels"], clean["kernels"]
     # unlisted rows full of NaN / inf: bit-identical outputs
     junk = kp.copy()
     junk[5, 2, 2:] = np.nan
     junk[9, 7, 3, :, 0] = np.inf
     junk[9, 7, 3, :, 2] = np.nan
-    out = _run(api, K, R, t, prm, junk, npers, P + 2, monkeypatch)
+    out = _run(api, K, R, t, prm, junk, npers, P + 2, knobs)
     for k in ("xyzs", "pscore", "count", "flags"):
         assert np.array_equal(out[k], clean[k], equal_nan=True), k
     # listed rows: one NaN pixel, one infinite pixel, one NaN confidence, one -inf confidence (simply gated), in four frames
@@ -842,8 +836,8 @@ def test_records_that_are_not_finite_send_their_frame_to_the_exact_pass(api, in_
     bad[3, 6, 0, 60, 2] = np.nan
     bad[4, 5, 3, 5, 2] = -np.inf
     ref = orc.triangulate_condense_batch(K, R, t, bad, npers, orc.make_params(**prm), 64)
-    out = _run(api, K, R, t, prm, bad, npers, P + 2, monkeypatch)
-    off = _run(api, K, R, t, prm, bad, npers, P + 2, monkeypatch, handover=False)
+    out = _run(api, K, R, t, prm, bad, npers, P + 2, knobs)
+    off = _run(api, K, R, t, prm, bad, npers, P + 2, knobs, handover=False)
     np.testing.assert_array_equal(out["count"], ref["count"])
     np.testing.assert_array_equal(off["count"], ref["count"])
     for f in range(F):
@@ -859,12 +853,12 @@ def test_records_that_are_not_finite_send_their_frame_to_the_exact_pass(api, in_
     # negative distance_threshold: not a streaming batch, and the reference's result (nothing survives the pair gate)
     neg = dict(prm, distance_threshold=-0.05)
     refn = orc.triangulate_condense_batch(K, R, t, kp, npers, orc.make_params(**neg), 64)
-    outn = _run(api, K, R, t, neg, kp, npers, P + 2, monkeypatch)
+    outn = _run(api, K, R, t, neg, kp, npers, P + 2, knobs)
     assert "k_candidate_sums<" not in outn["kernels"], outn["kernels"]
     np.testing.assert_array_equal(outn["count"], refn["count"])
 
 
-def test_a_record_that_is_not_finite_in_the_second_candidate_sum_launch(api, monkeypatch):
+def test_a_record_that_is_not_finite_in_the_second_candidate_sum_launch(api, knobs):
     """keypoint_num < J with an active condense_score_tol: k_candidate_sums runs a second time over the first keypoint_num joints,
     without an exact list -- a frame with a NaN record there gets NaN sums (which is what they are) and k_associate leaves it to
     k_frame_recompute.  Against the oracle, NaN patterns included."""
@@ -880,7 +874,7 @@ def test_a_record_that_is_not_finite_in_the_second_candidate_sum_launch(api, mon
     kp[2, 1, 0, 7, 0] = np.nan        # inside the first keypoint_num joints: both launches see it
     kp[5, 4, 2, 100, 2] = np.nan      # behind them: only the launch over all J joints does
     ref = orc.triangulate_condense_batch(K, R, t, kp, npers, orc.make_params(**prm), 64)
-    out = _run(api, K, R, t, prm, kp, npers, P + 2, monkeypatch)
+    out = _run(api, K, R, t, prm, kp, npers, P + 2, knobs)
     assert "k_candidate_sums<" in out["kernels"], out["kernels"]
     np.testing.assert_array_equal(out["count"], ref["count"])
     for f in range(F):
@@ -892,3 +886,38 @@ def test_a_record_that_is_not_finite_in_the_second_candidate_sum_launch(api, mon
         np.testing.assert_array_equal(np.isnan(out["pscore"][f, :m]), np.isnan(ref["pscore"][f, :m]), err_msg=f"pscore frame {f}")
         ok = np.isfinite(ref["pscore"][f, :m])
         assert_scores_close(out["pscore"][f, :m][ok], ref["pscore"][f, :m][ok], rtol=3e-7, nterms=kn, what=f"pscore frame {f}")
+
+
+@pytest.mark.parametrize("C,P,kn", [(8, 4, 133), (8, 4, 30), (16, 2, 133), (5, 3, 133)])
+def test_equal_rays_in_a_multi_person_batch_are_flagged(api, C, P, kn, knobs):
+    """Round-5 advice: the candidate pass formed the determinant FUSED, fma(a, c, -(b b)) -- for equal rays the rounding error of
+    b b, positive often enough for a finite (wrong) score and no flag.  Now det comes from separately rounded products (singular as
+    the reference sees it <=> det == 0 exactly -> det * rsq(0) = NaN -> the frame goes to k_candidate_sums_exact, which tests
+    a c == b b).  Camera 1 is camera 0 moved sideways (the same K and R under a general rig); person 0 of both shows one joint
+    at the same pixel in two frames of three.  The flag is on exactly those frames -- also for a joint behind keypoint_num, and
+    also when everything runs inside k_frame_recompute (the test build, SNOWTRI_HANDOVER_MODE=0)."""
+    from snowmocap_amd import synth, _lib
+    rng = np.random.default_rng(31 + C + P + kn)
+    J, F = 133, 48
+    K, R, t = synth.ring_rig(C, radius=4.5)
+    K, R, t = K.copy(), R.copy(), t.copy()
+    K[1], R[1] = K[0], R[0]
+    t[1] = t[0] + R[0] @ np.array([0.4, 0.1, 0.0])
+    X = synth.make_people(rng, F, P, J=J)
+    kp, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=0.7, score_range=(3.5, 9.0), permute_persons=False, dtype=np.float32)
+    kp = kp.copy()
+    hit = np.arange(F) % 3 != 2
+    joint = 100
+    px = rng.uniform(200, 1000, size=(F, 2)).astype(np.float32)
+    kp[hit, 0, 0, joint, :2] = px[hit]
+    kp[hit, 1, 0, joint, :2] = px[hit]
+    prm = dict(PRM, keypoint_num=kn, condense_person_num_tol=1)
+    out = _run(api, K, R, t, prm, kp, npers, P + 2, knobs)
+    assert "k_candidate_sums<" in out["kernels"], out["kernels"]
+    sing = (out["flags"] & _lib.FLAG_SINGULAR) != 0
+    assert np.array_equal(sing, hit), np.nonzero(sing != hit)[0]
+    assert out["stream_counts"][1] >= int(hit.sum()), out["stream_counts"]      # the exact pass took those frames
+    off = _run(api, K, R, t, prm, kp, npers, P + 2, knobs, handover=False)
+    assert np.array_equal((off["flags"] & _lib.FLAG_SINGULAR) != 0, hit)
+    ok = ~hit                                                                   # the other frames: the two routes agree as everywhere
+    np.testing.assert_array_equal(out["count"][ok], off["count"][ok])

@@ -28,17 +28,16 @@ def api():
     return sm
 
 
-def _run(api, K, R, t, prm, kp, npers, env=None, monkeypatch=None):
-    if env:
+def _run(api, K, R, t, prm, kp, npers, env=None, knobs=None):
+    if env:      # (a forced route: the test build of the library, conftest.Knobs)
         for k, v in env.items():
-            monkeypatch.setenv(k, v)
+            knobs.set(k, v)
     bt = api.BatchTriangulator(K, R, t, prm, pout_max=1, out_dtype=np.float32)
     out = bt.run_host(kp, npers)
     out["slow"] = bt.ctx.last_slow_frames()
     bt.close()
     if env:
-        for k in env:
-            monkeypatch.delenv(k)
+        knobs.clear(*env)
     return out
 
 
@@ -77,7 +76,7 @@ def _break_some_frames(rng, kp, npers, F, n_each=3):
 
 @pytest.mark.parametrize("F,tiles_per_wave", [(1, None), (3, None), (37, None), (700, None), (4099, None), (30011, None),
                                               (30011, "1"), (52000, "2")])
-def test_lean_fallback_frames_against_oracle(api, F, tiles_per_wave, monkeypatch):
+def test_lean_fallback_frames_against_oracle(api, F, tiles_per_wave, knobs):
     """Broken frames sprinkled over a batch: they lose the fast-path flag, are re-done inside the same launch, and
     every checked frame -- broken or not -- equals the oracle.  F sweeps the launch shapes: fewer frames than waves,
     one tile per wave, several tiles per wave (tile ordinals > 0 in the slow-frame bit words), many workgroups."""
@@ -92,7 +91,7 @@ def test_lean_fallback_frames_against_oracle(api, F, tiles_per_wave, monkeypatch
     prm = dict(wl["params"], condense_distance_tol=0.5, condense_score_tol=0.2)
     K, R, t = wl["rig"]
     env = {"SNOWTRI_LEAN_TILES_PER_WAVE": tiles_per_wave} if tiles_per_wave else None
-    out = _run(api, K, R, t, prm, kp, npers, env, monkeypatch)
+    out = _run(api, K, R, t, prm, kp, npers, env, knobs)
     assert out["status"] in (_lib.OK, _lib.ERR_OVERFLOW)      # a broken frame may resolve to more persons than the one slot
     fast = (out["flags"] & _lib.FLAG_FASTPATH) != 0
     for f, kind in broken.items():
@@ -221,14 +220,14 @@ def test_lean_special_values(api):
     assert compared > 10
 
 
-def test_lean_agrees_with_fused_single(api, monkeypatch):
+def test_lean_agrees_with_fused_single(api, knobs):
     """SNOWTRI_LEAN_MODE=0 keeps float32-output batches on k_fused_single: same counts / flags, joints within the
     float32 tolerance of each other (the two kernels round 1/dist differently), on a 10 000-frame batch."""
     from snowmocap_amd import synth, _lib
     wl = synth.config_workload(2, 10000, seed=3)
     K, R, t = wl["rig"]
     a = _run(api, K, R, t, wl["params"], wl["kpts"], wl["n_persons"])
-    b = _run(api, K, R, t, wl["params"], wl["kpts"], wl["n_persons"], {"SNOWTRI_LEAN_MODE": "0"}, monkeypatch)
+    b = _run(api, K, R, t, wl["params"], wl["kpts"], wl["n_persons"], {"SNOWTRI_LEAN_MODE": "0"}, knobs)
     assert np.array_equal(a["count"], b["count"]) and np.array_equal(a["flags"], b["flags"])
     assert (a["count"] == 1).all()
     assert np.abs(a["xyzs"][..., :3].astype(np.float64) - b["xyzs"][..., :3]).max() < XYZ_F32
@@ -322,7 +321,7 @@ def test_raw_rsq_accuracy_behind_the_float32_score_contract(api):
 
 
 @pytest.mark.parametrize("F", [1, 2, 3, 5, 511, 513, 1024, 4000, 10000, 16384, 16385])
-def test_small_launches_cooperative_kernel_equals_wave_autonomous_kernel(api, F, monkeypatch):
+def test_small_launches_cooperative_kernel_equals_wave_autonomous_kernel(api, F, knobs):
     """k_fused_lean_coop takes launches of up to 32 frames per resident workgroup (16 384 frames on an MI355X): a
     workgroup tile whose PASSES are dealt to the waves (frames straddle waves), one cooperative epilogue.  Items, check
     and mean are the functions k_fused_lean uses: the same frames through SNOWTRI_LEAN_COOP=0 are bit-identical --
@@ -342,7 +341,7 @@ def test_small_launches_cooperative_kernel_equals_wave_autonomous_kernel(api, F,
     names = bt.ctx.last_kernel_names()
     bt.close()
     assert names.startswith("k_fused_lean_coop<4,float,133>" if F <= 16384 else "k_fused_lean<4,float,133>"), names
-    b = _run(api, K, R, t, wl["params"], kp, npers, {"SNOWTRI_LEAN_COOP": "0"}, monkeypatch)
+    b = _run(api, K, R, t, wl["params"], kp, npers, {"SNOWTRI_LEAN_COOP": "0"}, knobs)
     for key in ("xyzs", "pscore", "count", "flags"):
         assert np.array_equal(a[key], b[key], equal_nan=True), f"F={F}: {key} differs between the two kernels"
     from snowmocap_amd import _lib

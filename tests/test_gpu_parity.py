@@ -356,12 +356,12 @@ def test_dlt_multi_person_against_oracle(api):
 
 
 @pytest.mark.parametrize("mode", ["1", "2"])
-def test_general_kernels_agree(api, mode, monkeypatch):
+def test_general_kernels_agree(api, mode, knobs):
     """Spill kernel (mode 1) and recompute kernel (mode 2) forced on a single-person batch must both
     equal the oracle -- and so must the fast path (default), tested above."""
     from snowmocap_amd import synth, _lib
     from oracle import oracle as orc
-    monkeypatch.setenv("SNOWTRI_GENERAL_MODE", mode)
+    knobs.set("SNOWTRI_GENERAL_MODE", mode)
     wl = synth.config_workload(2, 50, seed=21)
     K, R, t = wl["rig"]
     ref = orc.triangulate_condense_batch(K, R, t, wl["kpts"], wl["n_persons"], orc.make_params(**wl["params"]), 2)
@@ -377,7 +377,7 @@ def test_general_kernels_agree(api, mode, monkeypatch):
 
 
 @pytest.mark.parametrize("mode", ["auto", "spill"])
-def test_random_small_rigs_against_oracle(api, mode, monkeypatch):
+def test_random_small_rigs_against_oracle(api, mode, knobs):
     """Randomised sweep of the shapes the fused entry can meet -- 2..6 cameras, 1..3 detections per camera with
     ragged (also empty) person lists, 3..40 joints, keypoint_num <= J, any centre joint, thresholds that switch
     every filter on and off -- against the oracle: identical person counts, joints within 1e-8 m.
@@ -385,7 +385,7 @@ def test_random_small_rigs_against_oracle(api, mode, monkeypatch):
     from snowmocap_amd import synth, _lib
     from oracle import oracle as orc
     if mode == "spill":
-        monkeypatch.setenv("SNOWTRI_GENERAL_MODE", "1")
+        knobs.set("SNOWTRI_GENERAL_MODE", "1")
     rng = np.random.default_rng(2024 if mode == "auto" else 7)
     checked = 0
     for trial in range(60):
@@ -605,13 +605,13 @@ def test_exact_intersection_with_gated_confidence_multi_person(api):
 
 
 @pytest.mark.parametrize("mode", ["auto", "spill"])
-def test_random_special_values_against_oracle(api, mode, monkeypatch):
+def test_random_special_values_against_oracle(api, mode, knobs):
     """Adversarial inputs through the fused entry: exactly intersecting rays (dist == 0 -> inf score -> NaN fused
     joint), NaN pixels, NaN / negative / zero confidences, negative thresholds.  The NaN / inf / zero patterns and
     the person counts must equal the oracle's; finite values must agree."""
     from oracle import oracle as orc
     if mode == "spill":
-        monkeypatch.setenv("SNOWTRI_GENERAL_MODE", "1")
+        knobs.set("SNOWTRI_GENERAL_MODE", "1")
     rng = np.random.default_rng(99 if mode == "auto" else 98)
     compared = 0
     for trial in range(40):
@@ -1094,7 +1094,7 @@ def test_fast_path_other_camera_counts(api, C):
         assert names.startswith(f"k_fused_single<{C},0,")
         assert ((out["flags"] & _lib.FLAG_FASTPATH) != 0).mean() > 0.9      # opposite cameras may flag a few frames
     else:
-        assert names.startswith("k_associate<") and "k_candidate_sums" not in names, names
+        assert names.startswith("k_singular_scan<") and "k_associate<" in names and "k_candidate_sums" not in names, names
     for f in range(70):
         m = int(ref["count"][f])
         assert not out["xyzs"][f, m:].any()

@@ -23,15 +23,15 @@ def api():
     return sm
 
 
-def _run(api, K, R, t, prm, kp, npers, out_dtype, pout=1, env=None, monkeypatch=None):
-    for k, v in (env or {}).items():
-        monkeypatch.setenv(k, v)
+def _run(api, K, R, t, prm, kp, npers, out_dtype, pout=1, env=None, knobs=None):
+    for k, v in (env or {}).items():      # (a forced route: the test build of the library, conftest.Knobs)
+        knobs.set(k, v)
     bt = api.BatchTriangulator(K, R, t, prm, pout_max=pout, out_dtype=out_dtype)
     out = bt.run_host(kp, npers)
     out["names"] = bt.ctx.last_kernel_names()
     bt.close()
-    for k in (env or {}):
-        monkeypatch.delenv(k)
+    if env:
+        knobs.clear(*env)
     return out
 
 
@@ -150,13 +150,13 @@ def test_sumless_route_against_oracle(api, C, out_dtype, kn):
     prm = dict(synth.default_thresholds(), condense_distance_tol=0.5, keypoint_num=kn, center_point_index=min(18, kn - 1))
     ref = orc.triangulate_condense_batch(K, R, t, kp, npers, orc.make_params(**prm), pout)
     out = _run(api, K, R, t, prm, kp, npers, out_dtype, pout=pout)
-    assert "k_candidate_sums" not in out["names"] and out["names"].startswith("k_associate<"), out["names"]
+    assert "k_candidate_sums" not in out["names"] and out["names"].startswith("k_singular_scan<") and "k_associate<" in out["names"], out["names"]
     assert ("k_cluster_fuse<%d," % C if C <= 8 else "k_cluster_fuse_wide<") in out["names"], out["names"]
     _compare(out, ref, F, out_dtype, kn, f"C={C} {np.dtype(out_dtype).name} kn={kn}")
 
 
 @pytest.mark.parametrize("C", [5, 8, 12])
-def test_sumless_equals_candidate_pass(api, C, monkeypatch):
+def test_sumless_equals_candidate_pass(api, C, knobs):
     """SNOWTRI_SUMLESS_MODE=0 keeps the candidate pass: the same counts, the same joints bit for bit (the same fusion
     kernels on the same descriptors), the persons' mean scores within the float32 contract (candidate sums vs fused joints)."""
     from snowmocap_amd import synth
@@ -169,7 +169,7 @@ def test_sumless_equals_candidate_pass(api, C, monkeypatch):
     npers[7, 0] = 0
     prm = dict(synth.default_thresholds(), condense_distance_tol=0.5)
     a = _run(api, K, R, t, prm, kp, npers, np.float32, pout=2)
-    b = _run(api, K, R, t, prm, kp, npers, np.float32, pout=2, env={"SNOWTRI_SUMLESS_MODE": "0"}, monkeypatch=monkeypatch)
+    b = _run(api, K, R, t, prm, kp, npers, np.float32, pout=2, env={"SNOWTRI_SUMLESS_MODE": "0"}, knobs=knobs)
     assert "k_candidate_sums" in b["names"] and "k_candidate_sums" not in a["names"]
     assert np.array_equal(a["count"], b["count"])
     assert np.array_equal(a["xyzs"], b["xyzs"], equal_nan=True)
@@ -197,10 +197,84 @@ def test_sumless_flags_a_singular_pair(api):
     out = bt.run_host(kp, npers)
     names = bt.ctx.last_kernel_names()
     bt.close()
-    assert names.startswith("k_associate<"), names
+    assert names.startswith("k_singular_scan<") and "k_associate<" in names, names
     sing = (out["flags"] & _lib.FLAG_SINGULAR) != 0
     assert sing[4] and sing.sum() == 1
     assert out["status"] == _lib.ERR_SINGULAR
+
+
+def _twin_camera_rig(C, rng):
+    """A ring rig whose camera 1 is camera 0 moved sideways: the same K and R, another centre.  Equal pixels in the two are
+    bit-identical, PARALLEL rays under a general K and R (not the K = R = I of the test above): a = b = c in H^T H, the pair is
+    singular as the reference's LU sees it, np.linalg.inv raises (triangulation.py:26)."""
+    from snowmocap_amd import synth
+    K, R, t = synth.ring_rig(C, radius=4.5)
+    K, R, t = K.copy(), R.copy(), t.copy()
+    K[1], R[1] = K[0], R[0]
+    t[1] = t[0] + R[0] @ np.array([0.4, 0.1, 0.0])
+    return K, R, t
+
+
+@pytest.mark.parametrize("C,out_dtype,kn,pout,joint,route", [
+    (4, np.float32, J, 1, 40, "k_fused_lean"),            # lean_item (the bench's kernel)
+    (4, np.float64, J, 1, 7, "k_fused_single<4,0"),       # pairwise_item: one reciprocal for the six determinants
+    (4, np.float32, 30, 1, 100, "k_fused_single<4,0"),    # ... a singular pair at a joint BEHIND keypoint_num
+    (8, np.float32, J, 1, 132, "k_fused_lean"),           # cluster_item inside the lean kernel
+    (6, np.float64, J, 2, 3, "k_singular_scan"),          # the streaming route without its candidate pass, a fused joint
+    (6, np.float32, 30, 1, 90, "k_singular_scan"),        # ... a joint behind keypoint_num: only the scan meets it
+    (12, np.float32, J, 1, 50, "k_cluster_fuse_wide"),    # nine and more cameras: the LDS-resident item
+    (12, np.float32, 20, 1, 77, "k_cluster_fuse_wide"),
+])
+def test_equal_rays_under_a_general_rig_are_flagged_on_every_single_detection_route(api, C, out_dtype, kn, pout, joint, route, knobs):
+    """Round-5 advice: with a FUSED determinant fma(a, c, -(b b)) equal rays give the rounding error of b b, which is positive
+    in ~18 % of the cases -- a finite, wrong joint and no flag.  Every fast item now forms det from separately rounded products
+    (singular <=> det == 0 exactly -> the sum is not finite -> the exact routine flags the frame) or tests a c == b b itself, and
+    the route without a candidate pass scans every listed pair at every joint.  64 frames with their own pixel each, so that
+    several roundings of b b are met; the flag must be on every one of them and nowhere else, whatever route the call takes --
+    and, where a knob forces another route (the test build), the same frames."""
+    from snowmocap_amd import synth, _lib
+    rng = np.random.default_rng(900 + C + kn)
+    K, R, t = _twin_camera_rig(C, rng)
+    F = 96
+    X = synth.make_people(rng, F, 1)
+    kp, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=0.8, score_range=(3.5, 8.0))
+    kp = kp.copy()
+    hit = np.arange(F) % 3 != 1                            # two frames of three carry the singular pair
+    px = rng.uniform(200, 1000, size=(F, 2)).astype(np.float32)
+    kp[hit, 1, 0, joint, :2] = px[hit]
+    kp[hit, 0, 0, joint, :2] = px[hit]                     # cameras 0 and 1: the same pixel -> the same ray, bit for bit
+    prm = dict(synth.default_thresholds(), condense_distance_tol=10.0, keypoint_num=kn, center_point_index=0)
+    out = _run(api, K, R, t, prm, kp, npers, out_dtype, pout=pout)
+    assert route in out["names"], out["names"]
+    sing = (out["flags"] & _lib.FLAG_SINGULAR) != 0
+    assert np.array_equal(sing, hit), (np.nonzero(sing != hit)[0], out["names"])
+    assert out["status"] == _lib.ERR_SINGULAR
+    if route == "k_singular_scan":                         # the flag does not depend on the route: the candidate pass finds the same frames
+        b = _run(api, K, R, t, prm, kp, npers, out_dtype, pout=pout, env={"SNOWTRI_SUMLESS_MODE": "0"}, knobs=knobs)
+        assert "k_candidate_sums" in b["names"], b["names"]
+        assert np.array_equal((b["flags"] & _lib.FLAG_SINGULAR) != 0, hit)
+
+
+def test_sumless_flags_a_singular_pair_of_a_candidate_outside_every_kept_cluster(api, knobs):
+    """... and a candidate no kept cluster holds: with a tight condense_distance_tol the candidate of the twin cameras (its 3D
+    points are garbage) clusters with nobody, condense_person_num_tol = 2 drops it, nothing of it is ever fused -- the reference
+    has raised long before (triangulation.py:26 runs in Human_Triangulation)."""
+    from snowmocap_amd import synth, _lib
+    rng = np.random.default_rng(77)
+    C = 7
+    K, R, t = _twin_camera_rig(C, rng)
+    F = 24
+    X = synth.make_people(rng, F, 1)
+    kp, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=0.5, score_range=(3.5, 8.0))
+    kp = kp.copy()
+    kp[5, 0, 0, 60, :2] = kp[5, 1, 0, 60, :2]
+    prm = dict(synth.default_thresholds(), condense_distance_tol=0.05, condense_person_num_tol=2, keypoint_num=40, center_point_index=0)
+    a = _run(api, K, R, t, prm, kp, npers, np.float32, pout=3)
+    b = _run(api, K, R, t, prm, kp, npers, np.float32, pout=3, env={"SNOWTRI_SUMLESS_MODE": "0"}, knobs=knobs)
+    assert "k_singular_scan" in a["names"] and "k_candidate_sums" in b["names"]
+    for o in (a, b):
+        sing = (o["flags"] & _lib.FLAG_SINGULAR) != 0
+        assert sing[5] and sing.sum() == 1, np.nonzero(sing)[0]
 
 
 @pytest.mark.parametrize("C", [5, 6, 8])
