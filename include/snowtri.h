@@ -242,10 +242,16 @@ int snowtri_triangulate_condense_ex(snowtri_ctx *ctx, int64_t F, int32_t Pmax, i
 /* N1  Human_Triangulation_Smooth / SecondOrderDynamic (triangulation.py:4-22,164-186) over a whole track.
  * x[T][n] fp64, frame-major, n = persons * joints * 3 lanes (persons matched by index, as the reference does)
  * -> y[T][n].  Frame 0 passes through and seeds xp = y = x0, yd = 0; f, z, r, dt as in the reference
- * (main.py:72-77).  Evaluated as a chunked linear scan over frames (results equal the sequential recurrence
- * to rounding: ~1e-13 m).  T <= 1 + 256 * 65535 frames. */
+ * (main.py:72-77).  Evaluated as ONE pass over HBM -- a chained scan over 256-frame blocks with decoupled look-back: x is read
+ * once, y written once (results equal the sequential recurrence to rounding: ~1e-13 m).  T <= 1 + 256 * 65535 frames, n <= 2^22 lanes. */
 int snowtri_smooth_track(snowtri_ctx *ctx, int64_t T, int64_t n, const double *x, double f, double z, double r,
                          double dt, double *y, int memspace, void *stream);
+/* The same on a track of JOINT RECORDS as snowtri_triangulate_condense writes them with SNOWTRI_F64 outputs: xyzs[T][m][4] =
+ * (x, y, z, score), m = persons * keypoint_num -> out[T][m][4] with the three coordinates filtered and the score COPIED (the
+ * reference filters the points only, triangulation.py:169-184: a caller of snowtri_smooth_track had to filter the score lane
+ * for nothing and copy the scores over afterwards).  out may not alias xyzs. */
+int snowtri_smooth_joint_track(snowtri_ctx *ctx, int64_t T, int64_t m, const double *xyzs, double f, double z, double r,
+                               double dt, double *out, int memspace, void *stream);
 
 /* N1 on a FRAME-SHARDED track (one contiguous frame block per rank).  The filter is linear in its state, so a
  * shard is processed in two calls around ONE small exchange of carries (3n doubles per rank):

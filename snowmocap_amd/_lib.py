@@ -94,6 +94,8 @@ _SIGNATURES = {
                                                    _c_p, ct.c_int, _c_p, _c_p, ct.c_int, _c_p, ct.c_uint32]),
     "snowtri_smooth_track": (ct.c_int, [_c_p, ct.c_int64, ct.c_int64, _c_p, ct.c_double, ct.c_double, ct.c_double,
                                         ct.c_double, _c_p, ct.c_int, _c_p]),
+    "snowtri_smooth_joint_track": (ct.c_int, [_c_p, ct.c_int64, ct.c_int64, _c_p, ct.c_double, ct.c_double, ct.c_double,
+                                              ct.c_double, _c_p, ct.c_int, _c_p]),
     "snowtri_smooth_coeffs": (ct.c_int, [ct.c_double, ct.c_double, ct.c_double, ct.c_double, _c_p]),
     "snowtri_smooth_shard_local": (ct.c_int, [_c_p, ct.c_int64, ct.c_int64, _c_p, ct.c_int, ct.c_double, ct.c_double,
                                               ct.c_double, ct.c_double, _c_p, _c_p, ct.c_int, _c_p]),

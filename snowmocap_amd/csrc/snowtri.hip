@@ -1272,6 +1272,13 @@ SmoothCoef smooth_coef(double f, double z, double r, double dt) {
         p[0] = q0; p[1] = q1; p[2] = q2; p[3] = q3;
     }
     k.p00 = p[0]; k.p01 = p[1]; k.p10 = p[2]; k.p11 = p[3];
+    double q[4] = {1, 0, 0, 1};  // A^32: the frames one wave of the one-pass scan holds (k_smooth_scan)
+    for (int i = 0; i < kScanL; i++) {
+        const double q0 = k.a00 * q[0] + k.a01 * q[2], q1 = k.a00 * q[1] + k.a01 * q[3];
+        const double q2 = k.a10 * q[0] + k.a11 * q[2], q3 = k.a10 * q[1] + k.a11 * q[3];
+        q[0] = q0; q[1] = q1; q[2] = q2; q[3] = q3;
+    }
+    k.r00 = q[0]; k.r01 = q[1]; k.r10 = q[2]; k.r11 = q[3];
     return k;
 }
 
@@ -1328,32 +1335,33 @@ int smooth_fix_dev(snowtri_ctx *ctx, hipStream_t st, int64_t T, int64_t n, doubl
     return SNOWTRI_OK;
 }
 
-// A whole (unsharded) track in three passes: chunk-end states of the zero-state response (reads x, writes
-// nothing per frame), the sequential carry over chunks from the seed (x_0, 0), then the exact recurrence of
-// every chunk from its true entering state (reads x, writes y).  d_seed_row: [n] inputs of frame 0 as the
-// filters see them (x[0] itself for N1; the held x_eff[0] for N2).
+// A whole (unsharded) track in ONE pass over HBM: the chained scan with decoupled look-back of snowtri_smooth.hpp
+// (k_smooth_scan) -- x read once, y written once.  d_seed_row: [n] inputs of frame 0 as the filters see them (x[0] itself for
+// N1; the held x_eff[0] for N2).  skip4: every fourth lane (the score of a joint record) is copied instead of filtered.
+// (Rounds 1-5 ran three passes -- chunk-end states, the carry over the chunks, the recurrence again: 24 bytes moved per 16
+// algorithmic; the sharded protocol below still does, its entering state is not known before the exchange.)
 template <typename KS, typename HS>
 int smooth_whole_dev(snowtri_ctx *ctx, hipStream_t st, int64_t T, int64_t n, const double *dx, double *dy,
-                     const double *d_seed_row, const KS &k, const HS &hs) {
-    const int64_t m = T - 1, nchunks = (m + kSmoothChunk - 1) / kSmoothChunk;
-    if (nchunks > 65535) return SNOWTRI_ERR_BAD_ARG;
+                     const double *d_seed_row, const KS &k, const HS &hs, bool skip4 = false) {
+    const int64_t m = T - 1, nsuper = (m + kScanSuper - 1) / kScanSuper, ncols = (n + 63) / 64;
+    if (nsuper > 65535) return SNOWTRI_ERR_BAD_ARG;   // (the documented limit of the track length: 1 + 256 * 65535 frames)
     if (m <= 0) {
         HIP_TRY(hipMemcpyAsync(dy, dx, sizeof(double) * (size_t)T * n, hipMemcpyDeviceToDevice, st));
         return SNOWTRI_OK;
     }
-    int rc = ctx->work.ensure(sizeof(double) * 4 * (size_t)nchunks * n + 64);
+    if (nsuper * ncols >= ((int64_t)1 << 31) || n > ((int64_t)1 << 22)) return SNOWTRI_ERR_BAD_ARG;   // (lanes: the 32-bit buffer offsets of k_smooth_scan)
+    const size_t nwg = (size_t)nsuper * ncols;
+    const size_t off_flags = 256, off_agg = (off_flags + 4 * nwg + 255) & ~(size_t)255, off_incl = off_agg + sizeof(double) * 128 * nwg;
+    int rc = ctx->work.ensure(off_incl + sizeof(double) * 128 * nwg);
     if (rc) return rc;
-    rc = ctx->misc.ensure(sizeof(double) * 2 * n);
-    if (rc) return rc;
-    double *E = (double *)ctx->work.p, *S = E + 2 * (size_t)nchunks * n, *seed = (double *)ctx->misc.p;
-    const dim3 g2 = smooth_grid(n, nchunks), g1 = smooth_grid(n, 1);
-    hipLaunchKernelGGL((k_smooth_local<KS, HS>), g2, dim3(kSmoothBlock), 0, st, T, n, kSmoothChunk, 1, k, hs, dx,
-                       (const double *)nullptr, (double *)nullptr, E);
-    hipLaunchKernelGGL(k_smooth_seed, g1, dim3(kSmoothBlock), 0, st, n, d_seed_row, seed);
-    hipLaunchKernelGGL(k_smooth_carry<KS>, g1, dim3(kSmoothBlock), 0, st, n, nchunks, k, (const double *)seed,
-                       (const double *)E, S);
-    hipLaunchKernelGGL((k_smooth_local<KS, HS>), g2, dim3(kSmoothBlock), 0, st, T, n, kSmoothChunk, 1, k, hs, dx,
-                       (const double *)S, dy, (double *)nullptr);
+    char *base = (char *)ctx->work.p;
+    HIP_TRY(hipMemsetAsync(base, 0, off_agg, st));   // the ticket and the flags
+    unsigned int *ticket = (unsigned int *)base, *flags = (unsigned int *)(base + off_flags);
+    double *agg = (double *)(base + off_agg), *incl = (double *)(base + off_incl);
+    if (skip4)
+        hipLaunchKernelGGL((k_smooth_scan<KS, HS, true>), dim3((unsigned)nwg), dim3(kScanThreads), 0, st, T, n, k, hs, dx, d_seed_row, dy, ticket, flags, agg, incl);
+    else
+        hipLaunchKernelGGL((k_smooth_scan<KS, HS, false>), dim3((unsigned)nwg), dim3(kScanThreads), 0, st, T, n, k, hs, dx, d_seed_row, dy, ticket, flags, agg, incl);
     HIP_TRY(hipGetLastError());
     return SNOWTRI_OK;
 }
@@ -1361,6 +1369,8 @@ int smooth_whole_dev(snowtri_ctx *ctx, hipStream_t st, int64_t T, int64_t n, con
 bool smooth_args_ok(snowtri_ctx *ctx, int64_t T, int64_t n, double f, double dt, int memspace) {
     return ctx && T >= 0 && n >= 0 && f > 0.0 && dt > 0.0 && (memspace == SNOWTRI_HOST || memspace == SNOWTRI_DEVICE);
 }
+int smooth_track_impl(snowtri_ctx *ctx, int64_t T, int64_t n, const double *x, double f, double z, double r, double dt, double *y, int memspace,
+                      void *stream, bool skip4);
 
 }  // namespace
 
@@ -1465,8 +1475,22 @@ int snowtri_smooth_shard_combine(snowtri_ctx *ctx, int32_t world, int32_t rank, 
     return SNOWTRI_OK;
 }
 
+int snowtri_smooth_joint_track(snowtri_ctx *ctx, int64_t T, int64_t m, const double *xyzs, double f, double z, double r,
+                               double dt, double *out, int memspace, void *stream) {
+    if (m < 0 || m > ((int64_t)1 << 40)) return SNOWTRI_ERR_BAD_ARG;
+    return smooth_track_impl(ctx, T, 4 * m, xyzs, f, z, r, dt, out, memspace, stream, true);
+}
+
 int snowtri_smooth_track(snowtri_ctx *ctx, int64_t T, int64_t n, const double *x, double f, double z, double r,
                          double dt, double *y, int memspace, void *stream) {
+    return smooth_track_impl(ctx, T, n, x, f, z, r, dt, y, memspace, stream, false);
+}
+
+}  // extern "C"
+
+namespace {
+int smooth_track_impl(snowtri_ctx *ctx, int64_t T, int64_t n, const double *x, double f, double z, double r,
+                      double dt, double *y, int memspace, void *stream, bool skip4) {
     if (!smooth_args_ok(ctx, T, n, f, dt, memspace)) return SNOWTRI_ERR_BAD_ARG;
     if (T == 0 || n == 0) return SNOWTRI_OK;
     if (!x || !y) return SNOWTRI_ERR_BAD_ARG;
@@ -1485,7 +1509,7 @@ int snowtri_smooth_track(snowtri_ctx *ctx, int64_t T, int64_t n, const double *x
         dx = (const double *)ctx->in.p;
         dy = (double *)ctx->out.p;
     }
-    int rc = smooth_whole_dev(ctx, st, T, n, dx, dy, dx, k, NoHold{});
+    int rc = smooth_whole_dev(ctx, st, T, n, dx, dy, dx, k, NoHold{}, skip4);
     if (rc) return rc;
     if (memspace == SNOWTRI_HOST) {
         HIP_TRY(hipMemcpyAsync(y, dy, bytes, hipMemcpyDeviceToHost, st));
@@ -1493,6 +1517,9 @@ int snowtri_smooth_track(snowtri_ctx *ctx, int64_t T, int64_t n, const double *x
     }
     return SNOWTRI_OK;
 }
+}  // namespace
+
+extern "C" {
 
 // ---------------------------------------------------------------------------------------- N4
 int snowtri_ctx_set_distortion(snowtri_ctx *ctx, const double *D) {

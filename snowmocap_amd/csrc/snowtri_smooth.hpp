@@ -21,7 +21,8 @@ namespace snowtri {
 struct SmoothCoef {
     double a00, a01, a10, a11;  // A
     double cx, cxd;             // c_t = cx * x_t + cxd * (x_t - x_{t-1})      (cxd = (T/k2) k3 / T)
-    double p00, p01, p10, p11;  // A^L
+    double p00, p01, p10, p11;  // A^L   (L = 256 frames: a chunk of the three-pass scan = a workgroup of the one-pass scan)
+    double r00, r01, r10, r11;  // A^32  (the frames one wave of the one-pass scan holds in registers)
 };
 
 constexpr int kSmoothBlock = 256;
@@ -42,6 +43,7 @@ struct TableCoef {
 // What a lane's input is: the track itself (N1), or the track with invalid points replaced by the lane's
 // previous input (N2, blender.py:157-160: `flt.update(dt, x if score else flt.xp)`).
 struct NoHold {
+    static constexpr bool kHold = false;
     __device__ __forceinline__ double entering(const double *x, int64_t t0, int64_t, int64_t n, int64_t lane) const {
         return x[(t0 > 0 ? t0 - 1 : 0) * n + lane];
     }
@@ -50,6 +52,7 @@ struct NoHold {
     __device__ __forceinline__ bool ok(int64_t) const { return true; }
 };
 struct HoldInput {
+    static constexpr bool kHold = true;
     const uint8_t *valid;  // [T][n / comps]
     const double *start;   // [nchunks][n]: the held input entering each chunk (k_hold_carry)
     int comps;
@@ -216,6 +219,196 @@ __global__ __launch_bounds__(kSmoothBlock) void k_smooth_shard_end(int64_t T, in
     }
     end_out[2 * lane] = vy + E[(c * n + lane) * 2];
     end_out[2 * lane + 1] = vyd + E[(c * n + lane) * 2 + 1];
+}
+
+// ---- the whole track in ONE pass over HBM (round 6): a chained scan with decoupled look-back ------------------------------------
+// The three-pass form above reads x twice and writes y once: 24 bytes moved per 16 algorithmic, and it is HBM-bound (0.27 of 8 TB/s,
+// round-5 review).  Here a workgroup of kScanWaves waves owns kScanSuper = 256 consecutive frames of 64 lanes, each wave 32 of them
+// IN REGISTERS (32 loads per lane in flight), and the track is read once and written once:
+//   A  every wave: zero-state response of its 32 frames -> end state e_w (LDS);
+//   B  in the workgroup: z_w = sum_{j<w} R^(w-1-j) e_j (R = A^32): the zero-state state entering wave w; the last wave has the
+//      workgroup's aggregate G = R z + e and PUBLISHES it (flag 1);
+//   C  the last wave looks back over the workgroups before it in its lane column: S_in = G_(b-1) + P G_(b-2) + P^2 G_(b-3) + ...
+//      (P = A^256) until it meets one that has published its INCLUSIVE state (flag 2), then publishes its own P S_in + G.  The
+//      workgroups of a column finish their local phase at about the same time, the first publishes at once, and the distance a
+//      workgroup walks grows like the square root of its position among those in flight (~10 steps of 57): microseconds;
+//   D  every wave: its true entering state R^w S_in + z_w, then the exact recurrence over its registers, y stored.
+// (The look-back multiplies by growing powers of P: for a STABLE filter -- spectral radius of A below 1, the reference's profiles:
+// 1.5 ... 3 Hz at 30 fps -- they decay; a filter beyond ~4.7 Hz at z = 0.75 diverges in the reference too, and here its powers
+// overflow after a few workgroups.)
+// Workgroups take their (time, column) position from a ticket: a workgroup only ever waits for SMALLER tickets, which have started
+// and cannot be descheduled, so the spin cannot deadlock whatever order the dispatcher picks.  SKIP4: the track is [T][m][4] joint
+// records (x, y, z, score) and every fourth lane is copied, not filtered (triangulation.py:169-184 filters the points only).
+constexpr int kScanL = 32, kScanWaves = 8, kScanSuper = kScanL * kScanWaves, kScanThreads = 64 * kScanWaves;
+// A wave publishes (y, yd) per lane, then the flag.  Everything that crosses workgroups -- they may sit on different XCDs, whose L2s
+// are not coherent with one another -- goes through agent-scope atomics (sc1: written through to / read from the memory side),
+// and the flag is stored once the state's stores have been acknowledged (s_waitcnt vmcnt(0)).  A release FENCE instead
+// (__threadfence: write back the L2, 4 MB of it dirty with the track's own stores) and an acquire load per poll (invalidate)
+// cost ~2 us per link of a chain of hundreds: the first version of this kernel ran 2.7 x SLOWER than the three passes it replaces.
+__device__ __forceinline__ void scan_publish(double *dst, double vy, double vyd, unsigned int *flag, unsigned int value, int l) {
+    __hip_atomic_store(dst, vy, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(dst + 64, vyd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (l == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+static_assert(kScanSuper == 256, "a workgroup of the one-pass scan covers one chunk of the hold kernels (kSmoothChunk)");
+template <typename KS, typename HS, bool SKIP4>
+__global__ __launch_bounds__(kScanThreads) void k_smooth_scan(int64_t T, int64_t n, KS ks, HS hs, const double *__restrict__ x,
+                                                              const double *__restrict__ seed_row, double *__restrict__ y,
+                                                              unsigned int *ticket, unsigned int *flags, double *agg, double *incl) {
+    __shared__ unsigned int s_bid;
+    __shared__ double s_e[kScanWaves][2][64];
+    __shared__ double s_in[2][64];
+    const int tid = threadIdx.x, l = tid & 63;
+    const int w = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid == 0) s_bid = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const unsigned int bid = s_bid;
+    const unsigned int ncols = (unsigned int)((n + 63) >> 6);
+    const unsigned int sc = bid / ncols, col = bid - sc * ncols;
+    const int64_t lane = (int64_t)col * 64 + l;
+    const bool live = lane < n;
+    const int64_t lc = live ? lane : n - 1;   // (idle lanes of the last column read the last lane's data and store nothing)
+    const SmoothCoef k = ks.at(lc);
+    const int64_t t0 = 1 + (int64_t)sc * kScanSuper + (int64_t)w * kScanL;   // frames 1 .. T-1 are the filtered ones
+    const int nt = (int)(T - t0 < 0 ? 0 : (T - t0 > kScanL ? kScanL : T - t0));
+    const int64_t nv = hs.groups(n), g = hs.group(lc);
+    // ---- A: this wave's frames into registers, zero-state end state
+    double xv[kScanL];
+    unsigned int okm = 0xffffffffu;   // bit u: frame t0 + u carries a valid point (HoldInput; one register instead of 32 flags)
+    double x_enter = nt > 0 ? hs.entering(x, t0, (int64_t)sc, n, lc) : 0.0;   // the input in front of frame t0 (HoldInput: of the WORKGROUP's first frame)
+    // Range-checked buffer accesses over the rows [t0, T) of x and y (byte offset = row * 8 n + 8 lane, all of it in the
+    // per-lane offset): a frame behind the track's end reads zeros and its store is dropped, so the 32 loads and the 32
+    // stores of a wave are branch-free (with `if (u < nt)` around each the compiler built a branch per frame and kept
+    // 170 VGPRs: one workgroup per CU).  A partial wave's end state is then garbage -- and unused: only later frames
+    // would read it.  Idle lanes of the last column get an offset no descriptor covers.
+    typedef unsigned scan_u2 __attribute__((ext_vector_type(2)));
+    const int64_t rows_left = T - t0 > 0 ? T - t0 : 0;
+    const unsigned long long span = (unsigned long long)rows_left * (unsigned long long)n * 8ull;
+    // (a wave's offsets stay below 32 x 8 n < 2^30: the host keeps n at 2^22 lanes at most; an idle lane starts at 2^31 and
+    // never wraps into the range -- it did, from 0xfffffff0, and wrote its garbage over lane 0's results: found by the n < 64 tests)
+    const unsigned int span32 = span > 0x7ffffff0ull ? 0x7ffffff0u : (unsigned int)span;
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(x + t0 * n), 0, (int)span32, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(y + t0 * n, 0, (int)span32, 0x00020000);
+    const unsigned int row_bytes = (unsigned int)n * 8u;
+    const unsigned int off0 = live ? (unsigned int)lane * 8u : 0x80000000u;
+    unsigned int off = off0;   // (a running offset: one register, not 32 kept for the stores)
+#pragma unroll
+    for (int u = 0; u < kScanL; u++, off += row_bytes) {
+        const scan_u2 wv = __builtin_amdgcn_raw_buffer_load_b64(rx, (int)off, 0, 0);
+        xv[u] = __hiloint2double((int)wv.y, (int)wv.x);
+        if constexpr (HS::kHold) {
+            const int64_t tt = t0 + u < T ? t0 + u : T - 1;
+            if (!hs.ok(tt * nv + g)) okm &= ~(1u << u);
+        }
+    }
+    if constexpr (HS::kHold) {
+        // an invalid point repeats the previous input (blender.py:157-160): the held input entering wave w is the last valid
+        // input of the nearest wave before it that has one, else the one entering the workgroup (start[sc], k_hold_carry)
+        double hv = 0.0;
+        bool hf = false;
+#pragma unroll
+        for (int u = 0; u < kScanL; u++)
+            if (u < nt && ((okm >> u) & 1u)) {   // (nt: a frame behind the track's end is not an input)
+                hv = xv[u];
+                hf = true;
+            }
+        s_e[w][0][l] = hv;
+        s_e[w][1][l] = hf ? 1.0 : 0.0;
+        __syncthreads();
+        for (int j = 0; j < w; j++)
+            if (s_e[j][1][l] != 0.0) x_enter = s_e[j][0][l];
+        __syncthreads();   // (s_e is rewritten below)
+    }
+    double sy = 0.0, syd = 0.0, xp = x_enter;
+    auto step = [&](double xraw, bool okt) {
+        const double xt = okt ? xraw : xp;
+        const double ct = fma(k.cxd, xt - xp, k.cx * xt);
+        xp = xt;
+        const double ny = fma(k.a01, syd, k.a00 * sy);
+        const double nyd = fma(k.a11, syd, fma(k.a10, sy, ct));
+        sy = ny;
+        syd = nyd;
+    };
+#pragma unroll
+    for (int u = 0; u < kScanL; u++) step(xv[u], !HS::kHold || ((okm >> u) & 1u));
+    // (the inputs are laundered: otherwise the compiler keeps the 32 forcing terms c_t of this pass for the second one BESIDE
+    // the inputs the copied lanes need -- 128 registers of frame data, one workgroup per CU; recomputing c_t costs three
+    // instructions per frame of a kernel that waits for HBM)
+#pragma unroll
+    for (int u = 0; u < kScanL; u++) asm volatile("" : "+v"(xv[u]));
+    s_e[w][0][l] = sy;
+    s_e[w][1][l] = syd;
+    __syncthreads();
+    // ---- B: zero-state state entering this wave; the last wave: the workgroup's aggregate
+    double zy = 0.0, zyd = 0.0;
+    for (int j = 0; j < w; j++) {
+        const double ey = s_e[j][0][l], eyd = s_e[j][1][l];
+        const double ny = fma(k.r01, zyd, fma(k.r00, zy, ey));
+        const double nyd = fma(k.r11, zyd, fma(k.r10, zy, eyd));
+        zy = ny;
+        zyd = nyd;
+    }
+    if (w == kScanWaves - 1) {
+        const double gy = fma(k.r01, zyd, fma(k.r00, zy, sy)), gyd = fma(k.r11, zyd, fma(k.r10, zy, syd));   // G = R z + e
+        const size_t slot = ((size_t)sc * ncols + col) * 128 + l;
+        double iny, inyd;   // S_in: the true state entering this workgroup
+        if (sc == 0) {
+            iny = seed_row[lc];   // (x_0, 0): frame 0 seeds the filters (:11-13)
+            inyd = 0.0;
+        } else {
+            scan_publish(agg + slot, gy, gyd, flags + (size_t)sc * ncols + col, 1u, l);
+            // ---- C: look back
+            double ay = 0.0, ayd = 0.0, m00 = 1.0, m01 = 0.0, m10 = 0.0, m11 = 1.0;   // acc, M = P^(steps so far)
+            for (int64_t b = (int64_t)sc - 1;; b--) {
+                unsigned int f;
+                while ((f = __hip_atomic_load(&flags[(size_t)b * ncols + col], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u)
+                    __builtin_amdgcn_s_sleep(1);
+                asm volatile("" ::: "memory");   // (the state is read behind the flag, by loads of the same coherence level: no cache to invalidate)
+                const double *src = (f == 2u ? incl : agg) + ((size_t)b * ncols + col) * 128 + l;
+                const double vy = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const double vyd = __hip_atomic_load(src + 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ay = fma(m01, vyd, fma(m00, vy, ay));
+                ayd = fma(m11, vyd, fma(m10, vy, ayd));
+                if (f == 2u) break;
+                const double t00 = fma(m00, k.p00, m01 * k.p10), t01 = fma(m00, k.p01, m01 * k.p11);   // M <- M P
+                const double t10 = fma(m10, k.p00, m11 * k.p10), t11 = fma(m10, k.p01, m11 * k.p11);
+                m00 = t00; m01 = t01; m10 = t10; m11 = t11;
+            }
+            iny = ay;
+            inyd = ayd;
+        }
+        // the state BEHIND this workgroup: P S_in + G
+        scan_publish(incl + slot, fma(k.p01, inyd, fma(k.p00, iny, gy)), fma(k.p11, inyd, fma(k.p10, iny, gyd)), flags + (size_t)sc * ncols + col, 2u, l);
+        s_in[0][l] = iny;
+        s_in[1][l] = inyd;
+    }
+    __syncthreads();
+    // ---- D: the true state entering this wave, then the exact recurrence over the registers
+    sy = s_in[0][l];
+    syd = s_in[1][l];
+    for (int j = 0; j < w; j++) {
+        const double ny = fma(k.r01, syd, k.r00 * sy), nyd = fma(k.r11, syd, k.r10 * sy);
+        sy = ny;
+        syd = nyd;
+    }
+    sy += zy;
+    syd += zyd;
+    xp = x_enter;
+    const bool copy = SKIP4 && (lane & 3) == 3;
+    if (sc == 0 && w == 0 && live) y[lane] = x[lane];   // frame 0 passes through (:180-181)
+    off = off0;
+    asm volatile("" : "+v"(off));   // (not the offsets of the loads again: they would live across the whole kernel)
+#pragma unroll
+    for (int u = 0; u < kScanL; u++, off += row_bytes) {
+        step(xv[u], !HS::kHold || ((okm >> u) & 1u));
+        const double out = copy ? xv[u] : sy;
+        scan_u2 ow;
+        ow.x = (unsigned int)__double2loint(out);
+        ow.y = (unsigned int)__double2hiint(out);
+        __builtin_amdgcn_raw_buffer_store_b64(ow, ry, (int)off, 0, 0);
+        if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // a frame's store leaves with its step: the results are not collected in registers first
+    }
 }
 
 // Sharded track (snowtri_smooth_shard_local / _fix): the true state entering shard `rank` from the gathered carries of the

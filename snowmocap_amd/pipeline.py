@@ -85,11 +85,9 @@ class TrackPipeline:
                                                 ct.c_void_p(v_out.data_ptr()), _lib.DEVICE, st), "snowtri_blender_points")
 
         if tracked is None:
-            n = self.P * self.kn * 4
-            sm = torch.empty_like(xyzs)
-            _lib.check(L.snowtri_smooth_track(h, F, n, ct.c_void_p(xyzs.data_ptr()), *fzrd, ct.c_void_p(sm.data_ptr()), _lib.DEVICE, st),
-                       "snowtri_smooth_track")
-            sm[..., 3] = xyzs[..., 3]                      # only the points are filtered (triangulation.py:169-184)
+            sm = torch.empty_like(xyzs)                    # only the points are filtered, the scores copied (triangulation.py:169-184)
+            _lib.check(L.snowtri_smooth_joint_track(h, F, self.P * self.kn, ct.c_void_p(xyzs.data_ptr()), *fzrd, ct.c_void_p(sm.data_ptr()),
+                                                    _lib.DEVICE, st), "snowtri_smooth_joint_track")
             blender_points(sm, F * self.P, pts, val)
             pts_s = torch.empty_like(pts)
             _lib.check(L.snowtri_blender_smooth(h, F, self.P, ct.c_void_p(pts.data_ptr()), ct.c_void_p(val.data_ptr()),
@@ -108,9 +106,8 @@ class TrackPipeline:
                 T = int(idx.numel())
                 xi = xyzs[idx, i].contiguous()                                  # [T, kn, 4]
                 si = torch.empty_like(xi)
-                _lib.check(L.snowtri_smooth_track(h, T, self.kn * 4, ct.c_void_p(xi.data_ptr()), *fzrd, ct.c_void_p(si.data_ptr()),
-                                                  _lib.DEVICE, st), "snowtri_smooth_track")
-                si[..., 3] = xi[..., 3]
+                _lib.check(L.snowtri_smooth_joint_track(h, T, self.kn, ct.c_void_p(xi.data_ptr()), *fzrd, ct.c_void_p(si.data_ptr()),
+                                                        _lib.DEVICE, st), "snowtri_smooth_joint_track")
                 pi = torch.empty((T, 1, 24, 4), dtype=torch.float64, device=dev)
                 vi = torch.empty((T, 1, 24), dtype=torch.uint8, device=dev)
                 blender_points(si, T, pi, vi)

@@ -92,6 +92,7 @@ int main(void) {
                                            SNOWTRI_F32, ibuf, ubuf, SNOWTRI_HOST, NULL, SNOWTRI_CALL_NO_ZERO_FILL),
            SNOWTRI_ERR_BAD_ARG);
     EXPECT(snowtri_smooth_track(NULL, 4, 3, buf, 2.0, 0.75, 0.0, 1.0 / 30, buf, SNOWTRI_HOST, NULL), SNOWTRI_ERR_BAD_ARG);
+    EXPECT(snowtri_smooth_joint_track(NULL, 4, 3, buf, 2.0, 0.75, 0.0, 1.0 / 30, buf, SNOWTRI_HOST, NULL), SNOWTRI_ERR_BAD_ARG);
     EXPECT(snowtri_smooth_shard_local(NULL, 4, 3, buf, 1, 2.0, 0.75, 0.0, 1.0 / 30, buf, buf, SNOWTRI_HOST, NULL),
            SNOWTRI_ERR_BAD_ARG);
     EXPECT(snowtri_smooth_shard_fix(NULL, 4, 3, 1, buf, 2.0, 0.75, 0.0, 1.0 / 30, buf, SNOWTRI_HOST, NULL),
@@ -206,6 +207,8 @@ int main(void) {
         EXPECT(snowtri_smooth_track(ctx, 4, 3, buf, -2.0, 0.75, 0.0, 1.0 / 30, buf, SNOWTRI_HOST, NULL), SNOWTRI_ERR_BAD_ARG);
         EXPECT(snowtri_smooth_track(ctx, 4, 3, NULL, 2.0, 0.75, 0.0, 1.0 / 30, buf, SNOWTRI_HOST, NULL), SNOWTRI_ERR_BAD_ARG);
         EXPECT(snowtri_smooth_track(ctx, -1, 3, buf, 2.0, 0.75, 0.0, 1.0 / 30, buf, SNOWTRI_HOST, NULL), SNOWTRI_ERR_BAD_ARG);
+        EXPECT(snowtri_smooth_joint_track(ctx, 4, -1, buf, 2.0, 0.75, 0.0, 1.0 / 30, buf, SNOWTRI_HOST, NULL), SNOWTRI_ERR_BAD_ARG);
+        EXPECT(snowtri_smooth_joint_track(ctx, 4, 3, NULL, 2.0, 0.75, 0.0, 1.0 / 30, buf, SNOWTRI_HOST, NULL), SNOWTRI_ERR_BAD_ARG);
         EXPECT(snowtri_blender_points(ctx, 1, 100, buf, SNOWTRI_F64, buf, bbuf, SNOWTRI_HOST, NULL), SNOWTRI_ERR_BAD_INDEX);
         EXPECT(snowtri_blender_points(ctx, 1, 133, buf, 5, buf, bbuf, SNOWTRI_HOST, NULL), SNOWTRI_ERR_BAD_ARG);
         EXPECT(snowtri_blender_smooth(ctx, 2, 1, buf, bbuf, NULL, 1.0 / 30, buf, SNOWTRI_HOST, NULL), SNOWTRI_ERR_BAD_ARG);

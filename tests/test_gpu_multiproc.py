@@ -188,7 +188,13 @@ def _full_worker(rank, world, port, case, tmp):
         wall = time.perf_counter() - t0
         expect(not bool(out["rank_status"].any()), f"rank_status compact={compact}")
         if multi:
-            expect(st.bt.ctx.last_stream_counts() == (0, 0, 0), f"fall-back counters {st.bt.ctx.last_stream_counts()} compact={compact}")
+            # (last segment of the last piece.)  No frame may leave the streaming route -- [0] second association launch,
+            # [2] k_frame_recompute.  [1] counts frames with a candidate whose mean lay within 1e-6 of average_score_threshold
+            # and was re-done exactly (the numerics contract): on 12 500 FRESH frames x 7 680 candidates a handful do -- the
+            # tiled 250-frame batches of the other tests never met one -- so it is recorded and bounded, not required to be 0
+            sc = st.bt.ctx.last_stream_counts()
+            expect(sc[0] == 0 and sc[2] == 0 and 0 <= sc[1] <= 16, f"fall-back counters {sc} compact={compact}")
+            rec.setdefault("exactly_resummed_frames_last_segment", {})["compact" if compact else "padded"] = sc[1]
         # kernels alone, same pieces, no gather: what the rank computes while it waits for the exchange
         t1 = time.perf_counter()
         st.run(kp, F, npers, gather=False)
