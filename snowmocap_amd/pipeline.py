@@ -152,12 +152,17 @@ class ShardedTrackPipeline:
 
         A1-A4 on the block  ->  N1 with the carry exchange (4n + 1 doubles per rank, sharded.smooth_track_sharded)
         ->  N2 control points (per frame)  ->  N2 per-bone filters with the hold exchange + the carry exchange
-        (sharded.blender_smooth_sharded)  ->  ONE all-gather of [F, P, 24, 4] float64 + valid [F, P, 24]
+        (sharded.blender_smooth_sharded)  ->  ONE all-gather of [F, P, 24, 4] float64 + valid [F, P, 24] + tracked [F]
 
     instead of gathering the [F, P, kn, 4] joint track first (at roofline speed that gather is ~8x the kernel):
-    792 + 24 bytes per person and frame against 2 128 for 133 float32 joints.  Every frame must resolve to exactly
-    n_persons_out persons (the reference's list-index matching with a varying count needs the counts of ALL earlier
-    frames: TrackPipeline handles that on one GPU); a rank that sees another count makes every rank raise."""
+    792 + 24 bytes per person and frame against 2 128 for 133 float32 joints.
+    A person count that varies from frame to frame follows the reference, as TrackPipeline.run(ragged="reference") does on one
+    GPU (round-5 review, item 4): the filter banks are those of frame 0 and `zip` matches a frame's persons to them by list
+    index (triangulation.py:169-171, blender.py:152-166), so frame f carries tracked[f] = min(count[f], count[0]) persons.
+    That needs ONE number of another rank -- count[0], handed round with the ranks' error bits (sharded.tracked_counts) --
+    and per slot i the frames with tracked > i that a rank holds are a block of the slot's own frame sequence: the N1 carry
+    exchange and the N2 hold + carry exchanges run on those blocks unchanged (an empty block is a rank none of whose frames
+    carries the slot; the block with frame 0 starts the sequence)."""
 
     def __init__(self, K, R, t, thresholds, blender_smooth_profile, n_persons_out=1, device=0, group=None, method=_lib.PAIRWISE):
         self.pipe = TrackPipeline(K, R, t, thresholds, blender_smooth_profile, n_persons_out=n_persons_out, device=device, method=method)
@@ -167,12 +172,13 @@ class ShardedTrackPipeline:
     def close(self):
         self.pipe.close()
 
-    def run(self, kpts_local, F_total, n_persons_local=None, gather=True):
+    def run(self, kpts_local, F_total, n_persons_local=None, gather=True, ragged="reference"):
         """kpts_local [T_r, C, Pmax, J, 3] CUDA tensor: the block shard_bounds(F_total, world, rank) gives this rank.  Returns
-        points_smoothed / valid of the WHOLE track on every rank (gather=True) or of the block, plus the block's own stages."""
+        points_smoothed / valid / tracked of the WHOLE track on every rank (gather=True) or of the block, plus the block's own
+        stages.  ragged="refuse": every frame of every rank must resolve to exactly n_persons_out persons (round 4's contract)."""
         import torch
         import torch.distributed as dist
-        from .sharded import (all_gather_flat, blender_smooth_sharded, gather_track_chunked, shard_bounds, smooth_track_sharded)
+        from .sharded import (blender_smooth_sharded, gather_track_chunked, shard_bounds, smooth_track_sharded, tracked_counts)
         p = self.pipe
         dev = kpts_local.device
         rank, world = dist.get_rank(self.group), dist.get_world_size(self.group)
@@ -187,39 +193,65 @@ class ShardedTrackPipeline:
             tri = p.bt.run_torch(kpts_local, n_persons_local)
         else:
             tri = p.bt.alloc_outputs(0, dev)
-        # every rank learns whether every block is usable BEFORE the exchanges below (nobody is left waiting in one)
-        bad = torch.zeros(2, dtype=torch.int32, device=dev)
+        # every rank learns count[0] and whether every block is usable BEFORE the exchanges below (nobody is left waiting in one)
+        bits = torch.zeros((), dtype=torch.int32, device=dev)
         if T:
-            bad[0] = (tri["count"] != P).any().to(torch.int32)
-            bad[1] = ((tri["flags"] & _lib.FLAG_SINGULAR) != 0).any().to(torch.int32)
-        allbad = torch.empty(2 * world, dtype=torch.int32, device=dev)
-        all_gather_flat(allbad, bad, group=self.group)
-        allbad = allbad.view(world, 2).cpu().numpy()
-        if allbad[:, 1].any():
-            raise np.linalg.LinAlgError(f"Singular matrix (a frame of rank(s) {np.nonzero(allbad[:, 1])[0].tolist()})")
-        if allbad[:, 0].any():
-            raise ValueError(f"a frame of rank(s) {np.nonzero(allbad[:, 0])[0].tolist()} did not resolve to {P} persons "
-                             "(varying person counts: TrackPipeline on one GPU)")
+            bits = (((tri["flags"] & _lib.FLAG_SINGULAR) != 0).any().to(torch.int32) + 2 * (tri["count"] != P).any().to(torch.int32)).to(torch.int32)
+        tracked, count0, bits = tracked_counts(tri["count"], int(F_total), P, group=self.group, flag_bits=bits)
+        if bits & 1:
+            raise np.linalg.LinAlgError("Singular matrix (a frame of some rank)")     # the reference's np.linalg.inv raises (triangulation.py:26)
+        if (bits & 2) and ragged == "refuse":
+            raise ValueError(f"a frame of some rank did not resolve to {P} persons (ragged=\"refuse\")")
         xyzs = tri["xyzs"]
-        sm = smooth_track_sharded(xyzs.view(T, P * kn * 4) if T else xyzs.reshape(0, P * kn * 4), f=th["smooth_f"], z=th["smooth_z"],
-                                  r=th["smooth_r"], delta_time=th["smooth_delta_time"], group=self.group, ctx=p.bt.ctx,
-                                  F_total=F_total).view(T, P, kn, 4)
+        fkw = dict(f=th["smooth_f"], z=th["smooth_z"], r=th["smooth_r"], delta_time=th["smooth_delta_time"], group=self.group, ctx=p.bt.ctx)
         pts = torch.empty((T, P, 24, 4), dtype=torch.float64, device=dev)
         val = torch.empty((T, P, 24), dtype=torch.uint8, device=dev)
-        if T:
-            sm[..., 3] = xyzs[..., 3]                  # only the points are filtered (triangulation.py:169-184)
-            _lib.check(L.snowtri_blender_points(h, T * P, kn, ct.c_void_p(sm.data_ptr()), _lib.F64, ct.c_void_p(pts.data_ptr()),
-                                                ct.c_void_p(val.data_ptr()), _lib.DEVICE, st), "snowtri_blender_points")
-        pts_s = blender_smooth_sharded(pts, val, p.fzr, th["smooth_delta_time"], group=self.group, ctx=p.bt.ctx, F_total=F_total)
+
+        def blender_points(x, n_, p_out, v_out):
+            _lib.check(L.snowtri_blender_points(h, n_, kn, ct.c_void_p(x.data_ptr()), _lib.F64, ct.c_void_p(p_out.data_ptr()),
+                                                ct.c_void_p(v_out.data_ptr()), _lib.DEVICE, st), "snowtri_blender_points")
+
+        if not (bits & 2):
+            # every frame of every rank carries all P slots: the whole block at once
+            sm = smooth_track_sharded(xyzs.view(T, P * kn * 4) if T else xyzs.reshape(0, P * kn * 4), F_total=F_total, **fkw).view(T, P, kn, 4)
+            if T:
+                sm[..., 3] = xyzs[..., 3]                  # only the points are filtered (triangulation.py:169-184)
+                blender_points(sm, T * P, pts, val)
+            pts_s = blender_smooth_sharded(pts, val, p.fzr, th["smooth_delta_time"], group=self.group, ctx=p.bt.ctx, F_total=F_total)
+        else:
+            # slot by slot over the frames that carry it; every rank walks the SAME count0 slots (the exchanges are collectives)
+            sm = torch.zeros_like(xyzs)
+            pts.zero_()
+            val.zero_()
+            pts_s = torch.zeros_like(pts)
+            holds0 = lo == 0 and hi > 0                    # frame 0 carries every tracked slot: its rank starts every slot's sequence
+            for i in range(count0):
+                idx = torch.nonzero(tracked > i).view(-1)
+                Ti = int(idx.numel())
+                xi = xyzs[idx, i].contiguous().view(Ti, kn * 4)
+                si = smooth_track_sharded(xi, first=holds0 and Ti > 0, **fkw).view(Ti, kn, 4)
+                pi = torch.empty((Ti, 1, 24, 4), dtype=torch.float64, device=dev)
+                vi = torch.empty((Ti, 1, 24), dtype=torch.uint8, device=dev)
+                if Ti:
+                    si[..., 3] = xi.view(Ti, kn, 4)[..., 3]
+                    blender_points(si, Ti, pi, vi)
+                qi = blender_smooth_sharded(pi, vi, p.fzr, th["smooth_delta_time"], group=self.group, ctx=p.bt.ctx, first=holds0 and Ti > 0)
+                if Ti:
+                    sm[idx, i] = si
+                    pts[idx, i] = pi[:, 0]
+                    val[idx, i] = vi[:, 0]
+                    pts_s[idx, i] = qi[:, 0]
         out = dict(xyzs_local=xyzs, smoothed_local=sm, points_local=pts, valid_local=val, points_smoothed_local=pts_s,
-                   count_local=tri["count"], flags_local=tri["flags"])
+                   count_local=tri["count"], flags_local=tri["flags"], tracked_local=tracked, count0=count0)
         if gather:
             def copy_block(lo_, hi_, views):
                 views["points_smoothed"][: hi_ - lo_] = pts_s[lo_:hi_]
                 views["valid"][: hi_ - lo_] = val[lo_:hi_]
-            g = gather_track_chunked(copy_block, T, int(F_total), {"points_smoothed": ((P, 24, 4), torch.float64), "valid": ((P, 24), torch.uint8)},
+                views["tracked"][: hi_ - lo_] = tracked[lo_:hi_]
+            g = gather_track_chunked(copy_block, T, int(F_total), {"points_smoothed": ((P, 24, 4), torch.float64), "valid": ((P, 24), torch.uint8),
+                                                                   "tracked": ((), torch.int32)},
                                      chunks=1, group=self.group, device=dev)
-            out["points_smoothed"], out["valid"] = g["points_smoothed"], g["valid"]
-            out["gather_bytes"] = world * per * (P * 24 * 4 * 8 + P * 24) + world * 16
+            out["points_smoothed"], out["valid"], out["tracked"] = g["points_smoothed"], g["valid"], g["tracked"]
+            out["gather_bytes"] = world * per * (P * 24 * 4 * 8 + P * 24 + 4) + world * 16
             out["gather_bytes_joint_track"] = world * per * (P * kn * 16 + P * 4 + 8)
         return out

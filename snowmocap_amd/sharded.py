@@ -470,6 +470,46 @@ class ShardedTriangulator:
 
 
 # ---------------------------------------------------------------------------------------------------
+# Person counts that vary from frame to frame, on a frame-sharded track.  The reference identifies persons by LIST INDEX and its
+# filter banks are those of frame 0: `zip` truncates every later frame against them (triangulation.py:169-171, blender.py:152-166),
+# so frame f carries tracked[f] = min(count[f], count[0]) persons and slot i is filtered over the frames with tracked > i -- in frame
+# order, frame 0 among them (it seeds the slot).  Nothing of that depends on EARLIER frames except through count[0]: one small
+# exchange hands every rank count[0], and per slot the frames a rank holds are a contiguous-in-order piece of the slot's sequence,
+# i.e. exactly a "block" of the carry exchanges below (blocks may be empty; the block that holds frame 0 starts the track).
+
+def tracked_counts(count_local, F_total, n_slots, group=None, flag_bits=0):
+    """count_local [T_r] int32: the person counts of this rank's shard_bounds block.  ONE all-gather of 3 int32 per rank ->
+    (tracked_local [T_r] int32 = min(count, count[0]), count0, bits): count0 = the count of frame 0 of the TRACK (from the
+    rank that holds it), bits = OR over the ranks of `flag_bits` (an int or an int32 scalar tensor of this rank's condition bits,
+    e.g. 1 = "a singular frame"): every rank learns them before the exchanges that follow, so all raise together and nobody is
+    left waiting in a collective.  Raises ValueError on every rank if frame 0 holds more persons than the track has slots."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    lo, hi, _ = shard_bounds(int(F_total), world, rank)
+    if hi - lo != int(count_local.shape[0]):
+        raise ValueError(f"tracked_counts: rank {rank} holds {int(count_local.shape[0])} frames, shard_bounds gives it [{lo}, {hi})")
+    dev = count_local.device
+    mine = torch.zeros(3, dtype=torch.int32, device=dev)
+    if lo == 0 and hi > 0:
+        mine[0] = 1
+        mine[1] = count_local[0]
+    mine[2] = flag_bits.to(device=dev, dtype=torch.int32) if torch.is_tensor(flag_bits) else int(flag_bits)
+    allr = torch.empty(3 * world, dtype=torch.int32, device=dev)
+    all_gather_flat(allr, mine, group=group)
+    allr = allr.view(world, 3).cpu()
+    holders = [q for q in range(world) if int(allr[q, 0])]
+    count0 = int(allr[holders[0], 1]) if holders else 0
+    if count0 > int(n_slots):
+        raise ValueError(f"frame 0 resolved to {count0} persons, the track has {int(n_slots)} slots (n_persons_out)")
+    tracked = torch.clamp(count_local, max=count0).to(torch.int32)
+    bits = 0
+    for q in range(world):
+        bits |= int(allr[q, 2])
+    return tracked, count0, bits
+
+
+# ---------------------------------------------------------------------------------------------------
 # Row N1 on the sharded track: temporal smoothing WITHOUT reassembling the track.
 # The filter state obeys s_t = A s_{t-1} + b_t (snowtri_smooth.hpp), so each rank filters its own frame
 # block from a zero entering state, the ranks exchange ONE small all-gather (4n+1 doubles each: end state,
@@ -555,18 +595,18 @@ def smooth_exchange(x_local, local_fn, combine_fn, fix_fn, group=None, first=Non
     return y
 
 
-def smooth_track_sharded(x_local, f=2, z=0.75, r=0, delta_time=1 / 30, group=None, ctx=None, F_total=None):
+def smooth_track_sharded(x_local, f=2, z=0.75, r=0, delta_time=1 / 30, group=None, ctx=None, F_total=None, first=None):
     """x_local: this rank's frame block [T_r, ...] (CUDA float64 tensor, frame-major) of a track sharded in
     frame order over the ranks of `group`.  Returns the filtered block; the full track is never gathered.
     F_total (optional): the length of the whole track -- the block is then checked against shard_bounds and "this block
-    starts the track" is derived from it instead of assumed for rank 0."""
+    starts the track" is derived from it instead of assumed for rank 0.  first (optional, without F_total): says it outright --
+    for blocks that are NOT shard_bounds blocks, e.g. the frames of a block that carry one person slot (ShardedTrackPipeline)."""
     import ctypes as ct
     import torch
     import torch.distributed as dist
     from . import _lib
     assert x_local.is_cuda and x_local.dtype == torch.float64 and x_local.is_contiguous()
     rank, world = dist.get_rank(group), dist.get_world_size(group)
-    first = None
     if F_total is not None:
         lo, hi, _ = shard_bounds(int(F_total), world, rank)
         if hi - lo != int(x_local.shape[0]):
@@ -624,7 +664,7 @@ def hold_exchange(pts_local, val_local, last_fn, apply_fn, group=None):
     return held
 
 
-def blender_smooth_sharded(pts_local, val_local, fzr, delta_time=1 / 30, group=None, ctx=None, F_total=None):
+def blender_smooth_sharded(pts_local, val_local, fzr, delta_time=1 / 30, group=None, ctx=None, F_total=None, first=None):
     """pts_local [T_r, P, 24, 4] (CUDA float64), val_local [T_r, P, 24] (CUDA uint8): this rank's frame block of a control-point
     track sharded in frame order.  Returns the smoothed block [T_r, P, 24, 4] = the rows snowtri_blender_smooth returns for
     these frames on the whole track (to rounding: the carries are propagated in closed form).  Two small all-gathers
@@ -638,7 +678,6 @@ def blender_smooth_sharded(pts_local, val_local, fzr, delta_time=1 / 30, group=N
     assert val_local.is_cuda and val_local.dtype == torch.uint8 and val_local.is_contiguous()
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     T, P = int(pts_local.shape[0]), int(pts_local.shape[1])
-    first = None
     if F_total is not None:
         lo, hi, _ = shard_bounds(int(F_total), world, rank)
         if hi - lo != T:

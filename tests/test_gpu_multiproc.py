@@ -285,3 +285,113 @@ def test_baseline_configs_3_and_4_at_full_size_over_eight_ranks(tmp_path, case):
     if os.path.isdir(out_dir):
         with open(os.path.join(out_dir, "multiproc_full.jsonl"), "a") as fh:
             fh.write(json.dumps(line) + "\n")
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# ShardedTrackPipeline with a person count that varies from frame to frame (round-5 review, item 4): the reference's list-index
+# semantics -- banks of frame 0, zip truncation -- on a frame shard: ONE exchange of count[0] with the ranks' error bits, then per
+# slot the carry / hold exchanges on the frames that carry the slot.  Four processes on the GPU: (a) fixture G9 -- the reference's
+# own main.py loop on an 8-camera sequence with 0 ... 7 persons per frame -- must come out as the reference's JSON; (b) a
+# BASELINE configs[2] batch (8 x 4, ~5 persons per frame with ghosts) must equal TrackPipeline.run(ragged="reference") on one GPU.
+
+def _ragged_worker(rank, world, port, tmp):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    import json
+    import torch
+    import torch.distributed as dist
+    from conftest import GOLDEN
+    from snowmocap_amd import synth
+    from snowmocap_amd.blender import CONTROL_POINT_NAMES
+    from snowmocap_amd.pipeline import ShardedTrackPipeline, TrackPipeline
+    from snowmocap_amd.sharded import shard_bounds
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    ok, notes = True, []
+
+    def expect(cond, what):
+        nonlocal ok
+        if not cond:
+            ok = False
+            notes.append(what)
+
+    def both(K, R, t, th, smo, slots, kp, npers, tol):
+        F = int(kp.shape[0])
+        lo, hi, _ = shard_bounds(F, world, rank)
+        one = TrackPipeline(K, R, t, th, smo, n_persons_out=slots)
+        ref = one.run(kp, npers)
+        torch.cuda.synchronize(dev)
+        ref = {k: v.clone() for k, v in ref.items()}
+        one.close()
+        sp = ShardedTrackPipeline(K, R, t, th, smo, n_persons_out=slots, device=0)
+        got = sp.run(kp[lo:hi].contiguous(), F, npers[lo:hi].contiguous())
+        torch.cuda.synchronize(dev)
+        expect(torch.equal(got["tracked"], ref["tracked"]), "tracked")
+        expect(torch.equal(got["valid"], ref["valid"]), "valid")
+        expect(got["count0"] == int(ref["count"][0]), "count0")
+        live = (torch.arange(slots, device=dev)[None, :] < ref["tracked"][:, None])
+        fin = torch.isfinite(ref["points_smoothed"]) & live[:, :, None, None]
+        e = float((got["points_smoothed"][fin] - ref["points_smoothed"][fin]).abs().max()) if bool(fin.any()) else 0.0
+        expect(e < tol, f"animation track differs by {e}")
+        expect(torch.equal(torch.isnan(got["points_smoothed"]), torch.isnan(ref["points_smoothed"])), "NaN pattern of the animation track")
+        expect(not bool(got["points_smoothed"][~live].any()), "slots behind tracked[f] must stay zero")
+        if hi > lo:
+            e1 = float((got["smoothed_local"][..., :3] - ref["smoothed"][lo:hi][..., :3]).abs().max())
+            expect(e1 < tol, f"N1 of the block differs by {e1}")
+        sp.close()
+        return got, ref
+
+    # (a) fixture G9: the reference's JSON
+    z = np.load(f"{GOLDEN}/g9_pipeline_multi.npz")
+    th, arm, smo = json.loads(str(z["thresholds"])), json.loads(str(z["armature"])), json.loads(str(z["smooth"]))
+    want = json.loads(str(z["result"]))
+    kp = torch.from_numpy(z["kpts"]).to(dev)
+    npers = torch.from_numpy(z["n_persons"].astype(np.int32)).to(dev)
+    got, _ = both(z["K"], z["R"], z["t"], th, smo, 8, kp, npers, 1e-9)
+    expect(np.array_equal(got["tracked"].cpu().numpy(), z["tracked"]), "G9: tracked")
+    res = TrackPipeline.to_blender_result(got["points_smoothed"], got["valid"], arm, got["tracked"])
+    expect(len(res) == len(want), "G9: frames")
+    worst = 0.0
+    for f, (g, w) in enumerate(zip(res, want)):
+        expect(len(g["armature"]) == len(w["armature"]) == int(z["tracked"][f]) and g["score"] == w["score"], f"G9 frame {f}: persons / scores")
+        for ga, wa in zip(g["armature"], w["armature"]):
+            for name, vec in wa.items():
+                worst = max(worst, float(np.abs(np.asarray(ga[name]) - np.asarray(vec)).max()))
+    expect(worst < 1e-8, f"G9: the reference's JSON differs by {worst}")
+    # (b) a BASELINE configs[2] batch: ~5 persons per frame, the count varies
+    wl = synth.config_workload(3, 300, seed=11)
+    K, R, t = wl["rig"]
+    th2 = dict(synth.default_thresholds(), **wl["params"])
+    smo2 = {nm: [1.5 + 0.1 * i, 0.75, 0.1 * (i % 3)] for i, nm in enumerate(CONTROL_POINT_NAMES)}
+    kp2 = torch.from_numpy(wl["kpts"]).to(dev).repeat(5, 1, 1, 1, 1)[:1403].contiguous()      # 1 403 frames: uneven blocks
+    np2 = torch.from_numpy(wl["n_persons"]).to(dev).repeat(5, 1)[:1403].contiguous()
+    got2, ref2 = both(K, R, t, th2, smo2, 10, kp2, np2, 1e-9)
+    expect(len(set(ref2["count"].cpu().numpy().tolist())) > 1, "configs[2] batch: the count should vary")
+    expect(got2["gather_bytes"] < 0.5 * got2["gather_bytes_joint_track"], "gathers the control points, not the joints")
+    # ragged="refuse" raises on EVERY rank (the bits travel with count[0]): nobody hangs
+    sp = ShardedTrackPipeline(K, R, t, th2, smo2, n_persons_out=10, device=0)
+    lo, hi, _ = shard_bounds(1403, world, rank)
+    try:
+        sp.run(kp2[lo:hi].contiguous(), 1403, np2[lo:hi].contiguous(), ragged="refuse")
+        expect(False, "ragged=refuse did not raise")
+    except ValueError:
+        pass
+    sp.close()
+    np.save(os.path.join(tmp, f"ok{rank}.npy"), np.array([ok]))
+    if notes:
+        with open(os.path.join(tmp, f"notes{rank}.txt"), "w") as fh:
+            fh.write("\n".join(notes))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_pipeline_with_varying_person_counts_on_four_ranks(tmp_path):
+    import torch.multiprocessing as mp
+    world = 4
+    port = 26000 + (os.getpid() * 11) % 1500
+    mp.spawn(_ragged_worker, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        note = tmp_path / f"notes{r}.txt"
+        assert np.load(tmp_path / f"ok{r}.npy").all(), f"rank {r}: " + (note.read_text() if note.exists() else "?")

@@ -355,6 +355,89 @@ def test_eight_rank_sharded_blender_smoothing_matches_the_sequential_filters(tmp
     np.testing.assert_allclose(got, want, rtol=0, atol=1e-10)
 
 
+def _ragged_worker(rank, port, T, P, tmp):
+    """The sharded form of the reference's list-index semantics (triangulation.py:169-171: banks of frame 0, zip truncation) with
+    the host twins of the kernels: tracked_counts hands count[0] round, then slot i is filtered over the frames with
+    tracked > i -- per rank a block of the slot's own sequence, possibly EMPTY -- with the carry exchange."""
+    _init(rank, port)
+    from snowmocap_amd.sharded import combine_carries, smooth_exchange, tracked_counts
+    f, z, r, dt = 2.5, 0.75, 0.6, 1 / 30
+    A, cx, cxd = _coeffs(f, z, r, dt)
+    n = 5
+    rng = np.random.default_rng(9)
+    x = np.cumsum(rng.normal(0, 0.01, size=(T, P, n)), axis=0) + 1.0          # the same track and counts on every rank
+    count = rng.integers(0, P + 3, size=T).astype(np.int32)
+    count[0] = P - 1                                                          # the banks of frame 0: P - 1 slots are ever tracked
+    if T > 9:
+        count[5:9] = 0                                                        # frames nobody is tracked in
+    lo, hi, _ = shard_bounds(T, WORLD, rank)
+    tracked, count0, bits = tracked_counts(torch.from_numpy(count[lo:hi].copy()), T, P, flag_bits=4 if rank == 3 else 0)
+    ok = count0 == P - 1 and bits == 4 and np.array_equal(tracked.numpy(), np.minimum(count[lo:hi], count0))
+
+    def local_fn(xl, first, y, payload):
+        xv = xl.numpy()
+        s = np.zeros((n, 2))
+        yv = np.zeros_like(xv)
+        if first:
+            yv[0] = xv[0]
+        xp = xv[0].copy()
+        for t in range(1 if first else 0, xv.shape[0]):
+            c = cx * xv[t] + cxd * (xv[t] - xp)
+            xp = xv[t]
+            s = s @ A.T + np.stack([np.zeros(n), c], axis=1)
+            yv[t] = s[:, 0]
+        y.copy_(torch.from_numpy(yv))
+        payload[: 2 * n] = torch.from_numpy(s.reshape(-1))
+
+    def combine_fn(allp, rk, start):
+        a = allp.numpy()
+        payloads = [(a[q, : 2 * n].reshape(n, 2), a[q, 2 * n:3 * n], a[q, 3 * n:4 * n], a[q, 4 * n]) for q in range(WORLD)]
+        start.copy_(torch.from_numpy(combine_carries(payloads, rk, A, cxd)))
+
+    def fix_fn(y, first, start):
+        v = start.numpy().copy()
+        yv = y.numpy()
+        for t in range(1 if first else 0, yv.shape[0]):
+            v = v @ A.T
+            yv[t] += v[:, 0]
+
+    out = np.zeros((hi - lo, P, n))
+    holds0 = lo == 0 and hi > 0
+    for i in range(count0):                                                   # every rank walks the same slots: the exchanges are collectives
+        idx = np.nonzero(tracked.numpy() > i)[0]
+        xi = torch.from_numpy(x[lo:hi][idx, i].copy())
+        yi = smooth_exchange(xi, local_fn, combine_fn, fix_fn, first=holds0 and len(idx) > 0)
+        out[idx, i] = yi.numpy()
+    np.save(os.path.join(tmp, f"y{rank}.npy"), out)
+    np.save(os.path.join(tmp, f"ok{rank}.npy"), np.array([ok]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("T,P", [(97, 4), (11, 3), (5, 2)])
+def test_eight_rank_list_index_semantics_of_a_varying_person_count(tmp_path, T, P):
+    """Against the reference's own protocol run frame by frame: filter banks created at frame 0 for its persons, `zip(persons,
+    banks)` per later frame -- a bank is stepped only in frames that carry its slot (its time stands still otherwise), persons
+    beyond the banks are dropped.  11 and 5 frames over 8 ranks: blocks of 2 / 1 frames and EMPTY trailing blocks, and ranks
+    whose frames carry no person of a slot at all."""
+    from oracle import oracle as orc
+    mp.spawn(_ragged_worker, args=(_port(T * 3 + P), T, P, str(tmp_path)), nprocs=WORLD, join=True)
+    got = np.concatenate([np.load(tmp_path / f"y{r}.npy") for r in range(WORLD)])
+    assert all(np.load(tmp_path / f"ok{r}.npy").all() for r in range(WORLD))
+    rng = np.random.default_rng(9)
+    x = np.cumsum(rng.normal(0, 0.01, size=(T, P, 5)), axis=0) + 1.0
+    count = rng.integers(0, P + 3, size=T).astype(np.int32)
+    count[0] = P - 1
+    if T > 9:
+        count[5:9] = 0
+    want = np.zeros_like(x)
+    for i in range(P - 1):                                                    # bank i sees exactly the frames whose list is long enough
+        idx = np.nonzero(np.minimum(count, P - 1) > i)[0]
+        want[idx, i] = orc.second_order_track(x[idx, i], 2.5, 0.75, 0.6, 1 / 30)
+    np.testing.assert_allclose(got, want, rtol=0, atol=1e-11)
+    assert not got[:, P - 1].any()                                            # the slot frame 0 did not fill is never tracked
+
+
 def test_bench_dry_run_with_eight_ranks():
     """`python bench.py --gpus 8 --dry-run`: the launcher logic and bench's gather leg (gather_track_chunked) with the rank
     count the driver's SCALE run uses."""
