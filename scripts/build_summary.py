@@ -89,7 +89,11 @@ def bench_digest(line):
                          "frames_per_s": e["frames_per_s"], "pair_solves_per_s": e["pair_solves_per_s"], "frac": e["roofline"]["frac"],
                          "fall_backs": e.get("fall_back_frames_last_segment"),
                          "two_streams_frames_per_s": (e.get("two_streams") or {}).get("frames_per_s"),
-                         "two_streams_frac": (e.get("two_streams") or {}).get("frac")}
+                         "two_streams_frac": (e.get("two_streams") or {}).get("frac"),
+                         # (round 6: the lines are found by what they are, not by their position)
+                         "method": e.get("method", "pairwise"), "zero_fill": e.get("zero_fill", True), "pout_max": e.get("pout_max"),
+                         "written_bytes_per_frame": e.get("output_bytes_written_per_frame"), "joints_per_s": e.get("joints_per_s"),
+                         "hbm_frac": (e.get("hbm") or {}).get("frac_of_8TBs")}
                         for e in d["extra_workloads"]]
     if d.get("cpu_baseline"):
         c = d["cpu_baseline"]
@@ -147,6 +151,27 @@ def build(tag):
         j = json.load(open(drv))
         if j.get("parsed"):
             s["driver"] = dict(bench_digest(json.dumps(j["parsed"])), file=j["file"], head=j.get("head"))
+    nr = os.path.join(d, "next_rows.jsonl")      # rows N1 / N2 / N4 and the whole pipeline (scripts/bench_next_rows.py)
+    if os.path.exists(nr):
+        s["next_rows"] = {}
+        for ln in open(nr):
+            if ln.startswith("{"):
+                r = json.loads(ln)
+                s["next_rows"][r["row"]] = {k: v for k, v in r.items() if k != "row"}
+    mf = os.path.join(d, "multiproc_full.jsonl")  # tests/test_gpu_multiproc.py: BASELINE configs[3] / [4] at full size, 8 ranks on the one GPU
+    if os.path.exists(mf):
+        s["multiproc_full"] = []
+        for ln in open(mf):
+            if ln.startswith("{"):
+                r = json.loads(ln)
+                ranks = r["ranks"]
+                ent = {"config": r["config"], "world": r["world"], "frames_total": ranks[0]["frames_total"], "pout_max": ranks[0]["pout_max"]}
+                for kind in ("padded", "compact"):
+                    rs = [q[kind] for q in ranks if kind in q]
+                    if rs:
+                        ent[kind] = {"run_wall_s_max": max(x["run_wall_s"] for x in rs), "kernels_only_wall_s_max": max(x["kernels_only_wall_s"] for x in rs),
+                                     "pieces": rs[0]["pieces"], "gather_MB_received_per_rank": rs[0]["gather_bytes_received"] / 1e6}
+                s["multiproc_full"].append(ent)
     pw = os.path.join(d, "power_trace.json")
     if os.path.exists(pw):
         j = json.load(open(pw))

@@ -43,7 +43,7 @@ import json
 d = json.load(open("$NEWEST"))
 line = d.get("parsed")
 run = d.get("run")
-if isinstance(run, dict):      # the whole JSON line bench.py printed (the driver's `parsed` keeps the contract keys only)
+if isinstance(run, dict):      # the whole JSON line bench.py printed (the driver keeps the contract keys only in its parsed record)
     full = [l for l in (run.get("stdout_tail") or "").splitlines() if l.startswith('{"metric"')]
     try:
         line = json.loads(full[-1])

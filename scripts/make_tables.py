@@ -35,6 +35,19 @@ def headline(s):
     d = s.get("driver")
     dx = (d or {}).get("extra") or []
     pw = (s.get("power") or {}).get("workloads", {})
+    ex = b.get("extra") or []
+
+    def find(*needles, method="pairwise", zero_fill=True, lines=None):
+        for x in (ex if lines is None else lines):
+            if all(n in x["workload"] for n in needles) and x.get("method", "pairwise") == method and x.get("zero_fill", True) == zero_fill:
+                return x
+        return None
+    x_f32, x_168, x_f64 = find("configs[2]: 8 cameras"), find("configs[4]"), find("configs[2] with float64")
+    x_nzf, x_dlt84 = find("NO_ZERO_FILL", zero_fill=False), find("DLT", "configs[2]", method="dlt")
+    singles = [x for x in ex if " x 1 person" in x["workload"] and x.get("method", "pairwise") == "pairwise" and "configs[" not in x["workload"]]
+    dlts = [x for x in ex if " x 1 person" in x["workload"] and x.get("method") == "dlt"]
+    dx0, dx1 = find("configs[2]: 8 cameras", lines=dx), find("configs[4]", lines=dx)
+    nrw = s.get("next_rows") or {}
 
     def drv(fn, *need):
         try:
@@ -80,19 +93,36 @@ def headline(s):
          "2 000 000-frame launches: %s; 10 000-frame launches on two streams: %s; `v_fma_f64` loop: %s; 8 x 4: %s; 16 x 8: %s"
          % (clk("lean_2M"), clk("lean_10k_two_streams"), clk("fp64_fma"), clk("multi_8x4"), clk("multi_16x8")), "-"),
         ("multi-person, 8 cameras x 4 persons, 10 000 frames (BASELINE configs[2]), ONE call",
-         "%s frames/s (%.3f ms), %s pair solves/s = **%.3f of the fp64 vector peak** (`extra_workloads[0]`), %s; sum of the kernels under rocprofv3 (one stream) %.3f ms"
-         % (e(b["extra"][0]["frames_per_s"]), b["extra"][0]["kernel_ms"], e(b["extra"][0]["pair_solves_per_s"]), b["extra"][0]["frac"], fb(b["extra"][0]), m3["sum_of_kernels_ms_per_call"]),
-         drv(lambda d: "%s frames/s (%.3f); two calls in flight %s" % (e(dx[0]["frames_per_s"]), dx[0]["frac"], e(dx[0]["two_streams_frames_per_s"])))),
+         "%s frames/s (%.3f ms), %s pair solves/s = **%.3f of the fp64 vector peak** (nominal: the reference's 90 flop per candidate joint), %s; sum of the kernels under rocprofv3 (one stream) %.3f ms"
+         % (e(x_f32["frames_per_s"]), x_f32["kernel_ms"], e(x_f32["pair_solves_per_s"]), x_f32["frac"], fb(x_f32), m3["sum_of_kernels_ms_per_call"]),
+         drv(lambda d: "%s frames/s (%.3f); two calls in flight %s" % (e(dx0["frames_per_s"]), dx0["frac"], e(dx0["two_streams_frames_per_s"])))),
         ("multi-person, 16 x 8, 12 500 frames (one GPU's share of configs[4]), ONE call",
-         "%s frames/s (%.2f ms), %s pair solves/s = **%.3f of the fp64 vector peak** (`extra_workloads[1]`), %s; 12 000 frames under rocprofv3: %.2f ms"
-         % (e(b["extra"][1]["frames_per_s"]), b["extra"][1]["kernel_ms"], e(b["extra"][1]["pair_solves_per_s"]), b["extra"][1]["frac"], fb(b["extra"][1]), m5["sum_of_kernels_ms_per_call"]),
-         drv(lambda d: "%s frames/s (%.3f); two calls in flight %s" % (e(dx[1]["frames_per_s"]), dx[1]["frac"], e(dx[1]["two_streams_frames_per_s"])))),
+         "%s frames/s (%.2f ms), %s pair solves/s = **%.3f of the fp64 vector peak** (nominal), %s; 12 000 frames under rocprofv3: %.2f ms"
+         % (e(x_168["frames_per_s"]), x_168["kernel_ms"], e(x_168["pair_solves_per_s"]), x_168["frac"], fb(x_168), m5["sum_of_kernels_ms_per_call"]),
+         drv(lambda d: "%s frames/s (%.3f); two calls in flight %s" % (e(dx1["frames_per_s"]), dx1["frac"], e(dx1["two_streams_frames_per_s"])))),
         ("8 x 4 x 10 000 frames with float64 outputs (the reference's output type), ONE call",
-         ("%s frames/s (%.3f ms; float32: %.3f ms), same route" % (e(b["extra"][2]["frames_per_s"]), b["extra"][2]["kernel_ms"], b["extra"][0]["kernel_ms"]))
-         if len(b["extra"]) > 2 else "-", "- (k_frame_recompute then)"),
-        ("one detection per camera, other shapes, 10 000 frames per call (`extra_workloads[3..]`; fp64-vector roof against the reference's 90 flop per pair solve + 15 per ray)",
+         ("%s frames/s (%.3f ms; float32: %.3f ms), same route" % (e(x_f64["frames_per_s"]), x_f64["kernel_ms"], x_f32["kernel_ms"])) if x_f64 else "-",
+         drv(lambda d: "%s frames/s" % e(find("configs[2] with float64", lines=dx)["frames_per_s"]))),
+        ("8 x 4 x 10 000 frames, `Pout_max` 16, with `SNOWTRI_CALL_NO_ZERO_FILL` (the slots behind `out_count[f]` are not written)",
+         ("%s frames/s (%.3f ms); the call writes %.0f MB of joints and scores instead of %.0f MB; two calls in flight %s frames/s"
+          % (e(x_nzf["frames_per_s"]), x_nzf["kernel_ms"], x_nzf["written_bytes_per_frame"] * x_nzf["frames"] / 1e6, x_nzf["pout_max"] * (133 * 16 + 4) * x_nzf["frames"] / 1e6,
+             e(x_nzf["two_streams_frames_per_s"]))) if x_nzf else "-", "-"),
+        ("one detection per camera, other shapes, 10 000 frames per call (fp64-vector roof against the reference's 90 flop per pair solve + 15 per ray)",
          "; ".join("%s: %.1f us = %s joints/s, **%.3f**" % (x["workload"].split(" x 133")[0].replace(" cameras x 1 person", " x 1") + (" float64 out" if "double" in x["kernel"] or "k_associate" in x["kernel"] else ""),
-                                                        x["kernel_ms"] * 1e3, e(x["frames_per_s"] * 133), x["frac"]) for x in b["extra"][3:]) or "-", "-"),
+                                                        x["kernel_ms"] * 1e3, e(x["frames_per_s"] * 133), x["frac"]) for x in singles) or "-", "-"),
+        ("`method = SNOWTRI_DLT` (north_star's N-view DLT; NOT the reference's algorithm), 10 000 frames per call; roofs: HBM (64 / 112 B per joint) and fp64 vector against the stated 64 C + 310 flop per joint",
+         ("; ".join("%s: %.1f us = %s joints/s, %.3f of 8 TB/s, %.3f of the fp64 peak" % (x["workload"].split(": ")[1].split(" x 133")[0].replace(" cameras x 1 person", " x 1"), x["kernel_ms"] * 1e3,
+                                                                                        e(x["joints_per_s"]), x.get("hbm_frac") or 0.0, x["frac"]) for x in dlts)
+          + ("; 8 x 4 behind the reference's association (DLT per cluster): %s frames/s (%.3f ms)" % (e(x_dlt84["frames_per_s"]), x_dlt84["kernel_ms"]) if x_dlt84 else "")) if dlts else "-", "-"),
+        ("rows after the path, device-resident, 100 000 frames (`next_rows.jsonl`): N1 smoothing of 399 lanes / N2 per-bone smoothing of 4 persons / the whole chain A1-A4 + N1 + N2",
+         ("N1 %.3f ms = %.0f GB/s algorithmic = **%.3f of 8 TB/s** (one pass: 16 B per lane-frame); N2 %.3f ms = %.0f GB/s (%.3f); `TrackPipeline` %.3f ms (%.3f ms from raw-frame detections)"
+          % (nrw["N1 smooth_track"]["ms"], nrw["N1 smooth_track"]["algorithmic_GBs"], nrw["N1 smooth_track"]["algorithmic_GBs"] / 8000.0,
+             nrw["N2 blender_smooth"]["ms"], nrw["N2 blender_smooth"]["algorithmic_GBs"], nrw["N2 blender_smooth"]["algorithmic_GBs"] / 8000.0,
+             nrw["pipeline A1-A4 + N1 + N2"]["ms"], nrw["pipeline A1-A4 + N1 + N2 + N4"]["ms"])) if "N1 smooth_track" in nrw else "-", "-"),
+        ("BASELINE configs[3] / configs[4] at their FULL size over 8 ranks sharing the one GPU (gloo-staged collectives; `multiproc_full.jsonl`): wall time of `ShardedTriangulator.run`, slowest rank",
+         "; ".join("%s frames of %s: %s" % ("{:,}".format(m["frames_total"]).replace(",", " "), m["config"].split(":")[1].split(",")[0].strip(),
+                                            ", ".join("%s gather %.2f s (%.0f MB received per rank, %d pieces; the kernels alone %.3f s)" % (k, m[k]["run_wall_s_max"], m[k]["gather_MB_received_per_rank"], m[k]["pieces"], m[k]["kernels_only_wall_s_max"])
+                                                      for k in ("padded", "compact") if k in m)) for m in (s.get("multiproc_full") or [])) or "-", "-"),
         ("per-frame API (`main.py:50-71,106`, floor rig, 300 frames one by one)",
          "%.0f us per frame through the reference-named calls, %.0f us as one F = 1 fused host call (reference: %.1f ms per frame)"
          % (b["per_frame"]["api_sequence_us"], b["per_frame"]["fused_host_call_us"], b["per_frame"]["reference_ms"]),
@@ -101,8 +131,8 @@ def headline(s):
          "%s joints/s; GPU batch vs oracle %.1e m" % (e(b["cpu"]["value"]), b["cpu"]["gpu_vs_oracle_max_abs_m"]),
          drv(lambda d: "%s joints/s" % e(d["cpu"]["value"]))),
     ]
-    out = ["| Quantity | Round 5 (`profiles/%s/`, our boxes) | Driver's record `%s` (round-%s sources) |"
-           % (s["tag"], (d or {}).get("file", "-"), ((d or {}).get("file", "BENCH_r??")[7:9])), "|---|---|---|"]
+    out = ["| Quantity | Round %d (`profiles/%s/`, our boxes) | Driver's record `%s` (round-%s sources) |"
+           % (int(s["tag"][1:3]), s["tag"], (d or {}).get("file", "-"), ((d or {}).get("file", "BENCH_r??")[7:9])), "|---|---|---|"]
     out += ["| %s | %s | %s |" % r for r in rows]
     return "\n".join(out)
 
