@@ -278,6 +278,17 @@ int snowtri_smooth_shard_fix(snowtri_ctx *ctx, int64_t T, int64_t n, int first, 
                              double z, double r, double dt, double *y, int memspace, void *stream);
 int snowtri_smooth_shard_combine(snowtri_ctx *ctx, int32_t world, int32_t rank, int64_t n, const double *gathered, double f,
                                  double z, double r, double dt, double *start_state, int memspace, void *stream);
+/* The same exchange in TWO passes over the shard instead of five (round 6; DEVICE pointers, asynchronous on `stream`):
+ *   snowtri_smooth_shard_reduce  end_state[2n] of the shard's zero-state response -- what _local returns -- from ONE read of x,
+ *                                without writing a track;
+ *   (the all-gather and snowtri_smooth_shard_combine as above)
+ *   snowtri_smooth_shard_scan    y = the shard filtered from its true entering state start_state[2n]: x read once, y written once.
+ * 24 bytes moved per lane-frame against the 40 of _local + _fix; same `first` contract; results equal to rounding (~1e-13 m).
+ * snowmocap_amd/sharded.py::smooth_exchange2 drives it. */
+int snowtri_smooth_shard_reduce(snowtri_ctx *ctx, int64_t T, int64_t n, const double *x, int first, double f, double z, double r,
+                                double dt, double *end_state, void *stream);
+int snowtri_smooth_shard_scan(snowtri_ctx *ctx, int64_t T, int64_t n, const double *x, int first, const double *start_state, double f,
+                              double z, double r, double dt, double *y, void *stream);
 
 /* N2  Blender IK control points (blender.py:98-143; names and order of configs/blender_armature_profile.json:
  * root_position, root_rotation, clavicle_r_ik, clavicle_l_ik, arm_r_ik, arm_r_pole, arm_l_ik, arm_l_pole,
@@ -327,6 +338,11 @@ int snowtri_blender_smooth_shard_combine(snowtri_ctx *ctx, int32_t world, int32_
                                          const double *fzr, double dt, double *start_state, void *stream);
 int snowtri_blender_smooth_shard_fix(snowtri_ctx *ctx, int64_t T, int64_t n_persons, int first, const double *start_state, const double *fzr,
                                      double dt, double *y, void *stream);
+/* ... and its two-pass form on `held` (snowtri_smooth_shard_reduce / _scan with the per-point coefficients). */
+int snowtri_blender_smooth_shard_reduce(snowtri_ctx *ctx, int64_t T, int64_t n_persons, const double *held, int first, const double *fzr,
+                                        double dt, double *end_state, void *stream);
+int snowtri_blender_smooth_shard_scan(snowtri_ctx *ctx, int64_t T, int64_t n_persons, const double *held, int first, const double *start_state,
+                                      const double *fzr, double dt, double *y, void *stream);
 
 /* N4  Keypoint-level lens undistortion, for detections made on RAW frames (the reference undistorts whole
  * images before detection: main.py:52 cv2.undistort(frame, K, D)).  OpenCV's 5-coefficient Brown-Conrady model,

@@ -101,6 +101,10 @@ _SIGNATURES = {
                                               ct.c_double, ct.c_double, _c_p, _c_p, ct.c_int, _c_p]),
     "snowtri_smooth_shard_fix": (ct.c_int, [_c_p, ct.c_int64, ct.c_int64, ct.c_int, _c_p, ct.c_double, ct.c_double,
                                             ct.c_double, ct.c_double, _c_p, ct.c_int, _c_p]),
+    "snowtri_smooth_shard_reduce": (ct.c_int, [_c_p, ct.c_int64, ct.c_int64, _c_p, ct.c_int, ct.c_double, ct.c_double, ct.c_double, ct.c_double, _c_p, _c_p]),
+    "snowtri_smooth_shard_scan": (ct.c_int, [_c_p, ct.c_int64, ct.c_int64, _c_p, ct.c_int, _c_p, ct.c_double, ct.c_double, ct.c_double, ct.c_double, _c_p, _c_p]),
+    "snowtri_blender_smooth_shard_reduce": (ct.c_int, [_c_p, ct.c_int64, ct.c_int64, _c_p, ct.c_int, _c_p, ct.c_double, _c_p, _c_p]),
+    "snowtri_blender_smooth_shard_scan": (ct.c_int, [_c_p, ct.c_int64, ct.c_int64, _c_p, ct.c_int, _c_p, _c_p, ct.c_double, _c_p, _c_p]),
     "snowtri_smooth_shard_combine": (ct.c_int, [_c_p, ct.c_int32, ct.c_int32, ct.c_int64, _c_p, ct.c_double, ct.c_double,
                                                 ct.c_double, ct.c_double, _c_p, ct.c_int, _c_p]),
     "snowtri_blender_points": (ct.c_int, [_c_p, ct.c_int64, ct.c_int32, _c_p, ct.c_int, _c_p, _c_p, ct.c_int, _c_p]),

@@ -1340,13 +1340,22 @@ int smooth_fix_dev(snowtri_ctx *ctx, hipStream_t st, int64_t T, int64_t n, doubl
 // N1; the held x_eff[0] for N2).  skip4: every fourth lane (the score of a joint record) is copied instead of filtered.
 // (Rounds 1-5 ran three passes -- chunk-end states, the carry over the chunks, the recurrence again: 24 bytes moved per 16
 // algorithmic; the sharded protocol below still does, its entering state is not known before the exchange.)
+// tb / d_start / d_end: the frame-shard forms (k_smooth_scan): tb = 0 filters every frame, d_start [2n] is the state entering the
+// first filtered frame, d_end [2n] receives the state behind the last frame, dy == nullptr stores no track (the "reduce" pass).
 template <typename KS, typename HS>
 int smooth_whole_dev(snowtri_ctx *ctx, hipStream_t st, int64_t T, int64_t n, const double *dx, double *dy,
-                     const double *d_seed_row, const KS &k, const HS &hs, bool skip4 = false) {
-    const int64_t m = T - 1, nsuper = (m + kScanSuper - 1) / kScanSuper, ncols = (n + 63) / 64;
+                     const double *d_seed_row, const KS &k, const HS &hs, bool skip4 = false, int tb = 1, const double *d_start = nullptr,
+                     double *d_end = nullptr) {
+    const int64_t m = T - tb, nsuper = (m + kScanSuper - 1) / kScanSuper, ncols = (n + 63) / 64;
     if (nsuper > 65535) return SNOWTRI_ERR_BAD_ARG;   // (the documented limit of the track length: 1 + 256 * 65535 frames)
-    if (m <= 0) {
-        HIP_TRY(hipMemcpyAsync(dy, dx, sizeof(double) * (size_t)T * n, hipMemcpyDeviceToDevice, st));
+    if (m <= 0) {   // a one-frame track / first shard: nothing is filtered; the state behind it is the entering one
+        if (dy) HIP_TRY(hipMemcpyAsync(dy, dx, sizeof(double) * (size_t)T * n, hipMemcpyDeviceToDevice, st));
+        if (d_end) {
+            if (d_start)
+                HIP_TRY(hipMemcpyAsync(d_end, d_start, sizeof(double) * 2 * n, hipMemcpyDeviceToDevice, st));
+            else
+                HIP_TRY(hipMemsetAsync(d_end, 0, sizeof(double) * 2 * n, st));
+        }
         return SNOWTRI_OK;
     }
     if (nsuper * ncols >= ((int64_t)1 << 31) || n > ((int64_t)1 << 22)) return SNOWTRI_ERR_BAD_ARG;   // (lanes: the 32-bit buffer offsets of k_smooth_scan)
@@ -1359,9 +1368,11 @@ int smooth_whole_dev(snowtri_ctx *ctx, hipStream_t st, int64_t T, int64_t n, con
     unsigned int *ticket = (unsigned int *)base, *flags = (unsigned int *)(base + off_flags);
     double *agg = (double *)(base + off_agg), *incl = (double *)(base + off_incl);
     if (skip4)
-        hipLaunchKernelGGL((k_smooth_scan<KS, HS, true>), dim3((unsigned)nwg), dim3(kScanThreads), 0, st, T, n, k, hs, dx, d_seed_row, dy, ticket, flags, agg, incl);
+        hipLaunchKernelGGL((k_smooth_scan<KS, HS, true>), dim3((unsigned)nwg), dim3(kScanThreads), 0, st, T, n, k, hs, dx, d_seed_row, dy, ticket, flags, agg, incl,
+                           tb, d_start, d_end);
     else
-        hipLaunchKernelGGL((k_smooth_scan<KS, HS, false>), dim3((unsigned)nwg), dim3(kScanThreads), 0, st, T, n, k, hs, dx, d_seed_row, dy, ticket, flags, agg, incl);
+        hipLaunchKernelGGL((k_smooth_scan<KS, HS, false>), dim3((unsigned)nwg), dim3(kScanThreads), 0, st, T, n, k, hs, dx, d_seed_row, dy, ticket, flags, agg, incl,
+                           tb, d_start, d_end);
     HIP_TRY(hipGetLastError());
     return SNOWTRI_OK;
 }
@@ -1443,6 +1454,28 @@ int snowtri_smooth_shard_fix(snowtri_ctx *ctx, int64_t T, int64_t n, int first, 
         HIP_TRY(hipStreamSynchronize(st));
     }
     return SNOWTRI_OK;
+}
+
+// The two-pass form of the sharded protocol (round 6): _reduce = the shard's zero-state end state from ONE read of x, _scan = the
+// shard filtered from its true entering state in one more pass (k_smooth_scan both times); device pointers.
+int snowtri_smooth_shard_reduce(snowtri_ctx *ctx, int64_t T, int64_t n, const double *x, int first, double f, double z, double r,
+                                double dt, double *end_state, void *stream) {
+    if (!smooth_args_ok(ctx, T, n, f, dt, SNOWTRI_DEVICE)) return SNOWTRI_ERR_BAD_ARG;
+    if (T == 0 || n == 0) return SNOWTRI_OK;
+    if (!x || !end_state) return SNOWTRI_ERR_BAD_ARG;
+    ENTER_DEVICE(ctx->device);
+    return smooth_whole_dev(ctx, (hipStream_t)stream, T, n, x, (double *)nullptr, (const double *)nullptr, UniformCoef{smooth_coef(f, z, r, dt)}, NoHold{}, false,
+                            first ? 1 : 0, (const double *)nullptr, end_state);
+}
+
+int snowtri_smooth_shard_scan(snowtri_ctx *ctx, int64_t T, int64_t n, const double *x, int first, const double *start_state, double f,
+                              double z, double r, double dt, double *y, void *stream) {
+    if (!smooth_args_ok(ctx, T, n, f, dt, SNOWTRI_DEVICE)) return SNOWTRI_ERR_BAD_ARG;
+    if (T == 0 || n == 0) return SNOWTRI_OK;
+    if (!x || !y || !start_state) return SNOWTRI_ERR_BAD_ARG;
+    ENTER_DEVICE(ctx->device);
+    return smooth_whole_dev(ctx, (hipStream_t)stream, T, n, x, y, (const double *)nullptr, UniformCoef{smooth_coef(f, z, r, dt)}, NoHold{}, false,
+                            first ? 1 : 0, start_state, (double *)nullptr);
 }
 
 int snowtri_smooth_shard_combine(snowtri_ctx *ctx, int32_t world, int32_t rank, int64_t n, const double *gathered, double f,
@@ -1701,6 +1734,34 @@ int snowtri_blender_smooth_shard_local(snowtri_ctx *ctx, int64_t T, int64_t n_pe
     if (rc) return rc;
     const TableCoef k{(const SmoothCoef *)ctx->dBlenderTab, 4, kBlenderPoints};
     return smooth_local_dev(ctx, st, T, n, held, y, first != 0, k, end_state);
+}
+
+int snowtri_blender_smooth_shard_reduce(snowtri_ctx *ctx, int64_t T, int64_t n_persons, const double *held, int first, const double *fzr,
+                                        double dt, double *end_state, void *stream) {
+    if (!fzr || !blender_shard_args_ok(ctx, T, n_persons, fzr, dt)) return SNOWTRI_ERR_BAD_ARG;
+    const int64_t n = n_persons * kBlenderPoints * 4;
+    if (T == 0 || n == 0) return SNOWTRI_OK;
+    if (!held || !end_state) return SNOWTRI_ERR_BAD_ARG;
+    ENTER_DEVICE(ctx->device);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = blender_table(ctx, st, fzr, dt);
+    if (rc) return rc;
+    const TableCoef k{(const SmoothCoef *)ctx->dBlenderTab, 4, kBlenderPoints};
+    return smooth_whole_dev(ctx, st, T, n, held, (double *)nullptr, (const double *)nullptr, k, NoHold{}, false, first ? 1 : 0, (const double *)nullptr, end_state);
+}
+
+int snowtri_blender_smooth_shard_scan(snowtri_ctx *ctx, int64_t T, int64_t n_persons, const double *held, int first, const double *start_state,
+                                      const double *fzr, double dt, double *y, void *stream) {
+    if (!fzr || !blender_shard_args_ok(ctx, T, n_persons, fzr, dt)) return SNOWTRI_ERR_BAD_ARG;
+    const int64_t n = n_persons * kBlenderPoints * 4;
+    if (T == 0 || n == 0) return SNOWTRI_OK;
+    if (!held || !y || !start_state) return SNOWTRI_ERR_BAD_ARG;
+    ENTER_DEVICE(ctx->device);
+    hipStream_t st = (hipStream_t)stream;
+    int rc = blender_table(ctx, st, fzr, dt);
+    if (rc) return rc;
+    const TableCoef k{(const SmoothCoef *)ctx->dBlenderTab, 4, kBlenderPoints};
+    return smooth_whole_dev(ctx, st, T, n, held, y, (const double *)nullptr, k, NoHold{}, false, first ? 1 : 0, start_state, (double *)nullptr);
 }
 
 int snowtri_blender_smooth_shard_combine(snowtri_ctx *ctx, int32_t world, int32_t rank, int64_t n_persons, const double *gathered,

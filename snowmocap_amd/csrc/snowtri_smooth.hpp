@@ -252,10 +252,18 @@ __device__ __forceinline__ void scan_publish(double *dst, double vy, double vyd,
     if (l == 0) __hip_atomic_store(flag, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 static_assert(kScanSuper == 256, "a workgroup of the one-pass scan covers one chunk of the hold kernels (kSmoothChunk)");
+// The same kernel serves a frame SHARD (round 6: the sharded protocol used to run the three passes from a zero state and then a
+// fourth and fifth over y to add the entering state's response -- 40 bytes per lane-frame): tb = 0 filters every frame (the first
+// one with xd = 0: the caller's combine corrects for the true previous input), `start` ([2n], optional) is the state entering the
+// first filtered frame (absent: (seed_row, 0), or zero without a seed row), `end_out` ([2n], optional) receives the state behind
+// the LAST frame, and y == nullptr stores nothing (a zero-length buffer descriptor drops every store): the shard's zero-state end
+// state costs ONE read of x ("reduce"), and after the exchange the shard is filtered in one more pass ("scan"): 24 bytes.
 template <typename KS, typename HS, bool SKIP4>
 __global__ __launch_bounds__(kScanThreads) void k_smooth_scan(int64_t T, int64_t n, KS ks, HS hs, const double *__restrict__ x,
                                                               const double *__restrict__ seed_row, double *__restrict__ y,
-                                                              unsigned int *ticket, unsigned int *flags, double *agg, double *incl) {
+                                                              unsigned int *ticket, unsigned int *flags, double *agg, double *incl,
+                                                              int tb = 1, const double *__restrict__ start = nullptr,
+                                                              double *__restrict__ end_out = nullptr) {
     __shared__ unsigned int s_bid;
     __shared__ double s_e[kScanWaves][2][64];
     __shared__ double s_in[2][64];
@@ -270,7 +278,7 @@ __global__ __launch_bounds__(kScanThreads) void k_smooth_scan(int64_t T, int64_t
     const bool live = lane < n;
     const int64_t lc = live ? lane : n - 1;   // (idle lanes of the last column read the last lane's data and store nothing)
     const SmoothCoef k = ks.at(lc);
-    const int64_t t0 = 1 + (int64_t)sc * kScanSuper + (int64_t)w * kScanL;   // frames 1 .. T-1 are the filtered ones
+    const int64_t t0 = tb + (int64_t)sc * kScanSuper + (int64_t)w * kScanL;   // frames tb .. T-1 are the filtered ones
     const int nt = (int)(T - t0 < 0 ? 0 : (T - t0 > kScanL ? kScanL : T - t0));
     const int64_t nv = hs.groups(n), g = hs.group(lc);
     // ---- A: this wave's frames into registers, zero-state end state
@@ -289,7 +297,7 @@ __global__ __launch_bounds__(kScanThreads) void k_smooth_scan(int64_t T, int64_t
     // never wraps into the range -- it did, from 0xfffffff0, and wrote its garbage over lane 0's results: found by the n < 64 tests)
     const unsigned int span32 = span > 0x7ffffff0ull ? 0x7ffffff0u : (unsigned int)span;
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(x + t0 * n), 0, (int)span32, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(y + t0 * n, 0, (int)span32, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc(y ? y + t0 * n : const_cast<double *>(x), 0, y ? (int)span32 : 0, 0x00020000);
     const unsigned int row_bytes = (unsigned int)n * 8u;
     const unsigned int off0 = live ? (unsigned int)lane * 8u : 0x80000000u;
     unsigned int off = off0;   // (a running offset: one register, not 32 kept for the stores)
@@ -354,8 +362,8 @@ __global__ __launch_bounds__(kScanThreads) void k_smooth_scan(int64_t T, int64_t
         const size_t slot = ((size_t)sc * ncols + col) * 128 + l;
         double iny, inyd;   // S_in: the true state entering this workgroup
         if (sc == 0) {
-            iny = seed_row[lc];   // (x_0, 0): frame 0 seeds the filters (:11-13)
-            inyd = 0.0;
+            iny = start ? start[2 * lc] : (seed_row ? seed_row[lc] : 0.0);   // (x_0, 0): frame 0 seeds the filters (:11-13); a shard: its entering state
+            inyd = start ? start[2 * lc + 1] : 0.0;
         } else {
             scan_publish(agg + slot, gy, gyd, flags + (size_t)sc * ncols + col, 1u, l);
             // ---- C: look back
@@ -396,7 +404,8 @@ __global__ __launch_bounds__(kScanThreads) void k_smooth_scan(int64_t T, int64_t
     syd += zyd;
     xp = x_enter;
     const bool copy = SKIP4 && (lane & 3) == 3;
-    if (sc == 0 && w == 0 && live) y[lane] = x[lane];   // frame 0 passes through (:180-181)
+    if (sc == 0 && w == 0 && live && tb == 1 && y) y[lane] = x[lane];   // frame 0 passes through (:180-181)
+    const int last_u = (t0 + nt == T) ? nt - 1 : -1;   // this wave holds the last frame of the track / shard at position last_u
     off = off0;
     asm volatile("" : "+v"(off));   // (not the offsets of the loads again: they would live across the whole kernel)
 #pragma unroll
@@ -407,6 +416,10 @@ __global__ __launch_bounds__(kScanThreads) void k_smooth_scan(int64_t T, int64_t
         ow.x = (unsigned int)__double2loint(out);
         ow.y = (unsigned int)__double2hiint(out);
         __builtin_amdgcn_raw_buffer_store_b64(ow, ry, (int)off, 0, 0);
+        if (end_out && u == last_u && live) {   // (wave-uniform; the steps behind it run on zeros and are never read)
+            end_out[2 * lane] = sy;
+            end_out[2 * lane + 1] = syd;
+        }
         if ((u & 3) == 3) __builtin_amdgcn_sched_barrier(0);   // a frame's store leaves with its step: the results are not collected in registers first
     }
 }

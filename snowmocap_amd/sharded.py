@@ -595,6 +595,41 @@ def smooth_exchange(x_local, local_fn, combine_fn, fix_fn, group=None, first=Non
     return y
 
 
+def smooth_exchange2(x_local, reduce_fn, combine_fn, scan_fn, group=None, first=None):
+    """The sharded smoothing protocol in TWO passes over the block (round 6; smooth_exchange above is the five-pass form the
+    first rounds shipped, kept for its callers and its gloo tests):
+
+        reduce_fn(x_local, first, payload)   payload[:2n] = end state of the block's ZERO-STATE response (x read once, no track written)
+        combine_fn(allp, rank, start)        entering state of `rank` from the gathered payloads [world, 4n + 1] (unchanged)
+        scan_fn(x_local, first, start, y)    y = the block filtered from its true entering state (x read once, y written once)
+
+    Same payload, same ONE all-gather, same `first` contract as smooth_exchange."""
+    import torch
+    import torch.distributed as dist
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    T = int(x_local.shape[0])
+    n = 1
+    for d in x_local.shape[1:]:
+        n *= int(d)
+    if first is None:
+        first = rank == 0
+    y = torch.empty_like(x_local)
+    payload = torch.zeros(4 * n + 1, dtype=torch.float64, device=x_local.device)
+    payload[4 * n] = T
+    if T > 0:
+        reduce_fn(x_local, bool(first), payload)
+        payload[2 * n:3 * n] = x_local[0].reshape(-1)
+        payload[3 * n:4 * n] = x_local[-1].reshape(-1)
+    flat = torch.empty(world * (4 * n + 1), dtype=torch.float64, device=x_local.device)
+    all_gather_flat(flat, payload, group=group)
+    if T == 0:
+        return y
+    start = torch.empty((n, 2), dtype=torch.float64, device=x_local.device)
+    combine_fn(flat.view(world, 4 * n + 1), rank, start)
+    scan_fn(x_local, bool(first), start, y)
+    return y
+
+
 def smooth_track_sharded(x_local, f=2, z=0.75, r=0, delta_time=1 / 30, group=None, ctx=None, F_total=None, first=None):
     """x_local: this rank's frame block [T_r, ...] (CUDA float64 tensor, frame-major) of a track sharded in
     frame order over the ranks of `group`.  Returns the filtered block; the full track is never gathered.
@@ -620,10 +655,9 @@ def smooth_track_sharded(x_local, f=2, z=0.75, r=0, delta_time=1 / 30, group=Non
     L = ctx.L
     fzrd = (float(f), float(z), float(r), float(delta_time))
 
-    def local_fn(x, is_first, y, payload):
-        _lib.check(L.snowtri_smooth_shard_local(ctx.handle, int(x.shape[0]), n, ct.c_void_p(x.data_ptr()), 1 if is_first else 0, *fzrd,
-                                                ct.c_void_p(y.data_ptr()), ct.c_void_p(payload.data_ptr()), _lib.DEVICE, stream),
-                   "snowtri_smooth_shard_local")
+    def reduce_fn(x, is_first, payload):
+        _lib.check(L.snowtri_smooth_shard_reduce(ctx.handle, int(x.shape[0]), n, ct.c_void_p(x.data_ptr()), 1 if is_first else 0, *fzrd,
+                                                 ct.c_void_p(payload.data_ptr()), stream), "snowtri_smooth_shard_reduce")
 
     def combine_fn(allp, rk, start):
         # the entering state of this shard from the gathered carries, ON the device and the stream (k_smooth_combine: no host
@@ -631,11 +665,11 @@ def smooth_track_sharded(x_local, f=2, z=0.75, r=0, delta_time=1 / 30, group=Non
         _lib.check(L.snowtri_smooth_shard_combine(ctx.handle, world, rk, n, ct.c_void_p(allp.data_ptr()), *fzrd,
                                                   ct.c_void_p(start.data_ptr()), _lib.DEVICE, stream), "snowtri_smooth_shard_combine")
 
-    def fix_fn(y, is_first, start):
-        _lib.check(L.snowtri_smooth_shard_fix(ctx.handle, int(y.shape[0]), n, 1 if is_first else 0, ct.c_void_p(start.data_ptr()), *fzrd,
-                                              ct.c_void_p(y.data_ptr()), _lib.DEVICE, stream), "snowtri_smooth_shard_fix")
+    def scan_fn(x, is_first, start, y):
+        _lib.check(L.snowtri_smooth_shard_scan(ctx.handle, int(x.shape[0]), n, ct.c_void_p(x.data_ptr()), 1 if is_first else 0,
+                                               ct.c_void_p(start.data_ptr()), *fzrd, ct.c_void_p(y.data_ptr()), stream), "snowtri_smooth_shard_scan")
 
-    return smooth_exchange(x_local, local_fn, combine_fn, fix_fn, group=group, first=first)
+    return smooth_exchange2(x_local, reduce_fn, combine_fn, scan_fn, group=group, first=first)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -700,20 +734,20 @@ def blender_smooth_sharded(pts_local, val_local, fzr, delta_time=1 / 30, group=N
 
     held = hold_exchange(pts_local, val_local, last_fn, apply_fn, group=group)
 
-    def local_fn(x, is_first, y, payload):
-        _lib.check(L.snowtri_blender_smooth_shard_local(ctx.handle, int(x.shape[0]), P, ct.c_void_p(x.data_ptr()), 1 if is_first else 0,
-                                                        _lib.ptr(fzr), dt, ct.c_void_p(y.data_ptr()), ct.c_void_p(payload.data_ptr()), stream),
-                   "snowtri_blender_smooth_shard_local")
+    def reduce_fn(x, is_first, payload):
+        _lib.check(L.snowtri_blender_smooth_shard_reduce(ctx.handle, int(x.shape[0]), P, ct.c_void_p(x.data_ptr()), 1 if is_first else 0,
+                                                         _lib.ptr(fzr), dt, ct.c_void_p(payload.data_ptr()), stream), "snowtri_blender_smooth_shard_reduce")
 
     def combine_fn(allp, rk, start):
         _lib.check(L.snowtri_blender_smooth_shard_combine(ctx.handle, world, rk, P, ct.c_void_p(allp.data_ptr()), _lib.ptr(fzr), dt,
                                                           ct.c_void_p(start.data_ptr()), stream), "snowtri_blender_smooth_shard_combine")
 
-    def fix_fn(y, is_first, start):
-        _lib.check(L.snowtri_blender_smooth_shard_fix(ctx.handle, int(y.shape[0]), P, 1 if is_first else 0, ct.c_void_p(start.data_ptr()),
-                                                      _lib.ptr(fzr), dt, ct.c_void_p(y.data_ptr()), stream), "snowtri_blender_smooth_shard_fix")
+    def scan_fn(x, is_first, start, y):
+        _lib.check(L.snowtri_blender_smooth_shard_scan(ctx.handle, int(x.shape[0]), P, ct.c_void_p(x.data_ptr()), 1 if is_first else 0,
+                                                       ct.c_void_p(start.data_ptr()), _lib.ptr(fzr), dt, ct.c_void_p(y.data_ptr()), stream),
+                   "snowtri_blender_smooth_shard_scan")
 
-    y = smooth_exchange(held, local_fn, combine_fn, fix_fn, group=group, first=first)
+    y = smooth_exchange2(held, reduce_fn, combine_fn, scan_fn, group=group, first=first)
     is_first = (rank == 0) if first is None else first
     if is_first and T > 0:
         y[0].copy_(pts_local[0])       # frame 0 of the track is returned as given, NaNs included (blender.py:176)

@@ -85,3 +85,55 @@ def test_the_scan_is_deterministic_and_reuses_its_scratch():
     for _ in range(3):
         assert np.array_equal(api.smooth_track(a, f=2.5, z=0.75, r=0.5, delta_time=1 / 30), ya)
         assert np.array_equal(api.smooth_track(b, f=2.5, z=0.75, r=0.5, delta_time=1 / 30), yb)
+
+
+@pytest.mark.parametrize("n", [5, 399])
+def test_two_pass_shard_protocol_equals_the_five_pass_one_and_the_sequential_filter(n):
+    """snowtri_smooth_shard_reduce / _scan (one read for the carry, one pass for the block) against snowtri_smooth_shard_local /
+    _fix (the five-pass form) and the sequential recurrence, on uneven frame blocks -- a one-frame first block, a block of exactly
+    one workgroup (256 frames), a long one, an empty one in the middle."""
+    import ctypes as ct
+    import torch
+    from snowmocap_amd import _lib
+    from snowmocap_amd.sharded import combine_carries, smooth_coeffs
+    from oracle import oracle as orc
+    f, z, r, dt = 2.5, 0.75, 0.6, 1 / 30
+    rng = np.random.default_rng(n)
+    sizes = [1, 256, 0, 1900, 33]
+    T = sum(sizes)
+    x = np.cumsum(rng.normal(0, 0.01, size=(T, n)), axis=0) + 1.0
+    want = orc.second_order_track(x, f, z, r, dt)
+    A, cx, cxd = smooth_coeffs(f, z, r, dt)
+    ctx = _lib.scratch_context()
+    L = ctx.L
+    dev = torch.device("cuda", 0)
+    bounds = np.cumsum([0] + sizes)
+    blocks = [torch.from_numpy(x[bounds[q]:bounds[q + 1]].copy()).to(dev) for q in range(len(sizes))]
+    first_q = next(q for q, s_ in enumerate(sizes) if s_ > 0)
+    payloads = []
+    for q, xb in enumerate(blocks):
+        Tq = int(xb.shape[0])
+        E = torch.zeros(2 * n, dtype=torch.float64, device=dev)
+        E5 = torch.zeros(2 * n, dtype=torch.float64, device=dev)
+        if Tq:
+            _lib.check(L.snowtri_smooth_shard_reduce(ctx.handle, Tq, n, ct.c_void_p(xb.data_ptr()), 1 if q == first_q else 0, f, z, r, dt,
+                                                     ct.c_void_p(E.data_ptr()), None), "reduce")
+            y5 = torch.empty_like(xb)
+            _lib.check(L.snowtri_smooth_shard_local(ctx.handle, Tq, n, ct.c_void_p(xb.data_ptr()), 1 if q == first_q else 0, f, z, r, dt,
+                                                    ct.c_void_p(y5.data_ptr()), ct.c_void_p(E5.data_ptr()), _lib.DEVICE, None), "local")
+            torch.cuda.synchronize()
+            assert float((E - E5).abs().max()) < 1e-11, q           # the same carry from one read of x
+        Eh = E.cpu().numpy().reshape(n, 2)
+        payloads.append((Eh, x[bounds[q]] if Tq else np.zeros(n), x[bounds[q + 1] - 1] if Tq else np.zeros(n), Tq))
+    got = np.zeros_like(x)
+    for q, xb in enumerate(blocks):
+        Tq = int(xb.shape[0])
+        if not Tq:
+            continue
+        start = torch.from_numpy(combine_carries(payloads, q, A, cxd)).to(dev)
+        yb = torch.empty_like(xb)
+        _lib.check(L.snowtri_smooth_shard_scan(ctx.handle, Tq, n, ct.c_void_p(xb.data_ptr()), 1 if q == first_q else 0, ct.c_void_p(start.data_ptr()),
+                                               f, z, r, dt, ct.c_void_p(yb.data_ptr()), None), "scan")
+        torch.cuda.synchronize()
+        got[bounds[q]:bounds[q + 1]] = yb.cpu().numpy()
+    assert np.abs(got - want).max() < 2e-10, np.abs(got - want).max()

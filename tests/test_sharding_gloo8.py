@@ -355,6 +355,55 @@ def test_eight_rank_sharded_blender_smoothing_matches_the_sequential_filters(tmp
     np.testing.assert_allclose(got, want, rtol=0, atol=1e-10)
 
 
+def _smooth2_worker(rank, port, T, tmp):
+    """smooth_exchange2 -- the two-pass protocol: reduce (the block's zero-state end state), combine, scan (the block from its
+    true entering state) -- with the host twins of the kernels."""
+    _init(rank, port)
+    from snowmocap_amd.sharded import combine_carries, smooth_exchange2
+    f, z, r, dt = 2.5, 0.75, 0.6, 1 / 30
+    A, cx, cxd = _coeffs(f, z, r, dt)
+    n = 7
+    x = np.cumsum(np.random.default_rng(3).normal(0, 0.01, size=(T, n)), axis=0) + 1.0
+    lo, hi, _ = shard_bounds(T, WORLD, rank)
+
+    def run(xv, first, s):                      # the recurrence of a block from state s; returns (y, end state)
+        yv = np.zeros_like(xv)
+        if first:
+            yv[0] = xv[0]
+        xp = xv[0].copy()
+        for t in range(1 if first else 0, xv.shape[0]):
+            c = cx * xv[t] + cxd * (xv[t] - xp)
+            xp = xv[t]
+            s = s @ A.T + np.stack([np.zeros(n), c], axis=1)
+            yv[t] = s[:, 0]
+        return yv, s
+
+    def reduce_fn(xl, first, payload):
+        payload[: 2 * n] = torch.from_numpy(run(xl.numpy(), first, np.zeros((n, 2)))[1].reshape(-1))
+
+    def combine_fn(allp, rk, start):
+        a = allp.numpy()
+        payloads = [(a[q, : 2 * n].reshape(n, 2), a[q, 2 * n:3 * n], a[q, 3 * n:4 * n], a[q, 4 * n]) for q in range(WORLD)]
+        start.copy_(torch.from_numpy(combine_carries(payloads, rk, A, cxd)))
+
+    def scan_fn(xl, first, start, y):
+        y.copy_(torch.from_numpy(run(xl.numpy(), first, start.numpy().copy())[0]))
+
+    y = smooth_exchange2(torch.from_numpy(x[lo:hi].copy()), reduce_fn, combine_fn, scan_fn)
+    np.save(os.path.join(tmp, f"y{rank}.npy"), y.numpy())
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("T", [41, 3])
+def test_eight_rank_two_pass_smoothing_exchange_matches_the_sequential_filter(tmp_path, T):
+    from oracle import oracle as orc
+    mp.spawn(_smooth2_worker, args=(_port(T + 77), T, str(tmp_path)), nprocs=WORLD, join=True)
+    got = np.concatenate([np.load(tmp_path / f"y{r}.npy") for r in range(WORLD)])
+    x = np.cumsum(np.random.default_rng(3).normal(0, 0.01, size=(T, 7)), axis=0) + 1.0
+    np.testing.assert_allclose(got, orc.second_order_track(x, 2.5, 0.75, 0.6, 1 / 30), rtol=0, atol=1e-11)
+
+
 def _ragged_worker(rank, port, T, P, tmp):
     """The sharded form of the reference's list-index semantics (triangulation.py:169-171: banks of frame 0, zip truncation) with
     the host twins of the kernels: tracked_counts hands count[0] round, then slot i is filtered over the frames with
