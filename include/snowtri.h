@@ -215,6 +215,9 @@ int snowtri_condense_resident(snowtri_ctx *ctx, int64_t token, const snowtri_par
  * of the project's parity bar only for coordinates under ~840 m.  Real joints are metres from the origin (error < 1e-6 m);
  * the ghost clusters near-parallel rays produce under a wide condense_distance_tol can lie hundreds of metres out, where
  * a float32 cannot hold 1e-4 m: ask for SNOWTRI_F64 outputs if such points matter.
+ * out_pscore (triangulation.py:150, the mean of a person's keypoint scores): where it is taken from the STORED joint scores --
+ * keypoint_num < J, SNOWTRI_F64 outputs, one detection per camera on five and more cameras (k_person_scores) -- a SNOWTRI_F32
+ * value is the mean of the already rounded scores, up to 2 float32 ulp from the fp64 mean rounded once.
  * SNOWTRI_FLAG_SINGULAR: a pair is exactly singular when a c == b b in separately rounded products (a = hm.hm, b = hm.hs,
  * c = hs.hs: what the reference's LU of [[a, b], [b, c]] sees for equal rays, np.linalg.inv raises, triangulation.py:26). */
 int snowtri_triangulate_condense(snowtri_ctx *ctx, int64_t F, int32_t Pmax, int32_t J,
