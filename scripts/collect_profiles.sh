@@ -1,6 +1,6 @@
 #!/bin/bash
 # Copy the summaries of scripts/profile.sh <tag> + scripts/pmc_multi.sh (under gpurun_out/) into profiles/<tag>/.
-TAG=${1:-r05}; SRC=gpurun_out/prof_$TAG; DST=profiles/$TAG; mkdir -p $DST
+TAG=${1:-r06}; SRC=gpurun_out/prof_$TAG; DST=profiles/$TAG; mkdir -p $DST
 cp $SRC/summary.txt $SRC/bench_lines.jsonl $SRC/next_rows.jsonl $SRC/pmc_traffic.json $DST/
 cp $SRC/kernel_stats_stats.csv $DST/kernel_stats_cfg2_10k.csv
 cp $SRC/kernel_stats_stats_large.csv $DST/kernel_stats_large_2M.csv
@@ -17,6 +17,7 @@ grep "^a\|^b\|^{" gpurun_out/pmc_multi_stdout.txt > $DST/multi_person_counters.t
 [ -f profiles/pmc_multi.json ] && cp profiles/pmc_multi.json $DST/pmc_multi.json
 fi
 cp $SRC/bench_default.json $SRC/bench_steps20.json $SRC/large_launches.json $DST/
+[ -f gpurun_out/multiproc_full.jsonl ] && cp gpurun_out/multiproc_full.jsonl $DST/multiproc_full.jsonl   # tests/test_gpu_multiproc.py: configs[3] / [4] at full size, 8 ranks on the one GPU
 python - <<PY
 import csv, os
 for t in ("a3", "b3", "a5", "b5"):

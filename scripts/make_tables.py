@@ -12,7 +12,7 @@ import re
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = "r05"
+TAG = "r06"
 DOCS = {"README.md": ["headline"], "DESIGN.md": ["headline", "detail"], os.path.join("profiles", "README.md"): ["detail"]}
 
 
