@@ -137,3 +137,32 @@ def test_two_pass_shard_protocol_equals_the_five_pass_one_and_the_sequential_fil
         torch.cuda.synchronize()
         got[bounds[q]:bounds[q + 1]] = yb.cpu().numpy()
     assert np.abs(got - want).max() < 2e-10, np.abs(got - want).max()
+
+
+def test_long_tracks_repeat_bit_for_bit_under_thousands_of_chained_workgroups():
+    """The look-back reads states other workgroups -- on other XCDs, whose L2s are not coherent with this one's -- published
+    through agent-scope atomics, the flag behind the acknowledged state.  A missing ordering would show as a rare wrong carry:
+    200 001 frames x 532 lanes = 782 workgroups down each of 9 columns, twenty times, every run equal to the first bit for
+    bit and the first equal to the sequential recurrence."""
+    import ctypes as ct
+    import torch
+    from snowmocap_amd import _lib
+    from oracle import oracle as orc
+    T, n = 200001, 532
+    rng = np.random.default_rng(42)
+    x = np.cumsum(rng.normal(0, 0.01, size=(T, n)), axis=0) + 1.5
+    ctx = _lib.scratch_context()
+    dev = torch.device("cuda", 0)
+    xd = torch.from_numpy(x).to(dev)
+    first = None
+    for rep in range(20):
+        yd = torch.empty_like(xd)
+        _lib.check(ctx.L.snowtri_smooth_track(ctx.handle, T, n, ct.c_void_p(xd.data_ptr()), 2.5, 0.75, 0.5, 1 / 30, ct.c_void_p(yd.data_ptr()),
+                                              _lib.DEVICE, None), "snowtri_smooth_track")
+        torch.cuda.synchronize(dev)
+        if first is None:
+            first = yd
+            want = orc.second_order_track(x, 2.5, 0.75, 0.5, 1 / 30)
+            assert np.abs(first.cpu().numpy() - want).max() < 2e-10
+        else:
+            assert torch.equal(yd.view(torch.int64), first.view(torch.int64)), rep
