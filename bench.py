@@ -207,6 +207,9 @@ def main():
                     help="pairwise = the reference's algorithm (the metric); dlt = N-view DLT (row N3), for comparison only")
     ap.add_argument("--force-dist", action="store_true",
                     help="testing aid: run the torch.distributed / all-gather code path even with --gpus 1")
+    ap.add_argument("--one-device", action="store_true",
+                    help="testing aid for a one-GPU box: every rank on cuda:0, torch.distributed over gloo (RCCL refuses two ranks "
+                         "on one device) -- the N > 1 code path with the real kernels; the line says `backend: gloo`")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the multi-person extra workloads")
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
@@ -226,8 +229,9 @@ def main():
 
     world = args.gpus
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.one_device else int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
+    backend = "gloo" if args.one_device else "nccl"
     if world > 1 or args.force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -235,8 +239,11 @@ def main():
         os.environ.setdefault("NCCL_DEBUG", "NONE")      # no RCCL version banner on stdout
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", rank=rank, world_size=int(os.environ.get("WORLD_SIZE", world)),
-                                device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=int(os.environ.get("WORLD_SIZE", world)),
+                                    device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group("gloo", rank=rank, world_size=int(os.environ.get("WORLD_SIZE", world)))
         assert dist.get_world_size() == world
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)
@@ -436,8 +443,9 @@ def main():
     kernel_ms_ranks = [kernel_ms]
     step_ms_ranks = [own_ms_per_step]
     if dist is not None:
-        kt = torch.zeros(2 * world, dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(kt, torch.tensor([kernel_ms, own_ms_per_step], dtype=torch.float64, device=dev))
+        kdev = dev if backend == "nccl" else "cpu"        # (gloo gathers host tensors)
+        kt = torch.zeros(2 * world, dtype=torch.float64, device=kdev)
+        dist.all_gather_into_tensor(kt, torch.tensor([kernel_ms, own_ms_per_step], dtype=torch.float64, device=kdev))
         kt = kt.cpu().view(world, 2)
         kernel_ms_ranks = [float(x) for x in kt[:, 0]]
         step_ms_ranks = [float(x) for x in kt[:, 1]]
@@ -541,6 +549,7 @@ def main():
             "steps": K_steps, "warmup": W_steps, "ms_per_step": ms_per_step, "ms_per_step_per_rank": step_ms_ranks, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "rccl_ranks": dist.get_world_size() if dist is not None else 1,
+            "backend": (backend if backend == "gloo" else "nccl (RCCL)") if dist is not None else None,
             "ranks": ranks_seen,
             "device_warmup": {"ms": args.device_warmup_ms, "untimed_steps": n_w},
             "repeats": {"n": len(regions), "statistic": "median", "ms_per_step_min": min(regions) / K_steps * 1e3,
