@@ -3,7 +3,7 @@
 single-cluster rig, configs/snowmocap_default_config.json:13), timed like the multi-person lines of bench.py: calls queued
 back to back on one stream, the context's event pair around each, median.
 
-    python scripts/bench_single_rigs.py [--cams=6,8] [--frames=10000,100000] [--out64] [--calls=N] [--kn=K]
+    python scripts/bench_single_rigs.py [--cams=6,8] [--frames=10000,100000] [--out64] [--calls=N] [--kn=K] [--dlt]
 A/B of development builds: SNOWTRI_LIB=.../ab/libsnowtri_<tag>.so python scripts/bench_single_rigs.py
 
 Roofline of a line: fp64 vector peak 78.6 TFLOP/s against the REFERENCE's work per output joint, 90 flop per pair solve
@@ -116,6 +116,6 @@ if __name__ == "__main__":
     for C in CAMS:
         for F in FRAMES:
             for odt in ([np.float64] if OUT64 else [np.float32, np.float64] if "--both" in sys.argv else [np.float32]):
-                ln = measure(C, F, odt, CALLS, KN)
+                ln = measure(C, F, odt, CALLS, KN, method=(1 if "--dlt" in sys.argv else 0), rig=arg("rig", "ring"))
                 print(json.dumps(ln))
                 sys.stdout.flush()

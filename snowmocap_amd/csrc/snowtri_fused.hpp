@@ -119,10 +119,12 @@ constexpr int kFastWaves = 2;
 #ifndef SNOWTRI_DLT_WIDE_WAVES
 #define SNOWTRI_DLT_WIDE_WAVES 2
 #endif
+// (DLT up to four cameras, round 6: the matrices read per camera as well, three waves per SIMD and two buffers -- 139 VGPRs; with the
+// 48 doubles of P hoisted it held 226 and two waves: 29.0 against 28.4 us per 10 000 frames of 4 x 1, the item is VALU-bound either way)
 template <int C, int METHOD, typename TIn>
 struct FusedShape {
-    static constexpr int kRing = C >= SNOWTRI_DLT_RING1_FROM ? 1 : ((C >= 5 || sizeof(TIn) == 8) ? 2 : 3);
-    static constexpr int kWaves = C >= 5 ? SNOWTRI_DLT_WIDE_WAVES : kFastWaves;
+    static constexpr int kRing = C >= SNOWTRI_DLT_RING1_FROM ? 1 : ((C >= 5 || sizeof(TIn) == 8) ? 2 : (METHOD == 1 ? 2 : 3));
+    static constexpr int kWaves = C >= 5 ? SNOWTRI_DLT_WIDE_WAVES : (METHOD == 1 ? 3 : kFastWaves);
 };
 
 template <typename T>
@@ -315,14 +317,19 @@ __device__ __forceinline__ bool pairwise_item(const Rig &rig, const double *__re
 // (6 sweeps x 6 rotations, fixed count: converged to 2e-14 m after 5 on the bench rig).
 // One observation (u, v) of a camera with world->pixel matrix P (12 doubles): adds the two rows
 // u P[2] - P[0], v P[2] - P[1] (scaled by w in {0, 1}) to the upper triangle of A^T A.
-template <typename PPtr>
+// MASKED = false: the caller knows w == 1 in every lane of the wave (1.0 * x is exact: the same bits without the eight products).
+template <bool MASKED = true, typename PPtr>
 __device__ __forceinline__ void dlt_add_observation(double (&A)[4][4], PPtr P, double u, double v, double w) {
 #pragma clang fp contract(off)   // results must not depend on which inlined copy computes them (see pairwise_item)
     double r1[4], r2[4];
 #pragma unroll
     for (int k = 0; k < 4; k++) {
-        r1[k] = w * fma(u, P[8 + k], -P[k]);
-        r2[k] = w * fma(v, P[8 + k], -P[4 + k]);
+        r1[k] = fma(u, P[8 + k], -P[k]);
+        r2[k] = fma(v, P[8 + k], -P[4 + k]);
+        if constexpr (MASKED) {
+            r1[k] = w * r1[k];
+            r2[k] = w * r2[k];
+        }
     }
 #pragma unroll
     for (int i = 0; i < 4; i++)
@@ -399,9 +406,12 @@ constexpr int kDltInvit = 8;
 // The wanted eigenvalue is the squared reprojection residual (tiny), the next one is ~1e4..1e5 times larger at
 // one pixel of noise, so four steps reach 2e-14 m (same as the SVD oracle) -- ~15x fewer instructions than the
 // Jacobi sweeps.  Convergence is linear, so a lane is done when (step length)^2 / (previous step length), the
-// estimate of the error left, drops below 1e-14; the loop leaves when every lane of the wave is done; lanes that
-// are not by kDltInvit steps (gross outliers: eigenvalue ratio above ~0.02) report false and the caller
-// re-solves them with Jacobi.  `live` = false lanes (fewer than two cameras) never block.
+// estimate of the error left, drops below 1e-14.  The first FOUR steps run without a test (round 6: a step with its
+// normalisation, step length, test, selects and wave vote was 70 instructions for 20 of solve; the first step from e_4 is
+// half a solve, the second needs no normalisation, the step lengths of steps 3 and 4 decide) -- 4 x 70 -> 140; only a wave
+// with a lane that has not settled by then goes on, step by step, up to kDltInvit; lanes that have not by then
+// (gross outliers: eigenvalue ratio above ~0.02) report false and the caller re-solves them with Jacobi.
+// `live` = false lanes (fewer than two cameras) never block.
 __device__ __forceinline__ bool dlt_inverse_iteration(const double (&A)[4][4], bool live, double (&e)[4]) {
 #pragma clang fp contract(off)   // results must not depend on which inlined copy computes them (see pairwise_item)
     const double mu = (A[0][0] + A[1][1] + A[2][2] + A[3][3]) * (64.0 * 2.220446049250313e-16);
@@ -420,12 +430,8 @@ __device__ __forceinline__ bool dlt_inverse_iteration(const double (&A)[4][4], b
             L[i][j] = v * inv[j];
         }
     }
-    double x[4] = {0.0, 0.0, 0.0, 1.0};
-    double prev = 1.0;  // previous step length
-    bool conv = !live;
-#pragma unroll 1
-    for (int it = 0; it < kDltInvit; it++) {
-        double y[4], z[4];
+    auto solve = [&](const double (&x)[4], double (&z)[4]) {   // z = G^-1 x
+        double y[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) {  // L y = x
             double v = x[i];
@@ -440,18 +446,45 @@ __device__ __forceinline__ bool dlt_inverse_iteration(const double (&A)[4][4], b
             for (int k = i + 1; k < 4; k++) v = fma(-L[k][i], z[k], v);
             z[i] = v * inv[i];
         }
+    };
+    auto unit = [](const double (&z)[4], double (&n)[4]) {
         const double rn = rsq_nr2(fma(z[3], z[3], fma(z[2], z[2], fma(z[1], z[1], z[0] * z[0]))));
-        double diff = 0.0;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const double xn = z[i] * rn;
-            diff = fmax(diff, fabs(xn - x[i]));
-            x[i] = conv ? x[i] : xn;   // a settled lane keeps its answer: it must not depend on how long its wave iterates
+        for (int i = 0; i < 4; i++) n[i] = z[i] * rn;
+    };
+    auto step_length = [](const double (&a)[4], const double (&b)[4]) {
+        return fmax(fmax(fabs(a[0] - b[0]), fabs(a[1] - b[1])), fmax(fabs(a[2] - b[2]), fabs(a[3] - b[3])));
+    };
+    double x[4], z[4], n[4];
+    // step 1 from e_4: L y = e_4 has y = (0, 0, 0, inv_3), so only the back substitution is left
+    z[3] = inv[3] * inv[3];
+    z[2] = -(L[3][2] * z[3]) * inv[2];
+    z[1] = fma(-L[3][1], z[3], -(L[2][1] * z[2])) * inv[1];
+    z[0] = fma(-L[3][0], z[3], fma(-L[2][0], z[2], -(L[1][0] * z[1]))) * inv[0];
+    solve(z, x);          // step 2 (the length of its input does not matter)
+    unit(x, n);
+    solve(n, z);          // step 3
+    unit(z, x);
+    const double d3 = step_length(x, n);
+    solve(x, z);          // step 4
+    unit(z, n);
+    double prev = step_length(n, x);
+    // linear convergence with ratio r = step / previous step: the error left after a step is ~ step * r
+    bool conv = !live || (prev * prev < 1e-14 * d3);
+#pragma unroll
+    for (int i = 0; i < 4; i++) x[i] = n[i];
+    if (!__all(conv)) {
+#pragma unroll 1
+        for (int it = 4; it < kDltInvit; it++) {
+            solve(x, z);
+            unit(z, n);
+            const double diff = step_length(n, x);
+#pragma unroll
+            for (int i = 0; i < 4; i++) x[i] = conv ? x[i] : n[i];   // a settled lane keeps its answer: it must not depend on how long its wave iterates
+            conv = conv || (diff * diff < 1e-14 * prev);
+            prev = diff;
+            if (__all(conv)) break;
         }
-        // linear convergence with ratio r = diff / prev: the error left after this step is ~ diff * r
-        conv = conv || (diff * diff < 1e-14 * prev);
-        prev = diff;
-        if (__all(conv)) break;
     }
 #pragma unroll
     for (int i = 0; i < 4; i++) e[i] = x[i];
@@ -469,19 +502,18 @@ __device__ __forceinline__ void dlt_solve(double (&A)[4][4], bool live, double (
     }
 }
 
+// X = e / e_3 and the mean confidence: reciprocals by v_rcp_f64 + two Newton steps (~1 ulp; the IEEE divisions were 2 x ~14
+// instructions per joint), 1 / 0 kept as the division has it
+__device__ __forceinline__ double dlt_recip(double x) { return x == 0.0 ? copysign(__builtin_inf(), x) : rcp_nr2(x); }
+
+// npmask: bit c set = camera c lists a detection in this frame (all ones without an n_persons array)
 template <int C, typename TIn>
-__device__ __forceinline__ void dlt_item(const double *__restrict__ Plds, const Kp3<TIn> (&cur)[C], const int32_t *np_f,
+__device__ __forceinline__ void dlt_item(const double *__restrict__ Plds, const Kp3<TIn> (&cur)[C], uint32_t npmask,
                                          const Params &prm, double &ox, double &oy, double &oz, double &os) {
 #pragma clang fp contract(off)   // (same reason as in pairwise_item)
-    // world->pixel matrices P[C][12] come from LDS (broadcast reads), like the ray matrices of the pairwise
-    // item: 96 doubles in scalar registers overflow the SGPR file and come back as v_readlane traffic
-    // (five cameras and more: 60+ doubles of P beside the ring spilled; there a camera's matrix is read where it is used)
-    constexpr bool kHoist = C <= 4;
-    double Pp[kHoist ? 12 * C : 1];
-    if constexpr (kHoist) {
-#pragma unroll
-        for (int i = 0; i < 12 * C; i++) Pp[i] = Plds[i];
-    }
+    // world->pixel matrices P[C][12] come from LDS (broadcast reads), like the ray matrices of the pairwise item, a camera's
+    // matrix where its observation is added: 96 doubles in scalar registers overflow the SGPR file and come back as v_readlane
+    // traffic, in vector registers they cost a wave per SIMD
     double A[4][4];
 #pragma unroll
     for (int i = 0; i < 4; i++)
@@ -489,27 +521,36 @@ __device__ __forceinline__ void dlt_item(const double *__restrict__ Plds, const 
         for (int k = 0; k < 4; k++) A[i][k] = 0.0;
     double ssum = 0.0;
     int cnt = 0;
+    bool use[C];
+    bool every = true;
 #pragma unroll
     for (int c = 0; c < C; c++) {
-        bool use = !((double)cur[c].s < prm.kthr);
-        if (np_f) use &= np_f[c] > 0;
-        if constexpr (kHoist)
-            dlt_add_observation(A, Pp + 12 * c, (double)cur[c].u, (double)cur[c].v, use ? 1.0 : 0.0);
-        else {
-            __builtin_amdgcn_sched_barrier(0);   // a camera's twelve LDS reads stay with its observation (register budget)
-            dlt_add_observation(A, Plds + 12 * c, (double)cur[c].u, (double)cur[c].v, use ? 1.0 : 0.0);
-        }
-        ssum += use ? (double)cur[c].s : 0.0;
-        cnt += use ? 1 : 0;
+        use[c] = !((double)cur[c].s < prm.kthr) && ((npmask >> c) & 1u);
+        every = every && use[c];
+        ssum += use[c] ? (double)cur[c].s : 0.0;
+        cnt += use[c] ? 1 : 0;
     }
+    // every camera of every lane counts (the usual wave): the rows are added as they are, no product with the mask
+    auto accumulate = [&](auto masked_c) {
+        constexpr bool MASKED = decltype(masked_c)::value;
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            __builtin_amdgcn_sched_barrier(0);   // a camera's twelve LDS reads stay with its observation (register budget)
+            dlt_add_observation<MASKED>(A, Plds + 12 * c, (double)cur[c].u, (double)cur[c].v, use[c] ? 1.0 : 0.0);
+        }
+    };
+    if (__all(every))
+        accumulate(std::false_type{});
+    else
+        accumulate(std::true_type{});
     const bool ok = cnt >= 2;
     double e[4];
     dlt_solve(A, ok, e);
-    const double r = 1.0 / e[3];
+    const double r = dlt_recip(e[3]);
     ox = ok ? e[0] * r : 0.0;
     oy = ok ? e[1] * r : 0.0;
     oz = ok ? e[2] * r : 0.0;
-    os = ok ? ssum / (double)cnt : 0.0;
+    os = ok ? ssum * dlt_recip((double)cnt) : 0.0;
 }
 
 template <int C, int METHOD, typename TIn, typename TOut>
@@ -550,7 +591,18 @@ __global__ __launch_bounds__(kBlock, (FusedShape<C, METHOD, TIn>::kWaves)) void 
         const int64_t f0 = tile * T;
         const int nf = (int)((F - f0) < T ? (F - f0) : T);
         const int nitems = nf * J;
-        for (int i = tid; i < nf; i += kBlock) fflag[i] = 0;
+        // (DLT: bits 16.. = the cameras that list a detection in the frame -- read once per frame here, not once per item)
+        for (int i = tid; i < nf; i += kBlock) {
+            uint32_t m = 0u;
+            if constexpr (METHOD == 1) {
+                m = 0xffff0000u;
+                if (n_persons) {
+                    m = 0u;
+                    for (int c = 0; c < C; c++) m |= n_persons[(f0 + i) * C + c] > 0 ? (0x10000u << c) : 0u;
+                }
+            }
+            fflag[i] = m;
+        }
         // centre joints for the single-cluster check of the epilogue: fetched now, used after the item loop
         Kp3<TIn> ck[4];
         bool have_centres = false;
@@ -579,7 +631,7 @@ __global__ __launch_bounds__(kBlock, (FusedShape<C, METHOD, TIn>::kWaves)) void 
                 } else {
                     bad = false;
                     if constexpr (C >= 5) asm volatile("" ::: "memory");   // (P is re-read from LDS by every item: hoisted out of the loop it takes 12 C doubles)
-                    dlt_item<C>(Mlds, buf, n_persons ? n_persons + (f0 + fl_) * C : nullptr, prm, ox, oy, oz, os);
+                    dlt_item<C>(Mlds, buf, fflag[fl_] >> 16, prm, ox, oy, oz, os);
                 }
                 if (j_ < kn) {
                     Vec4T<TOut> *tile_out = reinterpret_cast<Vec4T<TOut> *>(out4) + f0 * Pout * (int64_t)kn;

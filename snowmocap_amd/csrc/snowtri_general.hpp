@@ -678,11 +678,11 @@ __global__ __launch_bounds__(kBlock, kRecomputeWaves) void k_frame_recompute(int
                     double e[4];
                     dlt_solve(A, cnt >= 2, e);
                     if (cnt >= 2) {
-                        const double r = 1.0 / e[3];
+                        const double r = dlt_recip(e[3]);
                         ox = e[0] * r;
                         oy = e[1] * r;
                         oz = e[2] * r;
-                        os = ssum / (double)cnt;
+                        os = ssum * dlt_recip((double)cnt);
                     }
                 }
 
