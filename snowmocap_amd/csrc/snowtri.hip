@@ -2149,8 +2149,13 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st_call, int64_t F, int
     // the first keypoint_num joints (kn / J of the first).
     // handover_mode 1: the streaming association (<= 16 cameras); 2: descriptors written by k_frame_recompute itself
     // (<= 8 cameras, float32 outputs, keypoint_num == J: register-resident rays in k_cluster_fuse), staged in its arena.
-    const bool can_hand = METHOD == 0 && C >= 2 && Pmax <= kClusterMaxPersons && prm.kn >= 1 && J <= 256 && prm.kthr >= 0.0 && Pout >= 1 &&
-                          (size_t)Pout * 24 + 80 <= (size_t)kRayChunkBytes && !(prm.score_tol != prm.score_tol);
+    // METHOD = 1 (DLT behind the reference's association, row N3): the streaming association too, then k_cluster_dlt on its
+    // descriptors.  A person's mean score there is the mean of the DLT joint scores (mean confidences >= keypoint_score_threshold
+    // >= 0), which the association cannot know: the route is taken when the filter of :151-152 cannot drop anybody
+    // (condense_score_tol <= 0, the reference's default); otherwise the frames stay on k_frame_recompute<1>.
+    const bool can_hand = C >= 2 && Pmax <= kClusterMaxPersons && prm.kn >= 1 && J <= 256 && prm.kthr >= 0.0 && Pout >= 1 &&
+                          (size_t)Pout * 24 + 80 <= (size_t)kRayChunkBytes && !(prm.score_tol != prm.score_tol) &&
+                          (METHOD == 0 || prm.score_tol <= 0.0);
     // ONE detection per camera with average_score_threshold <= 0 <= keypoint_score_threshold and no mean-score filter: every
     // listed candidate is kept whatever its mean (:80-81; scores that pass the keypoint gate are >= 0), so the candidate pass
     // has nothing to decide.  It is skipped (`sumless`): k_associate reads a constant positive sum for every slot, the
@@ -2159,7 +2164,7 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st_call, int64_t F, int
     // cameras on the shapes the lean kernels do not take (fused_dispatch).
     const bool sumless = METHOD == 0 && Pmax == 1 && prm.avg_thr <= 0.0 && prm.kthr >= 0.0 && prm.score_tol <= 0.0 && ctx->sumless_mode != 0;
     const bool sums_kn = !sumless && prm.kn != J && !(prm.score_tol <= 0.0);   // second candidate-sum launch over the first keypoint_num joints
-    const bool post_scores = sumless || sizeof(TOut) == 8 || prm.kn != J;   // the persons' mean scores by k_person_scores
+    const bool post_scores = sumless || sizeof(TOut) == 8 || prm.kn != J || METHOD == 1;   // the persons' mean scores by k_person_scores
     SumsLaunch SL{};
     // (distance_threshold >= 0: k_candidate_sums reads its distance gate off a sign bit, p1_tile_sums)
     bool stream = can_hand && ctx->handover_mode == 1 && C <= 16 && Kc < ((int64_t)1 << 24) && Pout <= 1024 && (sumless || prm.dthr >= 0.0);
@@ -2167,7 +2172,7 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st_call, int64_t F, int
         SL = sums_launch_shape(ctx, Pmax, J);
         stream = SL.Jc >= 1;
     }
-    const bool handover = !stream && can_hand && sizeof(TOut) == 4 && prm.kn == J && ctx->handover_mode != 0 && C <= kClusterMaxCams;
+    const bool handover = METHOD == 0 && !stream && can_hand && sizeof(TOut) == 4 && prm.kn == J && ctx->handover_mode != 0 && C <= kClusterMaxCams;
     // the two descriptor lists hold Pout persons for every frame of a segment (<= 2 M entries each, 64 MB together), the
     // member list Kc words per frame (<= 64 M words, 256 MB); row indices are 32-bit; the candidate sums of the
     // streaming association 8 Kc bytes per frame (<= 1 GB).  Sized for the LARGE rigs: a frame of 16 x 8 holds a CU for
@@ -2234,7 +2239,10 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st_call, int64_t F, int
             const std::string rec = "k_frame_recompute<" + std::to_string(METHOD) + "," + tin + "," + tout + ">";
             const std::string fuse = C <= kClusterMaxCams ? "k_cluster_fuse<" + std::to_string(C) + "," + tin + "> + k_cluster_members<" + tin + ">"
                                                            : "k_cluster_fuse_wide<" + tin + "> + k_cluster_members<" + tin + ">";
-            if (stream && sumless)
+            if (stream && METHOD == 1)
+                ctx->names_buf = "k_candidate_sums<" + tin + "," + std::to_string(SL.threads) + "> + k_candidate_sums_exact<" + tin +
+                                 "> + k_associate<" + tin + "> + k_cluster_dlt<" + std::to_string(C <= kClusterMaxCams ? C : 0) + "," + tin + "," + tout + "> + k_person_scores<" + tout + "> + " + rec + " (frames left behind)";
+            else if (stream && sumless)
                 ctx->names_buf = "k_singular_scan<" + tin + "> + k_associate<" + tin + "> + " + fuse + " + k_person_scores<" + tout + "> + " + rec + " (frames left behind)";
             else if (stream)
                 ctx->names_buf = "k_candidate_sums<" + tin + "," + std::to_string(SL.threads) + "> + k_candidate_sums_exact<" + tin +
@@ -2279,9 +2287,9 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st_call, int64_t F, int
         TOut *xyz_seg = d_xyzs + s0 * (int64_t)Pout * prm.kn * 4;
         TOut *ps_seg = d_ps ? d_ps + s0 * Pout : nullptr;
         uint32_t *fl_seg = d_fl ? d_fl + s0 : nullptr;
-        if constexpr (METHOD == 0) {
+        {
             if (stream) {
-                // ---- k_candidate_sums -> k_associate -> k_cluster_fuse, then k_frame_recompute on the frames left behind
+                // ---- k_candidate_sums -> k_associate -> k_cluster_fuse (DLT: k_cluster_dlt), then k_frame_recompute on the frames left behind
                 const size_t sum_bytes = ((size_t)Fs * Kc * 8 + 255) & ~(size_t)255;
                 rc = ctx->cur->sums.ensure((sums_kn ? 2 : 1) * sum_bytes + (size_t)Fs * 12 + 256);   // + the frames left behind (two passes) + the frames to re-do exactly
                 if (rc) return rc;
@@ -2366,8 +2374,36 @@ int launch_frame_recompute(snowtri_ctx *ctx, hipStream_t st_call, int64_t F, int
                                hand_counters, cap, word_cap, (const uint32_t *)nullptr, (const unsigned long long *)nullptr);
             HIP_TRY(hipGetLastError());
         }
-        if constexpr (METHOD == 0) {
-            if (stream || handover) {
+        if constexpr (METHOD == 1) {
+            if (stream) {
+                // both descriptor lists in one launch: an N-view DLT per (output person, joint)
+                const int64_t passes_max = (Fs * Pout * (int64_t)prm.kn + 63) / 64;
+                const int gridd = (int)std::max<int64_t>(1, std::min<int64_t>((passes_max + 3) / 4, (int64_t)ctx->num_cus * kClusterDltWaves));
+                switch (C) {
+#define SNOWTRI_CASE(CC)                                                                                                                \
+    case CC:                                                                                                                            \
+        hipLaunchKernelGGL((k_cluster_dlt<CC, TIn, TOut>), dim3(gridd), dim3(kBlock), cluster_dlt_lds_bytes(C), st, desc, words, hand_counters, cap, \
+                           ctx->rig(), kp_seg, prm, Pmax, J, prm.kn, kmagic, Pout, xyz_seg);                                            \
+        break;
+#ifndef SNOWTRI_DEV_MIN
+                    SNOWTRI_CASE(2)
+                    SNOWTRI_CASE(3)
+                    SNOWTRI_CASE(5)
+                    SNOWTRI_CASE(6)
+                    SNOWTRI_CASE(7)
+#endif
+                    SNOWTRI_CASE(4)
+                    SNOWTRI_CASE(8)
+                    default:   // more than 8 cameras
+                        hipLaunchKernelGGL((k_cluster_dlt<0, TIn, TOut>), dim3(gridd), dim3(kBlock), cluster_dlt_lds_bytes(C), st, desc, words, hand_counters, cap,
+                                           ctx->rig(), kp_seg, prm, Pmax, J, prm.kn, kmagic, Pout, xyz_seg);
+#undef SNOWTRI_CASE
+                }
+                HIP_TRY(hipGetLastError());
+            }
+        }
+        {
+            if constexpr (METHOD == 0) if (stream || handover) {
                 switch (C) {
 #define SNOWTRI_CASE(CC)                                                                                                       \
     case CC:                                                                                                                   \

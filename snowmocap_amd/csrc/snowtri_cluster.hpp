@@ -491,4 +491,136 @@ __global__ __launch_bounds__(kBlock, kWideWaves) void k_cluster_fuse_wide(const 
     }
 }
 
+// ------------------------------------------------------------------------------------------------ k_cluster_dlt
+// method = SNOWTRI_DLT behind the streaming association (row N3; k_frame_recompute<1> keeps the frames the association leaves
+// behind and the batches with an active condense_score_tol): lane = (descriptor, joint) over BOTH lists of a launch,
+// first the complete-graph descriptors, then the member lists.
+//   complete graph   one observation per camera: the person its 4-bit field names (cameras 0-7 in `persons`, 8-15 in `size`).
+//                    CT = the camera count at compile time (2..8): the CT keypoints requested together, dlt_item<CT> as in
+//                    k_fused_single<CT,1>; CT = 0: any count up to 16, four keypoints in flight at a time.
+//   member list      the DISTINCT (camera, person) rows its member words name: one pass over the words marks them in a 256-bit
+//                    set (<= 16 cameras x 16 persons), a second walks the set in row order -- one observation per row, not two
+//                    per member (a 7-camera cluster has 21 members and 7 rows).
+// Per lane the N-view DLT of k_fused_single<C,1> / k_frame_recompute<1> over them (dlt_add_observation, dlt_solve): the rows of
+// the observations whose confidence is not below keypoint_score_threshold, two needed, joint score = their mean confidence.
+// The persons' mean scores: k_person_scores.  P [C][12] in LDS (broadcast reads).  Dynamic LDS: cluster_dlt_lds_bytes(C).
+constexpr int kClusterDltWaves = 3;
+__host__ __device__ constexpr size_t cluster_dlt_lds_bytes(int C) { return (size_t)96 * C + 16; }
+template <int CT, typename TIn, typename TOut>
+__global__ __launch_bounds__(kBlock, kClusterDltWaves) void k_cluster_dlt(const ClusterDesc *__restrict__ desc, const uint32_t *__restrict__ words,
+                                                              const unsigned long long *__restrict__ cnt, uint32_t desc_cap, Rig rig,
+                                                              const TIn *__restrict__ kpts, Params prm, int Pmax, int J, int kn,
+                                                              unsigned long long kmagic, int Pout, TOut *__restrict__ out4) {
+#pragma clang fp contract(off)   // (as in dlt_item)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    double *Pl = reinterpret_cast<double *>(smem);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int C = CT > 0 ? CT : rig.C, R = C * Pmax;
+    for (int i = tid; i < 12 * C; i += kBlock) Pl[i] = rig.P[i];
+    const unsigned long long nc64 = cnt[kHandComplete];
+    const uint32_t ng_raw = hand_member_descs(cnt[kHandMembers]);
+    const uint32_t nc = nc64 < (unsigned long long)desc_cap ? (uint32_t)nc64 : desc_cap, ng = ng_raw < desc_cap ? ng_raw : desc_cap;
+    const uint32_t total_c = nc * (uint32_t)kn, total_g = ng * (uint32_t)kn;
+    const uint32_t npass_c = (total_c + 63u) >> 6, npass_g = (total_g + 63u) >> 6;
+    const uint32_t W = gridDim.x * (uint32_t)(kBlock / 64);
+    const unsigned long long magic_pmax = (((unsigned long long)1 << 40) + (unsigned)Pmax - 1) / (unsigned)Pmax;
+    const Kp3<TIn> *kp3 = reinterpret_cast<const Kp3<TIn> *>(kpts);
+    __syncthreads();
+    for (uint32_t p = blockIdx.x * (uint32_t)(kBlock / 64) + (uint32_t)wave; p < npass_c + npass_g; p += W) {
+        const bool gen = p >= npass_c;   // (wave-uniform)
+        const uint32_t i = ((gen ? p - npass_c : p) << 6) + (uint32_t)lane;
+        bool valid = i < (gen ? total_g : total_c);
+        const uint32_t ic = valid ? i : 0u;
+        const uint32_t di = (uint32_t)(((unsigned long long)ic * kmagic) >> 40);
+        const uint32_t j = ic - di * (uint32_t)kn;
+        uint4 d = make_uint4(0u, 0u, 0u, 0u);
+        if (valid) {
+            d = *reinterpret_cast<const uint4 *>(desc + (gen ? desc_cap : 0u) + di);
+            valid = d.z < (uint32_t)Pout;   // (a voided entry)
+        }
+        const uint64_t row0 = (uint64_t)d.x * (uint32_t)R;
+        double ox, oy, oz, os;
+        if constexpr (CT > 0) {
+            if (!gen) {
+                Kp3<TIn> cur[CT];
+#pragma unroll
+                for (int c = 0; c < CT; c++) {
+                    const uint32_t person = (d.y >> (4 * c)) & 15u;
+                    SNOWTRI_DEV_CHECK(!valid || person < (uint32_t)Pmax, 32);   // person index of camera c
+                    cur[c] = kp3[(row0 + (uint32_t)(c * Pmax) + (valid ? person : 0u)) * (uint32_t)J + j];
+                }
+                asm volatile("" ::: "memory");   // (P is read from LDS by every item)
+                dlt_item<CT, TIn>(Pl, cur, valid ? 0xffffu : 0u, prm, ox, oy, oz, os);
+            }
+        }
+        if (CT == 0 || gen) {
+            double A[4][4];
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) A[a][b] = 0.0;
+            double ssum = 0.0;
+            int nuse = 0;
+            auto observe = [&](int c, const Kp3<TIn> &k, bool have) {
+                const bool use = have && !below_kthr(k.s, prm);
+                dlt_add_observation(A, Pl + 12 * c, (double)k.u, (double)k.v, use ? 1.0 : 0.0);
+                ssum += use ? (double)k.s : 0.0;
+                nuse += use ? 1 : 0;
+            };
+            if (!gen) {
+                for (int c0 = 0; c0 < C; c0 += 4) {   // four keypoints in flight
+                    Kp3<TIn> k[4];
+#pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        const int c = c0 + u < C ? c0 + u : C - 1;
+                        const uint32_t person = ((c < 8 ? d.y : d.w) >> (4 * (c & 7))) & 15u;
+                        SNOWTRI_DEV_CHECK(!valid || person < (uint32_t)Pmax, 32);   // person index of camera c
+                        k[u] = kp3[(row0 + (uint32_t)(c * Pmax) + (valid ? person : 0u)) * (uint32_t)J + j];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; u++)
+                        if (c0 + u < C) observe(c0 + u, k[u], valid);
+                }
+            } else {
+                const int size = valid ? (int)d.w : 0;
+                unsigned long long seen[4] = {0ull, 0ull, 0ull, 0ull};   // rows of the frame (<= 16 cameras x 16 persons)
+                for (int m = 0; __ballot(m < size) != 0ull; m++) {
+                    const uint32_t w = m < size ? words[d.y + (uint32_t)m] : 0u;
+                    const int rm = (int)(w & 1023u), rs = (int)((w >> 10) & 1023u);
+                    SNOWTRI_DEV_CHECK(m >= size || (rm < R && rs < R && R <= 256), 33);   // rows of the member inside the frame
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+                        seen[q] |= m < size ? (((rm >> 6) == q ? 1ull << (rm & 63) : 0ull) | ((rs >> 6) == q ? 1ull << (rs & 63) : 0ull)) : 0ull;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    if (64 * q >= R) break;   // (wave-uniform)
+                    unsigned long long left = seen[q];
+                    while (__ballot(left != 0ull) != 0ull) {   // two rows per trip: their keypoints requested together
+                        const bool h0 = left != 0ull;
+                        const int r0 = 64 * q + (h0 ? __ffsll((long long)left) - 1 : 0);
+                        left &= left - 1ull;
+                        const bool h1 = left != 0ull;
+                        const int r1 = 64 * q + (h1 ? __ffsll((long long)left) - 1 : 0);
+                        left &= left - 1ull;
+                        const Kp3<TIn> k0 = kp3[(row0 + (uint32_t)r0) * (uint32_t)J + j], k1 = kp3[(row0 + (uint32_t)r1) * (uint32_t)J + j];
+                        observe((int)(((unsigned long long)(unsigned)r0 * magic_pmax) >> 40), k0, h0);
+                        observe((int)(((unsigned long long)(unsigned)r1 * magic_pmax) >> 40), k1, h1);
+                    }
+                }
+            }
+            const bool ok = valid && nuse >= 2;
+            double e[4];
+            dlt_solve(A, ok, e);   // (every lane of the wave: the solver votes)
+            const double r = dlt_recip(e[3]);
+            ox = ok ? e[0] * r : 0.0;
+            oy = ok ? e[1] * r : 0.0;
+            oz = ok ? e[2] * r : 0.0;
+            os = ok ? ssum * dlt_recip((double)nuse) : 0.0;
+        }
+        if (valid) cluster_store<TOut>(out4, ((uint64_t)d.x * (uint32_t)Pout + d.z) * (uint64_t)(uint32_t)kn + j, ox, oy, oz, os);
+    }
+}
+
 }  // namespace snowtri

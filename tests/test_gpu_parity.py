@@ -355,6 +355,61 @@ def test_dlt_multi_person_against_oracle(api):
     assert np.abs(out1["xyzs"][:, 0, :, :3] - X1[:, 0]).max() < 0.01
 
 
+def test_dlt_multi_person_streaming_route_equals_the_frame_kernel(api, knobs):
+    """method = DLT with several detections per camera takes the streaming association + k_cluster_dlt (complete-graph
+    descriptors AND member lists: ragged person counts, a camera that sees nobody, permuted person order) unless
+    condense_score_tol is active; k_frame_recompute<1> (forced by SNOWTRI_HANDOVER_MODE=0, and taken with an active tolerance)
+    solves the same clusters over the same observations: identical counts, joints within 1e-9 (relative beyond a metre: a ghost
+    cluster of two nearly parallel rays lies kilometres away), both against the oracle."""
+    from snowmocap_amd import synth, _lib
+    from oracle import dlt, oracle as orc
+    rng = np.random.default_rng(77)
+    for C, P, F, in_dtype, out_dtype in ((8, 4, 40, np.float32, np.float32), (6, 3, 30, np.float64, np.float64), (12, 3, 12, np.float32, np.float64)):
+        K, R, t = synth.ring_rig(C)
+        X = synth.make_people(rng, F, P)
+        kp, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=1.0, score_range=(2.0, 8.0), permute_persons=True, dtype=in_dtype)
+        npers[1, 0] = P - 1                      # ragged lists -> member-list clusters
+        npers[2, C - 1] = 0
+        npers[3, 1:3] = 1
+        kp[4, :, :, 5, 2] = 1.0                  # a joint nobody sees
+        prm = dict(synth.default_thresholds())
+        prm.update(average_score_threshold=1.0, condense_distance_tol=0.3)
+        pout = 2 * P + 2
+        want, wps, wcnt = dlt.dlt_multi_batch(K, R, t, kp, npers, orc.make_params(**prm), pout)
+        outs = {}
+        for route in ("stream", "frame"):
+            if route == "frame":
+                knobs.set("SNOWTRI_HANDOVER_MODE", "0")
+            bt = api.BatchTriangulator(K, R, t, prm, pout_max=pout, out_dtype=out_dtype, method=_lib.DLT)
+            outs[route] = bt.run_host(kp, npers)
+            names = bt.ctx.last_kernel_names()
+            handed = bt.ctx.last_handover_persons()
+            bt.close()
+            knobs.clear()
+            assert ("k_cluster_dlt<%d," % (C if C <= 8 else 0) in names) == (route == "stream"), names
+            if route == "stream":
+                assert handed[0] > 0 and handed[1] > 0, handed          # both lists of descriptors were used
+            o = outs[route]
+            np.testing.assert_array_equal(o["count"], wcnt)
+            # (float32 outputs: + one float32 ulp of the value -- a ghost cluster of two nearly parallel rays lies kilometres away)
+            tol = 1e-9 * (1.0 + np.abs(want[..., :3])) if out_dtype == np.float64 else XYZ_F32 + 1.2e-7 * np.abs(want[..., :3])
+            assert (np.abs(o["xyzs"][..., :3] - want[..., :3]) <= tol).all()
+            np.testing.assert_allclose(o["xyzs"][..., 3], want[..., 3], rtol=1e-6)
+            np.testing.assert_allclose(o["pscore"], wps, rtol=1e-6)
+        assert (np.abs(outs["stream"]["xyzs"][..., :3] - outs["frame"]["xyzs"][..., :3]) <= tol).all()
+    # an active condense_score_tol is decided on the DLT joint scores, which the association does not have: the frame kernel
+    prm2 = dict(prm, condense_score_tol=4.9)
+    want2, wps2, wcnt2 = dlt.dlt_multi_batch(K, R, t, kp, npers, orc.make_params(**prm2), pout)
+    bt = api.BatchTriangulator(K, R, t, prm2, pout_max=pout, out_dtype=np.float64, method=_lib.DLT)
+    o2 = bt.run_host(kp, npers)
+    names = bt.ctx.last_kernel_names()
+    bt.close()
+    assert "k_cluster_dlt" not in names and names.startswith("k_frame_recompute<1,"), names
+    np.testing.assert_array_equal(o2["count"], wcnt2)
+    assert (wcnt2 < wcnt).any()                  # the tolerance did drop somebody
+    assert np.abs(o2["xyzs"][..., :3] - want2[..., :3]).max() < 1e-9
+
+
 @pytest.mark.parametrize("mode", ["1", "2"])
 def test_general_kernels_agree(api, mode, knobs):
     """Spill kernel (mode 1) and recompute kernel (mode 2) forced on a single-person batch must both
