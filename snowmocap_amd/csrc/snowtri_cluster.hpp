@@ -585,28 +585,41 @@ __global__ __launch_bounds__(kBlock, kClusterDltWaves) void k_cluster_dlt(const 
             } else {
                 const int size = valid ? (int)d.w : 0;
                 unsigned long long seen[4] = {0ull, 0ull, 0ull, 0ull};   // rows of the frame (<= 16 cameras x 16 persons)
-                for (int m = 0; __ballot(m < size) != 0ull; m++) {
-                    const uint32_t w = m < size ? words[d.y + (uint32_t)m] : 0u;
-                    const int rm = (int)(w & 1023u), rs = (int)((w >> 10) & 1023u);
-                    SNOWTRI_DEV_CHECK(m >= size || (rm < R && rs < R && R <= 256), 33);   // rows of the member inside the frame
+                for (int m0 = 0; __ballot(m0 < size) != 0ull; m0 += 8) {   // eight member words requested together (one after the other
+                    uint32_t w[8];                                         // they were a chain of 10-21 round trips per item)
 #pragma unroll
-                    for (int q = 0; q < 4; q++)
-                        seen[q] |= m < size ? (((rm >> 6) == q ? 1ull << (rm & 63) : 0ull) | ((rs >> 6) == q ? 1ull << (rs & 63) : 0ull)) : 0ull;
+                    for (int u = 0; u < 8; u++) w[u] = m0 + u < size ? words[d.y + (uint32_t)(m0 + u)] : 0xffffffffu;
+#pragma unroll
+                    for (int u = 0; u < 8; u++) {
+                        const bool live = m0 + u < size;
+                        const int rm = (int)(w[u] & 1023u), rs = (int)((w[u] >> 10) & 1023u);
+                        SNOWTRI_DEV_CHECK(!live || (rm < R && rs < R && R <= 256), 33);   // rows of the member inside the frame
+                        if (R <= 64) {   // (wave-uniform; the usual rig: one word of the set -- the four-word update is 40 instructions per member)
+                            seen[0] |= live ? ((1ull << rm) | (1ull << rs)) : 0ull;
+                        } else {
+#pragma unroll
+                            for (int q = 0; q < 4; q++)
+                                seen[q] |= live ? (((rm >> 6) == q ? 1ull << (rm & 63) : 0ull) | ((rs >> 6) == q ? 1ull << (rs & 63) : 0ull)) : 0ull;
+                        }
+                    }
                 }
 #pragma unroll
                 for (int q = 0; q < 4; q++) {
                     if (64 * q >= R) break;   // (wave-uniform)
                     unsigned long long left = seen[q];
-                    while (__ballot(left != 0ull) != 0ull) {   // two rows per trip: their keypoints requested together
-                        const bool h0 = left != 0ull;
-                        const int r0 = 64 * q + (h0 ? __ffsll((long long)left) - 1 : 0);
-                        left &= left - 1ull;
-                        const bool h1 = left != 0ull;
-                        const int r1 = 64 * q + (h1 ? __ffsll((long long)left) - 1 : 0);
-                        left &= left - 1ull;
-                        const Kp3<TIn> k0 = kp3[(row0 + (uint32_t)r0) * (uint32_t)J + j], k1 = kp3[(row0 + (uint32_t)r1) * (uint32_t)J + j];
-                        observe((int)(((unsigned long long)(unsigned)r0 * magic_pmax) >> 40), k0, h0);
-                        observe((int)(((unsigned long long)(unsigned)r1 * magic_pmax) >> 40), k1, h1);
+                    while (__ballot(left != 0ull) != 0ull) {   // four rows per trip: their keypoints requested together
+                        bool h[4];
+                        int r[4];
+                        Kp3<TIn> k[4];
+#pragma unroll
+                        for (int u = 0; u < 4; u++) {
+                            h[u] = left != 0ull;
+                            r[u] = 64 * q + (h[u] ? __ffsll((long long)left) - 1 : 0);
+                            left &= left - 1ull;
+                            k[u] = kp3[(row0 + (uint32_t)r[u]) * (uint32_t)J + j];
+                        }
+#pragma unroll
+                        for (int u = 0; u < 4; u++) observe((int)(((unsigned long long)(unsigned)r[u] * magic_pmax) >> 40), k[u], h[u]);
                     }
                 }
             }

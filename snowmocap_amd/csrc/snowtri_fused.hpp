@@ -355,14 +355,21 @@ __device__ __forceinline__ void dlt_min_eigenvector(double (&A)[4][4], double (&
     for (int i = 0; i < 4; i++)
 #pragma unroll
         for (int k = 0; k < 4; k++) V[i][k] = (i == k) ? 1.0 : 0.0;
+    bool done = false;   // the lane's off-diagonal part is gone: it rotates no more (its answer must not depend on how long its wave goes on)
 #pragma unroll 1
     for (int sweep = 0; sweep < kJacobiSweeps; sweep++) {
+        // off-diagonal against diagonal, squared: below 1e-36 the rotations left move the eigenvector by less than 1e-18 x the
+        // spectrum's spread over the gap -- nothing in 53 bits; a wave leaves when all its lanes are there (usually after 4 of the 6 sweeps)
+        const double off2 = fma(A[0][1], A[0][1], fma(A[0][2], A[0][2], fma(A[0][3], A[0][3], fma(A[1][2], A[1][2], fma(A[1][3], A[1][3], A[2][3] * A[2][3])))));
+        const double dia2 = fma(A[0][0], A[0][0], fma(A[1][1], A[1][1], fma(A[2][2], A[2][2], A[3][3] * A[3][3])));
+        done = done || !(off2 > 1e-36 * dia2);
+        if (__all(done)) break;
 #pragma unroll
         for (int p = 0; p < 3; p++) {
 #pragma unroll
             for (int q = p + 1; q < 4; q++) {
                 const double apq = A[p][q];
-                const bool rot = fabs(apq) > 1e-280;
+                const bool rot = !done && fabs(apq) > 1e-280;
                 const double theta = (A[q][q] - A[p][p]) * (0.5 * rcp_nr2(rot ? apq : 1.0));
                 const double at = fmin(fabs(theta), 1e150);
                 double t = rcp_nr2(at + sqrt_nr(fma(at, at, 1.0)));
