@@ -68,7 +68,9 @@ typedef enum snowtri_method {
     SNOWTRI_PAIRWISE = 0, /* the reference's algorithm: pairwise skew-ray midpoints, score-weighted */
     SNOWTRI_DLT = 1       /* N-view DLT (A^T A smallest eigenvector; NOT reference behaviour).  One detection
                            * per camera: no association.  Several: the reference's association (candidates +
-                           * greedy clustering), then one DLT per cluster over its distinct observations.
+                           * greedy clustering: the streaming kernels of the pairwise method), then one DLT per
+                           * cluster over its distinct observations (k_cluster_dlt; with condense_score_tol > 0,
+                           * which is decided on the DLT joint scores, every frame inside k_frame_recompute<1>).
                            * Shape limits of that multi-detection route (and of DLT with more than 8 cameras):
                            * at most 16 cameras, C * Pmax <= 1024 detections per frame, keypoint_num <= 256;
                            * beyond them snowtri_triangulate_condense returns SNOWTRI_ERR_BAD_ARG and
