@@ -397,6 +397,19 @@ def test_dlt_multi_person_streaming_route_equals_the_frame_kernel(api, knobs):
             np.testing.assert_allclose(o["xyzs"][..., 3], want[..., 3], rtol=1e-6)
             np.testing.assert_allclose(o["pscore"], wps, rtol=1e-6)
         assert (np.abs(outs["stream"]["xyzs"][..., :3] - outs["frame"]["xyzs"][..., :3]) <= tol).all()
+    # the cut of a call into segments on two streams does not change a bit (the solver's wave votes never touch a settled lane)
+    wl = synth.config_workload(3, 1500, seed=5)
+    Kc, Rc, tc = wl["rig"]
+    cut = {}
+    for segs in (1, 4):
+        bt = api.BatchTriangulator(Kc, Rc, tc, wl["params"], pout_max=8, out_dtype=np.float32, method=_lib.DLT)
+        bt.ctx.set_split(segs)
+        cut[segs] = bt.run_host(wl["kpts"], wl["n_persons"])
+        assert "k_cluster_dlt<8," in bt.ctx.last_kernel_names()
+        bt.close()
+    for k in ("xyzs", "pscore", "count", "flags"):
+        assert np.array_equal(cut[1][k].view(np.uint8), cut[4][k].view(np.uint8)), k
+    assert (cut[1]["count"] >= 4).all()
     # an active condense_score_tol is decided on the DLT joint scores, which the association does not have: the frame kernel
     prm2 = dict(prm, condense_score_tol=4.9)
     want2, wps2, wcnt2 = dlt.dlt_multi_batch(K, R, t, kp, npers, orc.make_params(**prm2), pout)
