@@ -588,7 +588,7 @@ __global__ __launch_bounds__(kBlock, kClusterDltWaves) void k_cluster_dlt(const 
                 for (int m0 = 0; __ballot(m0 < size) != 0ull; m0 += 8) {   // eight member words requested together (one after the other
                     uint32_t w[8];                                         // they were a chain of 10-21 round trips per item)
 #pragma unroll
-                    for (int u = 0; u < 8; u++) w[u] = m0 + u < size ? words[d.y + (uint32_t)(m0 + u)] : 0xffffffffu;
+                    for (int u = 0; u < 8; u++) w[u] = m0 + u < size ? words[d.y + (uint32_t)(m0 + u)] : 0u;   // (rows 0 behind the list's end: in range for the shifts below, never marked)
 #pragma unroll
                     for (int u = 0; u < 8; u++) {
                         const bool live = m0 + u < size;

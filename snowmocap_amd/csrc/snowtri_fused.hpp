@@ -313,8 +313,9 @@ __device__ __forceinline__ bool pairwise_item(const Rig &rig, const double *__re
 // method = SNOWTRI_DLT (row N3; what north_star describes, NOT what the reference computes):
 // N-view DLT for one (frame, joint) in one lane.  Rows u*P[2]-P[0], v*P[2]-P[1] of every camera whose
 // confidence is not below keypoint_score_threshold are accumulated straight into the 10 unique
-// entries of A^T A; its smallest eigenvector comes from a register-resident cyclic Jacobi
-// (6 sweeps x 6 rotations, fixed count: converged to 2e-14 m after 5 on the bench rig).
+// entries of A^T A; its smallest eigenvector comes from shifted inverse iteration on a register-resident Cholesky
+// factor (dlt_inverse_iteration), and from a register-resident cyclic Jacobi for the lanes that do not settle there
+// (dlt_min_eigenvector: gross outliers; ghost clusters of nearly parallel rays, whose two smallest eigenvalues coincide).
 // One observation (u, v) of a camera with world->pixel matrix P (12 doubles): adds the two rows
 // u P[2] - P[0], v P[2] - P[1] (scaled by w in {0, 1}) to the upper triangle of A^T A.
 // MASKED = false: the caller knows w == 1 in every lane of the wave (1.0 * x is exact: the same bits without the eight products).
@@ -339,7 +340,8 @@ __device__ __forceinline__ void dlt_add_observation(double (&A)[4][4], PPtr P, d
 
 constexpr int kJacobiSweeps = 6;
 // Eigenvector of the smallest eigenvalue of the symmetric 4x4 whose upper triangle is in A: cyclic Jacobi,
-// register resident, fixed sweep count (converged to 2e-14 m after 5 sweeps on the bench rig).
+// register resident, at most kJacobiSweeps sweeps (converged to 2e-14 m after 5 on the bench rig; a lane whose off-diagonal
+// part is gone stops rotating, a wave leaves when all its lanes have).
 // Rotation: t = sign(theta) / (|theta| + sqrt(theta^2 + 1)), c = 1/sqrt(t^2 + 1), s = t c, with
 // rcp/rsq + Newton instead of IEEE divide/sqrt.  Those helpers return NaN on denormal inputs, and off-diagonal
 // entries decay THROUGH the denormal range on their way to zero: an entry below 1e-280 is treated as already
