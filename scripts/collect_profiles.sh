@@ -19,6 +19,7 @@ grep "^a\|^b\|^{" gpurun_out/pmc_multi_stdout.txt > $DST/multi_person_counters.t
 [ -f profiles/pmc_multi.json ] && cp profiles/pmc_multi.json $DST/pmc_multi.json
 fi
 cp $SRC/bench_default.json $SRC/bench_steps20.json $SRC/large_launches.json $DST/
+[ -f gpurun_out/dist/dist_lines.jsonl ] && cp gpurun_out/dist/dist_lines.jsonl $DST/dist_lines.jsonl   # bench.py's N > 1 path on the one GPU: --force-dist (RCCL, one rank) and --gpus 2 --one-device (gloo)
 [ -f gpurun_out/multiproc_full.jsonl ] && cp gpurun_out/multiproc_full.jsonl $DST/multiproc_full.jsonl   # tests/test_gpu_multiproc.py: configs[3] / [4] at full size, 8 ranks on the one GPU
 python - <<PY
 import csv, os
