@@ -111,7 +111,7 @@ int snowtri_ctx_synchronize(snowtri_ctx *ctx);
  * snowtri_build_info() names both variants) reads these environment variables ONCE, when a context is created, and names the
  * ones that were set as "NAME=value,..." (tests assert on it):
  *   SNOWTRI_GENERAL_MODE=1|2        multi-person batches on the spill kernel / on k_frame_recompute
- *   SNOWTRI_LEAN_MODE=0             float32-output single-detection batches stay on k_fused_single
+ *   SNOWTRI_LEAN_MODE=0             float32-output single-detection batches stay on k_fused_single (DLT: off k_dlt_coop)
  *   SNOWTRI_LEAN_COOP=0             small launches stay on k_fused_lean
  *   SNOWTRI_SUMLESS_MODE=0          single-detection batches on the streaming route keep its candidate pass
  *   SNOWTRI_HANDOVER_MODE=0|2       0: the whole multi-person path inside k_frame_recompute; 2: its descriptors to k_cluster_fuse

@@ -27,6 +27,7 @@
 #include "snowtri_cluster.hpp"
 #include "snowtri_general.hpp"
 #include "snowtri_assoc.hpp"
+#include "snowtri_dlt_lean.hpp"
 #include "snowtri_smooth.hpp"
 #include "snowtri_blender.hpp"
 #include "snowtri_undistort.hpp"
@@ -328,7 +329,7 @@ struct snowtri_ctx {
     bool last_handover = false;  // the last fused call went through k_frame_recompute with the cluster hand-over armed
     // test knobs (environment, read at creation; snowtri_ctx_overrides names the ones that are set)
     int general_mode = 0;        // SNOWTRI_GENERAL_MODE: 0 auto, 1 force the spill kernel, 2 force the recompute kernel
-    int lean_mode = 1;           // SNOWTRI_LEAN_MODE: 0 keeps float32-output batches on k_fused_single
+    int lean_mode = 1;           // SNOWTRI_LEAN_MODE: 0 keeps float32-output batches (and DLT batches) on k_fused_single
     int lean_coop = 1;           // SNOWTRI_LEAN_COOP: 0 keeps small launches on k_fused_lean
     int sumless_mode = 1;        // SNOWTRI_SUMLESS_MODE: 0 keeps the candidate pass for single-detection batches on the streaming route
     int handover_mode = 1;       // SNOWTRI_HANDOVER_MODE: 1 streaming association (k_candidate_sums / k_associate / k_cluster_fuse), 2 hand-over
@@ -2068,6 +2069,26 @@ int launch_frame_general(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax, 
 // The streaming kernels for the descriptors a k_frame_recompute launch over Fs frames left behind (snowtri_cluster.hpp):
 // `cnt[0]` complete-graph clusters in desc[0, cap), `cnt[1]` clusters of any other shape in desc[cap, 2 cap) with their
 // member words in `words`.
+// method = SNOWTRI_DLT, one detection per camera, keypoint_num == J == 133, one slot: k_dlt_coop (snowtri_dlt_lean.hpp).  Workgroup
+// tiles of equal size (+-1 frame): as many as the resident workgroups for a small batch, tiles of kCoopMaxFrames frames beyond.
+template <int C, typename TIn, typename TOut>
+int launch_dlt_coop(snowtri_ctx *ctx, hipStream_t st, int64_t F, const TIn *d_kpts, const int32_t *d_np, const Params &prm, TOut *d_xyzs,
+                    TOut *d_ps, int32_t *d_cnt, uint32_t *d_fl) {
+    const int64_t resident = (int64_t)ctx->num_cus * kDltCoopWaves;   // (2 / 3 / 4 / 6 tiles per CU: 27.2 / 26.7 / 26.5 / 27.8 us per 10 000 frames of 4 x 1)
+    const int64_t tiles = std::max<int64_t>((F + kCoopMaxFrames - 1) / kCoopMaxFrames, std::min<int64_t>(F, resident));
+    const int base = (int)(F / tiles);
+    const int64_t rem = F % tiles;
+    const int nf_max = base + (rem ? 1 : 0);
+    const size_t lds = dlt_coop_lds_bytes(C, kLeanJ, nf_max, (int)sizeof(TOut));
+    auto kern = k_dlt_coop<C, TIn, kLeanJ, TOut>;
+    if (lds > 48 * 1024 && ctx->raise_lds((const void *)kern, (int)lds)) return SNOWTRI_ERR_HIP;
+    hipLaunchKernelGGL(kern, dim3((unsigned)tiles), dim3(kBlock), lds, st, F, base, rem, nf_max, ctx->rig(), d_kpts, d_np, prm, d_xyzs, d_ps, d_cnt, d_fl);
+    HIP_TRY(hipGetLastError());
+    static const std::string name = std::string("k_dlt_coop<") + std::to_string(C) + "," + type_name<TIn>() + ",133," + type_name<TOut>() + ">";
+    ctx->last_kernels = name.c_str();
+    return SNOWTRI_OK;
+}
+
 template <int C, typename TIn, typename TOut>
 int launch_cluster_fuse(snowtri_ctx *ctx, hipStream_t st, int64_t Fs, int Pmax, int J, const TIn *d_kpts, const Params &prm,
                         int Pout, TOut *d_xyzs, uint32_t *d_fl, const ClusterDesc *desc, const uint32_t *words,
@@ -2513,10 +2534,13 @@ int fused_dispatch(snowtri_ctx *ctx, hipStream_t st, int64_t F, int Pmax, int J,
         }
         rc = launch_frame_recompute<1, TIn, TOut>(ctx, st, F, Pmax, J, d_kpts, d_np, prm, Pout, d_xyzs, d_ps, d_cnt, d_fl);
     } else if (method == SNOWTRI_DLT) {
-        switch (C) {  // one detection per camera: no association needed
+        // one detection per camera: no association needed.  The Wholebody skeleton with every joint asked for and one slot: k_dlt_coop
+        const bool dlt_lean = J == kLeanJ && prm.kn == kLeanJ && Pout == 1 && ctx->lean_mode != 0;
+        switch (C) {
 #define SNOWTRI_CASE(CC)                                                                                      \
     case CC:                                                                                                  \
-        rc = launch_fused_single<CC, 1, TIn, TOut>(ctx, st, F, J, d_kpts, d_np, prm, Pout, d_xyzs, d_ps, d_cnt, d_fl); \
+        rc = dlt_lean ? launch_dlt_coop<CC, TIn, TOut>(ctx, st, F, d_kpts, d_np, prm, d_xyzs, d_ps, d_cnt, d_fl)  \
+                      : launch_fused_single<CC, 1, TIn, TOut>(ctx, st, F, J, d_kpts, d_np, prm, Pout, d_xyzs, d_ps, d_cnt, d_fl); \
         break;
 #ifndef SNOWTRI_DEV_MIN
             SNOWTRI_CASE(2)

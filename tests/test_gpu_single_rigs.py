@@ -279,8 +279,10 @@ def test_sumless_flags_a_singular_pair_of_a_candidate_outside_every_kept_cluster
 
 @pytest.mark.parametrize("C", [5, 6, 8])
 @pytest.mark.parametrize("in_dtype", [np.float32, np.float64])
-def test_dlt_wide_rigs(api, C, in_dtype):
-    """DLT on 5-8 cameras (k_fused_single<C,1>: the world->pixel matrices read per camera, one or two keypoint buffers) vs oracle/dlt.py."""
+def test_dlt_wide_rigs(api, C, in_dtype, knobs):
+    """DLT on 5-8 cameras vs oracle/dlt.py on both kernels: k_dlt_coop (the Wholebody skeleton, one slot: workgroup tiles, buffer
+    loads) and k_fused_single<C,1> (every other shape; forced here by SNOWTRI_LEAN_MODE=0, and taken with keypoint_num < J).  The
+    item is the same function: the joints agree bit for bit."""
     from snowmocap_amd import synth, _lib
     from oracle import dlt as odlt
     rng = np.random.default_rng(60 + C)
@@ -288,18 +290,31 @@ def test_dlt_wide_rigs(api, C, in_dtype):
     F = 50
     X = synth.make_people(rng, F, 1)
     kp, npers = synth.make_keypoints(rng, K, R, t, X, pixel_sigma=0.5, score_range=(2.0, 8.0), dtype=in_dtype)
+    npers[3, 1] = 0                        # a camera that lists nobody in frame 3
     prm = dict(synth.default_thresholds())
-    bt = api.BatchTriangulator(K, R, t, prm, pout_max=1, out_dtype=np.float64, method=_lib.DLT)
-    out = bt.run_host(kp, npers)
-    names = bt.ctx.last_kernel_names()
+    want, wps, wcnt = odlt.dlt_batch(K, R, t, kp * (npers[:, :, None, None, None] > 0), prm["keypoint_score_threshold"], prm["keypoint_num"])
+    outs = {}
+    for kernel in ("k_dlt_coop", "k_fused_single"):
+        if kernel == "k_fused_single":
+            knobs.set("SNOWTRI_LEAN_MODE", "0")
+        bt = api.BatchTriangulator(K, R, t, prm, pout_max=1, out_dtype=np.float64, method=_lib.DLT)
+        out = outs[kernel] = bt.run_host(kp, npers)
+        names = bt.ctx.last_kernel_names()
+        bt.close()
+        knobs.clear()
+        assert names.startswith(f"k_dlt_coop<{C}," if kernel == "k_dlt_coop" else f"k_fused_single<{C},1,"), names
+        assert (out["count"] == 1).all()
+        err = np.abs(out["xyzs"][..., :3] - want[..., :3]).max()
+        assert err < 1e-9, err
+        np.testing.assert_allclose(out["xyzs"][..., 3], want[..., 3], rtol=1e-6)
+        np.testing.assert_allclose(out["pscore"], wps, rtol=1e-6)
+    assert np.array_equal(outs["k_dlt_coop"]["xyzs"].view(np.uint8), outs["k_fused_single"]["xyzs"].view(np.uint8))
+    # keypoint_num < J: not the Wholebody shape -> k_fused_single
+    bt = api.BatchTriangulator(K, R, t, dict(prm, keypoint_num=100), pout_max=1, out_dtype=np.float64, method=_lib.DLT)
+    o2 = bt.run_host(kp, npers)
+    assert bt.ctx.last_kernel_names().startswith(f"k_fused_single<{C},1,")
     bt.close()
-    assert names.startswith(f"k_fused_single<{C},1,"), names
-    want, wps, wcnt = odlt.dlt_batch(K, R, t, kp, prm["keypoint_score_threshold"], prm["keypoint_num"])
-    assert (out["count"] == 1).all()
-    err = np.abs(out["xyzs"][..., :3] - want[..., :3]).max()
-    assert err < 1e-9, err
-    np.testing.assert_allclose(out["xyzs"][..., 3], want[..., 3], rtol=1e-6)
-    np.testing.assert_allclose(out["pscore"], wps, rtol=1e-6)
+    assert np.array_equal(o2["xyzs"][:, :, :100].view(np.uint8), outs["k_dlt_coop"]["xyzs"][:, :, :100].view(np.uint8))
 
 
 def test_random_single_person_rigs_on_every_route(api):
