@@ -319,7 +319,8 @@ __device__ __forceinline__ bool pairwise_item(const Rig &rig, const double *__re
 // One observation (u, v) of a camera with world->pixel matrix P (12 doubles): adds the two rows
 // u P[2] - P[0], v P[2] - P[1] (scaled by w in {0, 1}) to the upper triangle of A^T A.
 // MASKED = false: the caller knows w == 1 in every lane of the wave (1.0 * x is exact: the same bits without the eight products).
-template <bool MASKED = true, typename PPtr>
+// FIRST: A holds nothing yet -- the entries are SET (r1 r1' + r2 r2' without the ten zeros and their additions).
+template <bool MASKED = true, bool FIRST = false, typename PPtr>
 __device__ __forceinline__ void dlt_add_observation(double (&A)[4][4], PPtr P, double u, double v, double w) {
 #pragma clang fp contract(off)   // results must not depend on which inlined copy computes them (see pairwise_item)
     double r1[4], r2[4];
@@ -335,7 +336,7 @@ __device__ __forceinline__ void dlt_add_observation(double (&A)[4][4], PPtr P, d
 #pragma unroll
     for (int i = 0; i < 4; i++)
 #pragma unroll
-        for (int k = i; k < 4; k++) A[i][k] = fma(r1[i], r1[k], fma(r2[i], r2[k], A[i][k]));
+        for (int k = i; k < 4; k++) A[i][k] = FIRST ? fma(r1[i], r1[k], r2[i] * r2[k]) : fma(r1[i], r1[k], fma(r2[i], r2[k], A[i][k]));
 }
 
 constexpr int kJacobiSweeps = 6;
@@ -523,11 +524,7 @@ __device__ __forceinline__ void dlt_item(const double *__restrict__ Plds, const 
     // world->pixel matrices P[C][12] come from LDS (broadcast reads), like the ray matrices of the pairwise item, a camera's
     // matrix where its observation is added: 96 doubles in scalar registers overflow the SGPR file and come back as v_readlane
     // traffic, in vector registers they cost a wave per SIMD
-    double A[4][4];
-#pragma unroll
-    for (int i = 0; i < 4; i++)
-#pragma unroll
-        for (int k = 0; k < 4; k++) A[i][k] = 0.0;
+    double A[4][4];   // (upper triangle; the first camera's observation sets it)
     double ssum = 0.0;
     int cnt = 0;
     bool use[C];
@@ -536,22 +533,34 @@ __device__ __forceinline__ void dlt_item(const double *__restrict__ Plds, const 
     for (int c = 0; c < C; c++) {
         use[c] = !((double)cur[c].s < prm.kthr) && ((npmask >> c) & 1u);
         every = every && use[c];
-        ssum += use[c] ? (double)cur[c].s : 0.0;
-        cnt += use[c] ? 1 : 0;
     }
-    // every camera of every lane counts (the usual wave): the rows are added as they are, no product with the mask
     auto accumulate = [&](auto masked_c) {
         constexpr bool MASKED = decltype(masked_c)::value;
 #pragma unroll
         for (int c = 0; c < C; c++) {
             __builtin_amdgcn_sched_barrier(0);   // a camera's twelve LDS reads stay with its observation (register budget)
-            dlt_add_observation<MASKED>(A, Plds + 12 * c, (double)cur[c].u, (double)cur[c].v, use[c] ? 1.0 : 0.0);
+            if (c == 0)
+                dlt_add_observation<MASKED, true>(A, Plds + 12 * c, (double)cur[c].u, (double)cur[c].v, use[c] ? 1.0 : 0.0);
+            else
+                dlt_add_observation<MASKED, false>(A, Plds + 12 * c, (double)cur[c].u, (double)cur[c].v, use[c] ? 1.0 : 0.0);
         }
     };
-    if (__all(every))
+    // every camera of every lane counts (the usual wave): the rows are added as they are, no product with the mask, and the
+    // confidences are summed as they are (+ 0.0 for a gated one is exact: the same sum either way)
+    if (__all(every)) {
         accumulate(std::false_type{});
-    else
+#pragma unroll
+        for (int c = 0; c < C; c++) ssum += (double)cur[c].s;
+        cnt = C;
+        asm volatile("" : "+v"(cnt));   // (1 / cnt below by the SAME instructions as in the other branch: a constant here would be folded, and differently rounded)
+    } else {
         accumulate(std::true_type{});
+#pragma unroll
+        for (int c = 0; c < C; c++) {
+            ssum += use[c] ? (double)cur[c].s : 0.0;
+            cnt += use[c] ? 1 : 0;
+        }
+    }
     const bool ok = cnt >= 2;
     double e[4];
     dlt_solve(A, ok, e);

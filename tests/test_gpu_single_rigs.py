@@ -309,6 +309,18 @@ def test_dlt_wide_rigs(api, C, in_dtype, knobs):
         np.testing.assert_allclose(out["xyzs"][..., 3], want[..., 3], rtol=1e-6)
         np.testing.assert_allclose(out["pscore"], wps, rtol=1e-6)
     assert np.array_equal(outs["k_dlt_coop"]["xyzs"].view(np.uint8), outs["k_fused_single"]["xyzs"].view(np.uint8))
+    # a joint's bits do not depend on its wave: frames whose cameras all count (the wave adds their rows without the mask product and sums
+    # the confidences as they are) next to frames with gated cameras, cut at frame offsets that move them between the two kinds of waves
+    kp2 = kp.copy()
+    kp2[:25, :, :, :, 2] = np.maximum(kp2[:25, :, :, :, 2], 3.5)
+    np2 = np.ones_like(npers)
+    bt = api.BatchTriangulator(K, R, t, prm, pout_max=1, out_dtype=np.float64, method=_lib.DLT)
+    whole = bt.run_host(kp2, np2)
+    for lo in (1, 7, 24, 26):
+        part = bt.run_host(np.ascontiguousarray(kp2[lo:]), np.ascontiguousarray(np2[lo:]))
+        assert np.array_equal(part["xyzs"].view(np.uint8), whole["xyzs"][lo:].view(np.uint8)), lo
+        assert np.array_equal(part["pscore"].view(np.uint8), whole["pscore"][lo:].view(np.uint8)), lo
+    bt.close()
     # keypoint_num < J: not the Wholebody shape -> k_fused_single
     bt = api.BatchTriangulator(K, R, t, dict(prm, keypoint_num=100), pout_max=1, out_dtype=np.float64, method=_lib.DLT)
     o2 = bt.run_host(kp, npers)
