@@ -14,7 +14,7 @@ cp gpurun_out/pmc_multi/kernel_stats_cfg5.csv $DST/kernel_stats_multi_cfg5_16x8_
 grep "^a\|^b\|^{" gpurun_out/pmc_multi_stdout.txt > $DST/multi_person_counters.txt
 [ -f gpurun_out/pmc_multi/single_rigs.txt ] && grep "k_fused\|raw:" gpurun_out/pmc_multi/single_rigs.txt > $DST/single_rigs_counters.txt
 [ -f gpurun_out/pmc_multi/kernel_stats_single_rigs.csv ] && cp gpurun_out/pmc_multi/kernel_stats_single_rigs.csv $DST/kernel_stats_single_rigs.csv
-[ -f gpurun_out/pmc_multi/dlt_rigs.txt ] && grep "k_fused\|k_cluster\|k_candidate\|k_associate\|k_person\|raw:" gpurun_out/pmc_multi/dlt_rigs.txt > $DST/dlt_counters.txt   # method = SNOWTRI_DLT: SQ counters per kernel
+[ -f gpurun_out/pmc_multi/dlt_rigs.txt ] && grep "k_fused\|k_dlt\|k_cluster\|k_candidate\|k_associate\|k_person\|raw:" gpurun_out/pmc_multi/dlt_rigs.txt > $DST/dlt_counters.txt   # method = SNOWTRI_DLT: SQ counters per kernel
 [ -f gpurun_out/pmc_multi/kernel_stats_dlt_8x4.csv ] && cp gpurun_out/pmc_multi/kernel_stats_dlt_8x4.csv gpurun_out/pmc_multi/kernel_stats_dlt_single.csv $DST/
 [ -f profiles/pmc_multi.json ] && cp profiles/pmc_multi.json $DST/pmc_multi.json
 fi

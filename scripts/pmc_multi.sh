@@ -37,10 +37,10 @@ grep -v "^    raw" $OUT/single_rigs.txt | grep "k_fused"
 cp $ROOT/gpurun_out/pmc_single/kernel_stats.csv $OUT/kernel_stats_single_rigs.csv 2>/dev/null
 # method = SNOWTRI_DLT (row N3): one detection per camera on the floor rig and on 8 cameras (k_fused_single<C,1>), and the 8 x 4
 # batch behind the association (k_candidate_sums -> k_associate -> k_cluster_dlt -> k_person_scores, one stream)
-bash scripts/pmc_any.sh dlt_single "k_fused_single" -- python scripts/bench_single_rigs.py --cams=4 --rig=floor --dlt --calls=20 > $OUT/dlt_rigs.txt 2>&1
-bash scripts/pmc_any.sh dlt_single8 "k_fused_single" -- python scripts/bench_single_rigs.py --cams=8 --dlt --calls=20 >> $OUT/dlt_rigs.txt 2>&1
+bash scripts/pmc_any.sh dlt_single "k_dlt_coop|k_fused_single" -- python scripts/bench_single_rigs.py --cams=4 --rig=floor --dlt --calls=20 > $OUT/dlt_rigs.txt 2>&1
+bash scripts/pmc_any.sh dlt_single8 "k_dlt_coop|k_fused_single" -- python scripts/bench_single_rigs.py --cams=8 --dlt --calls=20 >> $OUT/dlt_rigs.txt 2>&1
 bash scripts/pmc_any.sh dlt_multi "k_cluster_dlt|k_candidate_sums<|k_associate|k_person_scores" -- python scripts/bench_configs.py --dlt --only=3 --one-stream --no-oracle >> $OUT/dlt_rigs.txt 2>&1
-grep -v "^    raw" $OUT/dlt_rigs.txt | grep "k_fused\|k_cluster\|k_candidate\|k_associate\|k_person"
+grep -v "^    raw" $OUT/dlt_rigs.txt | grep "k_fused\|k_dlt\|k_cluster\|k_candidate\|k_associate\|k_person"
 cp $ROOT/gpurun_out/pmc_dlt_multi/kernel_stats.csv $OUT/kernel_stats_dlt_8x4.csv 2>/dev/null
 cat $ROOT/gpurun_out/pmc_dlt_single/kernel_stats.csv > $OUT/kernel_stats_dlt_single.csv 2>/dev/null
 tail -n +2 $ROOT/gpurun_out/pmc_dlt_single8/kernel_stats.csv >> $OUT/kernel_stats_dlt_single.csv 2>/dev/null
