@@ -411,7 +411,7 @@ __device__ __forceinline__ void dlt_min_eigenvector(double (&A)[4][4], double (&
 }
 
 constexpr int kDltInvit = 8;
-// The same eigenvector by shifted inverse iteration: G = A^T A + mu I = L L^T (Cholesky, mu = 64 eps trace keeps
+// The same eigenvector by shifted inverse iteration: G = A^T A + mu I = L D L^T (mu = 64 eps trace keeps
 // every pivot positive when the data are exact and A^T A is singular), x <- normalise(G^-1 x) from e_4.
 // The wanted eigenvalue is the squared reprojection residual (tiny), the next one is ~1e4..1e5 times larger at
 // one pixel of noise, so four steps reach 2e-14 m (same as the SVD oracle) -- ~15x fewer instructions than the
@@ -425,18 +425,25 @@ constexpr int kDltInvit = 8;
 __device__ __forceinline__ bool dlt_inverse_iteration(const double (&A)[4][4], bool live, double (&e)[4]) {
 #pragma clang fp contract(off)   // results must not depend on which inlined copy computes them (see pairwise_item)
     const double mu = (A[0][0] + A[1][1] + A[2][2] + A[3][3]) * (64.0 * 2.220446049250313e-16);
-    double L[4][4], inv[4];  // L strictly-lower entries, inv[i] = 1 / L[i][i]
+    // G = L D L^T with a UNIT lower triangle (round 6; before: Cholesky): four reciprocals (v_rcp_f64 + two Newton steps, 5 instructions)
+    // where the square-root form took four reciprocal square roots (9 each), and a solve is 12 fma + 4 products instead of 12 + 8
+    // A pivot that is not positive (A^T A singular to working precision: ghost clusters of nearly parallel rays) made the square-root form
+    // NaN and sent the lane to Jacobi; here it would iterate on an indefinite matrix: `posdef` keeps such a lane unsettled.
+    double L[4][4], W[4][4], inv[4];  // L strictly-lower entries; W[i][j] = L[i][j] d_j (the entry before its division); inv[j] = 1 / d_j
+    bool posdef = true;
 #pragma unroll
     for (int j = 0; j < 4; j++) {
         double d = A[j][j] + mu;
 #pragma unroll
-        for (int k = 0; k < j; k++) d = fma(-L[j][k], L[j][k], d);
-        inv[j] = rsq_nr2(d);
+        for (int k = 0; k < j; k++) d = fma(-W[j][k], L[j][k], d);
+        posdef = posdef && d > 0.0;
+        inv[j] = rcp_nr2(d);
 #pragma unroll
         for (int i = j + 1; i < 4; i++) {
             double v = A[j][i];
 #pragma unroll
-            for (int k = 0; k < j; k++) v = fma(-L[i][k], L[j][k], v);
+            for (int k = 0; k < j; k++) v = fma(-L[i][k], W[j][k], v);
+            W[i][j] = v;
             L[i][j] = v * inv[j];
         }
     }
@@ -447,14 +454,14 @@ __device__ __forceinline__ bool dlt_inverse_iteration(const double (&A)[4][4], b
             double v = x[i];
 #pragma unroll
             for (int k = 0; k < i; k++) v = fma(-L[i][k], y[k], v);
-            y[i] = v * inv[i];
+            y[i] = v;
         }
 #pragma unroll
-        for (int i = 3; i >= 0; i--) {  // L^T z = y
-            double v = y[i];
+        for (int i = 3; i >= 0; i--) {  // L^T z = D^-1 y
+            double v = y[i] * inv[i];
 #pragma unroll
             for (int k = i + 1; k < 4; k++) v = fma(-L[k][i], z[k], v);
-            z[i] = v * inv[i];
+            z[i] = v;
         }
     };
     auto unit = [](const double (&z)[4], double (&n)[4]) {
@@ -466,11 +473,11 @@ __device__ __forceinline__ bool dlt_inverse_iteration(const double (&A)[4][4], b
         return fmax(fmax(fabs(a[0] - b[0]), fabs(a[1] - b[1])), fmax(fabs(a[2] - b[2]), fabs(a[3] - b[3])));
     };
     double x[4], z[4], n[4];
-    // step 1 from e_4: L y = e_4 has y = (0, 0, 0, inv_3), so only the back substitution is left
-    z[3] = inv[3] * inv[3];
-    z[2] = -(L[3][2] * z[3]) * inv[2];
-    z[1] = fma(-L[3][1], z[3], -(L[2][1] * z[2])) * inv[1];
-    z[0] = fma(-L[3][0], z[3], fma(-L[2][0], z[2], -(L[1][0] * z[1]))) * inv[0];
+    // step 1 from e_4: L y = e_4 has y = e_4, D^-1 y = (0, 0, 0, 1 / d_3), so only the back substitution is left
+    z[3] = inv[3];
+    z[2] = -(L[3][2] * z[3]);
+    z[1] = fma(-L[3][1], z[3], -(L[2][1] * z[2]));
+    z[0] = fma(-L[3][0], z[3], fma(-L[2][0], z[2], -(L[1][0] * z[1])));
     solve(z, x);          // step 2 (the length of its input does not matter)
     unit(x, n);
     solve(n, z);          // step 3
@@ -480,10 +487,10 @@ __device__ __forceinline__ bool dlt_inverse_iteration(const double (&A)[4][4], b
     unit(z, n);
     double prev = step_length(n, x);
     // linear convergence with ratio r = step / previous step: the error left after a step is ~ step * r
-    bool conv = !live || (prev * prev < 1e-14 * d3);
+    bool conv = !live || (posdef && prev * prev < 1e-14 * d3);
 #pragma unroll
     for (int i = 0; i < 4; i++) x[i] = n[i];
-    if (!__all(conv)) {
+    if (!__all(conv || !posdef)) {
 #pragma unroll 1
         for (int it = 4; it < kDltInvit; it++) {
             solve(x, z);
@@ -491,9 +498,9 @@ __device__ __forceinline__ bool dlt_inverse_iteration(const double (&A)[4][4], b
             const double diff = step_length(n, x);
 #pragma unroll
             for (int i = 0; i < 4; i++) x[i] = conv ? x[i] : n[i];   // a settled lane keeps its answer: it must not depend on how long its wave iterates
-            conv = conv || (diff * diff < 1e-14 * prev);
+            conv = conv || (posdef && diff * diff < 1e-14 * prev);
             prev = diff;
-            if (__all(conv)) break;
+            if (__all(conv || !posdef)) break;   // (a lane without a factor never settles: Jacobi takes it)
         }
     }
 #pragma unroll
